@@ -1,0 +1,141 @@
+"""ctypes binding of libagents_amd.so (the C ABI declared in include/agents_amd.h).
+
+The product path has NO fallback: if the HIP library is missing or a kernel returns an error the
+call raises.  Torch is used only for device memory (`data_ptr()`) and the current HIP stream.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p)
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libagents_amd.so")
+
+AA_ACT_NONE, AA_ACT_RELU, AA_ACT_TANH = 0, 1, 2
+AA_A_ROW, AA_A_COL, AA_A_PATCH, AA_A_PATCH_U8, AA_A_PATCH_T, AA_A_PATCH_T_U8 = 0, 1, 2, 3, 4, 5
+AA_B_ROW, AA_B_COL = 0, 1
+AA_LOSS_HUBER, AA_LOSS_SQUARED = 0, 1
+AA_OBS_U8, AA_OBS_F32 = 0, 1
+AA_PPO_NSTATS = 8
+
+_ERRORS = {-22: "AA_ERR_INVALID (bad argument)", -34: "AA_ERR_RANGE (size / workspace)",
+           -5: "AA_ERR_LAUNCH (HIP launch failure)"}
+
+
+class AgentsAmdError(RuntimeError):
+    pass
+
+
+class GemmDesc(Structure):
+    _fields_ = [
+        ("A", c_void_p), ("B", c_void_p), ("C", c_void_p),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32),
+        ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32),
+        ("a_mode", c_int32), ("b_mode", c_int32),
+        ("n_img", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32),
+        ("KH", c_int32), ("KW", c_int32), ("stride", c_int32),
+        ("a_div", c_float),
+        ("bias", c_void_p), ("act", c_int32),
+        ("mask_src", c_void_p), ("ldm", c_int32), ("mask_kind", c_int32),
+        ("force_cfg", c_int32), ("force_splits", c_int32),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/agents_amd.h one to one.
+_SIGNATURES = {
+    "aa_abi_version": (c_int, []),
+    "aa_rb_scatter_rows": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int,
+                                   c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "aa_rb_sample_rows": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_uint64,
+                                  c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "aa_rb_gather_rows": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int,
+                                  c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "aa_rb_range_rows": (c_int, [c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "aa_counter_add": (c_int, [c_void_p, c_int64, c_void_p]),
+    "aa_gemm_f32_workspace_bytes": (c_int64, [POINTER(GemmDesc)]),
+    "aa_gemm_f32": (c_int, [POINTER(GemmDesc), c_void_p, c_int64, c_void_p]),
+    "aa_colsum_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "aa_colsum_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64,
+                              c_void_p]),
+    "aa_col2im_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                              c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
+    "aa_dqn_td_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                               c_float, c_float, c_int32, c_float, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p]),
+    "aa_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float,
+                             c_float, c_float, c_void_p, c_void_p]),
+    "aa_rmsprop_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                c_float, c_float, c_float, c_float, c_void_p]),
+    "aa_sgd_step": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    "aa_soft_update": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    "aa_segment_sumsq": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "aa_clip_by_norm": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_float, c_int32,
+                                c_void_p]),
+    "aa_eps_greedy_action": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p,
+                                     c_uint64, c_void_p, c_int64, c_void_p, c_int32, c_void_p]),
+    "aa_vecenv_random_step": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_float, c_float,
+                                      c_float, c_uint64, c_void_p, c_int32, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p]),
+    "aa_discounted_return": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                     c_int64, c_void_p, c_void_p]),
+    "aa_gae": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int64, c_int64,
+                       c_int64, c_void_p, c_void_p]),
+    "aa_normalize_moments": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
+    "aa_ppo_loss": (c_int, [c_void_p] * 11 + [c_int64, c_int32] + [c_float] * 6 + [c_int32] +
+                    [c_void_p] * 5),
+    "aa_add_l2_grad": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names every entry point declared in include/agents_amd.h must resolve to."""
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """Loads the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AgentsAmdError(
+            f"{LIB_PATH} is missing: build it with `python -m agents_amd._build` "
+            "(there is no CPU / torch fallback on the product path).")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.aa_abi_version() != 1:
+        raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise AgentsAmdError(f"{what} failed: {_ERRORS.get(rc, rc)}")
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream on the current device, as an int."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise AgentsAmdError(
+                "agents_amd kernels need device tensors (torch 'cuda' = HIP on ROCm); got a "
+                f"{t.device} tensor.  There is no CPU fallback on the product path.")

@@ -1,0 +1,236 @@
+// Fused flat-buffer optimizers, target-network soft update, gradient clipping.  HBM-bound
+// elementwise kernels over the flat fp32 parameter / gradient / slot buffers
+// (16-byte vectors, grid-stride).  Built with -ffp-contract=off: op order is the oracle's.
+//   keras Adam / RMSprop apply (agents/dqn/examples/v2/train_eval.py:180,
+//                               examples/dqn/mnih15/dqn_train_eval_atari.py:176-182)
+//   common.soft_variables_update   tf_agents/utils/common.py:250-346
+//   eager_utils.clip_gradient_norms tf_agents/utils/eager_utils.py:227-246 (per tensor)
+//   tf.clip_by_global_norm          tf_agents/agents/ppo/ppo_agent.py:948-949
+#include "common.h"
+#include "agents_amd.h"
+
+#define AA_EW_THREADS 256
+static inline unsigned aa_ew_blocks(int64_t n_vec) {
+  int64_t b = (n_vec + AA_EW_THREADS - 1) / AA_EW_THREADS;
+  if (b > 2048) b = 2048;  // 256 CUs x 8
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+__device__ static inline float adam_elem(float& p, float g, float& m, float& v, float alpha,
+                                         float omb1, float omb2, float eps) {
+  m = m + (g - m) * omb1;
+  v = v + (g * g - v) * omb2;
+  p = p - (m * alpha) / (sqrtf(v) + eps);
+  return p;
+}
+
+__global__ void __launch_bounds__(AA_EW_THREADS)
+aa_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+               float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps,
+               const int64_t* __restrict__ step_dev) {
+  __shared__ float s_alpha;
+  if (threadIdx.x == 0) {
+    const float t = (float)(*step_dev);
+    const float b1p = powf(beta1, t), b2p = powf(beta2, t);
+    s_alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+  }
+  __syncthreads();
+  const float alpha = s_alpha, omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+  const int64_t nv = n / 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    adam_elem(pp.x, gg.x, mm.x, vv.x, alpha, omb1, omb2, eps);
+    adam_elem(pp.y, gg.y, mm.y, vv.y, alpha, omb1, omb2, eps);
+    adam_elem(pp.z, gg.z, mm.z, vv.z, alpha, omb1, omb2, eps);
+    adam_elem(pp.w, gg.w, mm.w, vv.w, alpha, omb1, omb2, eps);
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  for (int64_t i = nv * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    adam_elem(p[i], g[i], m[i], v[i], alpha, omb1, omb2, eps);
+}
+
+template <bool CENTERED, bool MOMENTUM>
+__device__ static inline void rms_elem(float& p, float g, float& ms, float* mg, float* mom,
+                                       float lr, float rho, float omr, float momentum,
+                                       float eps) {
+  ms = rho * ms + omr * (g * g);
+  float denom;
+  if (CENTERED) {
+    *mg = rho * (*mg) + omr * g;
+    denom = ms - (*mg) * (*mg) + eps;
+  } else {
+    denom = ms + eps;
+  }
+  const float inc = lr * g * (1.0f / sqrtf(denom));
+  if (MOMENTUM) {
+    *mom = momentum * (*mom) + inc;
+    p = p - *mom;
+  } else {
+    p = p - inc;
+  }
+}
+
+template <bool CENTERED, bool MOMENTUM>
+__global__ void __launch_bounds__(AA_EW_THREADS)
+aa_rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ ms,
+                  float* __restrict__ mg, float* __restrict__ mom, int64_t n, float lr, float rho,
+                  float momentum, float eps) {
+  const float omr = 1.0f - rho;
+  const int64_t nv = n / 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 s = reinterpret_cast<float4*>(ms)[i];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), mo = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (CENTERED) a = reinterpret_cast<float4*>(mg)[i];
+    if (MOMENTUM) mo = reinterpret_cast<float4*>(mom)[i];
+    rms_elem<CENTERED, MOMENTUM>(pp.x, gg.x, s.x, &a.x, &mo.x, lr, rho, omr, momentum, eps);
+    rms_elem<CENTERED, MOMENTUM>(pp.y, gg.y, s.y, &a.y, &mo.y, lr, rho, omr, momentum, eps);
+    rms_elem<CENTERED, MOMENTUM>(pp.z, gg.z, s.z, &a.z, &mo.z, lr, rho, omr, momentum, eps);
+    rms_elem<CENTERED, MOMENTUM>(pp.w, gg.w, s.w, &a.w, &mo.w, lr, rho, omr, momentum, eps);
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(ms)[i] = s;
+    if (CENTERED) reinterpret_cast<float4*>(mg)[i] = a;
+    if (MOMENTUM) reinterpret_cast<float4*>(mom)[i] = mo;
+  }
+  for (int64_t i = nv * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float a = CENTERED ? mg[i] : 0.f, mo = MOMENTUM ? mom[i] : 0.f;
+    rms_elem<CENTERED, MOMENTUM>(p[i], g[i], ms[i], &a, &mo, lr, rho, omr, momentum, eps);
+    if (CENTERED) mg[i] = a;
+    if (MOMENTUM) mom[i] = mo;
+  }
+}
+
+__global__ void __launch_bounds__(AA_EW_THREADS)
+aa_sgd_kernel(float* __restrict__ p, const float* __restrict__ g, int64_t n, float lr) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    p[i] = p[i] - lr * g[i];
+}
+
+__global__ void __launch_bounds__(AA_EW_THREADS)
+aa_soft_update_kernel(float* __restrict__ t, const float* __restrict__ s, int64_t n, float tau) {
+  const float omt = 1.0f - tau;
+  const int64_t nv = n / 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    float4 a = reinterpret_cast<float4*>(t)[i];
+    const float4 b = reinterpret_cast<const float4*>(s)[i];
+    a.x = omt * a.x + tau * b.x;
+    a.y = omt * a.y + tau * b.y;
+    a.z = omt * a.z + tau * b.z;
+    a.w = omt * a.w + tau * b.w;
+    reinterpret_cast<float4*>(t)[i] = a;
+  }
+  for (int64_t i = nv * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    t[i] = omt * t[i] + tau * s[i];
+}
+
+// one workgroup per segment (tensor); deterministic tree
+__global__ void __launch_bounds__(1024)
+aa_segment_sumsq_kernel(const float* __restrict__ g, const int64_t* __restrict__ off,
+                        float* __restrict__ out) {
+  __shared__ float red[16];
+  const int64_t lo = off[blockIdx.x], hi = off[blockIdx.x + 1];
+  float s = 0.f;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) s += g[i] * g[i];
+  const float t = aa_block_sum(s, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = t;
+}
+
+__global__ void __launch_bounds__(AA_EW_THREADS)
+aa_clip_kernel(float* __restrict__ g, const int64_t* __restrict__ off, int n_seg,
+               const float* __restrict__ sumsq, float clip, int per_tensor) {
+  const int seg = blockIdx.y;
+  const int64_t lo = off[seg], hi = off[seg + 1];
+  float scale;
+  if (per_tensor) {
+    // tf.clip_by_norm: t * clip_norm / max(l2norm, clip_norm)
+    const float nrm = sqrtf(sumsq[seg]);
+    scale = clip / fmaxf(nrm, clip);
+  } else {
+    // tf.clip_by_global_norm: scale = clip_norm * min(1/global_norm, 1/clip_norm)
+    float tot = 0.f;
+    for (int i = 0; i < n_seg; ++i) tot += sumsq[i];
+    const float gn = sqrtf(tot);
+    scale = clip * fminf(1.0f / gn, 1.0f / clip);
+  }
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += stride)
+    g[i] = g[i] * scale;
+}
+
+extern "C" {
+
+int aa_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                 float beta2, float eps, const int64_t* step_dev, void* stream) {
+  if (!p || !g || !m || !v || !step_dev || n <= 0) return AA_ERR_INVALID;
+  if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0)
+    return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_adam_kernel, dim3(aa_ew_blocks(n / 4)), dim3(AA_EW_THREADS), 0,
+                     (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, step_dev);
+  return aa_launch_status();
+}
+
+int aa_rmsprop_step(float* p, const float* g, float* ms, float* mg, float* mom, int64_t n,
+                    float lr, float rho, float momentum, float eps, void* stream) {
+  if (!p || !g || !ms || n <= 0) return AA_ERR_INVALID;
+  if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)ms | (uintptr_t)mg | (uintptr_t)mom) & 15) != 0)
+    return AA_ERR_INVALID;
+  const dim3 grid(aa_ew_blocks(n / 4)), block(AA_EW_THREADS);
+  hipStream_t st = (hipStream_t)stream;
+  if (mg && mom)
+    hipLaunchKernelGGL((aa_rmsprop_kernel<true, true>), grid, block, 0, st, p, g, ms, mg, mom, n,
+                       lr, rho, momentum, eps);
+  else if (mg)
+    hipLaunchKernelGGL((aa_rmsprop_kernel<true, false>), grid, block, 0, st, p, g, ms, mg, mom, n,
+                       lr, rho, momentum, eps);
+  else if (mom)
+    hipLaunchKernelGGL((aa_rmsprop_kernel<false, true>), grid, block, 0, st, p, g, ms, mg, mom, n,
+                       lr, rho, momentum, eps);
+  else
+    hipLaunchKernelGGL((aa_rmsprop_kernel<false, false>), grid, block, 0, st, p, g, ms, mg, mom,
+                       n, lr, rho, momentum, eps);
+  return aa_launch_status();
+}
+
+int aa_sgd_step(float* p, const float* g, int64_t n, float lr, void* stream) {
+  if (!p || !g || n <= 0) return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_sgd_kernel, dim3(aa_ew_blocks(n)), dim3(AA_EW_THREADS), 0,
+                     (hipStream_t)stream, p, g, n, lr);
+  return aa_launch_status();
+}
+
+int aa_soft_update(float* target, const float* source, int64_t n, float tau, void* stream) {
+  if (!target || !source || n <= 0) return AA_ERR_INVALID;
+  if ((((uintptr_t)target | (uintptr_t)source) & 15) != 0) return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_soft_update_kernel, dim3(aa_ew_blocks(n / 4)), dim3(AA_EW_THREADS), 0,
+                     (hipStream_t)stream, target, source, n, tau);
+  return aa_launch_status();
+}
+
+int aa_segment_sumsq(const float* g, const int64_t* seg_offsets_dev, int32_t n_seg,
+                     float* sumsq_out, void* stream) {
+  if (!g || !seg_offsets_dev || !sumsq_out || n_seg <= 0) return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_segment_sumsq_kernel, dim3((unsigned)n_seg), dim3(1024), 0,
+                     (hipStream_t)stream, g, seg_offsets_dev, sumsq_out);
+  return aa_launch_status();
+}
+
+int aa_clip_by_norm(float* g, const int64_t* seg_offsets_dev, int32_t n_seg, const float* sumsq,
+                    float clip, int32_t per_tensor, void* stream) {
+  if (!g || !seg_offsets_dev || !sumsq || n_seg <= 0 || !(clip > 0.f)) return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_clip_kernel, dim3(64, (unsigned)n_seg), dim3(AA_EW_THREADS), 0,
+                     (hipStream_t)stream, g, seg_offsets_dev, n_seg, sumsq, clip, per_tensor);
+  return aa_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+// Replay ring-buffer kernels: batched row scatter (add_batch), uniform index sampling
+// (Philox), row gather (get_next / gather_all).  HBM-bound byte movers.
+//
+// Replaces, on the MI355X, the TensorFlow primitives the reference leans on:
+//   tf_agents/replay_buffers/table.py:112-137   (Table.write  -> scatter_update per leaf)
+//   tf_agents/replay_buffers/table.py:86-110    (Table.read   -> sparse_read per leaf)
+//   tf_agents/replay_buffers/tf_uniform_replay_buffer.py:182-209 (_add_batch)
+//   tf_agents/replay_buffers/tf_uniform_replay_buffer.py:211-310 (_get_next)
+//   tf_agents/replay_buffers/tf_uniform_replay_buffer.py:610-635 (_valid_range_ids)
+//
+// Layout in HBM: one contiguous [capacity, row_bytes] byte table per flattened leaf of the
+// data spec, capacity = batch_size * max_length; env b owns rows [b*L, (b+1)*L).  A parallel
+// int64 id table [capacity] and one int64 `last_id` word live next to them.
+//
+// Design: one launch moves ALL leaves.  grid = n_rows * n_chunks, a workgroup owns one
+// (row, 8 KiB chunk); every lane moves 16-byte vectors (global_load_dwordx4 /
+// global_store_dwordx4, both loads of the chunk issued before the stores) so a wave
+// instruction covers 1 KiB of a row.  Narrow leaves (scalars) ride in the chunk-0 workgroup.
+#include "common.h"
+
+#define AA_MAX_LEAVES 24
+#define AA_RB_CHUNK 8192  // bytes of one row handled per workgroup per leaf
+#define AA_RB_THREADS 256
+
+struct AaLeafSet {
+  int n;
+  char* table[AA_MAX_LEAVES];   // [capacity, row_bytes]
+  char* io[AA_MAX_LEAVES];      // items (scatter source) or out (gather destination)
+  int64_t row_bytes[AA_MAX_LEAVES];
+};
+
+template <typename V>
+__device__ static inline void aa_copy_span(const char* __restrict__ src, char* __restrict__ dst,
+                                           int64_t len) {
+  // len bytes, multiple of sizeof(V); src/dst aligned to sizeof(V).  At most
+  // AA_RB_CHUNK bytes, i.e. <= 2 vectors per lane at V = 16 B: issue both loads first.
+  const int64_t n = len / (int64_t)sizeof(V);
+  const V* s = reinterpret_cast<const V*>(src);
+  V* d = reinterpret_cast<V*>(dst);
+  for (int64_t i = threadIdx.x; i < n; i += 2 * AA_RB_THREADS) {
+    const int64_t j = i + AA_RB_THREADS;
+    V a = s[i];
+    V b;
+    const bool hb = j < n;
+    if (hb) b = s[j];
+    d[i] = a;
+    if (hb) d[j] = b;
+  }
+}
+
+__device__ static inline void aa_copy_row_chunk(const char* src, char* dst, int64_t row_bytes,
+                                                int chunk) {
+  const int64_t off = (int64_t)chunk * AA_RB_CHUNK;
+  if (off >= row_bytes) return;
+  int64_t len = row_bytes - off;
+  if (len > AA_RB_CHUNK) len = AA_RB_CHUNK;
+  src += off;
+  dst += off;
+  const uintptr_t al = (uintptr_t)src | (uintptr_t)dst | (uintptr_t)len;
+  if ((al & 15) == 0) {
+    aa_copy_span<uint4>(src, dst, len);
+  } else if ((al & 7) == 0) {
+    aa_copy_span<uint2>(src, dst, len);
+  } else if ((al & 3) == 0) {
+    aa_copy_span<uint32_t>(src, dst, len);
+  } else {
+    aa_copy_span<uint8_t>(src, dst, len);
+  }
+}
+
+// ---- add_batch: rows[b] = b*L + (last_id+1) mod L ------------------------------------------
+__global__ void __launch_bounds__(AA_RB_THREADS)
+aa_rb_scatter_kernel(AaLeafSet leaves, int64_t* __restrict__ id_table,
+                     const int64_t* __restrict__ last_id, int64_t max_len, int n_chunks) {
+  const int64_t b = blockIdx.x / n_chunks;
+  const int chunk = blockIdx.x % n_chunks;
+  const int64_t id = *last_id + 1;  // bumped by aa_rb_bump_kernel AFTER this kernel
+  // tf.math.mod semantics (floor mod); id >= 0 always here.
+  const int64_t row = b * max_len + (id % max_len);
+  for (int l = 0; l < leaves.n; ++l) {
+    const int64_t rb = leaves.row_bytes[l];
+    aa_copy_row_chunk(leaves.io[l] + b * rb, leaves.table[l] + row * rb, rb, chunk);
+  }
+  if (chunk == 0 && threadIdx.x == 0) id_table[row] = id;
+}
+
+__global__ void aa_rb_bump_kernel(int64_t* last_id, int64_t inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *last_id += inc;
+}
+
+// ---- get_next: gather rows -----------------------------------------------------------------
+__global__ void __launch_bounds__(AA_RB_THREADS)
+aa_rb_gather_kernel(AaLeafSet leaves, const int64_t* __restrict__ id_table,
+                    int64_t* __restrict__ ids_out, const int64_t* __restrict__ rows,
+                    int n_chunks) {
+  const int64_t r = blockIdx.x / n_chunks;
+  const int chunk = blockIdx.x % n_chunks;
+  const int64_t row = rows[r];
+  for (int l = 0; l < leaves.n; ++l) {
+    const int64_t rb = leaves.row_bytes[l];
+    aa_copy_row_chunk(leaves.table[l] + row * rb, leaves.io[l] + r * rb, rb, chunk);
+  }
+  if (chunk == 0 && threadIdx.x == 0 && ids_out != nullptr) ids_out[r] = id_table[row];
+}
+
+// ---- uniform sampling of (start id, env block) pairs -----------------------------------------
+// Stream definition (canonical for this package; see oracle/replay.py):
+//   (x0,x1,x2,x3) = Philox4x32-10(counter = (s_lo, s_hi, call_lo, call_hi), key = (seed_lo, seed_hi))
+//   id   = min_id + ((x1<<32 | x0) mod (max_id - min_id))     -- TF-style modulo map, no rejection
+//   seg  =           (x3<<32 | x2) mod batch
+//   rows[s,t] = (id + t) mod L + seg*L ;  prob = 1 / float32((max_id-min_id)*batch)
+__global__ void aa_rb_sample_kernel(const int64_t* __restrict__ last_id_p, int64_t batch,
+                                    int64_t max_len, int64_t S, int64_t T, uint32_t k0,
+                                    uint32_t k1, uint64_t call, int64_t* __restrict__ rows,
+                                    float* __restrict__ probs, int* __restrict__ err) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const int64_t last_id = *last_id_p;
+  int64_t min_id, max_id;
+  if (last_id < max_len) {
+    min_id = 0;
+    max_id = last_id + 1 - T + 1;
+    if (max_id < 0) max_id = 0;
+  } else {
+    min_id = last_id + 1 - max_len;
+    max_id = last_id + 1 - T + 1;
+  }
+  const int64_t num_ids = max_id - min_id;
+  if (num_ids <= 0) {
+    if (s == 0 && err != nullptr) *err = 1;
+    for (int64_t t = 0; t < T; ++t) rows[s * T + t] = 0;
+    if (probs) probs[s] = 0.f;
+    return;
+  }
+  const Philox4 r = philox4x32_10((uint32_t)s, (uint32_t)((uint64_t)s >> 32), (uint32_t)call,
+                                  (uint32_t)(call >> 32), k0, k1);
+  const uint64_t a = ((uint64_t)r.y << 32) | r.x;
+  const uint64_t c = ((uint64_t)r.w << 32) | r.z;
+  const int64_t id = min_id + (int64_t)(a % (uint64_t)num_ids);
+  const int64_t seg = (int64_t)(c % (uint64_t)batch);
+  for (int64_t t = 0; t < T; ++t) rows[s * T + t] = (id + t) % max_len + seg * max_len;
+  if (probs) probs[s] = 1.0f / (float)(num_ids * batch);
+}
+
+// rows[b, i] = (start_id + i) mod L + b*L   (gather_all and deterministic passes)
+__global__ void aa_rb_range_rows_kernel(int64_t start_id, int64_t n_ids, int64_t batch,
+                                        int64_t max_len, int64_t* __restrict__ rows) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_ids * batch) return;
+  const int64_t b = i / n_ids, k = i % n_ids;
+  rows[i] = (start_id + k) % max_len + b * max_len;
+}
+
+static int aa_fill_leaves(AaLeafSet& ls, void* const* tables, void* const* ios,
+                          const int64_t* row_bytes, int n, int64_t* max_rb) {
+  if (n < 0 || n > AA_MAX_LEAVES) return AA_ERR_RANGE;
+  ls.n = n;
+  int64_t m = 0;
+  for (int i = 0; i < n; ++i) {
+    if (row_bytes[i] < 0 || (row_bytes[i] > 0 && (tables[i] == nullptr || ios[i] == nullptr)))
+      return AA_ERR_INVALID;
+    ls.table[i] = (char*)tables[i];
+    ls.io[i] = (char*)ios[i];
+    ls.row_bytes[i] = row_bytes[i];
+    if (row_bytes[i] > m) m = row_bytes[i];
+  }
+  *max_rb = m;
+  return AA_OK;
+}
+
+extern "C" {
+
+int aa_rb_scatter_rows(void* const* leaf_tables_h, const void* const* leaf_items_h,
+                       const int64_t* leaf_row_bytes_h, int n_leaves, int64_t* id_table,
+                       int64_t* last_id_dev, int64_t batch, int64_t max_len, void* stream) {
+  if (batch <= 0 || max_len <= 0 || id_table == nullptr || last_id_dev == nullptr)
+    return AA_ERR_INVALID;
+  AaLeafSet ls;
+  int64_t max_rb = 0;
+  int rc = aa_fill_leaves(ls, leaf_tables_h, (void* const*)leaf_items_h, leaf_row_bytes_h,
+                          n_leaves, &max_rb);
+  if (rc != AA_OK) return rc;
+  int n_chunks = (int)((max_rb + AA_RB_CHUNK - 1) / AA_RB_CHUNK);
+  if (n_chunks < 1) n_chunks = 1;
+  const int64_t grid = batch * n_chunks;
+  if (grid > 0x7fffffffLL) return AA_ERR_RANGE;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(aa_rb_scatter_kernel, dim3((unsigned)grid), dim3(AA_RB_THREADS), 0, st, ls,
+                     id_table, (const int64_t*)last_id_dev, max_len, n_chunks);
+  hipLaunchKernelGGL(aa_rb_bump_kernel, dim3(1), dim3(64), 0, st, last_id_dev, (int64_t)1);
+  return aa_launch_status();
+}
+
+int aa_rb_sample_rows(const int64_t* last_id_dev, int64_t batch, int64_t max_len, int64_t S,
+                      int64_t T, uint64_t seed, uint64_t call_counter, int64_t* rows_out,
+                      float* prob_out, int* err_flag_dev, void* stream) {
+  if (S <= 0 || T <= 0 || batch <= 0 || max_len <= 0 || rows_out == nullptr ||
+      last_id_dev == nullptr)
+    return AA_ERR_INVALID;
+  const int threads = 256;
+  const int64_t grid = (S + threads - 1) / threads;
+  if (grid > 0x7fffffffLL) return AA_ERR_RANGE;
+  hipLaunchKernelGGL(aa_rb_sample_kernel, dim3((unsigned)grid), dim3(threads), 0,
+                     (hipStream_t)stream, last_id_dev, batch, max_len, S, T, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), call_counter, rows_out, prob_out, err_flag_dev);
+  return aa_launch_status();
+}
+
+int aa_rb_gather_rows(const void* const* leaf_tables_h, void* const* leaf_out_h,
+                      const int64_t* leaf_row_bytes_h, int n_leaves, const int64_t* id_table,
+                      int64_t* ids_out, const int64_t* rows, int64_t n_rows, void* stream) {
+  if (n_rows < 0 || rows == nullptr) return AA_ERR_INVALID;
+  if (n_rows == 0) return AA_OK;
+  AaLeafSet ls;
+  int64_t max_rb = 0;
+  int rc = aa_fill_leaves(ls, (void* const*)leaf_tables_h, leaf_out_h, leaf_row_bytes_h,
+                          n_leaves, &max_rb);
+  if (rc != AA_OK) return rc;
+  if (ids_out != nullptr && id_table == nullptr) return AA_ERR_INVALID;
+  int n_chunks = (int)((max_rb + AA_RB_CHUNK - 1) / AA_RB_CHUNK);
+  if (n_chunks < 1) n_chunks = 1;
+  const int64_t grid = n_rows * n_chunks;
+  if (grid > 0x7fffffffLL) return AA_ERR_RANGE;
+  hipLaunchKernelGGL(aa_rb_gather_kernel, dim3((unsigned)grid), dim3(AA_RB_THREADS), 0,
+                     (hipStream_t)stream, ls, id_table, ids_out, rows, n_chunks);
+  return aa_launch_status();
+}
+
+int aa_rb_range_rows(int64_t start_id, int64_t n_ids, int64_t batch, int64_t max_len,
+                     int64_t* rows_out, void* stream) {
+  if (n_ids < 0 || batch <= 0 || max_len <= 0 || rows_out == nullptr) return AA_ERR_INVALID;
+  const int64_t n = n_ids * batch;
+  if (n == 0) return AA_OK;
+  const int threads = 256;
+  const int64_t grid = (n + threads - 1) / threads;
+  if (grid > 0x7fffffffLL) return AA_ERR_RANGE;
+  hipLaunchKernelGGL(aa_rb_range_rows_kernel, dim3((unsigned)grid), dim3(threads), 0,
+                     (hipStream_t)stream, start_id, n_ids, batch, max_len, rows_out);
+  return aa_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,181 @@
+// Reverse-time scans (discounted return, GAE) and the advantage normaliser.
+// Built with -ffp-contract=off; per-lane op order is exactly the reference's tf.scan body so the
+// results agree bit-for-bit with oracle/value_ops.py.
+//   discounted_return                   tf_agents/utils/value_ops.py:21-99
+//   generalized_advantage_estimation    tf_agents/utils/value_ops.py:102-164
+//   _normalize_advantages               tf_agents/agents/ppo/ppo_agent.py:100-110
+//
+// One lane per trajectory b, sequential over T (first-order linear recurrence).  Batch-major
+// [B,T] inputs are walked through a 64x64 LDS tile per wave so global traffic stays coalesced
+// (lanes read along t, the scan runs along the tile's other axis).
+#include "common.h"
+#include "agents_amd.h"
+
+#define AA_SCAN_TILE 64
+
+// MODE 0: discounted return   acc = acc*discount + reward          (init final_value or 0)
+// MODE 1: GAE                 delta = r + d*v_next - v ; acc = delta + (d*lambda)*acc  (init 0)
+template <int MODE>
+__global__ void __launch_bounds__(64)
+aa_scan_kernel(const float* __restrict__ values, const float* __restrict__ final_value,
+               const float* __restrict__ discounts, const float* __restrict__ rewards,
+               float td_lambda, int64_t B, int64_t T, int64_t sb, int64_t st,
+               float* __restrict__ out) {
+  // tile[t][b] with +1 padding: conflict-free both for row-wise fills and column-wise scans
+  __shared__ float t_r[AA_SCAN_TILE][AA_SCAN_TILE + 1];
+  __shared__ float t_d[AA_SCAN_TILE][AA_SCAN_TILE + 1];
+  __shared__ float t_v[AA_SCAN_TILE][AA_SCAN_TILE + 1];
+  const int lane = threadIdx.x;
+  const int64_t b0 = (int64_t)blockIdx.x * AA_SCAN_TILE;
+  const int64_t b = b0 + lane;
+  const bool t_contig = (st == 1);  // batch-major: lanes read along t
+  float acc = 0.f;
+  float v_next = 0.f;
+  if (b < B) {
+    if (MODE == 0) acc = final_value != nullptr ? final_value[b] : 0.f;
+    if (MODE == 1) v_next = final_value[b];
+  }
+  for (int64_t t_hi = T; t_hi > 0; t_hi -= AA_SCAN_TILE) {
+    const int64_t t_lo = t_hi > AA_SCAN_TILE ? t_hi - AA_SCAN_TILE : 0;
+    const int nt = (int)(t_hi - t_lo);
+    // ---- fill ---------------------------------------------------------------------------
+    if (t_contig) {
+      for (int bb = 0; bb < AA_SCAN_TILE; ++bb) {
+        if (b0 + bb < B && lane < nt) {
+          const int64_t o = (b0 + bb) * sb + (t_lo + lane);
+          t_r[lane][bb] = rewards[o];
+          t_d[lane][bb] = discounts[o];
+          if (MODE == 1) t_v[lane][bb] = values[o];
+        }
+      }
+    } else {
+      for (int tt = 0; tt < nt; ++tt) {
+        if (b < B) {
+          const int64_t o = b * sb + (t_lo + tt) * st;
+          t_r[tt][lane] = rewards[o];
+          t_d[tt][lane] = discounts[o];
+          if (MODE == 1) t_v[tt][lane] = values[o];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- scan (reverse) -------------------------------------------------------------------
+    if (b < B) {
+      for (int tt = nt - 1; tt >= 0; --tt) {
+        const float r = t_r[tt][lane], d = t_d[tt][lane];
+        if (MODE == 0) {
+          acc = acc * d + r;
+        } else {
+          const float v = t_v[tt][lane];
+          const float delta = r + d * v_next - v;
+          acc = delta + (d * td_lambda) * acc;
+          v_next = v;
+        }
+        t_r[tt][lane] = acc;  // reuse the reward tile for the output
+      }
+    }
+    __syncthreads();
+    // ---- drain ----------------------------------------------------------------------------
+    if (t_contig) {
+      for (int bb = 0; bb < AA_SCAN_TILE; ++bb)
+        if (b0 + bb < B && lane < nt) out[(b0 + bb) * sb + (t_lo + lane)] = t_r[lane][bb];
+    } else {
+      for (int tt = 0; tt < nt; ++tt)
+        if (b < B) out[b * sb + (t_lo + tt) * st] = t_r[tt][lane];
+    }
+    __syncthreads();
+  }
+}
+
+// Two-pass moments over n elements in ONE workgroup launch pair (n is B*T <= a few million):
+// pass 1: per-block partial sums -> mean ; pass 2: partial sum of squared deviations -> var
+// (tf.nn.moments computes mean, then mean(squared_difference(x, stop_gradient(mean)))).
+__global__ void __launch_bounds__(256)
+aa_partial_sum_kernel(const float* __restrict__ x, int64_t n, const float* __restrict__ mean_p,
+                      int squared_dev, float* __restrict__ partial) {
+  __shared__ float red[16];
+  const float mean = squared_dev ? mean_p[0] : 0.f;
+  float s = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = x[i];
+    if (squared_dev) {
+      const float dlt = v - mean;
+      s += dlt * dlt;
+    } else {
+      s += v;
+    }
+  }
+  const float t = aa_block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+__global__ void aa_finish_mean_kernel(const float* __restrict__ partial, int P, float n,
+                                      float* __restrict__ dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < P; ++i) s += partial[i];
+    dst[0] = s / n;
+  }
+}
+__global__ void __launch_bounds__(256)
+aa_apply_norm_kernel(const float* __restrict__ x, int64_t n, const float* __restrict__ stats,
+                     float eps, float* __restrict__ out) {
+  // tf.nn.batch_normalization with offset=None, scale=None: x*inv + (-mean*inv), inv = rsqrt(var+eps)
+  const float mean = stats[0], var = stats[1];
+  const float inv = 1.0f / sqrtf(var + eps);
+  const float shift = -mean * inv;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = x[i] * inv + shift;
+}
+
+#define AA_NORM_P 256
+
+extern "C" {
+
+int aa_discounted_return(const float* rewards, const float* discounts, const float* final_value,
+                         int64_t B, int64_t T, int64_t stride_b, int64_t stride_t, float* out,
+                         void* stream) {
+  if (!rewards || !discounts || !out || B <= 0 || T <= 0) return AA_ERR_INVALID;
+  const dim3 grid((unsigned)((B + AA_SCAN_TILE - 1) / AA_SCAN_TILE));
+  hipLaunchKernelGGL(aa_scan_kernel<0>, grid, dim3(64), 0, (hipStream_t)stream,
+                     (const float*)nullptr, final_value, discounts, rewards, 0.f, B, T, stride_b,
+                     stride_t, out);
+  return aa_launch_status();
+}
+
+int aa_gae(const float* values, const float* final_value, const float* discounts,
+           const float* rewards, float td_lambda, int64_t B, int64_t T, int64_t stride_b,
+           int64_t stride_t, float* out, void* stream) {
+  if (!values || !final_value || !rewards || !discounts || !out || B <= 0 || T <= 0)
+    return AA_ERR_INVALID;
+  const dim3 grid((unsigned)((B + AA_SCAN_TILE - 1) / AA_SCAN_TILE));
+  hipLaunchKernelGGL(aa_scan_kernel<1>, grid, dim3(64), 0, (hipStream_t)stream, values,
+                     final_value, discounts, rewards, td_lambda, B, T, stride_b, stride_t, out);
+  return aa_launch_status();
+}
+
+// stats_out must hold 2 + AA_NORM_P floats: [mean, var, partials...]
+int aa_normalize_moments(const float* x, int64_t n, float eps, float* out, float* stats_out,
+                         void* stream) {
+  if (!x || !out || !stats_out || n <= 0) return AA_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = stats_out + 2;
+  int P = (int)((n + 255) / 256);
+  if (P > AA_NORM_P) P = AA_NORM_P;
+  hipLaunchKernelGGL(aa_partial_sum_kernel, dim3(P), dim3(256), 0, st, x, n,
+                     (const float*)nullptr, 0, partial);
+  hipLaunchKernelGGL(aa_finish_mean_kernel, dim3(1), dim3(64), 0, st, (const float*)partial, P,
+                     (float)n, stats_out + 0);
+  hipLaunchKernelGGL(aa_partial_sum_kernel, dim3(P), dim3(256), 0, st, x, n,
+                     (const float*)stats_out, 1, partial);
+  hipLaunchKernelGGL(aa_finish_mean_kernel, dim3(1), dim3(64), 0, st, (const float*)partial, P,
+                     (float)n, stats_out + 1);
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(aa_apply_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n,
+                     (const float*)stats_out, eps, out);
+  return aa_launch_status();
+}
+
+}  // extern "C"

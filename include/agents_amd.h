@@ -1,0 +1,219 @@
+/* agents_amd.h -- C ABI of libagents_amd.so: the MI355X (gfx950) kernels behind the TF-Agents
+ * trainer hot path (TFUniformReplayBuffer add/sample, DynamicStepDriver rollout, DqnAgent /
+ * PPOAgent loss + update, Learner gradient step).
+ *
+ * The reference (tensorflow/agents) has NO native code and no FFI of its own: every entry below
+ * replaces a TensorFlow / tf-keras / TFP primitive the reference calls from Python.  Each
+ * declaration cites that call site (paths relative to the reference root).  The Python side
+ * (agents_amd/_lib.py) binds these with ctypes; INTEGRATION.md shows the binding a TF-Agents
+ * maintainer would add.
+ *
+ * Conventions: every function returns 0 on success or a negative errno-style code
+ * (AA_ERR_INVALID = -22 bad argument, AA_ERR_RANGE = -34 size/workspace out of range,
+ * AA_ERR_LAUNCH = -5 HIP launch failure).  All pointers are DEVICE pointers unless the name
+ * ends in `_h` (host array).  `stream` is a hipStream_t passed as void*.  Nothing synchronises
+ * the device.  No function allocates device memory; scratch is caller-provided.
+ */
+#ifndef AGENTS_AMD_H_
+#define AGENTS_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AA_ABI_VERSION 1
+int aa_abi_version(void);
+
+/* ---- activations (epilogues / derivative masks) ---------------------------------------- */
+#define AA_ACT_NONE 0
+#define AA_ACT_RELU 1
+#define AA_ACT_TANH 2
+
+/* =========================================================================================
+ * Replay ring buffer   (tf_agents/replay_buffers/tf_uniform_replay_buffer.py, table.py)
+ * ========================================================================================= */
+
+/* add_batch: id = *last_id + 1; rows[b] = b*max_len + id mod max_len; for every leaf copy
+ * items[b] -> table[rows[b]]; id_table[rows[b]] = id; then *last_id = id.
+ * Replaces Table.write / tf.compat.v1.scatter_update per leaf (table.py:112-137) driven by
+ * TFUniformReplayBuffer._add_batch (tf_uniform_replay_buffer.py:182-209, 582-607). */
+int aa_rb_scatter_rows(void* const* leaf_tables_h, const void* const* leaf_items_h,
+                       const int64_t* leaf_row_bytes_h, int n_leaves, int64_t* id_table,
+                       int64_t* last_id_dev, int64_t batch, int64_t max_len, void* stream);
+
+/* get_next index sampling: S independent (start id, env block) pairs from the Philox4x32-10
+ * stream (counter = (s, call_counter), key = seed), mapped with _valid_range_ids
+ * (tf_uniform_replay_buffer.py:610-635) and rows[s,t] = (id+t) mod L + block*L (:265-292);
+ * prob_out[s] = 1/((max-min)*batch) (:255-264).  Sets *err_flag_dev = 1 if the buffer is empty
+ * (the reference's assert_greater at :246-253).  Replaces tf.random.uniform(int64) x2. */
+int aa_rb_sample_rows(const int64_t* last_id_dev, int64_t batch, int64_t max_len, int64_t S,
+                      int64_t T, uint64_t seed, uint64_t call_counter, int64_t* rows_out,
+                      float* prob_out, int* err_flag_dev, void* stream);
+
+/* Row gather of every leaf + the id table: out[r] = table[rows[r]].
+ * Replaces Table.read / ResourceVariable.sparse_read per leaf (table.py:86-110). */
+int aa_rb_gather_rows(const void* const* leaf_tables_h, void* const* leaf_out_h,
+                      const int64_t* leaf_row_bytes_h, int n_leaves, const int64_t* id_table,
+                      int64_t* ids_out, const int64_t* rows, int64_t n_rows, void* stream);
+
+/* rows[b, i] = (start_id + i) mod L + b*L for gather_all (tf_uniform_replay_buffer.py:533-557). */
+int aa_rb_range_rows(int64_t start_id, int64_t n_ids, int64_t batch, int64_t max_len,
+                     int64_t* rows_out, void* stream);
+
+/* *counter += inc (device-side step / id counters; tf.Variable.assign_add). */
+int aa_counter_add(int64_t* counter_dev, int64_t inc, void* stream);
+
+/* =========================================================================================
+ * fp32 MFMA GEMM with dense / conv-patch operand loaders
+ *   (keras Dense / Conv2D forward + tf.GradientTape backward:
+ *    agents/dqn/dqn_agent.py:412-449, examples/dqn/mnih15/dqn_train_eval_atari.py:80-112)
+ * ========================================================================================= */
+#define AA_A_ROW 0        /* A(m,k) = A[m*lda + k]                                  */
+#define AA_A_COL 1        /* A(m,k) = A[k*lda + m]        (X^T for weight grads)    */
+#define AA_A_PATCH 2      /* A(pixel,k): f32 NHWC conv patches (forward)            */
+#define AA_A_PATCH_U8 3   /* same, uint8 input, value = (float)u8 / a_div           */
+#define AA_A_PATCH_T 4    /* A(k,pixel): transposed patches (conv weight gradient)  */
+#define AA_A_PATCH_T_U8 5
+#define AA_B_ROW 0        /* B(k,n) = B[k*ldb + n]                                  */
+#define AA_B_COL 1        /* B(k,n) = B[n*ldb + k]        (W^T for input grads)     */
+
+typedef struct aa_gemm_desc {
+  const void* A;
+  const float* B;
+  float* C;               /* C[m*ldc + n] */
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc;
+  int32_t a_mode, b_mode;
+  /* conv geometry for AA_A_PATCH*: NHWC input [n_img,H,W,Cin], VALID padding */
+  int32_t n_img, H, W, Cin, KH, KW, stride;
+  float a_div;            /* uint8 inputs: divisor (255 for the Atari Lambda(x/255) layer) */
+  /* epilogue: C = act(acc + bias[n]) * actgrad_{mask_kind}(mask_src[m*ldm + n]) */
+  const float* bias;      /* nullable */
+  int32_t act;
+  const float* mask_src;  /* nullable: forward OUTPUT of the layer whose activation is undone */
+  int32_t ldm;
+  int32_t mask_kind;
+  int32_t force_cfg;      /* 0 = auto; 1 = 128x64, 2 = 128x32, 3 = 64x64 tile */
+  int32_t force_splits;   /* 0 = auto split-K */
+} aa_gemm_desc;
+
+int64_t aa_gemm_f32_workspace_bytes(const aa_gemm_desc* d);
+int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* out[n] = sum_m x[m*ld + n]  (bias gradients).  workspace >= aa_colsum_workspace_bytes. */
+int64_t aa_colsum_workspace_bytes(int64_t M, int64_t N);
+int aa_colsum_f32(const float* x, int64_t ld, int64_t M, int64_t N, float* out, void* workspace,
+                  int64_t workspace_bytes, void* stream);
+
+/* dX[b,iy,ix,c] = sum over patches containing (iy,ix) of dcol[pixel][(ky*KW+kx)*Cin + c], times
+ * actgrad(mask_src) -- the input gradient of a VALID Conv2D from its column gradient. */
+int aa_col2im_f32(const float* dcol, int32_t n_img, int32_t H, int32_t W, int32_t Cin, int32_t KH,
+                  int32_t KW, int32_t stride, float* dx, const float* mask_src, int32_t mask_kind,
+                  void* stream);
+
+/* =========================================================================================
+ * DQN loss  (agents/dqn/dqn_agent.py:75-78, 451-460, 462-579; utils/common.py:367-411,
+ *            1199-1208, 1400-1476; trajectories/trajectory.py:716-850; utils/value_ops.py:21-99)
+ * ========================================================================================= */
+#define AA_LOSS_HUBER 0
+#define AA_LOSS_SQUARED 1
+
+/* Inputs are the [B,T] trajectory fields (T = n_step+1) and the three Q tables [B,A].
+ * Computes the n-step return/discount, td_targets, td_error, element-wise loss, the
+ * ~is_last mask, sample weights, loss = sum/global_batch, and dq = dLoss/dq_online. */
+int aa_dqn_td_loss(const float* q_online, const float* q_next_target,
+                   const float* q_next_select /* nullable: online net on next obs (DDQN) */,
+                   const int32_t* next_mask /* nullable [B,A]: 1 = action allowed */,
+                   const void* actions, int32_t actions_are_i64, int64_t action_stride,
+                   const float* reward, const float* discount, const int32_t* step_type,
+                   const float* weights /* nullable [B] */, int64_t B, int32_t T, int32_t A,
+                   float gamma, float reward_scale, int32_t loss_kind, float global_batch,
+                   float* loss_out, float* td_loss_out, float* td_error_out, float* dq_out,
+                   void* stream);
+
+/* =========================================================================================
+ * Optimizers / target update / clipping  (keras optimizers; utils/common.py:250-346;
+ *                                          utils/eager_utils.py:227-246; ppo_agent.py:948-949)
+ * ========================================================================================= */
+/* Adam, TF ApplyAdam form: alpha = lr*sqrt(1-b2^t)/(1-b1^t); m += (g-m)(1-b1);
+ * v += (g*g-v)(1-b2); p -= m*alpha/(sqrt(v)+eps).  t = *step_dev (already incremented). */
+int aa_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                 float beta2, float eps, const int64_t* step_dev, void* stream);
+/* keras RMSprop: ms = rho*ms + (1-rho) g^2; [mg = rho*mg + (1-rho) g];
+ * denom = ms - mg^2 + eps; inc = lr*g*rsqrt(denom); [mom = momentum*mom + inc; p -= mom]. */
+int aa_rmsprop_step(float* p, const float* g, float* ms, float* mg /* nullable: centered */,
+                    float* mom /* nullable: momentum */, int64_t n, float lr, float rho,
+                    float momentum, float eps, void* stream);
+int aa_sgd_step(float* p, const float* g, int64_t n, float lr, void* stream);
+/* t = (1-tau)*t + tau*s  (soft_variables_update, utils/common.py:314-346) */
+int aa_soft_update(float* target, const float* source, int64_t n, float tau, void* stream);
+/* sumsq_out[s] = sum g[off[s]:off[s+1]]^2 ; offsets are DEVICE int64[n_seg+1] */
+int aa_segment_sumsq(const float* g, const int64_t* seg_offsets_dev, int32_t n_seg,
+                     float* sumsq_out, void* stream);
+/* per_tensor=1: g *= clip/max(norm_s, clip) (tf.clip_by_norm per tensor);
+ * per_tensor=0: g *= clip*min(1/gnorm, 1/clip) (tf.clip_by_global_norm). */
+int aa_clip_by_norm(float* g, const int64_t* seg_offsets_dev, int32_t n_seg,
+                    const float* sumsq, float clip, int32_t per_tensor, void* stream);
+
+/* =========================================================================================
+ * Rollout: epsilon-greedy action selection + device-resident synthetic vector env
+ *   (policies/epsilon_greedy_policy.py:120-143, q_policy.py:150-194, greedy_policy.py:70-89;
+ *    environments/random_tf_environment.py, py_environment.py:233-239 auto-reset contract)
+ * ========================================================================================= */
+int aa_eps_greedy_action(const float* q, const int32_t* mask /* nullable [B,A] */, int64_t B,
+                         int32_t A, float epsilon, const float* epsilon_dev /* nullable */,
+                         uint64_t seed, const int64_t* call_counter_dev, int64_t action_min,
+                         void* actions_out, int32_t actions_are_i64, void* stream);
+
+#define AA_OBS_U8 0
+#define AA_OBS_F32 1
+/* One batched step of the synthetic env.  In: cur_step_type[B] (state), actions ignored.
+ * Out: next step_type/reward/discount/observation; cur_step_type is NOT modified. */
+int aa_vecenv_random_step(const int32_t* cur_step_type, int64_t B, int64_t obs_elems,
+                          int32_t obs_kind, float obs_lo, float obs_hi, float p_end,
+                          uint64_t seed, const int64_t* step_counter_dev, int32_t force_first,
+                          int32_t* step_type_out, float* reward_out, float* discount_out,
+                          void* obs_out, void* stream);
+
+/* =========================================================================================
+ * Value ops  (utils/value_ops.py:21-99 discounted_return, :102-164 GAE; ppo_agent.py:100-110)
+ * ========================================================================================= */
+/* Strided [B,T] access: element (b,t) at b*stride_b + t*stride_t. final_value nullable (zeros). */
+int aa_discounted_return(const float* rewards, const float* discounts, const float* final_value,
+                         int64_t B, int64_t T, int64_t stride_b, int64_t stride_t, float* out,
+                         void* stream);
+int aa_gae(const float* values, const float* final_value, const float* discounts,
+           const float* rewards, float td_lambda, int64_t B, int64_t T, int64_t stride_b,
+           int64_t stride_t, float* out, void* stream);
+/* out = (x - mean) / sqrt(var + eps) over all n elements (tf.nn.moments + batch_normalization);
+ * stats_out holds 2+256 floats: [0]=mean, [1]=var, rest scratch. */
+int aa_normalize_moments(const float* x, int64_t n, float eps, float* out, float* stats_out,
+                         void* stream);
+
+/* =========================================================================================
+ * PPO loss forward+backward for the diagonal-Normal head of PPOActorNetwork
+ *   (agents/ppo/ppo_agent.py:481-615, 1159-1201, 1203-1327, 1329-1512;
+ *    agents/ppo/ppo_actor_network.py:30-113; utils/common.py:682-756)
+ * ========================================================================================= */
+/* z[N,D] = means-layer output (pre tanh), std_bias[D] (pre softplus).  act_mean/act_mag[D]
+ * nullable together (no tanh squashing).  denom = N * num_replicas.  value_clip/logp_clip/c_e
+ * <= 0 disable the respective term.  Outputs: dz[N,D], dbias_elem[N,D] (column-sum it for the
+ * bias gradient), dv[N] (d loss / d value prediction), stats[8 + 5*256]:
+ * [0] policy_gradient_loss [1] value_estimation_loss [2] entropy_regularization_loss
+ * [3] clip_fraction [4] mean(entropy*weights) [5] sum of [0..2]; the rest is scratch. */
+int aa_ppo_loss(const float* z, const float* std_bias, const float* act_mean,
+                const float* act_mag, const float* actions, const float* old_logp,
+                const float* adv, const float* returns, const float* vpred,
+                const float* old_vpred, const float* weights, int64_t N, int32_t D,
+                float clip_eps, float value_clip, float c_v, float c_e, float denom,
+                float logp_clip, int32_t flags, float* dz, float* dbias_elem, float* dv,
+                float* stats, void* stream);
+/* g += c * p  (L2 regularisation gradient on a flat parameter range). */
+int aa_add_l2_grad(float* g, const float* p, int64_t n, float c, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGENTS_AMD_H_ */
