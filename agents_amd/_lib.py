@@ -5,7 +5,7 @@ call raises.  Torch is used only for device memory (`data_ptr()`) and the curren
 """
 import ctypes
 import os
-from ctypes import (POINTER, Structure, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p)
+from ctypes import (POINTER, Structure, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p)
 
 import torch
 
@@ -34,7 +34,7 @@ class GemmDesc(Structure):
         ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32),
         ("a_mode", c_int32), ("b_mode", c_int32),
         ("n_img", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32),
-        ("KH", c_int32), ("KW", c_int32), ("stride", c_int32),
+        ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("img_pitch", c_int32),
         ("a_div", c_float),
         ("bias", c_void_p), ("act", c_int32),
         ("mask_src", c_void_p), ("ldm", c_int32), ("mask_kind", c_int32),
@@ -51,6 +51,8 @@ _SIGNATURES = {
                                   c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "aa_rb_gather_rows": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int,
                                   c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "aa_rb_write_rows": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int,
+                                 c_void_p, c_int64, c_void_p]),
     "aa_rb_range_rows": (c_int, [c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "aa_counter_add": (c_int, [c_void_p, c_int64, c_void_p]),
     "aa_gemm_f32_workspace_bytes": (c_int64, [POINTER(GemmDesc)]),
@@ -58,12 +60,14 @@ _SIGNATURES = {
     "aa_colsum_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "aa_colsum_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64,
                               c_void_p]),
+    "aa_act_backward": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
+    "aa_sumsq_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "aa_col2im_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                               c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
     "aa_dqn_td_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
-                               c_float, c_float, c_int32, c_float, c_void_p, c_void_p, c_void_p,
-                               c_void_p, c_void_p]),
+                               c_double, c_double, c_double, c_int32, c_float, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p]),
     "aa_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float,
                              c_float, c_float, c_void_p, c_void_p]),
     "aa_rmsprop_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
@@ -73,6 +77,7 @@ _SIGNATURES = {
     "aa_segment_sumsq": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "aa_clip_by_norm": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_float, c_int32,
                                 c_void_p]),
+    "aa_count_steps": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "aa_eps_greedy_action": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p,
                                      c_uint64, c_void_p, c_int64, c_void_p, c_int32, c_void_p]),
     "aa_vecenv_random_step": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_float, c_float,

@@ -1,0 +1,281 @@
+"""DqnAgent / DdqnAgent on HIP kernels.
+
+Same constructor and behaviour as tf_agents/agents/dqn/dqn_agent.py:82-753 for feed-forward
+Q-networks:
+  _initialize         :380-383   hard copy theta -> theta_target
+  _train              :412-449   loss -> grads -> (per-tensor clip) -> optimizer -> counter -> target
+  _loss               :462-579   n-step transition, q / next-q, TD target, Huber|squared, ~is_last
+                                 mask, aggregate_losses (mean over the FULL batch, /replicas)
+  _compute_q_values / _compute_next_q_values :581-645 (DQN), :659-700 (Double DQN)
+  _get_target_updater :385-409   Periodically(period) -> soft_variables_update(tau)
+
+One train step is: online forward (activations kept), target forward (+ online forward on the
+next observation for DDQN) -> aa_dqn_td_loss (loss, td_error, dL/dq in one kernel) -> backward
+GEMMs into the flat gradient buffer -> [gradient hook: the Learner's RCCL all-reduce] -> fused
+optimizer over the flat parameter buffer -> target update.  Nothing syncs the device; LossInfo
+holds device tensors.
+"""
+import collections
+
+import numpy as np
+import torch
+
+from agents_amd import _lib, ops
+from agents_amd.agents import tf_agent
+from agents_amd.policies import q_policy
+from agents_amd.utils import common, nest_utils
+
+
+class DqnLossInfo(collections.namedtuple("DqnLossInfo", ("td_loss", "td_error"))):
+    """td_loss / td_error per example, masked by ~is_last (dqn_agent.py:50-72)."""
+
+
+def compute_td_targets(next_q_values, rewards, discounts):
+    """rewards + discounts * next_q (dqn_agent.py:75-78); API parity helper."""
+    return (rewards + discounts * next_q_values).detach()
+
+
+class _Work:
+    """Static per-batch-size outputs of the loss kernel (graph-capture friendly)."""
+
+    def __init__(self, B, A, device):
+        f = dict(dtype=torch.float32, device=device)
+        self.loss = torch.zeros((1,), **f)
+        self.td_loss = torch.zeros((B,), **f)
+        self.td_error = torch.zeros((B,), **f)
+        self.dq = torch.zeros((B, A), **f)
+
+
+class DqnAgent(tf_agent.TFAgent):
+    _double_q = False
+
+    def __init__(self, time_step_spec, action_spec, q_network, optimizer,
+                 observation_and_action_constraint_splitter=None, epsilon_greedy=0.1,
+                 n_step_update=1, boltzmann_temperature=None, emit_log_probability=False,
+                 target_q_network=None, target_update_tau=1.0, target_update_period=1,
+                 td_errors_loss_fn=None, gamma=1.0, reward_scale_factor=1.0,
+                 gradient_clipping=None, debug_summaries=False, summarize_grads_and_vars=False,
+                 train_step_counter=None, training_data_spec=None, name=None, seed=0):
+        self._check_action_spec(action_spec)
+        if epsilon_greedy is not None and boltzmann_temperature is not None:
+            raise ValueError(
+                "Configured both epsilon_greedy value {} and temperature {}, however only one of "
+                "them can be used for exploration.".format(epsilon_greedy, boltzmann_temperature))
+        if boltzmann_temperature is not None:
+            raise NotImplementedError("Boltzmann exploration is outside the hot-path scope")
+        self._observation_and_action_constraint_splitter = \
+            observation_and_action_constraint_splitter
+        self._q_network = q_network
+        net_observation_spec = time_step_spec.observation
+        if observation_and_action_constraint_splitter:
+            net_observation_spec, _ = observation_and_action_constraint_splitter(
+                net_observation_spec)
+        q_network.create_variables(net_observation_spec)
+        if target_q_network is not None:
+            target_q_network.create_variables(net_observation_spec)
+            if target_q_network is q_network or \
+                    target_q_network.flat_params.data_ptr() == q_network.flat_params.data_ptr():
+                raise ValueError("target_q_network shares weights with the original network")
+            self._target_q_network = target_q_network
+        else:
+            self._target_q_network = q_network.copy(name="TargetQNetwork")
+        self._check_network_output(self._q_network, "q_network")
+        self._check_network_output(self._target_q_network, "target_q_network")
+        self._epsilon_greedy = epsilon_greedy
+        self._n_step_update = n_step_update
+        self._optimizer = optimizer
+        self._td_errors_loss_fn = td_errors_loss_fn or common.element_wise_huber_loss
+        self._gamma = gamma
+        self._reward_scale_factor = reward_scale_factor
+        self._gradient_clipping = gradient_clipping
+        self._target_update_tau = target_update_tau
+        self._update_target = self._get_target_updater(target_update_tau, target_update_period)
+        self._seed = seed
+        policy, collect_policy = self._setup_policy(time_step_spec, action_spec,
+                                                    emit_log_probability)
+        if getattr(q_network, "state_spec", ()) and n_step_update != 1:
+            raise NotImplementedError(
+                "DqnAgent does not currently support n-step updates with stateful networks "
+                "(i.e., RNNs), but n_step_update = {}".format(n_step_update))
+        super().__init__(time_step_spec, action_spec, policy, collect_policy,
+                         train_sequence_length=n_step_update + 1,
+                         debug_summaries=debug_summaries,
+                         summarize_grads_and_vars=summarize_grads_and_vars,
+                         train_step_counter=train_step_counter,
+                         training_data_spec=training_data_spec)
+        self._work = {}
+        self._seg_offsets = None
+        self._seg_sumsq = None
+        # Data-parallel hooks installed by train.Learner: number of replicas the loss is averaged
+        # over (tf.nn.compute_average_loss, utils/common.py:1462-1467) and the gradient all-reduce.
+        self.num_replicas = 1
+        self.gradient_hook = None
+        self.check_numerics = False  # the reference's check_numerics needs a device sync
+
+    # ---- construction helpers -----------------------------------------------------------------
+    def _check_action_spec(self, action_spec):
+        flat = nest_utils.flatten(action_spec)
+        if len(flat) > 1 or len(flat[0].shape) > 0:
+            raise ValueError("Only scalar actions are supported now, but action spec is: {}"
+                             .format(action_spec))
+        spec = flat[0]
+        if int(np.asarray(spec.minimum)) != 0:
+            raise ValueError("Action specs should have minimum of 0, but saw: {0}".format(spec))
+        self._num_actions = int(np.asarray(spec.maximum) - np.asarray(spec.minimum) + 1)
+
+    def _check_network_output(self, net, label):
+        out_shape = net.create_variables()
+        if tuple(out_shape) != (self._num_actions,):
+            raise ValueError(f"Expected {label} to emit a floating point tensor with inner dims "
+                             f"({self._num_actions},); but saw network output spec: {out_shape}")
+
+    def _setup_policy(self, time_step_spec, action_spec, emit_log_probability):
+        splitter = self._observation_and_action_constraint_splitter
+        policy = q_policy.QPolicy(time_step_spec, action_spec, q_network=self._q_network,
+                                  emit_log_probability=emit_log_probability,
+                                  observation_and_action_constraint_splitter=splitter,
+                                  seed=self._seed)
+        collect_policy = q_policy.EpsilonGreedyPolicy(policy, epsilon=self._epsilon_greedy)
+        greedy = q_policy.GreedyPolicy(policy)
+        target_policy = q_policy.QPolicy(time_step_spec, action_spec,
+                                         q_network=self._target_q_network,
+                                         observation_and_action_constraint_splitter=splitter)
+        self._target_greedy_policy = q_policy.GreedyPolicy(target_policy)
+        return greedy, collect_policy
+
+    def _get_target_updater(self, tau=1.0, period=1):
+        def update():
+            return common.soft_variables_update(self._q_network.flat_params,
+                                                self._target_q_network.flat_params, tau)
+        return common.Periodically(update, period, "periodic_update_targets")
+
+    # ---- TFAgent implementation ----------------------------------------------------------------
+    def _initialize(self):
+        common.soft_variables_update(self._q_network.flat_params,
+                                     self._target_q_network.flat_params, tau=1.0)
+
+    def _get_work(self, B, device):
+        w = self._work.get(B)
+        if w is None:
+            w = _Work(B, self._num_actions, device)
+            self._work[B] = w
+        return w
+
+    def _loss_kind(self, fn):
+        kind = getattr(fn, "aa_loss_kind", None)
+        if kind is None:
+            raise NotImplementedError(
+                "td_errors_loss_fn must be common.element_wise_huber_loss or "
+                "common.element_wise_squared_loss (the fused loss kernel implements those two)")
+        return kind
+
+    def _forward_and_loss(self, experience, td_errors_loss_fn, gamma, reward_scale_factor, weights,
+                          need_grad):
+        obs = experience.observation
+        mask = None
+        if self._observation_and_action_constraint_splitter is not None:
+            obs, mask = self._observation_and_action_constraint_splitter(obs)
+        B = experience.discount.shape[0]
+        dev = experience.discount.device
+        w = self._get_work(B, dev)
+        obs_t = obs[:, 0]
+        obs_next = obs[:, -1]
+        q_online = self._q_network.forward(obs_t, slot="train", need_grad=need_grad)
+        q_next_target = self._target_q_network.forward(obs_next, slot="train")
+        q_next_select = None
+        if self._double_q:
+            q_next_select = self._q_network.forward(obs_next, slot="next")
+        next_mask = None
+        if mask is not None:
+            next_mask = mask[:, -1].to(torch.int32).contiguous()
+        if weights is not None:
+            if not isinstance(weights, torch.Tensor):
+                weights = torch.full((B,), float(weights), dtype=torch.float32, device=dev)
+            elif weights.dim() == 0:
+                weights = weights.to(torch.float32).expand(B).contiguous()
+            else:
+                weights = weights.to(torch.float32).contiguous()
+        st = experience.step_type
+        if st.dtype != torch.int32:
+            st = st.to(torch.int32)
+        ops.dqn_td_loss(q_online, q_next_target, q_next_select, next_mask,
+                        experience.action, experience.reward.contiguous(),
+                        experience.discount.contiguous(), st.contiguous(), weights,
+                        self._gamma, reward_scale_factor,
+                        self._loss_kind(td_errors_loss_fn or self._td_errors_loss_fn),
+                        float(B * self.num_replicas), w.loss, w.td_loss, w.td_error, w.dq,
+                        gamma_loss=gamma)
+        return w
+
+    def _loss(self, experience, td_errors_loss_fn=None, gamma=1.0, reward_scale_factor=1.0,
+              weights=None, training=False):
+        """Scalar loss + DqnLossInfo.  NOTE: like the reference, `gamma` here defaults to 1.0 and
+        only scales the bootstrap discount; `_train` passes the agent's gamma (dqn_agent.py:
+        412-421,462-470)."""
+        with torch.cuda.device(experience.discount.device):
+            w = self._forward_and_loss(experience, td_errors_loss_fn, gamma, reward_scale_factor,
+                                       weights, need_grad=False)
+            total = w.loss.clone()
+            if self._q_network.has_regularization:
+                total = total + self._q_network.regularization_loss() / self.num_replicas
+        return tf_agent.LossInfo(total.reshape(()),
+                                 DqnLossInfo(td_loss=w.td_loss.clone(),
+                                             td_error=w.td_error.clone()))
+
+    def _clip_gradients(self, net):
+        """Per-tensor tf.clip_by_norm (eager_utils.clip_gradient_norms, eager_utils.py:227-246)."""
+        lib = _lib.load()
+        dev = net.flat_grads.device
+        if self._seg_offsets is None:
+            # consecutive variables: [start_i, start_{i+1}); alignment padding holds zeros
+            starts = [s0 for s0, _ in net.segment_offsets()] + [net.flat_grads.numel()]
+            self._seg_offsets = torch.tensor(starts, dtype=torch.int64, device=dev)
+            self._seg_sumsq = torch.zeros((len(starts) - 1,), dtype=torch.float32, device=dev)
+        st = _lib.stream_ptr()
+        n_seg = self._seg_sumsq.numel()
+        _lib.check(lib.aa_segment_sumsq(net.flat_grads.data_ptr(), self._seg_offsets.data_ptr(),
+                                        n_seg, self._seg_sumsq.data_ptr(), st),
+                   "aa_segment_sumsq")
+        _lib.check(lib.aa_clip_by_norm(net.flat_grads.data_ptr(), self._seg_offsets.data_ptr(),
+                                       n_seg, self._seg_sumsq.data_ptr(),
+                                       float(self._gradient_clipping), 1, st), "aa_clip_by_norm")
+
+    def _train(self, experience, weights):
+        net = self._q_network
+        with torch.cuda.device(experience.discount.device):
+            w = self._forward_and_loss(experience, self._td_errors_loss_fn, self._gamma,
+                                       self._reward_scale_factor, weights, need_grad=True)
+            if self.check_numerics and not bool(torch.isfinite(w.loss).all()):
+                raise FloatingPointError("Loss is inf or nan")
+            net.backward(w.dq, slot="train")
+            total = w.loss
+            if net.has_regularization:
+                net.add_regularization_grads(1.0 / self.num_replicas)
+                total = w.loss + net.regularization_loss() / self.num_replicas
+            if self._gradient_clipping is not None:
+                self._clip_gradients(net)
+            if self.gradient_hook is not None:
+                self.gradient_hook(net.flat_grads)
+            self._optimizer.apply_flat(net.flat_params, net.flat_grads)
+            self._train_step_counter.assign_add(1)
+            self._update_target()
+        return tf_agent.LossInfo(total.reshape(()),
+                                 DqnLossInfo(td_loss=w.td_loss, td_error=w.td_error))
+
+    # ---- checkpointing ---------------------------------------------------------------------------
+    def state_dict(self):
+        return {"q": self._q_network.flat_params.clone(),
+                "target": self._target_q_network.flat_params.clone(),
+                "train_step": int(self._train_step_counter),
+                "optimizer": self._optimizer.state_dict() if self._optimizer else None}
+
+    def load_state_dict(self, sd):
+        self._q_network.flat_params.copy_(sd["q"])
+        self._target_q_network.flat_params.copy_(sd["target"])
+        self._train_step_counter.assign(sd["train_step"])
+
+
+class DdqnAgent(DqnAgent):
+    """Double DQN: the online network selects the next action, the target network evaluates it
+    (dqn_agent.py:659-700)."""
+    _double_q = True

@@ -29,6 +29,7 @@ aa_dqn_td_loss_kernel(const float* __restrict__ q_online, const float* __restric
                       int64_t action_stride, const float* __restrict__ reward,
                       const float* __restrict__ discount, const int32_t* __restrict__ step_type,
                       const float* __restrict__ weights, int64_t B, int T, int A, float gamma,
+                      float gpow, float gamma_loss,
                       float reward_scale, int loss_kind, float global_batch,
                       float* __restrict__ loss_out, float* __restrict__ td_loss_out,
                       float* __restrict__ td_error_out, float* __restrict__ dq_out) {
@@ -44,14 +45,8 @@ aa_dqn_td_loss_kernel(const float* __restrict__ q_online, const float* __restric
       ret = ret * (gamma * d) + reward[b * T + t];
     }
     for (int t = 0; t < n; ++t) dprod = dprod * discount[b * T + t];
-    // gamma ** (n-1) as repeated multiplication in fp32 (tf pow on a python float constant is
-    // folded in float64 then cast; for n == 1 both give exactly 1).
-    float gpow = 1.f;
-    {
-      double gp = 1.0;
-      for (int t = 0; t < n - 1; ++t) gp *= (double)gamma;
-      gpow = (float)gp;
-    }
+    // gpow = float32(gamma ** (n-1)) evaluated in float64 on the host, like the python-float
+    // constant the reference folds into the graph (trajectory.py:826-829).
     const float final_discount = gpow * dprod;
 
     // ---- greedy next action: first arg-max of the selecting net's (masked) Q ----------------
@@ -74,7 +69,7 @@ aa_dqn_td_loss_kernel(const float* __restrict__ q_online, const float* __restric
     const float q = q_online[b * A + act];
 
     const float rewards = reward_scale * ret;
-    const float discounts = gamma * final_discount;
+    const float discounts = gamma_loss * final_discount;  // DqnAgent._loss(gamma=...)
     const float td_target = rewards + discounts * next_q;
     float td_error = td_target - q;
     float loss, dloss_dq;
@@ -115,7 +110,8 @@ extern "C" int aa_dqn_td_loss(const float* q_online, const float* q_next_target,
                               const void* actions, int32_t actions_are_i64, int64_t action_stride,
                               const float* reward, const float* discount,
                               const int32_t* step_type, const float* weights, int64_t B,
-                              int32_t T, int32_t A, float gamma, float reward_scale,
+                              int32_t T, int32_t A, double gamma, double gamma_loss,
+                              double reward_scale,
                               int32_t loss_kind, float global_batch, float* loss_out,
                               float* td_loss_out, float* td_error_out, float* dq_out,
                               void* stream) {
@@ -126,15 +122,21 @@ extern "C" int aa_dqn_td_loss(const float* q_online, const float* q_next_target,
   if (B <= 0 || T < 2 || A <= 0 || !(global_batch > 0.f)) return AA_ERR_INVALID;
   if (loss_kind != AA_LOSS_HUBER && loss_kind != AA_LOSS_SQUARED) return AA_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
+  // float32(gamma ** (n-1)) with the power taken in float64 (python-float semantics)
+  double gp = 1.0;
+  for (int t = 0; t < T - 2; ++t) gp *= gamma;
+  const float gpow = (float)gp;
   if (actions_are_i64)
     hipLaunchKernelGGL(aa_dqn_td_loss_kernel<true>, dim3(1), dim3(256), 0, st, q_online,
                        q_next_target, q_next_select, next_mask, actions, action_stride, reward,
-                       discount, step_type, weights, B, T, A, gamma, reward_scale, loss_kind,
+                       discount, step_type, weights, B, T, A, (float)gamma, gpow, (float)gamma_loss,
+                       (float)reward_scale, loss_kind,
                        global_batch, loss_out, td_loss_out, td_error_out, dq_out);
   else
     hipLaunchKernelGGL(aa_dqn_td_loss_kernel<false>, dim3(1), dim3(256), 0, st, q_online,
                        q_next_target, q_next_select, next_mask, actions, action_stride, reward,
-                       discount, step_type, weights, B, T, A, gamma, reward_scale, loss_kind,
+                       discount, step_type, weights, B, T, A, (float)gamma, gpow, (float)gamma_loss,
+                       (float)reward_scale, loss_kind,
                        global_batch, loss_out, td_loss_out, td_error_out, dq_out);
   return aa_launch_status();
 }

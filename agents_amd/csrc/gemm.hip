@@ -545,9 +545,12 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
     const int64_t npix = (int64_t)d->n_img * OH * OW;
     const bool fwd = d->a_mode == AA_A_PATCH || d->a_mode == AA_A_PATCH_U8;
     if (fwd ? (d->K != Kp || d->M != npix) : (d->M != Kp || d->K != npix)) return AA_ERR_INVALID;
-    if ((int64_t)d->n_img * d->H * d->W * d->Cin >= 0x7fffffffLL) return AA_ERR_RANGE;
+    const int64_t dense_pitch = (int64_t)d->H * d->W * d->Cin;
+    const int64_t pitch = d->img_pitch > 0 ? (int64_t)d->img_pitch : dense_pitch;
+    if (pitch < dense_pitch || pitch % vecw != 0) return AA_ERR_INVALID;
+    if ((int64_t)d->n_img * pitch >= 0x7fffffffLL) return AA_ERR_RANGE;
     p.W = d->W; p.Cin = d->Cin; p.OW = OW; p.OHW = OH * OW; p.stride = d->stride;
-    p.seg = seg; p.rowpitch = d->W * d->Cin; p.imgpitch = d->H * d->W * d->Cin;
+    p.seg = seg; p.rowpitch = d->W * d->Cin; p.imgpitch = (int)pitch;
   }
   p.a_vec = (!patch && (d->lda % 4 == 0) && (((uintptr_t)d->A & 15) == 0)) ? 1 : 0;
   p.b_vec = ((d->ldb % 4 == 0) && (((uintptr_t)d->B & 15) == 0)) ? 1 : 0;

@@ -109,9 +109,44 @@ aa_col2im_kernel(const float* __restrict__ dcol, int n_img, int H, int W, int Ci
   }
 }
 
+// dz = dy * act'(y)   (gradient through a trailing activation, expressed via its output y)
+__global__ void __launch_bounds__(256)
+aa_act_backward_kernel(const float* __restrict__ dy, const float* __restrict__ y, int kind,
+                       int64_t n, float* __restrict__ dz) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dz[i] = dy[i] * aa_actgrad2(y[i], kind);
+}
+
+// sumsq_out[0] = sum x^2 over n elements (keras l2 regulariser / tf.nn.l2_loss), one workgroup
+__global__ void __launch_bounds__(1024)
+aa_sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += x[i] * x[i];
+  const float t = aa_block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = t;
+}
+
 extern "C" {
 
 int aa_abi_version(void) { return AA_ABI_VERSION; }
+
+int aa_act_backward(const float* dy, const float* y, int32_t act, int64_t n, float* dz,
+                    void* stream) {
+  if (!dy || !y || !dz || n <= 0) return AA_ERR_INVALID;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(aa_act_backward_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, dy, y, (int)act, n, dz);
+  return aa_launch_status();
+}
+
+int aa_sumsq_f32(const float* x, int64_t n, float* out, void* stream) {
+  if (!x || !out || n <= 0) return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_sumsq_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out);
+  return aa_launch_status();
+}
 
 int aa_counter_add(int64_t* counter_dev, int64_t inc, void* stream) {
   if (counter_dev == nullptr) return AA_ERR_INVALID;

@@ -103,6 +103,18 @@ aa_rb_gather_kernel(AaLeafSet leaves, const int64_t* __restrict__ id_table,
   if (chunk == 0 && threadIdx.x == 0 && ids_out != nullptr) ids_out[r] = id_table[row];
 }
 
+// ---- Table.write with explicit rows: table[rows[r]] = values[r] ---------------------------------
+__global__ void __launch_bounds__(AA_RB_THREADS)
+aa_rb_write_kernel(AaLeafSet leaves, const int64_t* __restrict__ rows, int n_chunks) {
+  const int64_t r = blockIdx.x / n_chunks;
+  const int chunk = blockIdx.x % n_chunks;
+  const int64_t row = rows[r];
+  for (int l = 0; l < leaves.n; ++l) {
+    const int64_t rb = leaves.row_bytes[l];
+    aa_copy_row_chunk(leaves.io[l] + r * rb, leaves.table[l] + row * rb, rb, chunk);
+  }
+}
+
 // ---- uniform sampling of (start id, env block) pairs -----------------------------------------
 // Stream definition (canonical for this package; see oracle/replay.py):
 //   (x0,x1,x2,x3) = Philox4x32-10(counter = (s_lo, s_hi, call_lo, call_hi), key = (seed_lo, seed_hi))
@@ -223,6 +235,25 @@ int aa_rb_gather_rows(const void* const* leaf_tables_h, void* const* leaf_out_h,
   if (grid > 0x7fffffffLL) return AA_ERR_RANGE;
   hipLaunchKernelGGL(aa_rb_gather_kernel, dim3((unsigned)grid), dim3(AA_RB_THREADS), 0,
                      (hipStream_t)stream, ls, id_table, ids_out, rows, n_chunks);
+  return aa_launch_status();
+}
+
+int aa_rb_write_rows(void* const* leaf_tables_h, const void* const* leaf_values_h,
+                     const int64_t* leaf_row_bytes_h, int n_leaves, const int64_t* rows,
+                     int64_t n_rows, void* stream) {
+  if (n_rows < 0 || rows == nullptr) return AA_ERR_INVALID;
+  if (n_rows == 0) return AA_OK;
+  AaLeafSet ls;
+  int64_t max_rb = 0;
+  int rc = aa_fill_leaves(ls, leaf_tables_h, (void* const*)leaf_values_h, leaf_row_bytes_h,
+                          n_leaves, &max_rb);
+  if (rc != AA_OK) return rc;
+  int n_chunks = (int)((max_rb + AA_RB_CHUNK - 1) / AA_RB_CHUNK);
+  if (n_chunks < 1) n_chunks = 1;
+  const int64_t grid = n_rows * n_chunks;
+  if (grid > 0x7fffffffLL) return AA_ERR_RANGE;
+  hipLaunchKernelGGL(aa_rb_write_kernel, dim3((unsigned)grid), dim3(AA_RB_THREADS), 0,
+                     (hipStream_t)stream, ls, rows, n_chunks);
   return aa_launch_status();
 }
 

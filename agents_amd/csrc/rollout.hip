@@ -124,7 +124,31 @@ aa_vecenv_step_kernel(const int32_t* __restrict__ cur_step_type, int64_t B, int6
   }
 }
 
+// DynamicStepDriver loop counter: counter[b] += (step_type[b] != LAST); *total += that sum
+// (tf_agents/drivers/dynamic_step_driver.py:113,170).  One workgroup, deterministic.
+__global__ void __launch_bounds__(256)
+aa_count_steps_kernel(const int32_t* __restrict__ step_type, int64_t B,
+                      int32_t* __restrict__ counter, int64_t* __restrict__ total) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+    const int inc = step_type[b] != 2 ? 1 : 0;
+    if (counter != nullptr) counter[b] += inc;
+    s += (float)inc;
+  }
+  const float t = aa_block_sum(s, red);
+  if (threadIdx.x == 0) *total += (int64_t)(t + 0.5f);
+}
+
 extern "C" {
+
+int aa_count_steps(const int32_t* step_type, int64_t B, int32_t* counter_dev, int64_t* total_dev,
+                   void* stream) {
+  if (!step_type || !total_dev || B <= 0 || B > (1 << 24)) return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_count_steps_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, step_type,
+                     B, counter_dev, total_dev);
+  return aa_launch_status();
+}
 
 int aa_eps_greedy_action(const float* q, const int32_t* mask, int64_t B, int32_t A, float epsilon,
                          const float* epsilon_dev, uint64_t seed, const int64_t* call_counter_dev,

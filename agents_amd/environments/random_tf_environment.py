@@ -1,0 +1,84 @@
+"""Device-resident synthetic vector environment (one HIP launch per batched step).
+
+Plays the role of tf_agents/environments/random_tf_environment.py:129 (an in-graph batched
+random env) for the hot path, where the reference pays a device->host->Python hop per step
+through TFPyEnvironment's tf.numpy_function (tf_py_environment.py:296-326).  Differences from the
+reference fake, chosen to behave like real batched envs (BatchedPyEnvironment resets sub-envs
+independently, batched_py_environment.py:155-180): every env ends its episode independently with
+probability `episode_end_probability`, and an env whose current step is LAST ignores the action
+and restarts (py_environment.py:233-239).  Observations / rewards come from the package's Philox
+stream (csrc/rollout.hip documents the counter layout; oracle/env.py restates it).
+"""
+import numpy as np
+import torch
+
+from agents_amd import _lib
+from agents_amd.environments import tf_environment
+from agents_amd.specs import tensor_spec
+from agents_amd.trajectories import time_step as ts
+
+
+class RandomTFEnvironment(tf_environment.TFEnvironment):
+    def __init__(self, time_step_spec, action_spec, batch_size=1, episode_end_probability=0.1,
+                 seed=0, device=None):
+        super().__init__(time_step_spec, action_spec, batch_size)
+        obs_spec = time_step_spec.observation
+        if not isinstance(obs_spec, tensor_spec.TensorSpec):
+            raise NotImplementedError("RandomTFEnvironment takes a single-tensor observation")
+        if obs_spec.dtype == torch.uint8:
+            self._obs_kind, self._lo, self._hi = _lib.AA_OBS_U8, 0.0, 255.0
+        elif obs_spec.dtype == torch.float32:
+            self._obs_kind = _lib.AA_OBS_F32
+            if isinstance(obs_spec, tensor_spec.BoundedTensorSpec):
+                self._lo = float(np.asarray(obs_spec.minimum).reshape(-1)[0])
+                self._hi = float(np.asarray(obs_spec.maximum).reshape(-1)[0])
+            else:
+                self._lo, self._hi = -1.0, 1.0
+        else:
+            raise NotImplementedError("observations must be uint8 or float32")
+        self._obs_spec = obs_spec
+        self._p_end = float(episode_end_probability)
+        self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._device = torch.device(device) if device is not None else torch.device("cuda")
+        self._step_counter = torch.zeros((1,), dtype=torch.int64, device=self._device)
+        self._time_step = None
+
+    def _alloc(self):
+        B = self._batch_size
+        dev = self._device
+        return ts.TimeStep(
+            step_type=torch.empty((B,), dtype=torch.int32, device=dev),
+            reward=torch.empty((B,), dtype=torch.float32, device=dev),
+            discount=torch.empty((B,), dtype=torch.float32, device=dev),
+            observation=torch.empty((B,) + tuple(self._obs_spec.shape),
+                                    dtype=self._obs_spec.dtype, device=dev))
+
+    def _launch(self, cur_step_type, force_first):
+        lib = _lib.load()
+        out = self._alloc()
+        with torch.cuda.device(self._device):
+            st = _lib.stream_ptr()
+            _lib.check(lib.aa_vecenv_random_step(
+                None if cur_step_type is None else cur_step_type.data_ptr(), self._batch_size,
+                self._obs_spec.num_elements, self._obs_kind, self._lo, self._hi, self._p_end,
+                self._seed, self._step_counter.data_ptr(), 1 if force_first else 0,
+                out.step_type.data_ptr(), out.reward.data_ptr(), out.discount.data_ptr(),
+                out.observation.data_ptr(), st), "aa_vecenv_random_step")
+            _lib.check(lib.aa_counter_add(self._step_counter.data_ptr(), 1, st),
+                       "aa_counter_add")
+        return out
+
+    def _current_time_step(self):
+        if self._time_step is None:
+            self._time_step = self._reset()
+        return self._time_step
+
+    def _reset(self):
+        self._time_step = self._launch(None, True)
+        return self._time_step
+
+    def _step(self, action):
+        if self._time_step is None:
+            return self._reset()
+        self._time_step = self._launch(self._time_step.step_type, False)
+        return self._time_step

@@ -1,0 +1,340 @@
+"""Sequential: a feed-forward stack (Rescale / Conv2D / Flatten / Dense) executed by HIP kernels.
+
+API follows tf_agents/networks/sequential.py:294 (a Network built from a list of layers, used by
+agents/dqn/examples/v2/train_eval.py:168,364 and examples/dqn/mnih15/dqn_train_eval_atari.py:100).
+There is no autograd: `forward` caches each layer's output, `backward` walks the stack in reverse
+issuing the weight-gradient / input-gradient GEMMs of csrc/gemm.hip (what tf.GradientTape does for
+keras Dense / Conv2D in tf_agents/agents/dqn/dqn_agent.py:412-426).
+
+Memory: all parameters of the network live in ONE flat fp32 buffer (`flat_params`), gradients in a
+second one of identical layout (`flat_grads`) -- kernel then bias per layer, every tensor starting
+on a 16-byte boundary -- so the optimizer, the target-network update and the RCCL gradient
+all-reduce are each a single pass over one contiguous range.
+"""
+import numpy as np
+import torch
+
+from agents_amd import _lib, ops
+from agents_amd.networks import layers as L
+from agents_amd.networks import network
+from agents_amd.utils import nest_utils
+
+
+def _align4(n):
+    return (n + 3) // 4 * 4
+
+
+class _Slot:
+    """Per-(slot, batch) activation and gradient buffers."""
+
+    def __init__(self):
+        self.xs = []      # input of each parametrised layer (tensor views)
+        self.ys = []      # output (post-activation) of each parametrised layer
+        self.dxs = []     # gradient wrt input of each parametrised layer (None for the first)
+        self.dcol = None  # column-gradient scratch for conv input gradients
+        self.dz_top = None
+
+
+class Sequential(network.Network):
+    def __init__(self, layers, input_spec=None, name=None, seed=None):
+        super().__init__(input_tensor_spec=input_spec, state_spec=(), name=name or "Sequential")
+        if not layers:
+            raise ValueError("`layers` must not be empty")
+        for l in layers:
+            if not isinstance(l, L.Layer):
+                raise TypeError(
+                    f"Sequential layers must be agents_amd.networks.layers objects, got {l!r}")
+        self._layers = list(layers)
+        self._seed = seed
+        self._slots = {}
+        self.flat_params = None
+        self.flat_grads = None
+        self._param_layers = [l for l in self._layers if l.has_params]
+        self._shapes = None     # [(kernel_shape, bias_shape)]
+        self._offsets = None    # [(k_off, b_off)]
+        self._kviews = self._bviews = self._gkviews = self._gbviews = None
+        self._reg_scratch = None
+
+    # ---- construction -------------------------------------------------------------------------
+    @property
+    def layers(self):
+        return list(self._layers)
+
+    def _infer(self, input_shape):
+        """Walks the stack: per param layer (kernel shape, bias shape, in shape, out shape)."""
+        shape = tuple(input_shape)
+        info = []
+        for l in self._layers:
+            if isinstance(l, L.Rescale):
+                continue
+            if isinstance(l, L.Flatten):
+                shape = (int(np.prod(shape)),)
+            elif isinstance(l, L.Conv2D):
+                if len(shape) != 3:
+                    raise ValueError(f"Conv2D needs an [H,W,C] input, got {shape}")
+                H, W, C = shape
+                kh, kw = l.kernel_size
+                oh, ow = ops.conv_out_hw(H, W, kh, kw, l.stride)
+                info.append(((kh, kw, C, l.filters), (l.filters,), shape, (oh, ow, l.filters)))
+                shape = (oh, ow, l.filters)
+            elif isinstance(l, L.Dense):
+                k = int(np.prod(shape))
+                info.append(((k, l.units), (l.units,), (k,), (l.units,)))
+                shape = (l.units,)
+        return info, shape
+
+    def create_variables(self, input_tensor_spec=None, device=None, **kwargs):
+        if self._built:
+            return self._output_spec_shape
+        if input_tensor_spec is not None:
+            self._input_tensor_spec = input_tensor_spec
+        spec = self._input_tensor_spec
+        if spec is None:
+            raise ValueError("create_variables needs an input_tensor_spec")
+        if nest_utils.is_nested(spec):
+            raise NotImplementedError("Sequential takes a single-tensor observation")
+        dev = torch.device(device) if device is not None else torch.device("cuda")
+        info, out_shape = self._infer(spec.shape)
+        self._info = info
+        self._output_spec_shape = out_shape
+        offs, total = [], 0
+        for ks, bs, _, _ in info:
+            k_off = total
+            total = _align4(total + int(np.prod(ks)))
+            b_off = total
+            total = _align4(total + int(np.prod(bs)))
+            offs.append((k_off, b_off))
+        self._offsets = offs
+        self._shapes = [(ks, bs) for ks, bs, _, _ in info]
+        rng = np.random.default_rng(self._seed)
+        host = np.zeros((max(total, 4),), np.float32)
+        for l, (ks, bs, _, _), (k_off, b_off) in zip(self._param_layers, info, offs):
+            fan_in = int(np.prod(ks[:-1]))
+            fan_out = int(ks[-1]) * (int(np.prod(ks[:-2])) if len(ks) == 4 else 1)
+            host[k_off:k_off + int(np.prod(ks))] = l.kernel_initializer(
+                ks, rng, fan_in, fan_out).reshape(-1)
+            host[b_off:b_off + int(np.prod(bs))] = l.bias_initializer(
+                bs, rng, fan_in, fan_out).reshape(-1)
+        self.flat_params = torch.from_numpy(host).to(dev)
+        self.flat_grads = torch.zeros_like(self.flat_params)
+        self._make_views()
+        self._built = True
+        return out_shape
+
+    def _make_views(self):
+        def views(flat):
+            kv, bv = [], []
+            for (ks, bs), (k_off, b_off) in zip(self._shapes, self._offsets):
+                kv.append(flat[k_off:k_off + int(np.prod(ks))].view(ks))
+                bv.append(flat[b_off:b_off + int(np.prod(bs))].view(bs))
+            return kv, bv
+        self._kviews, self._bviews = views(self.flat_params)
+        self._gkviews, self._gbviews = views(self.flat_grads)
+
+    @property
+    def variables(self):
+        self._require_built()
+        out = []
+        for k, b in zip(self._kviews, self._bviews):
+            out += [k, b]
+        return out
+
+    @property
+    def gradients(self):
+        self._require_built()
+        out = []
+        for k, b in zip(self._gkviews, self._gbviews):
+            out += [k, b]
+        return out
+
+    @property
+    def num_params(self):
+        return sum(int(np.prod(ks)) + int(np.prod(bs)) for ks, bs in self._shapes)
+
+    def segment_offsets(self):
+        """[start, end) ranges of every variable inside the flat buffers (for per-tensor clips)."""
+        segs = []
+        for (ks, bs), (k_off, b_off) in zip(self._shapes, self._offsets):
+            segs.append((k_off, k_off + int(np.prod(ks))))
+            segs.append((b_off, b_off + int(np.prod(bs))))
+        return segs
+
+    def _require_built(self):
+        if not self._built:
+            raise RuntimeError("network variables do not exist yet; call create_variables(spec)")
+
+    def copy(self, **kwargs):
+        new = Sequential(self._layers, input_spec=self._input_tensor_spec,
+                         name=kwargs.get("name", self._name), seed=self._seed)
+        if self._built:
+            new.create_variables(self._input_tensor_spec, device=self.flat_params.device)
+            new.flat_params.copy_(self.flat_params)
+        return new
+
+    def set_weights(self, arrays):
+        """Assign variables from a list of numpy arrays in `variables` order (tests / restore)."""
+        self._require_built()
+        for v, a in zip(self.variables, arrays):
+            v.copy_(torch.as_tensor(np.asarray(a, np.float32)).reshape(v.shape))
+
+    def get_weights(self):
+        return [v.detach().cpu().numpy() for v in self.variables]
+
+    # ---- regularisation (keras kernel_regularizer=l2) ---------------------------------------------
+    @property
+    def has_regularization(self):
+        return any(getattr(l, "l2", 0.0) > 0 for l in self._param_layers)
+
+    def regularization_loss(self):
+        """Device scalar sum_l l2_l * sum(W_l^2) (keras regularizers.l2)."""
+        lib = _lib.load()
+        dev = self.flat_params.device
+        total = None
+        for l, k in zip(self._param_layers, self._kviews):
+            l2 = getattr(l, "l2", 0.0)
+            if l2 <= 0:
+                continue
+            s = torch.empty((1,), dtype=torch.float32, device=dev)
+            _lib.check(lib.aa_sumsq_f32(k.data_ptr(), k.numel(), s.data_ptr(), _lib.stream_ptr()),
+                       "aa_sumsq_f32")
+            s = s * l2
+            total = s if total is None else total + s
+        return total
+
+    def add_regularization_grads(self, scale=1.0):
+        lib = _lib.load()
+        for l, k, g in zip(self._param_layers, self._kviews, self._gkviews):
+            l2 = getattr(l, "l2", 0.0)
+            if l2 > 0:
+                _lib.check(lib.aa_add_l2_grad(g.data_ptr(), k.data_ptr(), k.numel(),
+                                              2.0 * l2 * scale, _lib.stream_ptr()),
+                           "aa_add_l2_grad")
+
+    @property
+    def losses(self):
+        r = self.regularization_loss() if self._built and self.has_regularization else None
+        return [] if r is None else [r]
+
+    # ---- execution -----------------------------------------------------------------------------
+    def _slot(self, slot, B, need_grad):
+        key = (slot, B)
+        s = self._slots.get(key)
+        dev = self.flat_params.device
+        if s is None:
+            s = _Slot()
+            for ks, bs, in_shape, out_shape in self._info:
+                s.ys.append(torch.empty((B,) + tuple(out_shape), dtype=torch.float32, device=dev))
+            s.xs = [None] * len(self._info)
+            s.dxs = [None] * len(self._info)
+            self._slots[key] = s
+        if need_grad and s.dz_top is None:
+            dcol = 0
+            for i, (ks, bs, in_shape, out_shape) in enumerate(self._info):
+                if i == 0:
+                    continue
+                s.dxs[i] = torch.empty((B,) + tuple(in_shape), dtype=torch.float32, device=dev)
+                if len(ks) == 4:
+                    dcol = max(dcol, B * out_shape[0] * out_shape[1] * ks[0] * ks[1] * ks[2])
+            s.dcol = torch.empty((max(dcol, 1),), dtype=torch.float32, device=dev)
+            s.dz_top = torch.empty((B,) + tuple(self._info[-1][3]), dtype=torch.float32,
+                                   device=dev)
+        return s
+
+    def forward(self, x, slot=0, need_grad=False):
+        """Runs the stack on x [B, *input_shape]; returns the last layer's output buffer
+        (owned by the network, overwritten by the next forward on the same slot and batch)."""
+        self._require_built()
+        _lib.require_cuda(x)
+        spec = self._input_tensor_spec
+        if tuple(x.shape[1:]) != tuple(spec.shape):
+            raise ValueError(f"network input has shape {tuple(x.shape)}, expected [B]+"
+                             f"{tuple(spec.shape)}")
+        B = x.shape[0]
+        s = self._slot(slot, B, need_grad)
+        cur = x
+        div = None
+        pi = 0
+        for l in self._layers:
+            if isinstance(l, L.Rescale):
+                div = l.divisor
+            elif isinstance(l, L.Flatten):
+                cur = cur.reshape(B, -1)
+            elif isinstance(l, L.Conv2D):
+                if cur.dtype == torch.uint8:
+                    a_div = div if div is not None else 1.0
+                elif div is not None:
+                    raise NotImplementedError("Rescale is fused only for uint8 inputs")
+                else:
+                    a_div = 1.0
+                div = None
+                s.xs[pi] = cur
+                ops.conv_forward(cur, self._kviews[pi], self._bviews[pi], l.stride, l.activation,
+                                 s.ys[pi], a_div=a_div)
+                cur = s.ys[pi]
+                pi += 1
+            elif isinstance(l, L.Dense):
+                if cur.dtype != torch.float32 or div is not None:
+                    raise NotImplementedError(
+                        "Dense needs float32 inputs (uint8 / Rescale inputs are fused into a "
+                        "leading Conv2D only)")
+                cur2 = cur.reshape(B, -1)
+                s.xs[pi] = cur2
+                ops.dense_forward(cur2, self._kviews[pi], self._bviews[pi], l.activation,
+                                  s.ys[pi])
+                cur = s.ys[pi]
+                pi += 1
+        return cur
+
+    def backward(self, dout, slot=0):
+        """Given d loss / d output [B, out], fills flat_grads (overwrites)."""
+        B = dout.shape[0]
+        s = self._slots.get((slot, B))
+        if s is None or s.dz_top is None or s.xs[0] is None:
+            raise RuntimeError("backward() needs a preceding forward(..., need_grad=True)")
+        lib = _lib.load()
+        n = len(self._param_layers)
+        top = self._param_layers[-1]
+        if top.activation is not None:
+            _lib.check(lib.aa_act_backward(dout.data_ptr(), s.ys[-1].data_ptr(),
+                                           ops.ACT[top.activation], dout.numel(),
+                                           s.dz_top.data_ptr(), _lib.stream_ptr()),
+                       "aa_act_backward")
+            dz = s.dz_top
+        else:
+            dz = dout.contiguous()
+        for i in range(n - 1, -1, -1):
+            l = self._param_layers[i]
+            ks = self._shapes[i][0]
+            x = s.xs[i]
+            prev_act = self._param_layers[i - 1].activation if i > 0 else None
+            if isinstance(l, L.Dense):
+                dz2 = dz.view(B, -1)
+                ops.dense_dw(x, dz2, self._gkviews[i])
+                ops.colsum(dz2, self._gbviews[i])
+                if i > 0:
+                    dx = s.dxs[i].view(B, -1)
+                    ops.dense_dx(dz2, self._kviews[i], dx, mask_src=x if prev_act else None,
+                                 mask_act=prev_act)
+                    dz = s.dxs[i]
+            else:
+                F = ks[3]
+                dz2 = dz.view(-1, F)
+                ops.conv_dw(x, dz2, ks, l.stride, self._gkviews[i],
+                            a_div=self._first_div() if i == 0 else 1.0)
+                ops.colsum(dz2, self._gbviews[i])
+                if i > 0:
+                    ops.conv_dx(dz2, self._kviews[i], tuple(x.shape), l.stride, s.dcol, s.dxs[i],
+                                mask_src=x if prev_act else None, mask_act=prev_act)
+                    dz = s.dxs[i]
+
+    def _first_div(self):
+        for l in self._layers:
+            if isinstance(l, L.Rescale):
+                return l.divisor
+            if l.has_params:
+                break
+        return 1.0
+
+    def call(self, inputs, step_type=None, network_state=(), training=False, **kwargs):
+        out = self.forward(inputs, slot="call")
+        return out.clone(), network_state

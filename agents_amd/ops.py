@@ -1,0 +1,253 @@
+"""Tensor-level wrappers over the C ABI (include/agents_amd.h).
+
+These take torch device tensors, validate shape / dtype / contiguity, and enqueue the HIP kernels on
+torch's current stream.  No arithmetic happens in torch; there is no CPU fallback.
+"""
+import ctypes
+
+import torch
+
+from agents_amd import _lib
+from agents_amd._lib import (AA_A_COL, AA_A_PATCH, AA_A_PATCH_T, AA_A_PATCH_T_U8, AA_A_PATCH_U8,
+                             AA_A_ROW, AA_ACT_NONE, AA_ACT_RELU, AA_ACT_TANH, AA_B_COL, AA_B_ROW,
+                             AA_LOSS_HUBER, AA_LOSS_SQUARED, GemmDesc, check, ptr, require_cuda,
+                             stream_ptr)
+
+ACT = {None: AA_ACT_NONE, "none": AA_ACT_NONE, "linear": AA_ACT_NONE, "relu": AA_ACT_RELU,
+       "tanh": AA_ACT_TANH}
+
+
+class _Workspace:
+    """Grow-only scratch buffer per device (split-K slabs, column-sum partials)."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, nbytes, device):
+        key = (device.type, device.index)
+        buf = self._buf.get(key)
+        if buf is None or buf.numel() < nbytes:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.AgentsAmdError(
+                    "workspace would grow during graph capture; run one eager step first")
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self._buf[key] = buf
+        return buf
+
+
+_WS = _Workspace()
+# Separate scratch for column-sum partials so a bias-grad launch never aliases a live split-K slab
+_WS2 = _Workspace()
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous float32 tensor, got {t.dtype} "
+                         f"contiguous={t.is_contiguous()}")
+
+
+def _rows_ok(t, name, dtype=torch.float32):
+    """2-D tensor whose rows are contiguous (outer stride free): returns the row pitch."""
+    if t.dtype != dtype or t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError(f"{name} must be a 2-D {dtype} tensor with contiguous rows")
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def _img_pitch(x):
+    """NHWC tensor with dense images but a free batch stride: returns elements between images."""
+    Bn, H, W, C = x.shape
+    if x.stride(3) != 1 or x.stride(2) != C or x.stride(1) != W * C:
+        raise ValueError("conv input images must be dense NHWC (only the batch dim may be strided)")
+    return x.stride(0) if Bn > 1 else H * W * C
+
+
+def gemm_desc(**kw):
+    d = GemmDesc()
+    for k, v in kw.items():
+        setattr(d, k, v)
+    return d
+
+
+def gemm(desc, device):
+    lib = _lib.load()
+    need = lib.aa_gemm_f32_workspace_bytes(ctypes.byref(desc))
+    if need < 0:
+        raise ValueError("aa_gemm_f32: invalid descriptor (M,N,K must be positive)")
+    ws = _WS.get(need, device) if need > 0 else None
+    check(lib.aa_gemm_f32(ctypes.byref(desc), ptr(ws), ws.numel() if ws is not None else 0,
+                          stream_ptr()), "aa_gemm_f32")
+
+
+# ---- Dense ---------------------------------------------------------------------------------
+def dense_forward(x, w, bias, act, out, a_div=None, force_cfg=0, force_splits=0):
+    """out[M,N] = act(x[M,K] @ w[K,N] + bias)."""
+    require_cuda(x, w, out)
+    lda = _rows_ok(x, "x"); _f32c(w, "w"); _f32c(out, "out")
+    M, K = x.shape
+    K2, N = w.shape
+    if K != K2 or tuple(out.shape) != (M, N):
+        raise ValueError(f"dense_forward shape mismatch x{tuple(x.shape)} w{tuple(w.shape)} "
+                         f"out{tuple(out.shape)}")
+    d = gemm_desc(A=ptr(x), B=ptr(w), C=ptr(out), M=M, N=N, K=K, lda=lda, ldb=N, ldc=N,
+                  a_mode=AA_A_ROW, b_mode=AA_B_ROW, bias=ptr(bias), act=ACT[act],
+                  force_cfg=force_cfg, force_splits=force_splits)
+    gemm(d, x.device)
+    return out
+
+
+def dense_dx(dz, w, out, mask_src=None, mask_act=None, force_cfg=0, force_splits=0):
+    """out[M,K] = (dz[M,N] @ w[K,N]^T) * act'(mask_src[M,K])."""
+    require_cuda(dz, w, out, mask_src)
+    _f32c(dz, "dz"); _f32c(w, "w"); _f32c(out, "out")
+    M, N = dz.shape
+    K, N2 = w.shape
+    if N != N2 or tuple(out.shape) != (M, K):
+        raise ValueError("dense_dx shape mismatch")
+    d = gemm_desc(A=ptr(dz), B=ptr(w), C=ptr(out), M=M, N=K, K=N, lda=N, ldb=N, ldc=K,
+                  a_mode=AA_A_ROW, b_mode=AA_B_COL, mask_src=ptr(mask_src), ldm=K,
+                  mask_kind=ACT[mask_act] if mask_src is not None else 0,
+                  force_cfg=force_cfg, force_splits=force_splits)
+    gemm(d, dz.device)
+    return out
+
+
+def dense_dw(x, dz, out, force_cfg=0, force_splits=0):
+    """out[K,N] = x[M,K]^T @ dz[M,N]."""
+    require_cuda(x, dz, out)
+    lda = _rows_ok(x, "x"); _f32c(dz, "dz"); _f32c(out, "out")
+    M, K = x.shape
+    M2, N = dz.shape
+    if M != M2 or tuple(out.shape) != (K, N):
+        raise ValueError("dense_dw shape mismatch")
+    d = gemm_desc(A=ptr(x), B=ptr(dz), C=ptr(out), M=K, N=N, K=M, lda=lda, ldb=N, ldc=N,
+                  a_mode=AA_A_COL, b_mode=AA_B_ROW, force_cfg=force_cfg,
+                  force_splits=force_splits)
+    gemm(d, x.device)
+    return out
+
+
+# ---- Conv2D (NHWC, VALID) -------------------------------------------------------------------
+def conv_out_hw(H, W, KH, KW, stride):
+    return (H - KH) // stride + 1, (W - KW) // stride + 1
+
+
+def _conv_common(x, w, stride):
+    if x.dim() != 4 or w.dim() != 4:
+        raise ValueError("conv expects NHWC input [B,H,W,C] and HWIO kernel [KH,KW,Cin,Cout]")
+    if not w.is_contiguous():
+        raise ValueError("conv kernel must be contiguous")
+    Bn, H, W, C = x.shape
+    KH, KW, Cin, Cout = w.shape
+    if Cin != C:
+        raise ValueError("conv channel mismatch")
+    OH, OW = conv_out_hw(H, W, KH, KW, stride)
+    return Bn, H, W, C, KH, KW, Cout, OH, OW
+
+
+def conv_forward(x, w, bias, stride, act, out, a_div=255.0, force_cfg=0, force_splits=0):
+    """out[B,OH,OW,Cout] = act(conv_valid(x / a_div if uint8 else x, w) + bias)."""
+    require_cuda(x, w, out)
+    Bn, H, W, C, KH, KW, Cout, OH, OW = _conv_common(x, w, stride)
+    _f32c(w, "w"); _f32c(out, "out")
+    if x.dtype == torch.uint8:
+        mode = AA_A_PATCH_U8
+    elif x.dtype == torch.float32:
+        mode = AA_A_PATCH
+    else:
+        raise ValueError("conv input must be uint8 or float32")
+    if out.numel() != Bn * OH * OW * Cout:
+        raise ValueError("conv_forward: bad output size")
+    Kp = KH * KW * C
+    d = gemm_desc(A=ptr(x), B=ptr(w), C=ptr(out), M=Bn * OH * OW, N=Cout, K=Kp, lda=0, ldb=Cout,
+                  ldc=Cout, a_mode=mode, b_mode=AA_B_ROW, n_img=Bn, H=H, W=W, Cin=C, KH=KH, KW=KW,
+                  stride=stride, img_pitch=_img_pitch(x), a_div=float(a_div), bias=ptr(bias),
+                  act=ACT[act], force_cfg=force_cfg, force_splits=force_splits)
+    gemm(d, x.device)
+    return out
+
+
+def conv_dw(x, dz, w_shape, stride, out, a_div=255.0, force_cfg=0, force_splits=0):
+    """out[KH,KW,Cin,Cout] = patches(x)^T @ dz[B*OH*OW, Cout]."""
+    require_cuda(x, dz, out)
+    KH, KW, Cin, Cout = w_shape
+    Bn, H, W, C = x.shape
+    OH, OW = conv_out_hw(H, W, KH, KW, stride)
+    _f32c(dz, "dz"); _f32c(out, "out")
+    mode = AA_A_PATCH_T_U8 if x.dtype == torch.uint8 else AA_A_PATCH_T
+    Kp = KH * KW * C
+    if dz.numel() != Bn * OH * OW * Cout or out.numel() != Kp * Cout:
+        raise ValueError("conv_dw: bad sizes")
+    d = gemm_desc(A=ptr(x), B=ptr(dz), C=ptr(out), M=Kp, N=Cout, K=Bn * OH * OW, lda=0, ldb=Cout,
+                  ldc=Cout, a_mode=mode, b_mode=AA_B_ROW, n_img=Bn, H=H, W=W, Cin=C, KH=KH, KW=KW,
+                  stride=stride, img_pitch=_img_pitch(x), a_div=float(a_div),
+                  force_cfg=force_cfg, force_splits=force_splits)
+    gemm(d, x.device)
+    return out
+
+
+def conv_dx(dz, w, x_shape, stride, dcol, out, mask_src=None, mask_act=None):
+    """Input gradient of a VALID conv: dcol = dz @ w^T (GEMM), out = col2im(dcol) * act'(mask)."""
+    require_cuda(dz, w, dcol, out, mask_src)
+    lib = _lib.load()
+    Bn, H, W, C = x_shape
+    KH, KW, Cin, Cout = w.shape
+    OH, OW = conv_out_hw(H, W, KH, KW, stride)
+    Kp = KH * KW * C
+    M = Bn * OH * OW
+    _f32c(dz, "dz"); _f32c(w, "w"); _f32c(dcol, "dcol"); _f32c(out, "out")
+    if dcol.numel() < M * Kp or out.numel() != Bn * H * W * C:
+        raise ValueError("conv_dx: bad sizes")
+    d = gemm_desc(A=ptr(dz), B=ptr(w), C=ptr(dcol), M=M, N=Kp, K=Cout, lda=Cout, ldb=Cout,
+                  ldc=Kp, a_mode=AA_A_ROW, b_mode=AA_B_COL)
+    gemm(d, dz.device)
+    check(lib.aa_col2im_f32(ptr(dcol), Bn, H, W, C, KH, KW, stride, ptr(out), ptr(mask_src),
+                            ACT[mask_act] if mask_src is not None else 0, stream_ptr()),
+          "aa_col2im_f32")
+    return out
+
+
+def colsum(x2d, out):
+    """out[N] = sum_m x2d[m, :]."""
+    require_cuda(x2d, out)
+    lib = _lib.load()
+    _f32c(x2d, "x"); _f32c(out, "out")
+    M, N = x2d.shape
+    need = lib.aa_colsum_workspace_bytes(M, N)
+    ws = _WS2.get(need, x2d.device)
+    check(lib.aa_colsum_f32(ptr(x2d), N, M, N, ptr(out), ptr(ws), ws.numel(), stream_ptr()),
+          "aa_colsum_f32")
+    return out
+
+
+# ---- DQN loss -------------------------------------------------------------------------------
+def dqn_td_loss(q_online, q_next_target, q_next_select, next_mask, actions, reward, discount,
+                step_type, weights, gamma, reward_scale, loss_kind, global_batch, loss_out,
+                td_loss_out, td_error_out, dq_out, gamma_loss=None):
+    if gamma_loss is None:
+        gamma_loss = gamma
+    require_cuda(q_online, q_next_target, actions, reward, discount, step_type)
+    lib = _lib.load()
+    B, A = q_online.shape
+    T = reward.shape[1]
+    for t, n in ((q_online, "q_online"), (q_next_target, "q_next_target"), (reward, "reward"),
+                 (discount, "discount")):
+        _f32c(t, n)
+    if step_type.dtype != torch.int32 or not step_type.is_contiguous():
+        raise ValueError("step_type must be contiguous int32 [B,T]")
+    if actions.dtype not in (torch.int32, torch.int64):
+        raise ValueError("actions must be int32 or int64")
+    if actions.dim() == 2:
+        action_stride = actions.stride(0)
+    else:
+        action_stride = actions.stride(0) if actions.numel() > 1 else 1
+    check(lib.aa_dqn_td_loss(ptr(q_online), ptr(q_next_target), ptr(q_next_select), ptr(next_mask),
+                             ptr(actions), 1 if actions.dtype == torch.int64 else 0,
+                             action_stride, ptr(reward), ptr(discount), ptr(step_type),
+                             ptr(weights), B, T, A, float(gamma), float(gamma_loss),
+                             float(reward_scale),
+                             int(loss_kind), float(global_batch), ptr(loss_out),
+                             ptr(td_loss_out), ptr(td_error_out), ptr(dq_out), stream_ptr()),
+          "aa_dqn_td_loss")
+
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,116 @@
+"""Fused flat-buffer optimizers (csrc/optim.hip) behind a keras-like surface.
+
+The reference's scripts hand the agent a TF optimizer object (tf.compat.v1.train.AdamOptimizer in
+agents/dqn/examples/v2/train_eval.py:180; keras RMSprop(rho=.95, momentum=.95, epsilon=.01,
+centered=True) in examples/dqn/mnih15/dqn_train_eval_atari.py:176-182; Adam(eps=1e-5) for PPO).
+These classes take the same hyper-parameters and expose `apply_gradients(grads_and_vars)` and
+`variables()`.  Update arithmetic is documented in include/agents_amd.h; slots live in flat fp32
+buffers parallel to the network's flat parameter buffer so one launch updates the whole model.
+"""
+import torch
+
+from agents_amd import _lib
+
+
+class Optimizer:
+    def __init__(self, name):
+        self._name = name
+        self._slots = {}       # id(flat param storage) -> dict of slot tensors
+        self.iterations = 0    # host mirror of the device step counter
+
+    # -- flat API (used by agents) -------------------------------------------------------------
+    def apply_flat(self, params, grads):
+        """One fused update of the flat fp32 `params` with `grads` (same layout)."""
+        raise NotImplementedError
+
+    def _slot(self, params, names):
+        key = params.data_ptr()
+        s = self._slots.get(key)
+        if s is None:
+            s = {n: torch.zeros_like(params) for n in names}
+            s["step"] = torch.zeros((1,), dtype=torch.int64, device=params.device)
+            self._slots[key] = s
+        return s
+
+    # -- keras-like API ----------------------------------------------------------------------------
+    def apply_gradients(self, grads_and_vars, name=None):
+        """Per-variable update; each (grad, var) pair must be fp32 device tensors of one shape.
+        Variables that are consecutive views of one flat buffer should use `apply_flat`."""
+        for g, v in grads_and_vars:
+            if g is None:
+                continue
+            self.apply_flat(v.reshape(-1), g.reshape(-1))
+        return None
+
+    def variables(self):
+        out = []
+        for s in self._slots.values():
+            out += list(s.values())
+        return out
+
+    def state_dict(self):
+        return {"iterations": self.iterations,
+                "slots": [{k: v.clone() for k, v in s.items()} for s in self._slots.values()]}
+
+
+class Adam(Optimizer):
+    """TF ApplyAdam arithmetic; epsilon defaults to keras' 1e-7 (tf.compat.v1 uses 1e-8)."""
+
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, name="Adam"):
+        super().__init__(name)
+        self.learning_rate, self.beta_1, self.beta_2, self.epsilon = \
+            float(learning_rate), float(beta_1), float(beta_2), float(epsilon)
+
+    def apply_flat(self, params, grads):
+        lib = _lib.load()
+        _lib.require_cuda(params, grads)
+        s = self._slot(params, ("m", "v"))
+        st = _lib.stream_ptr()
+        _lib.check(lib.aa_counter_add(s["step"].data_ptr(), 1, st), "aa_counter_add")
+        _lib.check(lib.aa_adam_step(params.data_ptr(), grads.data_ptr(), s["m"].data_ptr(),
+                                    s["v"].data_ptr(), params.numel(), self.learning_rate,
+                                    self.beta_1, self.beta_2, self.epsilon, s["step"].data_ptr(),
+                                    st), "aa_adam_step")
+        self.iterations += 1
+
+
+class AdamOptimizer(Adam):
+    """tf.compat.v1.train.AdamOptimizer signature (epsilon 1e-8)."""
+
+    def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8,
+                 use_locking=False, name="Adam"):
+        super().__init__(learning_rate, beta1, beta2, epsilon, name)
+
+
+class RMSprop(Optimizer):
+    def __init__(self, learning_rate=0.001, rho=0.9, momentum=0.0, epsilon=1e-7, centered=False,
+                 name="RMSprop"):
+        super().__init__(name)
+        self.learning_rate, self.rho, self.momentum, self.epsilon, self.centered = \
+            float(learning_rate), float(rho), float(momentum), float(epsilon), bool(centered)
+
+    def apply_flat(self, params, grads):
+        lib = _lib.load()
+        _lib.require_cuda(params, grads)
+        names = ["ms"] + (["mg"] if self.centered else []) + (["mom"] if self.momentum > 0 else [])
+        s = self._slot(params, names)
+        _lib.check(lib.aa_rmsprop_step(
+            params.data_ptr(), grads.data_ptr(), s["ms"].data_ptr(),
+            s["mg"].data_ptr() if self.centered else None,
+            s["mom"].data_ptr() if self.momentum > 0 else None, params.numel(),
+            self.learning_rate, self.rho, self.momentum, self.epsilon, _lib.stream_ptr()),
+            "aa_rmsprop_step")
+        self.iterations += 1
+
+
+class SGD(Optimizer):
+    def __init__(self, learning_rate=0.01, name="SGD"):
+        super().__init__(name)
+        self.learning_rate = float(learning_rate)
+
+    def apply_flat(self, params, grads):
+        lib = _lib.load()
+        _lib.require_cuda(params, grads)
+        _lib.check(lib.aa_sgd_step(params.data_ptr(), grads.data_ptr(), params.numel(),
+                                   self.learning_rate, _lib.stream_ptr()), "aa_sgd_step")
+        self.iterations += 1

@@ -1,0 +1,176 @@
+"""Q-value policies: QPolicy, GreedyPolicy, EpsilonGreedyPolicy, RandomTFPolicy.
+
+  QPolicy._distribution          tf_agents/policies/q_policy.py:150-194   (Categorical(logits=Q))
+  GreedyPolicy                   tf_agents/policies/greedy_policy.py:70-89 (mode = first arg-max)
+  EpsilonGreedyPolicy._action    tf_agents/policies/epsilon_greedy_policy.py:120-143
+  RandomTFPolicy                 tf_agents/policies/random_tf_policy.py
+The three are fused into one kernel launch after the Q-network forward: arg-max with the action
+mask (masked logits -> dtype.min), a Philox uniform per env, and the epsilon mix
+(csrc/rollout.hip: aa_eps_greedy_action).
+"""
+import numpy as np
+import torch
+
+from agents_amd import _lib
+from agents_amd.policies import tf_policy
+from agents_amd.trajectories import policy_step
+from agents_amd.utils import nest_utils
+
+
+def _action_bounds(action_spec):
+    spec = nest_utils.flatten(action_spec)[0]
+    lo = int(np.asarray(spec.minimum).reshape(-1)[0])
+    hi = int(np.asarray(spec.maximum).reshape(-1)[0])
+    return spec, lo, hi
+
+
+class _DiscretePolicy(tf_policy.TFPolicy):
+    """Shared machinery: run (optional) Q-network, then the fused select kernel."""
+
+    def __init__(self, time_step_spec, action_spec, q_network=None, epsilon=0.0, seed=0,
+                 observation_and_action_constraint_splitter=None, emit_log_probability=False,
+                 name=None):
+        super().__init__(time_step_spec, action_spec, emit_log_probability=emit_log_probability,
+                         observation_and_action_constraint_splitter=
+                         observation_and_action_constraint_splitter, name=name)
+        flat = nest_utils.flatten(action_spec)
+        if len(flat) != 1:
+            raise ValueError("Only scalar actions are supported now.")
+        self._spec, self._lo, self._hi = _action_bounds(action_spec)
+        if self._spec.shape not in [(), (1,)]:
+            raise ValueError("Only scalar actions are supported now.")
+        if self._spec.dtype not in (torch.int32, torch.int64):
+            raise ValueError("discrete policies need an int32/int64 action spec")
+        self._num_actions = self._hi - self._lo + 1
+        self._q_network = q_network
+        self._epsilon = epsilon
+        self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._call_counter = None
+        self._zero_q = {}
+        self._slot = "policy"
+
+    def _variables(self):
+        return self._q_network.variables if self._q_network is not None else []
+
+    @property
+    def q_network(self):
+        return self._q_network
+
+    def _get_epsilon(self):
+        e = self._epsilon
+        return float(e() if callable(e) else e)
+
+    def _q_values(self, observation, B, device):
+        if self._q_network is None:
+            z = self._zero_q.get((B, device))
+            if z is None:
+                z = torch.zeros((B, self._num_actions), dtype=torch.float32, device=device)
+                self._zero_q[(B, device)] = z
+            return z
+        return self._q_network.forward(observation, slot=self._slot)
+
+    def q_values(self, time_step):
+        """[B, A] Q table for a batch of time steps (network-owned buffer)."""
+        obs = time_step.observation
+        if self._observation_and_action_constraint_splitter is not None:
+            obs, _ = self._observation_and_action_constraint_splitter(obs)
+        return self._q_values(obs, obs.shape[0], obs.device)
+
+    def select(self, q, mask, epsilon, out=None):
+        """Fused masked arg-max + epsilon mix on a [B, A] Q table -> actions [B]."""
+        lib = _lib.load()
+        _lib.require_cuda(q)
+        B = q.shape[0]
+        dev = q.device
+        if self._call_counter is None:
+            self._call_counter = torch.zeros((1,), dtype=torch.int64, device=dev)
+        if out is None:
+            out = torch.empty((B,) + tuple(self._spec.shape), dtype=self._spec.dtype, device=dev)
+        if mask is not None:
+            mask = mask.to(torch.int32).contiguous() if mask.dtype != torch.int32 else \
+                mask.contiguous()
+        st = _lib.stream_ptr()
+        _lib.check(lib.aa_eps_greedy_action(
+            q.data_ptr(), None if mask is None else mask.data_ptr(), B, self._num_actions,
+            float(epsilon), None, self._seed, self._call_counter.data_ptr(), self._lo,
+            out.data_ptr(), 1 if self._spec.dtype == torch.int64 else 0, st),
+            "aa_eps_greedy_action")
+        if epsilon > 0:
+            _lib.check(lib.aa_counter_add(self._call_counter.data_ptr(), 1, st),
+                       "aa_counter_add")
+        return out
+
+    def _action(self, time_step, policy_state, seed):
+        obs = time_step.observation
+        mask = None
+        if self._observation_and_action_constraint_splitter is not None:
+            obs, mask = self._observation_and_action_constraint_splitter(obs)
+        batched = time_step.step_type.dim() > 0
+        if not batched:
+            obs = nest_utils.map_structure(lambda t: t.unsqueeze(0), obs)
+            mask = None if mask is None else mask.unsqueeze(0)
+        B = nest_utils.flatten(obs)[0].shape[0]
+        dev = nest_utils.flatten(obs)[0].device
+        with torch.cuda.device(dev):
+            q = self._q_values(obs, B, dev)
+            actions = self.select(q, mask, self._get_epsilon())
+        if not batched:
+            actions = actions.squeeze(0)
+        return policy_step.PolicyStep(actions, policy_state, ())
+
+
+class QPolicy(_DiscretePolicy):
+    """Greedy-capable Q policy; `action()` here samples the arg-max (the reference's QPolicy
+    samples Categorical(logits=Q); agents only use it wrapped in Greedy / EpsilonGreedy)."""
+
+    def __init__(self, time_step_spec, action_spec, q_network, emit_log_probability=False,
+                 observation_and_action_constraint_splitter=None, validate_action_spec=True,
+                 name=None, seed=0):
+        if validate_action_spec:
+            _, lo, _ = _action_bounds(action_spec)
+        super().__init__(time_step_spec, action_spec, q_network=q_network, epsilon=0.0, seed=seed,
+                         observation_and_action_constraint_splitter=
+                         observation_and_action_constraint_splitter,
+                         emit_log_probability=emit_log_probability, name=name)
+
+
+class GreedyPolicy(_DiscretePolicy):
+    def __init__(self, policy, name=None):
+        super().__init__(policy.time_step_spec, policy.action_spec, q_network=policy.q_network,
+                         epsilon=0.0, seed=policy._seed,
+                         observation_and_action_constraint_splitter=
+                         policy.observation_and_action_constraint_splitter, name=name)
+        self._wrapped_policy = policy
+        self._slot = "greedy"
+
+    @property
+    def wrapped_policy(self):
+        return self._wrapped_policy
+
+
+class EpsilonGreedyPolicy(_DiscretePolicy):
+    def __init__(self, policy, epsilon, exploration_mask=None, info_fields_to_inherit_from_greedy=
+                 (), name=None, seed=None):
+        if exploration_mask is not None:
+            raise NotImplementedError("exploration_mask is outside the hot-path scope")
+        super().__init__(policy.time_step_spec, policy.action_spec, q_network=policy.q_network,
+                         epsilon=epsilon, seed=policy._seed if seed is None else seed,
+                         observation_and_action_constraint_splitter=
+                         policy.observation_and_action_constraint_splitter, name=name)
+        self._greedy_policy = GreedyPolicy(policy)
+        self._slot = "collect"
+
+    @property
+    def wrapped_policy(self):
+        return self._greedy_policy.wrapped_policy
+
+
+class RandomTFPolicy(_DiscretePolicy):
+    """Uniform random discrete actions (respecting the action mask)."""
+
+    def __init__(self, time_step_spec, action_spec, *args, **kwargs):
+        splitter = kwargs.pop("observation_and_action_constraint_splitter", None)
+        seed = kwargs.pop("seed", 12345)
+        super().__init__(time_step_spec, action_spec, q_network=None, epsilon=1.0, seed=seed,
+                         observation_and_action_constraint_splitter=splitter,
+                         name=kwargs.get("name"))

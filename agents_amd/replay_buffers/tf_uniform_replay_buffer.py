@@ -1,0 +1,300 @@
+"""TFUniformReplayBuffer on MI355X: batched adds and uniform sampling, tables resident in HBM.
+
+Drop-in for tf_agents/replay_buffers/tf_uniform_replay_buffer.py:47-635 -- same constructor,
+methods, layout (B blocks of L frames, one shared `last_id`), valid-id ranges, BufferInfo -- with
+every data-path operation a HIP kernel from csrc/replay.hip:
+
+  add_batch   -> aa_rb_scatter_rows   (all leaves + id table in one launch, then last_id += 1)
+  get_next    -> aa_rb_sample_rows    (Philox4x32-10 ids/blocks -> rows, probabilities)
+                 aa_rb_gather_rows    (all leaves + ids in one launch)
+  gather_all  -> aa_rb_range_rows + aa_rb_gather_rows
+
+Ordering: every op is enqueued on the current HIP stream, which replaces the reference's
+tf.CriticalSection on `last_id` (:154,582-601).  `last_id` lives in device memory (graph-capture
+friendly) with a host mirror that lets the emptiness check raise without a device sync.
+Differences from the reference are listed in DESIGN.md (own documented random stream; `device`
+names a torch/HIP device).
+"""
+import collections
+
+import numpy as np
+import torch
+
+from agents_amd import _lib
+from agents_amd.replay_buffers import replay_buffer, table
+from agents_amd.replay_buffers.dataset import Dataset
+from agents_amd.specs import tensor_spec
+from agents_amd.utils import nest_utils
+
+BufferInfo = collections.namedtuple("BufferInfo", ["ids", "probabilities"])
+
+_EMPTY_SAMPLE = ("TFUniformReplayBuffer is empty. Make sure to add items before sampling the "
+                 "buffer.")
+_EMPTY_DATASET = ("TFUniformReplayBuffer is empty. Make sure to add items before asking the "
+                  "buffer for data.")
+
+
+def _valid_range_ids(last_id, max_length, num_steps=None):
+    """[min_id, max_id) of valid start ids; host mirror of the kernel's range logic (:610-635)."""
+    if num_steps is None:
+        num_steps = 1
+    if last_id < max_length:
+        return 0, max(last_id + 1 - num_steps + 1, 0)
+    return last_id + 1 - max_length, last_id + 1 - num_steps + 1
+
+
+def _resolve_device(device):
+    if device is None or (isinstance(device, str) and device in ("", "gpu:*", "GPU:*")):
+        return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() \
+            else torch.device("cuda")
+    if isinstance(device, str) and device.lower().startswith(("gpu:", "/gpu:", "/device:gpu:")):
+        idx = device.split(":")[-1]
+        return torch.device("cuda", int(idx)) if idx.isdigit() else torch.device("cuda")
+    d = torch.device(device) if not isinstance(device, torch.device) else device
+    return d
+
+
+class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
+    """A TFUniformReplayBuffer with batched adds and uniform sampling."""
+
+    def __init__(self, data_spec, batch_size, max_length=1000, scope="TFUniformReplayBuffer",
+                 device=None, table_fn=table.Table, dataset_drop_remainder=False,
+                 dataset_window_shift=None, stateful_dataset=False, seed=0):
+        self._batch_size = int(batch_size)
+        self._max_length = int(max_length)
+        capacity = self._batch_size * self._max_length
+        super().__init__(data_spec, capacity, stateful_dataset)
+        self._scope = scope
+        self._device = _resolve_device(device)
+        if self._device.type != "cuda":
+            raise _lib.AgentsAmdError(
+                f"TFUniformReplayBuffer tables live in GPU memory; device={device!r} is not a "
+                "HIP device (there is no CPU path).")
+        self._table_fn = table_fn
+        self._dataset_drop_remainder = dataset_drop_remainder
+        self._dataset_window_shift = dataset_window_shift
+        self._id_spec = tensor_spec.TensorSpec((), torch.int64, name="id")
+        self._data_table = table_fn(self._data_spec, capacity, device=self._device)
+        self._id_table = table_fn(self._id_spec, capacity, device=self._device)
+        self._last_id = torch.full((1,), -1, dtype=torch.int64, device=self._device)
+        self._err_flag = torch.zeros((1,), dtype=torch.int32, device=self._device)
+        self._last_id_host = -1          # mirror: every add_batch is +1, clear() is -> -1
+        self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._sample_calls = 0           # Philox call counter (one per get_next)
+
+    # ---- properties ------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def table_fn(self):
+        return self._table_fn
+
+    @property
+    def scope(self):
+        return self._scope
+
+    @property
+    def batch_size(self):
+        return self._batch_size
+
+    @property
+    def max_length(self):
+        return self._max_length
+
+    def variables(self):
+        return self._data_table.variables() + self._id_table.variables() + [self._last_id]
+
+    # ---- ReplayBuffer implementation ----------------------------------------------------------
+    def _num_frames(self):
+        return min((self._last_id_host + 1) * self._batch_size, self._capacity)
+
+    def _add_batch(self, items):
+        """Writes one frame per env block (:182-209)."""
+        lib = _lib.load()
+        flat = self._data_table.check_values(items, self._batch_size)
+        p = self._data_table.pack(flat)
+        with torch.cuda.device(self._device):
+            _lib.check(lib.aa_rb_scatter_rows(
+                p.tables, p.ios, p.row_bytes, p.n, self._id_table.variables()[0].data_ptr(),
+                self._last_id.data_ptr(), self._batch_size, self._max_length, _lib.stream_ptr()),
+                "aa_rb_scatter_rows")
+        self._last_id_host += 1
+
+    def _sample_rows(self, S, T):
+        lib = _lib.load()
+        rows = torch.empty((S, T), dtype=torch.int64, device=self._device)
+        probs = torch.empty((S,), dtype=torch.float32, device=self._device)
+        _lib.check(lib.aa_rb_sample_rows(
+            self._last_id.data_ptr(), self._batch_size, self._max_length, S, T, self._seed,
+            self._sample_calls, rows.data_ptr(), probs.data_ptr(), self._err_flag.data_ptr(),
+            _lib.stream_ptr()), "aa_rb_sample_rows")
+        self._sample_calls += 1
+        return rows, probs
+
+    def _get_next(self, sample_batch_size=None, num_steps=None, time_stacked=True):
+        """Uniformly sampled items (:211-310).  Returns (data, BufferInfo(ids, probabilities))."""
+        lo, hi = _valid_range_ids(self._last_id_host, self._max_length, num_steps)
+        if hi <= lo:
+            raise RuntimeError(_EMPTY_SAMPLE)
+        S = 1 if sample_batch_size is None else int(sample_batch_size)
+        T = 1 if num_steps is None else int(num_steps)
+        with torch.cuda.device(self._device):
+            rows, probs = self._sample_rows(S, T)
+            ids = torch.empty((S, T), dtype=torch.int64, device=self._device)
+            data = self._data_table.read(rows, self._id_table.variables()[0], ids)
+
+        def squeeze(t):
+            if num_steps is None:
+                t = t.squeeze(1)
+            if sample_batch_size is None:
+                t = t.squeeze(0)
+            return t
+
+        if num_steps is not None and not time_stacked:
+            # a T-tuple of [S, ...] items instead of [S, T, ...] (:295-306)
+            def unstack(t, i):
+                u = t[:, i]
+                return u.squeeze(0) if sample_batch_size is None else u
+            data = tuple(nest_utils.map_structure(lambda t, i=i: unstack(t, i), data)
+                         for i in range(T))
+            ids_out = tuple(unstack(ids, i) for i in range(T))
+        else:
+            data = nest_utils.map_structure(squeeze, data)
+            ids_out = squeeze(ids)
+        if sample_batch_size is None:
+            probs = probs.squeeze(0)
+        return data, BufferInfo(ids=ids_out, probabilities=probs)
+
+    def as_dataset(self, sample_batch_size=None, num_steps=None, num_parallel_calls=None,
+                   single_deterministic_pass=False):
+        return super().as_dataset(sample_batch_size, num_steps, num_parallel_calls,
+                                  single_deterministic_pass=single_deterministic_pass)
+
+    def _as_dataset(self, sample_batch_size=None, num_steps=None, sequence_preprocess_fn=None,
+                    num_parallel_calls=None):
+        """Infinite stream of get_next (:329-367).  num_parallel_calls is accepted and ignored:
+        sampling kernels are already asynchronous on the stream."""
+        if sequence_preprocess_fn is not None:
+            raise NotImplementedError("sequence_preprocess_fn is not supported.")
+
+        def gen():
+            while True:
+                yield self.get_next(sample_batch_size, num_steps, time_stacked=True)
+
+        return Dataset(gen, infinite=True)
+
+    def _single_deterministic_pass_dataset(self, sample_batch_size=None, num_steps=None,
+                                           sequence_preprocess_fn=None, num_parallel_calls=None):
+        """Fixed-order pass (:369-531); index order computed on the host, rows gathered on device."""
+        if sequence_preprocess_fn is not None:
+            raise NotImplementedError("sequence_preprocess_fn is not supported.")
+        drop = self._dataset_drop_remainder
+        if drop and sample_batch_size is not None and sample_batch_size > self._batch_size:
+            raise ValueError(
+                "sample_batch_size ({}) > self.batch_size ({}) and dataset_drop_remainder is "
+                "True.  In this case, ALL data will be dropped by the deterministic dataset."
+                .format(sample_batch_size, self._batch_size))
+        if drop and num_steps is not None and num_steps > self._max_length:
+            raise ValueError(
+                "num_steps_size ({}) > self.max_length ({}) and dataset_drop_remainder is "
+                "True.  In this case, ALL data will be dropped by the deterministic dataset."
+                .format(num_steps, self._max_length))
+
+        def gen():
+            for ids in deterministic_pass_ids(self._last_id_host, self._batch_size,
+                                              self._max_length, sample_batch_size, num_steps,
+                                              drop, self._dataset_window_shift):
+                ids_np = np.asarray(ids, dtype=np.int64)
+                ids_t = torch.as_tensor(ids_np, device=self._device)
+                rows = torch.as_tensor(np.mod(ids_np, self._capacity), device=self._device)
+                with torch.cuda.device(self._device):
+                    data = self._data_table.read(rows)
+                yield data, BufferInfo(ids=ids_t, probabilities=())
+
+        return Dataset(gen, infinite=False)
+
+    def _gather_all(self):
+        """All valid items, shape [batch_size, n, ...] in id order (:533-557)."""
+        lib = _lib.load()
+        lo, hi = _valid_range_ids(self._last_id_host, self._max_length)
+        n = hi - lo
+        rows = torch.empty((self._batch_size, max(n, 0)), dtype=torch.int64, device=self._device)
+        with torch.cuda.device(self._device):
+            if n > 0:
+                _lib.check(lib.aa_rb_range_rows(lo, n, self._batch_size, self._max_length,
+                                                rows.data_ptr(), _lib.stream_ptr()),
+                           "aa_rb_range_rows")
+            return self._data_table.read(rows)
+
+    def _clear(self, clear_all_variables=False):
+        """last_id = -1; tables untouched unless clear_all_variables (:559-579)."""
+        self._last_id.fill_(-1)
+        self._last_id_host = -1
+        if clear_all_variables:
+            for v in self._data_table.variables() + self._id_table.variables():
+                v.zero_()
+
+    def clear(self, clear_all_variables=False):
+        return self._clear(clear_all_variables)
+
+    # ---- helpers used by tests / checkpointing ------------------------------------------------
+    def _get_last_id(self):
+        return self._last_id_host
+
+    def state_dict(self):
+        return {"tables": [v.clone() for v in self._data_table.variables()],
+                "ids": self._id_table.variables()[0].clone(), "last_id": self._last_id_host,
+                "sample_calls": self._sample_calls, "seed": self._seed}
+
+    def load_state_dict(self, sd):
+        for v, s in zip(self._data_table.variables(), sd["tables"]):
+            v.copy_(s)
+        self._id_table.variables()[0].copy_(sd["ids"])
+        self._last_id_host = int(sd["last_id"])
+        self._last_id.fill_(self._last_id_host)
+        self._sample_calls = int(sd["sample_calls"])
+        self._seed = int(sd["seed"])
+
+
+def _windows(seq, size, shift, drop_remainder):
+    """tf.data `window(size, shift).flat_map(batch(size, drop_remainder))` over a python list."""
+    shift = size if shift is None else shift
+    out, i, n = [], 0, len(seq)
+    while i < n:
+        w = seq[i:i + size]
+        if len(w) == size or not drop_remainder:
+            out.append(w)
+        i += shift
+    return out
+
+
+def deterministic_pass_ids(last_id, batch_size, max_length, sample_batch_size, num_steps,
+                           drop_remainder, window_shift):
+    """Index order of the fixed-order dataset (:433-511): env-major frames when unbatched;
+    blocks of `sample_batch_size` envs, frame-major inside a block, windows transposed to
+    [S, num_steps] (remainder windows always dropped) when batched."""
+    lo, hi = _valid_range_ids(last_id, max_length, None)
+    if hi <= lo:
+        raise RuntimeError(_EMPTY_DATASET)
+    frames = list(range(lo, hi))
+    if sample_batch_size is None:
+        for b in range(batch_size):
+            ids = [b * max_length + f for f in frames]
+            if num_steps is None:
+                for i in ids:
+                    yield np.int64(i)
+            else:
+                for w in _windows(ids, num_steps, window_shift, drop_remainder):
+                    yield np.asarray(w, dtype=np.int64)
+        return
+    for envs in _windows(list(range(batch_size)), sample_batch_size, None, drop_remainder):
+        per_frame = [np.asarray([f + e * max_length for e in envs], dtype=np.int64)
+                     for f in frames]
+        if num_steps is None:
+            for v in per_frame:
+                yield v
+        else:
+            for w in _windows(per_frame, num_steps, window_shift, True):
+                yield np.stack(w, axis=0).T

@@ -1,0 +1,114 @@
+"""Learner: runs `agent.train` on batches from an experience dataset, data-parallel across GPUs.
+
+Mirrors tf_agents/train/learner.py:42-467:
+  __init__   :58-243   dataset via experience_dataset_fn, agent.initialize(), triggers
+  run        :265-305  `iterations` train steps, then triggers; returns the reduced LossInfo
+  _train / single_train_step :309-378   sample = next(iterator); strategy.run(agent.train)
+  loss       :380-467
+Data parallelism: each rank owns a replay shard and samples it independently; the
+per-replica loss is divided by B_local * num_replicas (tf.nn.compute_average_loss,
+utils/common.py:1462-1467) and the flat gradient buffer is SUM all-reduced once per step through
+`agent.gradient_hook`; every rank then applies the identical optimizer step, so replicas stay in
+lock-step without any weight broadcast.  LossInfo fields are SUM-reduced over replicas and over
+all axes like strategy.reduce(SUM) (:322-337).
+"""
+import os
+
+import torch
+
+from agents_amd.agents import tf_agent
+from agents_amd.train.utils import strategy_utils
+from agents_amd.utils import nest_utils
+
+TRAIN_DIR = "train"
+POLICY_SAVED_MODEL_DIR = "policies"
+
+
+class Learner:
+    def __init__(self, root_dir, train_step, agent, experience_dataset_fn=None,
+                 after_train_strategy_step_fn=None, triggers=None, checkpoint_interval=100000,
+                 summary_interval=1000, max_checkpoints_to_keep=3, use_kwargs_in_agent_train=False,
+                 strategy=None, run_optimizer_variable_init=True, use_reverb_v2=False,
+                 direct_sampling=False, experience_dataset_options=None,
+                 strategy_run_options=None, summary_root_dir=None):
+        if checkpoint_interval < 0:
+            raise ValueError("checkpoint_interval must be non-negative")
+        self._root_dir = root_dir
+        self._train_dir = os.path.join(root_dir, TRAIN_DIR) if root_dir else None
+        self.train_step = train_step
+        self._agent = agent
+        self.use_kwargs_in_agent_train = use_kwargs_in_agent_train
+        self.strategy = strategy or strategy_utils.get_strategy()
+        self._after_train_strategy_step_fn = after_train_strategy_step_fn
+        self.triggers = triggers or []
+        self._checkpoint_interval = checkpoint_interval
+        self._max_checkpoints_to_keep = max_checkpoints_to_keep
+        self._experience_dataset_fn = experience_dataset_fn
+        self._experience_iterator = None
+        if experience_dataset_fn is not None:
+            self._experience_iterator = iter(experience_dataset_fn())
+        # data-parallel wiring (the agent divides its loss by B_local * num_replicas)
+        self._agent.num_replicas = self.strategy.num_replicas_in_sync
+        if self.strategy.num_replicas_in_sync > 1:
+            self._agent.gradient_hook = self.strategy.all_reduce_sum_
+        self._agent.initialize()
+        self._last_checkpoint_step = int(self.train_step) if self.train_step is not None else 0
+
+    @property
+    def train_step_numpy(self):
+        return int(self.train_step)
+
+    def _reduce_loss(self, loss_info):
+        """SUM over replicas and over all axes of every LossInfo field (learner.py:322-337)."""
+        def red(t):
+            if not isinstance(t, torch.Tensor):
+                return t
+            s = t.sum() if t.dim() > 0 else t
+            return self.strategy.reduce_sum(s.reshape(1)).reshape(())
+        return nest_utils.map_structure(red, loss_info)
+
+    def single_train_step(self, iterator):
+        sample = next(iterator)
+        if isinstance(sample, tuple) and len(sample) == 2 and not hasattr(sample, "_fields"):
+            experience, sample_info = sample
+        else:
+            experience, sample_info = sample, None
+        if self.use_kwargs_in_agent_train:
+            loss_info = self._agent.train(**experience)
+        else:
+            loss_info = self._agent.train(experience)
+        if self._after_train_strategy_step_fn:
+            self._after_train_strategy_step_fn((experience, sample_info), loss_info)
+        return loss_info
+
+    def run(self, iterations=1, iterator=None, parallel_iterations=10):
+        """`iterations` train steps; returns the replica-summed LossInfo of the last one."""
+        if iterations < 1:
+            raise AssertionError("Iterations must be greater or equal to 1, was %d" % iterations)
+        iterator = iterator or self._experience_iterator
+        if iterator is None:
+            raise ValueError("Learner.run needs an iterator or an experience_dataset_fn")
+        loss_info = None
+        for _ in range(iterations):
+            loss_info = self.single_train_step(iterator)
+        if self.train_step is not None and self.train_step is not self._agent.train_step_counter:
+            self.train_step.assign(int(self._agent.train_step_counter))
+        reduced = self._reduce_loss(loss_info)
+        step = int(self._agent.train_step_counter)
+        for trigger in self.triggers:
+            trigger(step)
+        return reduced
+
+    def loss(self, experience_and_sample_info=None, reduce_op="sum"):
+        """agent.loss on one batch (no update), replica-reduced (learner.py:380-467)."""
+        if experience_and_sample_info is None:
+            experience_and_sample_info = next(self._experience_iterator)
+        if isinstance(experience_and_sample_info, tuple) and \
+                not hasattr(experience_and_sample_info, "_fields"):
+            experience = experience_and_sample_info[0]
+        else:
+            experience = experience_and_sample_info
+        loss_info = self._agent.loss(experience)
+        if not isinstance(loss_info, tf_agent.LossInfo):
+            raise TypeError("agent.loss must return a LossInfo")
+        return self._reduce_loss(loss_info)

@@ -1,0 +1,59 @@
+"""Data-parallel "strategy" over torch.distributed (RCCL on MI355X, gloo in CPU tests).
+
+Stands in for tf.distribute.MirroredStrategy as used by tf_agents/train/learner.py:170-177,
+356-360 and tf_agents/train/utils/strategy_utils.py:27-61: one PROCESS per GPU (torchrun), each
+with a full replica of the parameters and its own replay shard; the only exchange per train step is
+ONE sum all-reduce of the flat fp32 gradient buffer (the reference's implicit gradient all-reduce
+inside optimizer.apply_gradients under strategy.run), plus a sum of the LossInfo scalars
+(learner.py:322-337).
+"""
+import torch
+import torch.distributed as dist
+
+
+class Strategy:
+    """Single-replica default (tf.distribute.get_strategy())."""
+
+    num_replicas_in_sync = 1
+    rank = 0
+
+    def all_reduce_sum_(self, tensor):
+        return tensor
+
+    def reduce_sum(self, tensor):
+        return tensor
+
+    def barrier(self):
+        pass
+
+
+class DataParallelStrategy(Strategy):
+    """All ranks of the default torch.distributed process group."""
+
+    def __init__(self, process_group=None):
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised; launch with "
+                               "`python -m torch.distributed.run` and call init_process_group")
+        self._pg = process_group
+        self.num_replicas_in_sync = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+
+    def all_reduce_sum_(self, tensor):
+        """In-place SUM all-reduce (ncclAllReduce over xGMI on GPUs)."""
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self._pg)
+        return tensor
+
+    def reduce_sum(self, tensor):
+        out = tensor.clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self._pg)
+        return out
+
+    def barrier(self):
+        dist.barrier(group=self._pg)
+
+
+def get_strategy(tpu=None, use_gpu=True):
+    """strategy_utils.get_strategy: data-parallel if a process group exists, else single."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return DataParallelStrategy()
+    return Strategy()

@@ -58,6 +58,12 @@ int aa_rb_gather_rows(const void* const* leaf_tables_h, void* const* leaf_out_h,
                       const int64_t* leaf_row_bytes_h, int n_leaves, const int64_t* id_table,
                       int64_t* ids_out, const int64_t* rows, int64_t n_rows, void* stream);
 
+/* Table.write with explicit rows: table[rows[r]] = values[r] for every leaf (table.py:112-137).
+ * Rows must be distinct. */
+int aa_rb_write_rows(void* const* leaf_tables_h, const void* const* leaf_values_h,
+                     const int64_t* leaf_row_bytes_h, int n_leaves, const int64_t* rows,
+                     int64_t n_rows, void* stream);
+
 /* rows[b, i] = (start_id + i) mod L + b*L for gather_all (tf_uniform_replay_buffer.py:533-557). */
 int aa_rb_range_rows(int64_t start_id, int64_t n_ids, int64_t batch, int64_t max_len,
                      int64_t* rows_out, void* stream);
@@ -88,6 +94,7 @@ typedef struct aa_gemm_desc {
   int32_t a_mode, b_mode;
   /* conv geometry for AA_A_PATCH*: NHWC input [n_img,H,W,Cin], VALID padding */
   int32_t n_img, H, W, Cin, KH, KW, stride;
+  int32_t img_pitch;      /* elements between consecutive images; 0 = H*W*Cin (dense) */
   float a_div;            /* uint8 inputs: divisor (255 for the Atari Lambda(x/255) layer) */
   /* epilogue: C = act(acc + bias[n]) * actgrad_{mask_kind}(mask_src[m*ldm + n]) */
   const float* bias;      /* nullable */
@@ -106,6 +113,12 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
 int64_t aa_colsum_workspace_bytes(int64_t M, int64_t N);
 int aa_colsum_f32(const float* x, int64_t ld, int64_t M, int64_t N, float* out, void* workspace,
                   int64_t workspace_bytes, void* stream);
+
+/* dz = dy * act'(y): gradient through a trailing activation given its output y. */
+int aa_act_backward(const float* dy, const float* y, int32_t act, int64_t n, float* dz,
+                    void* stream);
+/* out[0] = sum x^2 (keras l2 regulariser, tf.nn.l2_loss). */
+int aa_sumsq_f32(const float* x, int64_t n, float* out, void* stream);
 
 /* dX[b,iy,ix,c] = sum over patches containing (iy,ix) of dcol[pixel][(ky*KW+kx)*Cin + c], times
  * actgrad(mask_src) -- the input gradient of a VALID Conv2D from its column gradient. */
@@ -129,7 +142,9 @@ int aa_dqn_td_loss(const float* q_online, const float* q_next_target,
                    const void* actions, int32_t actions_are_i64, int64_t action_stride,
                    const float* reward, const float* discount, const int32_t* step_type,
                    const float* weights /* nullable [B] */, int64_t B, int32_t T, int32_t A,
-                   float gamma, float reward_scale, int32_t loss_kind, float global_batch,
+                   double gamma /* n-step accumulation (agent gamma; python-float semantics) */,
+                   double gamma_loss /* DqnAgent._loss(gamma=...) applied to the final discount */,
+                   double reward_scale, int32_t loss_kind, float global_batch,
                    float* loss_out, float* td_loss_out, float* td_error_out, float* dq_out,
                    void* stream);
 
@@ -166,6 +181,11 @@ int aa_eps_greedy_action(const float* q, const int32_t* mask /* nullable [B,A] *
                          int32_t A, float epsilon, const float* epsilon_dev /* nullable */,
                          uint64_t seed, const int64_t* call_counter_dev, int64_t action_min,
                          void* actions_out, int32_t actions_are_i64, void* stream);
+
+/* DynamicStepDriver loop counter: counter[b] += (step_type[b] != LAST); *total_dev += the sum
+ * (drivers/dynamic_step_driver.py:113,170).  counter_dev nullable. */
+int aa_count_steps(const int32_t* step_type, int64_t B, int32_t* counter_dev, int64_t* total_dev,
+                   void* stream);
 
 #define AA_OBS_U8 0
 #define AA_OBS_F32 1

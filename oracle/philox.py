@@ -1,0 +1,40 @@
+"""Philox4x32-10 in numpy (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as
+1, 2, 3", SC'11).  Restates agents_amd/csrc/common.h::philox4x32_10 and is itself pinned to the
+published Random123 known-answer vectors (tests/test_oracle_philox.py).
+
+The reference draws replay indices with tf.random.uniform(int64)
+(tf_agents/replay_buffers/tf_uniform_replay_buffer.py:265-272), an unseeded TensorFlow-internal
+Philox stream that no reference test pins; this module defines the canonical stream instead.
+"""
+import numpy as np
+
+M0 = np.uint64(0xD2511F53)
+M1 = np.uint64(0xCD9E8D57)
+W0 = 0x9E3779B9
+W1 = 0xBB67AE85
+MASK = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised over broadcastable integer arrays.  Returns 4 uint32 arrays."""
+    c0, c1, c2, c3 = np.broadcast_arrays(*[np.asarray(c, dtype=np.uint64) & MASK
+                                           for c in (c0, c1, c2, c3)])
+    k0 = int(k0) & 0xFFFFFFFF
+    k1 = int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = M0 * c0
+        p1 = M1 * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & MASK
+        hi1, lo1 = p1 >> np.uint64(32), p1 & MASK
+        n0 = hi1 ^ c1 ^ np.uint64(k0)
+        n2 = hi0 ^ c3 ^ np.uint64(k1)
+        c0, c1, c2, c3 = n0, lo1, n2, lo0
+        k0 = (k0 + W0) & 0xFFFFFFFF
+        k1 = (k1 + W1) & 0xFFFFFFFF
+    return tuple(c.astype(np.uint32) for c in (c0, c1, c2, c3))
+
+
+def u01(bits):
+    """Top 24 bits * 2^-24, as float32 (agents_amd/csrc/common.h::aa_u01)."""
+    return ((np.asarray(bits, dtype=np.uint32) >> np.uint32(8)).astype(np.float32) *
+            np.float32(1.0 / 16777216.0))

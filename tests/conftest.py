@@ -1,0 +1,30 @@
+"""pytest configuration: `-m gpu` tests need an MI355X; everything else runs on CPU."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a HIP device (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def lib():
+    """The built C-ABI library (built in-tree if missing; hipcc cross-compiles without a GPU)."""
+    from agents_amd import _build, _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _build.build(verbose=False)
+    return _lib.load()
+
+
+@pytest.fixture(scope="session")
+def dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    return torch.device("cuda", 0)

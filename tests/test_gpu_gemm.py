@@ -1,0 +1,195 @@
+"""GPU parity of the fp32 MFMA GEMM family (csrc/gemm.hip) against a plain torch fp32/fp64 CPU
+reference of the same op.  Tolerance: |err| <= 2e-5 * max|ref| (fp32 accumulation-order noise;
+north star: 1e-5 relative on losses).  Covers every loader mode, every tile config, split-K,
+ragged edges, unaligned (scalar-path) operands, strided batches and the fused epilogues."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from agents_amd import ops
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def close(got, ref, tol=TOL):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape
+    scale = max(ref.abs().max().item(), 1e-30)
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.3e})"
+
+
+def rnd(rng, *shape):
+    return torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+
+
+def act_ref(x, act):
+    return {None: x, "relu": torch.relu(x), "tanh": torch.tanh(x)}[act]
+
+
+def actgrad_ref(y, act):
+    return {None: torch.ones_like(y), "relu": (y > 0).to(y.dtype), "tanh": 1 - y * y}[act]
+
+
+SHAPES = [(256, 512, 3136), (256, 6, 512), (64, 100, 4), (1, 2, 100), (37, 45, 53),
+          (300, 33, 64), (256, 64, 17), (128, 128, 32), (2048, 64, 64), (5, 7, 3)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("act", [None, "relu", "tanh"])
+def test_dense_forward(dev, M, N, K, act):
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    x, w, b = rnd(rng, M, K), rnd(rng, K, N) * 0.1, rnd(rng, N)
+    out = torch.empty(M, N, device=dev)
+    ops.dense_forward(x.to(dev), w.to(dev), b.to(dev), act, out)
+    close(out, act_ref(x.double() @ w.double() + b.double(), act))
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("splits", [1, 3])
+def test_dense_forward_forced_configs(dev, cfg, splits):
+    rng = np.random.default_rng(cfg * 10 + splits)
+    M, N, K = 200, 70, 300
+    x, w, b = rnd(rng, M, K), rnd(rng, K, N) * 0.1, rnd(rng, N)
+    out = torch.empty(M, N, device=dev)
+    ops.dense_forward(x.to(dev), w.to(dev), b.to(dev), "relu", out, force_cfg=cfg,
+                      force_splits=splits)
+    close(out, torch.relu(x.double() @ w.double() + b.double()))
+
+
+def test_dense_forward_strided_rows(dev):
+    """A operand = experience.observation[:, 0] of a [B, T, K] tensor (row pitch T*K)."""
+    rng = np.random.default_rng(5)
+    B, T, K, N = 64, 2, 4, 100
+    x3 = rnd(rng, B, T, K).to(dev)
+    w, b = rnd(rng, K, N), rnd(rng, N)
+    out = torch.empty(B, N, device=dev)
+    ops.dense_forward(x3[:, 1], w.to(dev), b.to(dev), None, out)
+    close(out, x3[:, 1].cpu().double() @ w.double() + b.double())
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_dense_dw(dev, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    x, dz = rnd(rng, M, K), rnd(rng, M, N)
+    out = torch.empty(K, N, device=dev)
+    ops.dense_dw(x.to(dev), dz.to(dev), out)
+    close(out, x.double().T @ dz.double())
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("mask_act", [None, "relu", "tanh"])
+def test_dense_dx(dev, M, N, K, mask_act):
+    rng = np.random.default_rng(M * 3 + N + K * 5)
+    dz, w = rnd(rng, M, N), rnd(rng, K, N) * 0.1
+    y = torch.tanh(rnd(rng, M, K))
+    out = torch.empty(M, K, device=dev)
+    ops.dense_dx(dz.to(dev), w.to(dev), out, mask_src=y.to(dev) if mask_act else None,
+                 mask_act=mask_act)
+    close(out, (dz.double() @ w.double().T) * actgrad_ref(y.double(), mask_act))
+
+
+CONVS = [  # (B, H, W, C, KH, KW, stride, F, dtype)
+    (4, 84, 84, 4, 8, 8, 4, 32, torch.uint8),      # Atari conv1
+    (3, 20, 20, 32, 4, 4, 2, 64, torch.float32),   # Atari conv2
+    (5, 9, 9, 64, 3, 3, 1, 64, torch.float32),     # Atari conv3
+    (2, 12, 10, 8, 3, 2, 1, 20, torch.float32),    # ragged N, rectangular kernel
+    (2, 36, 36, 4, 8, 8, 4, 32, torch.uint8),
+    (7, 11, 11, 4, 5, 5, 2, 16, torch.float32),
+]
+
+
+def conv_ref(x, w, b, stride, div):
+    xf = x.double() / div if x.dtype == torch.uint8 else x.double()
+    y = F.conv2d(xf.permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), b.double(),
+                 stride=stride)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def make_conv(rng, cfg):
+    B, H, W, C, KH, KW, s, Fo, dt = cfg
+    if dt == torch.uint8:
+        x = torch.from_numpy(rng.integers(0, 256, size=(B, H, W, C), dtype=np.uint8))
+    else:
+        x = rnd(rng, B, H, W, C)
+    w = rnd(rng, KH, KW, C, Fo) * 0.1
+    b = rnd(rng, Fo)
+    return x, w, b
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_forward(dev, cfg):
+    rng = np.random.default_rng(sum(cfg[:8]))
+    x, w, b = make_conv(rng, cfg)
+    B, H, W, C, KH, KW, s, Fo, dt = cfg
+    OH, OW = ops.conv_out_hw(H, W, KH, KW, s)
+    out = torch.empty(B, OH, OW, Fo, device=dev)
+    ops.conv_forward(x.to(dev), w.to(dev), b.to(dev), s, "relu", out, a_div=255.0)
+    close(out, torch.relu(conv_ref(x, w, b, s, 255.0)))
+
+
+def test_conv_forward_strided_batch(dev):
+    """x = observation[:, 1] of a [B, T, H, W, C] replay sample (image pitch T*H*W*C)."""
+    rng = np.random.default_rng(11)
+    x5 = torch.from_numpy(rng.integers(0, 256, size=(6, 2, 84, 84, 4), dtype=np.uint8)).to(dev)
+    w, b = rnd(rng, 8, 8, 4, 32) * 0.1, rnd(rng, 32)
+    out = torch.empty(6, 20, 20, 32, device=dev)
+    ops.conv_forward(x5[:, 1], w.to(dev), b.to(dev), 4, None, out, a_div=255.0)
+    close(out, conv_ref(x5[:, 1].cpu(), w, b, 4, 255.0))
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_dw(dev, cfg):
+    rng = np.random.default_rng(sum(cfg[:8]) + 1)
+    x, w, b = make_conv(rng, cfg)
+    B, H, W, C, KH, KW, s, Fo, dt = cfg
+    OH, OW = ops.conv_out_hw(H, W, KH, KW, s)
+    dz = rnd(rng, B, OH, OW, Fo)
+    out = torch.empty(KH, KW, C, Fo, device=dev)
+    ops.conv_dw(x.to(dev), dz.to(dev).view(-1, Fo), (KH, KW, C, Fo), s, out, a_div=255.0)
+    xf = (x.double() / 255.0 if dt == torch.uint8 else x.double()).requires_grad_(False)
+    wd = w.double().requires_grad_(True)
+    y = F.conv2d(xf.permute(0, 3, 1, 2), wd.permute(3, 2, 0, 1), None, stride=s)
+    g, = torch.autograd.grad(y, wd, dz.double().permute(0, 3, 1, 2))
+    close(out, g)
+
+
+@pytest.mark.parametrize("cfg", [c for c in CONVS if c[8] == torch.float32])
+@pytest.mark.parametrize("mask_act", [None, "relu"])
+def test_conv_dx(dev, cfg, mask_act):
+    rng = np.random.default_rng(sum(cfg[:8]) + 2)
+    x, w, b = make_conv(rng, cfg)
+    B, H, W, C, KH, KW, s, Fo, dt = cfg
+    OH, OW = ops.conv_out_hw(H, W, KH, KW, s)
+    dz = rnd(rng, B, OH, OW, Fo)
+    dcol = torch.empty(B * OH * OW * KH * KW * C, device=dev)
+    out = torch.empty(B, H, W, C, device=dev)
+    ops.conv_dx(dz.to(dev).view(-1, Fo), w.to(dev), (B, H, W, C), s, dcol, out,
+                mask_src=x.to(dev) if mask_act else None, mask_act=mask_act)
+    xd = x.double().requires_grad_(True)
+    y = F.conv2d(xd.permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), None, stride=s)
+    g, = torch.autograd.grad(y, xd, dz.double().permute(0, 3, 1, 2))
+    close(out, g * actgrad_ref(x.double(), mask_act))
+
+
+@pytest.mark.parametrize("M,N", [(102400, 32), (12544, 64), (256, 512), (256, 6), (7, 3),
+                                 (1000, 100)])
+def test_colsum(dev, M, N):
+    rng = np.random.default_rng(M + N)
+    x = rnd(rng, M, N)
+    out = torch.empty(N, device=dev)
+    ops.colsum(x.to(dev), out)
+    close(out, x.double().sum(0), tol=5e-6)
+
+
+def test_mfma_layout_transpose_detecting(dev):
+    """A = I with an ASYMMETRIC B: catches row/column swaps in the MFMA C layout."""
+    n = 96
+    eye = torch.eye(n)
+    b = torch.arange(n * 40, dtype=torch.float32).reshape(n, 40) / 7.0
+    out = torch.empty(n, 40, device=dev)
+    ops.dense_forward(eye.to(dev), b.to(dev), None, None, out)
+    assert torch.equal(out.cpu(), b)
