@@ -1,0 +1,366 @@
+#!/usr/bin/env python
+"""Benchmark of the trainer hot path on MI355X: DQN Atari (BASELINE.json configs[1] / [3]).
+
+  python bench.py --gpus 1 --steps 50 --warmup 10
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one iteration of the reference's train_eval hot loop
+(tf_agents/agents/dqn/examples/v2/train_eval.py:290-297) on synthetic 84x84x4 uint8 frames:
+  collect_driver.run()   256 envs x 1 step: Q-network forward + epsilon-greedy + env step +
+                         TFUniformReplayBuffer.add_batch
+  learner.run(1)         get_next(256, num_steps=2) from the per-GPU replay shard + DqnAgent.train
+                         (online fwd, target fwd, TD/Huber, backward, [RCCL all-reduce], centred
+                         RMSProp, periodic target copy)
+Weak scaling: every rank owns 256 envs, a 256 x L replay shard and samples 256 transitions; the
+global batch is 256 x N and the only exchange is one all-reduce of the 6.75 MB gradient buffer.
+`value` = transitions trained on per second, whole job (= learner steps/s x 256 x N).
+Prints ONE JSON line on rank 0 (plus a human-readable breakdown on stderr).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+OBS_SHAPE = (84, 84, 4)
+NUM_ACTIONS = 6
+ROW_BYTES = 4 + 28224 + 8 + 4 + 4 + 4   # Trajectory row: 28,248 B
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def atari_layers(L, num_actions):
+    vs = lambda: L.VarianceScaling(2.0)
+    return [L.Rescale(255.0), L.Conv2D(32, (8, 8), 4, "relu", kernel_initializer=vs()),
+            L.Conv2D(64, (4, 4), 2, "relu", kernel_initializer=vs()),
+            L.Conv2D(64, (3, 3), 1, "relu", kernel_initializer=vs()), L.Flatten(),
+            L.Dense(512, "relu", kernel_initializer=vs()),
+            L.Dense(num_actions, None, kernel_initializer=vs())]
+
+
+def fwd_macs_per_sample():
+    return (20 * 20 * 32 * 256, 9 * 9 * 64 * 512, 7 * 7 * 64 * 576, 3136 * 512,
+            512 * NUM_ACTIONS)
+
+
+def train_flops_per_sample():
+    """online fwd + target fwd + online bwd (weight grads for all layers, input grads for all but
+    the first): SURVEY.md §8d restated without the conv1 input gradient nobody needs."""
+    m = fwd_macs_per_sample()
+    fwd = sum(m)
+    bwd = sum(m) + sum(m[1:])
+    return 2.0 * (2 * fwd + bwd)
+
+
+def build_workload(dev, rank, world, B_env, max_length, S, seed):
+    from agents_amd import optimizers
+    from agents_amd.agents.dqn import dqn_agent
+    from agents_amd.drivers import dynamic_step_driver
+    from agents_amd.environments import random_tf_environment
+    from agents_amd.networks import layers as L
+    from agents_amd.networks import sequential
+    from agents_amd.policies import q_policy
+    from agents_amd.replay_buffers import tf_uniform_replay_buffer as rb_lib
+    from agents_amd.specs import tensor_spec
+    from agents_amd.train import learner
+    from agents_amd.trajectories import time_step as ts
+    from agents_amd.utils import common
+
+    obs_spec = tensor_spec.TensorSpec(OBS_SHAPE, torch.uint8, "observation")
+    aspec = tensor_spec.BoundedTensorSpec((), torch.int64, 0, NUM_ACTIONS - 1, "action")
+    tss = ts.time_step_spec(obs_spec)
+    env = random_tf_environment.RandomTFEnvironment(tss, aspec, batch_size=B_env,
+                                                    episode_end_probability=1e-3,
+                                                    seed=seed * 1000 + rank, device=dev)
+    net = sequential.Sequential(atari_layers(L, NUM_ACTIONS), seed=2)  # same init on every rank
+    train_step = common.Variable(0, name="train_step")
+    agent = dqn_agent.DqnAgent(
+        tss, aspec, q_network=net,
+        optimizer=optimizers.RMSprop(2.5e-4, rho=0.95, momentum=0.95, epsilon=0.01, centered=True),
+        td_errors_loss_fn=common.element_wise_huber_loss, gamma=0.99, epsilon_greedy=0.1,
+        target_update_tau=1.0, target_update_period=2500, train_step_counter=train_step,
+        seed=seed * 77 + rank)
+    rb = rb_lib.TFUniformReplayBuffer(agent.collect_data_spec, batch_size=B_env,
+                                      max_length=max_length, device=dev, seed=seed * 13 + rank)
+    random_policy = q_policy.RandomTFPolicy(tss, aspec, seed=seed * 5 + rank)
+    init_driver = dynamic_step_driver.DynamicStepDriver(env, random_policy,
+                                                        observers=[rb.add_batch],
+                                                        num_steps=B_env * max_length)
+    collect_driver = dynamic_step_driver.DynamicStepDriver(env, agent.collect_policy,
+                                                           observers=[rb.add_batch], num_steps=1)
+    dataset = rb.as_dataset(num_parallel_calls=3, sample_batch_size=S, num_steps=2).prefetch(3)
+    lrn = learner.Learner(None, train_step, agent, experience_dataset_fn=None)
+    return dict(env=env, agent=agent, rb=rb, init_driver=init_driver,
+                collect_driver=collect_driver, dataset=dataset, learner=lrn, net=net)
+
+
+def kernel_breakdown(w, S, reps=20):
+    """Times the major ops of one train step individually with HIP events on the stream the
+    kernels run on (torch's current stream).  Returns [(name, ms, flops, bytes)]."""
+    from agents_amd import ops
+    net = w["net"]
+    agent = w["agent"]
+    rb = w["rb"]
+    exp, _ = rb.get_next(S, 2)
+    agent.train(exp)  # make sure every buffer exists
+    torch.cuda.synchronize()
+    slot = net._slots[("train", S)]
+    kv, bv, gk, gb = net._kviews, net._bviews, net._gkviews, net._gbviews
+    m = fwd_macs_per_sample()
+    obs_t = exp.observation[:, 0]
+
+    def ev():
+        return torch.cuda.Event(enable_timing=True)
+
+    def timeit(fn):
+        fn()
+        torch.cuda.synchronize()
+        a, b = ev(), ev()
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    dz4 = torch.randn(S, 512, device=obs_t.device)
+    dz3 = torch.randn(S * 49, 64, device=obs_t.device)
+    dz2 = torch.randn(S * 81, 64, device=obs_t.device)
+    dz1 = torch.randn(S * 400, 32, device=obs_t.device)
+    out = []
+    f = lambda macs: 2.0 * macs * S
+    out.append(("replay.sample+gather(512 rows)", timeit(lambda: rb.get_next(S, 2)), 0.0,
+                2.0 * S * 2 * ROW_BYTES))
+    out.append(("conv1.fwd(u8)", timeit(lambda: ops.conv_forward(
+        obs_t, kv[0], bv[0], 4, "relu", slot.ys[0], a_div=255.0)), f(m[0]), 0))
+    out.append(("conv2.fwd", timeit(lambda: ops.conv_forward(
+        slot.ys[0], kv[1], bv[1], 2, "relu", slot.ys[1])), f(m[1]), 0))
+    out.append(("conv3.fwd", timeit(lambda: ops.conv_forward(
+        slot.ys[1], kv[2], bv[2], 1, "relu", slot.ys[2])), f(m[2]), 0))
+    x3 = slot.ys[2].view(S, -1)
+    out.append(("fc1.fwd", timeit(lambda: ops.dense_forward(
+        x3, kv[3], bv[3], "relu", slot.ys[3])), f(m[3]), 0))
+    out.append(("fc2.fwd", timeit(lambda: ops.dense_forward(
+        slot.ys[3], kv[4], bv[4], None, slot.ys[4])), f(m[4]), 0))
+    out.append(("fc1.dW", timeit(lambda: ops.dense_dw(x3, dz4, gk[3])), f(m[3]), 0))
+    out.append(("fc1.dX", timeit(lambda: ops.dense_dx(
+        dz4, kv[3], slot.dxs[3].view(S, -1), mask_src=x3, mask_act="relu")), f(m[3]), 0))
+    out.append(("conv3.dW", timeit(lambda: ops.conv_dw(
+        slot.ys[1], dz3, tuple(kv[2].shape), 1, gk[2])), f(m[2]), 0))
+    out.append(("conv3.dX(gemm+col2im)", timeit(lambda: ops.conv_dx(
+        dz3, kv[2], tuple(slot.ys[1].shape), 1, slot.dcol, slot.dxs[2], mask_src=slot.ys[1],
+        mask_act="relu")), f(m[2]), 0))
+    out.append(("conv2.dW", timeit(lambda: ops.conv_dw(
+        slot.ys[0], dz2, tuple(kv[1].shape), 2, gk[1])), f(m[1]), 0))
+    out.append(("conv2.dX(gemm+col2im)", timeit(lambda: ops.conv_dx(
+        dz2, kv[1], tuple(slot.ys[0].shape), 2, slot.dcol, slot.dxs[1], mask_src=slot.ys[0],
+        mask_act="relu")), f(m[1]), 0))
+    out.append(("conv1.dW(u8)", timeit(lambda: ops.conv_dw(
+        obs_t, dz1, tuple(kv[0].shape), 4, gk[0], a_div=255.0)), f(m[0]), 0))
+    out.append(("bias grads (5 colsums)", timeit(lambda: [
+        ops.colsum(dz1, gb[0]), ops.colsum(dz2, gb[1]), ops.colsum(dz3, gb[2]),
+        ops.colsum(dz4, gb[3])]), 0.0, 4.0 * (dz1.numel() + dz2.numel() + dz3.numel())))
+    n_par = net.flat_params.numel()
+    opt = agent._optimizer
+    out.append(("rmsprop(centered,mom)", timeit(lambda: opt.apply_flat(
+        net.flat_params.clone(), net.flat_grads)), 0.0, 36.0 * n_par))
+    return out
+
+
+def cpu_baseline(S, steps, threads):
+    """The oracle (numpy replay + torch-CPU DQN step) timed on this host: a bounded sample of the
+    same workload (same shapes, batch 256, replay ring shortened to 64 frames per env)."""
+    from oracle import dqn as odqn
+    from oracle import nets as onets
+    from oracle import optim as ooptim
+    from oracle import replay as oreplay
+    torch.set_num_threads(threads)
+    B_env, L_ = 256, 8
+    layers = onets.atari_q_layers(NUM_ACTIONS)
+    params = onets.init_params(layers, OBS_SHAPE, seed=0)
+    agent = odqn.OracleDqnAgent(layers, OBS_SHAPE, NUM_ACTIONS, params,
+                                optimizer=ooptim.RMSprop(2.5e-4, 0.95, 0.95, 0.01, True),
+                                gamma=0.99, loss="huber", target_update_period=2500)
+    shapes = [(), OBS_SHAPE, (), (), (), ()]
+    dtypes = [np.int32, np.uint8, np.int64, np.int32, np.float32, np.float32]
+    rb = oreplay.OracleReplayBuffer(shapes, dtypes, B_env, L_, seed=1)
+    rng = np.random.default_rng(0)
+    for _ in range(L_):
+        rb.add_batch([rng.integers(0, 3, B_env).astype(np.int32),
+                      rng.integers(0, 256, (B_env,) + OBS_SHAPE, dtype=np.uint8),
+                      rng.integers(0, NUM_ACTIONS, B_env).astype(np.int64),
+                      rng.integers(0, 3, B_env).astype(np.int32),
+                      rng.choice([-1.0, 0.0, 1.0], B_env).astype(np.float32),
+                      np.ones(B_env, np.float32)])
+
+    def one():
+        # collect: policy forward on 256 envs + add_batch ; learn: sample + train
+        with torch.no_grad():
+            obs = torch.from_numpy(rng.integers(0, 256, (B_env,) + OBS_SHAPE, dtype=np.uint8))
+            q = agent.q_values(obs)
+            act = q.argmax(1).numpy().astype(np.int64)
+        rb.add_batch([np.ones(B_env, np.int32), obs.numpy(), act, np.ones(B_env, np.int32),
+                      np.zeros(B_env, np.float32), np.ones(B_env, np.float32)])
+        data, ids, probs = rb.get_next(S, 2)
+        st, ob, ac, nst, rew, disc = data
+        agent.train(torch.from_numpy(ob), ac, rew, disc, st)
+
+    one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = (time.perf_counter() - t0) / steps
+    return S / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--max-length", type=int, default=3906,
+                    help="replay frames per env (3906 x 256 envs = the 1M-row config)")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--envs", type=int, default=256)
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--prefill", type=int, default=-1, help="frames per env to prefill (-1 = all)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with that many ranks "
+                         f"(WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from agents_amd import _lib
+    _lib.load()  # fail loudly if the HIP library is missing
+    S = args.batch
+    w = build_workload(dev, rank, world, args.envs, args.max_length, S, seed=1)
+    # ---- prefill the replay shard with the random policy (untimed) ---------------------------
+    t0 = time.perf_counter()
+    prefill = args.max_length if args.prefill < 0 else min(args.prefill, args.max_length)
+    w["init_driver"]._num_steps = args.envs * max(prefill, 2)
+    w["init_driver"].run()
+    torch.cuda.synchronize()
+    if rank == 0:
+        log(f"[bench] prefilled {w['rb'].num_frames()} frames "
+            f"({w['rb'].num_frames() * ROW_BYTES / 1e9:.1f} GB) in {time.perf_counter() - t0:.1f}s")
+    it = iter(w["dataset"])
+    lrn, drv = w["learner"], w["collect_driver"]
+    time_step = None
+
+    def step():
+        nonlocal time_step
+        time_step, _ = drv.run(time_step)
+        return lrn.run(iterations=1, iterator=it)
+
+    def sync_all():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss_info = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    steps_per_sec = args.steps / dt
+    value = steps_per_sec * S * world
+    loss_val = float(loss_info.loss.item())
+
+    out = {
+        "metric": "replay_samples_per_sec trained (= learner_steps_per_sec x 256 x n_gpus), "
+                  "DQN Atari b=256",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "learner_steps_per_sec": steps_per_sec,
+        "env_steps_per_sec": steps_per_sec * args.envs * world,
+        "replay_rows_gathered_per_sec": steps_per_sec * S * 2 * world,
+        "final_loss": loss_val,
+        "config": {"workload": "configs[1]: DQN Atari Pong-shaped (84x84x4 uint8 stack), replay "
+                               f"{args.envs}x{args.max_length} rows/GPU, batch={S}, num_steps=2, "
+                               "Mnih-15 Q-net, Huber, centred RMSProp, 1 collect step (256 envs) "
+                               "+ 1 train step per iteration",
+                   "global_batch": S * world, "envs_per_gpu": args.envs,
+                   "replay_rows_per_gpu": args.envs * args.max_length,
+                   "parallelism": f"dp{world}" if world > 1 else "single"},
+    }
+    if rank == 0:
+        flops_step = train_flops_per_sample() * S + 2.0 * sum(fwd_macs_per_sample()) * args.envs
+        out["step_algorithmic_gflop"] = flops_step / 1e9
+        out["step_mfma_frac"] = flops_step / (dt / args.steps) / 1e12 / MFMA_F32_PEAK_TFLOPS
+        if not args.no_breakdown:
+            bd = kernel_breakdown(w, S)
+            tot = sum(ms for _, ms, _, _ in bd)
+            log("[bench] per-op breakdown of one train step (HIP events, eager launches):")
+            for name, ms, fl, by in bd:
+                extra = f"{fl / ms / 1e9:8.1f} TFLOP/s" if fl else f"{by / ms / 1e6:8.1f} GB/s"
+                log(f"    {name:34s} {ms * 1e3:9.1f} us  {extra}  ({100 * ms / tot:4.1f}%)")
+            name, ms, fl, by = max(bd, key=lambda r: r[1])
+            if fl:
+                ach = fl / ms / 1e9
+                out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": ach,
+                                   "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                                   "avg_launch_ms": ms}
+            else:
+                ach = by / ms / 1e6
+                out["roofline"] = {"kernel": name, "bound": "hbm", "achieved": ach,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                   "avg_launch_ms": ms}
+            g = next(r for r in bd if r[0].startswith("replay.sample"))
+            out["roofline_replay_gather"] = {"bound": "hbm", "achieved": g[3] / g[1] / 1e6,
+                                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": g[3] / g[1] / 1e6 / HBM_PEAK_GBS,
+                                             "avg_launch_ms": g[1]}
+        if not args.no_cpu_baseline and world == 1:
+            threads = max(1, os.cpu_count() or 1)
+            v, spstep = cpu_baseline(S, args.cpu_steps, threads)
+            out["cpu_baseline"] = {
+                "value": v, "unit": "samples/s", "cores": threads, "kind": "port",
+                "sample": f"{args.cpu_steps} iterations (collect 256 envs + sample 256x2 + train "
+                          f"batch 256) of the numpy/torch-CPU oracle, {spstep:.2f} s/iteration, "
+                          "replay ring shortened to 8 frames/env"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

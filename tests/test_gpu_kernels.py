@@ -96,12 +96,11 @@ def test_discounted_return_and_gae_bit_exact(dev, B, T, batch_major):
         sb, st = 1, B
         shape = (T, B)
     out = torch.empty(shape, device=dev)
-    _lib.check(lib.aa_discounted_return(arr(r).data_ptr(), arr(d).data_ptr(),
-                                        dv(fv, dev).data_ptr(), B, T, sb, st, out.data_ptr(),
-                                        _lib.stream_ptr()), "ret")
+    R, D, V, FV = arr(r), arr(d), arr(v), dv(fv, dev)  # keep the device buffers alive
+    _lib.check(lib.aa_discounted_return(R.data_ptr(), D.data_ptr(), FV.data_ptr(), B, T, sb, st,
+                                        out.data_ptr(), _lib.stream_ptr()), "ret")
     got = out.cpu().numpy()
     np.testing.assert_array_equal(got.T if batch_major else got, want_ret)
-    R, D, V, FV = arr(r), arr(d), arr(v), dv(fv, dev)
     _lib.check(lib.aa_gae(V.data_ptr(), FV.data_ptr(), D.data_ptr(), R.data_ptr(), 0.95, B, T, sb,
                           st, out.data_ptr(), _lib.stream_ptr()), "gae")
     got = out.cpu().numpy()

@@ -223,4 +223,4 @@ def test_full_size_atari_properties(dev):
     np.testing.assert_array_equal(data.reward.cpu().numpy(),
                                   (envs + 0.5 * ids).astype(np.float32))
     np.testing.assert_array_equal(data.step_type.cpu().numpy(), (ids % 3).astype(np.int32))
-    assert abs(float(info.probabilities[0]) - 1.0 / ((L - 1) * B)) < 1e-12
+    assert np.float32(info.probabilities[0].item()) == np.float32(1.0) / np.float32((L - 1) * B)
