@@ -240,27 +240,43 @@ class DqnAgent(tf_agent.TFAgent):
                                        n_seg, self._seg_sumsq.data_ptr(),
                                        float(self._gradient_clipping), 1, st), "aa_clip_by_norm")
 
+    # The train step is split in three so that it can be replayed from HIP graphs
+    # (agents_amd/utils/graph.py): two capturable device phases around the gradient hook (the
+    # Learner's RCCL all-reduce) and a host phase (counters, periodic target update).
+    def _train_phase_grads(self, experience, weights):
+        """forward(s) + loss + backward (+ regulariser, clipping): fills flat_grads."""
+        net = self._q_network
+        w = self._forward_and_loss(experience, self._td_errors_loss_fn, self._gamma,
+                                   self._reward_scale_factor, weights, need_grad=True)
+        net.backward(w.dq, slot="train")
+        total = w.loss
+        if net.has_regularization:
+            net.add_regularization_grads(1.0 / self.num_replicas)
+            total = w.loss + net.regularization_loss() / self.num_replicas
+        if self._gradient_clipping is not None:
+            self._clip_gradients(net)
+        return tf_agent.LossInfo(total.reshape(()),
+                                 DqnLossInfo(td_loss=w.td_loss, td_error=w.td_error))
+
+    def _train_phase_apply(self):
+        net = self._q_network
+        self._optimizer.apply_flat(net.flat_params, net.flat_grads)
+
+    def _train_phase_host(self):
+        self._train_step_counter.assign_add(1)
+        self._update_target()
+
     def _train(self, experience, weights):
         net = self._q_network
         with torch.cuda.device(experience.discount.device):
-            w = self._forward_and_loss(experience, self._td_errors_loss_fn, self._gamma,
-                                       self._reward_scale_factor, weights, need_grad=True)
-            if self.check_numerics and not bool(torch.isfinite(w.loss).all()):
+            loss_info = self._train_phase_grads(experience, weights)
+            if self.check_numerics and not bool(torch.isfinite(loss_info.loss).all()):
                 raise FloatingPointError("Loss is inf or nan")
-            net.backward(w.dq, slot="train")
-            total = w.loss
-            if net.has_regularization:
-                net.add_regularization_grads(1.0 / self.num_replicas)
-                total = w.loss + net.regularization_loss() / self.num_replicas
-            if self._gradient_clipping is not None:
-                self._clip_gradients(net)
             if self.gradient_hook is not None:
                 self.gradient_hook(net.flat_grads)
-            self._optimizer.apply_flat(net.flat_params, net.flat_grads)
-            self._train_step_counter.assign_add(1)
-            self._update_target()
-        return tf_agent.LossInfo(total.reshape(()),
-                                 DqnLossInfo(td_loss=w.td_loss, td_error=w.td_error))
+            self._train_phase_apply()
+            self._train_phase_host()
+        return loss_info
 
     # ---- checkpointing ---------------------------------------------------------------------------
     def state_dict(self):

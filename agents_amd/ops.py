@@ -22,6 +22,7 @@ class _Workspace:
 
     def __init__(self):
         self._buf = {}
+        self._retired = []  # outgrown buffers stay alive: captured HIP graphs may point at them
 
     def get(self, nbytes, device):
         key = (device.type, device.index)
@@ -30,6 +31,8 @@ class _Workspace:
             if torch.cuda.is_current_stream_capturing():
                 raise _lib.AgentsAmdError(
                     "workspace would grow during graph capture; run one eager step first")
+            if buf is not None:
+                self._retired.append(buf)
             buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
             self._buf[key] = buf
         return buf

@@ -30,7 +30,7 @@ class Learner:
                  summary_interval=1000, max_checkpoints_to_keep=3, use_kwargs_in_agent_train=False,
                  strategy=None, run_optimizer_variable_init=True, use_reverb_v2=False,
                  direct_sampling=False, experience_dataset_options=None,
-                 strategy_run_options=None, summary_root_dir=None):
+                 strategy_run_options=None, summary_root_dir=None, use_graph=True):
         if checkpoint_interval < 0:
             raise ValueError("checkpoint_interval must be non-negative")
         self._root_dir = root_dir
@@ -52,6 +52,11 @@ class Learner:
         if self.strategy.num_replicas_in_sync > 1:
             self._agent.gradient_hook = self.strategy.all_reduce_sum_
         self._agent.initialize()
+        # learner.py:309-337 runs the step inside tf.function; here: HIP-graph replay
+        self._train_fn = self._agent.train
+        if use_graph and hasattr(self._agent, "_train_phase_grads"):
+            from agents_amd.utils import graph
+            self._train_fn = graph.graphed_train(self._agent)
         self._last_checkpoint_step = int(self.train_step) if self.train_step is not None else 0
 
     @property
@@ -74,9 +79,9 @@ class Learner:
         else:
             experience, sample_info = sample, None
         if self.use_kwargs_in_agent_train:
-            loss_info = self._agent.train(**experience)
+            loss_info = self._train_fn(**experience)
         else:
-            loss_info = self._agent.train(experience)
+            loss_info = self._train_fn(experience)
         if self._after_train_strategy_step_fn:
             self._after_train_strategy_step_fn((experience, sample_info), loss_info)
         return loss_info

@@ -83,6 +83,14 @@ def restart(observation, batch_size=None, reward_spec=None):
     return TimeStep(step_type, reward, discount, observation)
 
 
+def _reward_to_tensors(reward, dev):
+    """float32 tensors; a plain list/tuple of numbers is one array, not a nest of scalars."""
+    if isinstance(reward, (list, tuple)) and not hasattr(reward, "_fields") and \
+            not any(isinstance(r, (torch.Tensor, dict, list, tuple)) for r in reward):
+        reward = np.asarray(reward, dtype=np.float32)
+    return nest_utils.map_structure(lambda r: _tensor(r, torch.float32, dev), reward)
+
+
 def _shape_like_reward(reward):
     r = nest_utils.flatten(reward)[0]
     return tuple(r.shape)
@@ -92,7 +100,7 @@ def transition(observation, reward, discount=1.0, outer_dims=None):
     """MID step (time_step.py:209-284)."""
     observation = _obs_to_tensors(observation)
     dev = _first_leaf(observation).device
-    reward = nest_utils.map_structure(lambda r: _tensor(r, torch.float32, dev), reward)
+    reward = _reward_to_tensors(reward, dev)
     shape = tuple(outer_dims) if outer_dims is not None else _shape_like_reward(reward)
     step_type = torch.full(shape, int(StepType.MID), dtype=torch.int32, device=dev)
     discount = _tensor(discount, torch.float32, dev)
@@ -105,7 +113,7 @@ def termination(observation, reward, outer_dims=None):
     """LAST step with discount 0 (time_step.py:285-348)."""
     observation = _obs_to_tensors(observation)
     dev = _first_leaf(observation).device
-    reward = nest_utils.map_structure(lambda r: _tensor(r, torch.float32, dev), reward)
+    reward = _reward_to_tensors(reward, dev)
     shape = tuple(outer_dims) if outer_dims is not None else _shape_like_reward(reward)
     step_type = torch.full(shape, int(StepType.LAST), dtype=torch.int32, device=dev)
     discount = torch.zeros(shape, dtype=torch.float32, device=dev)
@@ -116,7 +124,7 @@ def truncation(observation, reward, discount=1.0, outer_dims=None):
     """LAST step that keeps its discount (time_step.py:349-412)."""
     observation = _obs_to_tensors(observation)
     dev = _first_leaf(observation).device
-    reward = nest_utils.map_structure(lambda r: _tensor(r, torch.float32, dev), reward)
+    reward = _reward_to_tensors(reward, dev)
     shape = tuple(outer_dims) if outer_dims is not None else _shape_like_reward(reward)
     step_type = torch.full(shape, int(StepType.LAST), dtype=torch.int32, device=dev)
     discount = _tensor(discount, torch.float32, dev)

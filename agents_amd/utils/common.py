@@ -18,12 +18,18 @@ from agents_amd import _lib
 def function(*args, **kwargs):
     """`common.function` wraps callables in tf.function; kernels here are enqueued eagerly on a
     HIP stream (and the agents capture HIP graphs themselves), so this is the identity."""
-    if len(args) == 1 and callable(args[0]) and not kwargs:
-        return args[0]
-
-    def deco(fn):
+    def wrap(fn):
+        # `common.function(agent.train)`: the tf.function analogue here is HIP-graph capture
+        owner = getattr(fn, "__self__", None)
+        if owner is not None and getattr(fn, "__name__", "") == "train" and \
+                hasattr(owner, "_train_phase_grads"):
+            from agents_amd.utils import graph
+            return graph.graphed_train(owner)
         return fn
-    return deco
+
+    if len(args) == 1 and callable(args[0]) and not kwargs:
+        return wrap(args[0])
+    return wrap
 
 
 def function_in_tf1(*args, **kwargs):

@@ -1,0 +1,189 @@
+"""CPU tests of the host-side logic: nest ordering, specs, replay index logic (vs the oracle),
+dataset combinators, trajectory helpers, Periodically, loud failure without a HIP device."""
+import collections
+
+import numpy as np
+import pytest
+import torch
+
+from agents_amd import _lib
+from agents_amd.replay_buffers import dataset as ds_lib
+from agents_amd.replay_buffers import tf_uniform_replay_buffer as rb_lib
+from agents_amd.specs import tensor_spec
+from agents_amd.trajectories import policy_step
+from agents_amd.trajectories import time_step as ts
+from agents_amd.trajectories import trajectory
+from agents_amd.utils import common, nest_utils
+from oracle import dqn as odqn
+from oracle import replay as oreplay
+
+
+def test_nest_order_matches_tf_nest():
+    """namedtuples in field order, dicts in sorted-key order (table.py:54-77)."""
+    info = {"value_prediction": "v", "dist_params": {"scale": "s", "loc": "l"}}
+    traj = trajectory.Trajectory("st", "obs", "act", info, "nst", "rew", "disc")
+    assert nest_utils.flatten(traj) == ["st", "obs", "act", "l", "s", "v", "nst", "rew", "disc"]
+    packed = nest_utils.pack_sequence_as(traj, list(range(9)))
+    assert packed.policy_info == {"dist_params": {"loc": 3, "scale": 4}, "value_prediction": 5}
+    assert nest_utils.flatten(trajectory.Trajectory(1, 2, 3, (), 4, 5, 6)) == [1, 2, 3, 4, 5, 6]
+    with pytest.raises(ValueError, match="do not match"):
+        nest_utils.assert_same_structure(traj, traj._replace(policy_info=()))
+    with pytest.raises(ValueError):
+        nest_utils.assert_same_structure((1, 2), [1, 2][:1])
+    assert nest_utils.has_lists((1, [2])) and not nest_utils.has_lists((1, (2,)))
+
+
+def test_specs():
+    s = tensor_spec.BoundedTensorSpec((84, 84, 4), np.uint8, 0, 255, "obs")
+    assert s.dtype == torch.uint8 and s.row_bytes == 28224 and s.num_elements == 28224
+    assert tensor_spec.TensorSpec((), torch.int64).row_bytes == 8
+    assert s == tensor_spec.BoundedTensorSpec((84, 84, 4), torch.uint8, 0, 255)
+    assert s != tensor_spec.BoundedTensorSpec((84, 84, 4), torch.uint8, 0, 254)
+    t = ts.time_step_spec(s)
+    assert t.step_type.dtype == torch.int32 and t.discount.maximum == 1.0
+    with pytest.raises(ValueError):
+        tensor_spec.BoundedTensorSpec((2,), torch.float32, [0, 0, 0], 1)
+
+
+def test_valid_range_matches_oracle():
+    for L in (1, 3, 10):
+        for last in range(-1, 3 * L + 2):
+            for T in (None, 1, 2, 3):
+                assert rb_lib._valid_range_ids(last, L, T) == oreplay.valid_range_ids(last, L, T)
+
+
+@pytest.mark.parametrize("args", [
+    (2, 3, 3, None, None, False, None), (8, 5, 4, None, 2, False, None),
+    (3, 5, 4, None, 2, True, 1), (10, 6, 4, 3, 2, False, None), (2, 5, 3, 2, None, False, None),
+    (2, 5, 3, 2, None, True, None), (6, 1, 4, None, 3, False, 2)])
+def test_deterministic_pass_ids_match_oracle(args):
+    got = list(rb_lib.deterministic_pass_ids(*args))
+    want = list(oreplay.deterministic_pass_ids(*args))
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
+
+
+def test_replay_buffer_needs_hip_device():
+    with pytest.raises(_lib.AgentsAmdError, match="no CPU path"):
+        rb_lib.TFUniformReplayBuffer(tensor_spec.TensorSpec((), torch.int64), batch_size=1,
+                                     device="cpu")
+
+
+def test_ops_refuse_cpu_tensors(lib):
+    from agents_amd import ops
+    x = torch.zeros(4, 4)
+    with pytest.raises(_lib.AgentsAmdError, match="no CPU fallback"):
+        ops.dense_forward(x, x, None, None, x.clone())
+
+
+def test_dataset_combinators():
+    base = ds_lib.Dataset(lambda: iter([(torch.tensor([i, i + 10]), i) for i in range(5)]))
+    assert [int(b) for _, b in base.take(3)] == [0, 1, 2]
+    assert [int(b) for _, b in base.prefetch(2)] == [0, 1, 2, 3, 4]
+    assert [int(x) for x in base.map(lambda a, b: a[0] * 2)] == [0, 2, 4, 6, 8]
+    assert [int(b) for _, b in base.filter(lambda a, b: b % 2 == 0)] == [0, 2, 4]
+    assert len(list(base.repeat(2))) == 10
+    un = ds_lib.Dataset(lambda: iter([torch.arange(6).reshape(3, 2)])).unbatch()
+    assert [u.tolist() for u in un] == [[0, 1], [2, 3], [4, 5]]
+    b = un.batch(2)
+    assert [x.tolist() for x in b] == [[[0, 1], [2, 3]], [[4, 5]]]
+    assert [x.tolist() for x in un.batch(2, drop_remainder=True)] == [[[0, 1], [2, 3]]]
+    sh = sorted(int(b) for _, b in base.shuffle(3, seed=1))
+    assert sh == [0, 1, 2, 3, 4]
+    c = base.cache()
+    assert len(list(c)) == 5 and len(list(c)) == 5
+    inf = ds_lib.Dataset(lambda: iter(range(10**9)), infinite=True)
+    it = iter(inf.prefetch(3))
+    assert [next(it) for _ in range(4)] == [0, 1, 2, 3]
+
+
+def test_time_step_constructors_and_from_transition():
+    obs = torch.tensor([[1.0, 2.0], [3.0, 4.0]])
+    r = ts.restart(obs, batch_size=2)
+    assert r.step_type.tolist() == [0, 0] and r.reward.tolist() == [0, 0] and \
+        r.discount.tolist() == [1, 1] and r.step_type.dtype == torch.int32
+    m = ts.transition(obs, torch.tensor([10.0, 20.0]), 0.9)
+    assert m.step_type.tolist() == [1, 1] and torch.allclose(m.discount, torch.tensor([.9, .9]))
+    t = ts.termination(obs, [1.0, 2.0])
+    assert t.step_type.tolist() == [2, 2] and t.discount.tolist() == [0, 0] and bool(t.is_last().all())
+    tr = ts.truncation(obs, [1.0, 2.0], 0.5)
+    assert tr.step_type.tolist() == [2, 2] and tr.discount.tolist() == [0.5, 0.5]
+    traj = trajectory.from_transition(r, policy_step.PolicyStep(torch.tensor([0, 1]), (), ()), m)
+    assert traj.next_step_type.tolist() == [1, 1] and traj.reward.tolist() == [10, 20]
+    assert not bool(traj.is_boundary().any()) and bool(traj.is_first().all())
+    assert ts.StepType(2) is ts.StepType.LAST
+    with pytest.raises(ValueError):
+        ts.StepType(5)
+
+
+def test_to_n_step_transition_matches_oracle():
+    rng = np.random.RandomState(0)
+    B, T = 6, 4
+    rew = rng.randn(B, T).astype(np.float32)
+    disc = (rng.rand(B, T) > 0.2).astype(np.float32) * 0.9
+    traj = trajectory.Trajectory(
+        torch.zeros(B, T, dtype=torch.int32), torch.randn(B, T, 3),
+        torch.zeros(B, T, dtype=torch.int64), (), torch.ones(B, T, dtype=torch.int32),
+        torch.tensor(rew), torch.tensor(disc))
+    tr = trajectory.to_n_step_transition(traj, gamma=0.99)
+    want_r, want_d = odqn.n_step_return(rew, disc, 0.99)
+    np.testing.assert_allclose(tr.next_time_step.reward.numpy(), want_r, rtol=1e-6)
+    np.testing.assert_allclose(tr.next_time_step.discount.numpy(), want_d, rtol=1e-6)
+    assert torch.equal(tr.next_time_step.observation, traj.observation[:, -1])
+    assert torch.isnan(tr.time_step.reward).all()
+    with pytest.raises(ValueError):
+        trajectory.to_n_step_transition(nest_utils.map_structure(lambda x: x[:, :1], traj), 0.9)
+
+
+def test_periodically_and_soft_update_validation():
+    hits = []
+    p = common.Periodically(lambda: hits.append(1), 3)
+    for _ in range(7):
+        p()
+    assert len(hits) == 2          # calls 3 and 6
+    p1 = common.Periodically(lambda: hits.append(1), 1)
+    p1(); p1()
+    assert len(hits) == 4
+    assert common.Periodically(lambda: 1, None)() is None
+    with pytest.raises(TypeError):
+        common.Periodically(3, 1)
+    with pytest.raises(ValueError):
+        common.soft_variables_update([torch.zeros(1)], [torch.zeros(1)], tau=1.5)
+    with pytest.raises(ValueError):
+        common.soft_variables_update([torch.zeros(1)], [], tau=0.5)
+    t = torch.zeros(3)
+    common.soft_variables_update([torch.ones(3)], [t], tau=1.0)   # tau == 1 is a plain copy
+    assert t.tolist() == [1, 1, 1]
+
+
+def test_sequential_shape_inference():
+    from agents_amd.networks import layers as L
+    from agents_amd.networks import sequential
+    net = sequential.Sequential([L.Rescale(255.0), L.Conv2D(32, 8, 4, "relu"),
+                                 L.Conv2D(64, 4, 2, "relu"), L.Conv2D(64, 3, 1, "relu"),
+                                 L.Flatten(), L.Dense(512, "relu"), L.Dense(6)])
+    info, out = net._infer((84, 84, 4))
+    assert out == (6,)
+    assert [i[0] for i in info] == [(8, 8, 4, 32), (4, 4, 32, 64), (3, 3, 64, 64), (3136, 512),
+                                    (512, 6)]
+    n = sum(int(np.prod(k)) + int(np.prod(b)) for k, b, _, _ in info)
+    assert n == 1687206        # Atari Q-net parameter count
+    with pytest.raises(NotImplementedError):
+        L.Conv2D(8, 3, 1, padding="same")
+    with pytest.raises(TypeError):
+        sequential.Sequential([object()])
+
+
+def test_initializers():
+    from agents_amd.networks import layers as L
+    rng = np.random.default_rng(0)
+    w = L.VarianceScaling(2.0)((3136, 512), rng, 3136, 512)
+    assert abs(w.std() - np.sqrt(2.0 / 3136)) < 5e-4 and np.abs(w).max() <= 2 * np.sqrt(
+        2.0 / 3136) / 0.87962566103423978 + 1e-6
+    u = L.RandomUniform(-0.03, 0.03)((512, 6), rng, 512, 6)
+    assert u.min() >= -0.03 and u.max() <= 0.03
+    q = L.Orthogonal()((64, 64), rng, 64, 64)
+    np.testing.assert_allclose(q.T @ q, np.eye(64), atol=1e-5)
+    assert L.Constant([[2, 1], [1, 1]])((2, 2), rng, 2, 2).tolist() == [[2, 1], [1, 1]]
+    assert L.Constant(-0.2)((3,), rng, 1, 3).tolist() == pytest.approx([-0.2] * 3)
