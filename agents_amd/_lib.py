@@ -39,6 +39,7 @@ class GemmDesc(Structure):
         ("bias", c_void_p), ("act", c_int32),
         ("mask_src", c_void_p), ("ldm", c_int32), ("mask_kind", c_int32),
         ("force_cfg", c_int32), ("force_splits", c_int32),
+        ("colsum_out", c_void_p),
     ]
 
 
@@ -115,7 +116,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 1:
+    if lib.aa_abi_version() != 2:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -104,6 +104,7 @@ class DqnAgent(tf_agent.TFAgent):
                          train_step_counter=train_step_counter,
                          training_data_spec=training_data_spec)
         self._work = {}
+        self._side_streams = {}
         self._seg_offsets = None
         self._seg_sumsq = None
         # Data-parallel hooks installed by train.Learner: number of replicas the loss is averaged
@@ -154,6 +155,13 @@ class DqnAgent(tf_agent.TFAgent):
         common.soft_variables_update(self._q_network.flat_params,
                                      self._target_q_network.flat_params, tau=1.0)
 
+    def _side_stream(self, device):
+        key = (device.type, device.index)
+        st = self._side_streams.get(key)
+        if st is None:
+            st = self._side_streams[key] = ops.new_side_stream(device)
+        return st
+
     def _get_work(self, B, device):
         w = self._work.get(B)
         if w is None:
@@ -180,11 +188,18 @@ class DqnAgent(tf_agent.TFAgent):
         w = self._get_work(B, dev)
         obs_t = obs[:, 0]
         obs_next = obs[:, -1]
+        # The online and the target forward are independent chains of small kernels: run the
+        # target one on a side stream so the two overlap (fork / join, also under graph capture).
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            q_next_target = self._target_q_network.forward(obs_next, slot="train")
         q_online = self._q_network.forward(obs_t, slot="train", need_grad=need_grad)
-        q_next_target = self._target_q_network.forward(obs_next, slot="train")
         q_next_select = None
         if self._double_q:
             q_next_select = self._q_network.forward(obs_next, slot="next")
+        main.wait_stream(side)
         next_mask = None
         if mask is not None:
             next_mask = mask[:, -1].to(torch.int32).contiguous()
@@ -248,7 +263,7 @@ class DqnAgent(tf_agent.TFAgent):
         net = self._q_network
         w = self._forward_and_loss(experience, self._td_errors_loss_fn, self._gamma,
                                    self._reward_scale_factor, weights, need_grad=True)
-        net.backward(w.dq, slot="train")
+        net.backward(w.dq, slot="train", side_stream=self._side_stream(w.dq.device))
         total = w.loss
         if net.has_regularization:
             net.add_regularization_grads(1.0 / self.num_replicas)

@@ -25,7 +25,19 @@
 #include "common.h"
 #include "agents_amd.h"
 
+#include <type_traits>
+#include <utility>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int N, typename F, int... I>
+__device__ static inline void aa_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ static inline void aa_static_for(F&& f) {
+  aa_static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 #define AA_GEMM_THREADS 256
 #define AA_BK 32
@@ -39,6 +51,12 @@ struct GemmP {
   // conv patch geometry (NHWC input [Bimg, H, W, Cin])
   int W, Cin, OW, OHW, stride, seg, rowpitch, imgpitch;
   float a_div;
+  float a_rcp;       // 1/a_div
+  int a_fast;        // (float)u8 / a_div == fma-refined product for all 256 bytes (host-verified)
+  unsigned magic_ohw, magic_ow, magic_seg;  // ceil(2^32/d): n / d == mulhi(n, magic) (host-verified range)
+  int fastdiv;
+  unsigned a_bytes, b_bytes;  // operand extents for the buffer resources (< 2^31, host-checked)
+  float* colsum_out; // nullable: sum_k B(k,n) (bias gradient fused into the dW GEMM)
   int k_per_split;
   int splits;
   const float* bias;
@@ -63,15 +81,21 @@ __device__ static inline float aa_actgrad(float y, int kind) {
 
 // Pixel index (b, oy, ox) -> element offset of the patch origin in the NHWC input.
 __device__ static inline int aa_pix_base(const GemmP& p, int pix) {
-  const int b = pix / p.OHW;
+  int b, oy;
+  if (p.fastdiv) {
+    b = (int)__umulhi((unsigned)pix, p.magic_ohw);
+    oy = (int)__umulhi((unsigned)(pix - b * p.OHW), p.magic_ow);
+  } else {
+    b = pix / p.OHW;
+    oy = (pix - b * p.OHW) / p.OW;
+  }
   const int rem = pix - b * p.OHW;
-  const int oy = rem / p.OW;
   const int ox = rem - oy * p.OW;
   return b * p.imgpitch + (oy * p.stride) * p.rowpitch + (ox * p.stride) * p.Cin;
 }
 // Patch element index k -> element offset relative to the patch origin.
 __device__ static inline int aa_patch_off(const GemmP& p, int k) {
-  const int ky = k / p.seg;
+  const int ky = p.fastdiv ? (int)__umulhi((unsigned)k, p.magic_seg) : k / p.seg;
   return ky * p.rowpitch + (k - ky * p.seg);
 }
 
@@ -95,28 +119,56 @@ struct StageU8 {  // one 16-byte vector of uint8 per thread
   uint4 r;
 };
 
+// All loaders are branch-free buffer loads: each operand is addressed through a buffer resource
+// (base, byte size) with a 32-bit byte offset per lane; an element outside the operand gets the
+// offset AA_OOB, which the hardware range check turns into a zero result.  No divergent branch
+// surrounds a load, so hipcc keeps every load of a K-tile in flight together and counts them with
+// partial vmcnt waits (branches around loads make it drain vmcnt to 0 at each join).  `vec`
+// (wave-uniform) says the operand allows 16-byte loads: base 16-byte aligned, leading dimension
+// and the contiguous extent multiples of 4 -- then a vector is entirely inside or outside.
+#define AA_OOB 0x80000000u
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t aa_rsrc;
+
+__device__ static inline aa_rsrc aa_make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ static inline float4 aa_ld4(aa_rsrc r, unsigned byte_off, bool ok) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? byte_off : AA_OOB, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                     __uint_as_float(v.w));
+}
+__device__ static inline float aa_ld1(aa_rsrc r, unsigned byte_off, bool ok) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, ok ? byte_off : AA_OOB, 0, 0));
+}
+__device__ static inline uint4 aa_ld16b(aa_rsrc r, unsigned byte_off, bool ok) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? byte_off : AA_OOB, 0, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // ---- dense K-contiguous (A_ROW for A, B_COL for B): elem(x,k) = base[x*ld + k] ------------
-template <int BX>
-__device__ static inline void load_T_dense(StageT<BX>& s, const float* base, int ld, int x0,
-                                           int X, int k0, int k_end, int vec) {
+template <int BX, int VEC>
+__device__ static inline void load_T_dense(StageT<BX>& s, aa_rsrc base, int ld, int x0,
+                                           int X, int k0, int k_end) {
   const int kq = threadIdx.x & 7, r = threadIdx.x >> 3;
   const int k = k0 + 4 * kq;
+  if constexpr (VEC) {
 #pragma unroll
-  for (int p = 0; p < StageT<BX>::PASSES; ++p) {
-    const int x = x0 + r + 32 * p;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (x < X) {
-      const float* src = base + (size_t)x * ld + k;
-      if (vec && k + 3 < k_end) {
-        v = *reinterpret_cast<const float4*>(src);
-      } else {
-        if (k + 0 < k_end) v.x = src[0];
-        if (k + 1 < k_end) v.y = src[1];
-        if (k + 2 < k_end) v.z = src[2];
-        if (k + 3 < k_end) v.w = src[3];
-      }
+    for (int p = 0; p < StageT<BX>::PASSES; ++p) {
+      const int x = x0 + r + 32 * p;
+      s.r[p] = aa_ld4(base, 4u * ((unsigned)x * ld + k), x < X && k < k_end);
     }
-    s.r[p] = v;
+  } else {
+#pragma unroll
+    for (int p = 0; p < StageT<BX>::PASSES; ++p) {
+      const int x = x0 + r + 32 * p;
+      const unsigned o = 4u * ((unsigned)x * ld + k);
+      const bool in = x < X;
+      s.r[p].x = aa_ld1(base, o + 0, in && k + 0 < k_end);
+      s.r[p].y = aa_ld1(base, o + 4, in && k + 1 < k_end);
+      s.r[p].z = aa_ld1(base, o + 8, in && k + 2 < k_end);
+      s.r[p].w = aa_ld1(base, o + 12, in && k + 3 < k_end);
+    }
   }
 }
 template <int BX, int LDS_LD>
@@ -133,29 +185,31 @@ __device__ static inline void store_T(const StageT<BX>& s, float* tile) {
 }
 
 // ---- dense X-contiguous (A_COL for A, B_ROW for B): elem(x,k) = base[k*ld + x] ------------
-template <int BX>
-__device__ static inline void load_D_dense(StageD<BX>& s, const float* base, int ld, int x0,
-                                           int X, int k0, int k_end, int vec) {
+template <int BX, int VEC>
+__device__ static inline void load_D_dense(StageD<BX>& s, aa_rsrc base, int ld, int x0,
+                                           int X, int k0, int k_end) {
   constexpr int V = StageD<BX>::V, RP = StageD<BX>::RP;
   const int v4 = threadIdx.x % V, r = threadIdx.x / V;
   const int x = x0 + 4 * v4;
+  if constexpr (VEC) {
 #pragma unroll
-  for (int p = 0; p < StageD<BX>::PASSES; ++p) {
-    const int kk = r + RP * p;
-    const int k = k0 + kk;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (kk < AA_BK && k < k_end) {
-      const float* src = base + (size_t)k * ld + x;
-      if (vec && x + 3 < X) {
-        v = *reinterpret_cast<const float4*>(src);
-      } else {
-        if (x + 0 < X) v.x = src[0];
-        if (x + 1 < X) v.y = src[1];
-        if (x + 2 < X) v.z = src[2];
-        if (x + 3 < X) v.w = src[3];
-      }
+    for (int p = 0; p < StageD<BX>::PASSES; ++p) {
+      const int kk = r + RP * p;
+      const int k = k0 + kk;
+      s.r[p] = aa_ld4(base, 4u * ((unsigned)k * ld + x), kk < AA_BK && k < k_end && x < X);
     }
-    s.r[p] = v;
+  } else {
+#pragma unroll
+    for (int p = 0; p < StageD<BX>::PASSES; ++p) {
+      const int kk = r + RP * p;
+      const int k = k0 + kk;
+      const unsigned o = 4u * ((unsigned)k * ld + x);
+      const bool in = kk < AA_BK && k < k_end;
+      s.r[p].x = aa_ld1(base, o + 0, in && x + 0 < X);
+      s.r[p].y = aa_ld1(base, o + 4, in && x + 1 < X);
+      s.r[p].z = aa_ld1(base, o + 8, in && x + 2 < X);
+      s.r[p].w = aa_ld1(base, o + 12, in && x + 3 < X);
+    }
   }
 }
 template <int BX, int LDS_LD>
@@ -169,37 +223,42 @@ __device__ static inline void store_D(const StageD<BX>& s, float* tile) {
   }
 }
 
+// (float)byte / div, bit-identical to the IEEE quotient: q0 = x*r; q = fma(fma(-d, q0, x), r, q0)
+// when the host has verified that for every byte (a_fast), else a true division.
+__device__ static inline float aa_u8_scale(uint32_t word, int j, const GemmP& p) {
+  const float x = (float)((word >> (8 * j)) & 0xffu);
+  if (p.a_fast) {
+    const float q0 = x * p.a_rcp;
+    return fmaf(fmaf(-p.a_div, q0, x), p.a_rcp, q0);
+  }
+  return x / p.a_div;
+}
+
 // ---- conv patches, forward orientation: A(m = pixel, k = patch element), K-contiguous -------
 template <int BX>
-__device__ static inline void load_T_patch(StageT<BX>& s, const GemmP& p, const int* rowbase,
-                                           int k0, int k_end) {
+__device__ static inline void load_T_patch(StageT<BX>& s, const GemmP& p, aa_rsrc A,
+                                           const int* rowbase, int k0, int k_end) {
   const int kq = threadIdx.x & 7;
   const int k = k0 + 4 * kq;
   const bool kin = k < k_end;  // K % 4 == 0 validated on host
-  const int koff = kin ? aa_patch_off(p, k) : 0;
-  const float* A = reinterpret_cast<const float*>(p.A);
+  const int koff = aa_patch_off(p, kin ? k : 0);
 #pragma unroll
   for (int q = 0; q < StageT<BX>::PASSES; ++q) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (kin && rowbase[q] >= 0) v = *reinterpret_cast<const float4*>(A + rowbase[q] + koff);
-    s.r[q] = v;
+    const bool ok = kin && rowbase[q] >= 0;
+    s.r[q] = aa_ld4(A, 4u * (unsigned)(rowbase[q] + koff), ok);
   }
 }
 // uint8 frames: 2 x 16-byte vectors per pixel row per K-step; thread -> (row = t>>1, half = t&1)
 template <int BX>
-__device__ static inline void load_T_patch_u8(StageU8& s, const GemmP& p, int rowbase, int k0,
-                                              int k_end) {
+__device__ static inline void load_T_patch_u8(StageU8& s, const GemmP& p, aa_rsrc A, int rowbase,
+                                              int k0, int k_end) {
   const int kq = threadIdx.x & 1;
   const int k = k0 + 16 * kq;
-  uint4 v = make_uint4(0u, 0u, 0u, 0u);
-  if (k < k_end && rowbase >= 0) {
-    const uint8_t* A = reinterpret_cast<const uint8_t*>(p.A);
-    v = *reinterpret_cast<const uint4*>(A + rowbase + aa_patch_off(p, k));
-  }
-  s.r = v;
+  const bool ok = k < k_end && rowbase >= 0;
+  s.r = aa_ld16b(A, (unsigned)(rowbase + aa_patch_off(p, ok ? k : 0)), ok);
 }
 template <int BX, int LDS_LD>
-__device__ static inline void store_T_patch_u8(const StageU8& s, float* tile, float div) {
+__device__ static inline void store_T_patch_u8(const StageU8& s, float* tile, const GemmP& p) {
   const int kq = threadIdx.x & 1, r = threadIdx.x >> 1;
   if (r >= BX) return;
   float* d = tile + (16 * kq) * LDS_LD + r;
@@ -208,45 +267,37 @@ __device__ static inline void store_T_patch_u8(const StageU8& s, float* tile, fl
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float f = (float)((w[i] >> (8 * j)) & 0xffu) / div;
-      d[(4 * i + j) * LDS_LD] = f;
+      d[(4 * i + j) * LDS_LD] = aa_u8_scale(w[i], j, p);
     }
   }
 }
 
 // ---- conv patches, weight-grad orientation: A'(i = patch element, kk = pixel), i-contiguous --
 template <int BX>
-__device__ static inline void load_D_patchT(StageD<BX>& s, const GemmP& p, int ioff, bool iin,
-                                            int k0, int k_end) {
+__device__ static inline void load_D_patchT(StageD<BX>& s, const GemmP& p, aa_rsrc A, int ioff,
+                                            bool iin, int k0, int k_end) {
   constexpr int V = StageD<BX>::V, RP = StageD<BX>::RP;
   const int r = threadIdx.x / V;
-  const float* A = reinterpret_cast<const float*>(p.A);
 #pragma unroll
   for (int q = 0; q < StageD<BX>::PASSES; ++q) {
     const int kk = r + RP * q;
     const int pix = k0 + kk;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (iin && kk < AA_BK && pix < k_end)
-      v = *reinterpret_cast<const float4*>(A + aa_pix_base(p, pix) + ioff);
-    s.r[q] = v;
+    const bool ok = iin && kk < AA_BK && pix < k_end;
+    s.r[q] = aa_ld4(A, 4u * (unsigned)(aa_pix_base(p, ok ? pix : 0) + ioff), ok);
   }
 }
 // uint8: 16 patch elements per vector; BX/16 vectors per pixel row.
 template <int BX>
-__device__ static inline void load_D_patchT_u8(StageU8& s, const GemmP& p, int ioff, bool iin,
-                                               int k0, int k_end) {
+__device__ static inline void load_D_patchT_u8(StageU8& s, const GemmP& p, aa_rsrc A, int ioff,
+                                               bool iin, int k0, int k_end) {
   constexpr int V = BX / 16;
   const int r = threadIdx.x / V;
   const int pix = k0 + r;
-  uint4 v = make_uint4(0u, 0u, 0u, 0u);
-  if (iin && r < AA_BK && pix < k_end) {
-    const uint8_t* A = reinterpret_cast<const uint8_t*>(p.A);
-    v = *reinterpret_cast<const uint4*>(A + aa_pix_base(p, pix) + ioff);
-  }
-  s.r = v;
+  const bool ok = iin && r < AA_BK && pix < k_end;
+  s.r = aa_ld16b(A, (unsigned)(aa_pix_base(p, ok ? pix : 0) + ioff), ok);
 }
 template <int BX, int LDS_LD>
-__device__ static inline void store_D_patchT_u8(const StageU8& s, float* tile, float div) {
+__device__ static inline void store_D_patchT_u8(const StageU8& s, float* tile, const GemmP& p) {
   constexpr int V = BX / 16;
   const int v16 = threadIdx.x % V, r = threadIdx.x / V;
   if (r >= AA_BK) return;
@@ -255,18 +306,18 @@ __device__ static inline void store_D_patchT_u8(const StageU8& s, float* tile, f
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float4 f;
-    f.x = (float)((w[i] >> 0) & 0xffu) / div;
-    f.y = (float)((w[i] >> 8) & 0xffu) / div;
-    f.z = (float)((w[i] >> 16) & 0xffu) / div;
-    f.w = (float)((w[i] >> 24) & 0xffu) / div;
+    f.x = aa_u8_scale(w[i], 0, p);
+    f.y = aa_u8_scale(w[i], 1, p);
+    f.z = aa_u8_scale(w[i], 2, p);
+    f.w = aa_u8_scale(w[i], 3, p);
     *reinterpret_cast<float4*>(d + 4 * i) = f;
   }
 }
 
 // ------------------------------------------------------------------------------------------
-template <int AM, int BMODE, int BM, int BN, int WGM, int WGN>
+template <int AM, int BMODE, int BM, int BN, int WGM, int WGN, int WGK, int PD, int VEC>
 __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
-  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  static_assert(WGM * WGN * WGK == 4, "4 waves per workgroup");
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   static_assert(TM >= 1 && TN >= 1, "tile too small");
   constexpr bool A_IS_T = (AM == AA_A_ROW || AM == AA_A_PATCH || AM == AA_A_PATCH_U8);
@@ -285,11 +336,13 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
   const int nk = (k_end - k_begin + AA_BK - 1) / AA_BK;
 
   // ---- per-thread loader state --------------------------------------------------------
-  StageT<BM> aT;
-  StageD<BM> aD;
-  StageU8 aU;
-  StageT<BN> bT;
-  StageD<BN> bD;
+  // PD register stages: the loads of K-tile t+PD are issued while tile t is multiplied, so a
+  // global load has PD K-steps of MFMA work to land before its ds_write needs it.
+  StageT<BM> aT[PD];
+  StageD<BM> aD[PD];
+  StageU8 aU[PD];
+  StageT<BN> bT[PD];
+  StageD<BN> bD[PD];
   int rowbase[StageT<BM>::PASSES];  // A_PATCH: patch origin per staged row (-1 = out of range)
   int rowbase_u8 = -1;
   int ioff = 0;
@@ -317,44 +370,61 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
     iin = i < p.M;
     ioff = iin ? aa_patch_off(p, i) : 0;
   }
+  // fused bias gradient: column sums of the B operand, taken by the first M-tile's workgroups
+  const bool do_colsum = (BMODE == AA_B_ROW) && p.colsum_out != nullptr && blockIdx.x == 0;
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  auto load_tiles = [&](int k0) {
+  const aa_rsrc rA = aa_make_rsrc(p.A, p.a_bytes);
+  const aa_rsrc rB = aa_make_rsrc(p.B, p.b_bytes);
+  auto load_tiles = [&](auto slot, int k0) {
+    constexpr int u = decltype(slot)::value;
     if constexpr (AM == AA_A_ROW)
-      load_T_dense<BM>(aT, reinterpret_cast<const float*>(p.A), p.lda, m0, p.M, k0, k_end, p.a_vec);
+      load_T_dense<BM, VEC>(aT[u], rA, p.lda, m0, p.M, k0, k_end);
     else if constexpr (AM == AA_A_COL)
-      load_D_dense<BM>(aD, reinterpret_cast<const float*>(p.A), p.lda, m0, p.M, k0, k_end, p.a_vec);
+      load_D_dense<BM, VEC>(aD[u], rA, p.lda, m0, p.M, k0, k_end);
     else if constexpr (AM == AA_A_PATCH)
-      load_T_patch<BM>(aT, p, rowbase, k0, k_end);
+      load_T_patch<BM>(aT[u], p, rA, rowbase, k0, k_end);
     else if constexpr (AM == AA_A_PATCH_U8)
-      load_T_patch_u8<BM>(aU, p, rowbase_u8, k0, k_end);
+      load_T_patch_u8<BM>(aU[u], p, rA, rowbase_u8, k0, k_end);
     else if constexpr (AM == AA_A_PATCH_T)
-      load_D_patchT<BM>(aD, p, ioff, iin, k0, k_end);
+      load_D_patchT<BM>(aD[u], p, rA, ioff, iin, k0, k_end);
     else
-      load_D_patchT_u8<BM>(aU, p, ioff, iin, k0, k_end);
+      load_D_patchT_u8<BM>(aU[u], p, rA, ioff, iin, k0, k_end);
     if constexpr (BMODE == AA_B_ROW)
-      load_D_dense<BN>(bD, p.B, p.ldb, n0, p.N, k0, k_end, p.b_vec);
+      load_D_dense<BN, VEC>(bD[u], rB, p.ldb, n0, p.N, k0, k_end);
     else
-      load_T_dense<BN>(bT, p.B, p.ldb, n0, p.N, k0, k_end, p.b_vec);
+      load_T_dense<BN, VEC>(bT[u], rB, p.ldb, n0, p.N, k0, k_end);
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](auto slot, int buf) {
+    constexpr int u = decltype(slot)::value;
     float* at = As + buf * AA_BK * LDA_S;
     float* bt = Bs + buf * AA_BK * LDB_S;
     if constexpr (AM == AA_A_ROW || AM == AA_A_PATCH)
-      store_T<BM, LDA_S>(aT, at);
+      store_T<BM, LDA_S>(aT[u], at);
     else if constexpr (AM == AA_A_COL || AM == AA_A_PATCH_T)
-      store_D<BM, LDA_S>(aD, at);
+      store_D<BM, LDA_S>(aD[u], at);
     else if constexpr (AM == AA_A_PATCH_U8)
-      store_T_patch_u8<BM, LDA_S>(aU, at, p.a_div);
+      store_T_patch_u8<BM, LDA_S>(aU[u], at, p);
     else
-      store_D_patchT_u8<BM, LDA_S>(aU, at, p.a_div);
-    if constexpr (BMODE == AA_B_ROW)
-      store_D<BN, LDB_S>(bD, bt);
-    else
-      store_T<BN, LDB_S>(bT, bt);
+      store_D_patchT_u8<BM, LDA_S>(aU[u], at, p);
+    if constexpr (BMODE == AA_B_ROW) {
+      store_D<BN, LDB_S>(bD[u], bt);
+      // the registers hold exactly one K-tile of B: add it once, here (unconditionally -- a
+      // branch in the K loop would cost more than the adds; only do_colsum groups publish it)
+#pragma unroll
+      for (int q = 0; q < StageD<BN>::PASSES; ++q) {
+        csum.x += bD[u].r[q].x; csum.y += bD[u].r[q].y;
+        csum.z += bD[u].r[q].z; csum.w += bD[u].r[q].w;
+      }
+    } else {
+      store_T<BN, LDB_S>(bT[u], bt);
+    }
   };
 
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wm = wave / WGN, wn = wave % WGN;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wk = wave / (WGM * WGN);           // k-slice owner (intra-workgroup split-K)
+  const int wmn = wave - wk * (WGM * WGN);
+  const int wm = wmn / WGN, wn = wmn % WGN;
   const int l31 = lane & 31, lh = lane >> 5;
 
   f32x16 acc[TM][TN];
@@ -365,21 +435,12 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  if (nk > 0) {
-    load_tiles(k_begin);
-    store_tiles(0);
-  }
-  __syncthreads();
-
-  for (int t = 0; t < nk; ++t) {
-    const int buf = t & 1;
-    const bool more = (t + 1) < nk;
-    if (more) load_tiles(k_begin + (t + 1) * AA_BK);
+  auto mma_tile = [&](int buf) {
     const float* at = As + buf * AA_BK * LDA_S + wm * (TM * 32) + l31;
     const float* bt = Bs + buf * AA_BK * LDB_S + wn * (TN * 32) + l31;
 #pragma unroll
-    for (int kk = 0; kk < AA_BK / 2; ++kk) {
-      const int k = 2 * kk + lh;
+    for (int kq = 0; kq < AA_BK / 2 / WGK; ++kq) {
+      const int k = 2 * (kq * WGK + wk) + lh;
       float a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[i] = at[k * LDA_S + 32 * i];
@@ -391,12 +452,93 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (more) store_tiles(buf ^ 1);
+  };
+
+  // prologue: tiles 0 .. PD-1 in flight, tile 0 staged in LDS buffer 0.  Loads past the last
+  // K-tile are issued anyway: every lane is out of range, the hardware returns zeros without
+  // touching memory, and the K loop stays free of conditionals (so hipcc counts vmcnt exactly).
+  aa_static_for<PD>([&](auto u) { load_tiles(u, k_begin + u.value * AA_BK); });
+  store_tiles(std::integral_constant<int, 0>{}, 0);
+  __syncthreads();
+
+  // step t (register slot u = t % PD): slot u held tile t (already in LDS) and is refilled with
+  // tile t + PD; tile t + 1 lives in slot (u + 1) % PD and is staged after the MFMAs of tile t.
+  auto step = [&](auto u, int t) {
+    const int buf = t & 1;
+    load_tiles(u, k_begin + (t + PD) * AA_BK);
+    mma_tile(buf);
+    store_tiles(std::integral_constant<int, (u.value + 1) % PD>{}, buf ^ 1);
     __syncthreads();
+  };
+  if (nk > 0) {
+    int t = 0;
+    while (true) {
+      step(std::integral_constant<int, 0>{}, t);
+      if (++t >= nk) break;
+      if constexpr (PD > 1) {
+        step(std::integral_constant<int, 1 % PD>{}, t);
+        if (++t >= nk) break;
+      }
+      if constexpr (PD > 2) {
+        step(std::integral_constant<int, 2 % PD>{}, t);
+        if (++t >= nk) break;
+      }
+    }
+  }
+
+  const bool raw = p.splits > 1;
+
+  // ---- fused bias gradient: reduce the per-thread column sums over the k-rows -------------
+  if constexpr (BMODE == AA_B_ROW) {
+    if (do_colsum) {  // workgroup-uniform
+      constexpr int V = StageD<BN>::V, RP = StageD<BN>::RP;
+      float* red = smem;  // [RP][BN], staging tiles are dead after the loop's last barrier
+      const int v4 = threadIdx.x % V, r = threadIdx.x / V;
+      *reinterpret_cast<float4*>(red + r * BN + 4 * v4) = csum;
+      __syncthreads();
+      if (threadIdx.x < BN) {
+        float s = 0.f;
+        for (int j = 0; j < RP; ++j) s += red[j * BN + threadIdx.x];
+        const int n = n0 + threadIdx.x;
+        if (n < p.N) {
+          if (raw)  // per-split partial rows after the slabs: [splits][N]
+            p.C[(size_t)p.splits * p.M * p.N + (size_t)blockIdx.z * p.N + n] = s;
+          else
+            p.colsum_out[n] = s;
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- intra-workgroup split-K: waves wk > 0 hand their accumulators to wave wk == 0 -------
+  if constexpr (WGK > 1) {
+    float* red = smem;  // [(WGK-1)][WGM*WGN][TM*TN][16][64]
+    constexpr int PER = TM * TN * 1024;
+    if (wk > 0) {
+      float* dst = red + ((wk - 1) * (WGM * WGN) + wmn) * PER + lane;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) dst[((i * TN + j) * 16 + e) * 64] = acc[i][j][e];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int w = 1; w < WGK; ++w) {
+      const float* src = red + ((w - 1) * (WGM * WGN) + wmn) * PER + lane;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] += src[((i * TN + j) * 16 + e) * 64];
+    }
   }
 
   // ---- epilogue ------------------------------------------------------------------------
-  const bool raw = p.splits > 1;
   float* C = raw ? p.C + (size_t)blockIdx.z * (size_t)p.M * (size_t)p.N : p.C;
   const int ldc = raw ? p.N : p.ldc;
 #pragma unroll
@@ -422,29 +564,83 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
   }
 }
 
-// out[m][n] = epilogue( sum_z slab[z][m][n] ), fixed z order => deterministic.
+// out[m][n] = epilogue( sum_z slab[z][m][n] ), fixed z order => deterministic.  Four consecutive
+// n per thread (16-byte loads) when N % 4 == 0 and C / mask rows are 16-byte aligned.
+// Elements [M*N, M*N + N) of the index space are the fused bias-gradient rows that follow the
+// slabs: colsum_out[n] = sum_z slab_end[z][n].
+template <int VEC>
 __global__ void __launch_bounds__(256)
 aa_splitk_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N,
                         float* __restrict__ C, int ldc, const float* __restrict__ bias, int act,
-                        const float* __restrict__ mask_src, int ldm, int mask_kind) {
+                        const float* __restrict__ mask_src, int ldm, int mask_kind,
+                        float* __restrict__ colsum_out) {
   const size_t MN = (size_t)M * N;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < MN;
-       i += (size_t)gridDim.x * blockDim.x) {
-    float v = 0.f;
-    for (int z = 0; z < splits; ++z) v += slab[(size_t)z * MN + i];
+  const size_t total = (MN + (colsum_out != nullptr ? (size_t)N : 0)) / VEC;
+  const float* cs_rows = slab + (size_t)splits * MN;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = q * VEC;
+    if (i >= MN) {  // bias-gradient tail
+      const size_t n = i - MN;
+      float v[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = 0.f;
+      for (int z = 0; z < splits; ++z)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] += cs_rows[(size_t)z * N + n + e];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) colsum_out[n + e] = v[e];
+      continue;
+    }
+    float v[VEC];
+    if constexpr (VEC == 4) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int z = 0; z < splits; ++z) {
+        const float4 t = *reinterpret_cast<const float4*>(slab + (size_t)z * MN + i);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+      }
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    } else {
+      v[0] = 0.f;
+      for (int z = 0; z < splits; ++z) v[0] += slab[(size_t)z * MN + i];
+    }
     const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
-    if (bias != nullptr) v += bias[n];
-    v = aa_act(v, act);
-    if (mask_kind != 0) v *= aa_actgrad(mask_src[(size_t)m * ldm + n], mask_kind);
-    C[(size_t)m * ldc + n] = v;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float x = v[e];
+      if (bias != nullptr) x += bias[n + e];
+      x = aa_act(x, act);
+      if (mask_kind != 0) x *= aa_actgrad(mask_src[(size_t)m * ldm + n + e], mask_kind);
+      v[e] = x;
+    }
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<float4*>(C + (size_t)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      C[(size_t)m * ldc + n] = v[0];
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // host side: shape-driven tile / split-K selection and dispatch
 // ------------------------------------------------------------------------------------------
+struct AaTileCfg {
+  int bm, bn, wgm, wgn, wgk;
+};
+// force_cfg - 1 indexes this table
+static const AaTileCfg kCfgs[] = {
+    {128, 64, 2, 2, 1},   // 1
+    {128, 32, 4, 1, 1},   // 2
+    {64, 64, 2, 2, 1},    // 3
+    {128, 128, 2, 2, 1},  // 4
+    {64, 32, 2, 1, 2},    // 5
+    {32, 64, 1, 2, 2},    // 6
+    {32, 32, 1, 1, 4},    // 7
+};
+#define AA_NCFG 7
+
 struct AaGemmPlan {
-  int cfg;       // 0: 128x64, 1: 128x32, 2: 64x64
+  int cfg;
   int bm, bn;
   int splits, k_per_split;
   size_t ws_bytes;
@@ -452,58 +648,97 @@ struct AaGemmPlan {
 
 static int aa_gemm_plan(const aa_gemm_desc* d, AaGemmPlan* pl) {
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return AA_ERR_INVALID;
+  const int64_t M = d->M, N = d->N, K = d->K;
+  auto ntiles = [&](int c) {
+    return ((M + kCfgs[c].bm - 1) / kCfgs[c].bm) * ((N + kCfgs[c].bn - 1) / kCfgs[c].bn);
+  };
+  // Shape-driven choice, fitted to tools/gemm_sweep.py runs on MI355X (256 CUs).  A launch of this
+  // kernel has ~5 us of fixed latency (kernarg fetch -> first global loads -> LDS -> MFMA ->
+  // stores retire), so what matters for these 1-2 GFLOP problems is that every CU gets two
+  // workgroups of balanced length: take the largest tile that still yields >= 512 workgroups;
+  // if even the smallest tile gives < 256, split K (partial slabs + one deterministic reduce).
+  const bool narrow = N <= 32;
+  static const int wide_c[] = {3, 2, 5};   // 128x128, 64x64, 32x64
+  static const int thin_c[] = {1, 4, 6};   // 128x32, 64x32, 32x32
+  const int* cand = narrow ? thin_c : wide_c;
   int cfg;
   if (d->force_cfg > 0) {
     cfg = d->force_cfg - 1;
-    if (cfg > 2) return AA_ERR_INVALID;
-  } else if (d->N <= 32) {
-    cfg = 1;
+    if (cfg >= AA_NCFG) return AA_ERR_INVALID;
   } else {
-    const int64_t t128 = (int64_t)((d->M + 127) / 128) * ((d->N + 63) / 64);
-    cfg = t128 >= 512 ? 0 : 2;
+    cfg = cand[2];
+    for (int i = 0; i < 3; ++i) {
+      const int64_t need = i == 0 ? 1024 : 512;  // the biggest tiles run one workgroup per CU
+      if (ntiles(cand[i]) >= need) { cfg = cand[i]; break; }
+    }
   }
   pl->cfg = cfg;
-  pl->bm = cfg == 2 ? 64 : 128;
-  pl->bn = cfg == 1 ? 32 : 64;
-  const int64_t tiles = (int64_t)((d->M + pl->bm - 1) / pl->bm) * ((d->N + pl->bn - 1) / pl->bn);
+  pl->bm = kCfgs[cfg].bm;
+  pl->bn = kCfgs[cfg].bn;
+  const int64_t tiles = ntiles(cfg);
   int splits = 1;
   if (d->force_splits > 0) {
     splits = d->force_splits;
-  } else if (tiles < 384) {
-    splits = (int)((768 + tiles - 1) / tiles);
-    const int max_by_k = d->K / (2 * AA_BK);  // at least two K-steps per split
+  } else if (tiles < 256) {
+    splits = (int)((512 + tiles - 1) / tiles);
+    const int max_by_k = (int)(K / (4 * AA_BK));  // at least four K-steps per split
     if (splits > max_by_k) splits = max_by_k;
     if (splits < 1) splits = 1;
   }
-  int kps = (d->K + splits - 1) / splits;
+  int kps = (int)((K + splits - 1) / splits);
   kps = ((kps + AA_BK - 1) / AA_BK) * AA_BK;
-  splits = (d->K + kps - 1) / kps;
+  splits = (int)((K + kps - 1) / kps);
   pl->splits = splits;
   pl->k_per_split = kps;
-  pl->ws_bytes = splits > 1 ? (size_t)splits * (size_t)d->M * (size_t)d->N * sizeof(float) : 0;
+  pl->ws_bytes = splits > 1 ? (size_t)splits * (size_t)(M * N + (d->colsum_out ? N : 0)) *
+                                  sizeof(float)
+                            : 0;
   return AA_OK;
+}
+
+template <int AM, int BMODE, int BM, int BN, int WGM, int WGN, int WGK, int PD, int VEC>
+static void aa_gemm_launch_pd(const GemmP& p, const AaGemmPlan& pl, hipStream_t st) {
+  dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, pl.splits);
+  constexpr bool A_IS_T = (AM == AA_A_ROW || AM == AA_A_PATCH || AM == AA_A_PATCH_U8);
+  constexpr bool B_IS_T = (BMODE == AA_B_COL);
+  constexpr int lda_s = BM + (A_IS_T ? 1 : 4), ldb_s = BN + (B_IS_T ? 1 : 4);
+  constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+  size_t smem = (size_t)2 * AA_BK * (lda_s + ldb_s) * sizeof(float);
+  const size_t red = (size_t)(WGK - 1) * WGM * WGN * TM * TN * 1024 * sizeof(float);
+  if (red > smem) smem = red;
+  if (smem < 4096) smem = 4096;  // fused column-sum scratch [1024/BN][BN]
+  hipLaunchKernelGGL((aa_gemm_kernel<AM, BMODE, BM, BN, WGM, WGN, WGK, PD, VEC>), grid,
+                     dim3(AA_GEMM_THREADS), smem, st, p);
+}
+
+template <int AM, int BMODE, int BM, int BN, int WGM, int WGN, int WGK>
+static void aa_gemm_launch_one(const GemmP& p, const AaGemmPlan& pl, hipStream_t st) {
+  constexpr bool dense = AM == AA_A_ROW || AM == AA_A_COL;
+  // dense operands that are ragged / unaligned use 4-byte loads (conv patches are always vectors)
+  if (!(p.b_vec && (p.a_vec || !dense))) {
+    aa_gemm_launch_pd<AM, BMODE, BM, BN, WGM, WGN, WGK, 2, 0>(p, pl, st);
+    return;
+  }
+  // two K-tiles of loads in flight measured best on MI355X (1: 3-8 % slower, 3: VGPR-bound)
+  aa_gemm_launch_pd<AM, BMODE, BM, BN, WGM, WGN, WGK, 2, 1>(p, pl, st);
 }
 
 template <int AM, int BMODE>
 static int aa_gemm_launch_cfg(const GemmP& p, const AaGemmPlan& pl, hipStream_t st) {
-  dim3 grid((p.M + pl.bm - 1) / pl.bm, (p.N + pl.bn - 1) / pl.bn, pl.splits);
-  dim3 block(AA_GEMM_THREADS);
-  constexpr bool A_IS_T = (AM == AA_A_ROW || AM == AA_A_PATCH || AM == AA_A_PATCH_U8);
-  constexpr bool B_IS_T = (BMODE == AA_B_COL);
-  const int lda_s = pl.bm + (A_IS_T ? 1 : 4), ldb_s = pl.bn + (B_IS_T ? 1 : 4);
-  const size_t smem = (size_t)2 * AA_BK * (lda_s + ldb_s) * sizeof(float);
   switch (pl.cfg) {
-    case 0:
-      hipLaunchKernelGGL((aa_gemm_kernel<AM, BMODE, 128, 64, 2, 2>), grid, block, smem, st, p);
-      break;
-    case 1:
-      hipLaunchKernelGGL((aa_gemm_kernel<AM, BMODE, 128, 32, 4, 1>), grid, block, smem, st, p);
-      break;
-    default:
-      hipLaunchKernelGGL((aa_gemm_kernel<AM, BMODE, 64, 64, 2, 2>), grid, block, smem, st, p);
-      break;
+    case 0: aa_gemm_launch_one<AM, BMODE, 128, 64, 2, 2, 1>(p, pl, st); break;
+    case 1: aa_gemm_launch_one<AM, BMODE, 128, 32, 4, 1, 1>(p, pl, st); break;
+    case 2: aa_gemm_launch_one<AM, BMODE, 64, 64, 2, 2, 1>(p, pl, st); break;
+    case 3: aa_gemm_launch_one<AM, BMODE, 128, 128, 2, 2, 1>(p, pl, st); break;
+    case 4: aa_gemm_launch_one<AM, BMODE, 64, 32, 2, 1, 2>(p, pl, st); break;
+    case 5: aa_gemm_launch_one<AM, BMODE, 32, 64, 1, 2, 2>(p, pl, st); break;
+    default: aa_gemm_launch_one<AM, BMODE, 32, 32, 1, 1, 4>(p, pl, st); break;
   }
   return aa_launch_status();
+}
+
+static unsigned aa_magic(int d) {  // ceil(2^32 / d); d >= 2 (d == 1 handled by the caller)
+  return (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d);
 }
 
 extern "C" {
@@ -523,6 +758,7 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
     return AA_ERR_RANGE;
   const bool patch = d->a_mode >= AA_A_PATCH;
   const bool u8 = d->a_mode == AA_A_PATCH_U8 || d->a_mode == AA_A_PATCH_T_U8;
+  if (d->colsum_out != nullptr && d->b_mode != AA_B_ROW) return AA_ERR_INVALID;
   GemmP p;
   p.A = d->A;
   p.B = d->B;
@@ -530,6 +766,23 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
   p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
   p.W = p.Cin = p.OW = p.OHW = p.stride = p.seg = p.rowpitch = p.imgpitch = 0;
   p.a_div = d->a_div != 0.f ? d->a_div : 1.f;
+  p.a_rcp = 1.0f / p.a_div;
+  p.a_fast = 0;
+  p.magic_ohw = p.magic_ow = p.magic_seg = 0;
+  p.fastdiv = 0;
+  p.colsum_out = d->colsum_out;
+  if (u8) {
+    // the refined product must reproduce the IEEE quotient for every byte value
+    int ok = 1;
+    for (int b = 0; b < 256 && ok; ++b) {
+      const float x = (float)b;
+      volatile float q0 = x * p.a_rcp;
+      const float q = fmaf(fmaf(-p.a_div, q0, x), p.a_rcp, q0);
+      volatile float want = x / p.a_div;
+      if (q != want) ok = 0;
+    }
+    p.a_fast = ok;
+  }
   if (patch) {
     if (d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0)
       return AA_ERR_INVALID;
@@ -551,9 +804,42 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
     if ((int64_t)d->n_img * pitch >= 0x7fffffffLL) return AA_ERR_RANGE;
     p.W = d->W; p.Cin = d->Cin; p.OW = OW; p.OHW = OH * OW; p.stride = d->stride;
     p.seg = seg; p.rowpitch = d->W * d->Cin; p.imgpitch = (int)pitch;
+    // n / d == mulhi(n, ceil(2^32/d)) whenever n * d < 2^32; n is a pixel or patch-element index
+    const int64_t nmax = (npix > Kp ? npix : Kp) + AA_BK + 256;
+    const int64_t dmax = p.OHW > seg ? p.OHW : seg;
+    if (OW >= 2 && p.OHW >= 2 && seg >= 2 && nmax * dmax < (1ll << 32)) {
+      p.fastdiv = 1;
+      p.magic_ohw = aa_magic(p.OHW);
+      p.magic_ow = aa_magic(OW);
+      p.magic_seg = aa_magic(seg);
+    }
   }
-  p.a_vec = (!patch && (d->lda % 4 == 0) && (((uintptr_t)d->A & 15) == 0)) ? 1 : 0;
-  p.b_vec = ((d->ldb % 4 == 0) && (((uintptr_t)d->B & 15) == 0)) ? 1 : 0;
+  // 16-byte loads need an aligned base, a leading dimension and a contiguous extent that are
+  // multiples of 4 (so no vector straddles the operand's edge)
+  const int a_contig = d->a_mode == AA_A_ROW ? d->K : d->M;
+  const int b_contig = d->b_mode == AA_B_ROW ? d->N : d->K;
+  p.a_vec = (!patch && d->lda % 4 == 0 && a_contig % 4 == 0 && (((uintptr_t)d->A & 15) == 0));
+  p.b_vec = (d->ldb % 4 == 0 && b_contig % 4 == 0 && (((uintptr_t)d->B & 15) == 0));
+  {
+    // operand spans in bytes: the buffer resources carry them and lane offsets are 32-bit
+    int64_t a_span, b_span;
+    if (patch) {
+      const int64_t pitch = d->img_pitch > 0 ? (int64_t)d->img_pitch : (int64_t)d->H * d->W * d->Cin;
+      a_span = ((int64_t)(d->n_img - 1) * pitch + (int64_t)d->H * d->W * d->Cin) * (u8 ? 1 : 4);
+    } else if (d->a_mode == AA_A_ROW) {
+      a_span = ((int64_t)(d->M - 1) * d->lda + d->K) * 4;
+    } else {
+      a_span = ((int64_t)(d->K - 1) * d->lda + d->M) * 4;
+    }
+    if (d->b_mode == AA_B_ROW)
+      b_span = ((int64_t)(d->K - 1) * d->ldb + d->N) * 4;
+    else
+      b_span = ((int64_t)(d->N - 1) * d->ldb + d->K) * 4;
+    if (a_span <= 0 || b_span <= 0 || a_span >= (1ll << 31) || b_span >= (1ll << 31))
+      return AA_ERR_RANGE;
+    p.a_bytes = (unsigned)a_span;
+    p.b_bytes = (unsigned)b_span;
+  }
   p.k_per_split = pl.k_per_split;
   p.splits = pl.splits;
   p.bias = d->bias;
@@ -581,11 +867,19 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
   if (rc != AA_OK) return rc;
   if (pl.splits > 1) {
     const size_t MN = (size_t)d->M * d->N;
-    int blocks = (int)((MN + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(aa_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st,
-                       (const float*)workspace, pl.splits, d->M, d->N, d->C, d->ldc, d->bias,
-                       d->act, d->mask_src, d->ldm, p.mask_kind);
+    const bool vec = d->N % 4 == 0 && d->ldc % 4 == 0 && (((uintptr_t)d->C & 15) == 0) &&
+                     (d->mask_src == nullptr || d->ldm % 4 == 0);
+    const size_t work = (MN + (d->colsum_out ? d->N : 0)) / (vec ? 4 : 1);
+    int blocks = (int)((work + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (vec)
+      hipLaunchKernelGGL(aa_splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st,
+                         (const float*)workspace, pl.splits, d->M, d->N, d->C, d->ldc, d->bias,
+                         d->act, d->mask_src, d->ldm, p.mask_kind, d->colsum_out);
+    else
+      hipLaunchKernelGGL(aa_splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st,
+                         (const float*)workspace, pl.splits, d->M, d->N, d->C, d->ldc, d->bias,
+                         d->act, d->mask_src, d->ldm, p.mask_kind, d->colsum_out);
     rc = aa_launch_status();
   }
   return rc;

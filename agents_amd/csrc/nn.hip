@@ -26,11 +26,18 @@ aa_colsum_partial_kernel(const float* __restrict__ x, int64_t ld, int64_t M, int
   const int64_t m_lo = (int64_t)blockIdx.x * rows_per_block;
   int64_t m_hi = m_lo + rows_per_block;
   if (m_hi > M) m_hi = M;
-  float s = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent chains keep loads in flight
   if (n < N) {
-    for (int64_t m = m_lo + ty; m < m_hi; m += nty) s += x[m * ld + n];
+    int64_t m = m_lo + ty;
+    for (; m + 3 * nty < m_hi; m += 4 * nty) {
+      s0 += x[m * ld + n];
+      s1 += x[(m + nty) * ld + n];
+      s2 += x[(m + 2 * nty) * ld + n];
+      s3 += x[(m + 3 * nty) * ld + n];
+    }
+    for (; m < m_hi; m += nty) s0 += x[m * ld + n];
   }
-  red[threadIdx.x] = s;
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (ty == 0 && n < N) {
     float t = 0.f;
@@ -38,26 +45,37 @@ aa_colsum_partial_kernel(const float* __restrict__ x, int64_t ld, int64_t M, int
     partial[(int64_t)blockIdx.x * N + n] = t;
   }
 }
-__global__ void aa_colsum_final_kernel(const float* __restrict__ partial, int64_t P, int64_t N,
-                                       float* __restrict__ out) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+// stage 2: 16 x 64 threads; thread (ty, tx) sums partial rows ty, ty+16, ... of column tx, then
+// the 16 row-groups are combined in fixed order.
+__global__ void __launch_bounds__(1024)
+aa_colsum_final_kernel(const float* __restrict__ partial, int64_t P, int64_t N,
+                       float* __restrict__ out) {
+  __shared__ float red[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 64 + tx;
   float s = 0.f;
-  for (int64_t p = 0; p < P; ++p) s += partial[p * N + n];
-  out[n] = s;
+  if (n < N)
+    for (int64_t p = ty; p < P; p += 16) s += partial[p * N + n];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && n < N) {
+    float t = 0.f;
+    for (int j = 0; j < 16; ++j) t += red[j][tx];
+    out[n] = t;
+  }
 }
 
 static void aa_colsum_plan(int64_t M, int64_t N, int64_t* P, int64_t* rpb, int* ncol) {
   int nc = 1;
   while (nc < N && nc < 256) nc <<= 1;
   *ncol = nc;
-  int64_t r = 256;  // rows per block
-  int64_t p = (M + r - 1) / r;
-  if (p > 1024) {
-    p = 1024;
-    r = (M + p - 1) / p;
-    p = (M + r - 1) / r;
-  }
+  // about 512 workgroups in total, at least 64 rows each
+  const int64_t col_blocks = (N + nc - 1) / nc;
+  int64_t p = 512 / col_blocks;
+  if (p < 1) p = 1;
+  int64_t r = (M + p - 1) / p;
+  if (r < 64) r = 64;
+  p = (M + r - 1) / r;
   if (p < 1) p = 1;
   *P = p;
   *rpb = r;
@@ -174,7 +192,7 @@ int aa_colsum_f32(const float* x, int64_t ld, int64_t M, int64_t N, float* out, 
   dim3 grid((unsigned)P, (unsigned)((N + ncol - 1) / ncol));
   hipLaunchKernelGGL(aa_colsum_partial_kernel, grid, dim3(256), 0, st, x, ld, M, N, rpb, ncol,
                      (float*)workspace);
-  hipLaunchKernelGGL(aa_colsum_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(aa_colsum_final_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, st,
                      (const float*)workspace, P, N, out);
   return aa_launch_status();
 }

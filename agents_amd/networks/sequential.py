@@ -285,8 +285,13 @@ class Sequential(network.Network):
                 pi += 1
         return cur
 
-    def backward(self, dout, slot=0):
-        """Given d loss / d output [B, out], fills flat_grads (overwrites)."""
+    def backward(self, dout, slot=0, side_stream=None):
+        """Given d loss / d output [B, out], fills flat_grads (overwrites).
+
+        The input-gradient chain (dX_n -> dX_{n-1} -> ...) is the critical path; every
+        weight/bias-gradient GEMM only needs its layer's dZ, so with `side_stream` they are
+        enqueued there (fork after the kernel that produced dZ, join at the end) and overlap with
+        the chain.  Works the same eagerly and under HIP-graph capture."""
         B = dout.shape[0]
         s = self._slots.get((slot, B))
         if s is None or s.dz_top is None or s.xs[0] is None:
@@ -302,6 +307,17 @@ class Sequential(network.Network):
             dz = s.dz_top
         else:
             dz = dout.contiguous()
+        main = torch.cuda.current_stream(dout.device)
+        if side_stream is None:
+            side_stream = main
+
+        def on_side(fn):
+            if side_stream is main:
+                return fn()
+            side_stream.wait_stream(main)  # dZ of this layer is ready once main gets here
+            with torch.cuda.stream(side_stream):
+                return fn()
+
         for i in range(n - 1, -1, -1):
             l = self._param_layers[i]
             ks = self._shapes[i][0]
@@ -309,8 +325,8 @@ class Sequential(network.Network):
             prev_act = self._param_layers[i - 1].activation if i > 0 else None
             if isinstance(l, L.Dense):
                 dz2 = dz.view(B, -1)
-                ops.dense_dw(x, dz2, self._gkviews[i])
-                ops.colsum(dz2, self._gbviews[i])
+                on_side(lambda: ops.dense_dw(x, dz2, self._gkviews[i],
+                                             bias_grad=self._gbviews[i]))
                 if i > 0:
                     dx = s.dxs[i].view(B, -1)
                     ops.dense_dx(dz2, self._kviews[i], dx, mask_src=x if prev_act else None,
@@ -319,13 +335,15 @@ class Sequential(network.Network):
             else:
                 F = ks[3]
                 dz2 = dz.view(-1, F)
-                ops.conv_dw(x, dz2, ks, l.stride, self._gkviews[i],
-                            a_div=self._first_div() if i == 0 else 1.0)
-                ops.colsum(dz2, self._gbviews[i])
+                on_side(lambda: ops.conv_dw(x, dz2, ks, l.stride, self._gkviews[i],
+                                            a_div=self._first_div() if i == 0 else 1.0,
+                                            bias_grad=self._gbviews[i]))
                 if i > 0:
                     ops.conv_dx(dz2, self._kviews[i], tuple(x.shape), l.stride, s.dcol, s.dxs[i],
                                 mask_src=x if prev_act else None, mask_act=prev_act)
                     dz = s.dxs[i]
+        if side_stream is not main:
+            main.wait_stream(side_stream)
 
     def _first_div(self):
         for l in self._layers:

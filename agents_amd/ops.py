@@ -18,14 +18,18 @@ ACT = {None: AA_ACT_NONE, "none": AA_ACT_NONE, "linear": AA_ACT_NONE, "relu": AA
 
 
 class _Workspace:
-    """Grow-only scratch buffer per device (split-K slabs, column-sum partials)."""
+    """Grow-only scratch buffer per (device, stream): split-K slabs, column-sum partials.  GEMMs
+    enqueued on different streams run concurrently, so each stream owns its scratch."""
 
     def __init__(self):
         self._buf = {}
         self._retired = []  # outgrown buffers stay alive: captured HIP graphs may point at them
 
     def get(self, nbytes, device):
-        key = (device.type, device.index)
+        # registered side streams own a scratch each; every other stream (the default stream, a
+        # graph-capture stream) is the "main" line of execution and shares one
+        sid = torch.cuda.current_stream(device).cuda_stream
+        key = (device.type, device.index, sid if sid in _SIDE_STREAMS else 0)
         buf = self._buf.get(key)
         if buf is None or buf.numel() < nbytes:
             if torch.cuda.is_current_stream_capturing():
@@ -36,6 +40,16 @@ class _Workspace:
             buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
             self._buf[key] = buf
         return buf
+
+
+_SIDE_STREAMS = set()
+
+
+def new_side_stream(device):
+    """A stream for work that overlaps with the caller's stream (fork/join by wait_stream)."""
+    st = torch.cuda.Stream(device=device)
+    _SIDE_STREAMS.add(st.cuda_stream)
+    return st
 
 
 _WS = _Workspace()
@@ -62,6 +76,16 @@ def _img_pitch(x):
     if x.stride(3) != 1 or x.stride(2) != C or x.stride(1) != W * C:
         raise ValueError("conv input images must be dense NHWC (only the batch dim may be strided)")
     return x.stride(0) if Bn > 1 else H * W * C
+
+
+def _bias_grad_ptr(bias_grad, n):
+    if bias_grad is None:
+        return None
+    require_cuda(bias_grad)
+    _f32c(bias_grad, "bias_grad")
+    if bias_grad.numel() != n:
+        raise ValueError(f"bias_grad must have {n} elements, got {bias_grad.numel()}")
+    return ptr(bias_grad)
 
 
 def gemm_desc(**kw):
@@ -114,8 +138,8 @@ def dense_dx(dz, w, out, mask_src=None, mask_act=None, force_cfg=0, force_splits
     return out
 
 
-def dense_dw(x, dz, out, force_cfg=0, force_splits=0):
-    """out[K,N] = x[M,K]^T @ dz[M,N]."""
+def dense_dw(x, dz, out, force_cfg=0, force_splits=0, bias_grad=None):
+    """out[K,N] = x[M,K]^T @ dz[M,N]; bias_grad[N] = sum_m dz[m, :] (fused, optional)."""
     require_cuda(x, dz, out)
     lda = _rows_ok(x, "x"); _f32c(dz, "dz"); _f32c(out, "out")
     M, K = x.shape
@@ -124,7 +148,7 @@ def dense_dw(x, dz, out, force_cfg=0, force_splits=0):
         raise ValueError("dense_dw shape mismatch")
     d = gemm_desc(A=ptr(x), B=ptr(dz), C=ptr(out), M=K, N=N, K=M, lda=lda, ldb=N, ldc=N,
                   a_mode=AA_A_COL, b_mode=AA_B_ROW, force_cfg=force_cfg,
-                  force_splits=force_splits)
+                  force_splits=force_splits, colsum_out=_bias_grad_ptr(bias_grad, N))
     gemm(d, x.device)
     return out
 
@@ -169,8 +193,10 @@ def conv_forward(x, w, bias, stride, act, out, a_div=255.0, force_cfg=0, force_s
     return out
 
 
-def conv_dw(x, dz, w_shape, stride, out, a_div=255.0, force_cfg=0, force_splits=0):
-    """out[KH,KW,Cin,Cout] = patches(x)^T @ dz[B*OH*OW, Cout]."""
+def conv_dw(x, dz, w_shape, stride, out, a_div=255.0, force_cfg=0, force_splits=0,
+            bias_grad=None):
+    """out[KH,KW,Cin,Cout] = patches(x)^T @ dz[B*OH*OW, Cout]; bias_grad[Cout] = column sums of
+    dz (fused, optional)."""
     require_cuda(x, dz, out)
     KH, KW, Cin, Cout = w_shape
     Bn, H, W, C = x.shape
@@ -183,7 +209,8 @@ def conv_dw(x, dz, w_shape, stride, out, a_div=255.0, force_cfg=0, force_splits=
     d = gemm_desc(A=ptr(x), B=ptr(dz), C=ptr(out), M=Kp, N=Cout, K=Bn * OH * OW, lda=0, ldb=Cout,
                   ldc=Cout, a_mode=mode, b_mode=AA_B_ROW, n_img=Bn, H=H, W=W, Cin=C, KH=KH, KW=KW,
                   stride=stride, img_pitch=_img_pitch(x), a_div=float(a_div),
-                  force_cfg=force_cfg, force_splits=force_splits)
+                  force_cfg=force_cfg, force_splits=force_splits,
+                  colsum_out=_bias_grad_ptr(bias_grad, Cout))
     gemm(d, x.device)
     return out
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 1
+#define AA_ABI_VERSION 2
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -102,8 +102,12 @@ typedef struct aa_gemm_desc {
   const float* mask_src;  /* nullable: forward OUTPUT of the layer whose activation is undone */
   int32_t ldm;
   int32_t mask_kind;
-  int32_t force_cfg;      /* 0 = auto; 1 = 128x64, 2 = 128x32, 3 = 64x64 tile */
+  int32_t force_cfg;      /* 0 = auto; 1..7 = 128x64, 128x32, 64x64, 128x128, 64x32, 32x64, 32x32 */
   int32_t force_splits;   /* 0 = auto split-K */
+  /* nullable, AA_B_ROW only: colsum_out[n] = sum_k B(k,n).  With B = dZ this is the bias
+   * gradient (tf.GradientTape of keras BiasAdd), produced by the weight-gradient GEMM that
+   * streams dZ anyway instead of by a second pass over it. */
+  float* colsum_out;
 } aa_gemm_desc;
 
 int64_t aa_gemm_f32_workspace_bytes(const aa_gemm_desc* d);

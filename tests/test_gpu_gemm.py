@@ -48,7 +48,10 @@ def test_dense_forward(dev, M, N, K, act):
     close(out, act_ref(x.double() @ w.double() + b.double(), act))
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3])
+ALL_CFGS = [1, 2, 3, 4, 5, 6, 7]  # 128x64, 128x32, 64x64, 128x128, 64x32(k2), 32x64(k2), 32x32(k4)
+
+
+@pytest.mark.parametrize("cfg", ALL_CFGS)
 @pytest.mark.parametrize("splits", [1, 3])
 def test_dense_forward_forced_configs(dev, cfg, splits):
     rng = np.random.default_rng(cfg * 10 + splits)
@@ -78,6 +81,32 @@ def test_dense_dw(dev, M, N, K):
     out = torch.empty(K, N, device=dev)
     ops.dense_dw(x.to(dev), dz.to(dev), out)
     close(out, x.double().T @ dz.double())
+
+
+@pytest.mark.parametrize("cfg", ALL_CFGS)
+@pytest.mark.parametrize("splits", [1, 2, 5])
+def test_dense_dw_fused_bias_grad(dev, cfg, splits):
+    """bias_grad = column sums of dz, produced by the dW GEMM (all tiles, with and without
+    split-K; ragged M/N/K so edge tiles and the zero-padded K tail are covered)."""
+    rng = np.random.default_rng(cfg * 100 + splits)
+    M, N, K = 333, 70, 150  # x[M,K], dz[M,N]
+    x, dz = rnd(rng, M, K), rnd(rng, M, N)
+    out = torch.empty(K, N, device=dev)
+    bg = torch.full((N,), float("nan"), device=dev)
+    ops.dense_dw(x.to(dev), dz.to(dev), out, force_cfg=cfg, force_splits=splits, bias_grad=bg)
+    close(out, x.double().T @ dz.double())
+    close(bg, dz.double().sum(0), tol=5e-6)
+
+
+@pytest.mark.parametrize("cfg", ALL_CFGS)
+def test_dense_dx_forced_configs(dev, cfg):
+    rng = np.random.default_rng(cfg)
+    M, N, K = 130, 40, 210
+    dz, w = rnd(rng, M, N), rnd(rng, K, N) * 0.1
+    y = torch.tanh(rnd(rng, M, K))
+    out = torch.empty(M, K, device=dev)
+    ops.dense_dx(dz.to(dev), w.to(dev), out, mask_src=y.to(dev), mask_act="tanh", force_cfg=cfg)
+    close(out, (dz.double() @ w.double().T) * actgrad_ref(y.double(), "tanh"))
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
@@ -141,15 +170,44 @@ def test_conv_forward_strided_batch(dev):
     close(out, conv_ref(x5[:, 1].cpu(), w, b, 4, 255.0))
 
 
+@pytest.mark.parametrize("cfg", CONVS[:3])
+@pytest.mark.parametrize("tile", ALL_CFGS)
+def test_conv_forward_forced_configs(dev, cfg, tile):
+    rng = np.random.default_rng(sum(cfg[:8]) + tile)
+    x, w, b = make_conv(rng, cfg)
+    B, H, W, C, KH, KW, s, Fo, dt = cfg
+    OH, OW = ops.conv_out_hw(H, W, KH, KW, s)
+    out = torch.empty(B, OH, OW, Fo, device=dev)
+    ops.conv_forward(x.to(dev), w.to(dev), b.to(dev), s, "relu", out, a_div=255.0,
+                     force_cfg=tile, force_splits=2)
+    close(out, torch.relu(conv_ref(x, w, b, s, 255.0)))
+
+
+def test_conv_u8_division_is_exact(dev):
+    """(float)u8 / 255 inside the conv1 loader must be the IEEE quotient (the reference's
+    tf.cast(obs, float32) / 255.): a 1x1 'conv' with identity weights returns it unchanged."""
+    x = torch.arange(256, dtype=torch.uint8).repeat(16).reshape(1, 16, 16, 16).contiguous()
+    w = torch.eye(16).reshape(1, 1, 16, 16).contiguous()
+    for div in (255.0, 3.0, 1.0, 127.5):
+        out = torch.empty(1, 16, 16, 16, device=dev)
+        ops.conv_forward(x.to(dev), w.to(dev), None, 1, None, out, a_div=div)
+        want = x.float() / np.float32(div)
+        assert torch.equal(out.cpu(), want), div
+
+
 @pytest.mark.parametrize("cfg", CONVS)
-def test_conv_dw(dev, cfg):
+@pytest.mark.parametrize("tile,splits", [(0, 0), (1, 4), (5, 1), (7, 3), (4, 2)])
+def test_conv_dw(dev, cfg, tile, splits):
     rng = np.random.default_rng(sum(cfg[:8]) + 1)
     x, w, b = make_conv(rng, cfg)
     B, H, W, C, KH, KW, s, Fo, dt = cfg
     OH, OW = ops.conv_out_hw(H, W, KH, KW, s)
     dz = rnd(rng, B, OH, OW, Fo)
     out = torch.empty(KH, KW, C, Fo, device=dev)
-    ops.conv_dw(x.to(dev), dz.to(dev).view(-1, Fo), (KH, KW, C, Fo), s, out, a_div=255.0)
+    bg = torch.full((Fo,), float("nan"), device=dev)
+    ops.conv_dw(x.to(dev), dz.to(dev).view(-1, Fo), (KH, KW, C, Fo), s, out, a_div=255.0,
+                force_cfg=tile, force_splits=splits, bias_grad=bg)
+    close(bg, dz.double().sum((0, 1, 2)), tol=5e-6)
     xf = (x.double() / 255.0 if dt == torch.uint8 else x.double()).requires_grad_(False)
     wd = w.double().requires_grad_(True)
     y = F.conv2d(xf.permute(0, 3, 1, 2), wd.permute(3, 2, 0, 1), None, stride=s)
