@@ -234,7 +234,7 @@ def main():
                     help="replay frames per env (3906 x 256 envs = the 1M-row config)")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--envs", type=int, default=256)
-    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--prefill", type=int, default=-1, help="frames per env to prefill (-1 = all)")
@@ -348,13 +348,20 @@ def main():
                                              "frac": g[3] / g[1] / 1e6 / HBM_PEAK_GBS,
                                              "avg_launch_ms": g[1]}
         if not args.no_cpu_baseline and world == 1:
-            threads = max(1, os.cpu_count() or 1)
+            # torch-CPU convolutions at batch 256 stop scaling (and collapse when every hardware
+            # thread of a 256-core host is used): probe a few thread counts, keep the fastest
+            ncpu = max(1, os.cpu_count() or 1)
+            cands = sorted({min(ncpu, t) for t in (8, 16, 32, 64)})
+            probe = {t: cpu_baseline(S, 2, t)[1] for t in cands}
+            threads = min(probe, key=probe.get)
             v, spstep = cpu_baseline(S, args.cpu_steps, threads)
             out["cpu_baseline"] = {
                 "value": v, "unit": "samples/s", "cores": threads, "kind": "port",
+                "learner_steps_per_sec": v / S,
                 "sample": f"{args.cpu_steps} iterations (collect 256 envs + sample 256x2 + train "
-                          f"batch 256) of the numpy/torch-CPU oracle, {spstep:.2f} s/iteration, "
-                          "replay ring shortened to 8 frames/env"}
+                          f"batch 256) of the numpy/torch-CPU oracle on {threads} of {ncpu} host "
+                          f"threads (fastest of {cands}), {spstep:.3f} s/iteration, replay ring "
+                          "shortened to 8 frames/env"}
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
