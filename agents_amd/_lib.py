@@ -39,7 +39,7 @@ class GemmDesc(Structure):
         ("bias", c_void_p), ("act", c_int32),
         ("mask_src", c_void_p), ("ldm", c_int32), ("mask_kind", c_int32),
         ("force_cfg", c_int32), ("force_splits", c_int32),
-        ("colsum_out", c_void_p),
+        ("colsum_out", c_void_p), ("no_dma", c_int32),
     ]
 
 

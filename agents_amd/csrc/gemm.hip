@@ -55,6 +55,7 @@ struct GemmP {
   int a_fast;        // (float)u8 / a_div == fma-refined product for all 256 bytes (host-verified)
   unsigned magic_ohw, magic_ow, magic_seg;  // ceil(2^32/d): n / d == mulhi(n, magic) (host-verified range)
   int fastdiv;
+  int use_dma;       // operands allow the LDS-DMA main loop (16-byte granules everywhere)
   unsigned a_bytes, b_bytes;  // operand extents for the buffer resources (< 2^31, host-checked)
   float* colsum_out; // nullable: sum_k B(k,n) (bias gradient fused into the dW GEMM)
   int k_per_split;
@@ -313,6 +314,8 @@ __device__ static inline void store_D_patchT_u8(const StageU8& s, float* tile, c
     *reinterpret_cast<float4*>(d + 4 * i) = f;
   }
 }
+
+#include "gemm_dma.h"
 
 // ------------------------------------------------------------------------------------------
 template <int AM, int BMODE, int BM, int BN, int WGM, int WGN, int WGK, int PD, int VEC>
@@ -714,6 +717,18 @@ static void aa_gemm_launch_pd(const GemmP& p, const AaGemmPlan& pl, hipStream_t 
 template <int AM, int BMODE, int BM, int BN, int WGM, int WGN, int WGK>
 static void aa_gemm_launch_one(const GemmP& p, const AaGemmPlan& pl, hipStream_t st) {
   constexpr bool dense = AM == AA_A_ROW || AM == AA_A_COL;
+  if (p.use_dma) {
+    constexpr int AK = AM == AA_A_ROW ? AA_KIND_T_DENSE
+                     : AM == AA_A_COL ? AA_KIND_D_DENSE
+                     : AM == AA_A_PATCH ? AA_KIND_T_PATCH
+                     : AM == AA_A_PATCH_U8 ? AA_KIND_T_PATCH_U8
+                     : AM == AA_A_PATCH_T ? AA_KIND_D_PATCHT : AA_KIND_D_PATCHT_U8;
+    constexpr int BKIND = BMODE == AA_B_ROW ? AA_KIND_D_DENSE : AA_KIND_T_DENSE;
+    constexpr int STAGE = DmaOp<AK, BM>::kPadded + DmaOp<BKIND, BN>::kPadded;
+    constexpr int NS = STAGE * 4 <= 65536 ? 4 : (STAGE * 3 <= 65536 ? 3 : 2);
+    aa_gemm_dma_launch<AK, BKIND, BM, BN, WGM, WGN, WGK, NS>(p, pl.splits, st);
+    return;
+  }
   // dense operands that are ragged / unaligned use 4-byte loads (conv patches are always vectors)
   if (!(p.b_vec && (p.a_vec || !dense))) {
     aa_gemm_launch_pd<AM, BMODE, BM, BN, WGM, WGN, WGK, 2, 0>(p, pl, st);
@@ -840,6 +855,9 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
     p.a_bytes = (unsigned)a_span;
     p.b_bytes = (unsigned)b_span;
   }
+  // LDS-DMA main loop for 16-byte-regular operands; contractions with only a few K-steps are
+  // epilogue-bound and run better on the register-staged loop (smaller LDS, more groups per CU)
+  p.use_dma = (p.b_vec && (p.a_vec || patch) && !d->no_dma && d->K > 128) ? 1 : 0;
   p.k_per_split = pl.k_per_split;
   p.splits = pl.splits;
   p.bias = d->bias;

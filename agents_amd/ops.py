@@ -95,8 +95,19 @@ def gemm_desc(**kw):
     return d
 
 
+# Test / tuning knob: True forces the register-staged GEMM main loop (aa_gemm_desc.no_dma) so the
+# two main loops can be compared on identical inputs.  The default is the LDS-DMA loop.
+FORCE_NO_DMA = False
+# a_mode values whose contractions take the LDS-DMA loop (tuning knob, env AA_DMA_MODES="3,4,5")
+import os as _os
+_DMA_MODES = _os.environ.get("AA_DMA_MODES")
+_DMA_MODES = None if _DMA_MODES is None else {int(x) for x in _DMA_MODES.split(",") if x != ""}
+
+
 def gemm(desc, device):
     lib = _lib.load()
+    if FORCE_NO_DMA or (_DMA_MODES is not None and desc.a_mode not in _DMA_MODES):
+        desc.no_dma = 1
     need = lib.aa_gemm_f32_workspace_bytes(ctypes.byref(desc))
     if need < 0:
         raise ValueError("aa_gemm_f32: invalid descriptor (M,N,K must be positive)")

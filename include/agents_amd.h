@@ -108,6 +108,8 @@ typedef struct aa_gemm_desc {
    * gradient (tf.GradientTape of keras BiasAdd), produced by the weight-gradient GEMM that
    * streams dZ anyway instead of by a second pass over it. */
   float* colsum_out;
+  int32_t no_dma;         /* 1 = force the register-staged main loop (default 0: operands that are
+                           * 16-byte regular go HBM -> LDS by buffer_load ... lds DMA) */
 } aa_gemm_desc;
 
 int64_t aa_gemm_f32_workspace_bytes(const aa_gemm_desc* d);

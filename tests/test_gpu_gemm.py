@@ -251,3 +251,75 @@ def test_mfma_layout_transpose_detecting(dev):
     out = torch.empty(n, 40, device=dev)
     ops.dense_forward(eye.to(dev), b.to(dev), None, None, out)
     assert torch.equal(out.cpu(), b)
+
+
+# ---- LDS-DMA main loop (gemm_dma.h): ragged but 16-byte-regular shapes, every tile, both loops ----
+@pytest.fixture
+def both_loops():
+    """Runs the body twice: LDS-DMA main loop (default) and register-staged loop."""
+    yield
+    ops.FORCE_NO_DMA = False
+
+
+DMA_SHAPES = [(200, 72, 300), (33, 36, 4), (260, 132, 68), (64, 64, 32), (1, 4, 4)]
+
+
+@pytest.mark.parametrize("M,N,K", DMA_SHAPES)
+@pytest.mark.parametrize("cfg", [0] + ALL_CFGS)
+@pytest.mark.parametrize("splits", [0, 3])
+def test_dma_dense_all_modes(dev, both_loops, M, N, K, cfg, splits):
+    """Forward (A_ROW x B_ROW), dX (A_ROW x B_COL) and dW (A_COL x B_ROW, fused bias gradient)
+    through the LDS-DMA loop with ragged M / N / K edges (zero fill must come from the DMA range
+    check), and the register-staged loop on the same inputs."""
+    if (cfg == 0) != (splits == 0):
+        pytest.skip("auto plan only with auto splits")
+    rng = np.random.default_rng(M * 5 + N * 3 + K + cfg)
+    x, w, b = rnd(rng, M, K), rnd(rng, K, N) * 0.1, rnd(rng, N)
+    dz = rnd(rng, M, N)
+    y = torch.tanh(rnd(rng, M, K))
+    res = {}
+    for no_dma in (False, True):
+        ops.FORCE_NO_DMA = no_dma
+        out = torch.full((M, N), float("nan"), device=dev)
+        ops.dense_forward(x.to(dev), w.to(dev), b.to(dev), "relu", out, force_cfg=cfg,
+                          force_splits=splits)
+        close(out, torch.relu(x.double() @ w.double() + b.double()))
+        dx = torch.full((M, K), float("nan"), device=dev)
+        ops.dense_dx(dz.to(dev), w.to(dev), dx, mask_src=y.to(dev), mask_act="tanh",
+                     force_cfg=cfg, force_splits=splits)
+        close(dx, (dz.double() @ w.double().T) * actgrad_ref(y.double(), "tanh"))
+        dw = torch.full((K, N), float("nan"), device=dev)
+        bg = torch.full((N,), float("nan"), device=dev)
+        ops.dense_dw(x.to(dev), dz.to(dev), dw, force_cfg=cfg, force_splits=splits, bias_grad=bg)
+        close(dw, x.double().T @ dz.double())
+        close(bg, dz.double().sum(0), tol=5e-6)
+        res[no_dma] = (out.cpu(), dx.cpu(), dw.cpu())
+    # the two loops agree to fp32 summation-order noise
+    for a, b2 in zip(res[False], res[True]):
+        close(a, b2.double(), tol=1e-5)
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 6, 7])
+def test_dma_conv_forward_and_dw(dev, both_loops, cfg, tile):
+    rng = np.random.default_rng(sum(cfg[:8]) + 7 * tile)
+    x, w, b = make_conv(rng, cfg)
+    B, H, W, C, KH, KW, s, Fo, dt = cfg
+    OH, OW = ops.conv_out_hw(H, W, KH, KW, s)
+    dz = rnd(rng, B, OH, OW, Fo)
+    xf = x.double() / 255.0 if dt == torch.uint8 else x.double()
+    wd = w.double().requires_grad_(True)
+    yref = F.conv2d(xf.permute(0, 3, 1, 2), wd.permute(3, 2, 0, 1), None, stride=s)
+    gref, = torch.autograd.grad(yref, wd, dz.double().permute(0, 3, 1, 2))
+    for no_dma in (False, True):
+        ops.FORCE_NO_DMA = no_dma
+        out = torch.full((B, OH, OW, Fo), float("nan"), device=dev)
+        ops.conv_forward(x.to(dev), w.to(dev), b.to(dev), s, "relu", out, a_div=255.0,
+                         force_cfg=tile, force_splits=0 if tile == 0 else 2)
+        close(out, torch.relu(conv_ref(x, w, b, s, 255.0)))
+        g = torch.full((KH, KW, C, Fo), float("nan"), device=dev)
+        bg = torch.full((Fo,), float("nan"), device=dev)
+        ops.conv_dw(x.to(dev), dz.to(dev).view(-1, Fo), (KH, KW, C, Fo), s, g, a_div=255.0,
+                    force_cfg=tile, force_splits=0 if tile == 0 else 3, bias_grad=bg)
+        close(g, gref)
+        close(bg, dz.double().sum((0, 1, 2)), tol=5e-6)

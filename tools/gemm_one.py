@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Runs one contraction of the DQN-Atari step N times (for rocprofv3 --pmc / --kernel-trace).
+  python tools/gemm_one.py conv2.fwd [--reps 20] [--cfg 0] [--splits 0] [--no-dma]"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from agents_amd import ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("name")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--cfg", type=int, default=0)
+    ap.add_argument("--splits", type=int, default=0)
+    ap.add_argument("--no-dma", action="store_true")
+    args = ap.parse_args()
+    ops.FORCE_NO_DMA = args.no_dma
+    S = 256
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    c, s = args.cfg, args.splits
+    if args.name == "conv1.fwd":
+        obs = torch.randint(0, 256, (S, 84, 84, 4), dtype=torch.uint8, generator=g).to(dev)
+        w, b, y = r(8, 8, 4, 32), r(32), r(S, 20, 20, 32)
+        fn = lambda: ops.conv_forward(obs, w, b, 4, "relu", y, a_div=255.0, force_cfg=c,
+                                      force_splits=s)
+    elif args.name == "conv2.fwd":
+        x, w, b, y = r(S, 20, 20, 32), r(4, 4, 32, 64), r(64), r(S, 9, 9, 64)
+        fn = lambda: ops.conv_forward(x, w, b, 2, "relu", y, force_cfg=c, force_splits=s)
+    elif args.name == "fc1.dW":
+        x, dz, gk = r(S, 3136), r(S, 512), r(3136, 512)
+        fn = lambda: ops.dense_dw(x, dz, gk, force_cfg=c, force_splits=s)
+    elif args.name == "conv1.dW":
+        obs = torch.randint(0, 256, (S, 84, 84, 4), dtype=torch.uint8, generator=g).to(dev)
+        dz, gk = r(S * 400, 32), r(8, 8, 4, 32)
+        fn = lambda: ops.conv_dw(obs, dz, (8, 8, 4, 32), 4, gk, a_div=255.0, force_cfg=c,
+                                 force_splits=s)
+    else:
+        raise SystemExit("unknown case")
+    for _ in range(args.reps):
+        fn()
+    torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()

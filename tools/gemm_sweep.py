@@ -44,7 +44,9 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--cfgs", default="0,1,2,3,4,5,6,7")
     ap.add_argument("--splits", default="0,1,2,3,4,6,8,12,16,24,32")
+    ap.add_argument("--no-dma", action="store_true", help="register-staged main loop")
     args = ap.parse_args()
+    ops.FORCE_NO_DMA = args.no_dma
     S = args.batch
     dev = torch.device("cuda", 0)
     g = torch.Generator(device="cpu").manual_seed(0)
