@@ -18,6 +18,7 @@ AA_B_ROW, AA_B_COL = 0, 1
 AA_LOSS_HUBER, AA_LOSS_SQUARED = 0, 1
 AA_OBS_U8, AA_OBS_F32 = 0, 1
 AA_PPO_NSTATS = 8
+AA_PPO_DIST_STATS = 16 + 6 * 256
 
 _ERRORS = {-22: "AA_ERR_INVALID (bad argument)", -34: "AA_ERR_RANGE (size / workspace)",
            -5: "AA_ERR_LAUNCH (HIP launch failure)"}
@@ -92,6 +93,17 @@ _SIGNATURES = {
     "aa_ppo_loss": (c_int, [c_void_p] * 11 + [c_int64, c_int32] + [c_float] * 6 + [c_int32] +
                     [c_void_p] * 5),
     "aa_add_l2_grad": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    "aa_ppo_loss_dist": (c_int, [c_void_p] * 11 + [c_int64, c_int32] + [c_float] * 6 +
+                         [c_void_p, c_float, c_float] + [c_void_p] * 5),
+    "aa_ppo_head_forward": (c_int, [c_void_p] * 4 + [c_int64, c_int32] + [c_void_p] * 3),
+    "aa_ppo_head_backward": (c_int, [c_void_p] * 5 + [c_int64, c_int32] + [c_void_p] * 3),
+    "aa_normal_log_prob": (c_int, [c_void_p] * 3 + [c_int64, c_int32, c_void_p, c_void_p]),
+    "aa_normal_sample": (c_int, [c_void_p, c_void_p, c_int64, c_uint64, c_void_p, c_void_p,
+                                 c_void_p]),
+    "aa_ppo_discounts": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int64, c_void_p,
+                                 c_void_p]),
+    "aa_ppo_trajectory_mask": (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p]),
+    "aa_ppo_update_kl_beta": (c_int, [c_void_p, c_float, c_float, c_void_p, c_void_p]),
 }
 
 _lib = None

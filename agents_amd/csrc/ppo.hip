@@ -158,6 +158,289 @@ aa_axpy_kernel(float* __restrict__ g, const float* __restrict__ p, int64_t n, fl
     g[i] = g[i] + c * p[i];
 }
 
+
+// =============================================================================================
+// General diagonal-Normal form: the actor network hands over loc[N,D] and scale[N,D] (any head:
+// PPOActorNetwork, NormalProjectionNetwork, the reference tests' DummyActorNet) and gets the
+// gradients wrt both back.  Adds the KL penalty terms of PPOAgent:
+//   kl_penalty_loss / kl_cutoff_loss / adaptive_kl_loss   ppo_agent.py:1514-1640
+//   _kl_divergence -> ppo_utils.nested_kl_divergence        ppo_utils.py:194-227
+//   TFP kl_normal_normal closed form (third-party, restated):
+//     kl(a||b) = 0.5*((mu_a - mu_b)/sigma_b)^2 + 0.5*expm1(2*(log sigma_a - log sigma_b))
+//                - (log sigma_a - log sigma_b)
+// Three launches: forward sums -> scalars (+ the KL gradient coefficient, which depends on the
+// batch mean) -> per-sample gradients.
+// =============================================================================================
+#define AA_PPO_NSUM 6   // pg, value, entropy, clip count, entropy*w, kl*w
+
+struct PpoDistArgs {
+  const float *loc, *scale, *old_loc, *old_scale, *actions, *old_logp, *adv, *returns, *vpred,
+      *old_vpred, *weights;
+  int64_t N;
+  int D;
+  float clip_eps, value_clip, c_v, c_e, denom, logp_clip;
+};
+
+__device__ static inline void aa_ppo_sample_terms(const PpoDistArgs& a, int64_t i, float* lp_out,
+                                                  float* ent_out, float* kl_out) {
+  float lp = 0.f, ent = 0.f, kl = 0.f;
+  for (int d = 0; d < a.D; ++d) {
+    const float mu = a.loc[i * a.D + d], sc = a.scale[i * a.D + d];
+    const float ls = logf(sc);
+    const float diff = a.actions[i * a.D + d] / sc - mu / sc;
+    lp += -0.5f * (diff * diff) - (AA_HALF_LOG_2PI + ls);
+    ent += 0.5f + AA_HALF_LOG_2PI + ls;
+    if (a.old_loc != nullptr) {
+      const float mo = a.old_loc[i * a.D + d], so = a.old_scale[i * a.D + d];
+      const float dl = logf(so) - ls;
+      const float dm = mo / sc - mu / sc;
+      kl += 0.5f * (dm * dm) + 0.5f * expm1f(2.0f * dl) - dl;
+    }
+  }
+  *lp_out = lp;
+  *ent_out = ent;
+  *kl_out = kl;
+}
+
+__global__ void __launch_bounds__(256)
+aa_ppo_dist_fwd_kernel(PpoDistArgs a, float* __restrict__ partial) {
+  __shared__ float red[16];
+  float s[AA_PPO_NSUM] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.N; i += stride) {
+    const float w = a.weights != nullptr ? a.weights[i] : 1.0f;
+    float lp, ent, kl;
+    aa_ppo_sample_terms(a, i, &lp, &ent, &kl);
+    if (a.logp_clip > 0.f) lp = fminf(fmaxf(lp, -a.logp_clip), a.logp_clip);
+    const float adv = a.adv[i];
+    const float ratio = expf(lp - a.old_logp[i]);
+    const float ratio_c = fminf(fmaxf(ratio, 1.0f - a.clip_eps), 1.0f + a.clip_eps);
+    float pg;
+    if (a.clip_eps > 0.f) {
+      pg = -fminf(ratio * adv, ratio_c * adv);
+      s[3] += fabsf(ratio - 1.0f) > a.clip_eps ? 1.0f : 0.0f;
+    } else {
+      pg = -(ratio * adv);
+    }
+    s[0] += (w == 0.f) ? 0.f : pg * w;
+    const float R = a.returns[i], V = a.vpred[i];
+    float verr = (R - V) * (R - V);
+    if (a.value_clip > 0.f && a.old_vpred != nullptr) {
+      const float ov = a.old_vpred[i];
+      const float Vc = ov + fminf(fmaxf(V - ov, -a.value_clip), a.value_clip);
+      verr = fmaxf(verr, (R - Vc) * (R - Vc));
+    }
+    s[1] += (w == 0.f) ? 0.f : verr * w;
+    s[2] += (w == 0.f) ? 0.f : (-ent) * w;
+    s[4] += ent * w;
+    s[5] += kl * w;
+  }
+  for (int k = 0; k < AA_PPO_NSUM; ++k) {
+    const float t = aa_block_sum(s[k], red);
+    if (threadIdx.x == 0) partial[blockIdx.x * AA_PPO_NSUM + k] = t;
+  }
+}
+
+// stats: [0] policy_gradient_loss [1] value_estimation_loss [2] entropy_regularization_loss
+// [3] clip_fraction [4] mean(entropy*w) [5] kl_penalty_loss [6] total [7] mean(kl*w)
+// [8] d loss / d mean(kl*w) [9] adaptive_kl_loss [10] kl_cutoff_loss
+__global__ void aa_ppo_dist_finish_kernel(const float* __restrict__ partial, int P, float denom,
+                                          float n_elems, float c_v, float c_e,
+                                          const float* __restrict__ kl_beta, float kl_cutoff_coef,
+                                          float kl_cutoff, float* __restrict__ stats) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s[AA_PPO_NSUM] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < P; ++p)
+    for (int k = 0; k < AA_PPO_NSUM; ++k) s[k] += partial[p * AA_PPO_NSUM + k];
+  const float pg = s[0] / denom;
+  const float v = (s[1] / denom) * c_v;
+  const float e = c_e > 0.f ? (s[2] / denom) * c_e : 0.f;
+  const float mean_kl = s[5] / n_elems;
+  const float beta = kl_beta != nullptr ? kl_beta[0] : 0.f;
+  const float adaptive = beta * mean_kl;
+  float cutoff_loss = 0.f, dcut = 0.f;
+  if (kl_cutoff_coef > 0.f && kl_cutoff > 0.f) {
+    const float over = fmaxf(mean_kl - kl_cutoff, 0.0f);
+    cutoff_loss = kl_cutoff_coef * (over * over);
+    dcut = 2.0f * kl_cutoff_coef * over;
+  }
+  stats[0] = pg;
+  stats[1] = v;
+  stats[2] = e;
+  stats[3] = s[3] / n_elems;
+  stats[4] = s[4] / n_elems;
+  stats[5] = adaptive + cutoff_loss;
+  stats[6] = pg + v + e + adaptive + cutoff_loss;
+  stats[7] = mean_kl;
+  stats[8] = beta + dcut;
+  stats[9] = adaptive;
+  stats[10] = cutoff_loss;
+}
+
+__global__ void __launch_bounds__(256)
+aa_ppo_dist_bwd_kernel(PpoDistArgs a, const float* __restrict__ stats, float n_elems,
+                       float* __restrict__ dloc, float* __restrict__ dscale,
+                       float* __restrict__ dv) {
+  const float kl_coef = stats[8] / n_elems;  // d loss / d (kl_i * w_i)
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.N; i += stride) {
+    const float w = a.weights != nullptr ? a.weights[i] : 1.0f;
+    float lp, ent, kl;
+    aa_ppo_sample_terms(a, i, &lp, &ent, &kl);
+    bool lp_live = true;
+    float lp_c = lp;
+    if (a.logp_clip > 0.f) {
+      lp_c = fminf(fmaxf(lp, -a.logp_clip), a.logp_clip);
+      lp_live = (lp >= -a.logp_clip) && (lp <= a.logp_clip);
+    }
+    const float adv = a.adv[i];
+    const float ratio = expf(lp_c - a.old_logp[i]);
+    const float ratio_c = fminf(fmaxf(ratio, 1.0f - a.clip_eps), 1.0f + a.clip_eps);
+    bool through = true;
+    if (a.clip_eps > 0.f) through = (ratio * adv) <= (ratio_c * adv);  // tf.minimum grad rule
+    float dlp = 0.f;
+    if (through && lp_live) dlp = -(adv * ratio) * w / a.denom;
+    const float R = a.returns[i], V = a.vpred[i];
+    float dverr = -2.0f * (R - V);
+    if (a.value_clip > 0.f && a.old_vpred != nullptr) {
+      const float ov = a.old_vpred[i];
+      const float dlt = V - ov;
+      const float Vc = ov + fminf(fmaxf(dlt, -a.value_clip), a.value_clip);
+      if ((R - Vc) * (R - Vc) > (R - V) * (R - V)) {  // tf.maximum: gradient to x when x >= y
+        const bool live = dlt >= -a.value_clip && dlt <= a.value_clip;
+        dverr = live ? -2.0f * (R - Vc) : 0.f;
+      }
+    }
+    dv[i] = a.c_v * dverr * w / a.denom;
+    const float dent = (a.c_e > 0.f) ? (-a.c_e * w / a.denom) : 0.f;
+    const float dkl = (a.old_loc != nullptr) ? kl_coef * w : 0.f;
+    for (int d = 0; d < a.D; ++d) {
+      const float mu = a.loc[i * a.D + d], sc = a.scale[i * a.D + d];
+      const float diff = a.actions[i * a.D + d] - mu;
+      float gl = dlp * (diff / (sc * sc));
+      float gs = dlp * ((diff * diff) / (sc * sc * sc) - 1.0f / sc) + dent * (1.0f / sc);
+      if (a.old_loc != nullptr) {
+        const float mo = a.old_loc[i * a.D + d], so = a.old_scale[i * a.D + d];
+        const float dm = mu - mo;
+        gl += dkl * (dm / (sc * sc));
+        gs += dkl * (-(dm * dm) / (sc * sc * sc) - (so * so) / (sc * sc * sc) + 1.0f / sc);
+      }
+      dloc[i * a.D + d] = gl;
+      dscale[i * a.D + d] = gs;
+    }
+  }
+}
+
+// PPOActorNetwork head (ppo_actor_network.py:42-113): loc = mean + mag*tanh(z) (or z when the
+// spec is unbounded / mean,mag null), scale = softplus(bias) broadcast over the batch.
+__global__ void __launch_bounds__(256)
+aa_ppo_head_fwd_kernel(const float* __restrict__ z, const float* __restrict__ std_bias,
+                       const float* __restrict__ act_mean, const float* __restrict__ act_mag,
+                       int64_t N, int D, float* __restrict__ loc, float* __restrict__ scale) {
+  const int64_t total = N * D, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int d = (int)(e % D);
+    const float zz = z[e];
+    loc[e] = act_mag != nullptr ? act_mean[d] + act_mag[d] * tanhf(zz) : zz;
+    scale[e] = aa_softplus(std_bias[d]);
+  }
+}
+__global__ void __launch_bounds__(256)
+aa_ppo_head_bwd_kernel(const float* __restrict__ z, const float* __restrict__ std_bias,
+                       const float* __restrict__ act_mag, const float* __restrict__ dloc,
+                       const float* __restrict__ dscale, int64_t N, int D,
+                       float* __restrict__ dz, float* __restrict__ dbias_elem) {
+  const int64_t total = N * D, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int d = (int)(e % D);
+    float g = dloc[e];
+    if (act_mag != nullptr) {
+      const float th = tanhf(z[e]);
+      g *= act_mag[d] * (1.0f - th * th);
+    }
+    dz[e] = g;
+    dbias_elem[e] = dscale[e] * (1.0f / (1.0f + expf(-std_bias[d])));  // softplus' = sigmoid
+  }
+}
+
+// log N(x; loc, scale) summed over D (common.log_probability, utils/common.py:682-717)
+__global__ void __launch_bounds__(256)
+aa_normal_log_prob_kernel(const float* __restrict__ loc, const float* __restrict__ scale,
+                          const float* __restrict__ x, int64_t N, int D,
+                          float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+    float lp = 0.f;
+    for (int d = 0; d < D; ++d) {
+      const float sc = scale[i * D + d];
+      const float diff = x[i * D + d] / sc - loc[i * D + d] / sc;
+      lp += -0.5f * (diff * diff) - (AA_HALF_LOG_2PI + logf(sc));
+    }
+    out[i] = lp;
+  }
+}
+
+// action = loc + scale * eps, eps ~ N(0,1) by Box-Muller on the package's Philox stream:
+// counter = (element index lo, hi, call counter lo, hi), key = seed; u1 from word 0, u2 from 1.
+__global__ void __launch_bounds__(256)
+aa_normal_sample_kernel(const float* __restrict__ loc, const float* __restrict__ scale,
+                        int64_t n, uint32_t seed_lo, uint32_t seed_hi,
+                        const int64_t* __restrict__ call_counter, float* __restrict__ out) {
+  const uint64_t call = (uint64_t)call_counter[0];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const Philox4 r = philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)call,
+                                    (uint32_t)(call >> 32), seed_lo, seed_hi);
+    const float u1 = 1.0f - aa_u01(r.x);  // (0, 1]
+    const float u2 = aa_u01(r.y);
+    const float eps = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    out[i] = loc[i] + scale[i] * eps;
+  }
+}
+
+// discounts for the return / GAE scans: discount * gamma * (next_step_type != LAST)
+// (ppo_agent.py:630-676, utils/common.py:883-895), over the first T of T+1 columns.
+__global__ void __launch_bounds__(256)
+aa_ppo_discounts_kernel(const float* __restrict__ discount, const int32_t* __restrict__ next_st,
+                        float gamma, int64_t B, int64_t T1, float* __restrict__ out) {
+  const int64_t T = T1 - 1, total = B * T, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t b = e / T, t = e - b * T;
+    const float d = discount[b * T1 + t] * gamma;
+    out[e] = d * (next_st[b * T1 + t] != 2 ? 1.0f : 0.0f);
+  }
+}
+// weights * ~is_boundary * ~(return == 0 & advantage == 0)   (ppo_utils.py:35-59)
+__global__ void __launch_bounds__(256)
+aa_ppo_mask_kernel(const int32_t* __restrict__ step_type, const float* __restrict__ ret,
+                   const float* __restrict__ adv, const float* __restrict__ weights, int64_t n,
+                   float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const bool valid = (step_type[i] != 2) && !(ret[i] == 0.f && adv[i] == 0.f);
+    const float m = valid ? 1.0f : 0.0f;
+    out[i] = weights != nullptr ? weights[i] * m : m;
+  }
+}
+// adaptive KL beta update (ppo_agent.py:1642-1690): x 1/1.5 below target*(1-tol), x 1.5 above
+// target*(1+tol), clipped to [1e-15, 1e17].
+__global__ void aa_ppo_update_beta_kernel(const float* __restrict__ mean_kl, float target,
+                                          float tol, float* __restrict__ beta) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float m = mean_kl[0];
+  float f = 1.0f;
+  if (m < target * (1.0f - tol)) f = 1.0f / 1.5f;
+  else if (m > target * (1.0f + tol)) f = 1.5f;
+  beta[0] = fminf(fmaxf(beta[0] * f, 10e-16f), 10e16f);
+}
+
+static inline unsigned aa_ew_blocks(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
 extern "C" {
 
 // stats must hold 8 + 5*256 floats (8 results + per-block partials).
@@ -194,6 +477,104 @@ int aa_add_l2_grad(float* g, const float* p, int64_t n, float c, void* stream) {
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(aa_axpy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g,
                      p, n, c);
+  return aa_launch_status();
+}
+
+
+#define AA_PPO_STATS 16
+// stats must hold AA_PPO_STATS + AA_PPO_NSUM*256 floats.
+int aa_ppo_loss_dist(const float* loc, const float* scale, const float* old_loc,
+                     const float* old_scale, const float* actions, const float* old_logp,
+                     const float* adv, const float* returns, const float* vpred,
+                     const float* old_vpred, const float* weights, int64_t N, int32_t D,
+                     float clip_eps, float value_clip, float c_v, float c_e, float denom,
+                     float logp_clip, const float* kl_beta_dev, float kl_cutoff_coef,
+                     float kl_cutoff, float* dloc, float* dscale, float* dv, float* stats,
+                     void* stream) {
+  if (!loc || !scale || !actions || !old_logp || !adv || !returns || !vpred || !stats)
+    return AA_ERR_INVALID;
+  if (N <= 0 || D <= 0 || !(denom > 0.f)) return AA_ERR_INVALID;
+  if ((old_loc == nullptr) != (old_scale == nullptr)) return AA_ERR_INVALID;
+  if ((dloc == nullptr) != (dscale == nullptr) || (dloc == nullptr) != (dv == nullptr))
+    return AA_ERR_INVALID;
+  PpoDistArgs a;
+  a.loc = loc; a.scale = scale; a.old_loc = old_loc; a.old_scale = old_scale;
+  a.actions = actions; a.old_logp = old_logp; a.adv = adv; a.returns = returns; a.vpred = vpred;
+  a.old_vpred = old_vpred; a.weights = weights; a.N = N; a.D = (int)D;
+  a.clip_eps = clip_eps; a.value_clip = value_clip; a.c_v = c_v; a.c_e = c_e; a.denom = denom;
+  a.logp_clip = logp_clip;
+  int P = (int)((N + 255) / 256);
+  if (P > AA_PPO_P) P = AA_PPO_P;
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = stats + AA_PPO_STATS;
+  hipLaunchKernelGGL(aa_ppo_dist_fwd_kernel, dim3(P), dim3(256), 0, st, a, partial);
+  hipLaunchKernelGGL(aa_ppo_dist_finish_kernel, dim3(1), dim3(64), 0, st, (const float*)partial,
+                     P, denom, (float)N, c_v, c_e, kl_beta_dev, kl_cutoff_coef, kl_cutoff, stats);
+  if (dloc != nullptr)
+    hipLaunchKernelGGL(aa_ppo_dist_bwd_kernel, dim3(P), dim3(256), 0, st, a,
+                       (const float*)stats, (float)N, dloc, dscale, dv);
+  return aa_launch_status();
+}
+
+int aa_ppo_head_forward(const float* z, const float* std_bias, const float* act_mean,
+                        const float* act_mag, int64_t N, int32_t D, float* loc, float* scale,
+                        void* stream) {
+  if (!z || !std_bias || !loc || !scale || N <= 0 || D <= 0) return AA_ERR_INVALID;
+  if ((act_mean == nullptr) != (act_mag == nullptr)) return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_ppo_head_fwd_kernel, dim3(aa_ew_blocks(N * D)), dim3(256), 0,
+                     (hipStream_t)stream, z, std_bias, act_mean, act_mag, N, (int)D, loc, scale);
+  return aa_launch_status();
+}
+
+int aa_ppo_head_backward(const float* z, const float* std_bias, const float* act_mag,
+                         const float* dloc, const float* dscale, int64_t N, int32_t D, float* dz,
+                         float* dbias_elem, void* stream) {
+  if (!z || !std_bias || !dloc || !dscale || !dz || !dbias_elem || N <= 0 || D <= 0)
+    return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_ppo_head_bwd_kernel, dim3(aa_ew_blocks(N * D)), dim3(256), 0,
+                     (hipStream_t)stream, z, std_bias, act_mag, dloc, dscale, N, (int)D, dz,
+                     dbias_elem);
+  return aa_launch_status();
+}
+
+int aa_normal_log_prob(const float* loc, const float* scale, const float* x, int64_t N, int32_t D,
+                       float* out, void* stream) {
+  if (!loc || !scale || !x || !out || N <= 0 || D <= 0) return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_normal_log_prob_kernel, dim3(aa_ew_blocks(N)), dim3(256), 0,
+                     (hipStream_t)stream, loc, scale, x, N, (int)D, out);
+  return aa_launch_status();
+}
+
+int aa_normal_sample(const float* loc, const float* scale, int64_t n, uint64_t seed,
+                     const int64_t* call_counter_dev, float* out, void* stream) {
+  if (!loc || !scale || !out || !call_counter_dev || n <= 0) return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_normal_sample_kernel, dim3(aa_ew_blocks(n)), dim3(256), 0,
+                     (hipStream_t)stream, loc, scale, n, (uint32_t)(seed & 0xffffffffu),
+                     (uint32_t)(seed >> 32), call_counter_dev, out);
+  return aa_launch_status();
+}
+
+int aa_ppo_discounts(const float* discount, const int32_t* next_step_type, float gamma, int64_t B,
+                     int64_t T1, float* out, void* stream) {
+  if (!discount || !next_step_type || !out || B <= 0 || T1 < 2) return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_ppo_discounts_kernel, dim3(aa_ew_blocks(B * (T1 - 1))), dim3(256), 0,
+                     (hipStream_t)stream, discount, next_step_type, gamma, B, T1, out);
+  return aa_launch_status();
+}
+
+int aa_ppo_trajectory_mask(const int32_t* step_type, const float* returns, const float* advantages,
+                           const float* weights, int64_t n, float* out, void* stream) {
+  if (!step_type || !returns || !advantages || !out || n <= 0) return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_ppo_mask_kernel, dim3(aa_ew_blocks(n)), dim3(256), 0, (hipStream_t)stream,
+                     step_type, returns, advantages, weights, n, out);
+  return aa_launch_status();
+}
+
+int aa_ppo_update_kl_beta(const float* mean_kl_dev, float target, float tolerance, float* beta_dev,
+                          void* stream) {
+  if (!mean_kl_dev || !beta_dev) return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_ppo_update_beta_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                     mean_kl_dev, target, tolerance, beta_dev);
   return aa_launch_status();
 }
 

@@ -236,6 +236,49 @@ int aa_ppo_loss(const float* z, const float* std_bias, const float* act_mean,
                 float clip_eps, float value_clip, float c_v, float c_e, float denom,
                 float logp_clip, int32_t flags, float* dz, float* dbias_elem, float* dv,
                 float* stats, void* stream);
+/* General diagonal-Normal PPO loss: the actor hands over loc/scale [N,D] of the CURRENT policy
+ * (any head) plus the collect-time dist_params (nullable: no KL terms), and gets d loss/d loc,
+ * d loss/d scale, d loss/d value back (all three nullable together: forward only).
+ * Adds kl_penalty_loss = adaptive (beta * mean(kl*w), beta read from *kl_beta_dev, nullable) +
+ * cutoff (kl_cutoff_coef * max(0, mean(kl*w) - kl_cutoff)^2)      (ppo_agent.py:1514-1640).
+ * stats[16 + 6*256]: [0] policy_gradient_loss [1] value_estimation_loss
+ * [2] entropy_regularization_loss [3] clip_fraction [4] mean(entropy*w) [5] kl_penalty_loss
+ * [6] sum of 0,1,2,5 [7] mean(kl*w) [8] d loss/d mean(kl*w) [9] adaptive_kl_loss
+ * [10] kl_cutoff_loss; rest scratch. */
+int aa_ppo_loss_dist(const float* loc, const float* scale, const float* old_loc,
+                     const float* old_scale, const float* actions, const float* old_logp,
+                     const float* adv, const float* returns, const float* vpred,
+                     const float* old_vpred, const float* weights, int64_t N, int32_t D,
+                     float clip_eps, float value_clip, float c_v, float c_e, float denom,
+                     float logp_clip, const float* kl_beta_dev, float kl_cutoff_coef,
+                     float kl_cutoff, float* dloc, float* dscale, float* dv, float* stats,
+                     void* stream);
+/* PPOActorNetwork head (ppo_actor_network.py:42-113): loc = mean + mag*tanh(z) (identity when
+ * mean/mag are null), scale = softplus(std_bias) broadcast; and its backward. */
+int aa_ppo_head_forward(const float* z, const float* std_bias, const float* act_mean,
+                        const float* act_mag, int64_t N, int32_t D, float* loc, float* scale,
+                        void* stream);
+int aa_ppo_head_backward(const float* z, const float* std_bias, const float* act_mag,
+                         const float* dloc, const float* dscale, int64_t N, int32_t D, float* dz,
+                         float* dbias_elem, void* stream);
+/* out[i] = sum_d log N(x[i,d]; loc[i,d], scale[i,d])   (utils/common.py:682-717) */
+int aa_normal_log_prob(const float* loc, const float* scale, const float* x, int64_t N, int32_t D,
+                       float* out, void* stream);
+/* out = loc + scale * eps, eps ~ N(0,1) (Box-Muller on Philox(counter = (i, *call_counter), key =
+ * seed)); replaces tfd.Normal.sample in PPOPolicy._action (policies/actor_policy.py). */
+int aa_normal_sample(const float* loc, const float* scale, int64_t n, uint64_t seed,
+                     const int64_t* call_counter_dev, float* out, void* stream);
+/* out[b,t] = discount[b,t] * gamma * (next_step_type[b,t] != LAST), t < T1-1
+ * (ppo_agent.py:630-676, utils/common.py:883-895); inputs are [B,T1]. */
+int aa_ppo_discounts(const float* discount, const int32_t* next_step_type, float gamma, int64_t B,
+                     int64_t T1, float* out, void* stream);
+/* out = weights (or 1) * (step_type != LAST) * !(return == 0 && advantage == 0)
+ * (ppo_utils.make_trajectory_mask, agents/ppo/ppo_utils.py:35-59). */
+int aa_ppo_trajectory_mask(const int32_t* step_type, const float* returns, const float* advantages,
+                           const float* weights, int64_t n, float* out, void* stream);
+/* update_adaptive_kl_beta (ppo_agent.py:1642-1690). */
+int aa_ppo_update_kl_beta(const float* mean_kl_dev, float target, float tolerance, float* beta_dev,
+                          void* stream);
 /* g += c * p  (L2 regularisation gradient on a flat parameter range). */
 int aa_add_l2_grad(float* g, const float* p, int64_t n, float c, void* stream);
 
