@@ -1,0 +1,103 @@
+"""PPOPolicy: samples actions from the actor network's diagonal Normal and records the
+distribution parameters (and, in collect mode with precomputed values, the value prediction).
+
+  tf_agents/agents/ppo/ppo_policy.py:21-240   (ActorPolicy subclass; info = {'dist_params': ...,
+                                               'value_prediction': ...})
+  tf_agents/policies/actor_policy.py          (distribution -> sample, optional clip to spec)
+  tf_agents/policies/greedy_policy.py:70-89   (mode of the distribution = loc)
+Sampling is `aa_normal_sample` (Box-Muller on the package's Philox stream, csrc/ppo.hip).
+"""
+import numpy as np
+import torch
+
+from agents_amd import _lib
+from agents_amd.policies import tf_policy
+from agents_amd.specs import tensor_spec
+from agents_amd.trajectories import policy_step
+from agents_amd.utils import nest_utils
+
+
+class PPOPolicy(tf_policy.TFPolicy):
+    def __init__(self, time_step_spec, action_spec, actor_network, value_network,
+                 observation_normalizer=None, clip=True, collect=True,
+                 compute_value_and_advantage_in_train=False, seed=0, greedy=False, name=None):
+        if observation_normalizer is not None:
+            raise NotImplementedError("observation normalisation is not implemented yet")
+        self._actor_network = actor_network
+        self._value_network = value_network
+        self._collect = collect
+        self._clip = clip
+        self._greedy = greedy
+        self._compute_value_in_train = compute_value_and_advantage_in_train
+        actor_network.create_variables(time_step_spec.observation)
+        value_network.create_variables(time_step_spec.observation)
+        spec = nest_utils.flatten(action_spec)[0]
+        self._spec = spec
+        self._D = int(np.prod(spec.shape)) if len(spec.shape) else 1
+        info_spec = ()
+        if collect:
+            pspec = tensor_spec.TensorSpec(spec.shape, torch.float32)
+            info_spec = {"dist_params": {"loc": pspec, "scale": pspec}}
+            if not compute_value_and_advantage_in_train:
+                info_spec["value_prediction"] = tensor_spec.TensorSpec((), torch.float32)
+        super().__init__(time_step_spec, action_spec, info_spec=info_spec, clip=clip, name=name)
+        self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._call_counter = None
+        self._lo = self._hi = None
+
+    def _variables(self):
+        return self._actor_network.variables + self._value_network.variables
+
+    def apply_value_network(self, observations, step_types=None, value_state=None, training=False):
+        """[B, T, ...] or [N, ...] observations -> value predictions of the same outer shape."""
+        obs_rank = len(self._time_step_spec.observation.shape)
+        outer = tuple(observations.shape[:observations.dim() - obs_rank])
+        flat = observations.reshape((-1,) + tuple(observations.shape[len(outer):]))
+        v = self._value_network.forward(flat, slot=("value", training), need_grad=training)
+        return v.view(outer), ()
+
+    def get_initial_value_state(self, batch_size=None):
+        return ()
+
+    def _action(self, time_step, policy_state, seed):
+        lib = _lib.load()
+        obs = time_step.observation
+        batched = time_step.step_type.dim() > 0
+        if not batched:
+            obs = obs.unsqueeze(0)
+        dev = obs.device
+        with torch.cuda.device(dev):
+            loc, scale = self._actor_network.forward(obs, slot="policy")
+            N = loc.shape[0]
+            if self._greedy:
+                action = loc.clone()
+            else:
+                if self._call_counter is None:
+                    self._call_counter = torch.zeros((1,), dtype=torch.int64, device=dev)
+                action = torch.empty_like(loc)
+                st = _lib.stream_ptr()
+                _lib.check(lib.aa_normal_sample(loc.data_ptr(), scale.data_ptr(), loc.numel(),
+                                                self._seed, self._call_counter.data_ptr(),
+                                                action.data_ptr(), st), "aa_normal_sample")
+                _lib.check(lib.aa_counter_add(self._call_counter.data_ptr(), 1, st),
+                           "aa_counter_add")
+            if self._clip:
+                if self._lo is None:
+                    self._lo = torch.as_tensor(np.broadcast_to(
+                        np.asarray(self._spec.minimum, np.float32), (self._D,)).copy(), device=dev)
+                    self._hi = torch.as_tensor(np.broadcast_to(
+                        np.asarray(self._spec.maximum, np.float32), (self._D,)).copy(), device=dev)
+                action = torch.maximum(torch.minimum(action, self._hi), self._lo)
+            action = action.view((N,) + tuple(self._spec.shape))
+            info = ()
+            if self._collect:
+                shp = (N,) + tuple(self._spec.shape)
+                info = {"dist_params": {"loc": loc.clone().view(shp),
+                                        "scale": scale.clone().view(shp)}}
+                if not self._compute_value_in_train:
+                    info["value_prediction"] = self._value_network.forward(
+                        obs, slot="policy").clone()
+        if not batched:
+            action = action.squeeze(0)
+            info = nest_utils.map_structure(lambda t: t.squeeze(0), info)
+        return policy_step.PolicyStep(action, policy_state, info)

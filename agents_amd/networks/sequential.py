@@ -131,6 +131,39 @@ class Sequential(network.Network):
         self._kviews, self._bviews = views(self.flat_params)
         self._gkviews, self._gbviews = views(self.flat_grads)
 
+    def rebind(self, flat_params, flat_grads):
+        """Moves the parameters into caller-provided storage (two fp32 views of identical length
+        `flat_params.numel()` == this network's flat size).  Lets an agent keep several networks
+        in ONE flat parameter / gradient buffer so that the optimizer, the global-norm clip and
+        the gradient all-reduce are single passes (PPO: actor + value)."""
+        self._require_built()
+        n = self.flat_params.numel()
+        if flat_params.numel() != n or flat_grads.numel() != n:
+            raise ValueError(f"rebind needs views of {n} elements")
+        if flat_params.dtype != torch.float32 or not flat_params.is_contiguous():
+            raise ValueError("rebind needs contiguous float32 storage")
+        flat_params.copy_(self.flat_params)
+        flat_grads.zero_()
+        self.flat_params = flat_params
+        self.flat_grads = flat_grads
+        self._make_views()
+
+    @property
+    def flat_size(self):
+        self._require_built()
+        return self.flat_params.numel()
+
+    @property
+    def kernels(self):
+        """Kernel (weight-matrix) views, for L2 regularisation over the weights only."""
+        self._require_built()
+        return list(self._kviews)
+
+    @property
+    def kernel_grads(self):
+        self._require_built()
+        return list(self._gkviews)
+
     @property
     def variables(self):
         self._require_built()

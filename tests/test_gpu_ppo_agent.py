@@ -1,0 +1,351 @@
+"""GPU parity of PPOAgent / PPOClipAgent (agents_amd/agents/ppo) against oracle/ppo.py and the
+reference's known answers (tf_agents/agents/ppo/ppo_agent_test.py).  Tolerance on losses and
+gradients: 1e-5 relative (north star), written per assertion."""
+import numpy as np
+import pytest
+import torch
+
+from agents_amd import optimizers
+from agents_amd.agents.ppo import ppo_actor_network as pan
+from agents_amd.agents.ppo import ppo_agent, ppo_clip_agent
+from agents_amd.networks import layers as L
+from agents_amd.networks import sequential
+from agents_amd.specs import tensor_spec
+from agents_amd.trajectories import time_step as ts
+from agents_amd.trajectories import trajectory
+from oracle import optim as ooptim
+from oracle import ppo as oppo
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+OBS_SPEC = tensor_spec.TensorSpec((2,), torch.float32)
+TS_SPEC = ts.time_step_spec(OBS_SPEC)
+ACT_SPEC = tensor_spec.BoundedTensorSpec((1,), torch.float32, -1, 1)
+
+
+def dummy_nets():
+    """DummyActorNet / DummyValueNet of ppo_agent_test.py:45-170."""
+    actor_body = sequential.Sequential([L.Dense(
+        2, None, kernel_initializer=L.Constant([[2.0, 1.0], [1.0, 1.0]]),
+        bias_initializer=L.Constant([5.0, 5.0]))])
+    value_body = sequential.Sequential([L.Dense(
+        1, None, kernel_initializer=L.Constant([[2.0], [1.0]]), bias_initializer=L.Constant([5.0]))])
+    return pan.SplitNormalActorNet(actor_body, ACT_SPEC), pan.ValueNet(value_body)
+
+
+def make_agent(cls=ppo_agent.PPOAgent, **kw):
+    actor, value = dummy_nets()
+    kw.setdefault("normalize_observations", False)
+    kw.setdefault("normalize_rewards", False)
+    return cls(TS_SPEC, ACT_SPEC, optimizers.AdamOptimizer(), actor_net=actor, value_net=value,
+               **kw)
+
+
+def f(x, dev, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(x), dtype=dtype, device=dev)
+
+
+def close(got, want, rtol=RTOL, atol=0.0):
+    np.testing.assert_allclose(np.asarray(got.detach().cpu() if isinstance(got, torch.Tensor)
+                                          else got, np.float64), want, rtol=rtol, atol=atol)
+
+
+# ---- known answers of the reference through the GPU path -------------------------------------
+def test_epoch_loss_known_answers(dev):  # ppo_agent_test.py:644-727
+    agent = make_agent(value_pred_loss_coef=1.0, policy_l2_reg=1e-4, value_function_l2_reg=1e-4,
+                       entropy_regularization=0.1, importance_ratio_clipping=10)
+    obs = f([[1, 2], [3, 4], [1, 2], [3, 4]], dev)
+    time_steps = ts.restart(obs, batch_size=4)
+    li = agent.get_loss(
+        time_steps, f([[0], [1], [0], [1]], dev), f([0.9, 0.3, 0.9, 0.3], dev),
+        f([1.9, 1.0, 1.9, 1.0], dev), f([1.9, 1.0, 1.9, 1.0], dev),
+        {"loc": f([[9.0], [15.0], [9.0], [15.0]], dev),
+         "scale": f([[8.0], [12.0], [8.0], [12.0]], dev)}, f([1.0, 1.0, 0.0, 0.0], dev))
+    e = li.extra
+    close(e.policy_gradient_loss, -0.0164646133 * 2 / 4)
+    close(e.value_estimation_loss, 123.205 * 2 / 4, rtol=1e-6)
+    close(e.entropy_regularization_loss, -0.370111 * 2 / 4)
+    close(e.l2_regularization_loss, 1e-4 * 12, rtol=1e-6)
+    close(e.kl_penalty_loss, 0.0, atol=1e-7)
+    close(e.clip_fraction, 0.0, atol=0)
+    close(li.loss, -0.0164646133 / 2 + 123.205 / 2 - 0.370111 / 2 + 1e-4 * 12, rtol=1e-5)
+
+
+def test_single_terms_known_answers(dev):  # :864-981
+    agent = make_agent(value_pred_loss_coef=1.0, importance_ratio_clipping=10.0,
+                       entropy_regularization=0.1, initial_adaptive_kl_beta=0.0,
+                       kl_cutoff_factor=0.0)
+    time_steps = ts.restart(f([[1, 2], [3, 4]], dev), batch_size=2)
+    li = agent.get_loss(time_steps, f([[0], [1]], dev), f([0.9, 0.3], dev), f([1.9, 1.0], dev),
+                        f([1.9, 1.0], dev), {"loc": f([[9.0], [15.0]], dev),
+                                             "scale": f([[8.0], [12.0]], dev)},
+                        f([1.0, 1.0], dev))
+    close(li.extra.value_estimation_loss, 123.205, rtol=1e-6)
+    close(li.extra.policy_gradient_loss, -0.0164646133)
+    close(li.extra.entropy_regularization_loss, -3.70111 * 0.1)
+
+
+def test_compute_advantages_known_answers(dev):  # :255-347
+    rewards = f(np.ones((2, 9)), dev)
+    discounts = f([[1, 1, 1, 1, 0, .9, .9, .9, 0]] * 2, dev)
+    returns = f([[5.0, 4.0, 3.0, 2.0, 1.0, 3.439, 2.71, 1.9, 1.0],
+                 [3.0, 4.0, 7.0, 2.0, -1.0, 5.439, 2.71, -2.9, 1.0]], dev)
+    vp = f(np.full((2, 10), 3.0), dev)
+    a = make_agent(use_gae=False).compute_advantages(rewards, returns, discounts, vp)
+    close(a, returns.cpu().numpy() - 3.0, rtol=1e-6)
+    g = make_agent(use_gae=True, lambda_value=0.95).compute_advantages(rewards, returns,
+                                                                       discounts, vp)
+    truth = [2.0808625, 1.13775, 0.145, -0.9, -2.0, 0.56016475, -0.16355, -1.01, -2.0]
+    close(g, [truth, truth])
+
+
+def test_kl_cutoff_and_beta_update_known_answers(dev):  # :1037-1075, 1126-1164
+    agent = make_agent(kl_cutoff_factor=5.0, adaptive_kl_target=0.1, kl_cutoff_coef=30.0)
+    close(agent.kl_cutoff_loss([[1.5, -0.5, 6.5, -1.5, -2.3]]), 30.0 * 0.24 ** 2)
+    agent = make_agent(initial_adaptive_kl_beta=1.0, adaptive_kl_target=10.0,
+                       adaptive_kl_tolerance=0.5)
+    assert float(agent.update_adaptive_kl_beta([10.0]).item()) == 1.0
+    assert float(agent.update_adaptive_kl_beta([100.0]).item()) == 1.5
+    close(agent.update_adaptive_kl_beta([1.0]), [1.0], rtol=1e-6)
+
+
+# ---- random data: every term + every gradient against the autograd oracle ---------------------
+def mlp_specs(obs_dim, D):
+    return [(obs_dim, 16), (16,), (16, 8), (8,), (8, D), (D,)]
+
+
+def build_tanh_agent(dev, obs_dim=5, D=3, **kw):
+    obs_spec = tensor_spec.TensorSpec((obs_dim,), torch.float32)
+    act_spec = tensor_spec.BoundedTensorSpec((D,), torch.float32, -2.0, 3.0)
+    actor = pan.PPOActorNetwork().create_sequential_actor_net((16, 8), act_spec, seed=3)
+    value = pan.value_network((12,), "tanh", seed=4)
+    kw.setdefault("normalize_observations", False)
+    kw.setdefault("normalize_rewards", False)
+    agent = ppo_agent.PPOAgent(ts.time_step_spec(obs_spec), act_spec,
+                               optimizers.Adam(3e-3, epsilon=1e-5), actor_net=actor,
+                               value_net=value, **kw)
+    return agent, obs_spec, act_spec
+
+
+def oracle_params(agent):
+    """torch-CPU leaf copies of (actor kernels/biases..., std_bias, value kernels/biases...)."""
+    a = [v.detach().cpu().clone().requires_grad_(True) for v in agent.actor_net.body.variables]
+    sb = agent.actor_net.std_bias.detach().cpu().clone().requires_grad_(True)
+    v = [x.detach().cpu().clone().requires_grad_(True) for x in agent._value_net.body.variables]
+    return a, sb, v
+
+
+def oracle_forward(a, sb, v, obs, lo=-2.0, hi=3.0):
+    h = obs
+    for i in range(0, len(a) - 2, 2):
+        h = torch.tanh(h @ a[i] + a[i + 1])
+    z = h @ a[-2] + a[-1]
+    mean, mag = (hi + lo) / 2.0, (hi - lo) / 2.0
+    loc = mean + mag * torch.tanh(z)
+    scale = torch.nn.functional.softplus(sb).expand_as(loc)
+    hv = obs
+    for i in range(0, len(v) - 2, 2):
+        hv = torch.tanh(hv @ v[i] + v[i + 1])
+    val = (hv @ v[-2] + v[-1])[:, 0]
+    return loc, scale, val
+
+
+def flat_oracle_grads(agent, grads_a, grad_sb, grads_v):
+    """Lay autograd gradients out like agent.flat_grads."""
+    out = np.zeros(agent.flat_grads.numel(), np.float32)
+    na = agent.actor_net.body.flat_size
+    segs = agent.actor_net.body.segment_offsets()
+    for (s0, s1), g in zip(segs, grads_a):
+        out[s0:s1] = g.reshape(-1).numpy()
+    D = grad_sb.numel()
+    out[na:na + D] = grad_sb.numpy()
+    nv0 = agent.actor_net.flat_size
+    for (s0, s1), g in zip(agent._value_net.body.segment_offsets(), grads_v):
+        out[nv0 + s0:nv0 + s1] = g.reshape(-1).numpy()
+    return out
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(importance_ratio_clipping=0.2, entropy_regularization=0.01, initial_adaptive_kl_beta=0.0,
+         kl_cutoff_factor=0.0),
+    dict(importance_ratio_clipping=0.0, entropy_regularization=0.0, initial_adaptive_kl_beta=0.7,
+         kl_cutoff_factor=2.0, kl_cutoff_coef=50.0, adaptive_kl_target=0.01),
+    dict(importance_ratio_clipping=0.3, value_clipping=0.2, log_prob_clipping=3.0,
+         policy_l2_reg=1e-3, value_function_l2_reg=2e-3, initial_adaptive_kl_beta=0.0,
+         kl_cutoff_factor=0.0, entropy_regularization=0.05),
+])
+def test_loss_and_gradients_vs_autograd_oracle(dev, cfg):
+    agent, obs_spec, act_spec = build_tanh_agent(dev, **cfg)
+    rng = np.random.default_rng(1)
+    N, D = 300, 3
+    obs = rng.normal(size=(N, 5)).astype(np.float32)
+    a, sb, v = oracle_params(agent)
+    with torch.no_grad():
+        loc0, scale0, val0 = oracle_forward(a, sb, v, torch.from_numpy(obs))
+    old_loc = (loc0 + torch.from_numpy(rng.normal(size=(N, D)).astype(np.float32)) * 0.1)
+    old_scale = scale0 * torch.from_numpy(rng.uniform(0.8, 1.25, size=(N, D)).astype(np.float32))
+    actions = (old_loc + old_scale * torch.from_numpy(
+        rng.normal(size=(N, D)).astype(np.float32)))
+    old_logp = oppo.normal_log_prob(old_loc, old_scale, actions)
+    adv = torch.from_numpy(rng.normal(size=N).astype(np.float32))
+    ret = torch.from_numpy(rng.normal(size=N).astype(np.float32))
+    old_v = val0 + torch.from_numpy(rng.normal(size=N).astype(np.float32)) * 0.3
+    w = torch.from_numpy((rng.uniform(size=N) > 0.2).astype(np.float32) *
+                         rng.uniform(0.5, 1.5, size=N).astype(np.float32))
+    # oracle
+    loc, scale, val = oracle_forward(a, sb, v, torch.from_numpy(obs))
+    out = oppo.losses(
+        loc, scale, actions, old_logp, adv, ret, val, w,
+        clip_eps=cfg.get("importance_ratio_clipping", 0.0),
+        value_clip=cfg.get("value_clipping", 0.0), c_v=0.5,
+        c_e=cfg.get("entropy_regularization", 0.0), logp_clip=cfg.get("log_prob_clipping", 0.0),
+        old_loc=old_loc, old_scale=old_scale, old_vpred=old_v,
+        kl_beta=cfg.get("initial_adaptive_kl_beta", 0.0),
+        kl_cutoff_coef=cfg.get("kl_cutoff_coef", 0.0) if cfg.get("kl_cutoff_factor", 0) else 0.0,
+        kl_cutoff=cfg.get("kl_cutoff_factor", 0.0) * cfg.get("adaptive_kl_target", 0.0))
+    l2 = cfg.get("policy_l2_reg", 0.0) * sum((k ** 2).sum() for k in a[0::2]) + \
+        cfg.get("value_function_l2_reg", 0.0) * sum((k ** 2).sum() for k in v[0::2])
+    total = out["total"] + l2
+    grads = torch.autograd.grad(total, a + [sb] + v)
+    want = flat_oracle_grads(agent, grads[:len(a)], grads[len(a)], grads[len(a) + 1:])
+    # HIP
+    time_steps = ts.TimeStep(step_type=torch.ones(N, dtype=torch.int32, device=dev),
+                             reward=torch.zeros(N, device=dev),
+                             discount=torch.ones(N, device=dev), observation=f(obs, dev))
+    li = agent.get_loss(time_steps, actions.to(dev), old_logp.to(dev), ret.to(dev), adv.to(dev),
+                        {"loc": old_loc.to(dev), "scale": old_scale.to(dev)}, w.to(dev),
+                        old_value_predictions=old_v.to(dev), training=True)
+    close(li.extra.policy_gradient_loss, float(out["policy_gradient_loss"]), rtol=2e-5)
+    close(li.extra.value_estimation_loss, float(out["value_estimation_loss"]), rtol=2e-5)
+    close(li.extra.entropy_regularization_loss, float(out["entropy_regularization_loss"]),
+          rtol=2e-5)
+    close(li.extra.kl_penalty_loss, float(out["kl_penalty_loss"]), rtol=2e-5, atol=1e-9)
+    close(li.extra.clip_fraction, float(out["clip_fraction"]), rtol=1e-6)
+    close(li.extra.l2_regularization_loss, float(l2), rtol=2e-5)
+    close(li.loss, float(total), rtol=2e-5)
+    got = agent.flat_grads.cpu().numpy()
+    scale_g = max(np.abs(want).max(), 1e-12)
+    assert np.abs(got - want).max() <= 2e-5 * scale_g, \
+        (np.abs(got - want).max(), scale_g)
+
+
+# ---- preprocess + full train step vs oracle ---------------------------------------------------
+def make_experience(rng, B, T1, obs_dim, D, dev, agent):
+    obs = rng.normal(size=(B, T1, obs_dim)).astype(np.float32)
+    st = rng.integers(0, 3, size=(B, T1)).astype(np.int32)
+    nst = rng.integers(0, 3, size=(B, T1)).astype(np.int32)
+    rew = rng.normal(size=(B, T1)).astype(np.float32)
+    disc = (rng.uniform(size=(B, T1)) > 0.15).astype(np.float32)
+    loc = rng.normal(size=(B, T1, D)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, size=(B, T1, D)).astype(np.float32)
+    act = (loc + scale * rng.normal(size=(B, T1, D))).astype(np.float32)
+    traj = trajectory.Trajectory(
+        step_type=f(st, dev, torch.int32), observation=f(obs, dev), action=f(act, dev),
+        policy_info={"dist_params": {"loc": f(loc, dev), "scale": f(scale, dev)}},
+        next_step_type=f(nst, dev, torch.int32), reward=f(rew, dev), discount=f(disc, dev))
+    return traj, dict(obs=obs, st=st, nst=nst, rew=rew, disc=disc, loc=loc, scale=scale, act=act)
+
+
+@pytest.mark.parametrize("use_gae,td_lambda", [(False, False), (True, False), (True, True)])
+def test_preprocess_matches_oracle(dev, use_gae, td_lambda):
+    agent, _, _ = build_tanh_agent(dev, use_gae=use_gae, use_td_lambda_return=td_lambda,
+                                   initial_adaptive_kl_beta=0.0, kl_cutoff_factor=0.0)
+    rng = np.random.default_rng(5)
+    B, T1 = 7, 9
+    traj, h = make_experience(rng, B, T1, 5, 3, dev, agent)
+    a, sb, v = oracle_params(agent)
+    with torch.no_grad():
+        _, _, val = oracle_forward(a, sb, v, torch.from_numpy(h["obs"].reshape(-1, 5)))
+    vp = val.numpy().reshape(B, T1)
+    ret, adv = oppo.compute_return_and_advantage(h["rew"], h["disc"], h["nst"], vp, 0.99, 0.95,
+                                                 use_gae, td_lambda)
+    out = agent._preprocess(traj)
+    close(out.policy_info["value_prediction"], vp, rtol=1e-5, atol=1e-6)
+    close(out.policy_info["return"], oppo.pad_last(ret), rtol=2e-5, atol=2e-6)
+    close(out.policy_info["advantage"], oppo.pad_last(adv), rtol=2e-5, atol=2e-6)
+
+
+def test_train_matches_oracle_epochs(dev):
+    """PPOClipAgent.train: 3 epochs of (loss, backward, global-norm clip 0.5, Adam) against the
+    torch-CPU oracle run on the same trajectories; parameters must agree afterwards."""
+    obs_spec = tensor_spec.TensorSpec((5,), torch.float32)
+    act_spec = tensor_spec.BoundedTensorSpec((3,), torch.float32, -2.0, 3.0)
+    actor = pan.PPOActorNetwork().create_sequential_actor_net((16, 8), act_spec, seed=3)
+    value = pan.value_network((12,), "tanh", seed=4)
+    agent = ppo_clip_agent.PPOClipAgent(
+        ts.time_step_spec(obs_spec), act_spec, optimizers.Adam(3e-3, epsilon=1e-5),
+        actor_net=actor, value_net=value, importance_ratio_clipping=0.2, use_gae=True,
+        num_epochs=3, gradient_clipping=0.5, entropy_regularization=0.01,
+        normalize_observations=False, normalize_rewards=False)
+    rng = np.random.default_rng(9)
+    B, T1, D = 6, 8, 3
+    traj, h = make_experience(rng, B, T1, 5, D, dev, agent)
+    a, sb, v = oracle_params(agent)
+    params = a + [sb] + v
+    opt = ooptim.Adam(3e-3, eps=1e-5)
+    obs_t = torch.from_numpy(h["obs"].reshape(-1, 5))
+    with torch.no_grad():
+        _, _, val = oracle_forward(a, sb, v, obs_t)
+    vp = val.numpy().reshape(B, T1)
+    ret, adv = oppo.compute_return_and_advantage(h["rew"], h["disc"], h["nst"], vp, 0.99, 0.95,
+                                                 True, False)
+    ret_p, adv_p = oppo.pad_last(ret), oppo.pad_last(adv)
+    mask = oppo.trajectory_mask(h["st"], ret_p, adv_p).reshape(-1)
+    adv_n = oppo.normalize_advantages(adv_p).reshape(-1)
+    old_loc = torch.from_numpy(h["loc"].reshape(-1, D))
+    old_scale = torch.from_numpy(h["scale"].reshape(-1, D))
+    acts = torch.from_numpy(h["act"].reshape(-1, D))
+    old_logp = oppo.normal_log_prob(old_loc, old_scale, acts)
+    last = None
+    for _ in range(3):
+        loc, scale, val = oracle_forward(a, sb, v, obs_t)
+        out = oppo.losses(loc, scale, acts, old_logp, torch.from_numpy(adv_n),
+                          torch.from_numpy(ret_p.reshape(-1)), val, torch.from_numpy(mask),
+                          clip_eps=0.2, c_v=0.5, c_e=0.01)
+        grads = torch.autograd.grad(out["total"], params)
+        gn = torch.sqrt(sum((g ** 2).sum() for g in grads))
+        sc = 0.5 * min(1.0 / float(gn), 1.0 / 0.5)  # tf.clip_by_global_norm
+        opt.step(params, [g * sc for g in grads])
+        last = out
+    li = agent.train(traj)
+    close(li.loss, float(last["total"]), rtol=1e-4)
+    close(li.extra.clip_fraction, float(last["clip_fraction"]), rtol=1e-6)
+    assert int(agent.train_step_counter.numpy()) == 3
+    for got, want in zip(agent.actor_net.body.variables + [agent.actor_net.std_bias] +
+                         agent._value_net.body.variables, params):
+        scale_p = max(float(want.abs().max()), 1e-6)
+        assert float((got.cpu() - want.detach()).abs().max()) <= 2e-4 * scale_p
+
+
+# ---- policy ---------------------------------------------------------------------------------------
+def test_collect_policy_samples_and_info(dev):
+    agent, obs_spec, act_spec = build_tanh_agent(dev, initial_adaptive_kl_beta=0.0,
+                                                 kl_cutoff_factor=0.0)
+    B = 4096
+    obs = torch.zeros((B, 5), device=dev)
+    step = ts.restart(obs, batch_size=B)
+    p1 = agent.collect_policy.action(step)
+    p2 = agent.collect_policy.action(step)
+    assert p1.action.shape == (B, 3)
+    loc, scale = p1.info["dist_params"]["loc"], p1.info["dist_params"]["scale"]
+    a, sb, v = oracle_params(agent)
+    with torch.no_grad():
+        oloc, oscale, _ = oracle_forward(a, sb, v, torch.zeros(B, 5))
+    close(loc, oloc.numpy(), rtol=1e-5, atol=1e-6)
+    close(scale, oscale.numpy(), rtol=1e-5)
+    z = ((p1.action - loc) / scale).cpu().numpy()
+    assert abs(z.mean()) < 0.03 and abs(z.std() - 1.0) < 0.03
+    assert not torch.equal(p1.action, p2.action)  # the call counter advances the stream
+    g = agent.policy.action(step)
+    close(g.action, oloc.numpy(), rtol=1e-5, atol=1e-6)  # greedy eval = mode of the Normal
+    assert g.info == ()
+
+
+def test_constructor_errors(dev):
+    actor, value = dummy_nets()
+    with pytest.raises(TypeError):
+        ppo_agent.PPOAgent(TS_SPEC, ACT_SPEC, optimizers.Adam(), actor_net=None, value_net=value)
+    with pytest.raises(NotImplementedError):
+        ppo_agent.PPOAgent(TS_SPEC, ACT_SPEC, optimizers.Adam(), actor_net=actor,
+                           value_net=value)  # normalisers default to True in the reference
