@@ -1,0 +1,136 @@
+"""PPOLearner: epochs x shuffled minibatches over a fixed set of collected sequences.
+
+Mirrors tf_agents/train/ppo_learner.py:40-345:
+  __init__ validation   :141-167  (minibatching needs shuffle_buffer_size, a feed-forward
+                                   network, compute_value_and_advantage_in_train=False and
+                                   update_normalizers_in_train=False)
+  _create_datasets      :198-262  take(num_samples) -> cache -> repeat(num_epochs) -> flatten
+                                   [B,T] -> shuffle -> batch(1) -> batch(minibatch_size,
+                                   drop_remainder)
+  run                   :264-305  update normalizers / count frames, then
+                                   iterations = int(frames / minibatch_size) * num_epochs train steps
+The reference builds this with tf.data; here the `num_samples` elements are materialised once as
+device tensors ([F, ...] after flattening), every epoch draws one permutation of the F frames and
+gathers `minibatch_size` rows per step, each handed to `agent.train` as a [minibatch, 1, ...]
+trajectory -- what batch(1).batch(minibatch_size) produces.  Differences, both in the data
+pipeline (whose random order no reference test pins): the permutation is per epoch (tf.data's
+shuffle buffer is filled from the repeated stream, so with a large buffer it can mix consecutive
+epochs), and in multi-GPU runs every rank runs all of ITS minibatches (one process per GPU with
+its own replay shard) instead of dividing one dataset's batches by the replica count.
+"""
+import torch
+
+from agents_amd.train import learner
+from agents_amd.utils import nest_utils
+
+
+class PPOLearner:
+    def __init__(self, root_dir, train_step, agent, experience_dataset_fn,
+                 normalization_dataset_fn, num_samples, num_epochs=1, minibatch_size=None,
+                 shuffle_buffer_size=None, after_train_strategy_step_fn=None, triggers=None,
+                 checkpoint_interval=100000, summary_interval=1000,
+                 use_kwargs_in_agent_train=False, strategy=None, seed=0):
+        if minibatch_size and shuffle_buffer_size is None:
+            raise ValueError("shuffle_buffer_size must be provided if minibatch_size is not None.")
+        if minibatch_size and (getattr(agent._actor_net, "state_spec", ()) or
+                               getattr(agent._value_net, "state_spec", ())):
+            raise ValueError("minibatch_size must be set to None for RNN networks.")
+        if minibatch_size and agent._compute_value_and_advantage_in_train:
+            raise ValueError("agent.compute_value_and_advantage_in_train should be set to False "
+                             "when mini batching is used.")
+        if agent.update_normalizers_in_train:
+            raise ValueError("agent.update_normalizers_in_train should be set to False when "
+                             "PPOLearner is used.")
+        self._agent = agent
+        self._minibatch_size = minibatch_size
+        self._shuffle_buffer_size = shuffle_buffer_size
+        self._num_epochs = num_epochs
+        self._experience_dataset_fn = experience_dataset_fn
+        self._normalization_dataset_fn = normalization_dataset_fn
+        self._num_samples = num_samples
+        self._generic_learner = learner.Learner(
+            root_dir, train_step, agent, experience_dataset_fn=None,
+            after_train_strategy_step_fn=after_train_strategy_step_fn, triggers=triggers,
+            checkpoint_interval=checkpoint_interval, summary_interval=summary_interval,
+            use_kwargs_in_agent_train=use_kwargs_in_agent_train, strategy=strategy)
+        self.num_replicas = self._generic_learner.strategy.num_replicas_in_sync
+        self.num_frames_for_training = 0
+        self._gen = None
+        self._seed = seed
+        self._train_iter = None
+        self._norm_iter = None
+
+    # ---- data ------------------------------------------------------------------------------------
+    def _take_samples(self):
+        if self._train_iter is None:
+            self._train_iter = iter(self._experience_dataset_fn())
+        out = []
+        for _ in range(self._num_samples):
+            out.append(next(self._train_iter))
+        return out
+
+    def _count_frames(self):
+        """_update_normalizers (:307-335): the agent has no normalisers here, so this only counts
+        the frames of `num_samples` elements of the normalisation dataset."""
+        if self._norm_iter is None:
+            self._norm_iter = iter(self._normalization_dataset_fn())
+        frames = 0
+        for _ in range(self._num_samples):
+            traj, _ = next(self._norm_iter)
+            n = 1
+            for d in traj.reward.shape[:2]:
+                n *= int(d)
+            frames += n
+        return frames
+
+    def _minibatches(self, samples):
+        mb = self._minibatch_size
+        trajs = [s[0] for s in samples]
+        spec_rank = {}
+        flat = []
+        for tr in trajs:
+            flat.append(nest_utils.map_structure(
+                lambda t: t.reshape((-1,) + tuple(t.shape[2:])), tr))
+        if len(flat) == 1:
+            frames = flat[0]
+        else:
+            frames = nest_utils.map_structure(lambda *ts_: torch.cat(ts_, dim=0), *flat)
+        F = int(frames.discount.shape[0])
+        dev = frames.discount.device
+        if self._gen is None:
+            self._gen = torch.Generator(device=dev)
+            self._gen.manual_seed(self._seed)
+        for _ in range(self._num_epochs):
+            perm = torch.randperm(F, device=dev, generator=self._gen)
+            for i in range(F // mb):
+                idx = perm[i * mb:(i + 1) * mb]
+                yield nest_utils.map_structure(
+                    lambda t: t.index_select(0, idx).unsqueeze(1), frames), None
+
+    def _full_batches(self, samples):
+        for _ in range(self._num_epochs):
+            for s in samples:
+                yield s
+
+    # ---- run -------------------------------------------------------------------------------------
+    def run(self, parallel_iterations=10):
+        num_frames = self._count_frames()
+        self.num_frames_for_training = num_frames
+        samples = self._take_samples()
+        if self._minibatch_size:
+            num_total_batches = int(num_frames / self._minibatch_size) * self._num_epochs
+            it = self._minibatches(samples)
+        else:
+            num_total_batches = self._num_samples * self._num_epochs
+            it = self._full_batches(samples)
+        if num_total_batches == 0:
+            raise ValueError(
+                "Cannot distribute {} batches across {} replicas. Please increase "
+                "PPOLearner.num_samples. See PPOLeaner.num_samples documentation for more "
+                "details.".format(num_total_batches, self.num_replicas))
+        return self._generic_learner.run(num_total_batches, it,
+                                         parallel_iterations=parallel_iterations)
+
+    @property
+    def train_step_numpy(self):
+        return self._generic_learner.train_step_numpy
