@@ -21,7 +21,7 @@ AA_PPO_NSTATS = 8
 AA_PPO_DIST_STATS = 16 + 6 * 256
 
 _ERRORS = {-22: "AA_ERR_INVALID (bad argument)", -34: "AA_ERR_RANGE (size / workspace)",
-           -5: "AA_ERR_LAUNCH (HIP launch failure)"}
+           -5: "AA_ERR_LAUNCH (HIP launch failure)", -62: "AA_ERR_TIMEOUT (mailbox wait)"}
 
 
 class AgentsAmdError(RuntimeError):
@@ -50,7 +50,7 @@ _SIGNATURES = {
     "aa_rb_scatter_rows": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int,
                                    c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "aa_rb_sample_rows": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_uint64,
-                                  c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                  c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "aa_rb_gather_rows": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int,
                                   c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "aa_rb_write_rows": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int,
@@ -79,7 +79,10 @@ _SIGNATURES = {
     "aa_segment_sumsq": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "aa_clip_by_norm": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_float, c_int32,
                                 c_void_p]),
-    "aa_count_steps": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "aa_count_steps": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "aa_mailbox_create": (c_int, [c_int64, POINTER(c_void_p), POINTER(c_void_p)]),
+    "aa_mailbox_destroy": (c_int, [c_void_p]),
+    "aa_mailbox_wait": (c_int, [c_void_p, c_int64, c_int64, POINTER(c_int64)]),
     "aa_eps_greedy_action": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p,
                                      c_uint64, c_void_p, c_int64, c_void_p, c_int32, c_void_p]),
     "aa_vecenv_random_step": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_float, c_float,
@@ -128,7 +131,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 2:
+    if lib.aa_abi_version() != 3:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -123,9 +123,17 @@ aa_rb_write_kernel(AaLeafSet leaves, const int64_t* __restrict__ rows, int n_chu
 //   rows[s,t] = (id + t) mod L + seg*L ;  prob = 1 / float32((max_id-min_id)*batch)
 __global__ void aa_rb_sample_kernel(const int64_t* __restrict__ last_id_p, int64_t batch,
                                     int64_t max_len, int64_t S, int64_t T, uint32_t k0,
-                                    uint32_t k1, uint64_t call, int64_t* __restrict__ rows,
-                                    float* __restrict__ probs, int* __restrict__ err) {
+                                    uint32_t k1, uint64_t call,
+                                    int64_t* call_dev, int bump_in_kernel,
+                                    int64_t* __restrict__ rows, float* __restrict__ probs,
+                                    int* __restrict__ err) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // graph replays keep the call counter in device memory (a by-value argument would be frozen)
+  if (call_dev != nullptr) call += (uint64_t)*call_dev;
+  if (bump_in_kernel) {  // single-workgroup launch: every lane has read the counter by now
+    __syncthreads();
+    if (threadIdx.x == 0) *call_dev += 1;
+  }
   if (s >= S) return;
   const int64_t last_id = *last_id_p;
   int64_t min_id, max_id;
@@ -204,8 +212,9 @@ int aa_rb_scatter_rows(void* const* leaf_tables_h, const void* const* leaf_items
 }
 
 int aa_rb_sample_rows(const int64_t* last_id_dev, int64_t batch, int64_t max_len, int64_t S,
-                      int64_t T, uint64_t seed, uint64_t call_counter, int64_t* rows_out,
-                      float* prob_out, int* err_flag_dev, void* stream) {
+                      int64_t T, uint64_t seed, uint64_t call_counter,
+                      int64_t* call_counter_dev, int64_t* rows_out, float* prob_out,
+                      int* err_flag_dev, void* stream) {
   if (S <= 0 || T <= 0 || batch <= 0 || max_len <= 0 || rows_out == nullptr ||
       last_id_dev == nullptr)
     return AA_ERR_INVALID;
@@ -214,7 +223,12 @@ int aa_rb_sample_rows(const int64_t* last_id_dev, int64_t batch, int64_t max_len
   if (grid > 0x7fffffffLL) return AA_ERR_RANGE;
   hipLaunchKernelGGL(aa_rb_sample_kernel, dim3((unsigned)grid), dim3(threads), 0,
                      (hipStream_t)stream, last_id_dev, batch, max_len, S, T, (uint32_t)seed,
-                     (uint32_t)(seed >> 32), call_counter, rows_out, prob_out, err_flag_dev);
+                     (uint32_t)(seed >> 32), call_counter, call_counter_dev,
+                     (call_counter_dev != nullptr && grid == 1) ? 1 : 0, rows_out, prob_out,
+                     err_flag_dev);
+  if (call_counter_dev != nullptr && grid != 1)
+    hipLaunchKernelGGL(aa_rb_bump_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                       call_counter_dev, (int64_t)1);
   return aa_launch_status();
 }
 

@@ -7,6 +7,7 @@
 //   RandomTFEnvironment           tf_agents/environments/random_tf_environment.py
 //   auto-reset contract           tf_agents/environments/py_environment.py:233-239
 #include "common.h"
+#include <chrono>
 #include "agents_amd.h"
 #include <float.h>
 
@@ -128,7 +129,8 @@ aa_vecenv_step_kernel(const int32_t* __restrict__ cur_step_type, int64_t B, int6
 // (tf_agents/drivers/dynamic_step_driver.py:113,170).  One workgroup, deterministic.
 __global__ void __launch_bounds__(256)
 aa_count_steps_kernel(const int32_t* __restrict__ step_type, int64_t B,
-                      int32_t* __restrict__ counter, int64_t* __restrict__ total) {
+                      int32_t* __restrict__ counter, int64_t* __restrict__ total,
+                      int64_t* mailbox) {
   __shared__ float red[16];
   float s = 0.f;
   for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
@@ -137,17 +139,68 @@ aa_count_steps_kernel(const int32_t* __restrict__ step_type, int64_t B,
     s += (float)inc;
   }
   const float t = aa_block_sum(s, red);
-  if (threadIdx.x == 0) *total += (int64_t)(t + 0.5f);
+  if (threadIdx.x == 0) {
+    const int64_t tot = *total + (int64_t)(t + 0.5f);
+    *total = tot;
+    if (mailbox != nullptr) {
+      // host-visible: value, fence, then the sequence word the host spins on
+      __hip_atomic_store(&mailbox[1], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+      const int64_t seq = __hip_atomic_load(&mailbox[0], __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_SYSTEM) + 1;
+      __hip_atomic_store(&mailbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 extern "C" {
 
 int aa_count_steps(const int32_t* step_type, int64_t B, int32_t* counter_dev, int64_t* total_dev,
-                   void* stream) {
+                   int64_t* mailbox, void* stream) {
   if (!step_type || !total_dev || B <= 0 || B > (1 << 24)) return AA_ERR_INVALID;
   hipLaunchKernelGGL(aa_count_steps_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, step_type,
-                     B, counter_dev, total_dev);
+                     B, counter_dev, total_dev, mailbox);
   return aa_launch_status();
+}
+
+int aa_mailbox_create(int64_t n_words, int64_t** host_ptr, int64_t** dev_ptr) {
+  if (n_words <= 0 || !host_ptr || !dev_ptr) return AA_ERR_INVALID;
+  void* h = nullptr;
+  if (hipHostMalloc(&h, (size_t)n_words * sizeof(int64_t),
+                    hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+    return AA_ERR_LAUNCH;
+  for (int64_t i = 0; i < n_words; ++i) ((volatile int64_t*)h)[i] = 0;
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+    (void)hipHostFree(h);
+    return AA_ERR_LAUNCH;
+  }
+  *host_ptr = (int64_t*)h;
+  *dev_ptr = (int64_t*)d;
+  return AA_OK;
+}
+
+int aa_mailbox_destroy(int64_t* host_ptr) {
+  if (!host_ptr) return AA_ERR_INVALID;
+  return hipHostFree(host_ptr) == hipSuccess ? AA_OK : AA_ERR_LAUNCH;
+}
+
+int aa_mailbox_wait(const int64_t* host_ptr, int64_t seq, int64_t timeout_us, int64_t* value) {
+  if (!host_ptr || !value) return AA_ERR_INVALID;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  for (;;) {
+    const int64_t cur = __atomic_load_n(&host_ptr[0], __ATOMIC_ACQUIRE);
+    if (cur >= seq) {
+      *value = __atomic_load_n(&host_ptr[1], __ATOMIC_RELAXED);
+      return AA_OK;
+    }
+    if ((++spins & 0x3ff) == 0) {
+      const auto dt = std::chrono::duration_cast<std::chrono::microseconds>(
+                          std::chrono::steady_clock::now() - t0).count();
+      if (dt > timeout_us) return AA_ERR_TIMEOUT;
+    }
+  }
 }
 
 int aa_eps_greedy_action(const float* q, const int32_t* mask, int64_t B, int32_t A, float epsilon,

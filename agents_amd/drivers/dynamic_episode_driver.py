@@ -37,7 +37,7 @@ class DynamicEpisodeDriver(driver.Driver):
             self._total = torch.zeros((1,), dtype=torch.int64, device=st.device)
         with torch.cuda.device(st.device):
             _lib.check(lib.aa_count_steps(st.data_ptr(), st.numel(), None,
-                                          self._total.data_ptr(), _lib.stream_ptr()),
+                                          self._total.data_ptr(), None, _lib.stream_ptr()),
                        "aa_count_steps")
         return st.numel()
 

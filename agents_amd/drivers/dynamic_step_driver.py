@@ -51,7 +51,7 @@ class DynamicStepDriver(driver.Driver):
             self._counter = torch.zeros((B,), dtype=torch.int32, device=st.device)
         with torch.cuda.device(st.device):
             _lib.check(lib.aa_count_steps(st.data_ptr(), B, self._counter.data_ptr(),
-                                          self._total.data_ptr(), _lib.stream_ptr()),
+                                          self._total.data_ptr(), None, _lib.stream_ptr()),
                        "aa_count_steps")
         return B
 

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from agents_amd import _lib
+from agents_amd.utils import graph
 from agents_amd.environments import tf_environment
 from agents_amd.specs import tensor_spec
 from agents_amd.trajectories import time_step as ts
@@ -42,6 +43,7 @@ class RandomTFEnvironment(tf_environment.TFEnvironment):
         self._device = torch.device(device) if device is not None else torch.device("cuda")
         self._step_counter = torch.zeros((1,), dtype=torch.int64, device=self._device)
         self._time_step = None
+        self._ring = None
 
     def _alloc(self):
         B = self._batch_size
@@ -53,9 +55,27 @@ class RandomTFEnvironment(tf_environment.TFEnvironment):
             observation=torch.empty((B,) + tuple(self._obs_spec.shape),
                                     dtype=self._obs_spec.dtype, device=dev))
 
+    def graph_ring(self):
+        """Switches the environment to two alternating output buffers (instead of a fresh
+        TimeStep per step) and returns the ring: what HIP-graph replay of a driver loop body
+        needs, since a captured step reads and writes fixed addresses.  A TimeStep handed out by
+        `step()` then stays valid for one further step."""
+        if self._ring is None:
+            self._ring = _TimeStepRing([self._alloc(), self._alloc()])
+        return self._ring
+
+    def _next_out(self):
+        if self._ring is None:
+            return self._alloc()
+        cur = self._ring.slot_of(self._time_step) if self._time_step is not None else None
+        return self._ring.slots[1 - cur] if cur is not None else self._ring.slots[0]
+
+    def _set_time_step(self, out):
+        self._time_step = out
+
     def _launch(self, cur_step_type, force_first):
         lib = _lib.load()
-        out = self._alloc()
+        out = self._next_out()
         with torch.cuda.device(self._device):
             st = _lib.stream_ptr()
             _lib.check(lib.aa_vecenv_random_step(
@@ -80,5 +100,23 @@ class RandomTFEnvironment(tf_environment.TFEnvironment):
     def _step(self, action):
         if self._time_step is None:
             return self._reset()
-        self._time_step = self._launch(self._time_step.step_type, False)
-        return self._time_step
+        out = self._launch(self._time_step.step_type, False)
+        # under HIP-graph capture the reference to the current step must move on every replay
+        graph.on_replay(lambda: self._set_time_step(out))
+        if graph.capturing():
+            self._time_step = out     # so that a second step captured in the same graph chains
+        return out
+
+
+class _TimeStepRing:
+    """Two preallocated TimeSteps the environment alternates between."""
+
+    def __init__(self, slots):
+        self.slots = slots
+        self._ptrs = [ts_.observation.data_ptr() for ts_ in slots]
+
+    def slot_of(self, time_step):
+        try:
+            return self._ptrs.index(time_step.observation.data_ptr())
+        except ValueError:
+            return None

@@ -24,7 +24,7 @@ from agents_amd import _lib
 from agents_amd.replay_buffers import replay_buffer, table
 from agents_amd.replay_buffers.dataset import Dataset
 from agents_amd.specs import tensor_spec
-from agents_amd.utils import nest_utils
+from agents_amd.utils import graph, nest_utils
 
 BufferInfo = collections.namedtuple("BufferInfo", ["ids", "probabilities"])
 
@@ -59,7 +59,7 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
 
     def __init__(self, data_spec, batch_size, max_length=1000, scope="TFUniformReplayBuffer",
                  device=None, table_fn=table.Table, dataset_drop_remainder=False,
-                 dataset_window_shift=None, stateful_dataset=False, seed=0):
+                 dataset_window_shift=None, stateful_dataset=False, seed=0, dataset_ring=8):
         self._batch_size = int(batch_size)
         self._max_length = int(max_length)
         capacity = self._batch_size * self._max_length
@@ -73,6 +73,7 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
         self._table_fn = table_fn
         self._dataset_drop_remainder = dataset_drop_remainder
         self._dataset_window_shift = dataset_window_shift
+        self._dataset_ring = int(dataset_ring)   # 0 -> as_dataset elements are fresh tensors
         self._id_spec = tensor_spec.TensorSpec((), torch.int64, name="id")
         self._data_table = table_fn(self._data_spec, capacity, device=self._device)
         self._id_table = table_fn(self._id_spec, capacity, device=self._device)
@@ -80,7 +81,9 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
         self._err_flag = torch.zeros((1,), dtype=torch.int32, device=self._device)
         self._last_id_host = -1          # mirror: every add_batch is +1, clear() is -> -1
         self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-        self._sample_calls = 0           # Philox call counter (one per get_next)
+        self._sample_calls = 0           # Philox call counter (one per get_next), host mirror
+        # the counter the kernels read: device resident so that captured graphs advance it
+        self._sample_calls_dev = torch.zeros((1,), dtype=torch.int64, device=self._device)
 
     # ---- properties ------------------------------------------------------------------------
     @property
@@ -120,24 +123,35 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
                 p.tables, p.ios, p.row_bytes, p.n, self._id_table.variables()[0].data_ptr(),
                 self._last_id.data_ptr(), self._batch_size, self._max_length, _lib.stream_ptr()),
                 "aa_rb_scatter_rows")
+        graph.on_replay(self._bump_last_id_host)
+
+    def _bump_last_id_host(self):
         self._last_id_host += 1
+
+    def _bump_sample_calls(self):
+        self._sample_calls += 1
+
+    def _check_not_empty(self, num_steps):
+        lo, hi = _valid_range_ids(self._last_id_host, self._max_length, num_steps)
+        if hi <= lo:
+            raise RuntimeError(_EMPTY_SAMPLE)
 
     def _sample_rows(self, S, T):
         lib = _lib.load()
         rows = torch.empty((S, T), dtype=torch.int64, device=self._device)
         probs = torch.empty((S,), dtype=torch.float32, device=self._device)
+        # call counter = 0 + *device counter; the launch advances the device counter by one
         _lib.check(lib.aa_rb_sample_rows(
             self._last_id.data_ptr(), self._batch_size, self._max_length, S, T, self._seed,
-            self._sample_calls, rows.data_ptr(), probs.data_ptr(), self._err_flag.data_ptr(),
-            _lib.stream_ptr()), "aa_rb_sample_rows")
-        self._sample_calls += 1
+            0, self._sample_calls_dev.data_ptr(), rows.data_ptr(), probs.data_ptr(),
+            self._err_flag.data_ptr(), _lib.stream_ptr()), "aa_rb_sample_rows")
+        graph.on_replay(self._bump_sample_calls)
         return rows, probs
 
     def _get_next(self, sample_batch_size=None, num_steps=None, time_stacked=True):
         """Uniformly sampled items (:211-310).  Returns (data, BufferInfo(ids, probabilities))."""
-        lo, hi = _valid_range_ids(self._last_id_host, self._max_length, num_steps)
-        if hi <= lo:
-            raise RuntimeError(_EMPTY_SAMPLE)
+        if not graph.capturing():
+            self._check_not_empty(num_steps)
         S = 1 if sample_batch_size is None else int(sample_batch_size)
         T = 1 if num_steps is None else int(num_steps)
         with torch.cuda.device(self._device):
@@ -180,8 +194,15 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
             raise NotImplementedError("sequence_preprocess_fn is not supported.")
 
         def gen():
+            # the iterator replays a HIP graph of (sample, gather) after two eager draws; its
+            # elements live in a ring of static buffers (graph.GraphedSampler)
+            if self._dataset_ring <= 0:
+                while True:
+                    yield self.get_next(sample_batch_size, num_steps, time_stacked=True)
+            sampler = graph.GraphedSampler(self, sample_batch_size, num_steps,
+                                           ring=self._dataset_ring)
             while True:
-                yield self.get_next(sample_batch_size, num_steps, time_stacked=True)
+                yield sampler.next()
 
         return Dataset(gen, infinite=True)
 
@@ -255,6 +276,7 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
         self._last_id_host = int(sd["last_id"])
         self._last_id.fill_(self._last_id_host)
         self._sample_calls = int(sd["sample_calls"])
+        self._sample_calls_dev.fill_(self._sample_calls)
         self._seed = int(sd["seed"])
 
 

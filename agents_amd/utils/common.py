@@ -25,6 +25,11 @@ def function(*args, **kwargs):
                 hasattr(owner, "_train_phase_grads"):
             from agents_amd.utils import graph
             return graph.graphed_train(owner)
+        # `common.function(driver.run)` (train_eval.py:234-237): HIP-graph replay of the loop body
+        if owner is not None and getattr(fn, "__name__", "") == "run" and \
+                type(owner).__name__ == "DynamicStepDriver":
+            from agents_amd.utils import graph
+            return graph.graphed_driver_run(owner)
         return fn
 
     if len(args) == 1 and callable(args[0]) and not kwargs:

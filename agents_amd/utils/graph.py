@@ -1,22 +1,83 @@
-"""HIP-graph capture of an agent's train step: the MI355X counterpart of wrapping `agent.train`
-in `common.function` (tf.function) as the reference's scripts do
+"""HIP-graph capture of the trainer loop's three device programs -- the MI355X counterpart of
+wrapping them in `common.function` (tf.function) as the reference's scripts do
 (tf_agents/agents/dqn/examples/v2/train_eval.py:234-237) and as `Learner._train` is
-(tf_agents/train/learner.py:309-337).
+(tf_agents/train/learner.py:309-337):
 
-A train step is ~45 short kernels; launched one by one from Python it is host-bound (~14 us per
-launch against 5-50 us of GPU work each).  `GraphedTrain` runs the step eagerly twice (buffers
-and workspaces get created), then captures its two device phases -- [forwards + loss + backward]
-and [optimizer] -- into hipGraphs on static input buffers and replays them: per step the host
-issues a handful of copies of the sampled batch into the static buffers plus two graph launches.
-The gradient hook (the Learner's RCCL all-reduce) runs between the two graphs, outside capture.
-Host bookkeeping (train_step_counter, optimizer.iterations, the periodic target update decided by
-a host counter) stays in Python, exactly as in the eager path.
+  GraphedTrain      agent.train            (forwards + loss + backward | optimizer)
+  GraphedDriverRun  DynamicStepDriver.run  (one loop body = policy forward, action select, env
+                                            step, replay add, step counter)
+  GraphedSampler    replay get_next        (index sampling + row gather; a ring of output buffers)
+
+Each of these is a chain of 10-45 short kernels; launched one by one from Python the loop is
+host-bound (~14 us per launch against 5-50 us of GPU work each), replayed as graphs the host
+issues about five graph launches per iteration.
+
+Python side effects inside a captured region happen at capture time only -- exactly tf.function's
+tracing semantics.  Components whose host mirrors must advance per execution (the replay buffer's
+`last_id` mirror, the environment's current-time-step reference, a decaying epsilon) register them
+with `on_replay`, which runs them before every replay.
 """
 import torch
 
 from agents_amd.utils import nest_utils
 
 _WARMUP_CALLS = 2
+_MAX_BINDINGS = 16   # captured train graphs per input signature (one per sampler ring slot)
+
+# ---- capture context: host bookkeeping that must run once per replay ------------------------
+_CAPTURE = None
+
+
+class _CaptureCtx:
+    def __init__(self):
+        self.hooks = []
+
+
+def capturing():
+    """True while one of this module's captures is recording."""
+    return _CAPTURE is not None
+
+
+def on_replay(fn):
+    """Runs `fn()` now -- or, while a HIP graph is being captured, registers it to run before
+    every replay of that graph (capture itself executes nothing, so it is not run now)."""
+    if _CAPTURE is None:
+        fn()
+    else:
+        _CAPTURE.hooks.append(fn)
+
+
+class _Captured:
+    """A torch CUDAGraph plus the host hooks registered while it was captured."""
+
+    def __init__(self):
+        self.graph = None
+        self.hooks = []
+        self.out = None
+
+    def capture(self, fn):
+        global _CAPTURE
+        if _CAPTURE is not None:
+            raise RuntimeError("nested HIP-graph capture")
+        ctx = _CaptureCtx()
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        _CAPTURE = ctx
+        try:
+            with torch.cuda.graph(g):
+                self.out = fn()
+        finally:
+            _CAPTURE = None
+        torch.cuda.synchronize()
+        self.graph = g
+        self.hooks = ctx.hooks
+        return self.out
+
+    def replay(self):
+        for h in self.hooks:
+            h()
+        self.graph.replay()
+        return self.out
 
 
 class _Entry:
@@ -43,7 +104,9 @@ class GraphedTrain:
 
     def __init__(self, agent):
         self._agent = agent
-        self._cache = {}
+        self._cache = {}       # signature -> {input address tuple | None: _Entry}
+        self._warm = {}
+        self._seen = {}
         self.enabled = all(hasattr(agent, n) for n in
                            ("_train_phase_grads", "_train_phase_apply", "_train_phase_host"))
         self.replays = 0
@@ -54,24 +117,42 @@ class GraphedTrain:
 
     def __call__(self, experience, weights=None, **kwargs):
         agent = self._agent
-        if not self.enabled or kwargs or getattr(agent, "check_numerics", False):
+        if not self.enabled or kwargs or getattr(agent, "check_numerics", False) or capturing():
             return agent.train(experience, weights=weights, **kwargs)
-        key = _sig(experience, weights)
-        e = self._cache.get(key)
-        if e is None:
-            e = self._cache[key] = _Entry()
-        if e.calls < _WARMUP_CALLS:
-            e.calls += 1
+        sig = _sig(experience, weights)
+        if self._warm.get(sig, 0) < _WARMUP_CALLS:
+            self._warm[sig] = self._warm.get(sig, 0) + 1
             return agent.train(experience, weights=weights)
         if not agent._initialized:
             agent.initialize()
         agent._check_trajectory(experience)
+        # Graphs are bound to the ADDRESSES of their inputs.  A sampler that hands out a ring of
+        # static buffers (GraphedSampler) gets one captured graph per ring slot -- no copies; any
+        # other caller (fresh tensors every step) shares the first graph and pays one copy per
+        # leaf into its static inputs.
+        ptrs = tuple(t.data_ptr() for t in nest_utils.flatten(experience))
+        bound = self._cache.setdefault(sig, {})
+        e = bound.get(ptrs)
         dev = experience.discount.device
         with torch.cuda.device(dev):
-            if e.g_grads is None:
-                self._capture(e, experience, weights)
-            # copy the sampled batch into the graph's static inputs (skipped when the caller
-            # already wrote into them, e.g. a sampler bound to `static_inputs()`)
+            if e is None and not bound:
+                # first graph: captured on private clones; serves every caller through copies
+                e = _Entry()
+                self._capture(e, experience, weights, clone=True)
+                bound[None] = e
+            elif e is None:
+                seen = self._seen.setdefault(sig, {})
+                seen[ptrs] = seen.get(ptrs, 0) + 1
+                if seen[ptrs] >= 2 and len(bound) < _MAX_BINDINGS:
+                    # an address set that came back (a ring slot): worth its own graph
+                    e = _Entry()
+                    self._capture(e, experience, weights, clone=False,
+                                  g_apply=bound[None].g_apply)
+                    bound[ptrs] = e
+                if len(seen) > 4 * _MAX_BINDINGS:
+                    seen.clear()
+            if e is None:
+                e = bound[None]
             for dst, src in zip(nest_utils.flatten(e.static_in), nest_utils.flatten(experience)):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src, non_blocking=True)
@@ -86,9 +167,10 @@ class GraphedTrain:
         self.replays += 1
         return e.out
 
-    def _capture(self, e, experience, weights):
+    def _capture(self, e, experience, weights, clone=True, g_apply=None):
         agent = self._agent
-        e.static_in = nest_utils.map_structure(lambda t: t.clone(), experience)
+        e.static_in = nest_utils.map_structure(lambda t: t.clone(), experience) if clone \
+            else experience
         e.static_w = weights.clone() if isinstance(weights, torch.Tensor) else None
         w_arg = e.static_w if e.static_w is not None else weights
         torch.cuda.synchronize()
@@ -96,17 +178,21 @@ class GraphedTrain:
         e.g_grads = torch.cuda.CUDAGraph()
         with torch.cuda.graph(e.g_grads):
             e.out = agent._train_phase_grads(e.static_in, w_arg)
-        e.g_apply = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(e.g_apply):
-            agent._train_phase_apply()
+        if g_apply is not None:
+            e.g_apply = g_apply          # the optimizer phase does not depend on the inputs
+        else:
+            e.g_apply = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(e.g_apply):
+                agent._train_phase_apply()
         agent._optimizer.iterations = iters  # capture enqueues nothing; undo the host mirror bump
         torch.cuda.synchronize()
 
     def static_inputs(self, experience_like=None):
         """Static input nest of the (single) captured signature, or None before capture."""
-        for e in self._cache.values():
-            if e.static_in is not None:
-                return e.static_in
+        for bound in self._cache.values():
+            for e in bound.values():
+                if e.static_in is not None:
+                    return e.static_in
         return None
 
 
@@ -116,4 +202,180 @@ def graphed_train(agent):
     if g is None:
         g = GraphedTrain(agent)
         agent._graphed_train = g
+    return g
+
+
+class GraphedSampler:
+    """`next()` == `rb.get_next(S, T)` (tf_uniform_replay_buffer.py:211-310), replayed as a HIP
+    graph of the two kernels (index sampling, row gather).  Outputs live in a ring of `ring`
+    static buffer sets: an element stays valid until `ring - 1` further elements have been drawn
+    (the reference's dataset hands out fresh tensors; consumers that keep samples longer than that
+    should call `get_next` directly).  The Philox call counter is device-resident, so the sampled
+    indices are bit-identical to the eager path's."""
+
+    def __init__(self, rb, sample_batch_size, num_steps, ring=8):
+        self._rb = rb
+        self._S = sample_batch_size
+        self._T = num_steps
+        self._ring = [None] * max(int(ring), 2)
+        self._i = 0
+        self._warm = 0
+        self.enabled = True
+        self.replays = 0
+
+    def next(self):
+        rb = self._rb
+        if not self.enabled or self._warm < _WARMUP_CALLS or capturing():
+            self._warm += 1
+            return rb.get_next(self._S, self._T, time_stacked=True)
+        rb._check_not_empty(self._T)
+        slot = self._i % len(self._ring)
+        self._i += 1
+        c = self._ring[slot]
+        with torch.cuda.device(rb.device):
+            if c is None:
+                c = _Captured()
+                try:
+                    c.capture(lambda: rb.get_next(self._S, self._T, time_stacked=True))
+                except Exception:
+                    self.enabled = False
+                    raise
+                self._ring[slot] = c
+            out = c.replay()
+        self.replays += 1
+        return out
+
+
+class GraphedDriverRun:
+    """`common.function(driver.run)` for a DynamicStepDriver: the loop body
+    (dynamic_step_driver.py:118-172) is captured once per environment output buffer (two: the
+    environment alternates between them) and replayed; the loop condition
+    `sum(counter) < num_steps` (:113) is evaluated on the host from a pinned-memory mailbox the
+    step-counter kernel writes at the START of each body (the count only depends on the incoming
+    step types), so the host learns whether another iteration is needed while the GPU is still
+    executing the body -- no stream synchronisation, and the same iteration count as the
+    reference's in-graph while_loop in every case.
+
+    Requirements, checked at first use: the environment supports `graph_ring()`, the policy has no
+    state, observers are device-side (the replay buffer's add_batch) or tolerate tf.function-style
+    tracing.  Otherwise every call falls through to the eager `driver.run`."""
+
+    def __init__(self, driver):
+        self._driver = driver
+        self._eager_run = driver.run          # bound method, captured before any patching
+        self._graphs = {}
+        self._warm = 0
+        self._seq = 0                          # replays issued == mailbox sequence expected
+        self._total_host = 0                   # exact device total at the start of the next run
+        self._total = None
+        self._counter = None
+        self._mbox_host = None
+        self._mbox_dev = None
+        self.enabled = hasattr(driver.env, "graph_ring") and not driver._transition_observers
+        self.replays = 0
+
+    def __del__(self):
+        try:
+            if self._mbox_host is not None:
+                from agents_amd import _lib
+                _lib.load().aa_mailbox_destroy(self._mbox_host)
+        except Exception:
+            pass
+
+    def _setup(self, dev, B):
+        import ctypes
+        from agents_amd import _lib
+        lib = _lib.load()
+        h, d = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.aa_mailbox_create(2, ctypes.byref(h), ctypes.byref(d)), "aa_mailbox_create")
+        self._mbox_host, self._mbox_dev = h.value, d.value
+        self._total = torch.zeros((1,), dtype=torch.int64, device=dev)
+        self._counter = torch.zeros((B,), dtype=torch.int32, device=dev)
+
+    def _body(self, time_step, policy_state):
+        """One loop body; the step count comes first (it only needs time_step.step_type)."""
+        from agents_amd import _lib
+        from agents_amd.trajectories import trajectory
+        drv = self._driver
+        lib = _lib.load()
+        st = time_step.step_type
+        _lib.check(lib.aa_count_steps(st.data_ptr(), st.numel(), self._counter.data_ptr(),
+                                      self._total.data_ptr(), self._mbox_dev, _lib.stream_ptr()),
+                   "aa_count_steps")
+        action_step = drv.policy.action(time_step, policy_state)
+        next_time_step = drv.env.step(action_step.action)
+        traj = trajectory.from_transition(time_step, action_step, next_time_step)
+        for observer in drv._observers:
+            observer(traj)
+        return next_time_step
+
+    def _wait_total(self):
+        import ctypes
+        from agents_amd import _lib
+        v = ctypes.c_int64(0)
+        _lib.check(_lib.load().aa_mailbox_wait(self._mbox_host, self._seq, 60_000_000,
+                                               ctypes.byref(v)), "aa_mailbox_wait")
+        self._total_host = int(v.value)
+        return self._total_host
+
+    def __call__(self, time_step=None, policy_state=None, maximum_iterations=None):
+        drv = self._driver
+        env = drv.env
+        if not self.enabled or capturing():
+            return self._eager_run(time_step, policy_state, maximum_iterations)
+        if policy_state is None:
+            policy_state = drv.policy.get_initial_state(env.batch_size)
+        if self._warm < _WARMUP_CALLS or policy_state != ():
+            self._warm += 1
+            return self._eager_run(time_step, policy_state, maximum_iterations)
+        if time_step is None:
+            time_step = env.current_time_step()
+        st = time_step.step_type
+        if st.dim() != 1 or st.dtype != torch.int32 or not st.is_cuda:
+            return self._eager_run(time_step, policy_state, maximum_iterations)
+        B = st.numel()
+        with torch.cuda.device(st.device):
+            if self._total is None:
+                self._setup(st.device, B)
+            ring = env.graph_ring()
+            num_steps = drv._num_steps
+            target = self._total_host + num_steps
+            n_min = -(-num_steps // B)
+            it = 0
+            while maximum_iterations is None or it < maximum_iterations:
+                if it >= n_min and self._wait_total() >= target:
+                    break
+                slot = ring.slot_of(time_step)
+                if slot is None or slot != ring.slot_of(env.current_time_step()):
+                    # a TimeStep that is not the environment's current ring buffer (first calls,
+                    # or a caller-made one): one eager run brings the loop into the ring
+                    if it > 0:
+                        self._wait_total()
+                    return self._eager_run(time_step, policy_state,
+                                           None if maximum_iterations is None
+                                           else maximum_iterations - it)
+                c = self._graphs.get(slot)
+                if c is None:
+                    c = _Captured()
+                    ts_in = time_step
+                    try:
+                        c.capture(lambda: self._body(ts_in, policy_state))
+                    except Exception:
+                        self.enabled = False
+                        raise
+                    self._graphs[slot] = c
+                time_step = c.replay()
+                self._seq += 1
+                self.replays += 1
+                it += 1
+            else:
+                self._wait_total()
+        return time_step, policy_state
+
+
+def graphed_driver_run(driver):
+    g = getattr(driver, "_graphed_run", None)
+    if g is None:
+        g = GraphedDriverRun(driver)
+        driver._graphed_run = g
     return g

@@ -229,7 +229,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--max-length", type=int, default=3906,
                     help="replay frames per env (3906 x 256 envs = the 1M-row config)")
     ap.add_argument("--batch", type=int, default=256)
@@ -269,11 +269,14 @@ def main():
             f"({w['rb'].num_frames() * ROW_BYTES / 1e9:.1f} GB) in {time.perf_counter() - t0:.1f}s")
     it = iter(w["dataset"])
     lrn, drv = w["learner"], w["collect_driver"]
+    # train_eval.py:234-237: `collect_driver.run = common.function(collect_driver.run)`
+    from agents_amd.utils import common
+    collect_run = common.function(drv.run)
     time_step = None
 
     def step():
         nonlocal time_step
-        time_step, _ = drv.run(time_step)
+        time_step, _ = collect_run(time_step)
         return lrn.run(iterations=1, iterator=it)
 
     def sync_all():

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 2
+#define AA_ABI_VERSION 3
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -49,8 +49,11 @@ int aa_rb_scatter_rows(void* const* leaf_tables_h, const void* const* leaf_items
  * prob_out[s] = 1/((max-min)*batch) (:255-264).  Sets *err_flag_dev = 1 if the buffer is empty
  * (the reference's assert_greater at :246-253).  Replaces tf.random.uniform(int64) x2. */
 int aa_rb_sample_rows(const int64_t* last_id_dev, int64_t batch, int64_t max_len, int64_t S,
-                      int64_t T, uint64_t seed, uint64_t call_counter, int64_t* rows_out,
-                      float* prob_out, int* err_flag_dev, void* stream);
+                      int64_t T, uint64_t seed, uint64_t call_counter,
+                      int64_t* call_counter_dev /* nullable: *call_counter_dev is added to
+                      call_counter and then incremented by one on the device, so a captured HIP
+                      graph advances the stream without new kernel arguments */,
+                      int64_t* rows_out, float* prob_out, int* err_flag_dev, void* stream);
 
 /* Row gather of every leaf + the id table: out[r] = table[rows[r]].
  * Replaces Table.read / ResourceVariable.sparse_read per leaf (table.py:86-110). */
@@ -189,9 +192,22 @@ int aa_eps_greedy_action(const float* q, const int32_t* mask /* nullable [B,A] *
                          void* actions_out, int32_t actions_are_i64, void* stream);
 
 /* DynamicStepDriver loop counter: counter[b] += (step_type[b] != LAST); *total_dev += the sum
- * (drivers/dynamic_step_driver.py:113,170).  counter_dev nullable. */
+ * (drivers/dynamic_step_driver.py:113,170).  counter_dev nullable.  mailbox (nullable) is a
+ * host-visible int64[2] from aa_mailbox_create: the kernel stores {sequence number, total} there
+ * (total first, then a system-scope fence, then ++sequence), which is how the host evaluates the
+ * reference's in-graph loop condition `sum(counter) < num_steps` (:113) while HIP graphs of the
+ * loop body replay, without a stream synchronisation. */
 int aa_count_steps(const int32_t* step_type, int64_t B, int32_t* counter_dev, int64_t* total_dev,
-                   void* stream);
+                   int64_t* mailbox, void* stream);
+
+/* Host-visible, device-writable mailbox of n int64 words (coherent pinned host memory), zeroed.
+ * *host_ptr is what the host reads, *dev_ptr what kernels are given. */
+int aa_mailbox_create(int64_t n_words, int64_t** host_ptr, int64_t** dev_ptr);
+int aa_mailbox_destroy(int64_t* host_ptr);
+/* Spins until mailbox[0] >= seq or timeout_us elapses; returns 0 and stores mailbox[1] in *value,
+ * or AA_ERR_TIMEOUT. */
+#define AA_ERR_TIMEOUT (-62)
+int aa_mailbox_wait(const int64_t* host_ptr, int64_t seq, int64_t timeout_us, int64_t* value);
 
 #define AA_OBS_U8 0
 #define AA_OBS_F32 1

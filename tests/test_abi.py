@@ -28,12 +28,12 @@ def test_binding_covers_header(lib):
 
 
 def test_abi_version(lib):
-    assert lib.aa_abi_version() == 2
+    assert lib.aa_abi_version() == 3
 
 
 def test_argument_validation_without_gpu(lib):
     """Entry points reject bad arguments before touching the device."""
-    assert lib.aa_rb_sample_rows(None, 1, 1, 1, 1, 0, 0, None, None, None, None) == -22
+    assert lib.aa_rb_sample_rows(None, 1, 1, 1, 1, 0, 0, None, None, None, None, None) == -22
     assert lib.aa_counter_add(None, 1, None) == -22
     d = _lib.GemmDesc()
     assert lib.aa_gemm_f32_workspace_bytes(ctypes.byref(d)) == -1

@@ -90,7 +90,7 @@ def test_gpu_replay_rows_match_golden_bit_exact(dev):
         rows = torch.empty((n, T), dtype=torch.int64, device=dev)
         prob = torch.empty((n,), dtype=torch.float32, device=dev)
         err = torch.zeros((1,), dtype=torch.int32, device=dev)
-        _lib.check(lib.aa_rb_sample_rows(lid.data_ptr(), B, L, n, T, seed, call, rows.data_ptr(),
+        _lib.check(lib.aa_rb_sample_rows(lid.data_ptr(), B, L, n, T, seed, call, None, rows.data_ptr(),
                                          prob.data_ptr(), err.data_ptr(), _lib.stream_ptr()),
                    "sample")
         np.testing.assert_array_equal(rows.cpu().numpy(), G[f"replay_{name}_rows"])

@@ -1,0 +1,19 @@
+"""Runs N full bench iterations (small replay) for profiling: python tools/step_loop.py [N]"""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+w = bench.build_workload(dev, 0, 1, 256, 64, 256, seed=1)
+w["init_driver"]._num_steps = 256 * 64
+w["init_driver"].run()
+it = iter(w["dataset"])
+ts = None
+for _ in range(N):
+    ts, _ = w["collect_driver"].run(ts)
+    w["learner"].run(iterations=1, iterator=it)
+torch.cuda.synchronize()
+print("done")
