@@ -40,6 +40,7 @@ __device__ static inline void aa_static_for(F&& f) {
 }
 
 #define AA_GEMM_THREADS 256
+#define AA_INKERNEL_MAX_SPLITS 8
 #define AA_BK 32
 
 struct GemmP {
@@ -60,6 +61,11 @@ struct GemmP {
   float* colsum_out; // nullable: sum_k B(k,n) (bias gradient fused into the dW GEMM)
   int k_per_split;
   int splits;
+  int* counters;     // non-null: split-K slabs are reduced in this launch by each output tile's
+                     // last-arriving workgroup (arrival counters, self-resetting)
+  float* Cout;       // final output of the in-kernel reduction (p.C is the slab base then)
+  int ldc_out;
+  int red_vec;       // the in-kernel reduction may use 16-byte accesses
   const float* bias;
   int act;
   const float* mask_src;
@@ -315,6 +321,73 @@ __device__ static inline void store_D_patchT_u8(const StageU8& s, float* tile, c
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// In-kernel split-K reduction.  Every workgroup of output tile (bx, by) has written its raw
+// partial tile into slab z = blockIdx.z; the LAST one to arrive (agent-scope arrival counter,
+// release fence before the increment, acquire fence after observing the final count) sums the
+// `splits` slabs of its tile in fixed z order -- so the result does not depend on which group
+// came last -- applies the epilogue and stores C.  Replaces a separate reduce launch per
+// split-K GEMM (eight per DQN train step).  The counter is reset by the group that consumed it.
+// ------------------------------------------------------------------------------------------
+// Memory ordering without agent-scope fences (a release fence = an L2 write-back per workgroup,
+// measured 2x slower for the whole train step): slab elements are written with agent-scope
+// relaxed atomic stores (write-through to the coherence point, `sc1`), the arrival increment is
+// issued after `s_waitcnt vmcnt(0)` (every lane's stores acknowledged) + a workgroup barrier, and
+// the reducing group reads the slabs with agent-scope relaxed atomic loads (`sc1`: never served
+// from a non-coherent cache line).
+__device__ static inline void aa_slab_store(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ static inline float aa_slab_load(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int BM, int BN>
+__device__ static inline void aa_splitk_tail(const GemmP& p, int m0, int n0, bool colsum_tile) {
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's slab stores are acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+    const int prev = __hip_atomic_fetch_add(&p.counters[tile], 1, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+    const int last = prev == p.splits - 1;
+    if (last) __hip_atomic_store(&p.counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const size_t MN = (size_t)p.M * (size_t)p.N;
+  const float* slab = p.C;
+  const int rows = min(BM, p.M - m0), cols = min(BN, p.N - n0);
+  for (int i = threadIdx.x; i < rows * BN; i += AA_GEMM_THREADS) {
+    const int r = i / BN, c = i - r * BN;
+    if (c >= cols) continue;
+    const int m = m0 + r, n = n0 + c;
+    const float* src = slab + (size_t)m * p.N + n;
+    float v = 0.f;
+    int z = 0;
+    for (; z + 8 <= p.splits; z += 8) {   // eight loads in flight, summed in slab order
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = aa_slab_load(src + (size_t)(z + u) * MN);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; z < p.splits; ++z) v += aa_slab_load(src + (size_t)z * MN);
+    if (p.bias != nullptr) v += p.bias[n];
+    v = aa_act(v, p.act);
+    if (p.mask_kind != 0) v *= aa_actgrad(p.mask_src[(size_t)m * p.ldm + n], p.mask_kind);
+    p.Cout[(size_t)m * p.ldc_out + n] = v;
+  }
+  if (colsum_tile && threadIdx.x < cols) {   // fused bias gradient: rows [splits][N] after the slabs
+    const float* cs = slab + (size_t)p.splits * MN + n0 + threadIdx.x;
+    float v = 0.f;
+    for (int z = 0; z < p.splits; ++z) v += aa_slab_load(cs + (size_t)z * p.N);
+    p.colsum_out[n0 + threadIdx.x] = v;
+  }
+}
+
 #include "gemm_dma.h"
 
 // ------------------------------------------------------------------------------------------
@@ -490,6 +563,7 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
   }
 
   const bool raw = p.splits > 1;
+  const bool inkernel = raw && p.counters != nullptr;
 
   // ---- fused bias gradient: reduce the per-thread column sums over the k-rows -------------
   if constexpr (BMODE == AA_B_ROW) {
@@ -505,7 +579,7 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
         const int n = n0 + threadIdx.x;
         if (n < p.N) {
           if (raw)  // per-split partial rows after the slabs: [splits][N]
-            p.C[(size_t)p.splits * p.M * p.N + (size_t)blockIdx.z * p.N + n] = s;
+            aa_slab_store(&p.C[(size_t)p.splits * p.M * p.N + (size_t)blockIdx.z * p.N + n], s);
           else
             p.colsum_out[n] = s;
         }
@@ -528,7 +602,7 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
           for (int e = 0; e < 16; ++e) dst[((i * TN + j) * 16 + e) * 64] = acc[i][j][e];
     }
     __syncthreads();
-    if (wk > 0) return;
+    if (wk == 0) {
 #pragma unroll
     for (int w = 1; w < WGK; ++w) {
       const float* src = red + ((w - 1) * (WGM * WGN) + wmn) * PER + lane;
@@ -539,11 +613,13 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][j][e] += src[((i * TN + j) * 16 + e) * 64];
     }
+    }
   }
 
   // ---- epilogue ------------------------------------------------------------------------
   float* C = raw ? p.C + (size_t)blockIdx.z * (size_t)p.M * (size_t)p.N : p.C;
   const int ldc = raw ? p.N : p.ldc;
+  if (WGK == 1 || wk == 0) {
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -561,10 +637,15 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
           v = aa_act(v + bv, p.act);
           if (p.mask_kind != 0) v *= aa_actgrad(p.mask_src[(size_t)m * p.ldm + n], p.mask_kind);
         }
-        C[(size_t)m * ldc + n] = v;
+        if (inkernel)
+          aa_slab_store(&C[(size_t)m * ldc + n], v);
+        else
+          C[(size_t)m * ldc + n] = v;
       }
     }
   }
+  }
+  if (inkernel) aa_splitk_tail<BM, BN>(p, m0, n0, do_colsum);
 }
 
 // out[m][n] = epilogue( sum_z slab[z][m][n] ), fixed z order => deterministic.  Four consecutive
@@ -694,7 +775,7 @@ static int aa_gemm_plan(const aa_gemm_desc* d, AaGemmPlan* pl) {
   pl->splits = splits;
   pl->k_per_split = kps;
   pl->ws_bytes = splits > 1 ? (size_t)splits * (size_t)(M * N + (d->colsum_out ? N : 0)) *
-                                  sizeof(float)
+                                      sizeof(float) + AA_GEMM_COUNTER_BYTES
                             : 0;
   return AA_OK;
 }
@@ -865,7 +946,26 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
   p.mask_src = d->mask_src;
   p.ldm = d->ldm;
   p.mask_kind = d->mask_src != nullptr ? d->mask_kind : 0;
-  p.C = pl.splits > 1 ? (float*)workspace : d->C;
+  // workspace = [arrival counters: AA_GEMM_COUNTER_BYTES][slabs][bias-gradient partial rows]
+  float* slabs = (float*)((char*)workspace + AA_GEMM_COUNTER_BYTES);
+  p.C = pl.splits > 1 ? slabs : d->C;
+  p.counters = nullptr;
+  p.Cout = d->C;
+  p.ldc_out = d->ldc;
+  p.red_vec = (d->N % 4 == 0 && d->ldc % 4 == 0 && (((uintptr_t)d->C & 15) == 0) &&
+               (d->bias == nullptr || (((uintptr_t)d->bias & 15) == 0)) &&
+               (d->mask_src == nullptr || (d->ldm % 4 == 0 && (((uintptr_t)d->mask_src & 15) == 0))))
+                  ? 1 : 0;
+  {
+    const int64_t tiles = (int64_t)((d->M + pl.bm - 1) / pl.bm) * ((d->N + pl.bn - 1) / pl.bn);
+    // Measured on MI355X: one group summing its tile's slabs beats a second launch only for a
+    // few splits (the sum is a serial chain of coherent loads per output element); with 16-64
+    // splits the parallel reduce kernel wins (train step 472 us vs 519 us in-kernel everywhere).
+    const bool few = pl.splits <= AA_INKERNEL_MAX_SPLITS || d->ws_counters_zeroed == 2;
+    if (pl.splits > 1 && d->ws_counters_zeroed && few &&
+        tiles * (int64_t)sizeof(int) <= AA_GEMM_COUNTER_BYTES)
+      p.counters = (int*)workspace;
+  }
   hipStream_t st = (hipStream_t)stream;
 
   if (d->b_mode != AA_B_ROW && d->b_mode != AA_B_COL) return AA_ERR_INVALID;
@@ -883,7 +983,7 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
     default: return AA_ERR_INVALID;
   }
   if (rc != AA_OK) return rc;
-  if (pl.splits > 1) {
+  if (pl.splits > 1 && p.counters == nullptr) {
     const size_t MN = (size_t)d->M * d->N;
     const bool vec = d->N % 4 == 0 && d->ldc % 4 == 0 && (((uintptr_t)d->C & 15) == 0) &&
                      (d->mask_src == nullptr || d->ldm % 4 == 0);
@@ -892,11 +992,11 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
     if (blocks > 2048) blocks = 2048;
     if (vec)
       hipLaunchKernelGGL(aa_splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st,
-                         (const float*)workspace, pl.splits, d->M, d->N, d->C, d->ldc, d->bias,
+                         (const float*)slabs, pl.splits, d->M, d->N, d->C, d->ldc, d->bias,
                          d->act, d->mask_src, d->ldm, p.mask_kind, d->colsum_out);
     else
       hipLaunchKernelGGL(aa_splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st,
-                         (const float*)workspace, pl.splits, d->M, d->N, d->C, d->ldc, d->bias,
+                         (const float*)slabs, pl.splits, d->M, d->N, d->C, d->ldc, d->bias,
                          d->act, d->mask_src, d->ldm, p.mask_kind, d->colsum_out);
     rc = aa_launch_status();
   }

@@ -274,12 +274,13 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
   __syncthreads();
 
   const bool raw = p.splits > 1;
+  const bool inkernel = raw && p.counters != nullptr;
   if constexpr (BKIND == AA_KIND_D_DENSE) {
     if (do_colsum && threadIdx.x < BN) {
       const int n = n0 + threadIdx.x;
       if (n < p.N) {
         if (raw)
-          p.C[(size_t)p.splits * p.M * p.N + (size_t)blockIdx.z * p.N + n] = csum;
+          aa_slab_store(&p.C[(size_t)p.splits * p.M * p.N + (size_t)blockIdx.z * p.N + n], csum);
         else
           p.colsum_out[n] = csum;
       }
@@ -299,7 +300,7 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
           for (int e = 0; e < 16; ++e) dst[((i * TN + j) * 16 + e) * 64] = acc[i][j][e];
     }
     __syncthreads();
-    if (wk > 0) return;
+    if (wk == 0) {
 #pragma unroll
     for (int w = 1; w < WGK; ++w) {
       const float* src = red + ((w - 1) * (WGM * WGN) + wmn) * PER + lane;
@@ -310,10 +311,12 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][j][e] += src[((i * TN + j) * 16 + e) * 64];
     }
+    }
   }
 
   float* C = raw ? p.C + (size_t)blockIdx.z * (size_t)p.M * (size_t)p.N : p.C;
   const int ldc = raw ? p.N : p.ldc;
+  if (WGK == 1 || wk == 0) {
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -331,10 +334,15 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
           v = aa_act(v + bv, p.act);
           if (p.mask_kind != 0) v *= aa_actgrad(p.mask_src[(size_t)m * p.ldm + n], p.mask_kind);
         }
-        C[(size_t)m * ldc + n] = v;
+        if (inkernel)
+          aa_slab_store(&C[(size_t)m * ldc + n], v);
+        else
+          C[(size_t)m * ldc + n] = v;
       }
     }
   }
+  }
+  if (inkernel) aa_splitk_tail<BM, BN>(p, m0, n0, do_colsum);
 }
 
 template <int AK, int BKIND, int BM, int BN, int WGM, int WGN, int WGK, int NS>

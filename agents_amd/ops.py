@@ -37,7 +37,9 @@ class _Workspace:
                     "workspace would grow during graph capture; run one eager step first")
             if buf is not None:
                 self._retired.append(buf)
-            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            # zero-filled: the head of a GEMM workspace holds split-K arrival counters that the
+            # kernels expect (and leave) zeroed -- aa_gemm_desc.ws_counters_zeroed
+            buf = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
             self._buf[key] = buf
         return buf
 
@@ -98,6 +100,9 @@ def gemm_desc(**kw):
 # Test / tuning knob: True forces the register-staged GEMM main loop (aa_gemm_desc.no_dma) so the
 # two main loops can be compared on identical inputs.  The default is the LDS-DMA loop.
 FORCE_NO_DMA = False
+# Test knob: True sums split-K slabs with the separate reduce launch instead of inside the GEMM.
+SEPARATE_SPLITK_REDUCE = False
+INKERNEL_SPLITK_ALWAYS = False   # test knob: in-kernel reduction for any split count
 # a_mode values whose contractions take the LDS-DMA loop (tuning knob, env AA_DMA_MODES="3,4,5")
 import os as _os
 _DMA_MODES = _os.environ.get("AA_DMA_MODES")
@@ -108,6 +113,7 @@ def gemm(desc, device):
     lib = _lib.load()
     if FORCE_NO_DMA or (_DMA_MODES is not None and desc.a_mode not in _DMA_MODES):
         desc.no_dma = 1
+    desc.ws_counters_zeroed = 0 if SEPARATE_SPLITK_REDUCE else (2 if INKERNEL_SPLITK_ALWAYS else 1)
     need = lib.aa_gemm_f32_workspace_bytes(ctypes.byref(desc))
     if need < 0:
         raise ValueError("aa_gemm_f32: invalid descriptor (M,N,K must be positive)")
