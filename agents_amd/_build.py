@@ -24,6 +24,7 @@ SOURCES = [
     ("replay.hip", []),
     ("gemm.hip", []),
     ("nn.hip", ["-ffp-contract=off"]),
+    ("dense_small.hip", []),
     ("dqn.hip", ["-ffp-contract=off"]),
     ("optim.hip", ["-ffp-contract=off"]),
     ("rollout.hip", ["-ffp-contract=off"]),

@@ -59,6 +59,12 @@ _SIGNATURES = {
     "aa_counter_add": (c_int, [c_void_p, c_int64, c_void_p]),
     "aa_gemm_f32_workspace_bytes": (c_int64, [POINTER(GemmDesc)]),
     "aa_gemm_f32": (c_int, [POINTER(GemmDesc), c_void_p, c_int64, c_void_p]),
+    "aa_dense_small_forward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64,
+                                       c_int32, c_int32, c_void_p, c_void_p]),
+    "aa_dense_small_dx": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
+                                  c_void_p, c_void_p]),
+    "aa_dense_small_dw": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p,
+                                  c_void_p, c_void_p]),
     "aa_colsum_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "aa_colsum_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64,
                               c_void_p]),

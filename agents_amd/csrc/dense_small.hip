@@ -1,0 +1,206 @@
+// Dense layers with a handful of output units (the Q-value / value heads: keras Dense(num_actions),
+// tf_agents/networks/q_network.py:139-150, value_network.py) -- forward, input gradient and weight
+// gradient as three small latency-tuned kernels instead of MFMA GEMM launches that would fill
+// 6 of 32 tile columns and need a split-K pass:   y[M,N] = act(x[M,K] W[K,N] + b),  N <= 16.
+//   forward : one wave per row; lanes stride K with 16-byte loads; W (K*N*4 bytes <= 32 KiB for
+//             the heads) is read through the scalar/vector caches; 64-lane shuffle reduction.
+//   dX      : dx[m,k] = (sum_n dz[m,n] W[k,n]) * act'(mask[m,k])   -- N MACs per element.
+//   dW,db   : dW[k,n] = sum_m x[m,k] dz[m,n]; 64 consecutive k per workgroup, the M rows split
+//             over the 4 waves and combined in LDS in wave order (deterministic).
+// Summation order differs from the MFMA GEMM's (fp32 rounding noise, covered by the 1e-5 relative
+// loss tolerance); every kernel is deterministic run to run.
+#include "common.h"
+#include "agents_amd.h"
+
+#define AA_SMALLN_MAX 16
+
+__device__ static inline float aa_sm_act(float v, int act) {
+  if (act == AA_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == AA_ACT_TANH) return tanhf(v);
+  return v;
+}
+__device__ static inline float aa_sm_actgrad(float y, int kind) {
+  if (kind == AA_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (kind == AA_ACT_TANH) return 1.f - y * y;
+  return 1.f;
+}
+
+template <int N>
+__global__ void __launch_bounds__(256)
+aa_dense_small_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                          const float* __restrict__ bias, int act, int64_t M, int K,
+                          float* __restrict__ y) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t m = (int64_t)blockIdx.x * 4 + wid;
+  if (m >= M) return;
+  const float* xr = x + m * ldx;
+  float acc[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) acc[n] = 0.f;
+  const bool vec = ((K & 3) == 0) && ((ldx & 3) == 0) && ((((uintptr_t)x) & 15) == 0);
+  if (vec) {
+    for (int k = 4 * lane; k < K; k += 256) {
+      const float4 xv = *reinterpret_cast<const float4*>(xr + k);
+      const float* wk = w + (size_t)k * N;
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        acc[n] = fmaf(xv.x, wk[n], acc[n]);
+        acc[n] = fmaf(xv.y, wk[N + n], acc[n]);
+        acc[n] = fmaf(xv.z, wk[2 * N + n], acc[n]);
+        acc[n] = fmaf(xv.w, wk[3 * N + n], acc[n]);
+      }
+    }
+  } else {
+    for (int k = lane; k < K; k += 64) {
+      const float xv = xr[k];
+      const float* wk = w + (size_t)k * N;
+#pragma unroll
+      for (int n = 0; n < N; ++n) acc[n] = fmaf(xv, wk[n], acc[n]);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    float v = acc[n];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    acc[n] = v;
+  }
+  if (lane < N) {
+    float v = 0.f;
+#pragma unroll
+    for (int n = 0; n < N; ++n) v = (lane == n) ? acc[n] : v;
+    if (bias != nullptr) v += bias[lane];
+    y[m * N + lane] = aa_sm_act(v, act);
+  }
+}
+
+template <int N>
+__global__ void __launch_bounds__(256)
+aa_dense_small_dx_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                         const float* __restrict__ mask_src, int mask_kind, int64_t M, int K,
+                         float* __restrict__ dx) {
+  // one row per workgroup-row: blockIdx.y = row block of 4, threads sweep k
+  const int64_t total = M * (int64_t)K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / K;
+    const int k = (int)(i - m * K);
+    const float* dzr = dz + m * N;
+    const float* wk = w + (size_t)k * N;
+    float v = 0.f;
+#pragma unroll
+    for (int n = 0; n < N; ++n) v = fmaf(dzr[n], wk[n], v);
+    if (mask_kind != 0) v *= aa_sm_actgrad(mask_src[i], mask_kind);
+    dx[i] = v;
+  }
+}
+
+template <int N>
+__global__ void __launch_bounds__(256)
+aa_dense_small_dw_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dz,
+                         int64_t M, int K, float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float red[3][64][N];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  float acc[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) acc[n] = 0.f;
+  // wave `wid` owns rows [m_lo, m_hi): a fixed quarter of M
+  const int64_t per = (M + 3) / 4;
+  const int64_t m_lo = wid * per, m_hi = (m_lo + per < M) ? m_lo + per : M;
+  if (k < K) {
+    for (int64_t m = m_lo; m < m_hi; ++m) {
+      const float xv = x[m * ldx + k];
+      const float* dzr = dz + m * N;   // wave-uniform address: scalar loads
+#pragma unroll
+      for (int n = 0; n < N; ++n) acc[n] = fmaf(xv, dzr[n], acc[n]);
+    }
+  }
+  if (wid > 0) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) red[wid - 1][lane][n] = acc[n];
+  }
+  __syncthreads();
+  if (wid == 0 && k < K) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int n = 0; n < N; ++n) acc[n] += red[j][lane][n];
+#pragma unroll
+    for (int n = 0; n < N; ++n) dw[(size_t)k * N + n] = acc[n];
+  }
+  // bias gradient: db[n] = sum_m dz[m,n], by the last workgroup's spare wave in fixed m order
+  if (db != nullptr && blockIdx.x == gridDim.x - 1 && wid == 1) {
+    float s[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) s[n] = 0.f;
+    for (int64_t m = lane; m < M; m += 64) {
+#pragma unroll
+      for (int n = 0; n < N; ++n) s[n] += dz[m * N + n];
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      float v = s[n];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) db[n] = v;
+    }
+  }
+}
+
+template <int N>
+static int aa_small_launch(int which, const float* a, int64_t lda, const float* b, const float* c,
+                           int i0, int64_t M, int K, float* out, float* out2, hipStream_t st) {
+  if (which == 0) {
+    hipLaunchKernelGGL(aa_dense_small_fwd_kernel<N>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0,
+                       st, a, lda, b, c, i0, M, K, out);
+  } else if (which == 1) {
+    int64_t blocks = (M * K + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(aa_dense_small_dx_kernel<N>, dim3((unsigned)blocks), dim3(256), 0, st, a, b,
+                       c, i0, M, K, out);
+  } else {
+    hipLaunchKernelGGL(aa_dense_small_dw_kernel<N>, dim3((unsigned)((K + 63) / 64)), dim3(256), 0,
+                       st, a, lda, b, M, K, out, out2);
+  }
+  return aa_launch_status();
+}
+
+static int aa_small_dispatch(int N, int which, const float* a, int64_t lda, const float* b,
+                             const float* c, int i0, int64_t M, int K, float* out, float* out2,
+                             hipStream_t st) {
+  switch (N) {
+#define AA_CASE(n) \
+  case n: return aa_small_launch<n>(which, a, lda, b, c, i0, M, K, out, out2, st);
+    AA_CASE(1) AA_CASE(2) AA_CASE(3) AA_CASE(4) AA_CASE(5) AA_CASE(6) AA_CASE(7) AA_CASE(8)
+    AA_CASE(9) AA_CASE(10) AA_CASE(11) AA_CASE(12) AA_CASE(13) AA_CASE(14) AA_CASE(15) AA_CASE(16)
+#undef AA_CASE
+    default: return AA_ERR_RANGE;
+  }
+}
+
+extern "C" {
+
+int aa_dense_small_forward(const float* x, int64_t ldx, const float* w, const float* bias,
+                           int32_t act, int64_t M, int32_t K, int32_t N, float* y, void* stream) {
+  if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0 || ldx < K) return AA_ERR_INVALID;
+  if (N > AA_SMALLN_MAX) return AA_ERR_RANGE;
+  return aa_small_dispatch(N, 0, x, ldx, w, bias, act, M, K, y, nullptr, (hipStream_t)stream);
+}
+
+int aa_dense_small_dx(const float* dz, const float* w, const float* mask_src, int32_t mask_kind,
+                      int64_t M, int32_t K, int32_t N, float* dx, void* stream) {
+  if (!dz || !w || !dx || M <= 0 || K <= 0 || N <= 0) return AA_ERR_INVALID;
+  if (N > AA_SMALLN_MAX) return AA_ERR_RANGE;
+  return aa_small_dispatch(N, 1, dz, 0, w, mask_src, mask_src ? mask_kind : 0, M, K, dx, nullptr,
+                           (hipStream_t)stream);
+}
+
+int aa_dense_small_dw(const float* x, int64_t ldx, const float* dz, int64_t M, int32_t K,
+                      int32_t N, float* dw, float* db, void* stream) {
+  if (!x || !dz || !dw || M <= 0 || K <= 0 || N <= 0 || ldx < K) return AA_ERR_INVALID;
+  if (N > AA_SMALLN_MAX) return AA_ERR_RANGE;
+  return aa_small_dispatch(N, 2, x, ldx, dz, nullptr, 0, M, K, dw, db, (hipStream_t)stream);
+}
+
+}  // extern "C"

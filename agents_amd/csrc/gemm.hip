@@ -720,8 +720,9 @@ static const AaTileCfg kCfgs[] = {
     {64, 32, 2, 1, 2},    // 5
     {32, 64, 1, 2, 2},    // 6
     {32, 32, 1, 1, 4},    // 7
+    {256, 32, 4, 1, 1},   // 8  (LDS-DMA loop only: whole-M tile of the conv1 weight gradient)
 };
-#define AA_NCFG 7
+#define AA_NCFG 8
 
 struct AaGemmPlan {
   int cfg;
@@ -729,6 +730,16 @@ struct AaGemmPlan {
   int splits, k_per_split;
   size_t ws_bytes;
 };
+
+// Operands regular enough for the LDS-DMA main loop (16-byte granules everywhere).
+static bool aa_desc_dma_ok(const aa_gemm_desc* d) {
+  const bool patch = d->a_mode >= AA_A_PATCH;
+  const int a_contig = d->a_mode == AA_A_ROW ? d->K : d->M;
+  const int b_contig = d->b_mode == AA_B_ROW ? d->N : d->K;
+  const bool a_vec = !patch && d->lda % 4 == 0 && a_contig % 4 == 0 && (((uintptr_t)d->A & 15) == 0);
+  const bool b_vec = d->ldb % 4 == 0 && b_contig % 4 == 0 && (((uintptr_t)d->B & 15) == 0);
+  return b_vec && (a_vec || patch) && !d->no_dma && d->K > 128;
+}
 
 static int aa_gemm_plan(const aa_gemm_desc* d, AaGemmPlan* pl) {
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return AA_ERR_INVALID;
@@ -746,9 +757,17 @@ static int aa_gemm_plan(const aa_gemm_desc* d, AaGemmPlan* pl) {
   static const int thin_c[] = {1, 4, 6};   // 128x32, 64x32, 32x32
   const int* cand = narrow ? thin_c : wide_c;
   int cfg;
+  // Weight gradient of a conv with few filters (conv1: M = 256 patch elements, N = 32, K = 102,400
+  // pixels): with 32x32 tiles the dZ operand is re-read once per M-tile (PMC: 123 MB fetched
+  // against 20 MB algorithmic), so one workgroup takes ALL of M and the pixels are split instead.
+  const bool tall_reduce = d->a_mode == AA_A_PATCH_T_U8 &&   // (fp32 images: 72 KB of LDS ring)
+                           N <= 32 && M > 128 && M <= 256 && K >= 64 * M && aa_desc_dma_ok(d);
   if (d->force_cfg > 0) {
     cfg = d->force_cfg - 1;
     if (cfg >= AA_NCFG) return AA_ERR_INVALID;
+    if (cfg == 7 && (!aa_desc_dma_ok(d) || d->a_mode != AA_A_PATCH_T_U8)) return AA_ERR_INVALID;
+  } else if (tall_reduce) {
+    cfg = 7;
   } else {
     cfg = cand[2];
     for (int i = 0; i < 3; ++i) {
@@ -763,6 +782,11 @@ static int aa_gemm_plan(const aa_gemm_desc* d, AaGemmPlan* pl) {
   int splits = 1;
   if (d->force_splits > 0) {
     splits = d->force_splits;
+  } else if (cfg == 7) {
+    splits = (int)(256 / tiles);   // one workgroup per CU, >= 12 K-steps each at conv1's size
+    const int max_by_k = (int)(K / (8 * AA_BK));
+    if (splits > max_by_k) splits = max_by_k;
+    if (splits < 1) splits = 1;
   } else if (tiles < 256) {
     splits = (int)((512 + tiles - 1) / tiles);
     const int max_by_k = (int)(K / (4 * AA_BK));  // at least four K-steps per split
@@ -810,6 +834,9 @@ static void aa_gemm_launch_one(const GemmP& p, const AaGemmPlan& pl, hipStream_t
     aa_gemm_dma_launch<AK, BKIND, BM, BN, WGM, WGN, WGK, NS>(p, pl.splits, st);
     return;
   }
+  if constexpr (BM > 128) {
+    return;  // 256-row tiles exist for the LDS-DMA loop only (the plan never picks them otherwise)
+  } else {
   // dense operands that are ragged / unaligned use 4-byte loads (conv patches are always vectors)
   if (!(p.b_vec && (p.a_vec || !dense))) {
     aa_gemm_launch_pd<AM, BMODE, BM, BN, WGM, WGN, WGK, 2, 0>(p, pl, st);
@@ -817,6 +844,7 @@ static void aa_gemm_launch_one(const GemmP& p, const AaGemmPlan& pl, hipStream_t
   }
   // two K-tiles of loads in flight measured best on MI355X (1: 3-8 % slower, 3: VGPR-bound)
   aa_gemm_launch_pd<AM, BMODE, BM, BN, WGM, WGN, WGK, 2, 1>(p, pl, st);
+  }
 }
 
 template <int AM, int BMODE>
@@ -828,6 +856,10 @@ static int aa_gemm_launch_cfg(const GemmP& p, const AaGemmPlan& pl, hipStream_t 
     case 3: aa_gemm_launch_one<AM, BMODE, 128, 128, 2, 2, 1>(p, pl, st); break;
     case 4: aa_gemm_launch_one<AM, BMODE, 64, 32, 2, 1, 2>(p, pl, st); break;
     case 5: aa_gemm_launch_one<AM, BMODE, 32, 64, 1, 2, 2>(p, pl, st); break;
+    case 7:
+      if (!p.use_dma) return AA_ERR_INVALID;
+      aa_gemm_launch_one<AM, BMODE, 256, 32, 4, 1, 1>(p, pl, st);
+      break;
     default: aa_gemm_launch_one<AM, BMODE, 32, 32, 1, 1, 4>(p, pl, st); break;
   }
   return aa_launch_status();
@@ -938,7 +970,7 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
   }
   // LDS-DMA main loop for 16-byte-regular operands; contractions with only a few K-steps are
   // epilogue-bound and run better on the register-staged loop (smaller LDS, more groups per CU)
-  p.use_dma = (p.b_vec && (p.a_vec || patch) && !d->no_dma && d->K > 128) ? 1 : 0;
+  p.use_dma = aa_desc_dma_ok(d) ? 1 : 0;
   p.k_per_split = pl.k_per_split;
   p.splits = pl.splits;
   p.bias = d->bias;

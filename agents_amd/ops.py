@@ -100,9 +100,15 @@ def gemm_desc(**kw):
 # Test / tuning knob: True forces the register-staged GEMM main loop (aa_gemm_desc.no_dma) so the
 # two main loops can be compared on identical inputs.  The default is the LDS-DMA loop.
 FORCE_NO_DMA = False
-# Test knob: True sums split-K slabs with the separate reduce launch instead of inside the GEMM.
+# Dense layers with at most SMALL_N output units (Q / value heads) take the dedicated small-N
+# kernels (csrc/dense_small.hip) instead of an MFMA GEMM launch; USE_SMALL_N = False is a test knob.
+SMALL_N = 16
+USE_SMALL_N = True
+# Split-K slabs are summed by a separate reduce launch.  INKERNEL_SPLITK_ALWAYS switches to the
+# in-kernel reduction by each tile's last-arriving workgroup (bit-identical, one launch fewer, but
+# measured slower on MI355X at every split count of the DQN step: 472 -> 519 us per train step).
 SEPARATE_SPLITK_REDUCE = False
-INKERNEL_SPLITK_ALWAYS = False   # test knob: in-kernel reduction for any split count
+INKERNEL_SPLITK_ALWAYS = False
 # a_mode values whose contractions take the LDS-DMA loop (tuning knob, env AA_DMA_MODES="3,4,5")
 import os as _os
 _DMA_MODES = _os.environ.get("AA_DMA_MODES")
@@ -113,7 +119,7 @@ def gemm(desc, device):
     lib = _lib.load()
     if FORCE_NO_DMA or (_DMA_MODES is not None and desc.a_mode not in _DMA_MODES):
         desc.no_dma = 1
-    desc.ws_counters_zeroed = 0 if SEPARATE_SPLITK_REDUCE else (2 if INKERNEL_SPLITK_ALWAYS else 1)
+    desc.ws_counters_zeroed = 2 if (INKERNEL_SPLITK_ALWAYS and not SEPARATE_SPLITK_REDUCE) else 0
     need = lib.aa_gemm_f32_workspace_bytes(ctypes.byref(desc))
     if need < 0:
         raise ValueError("aa_gemm_f32: invalid descriptor (M,N,K must be positive)")
@@ -132,6 +138,10 @@ def dense_forward(x, w, bias, act, out, a_div=None, force_cfg=0, force_splits=0)
     if K != K2 or tuple(out.shape) != (M, N):
         raise ValueError(f"dense_forward shape mismatch x{tuple(x.shape)} w{tuple(w.shape)} "
                          f"out{tuple(out.shape)}")
+    if N <= SMALL_N and not force_cfg and not force_splits and USE_SMALL_N:
+        check(_lib.load().aa_dense_small_forward(ptr(x), lda, ptr(w), ptr(bias), ACT[act], M, K, N,
+                                                 ptr(out), stream_ptr()), "aa_dense_small_forward")
+        return out
     d = gemm_desc(A=ptr(x), B=ptr(w), C=ptr(out), M=M, N=N, K=K, lda=lda, ldb=N, ldc=N,
                   a_mode=AA_A_ROW, b_mode=AA_B_ROW, bias=ptr(bias), act=ACT[act],
                   force_cfg=force_cfg, force_splits=force_splits)
@@ -147,6 +157,12 @@ def dense_dx(dz, w, out, mask_src=None, mask_act=None, force_cfg=0, force_splits
     K, N2 = w.shape
     if N != N2 or tuple(out.shape) != (M, K):
         raise ValueError("dense_dx shape mismatch")
+    if N <= SMALL_N and not force_cfg and not force_splits and USE_SMALL_N and \
+            (mask_src is None or mask_src.is_contiguous()):
+        check(_lib.load().aa_dense_small_dx(ptr(dz), ptr(w), ptr(mask_src),
+                                            ACT[mask_act] if mask_src is not None else 0, M, K, N,
+                                            ptr(out), stream_ptr()), "aa_dense_small_dx")
+        return out
     d = gemm_desc(A=ptr(dz), B=ptr(w), C=ptr(out), M=M, N=K, K=N, lda=N, ldb=N, ldc=K,
                   a_mode=AA_A_ROW, b_mode=AA_B_COL, mask_src=ptr(mask_src), ldm=K,
                   mask_kind=ACT[mask_act] if mask_src is not None else 0,
@@ -163,6 +179,11 @@ def dense_dw(x, dz, out, force_cfg=0, force_splits=0, bias_grad=None):
     M2, N = dz.shape
     if M != M2 or tuple(out.shape) != (K, N):
         raise ValueError("dense_dw shape mismatch")
+    if N <= SMALL_N and not force_cfg and not force_splits and USE_SMALL_N:
+        check(_lib.load().aa_dense_small_dw(ptr(x), lda, ptr(dz), M, K, N, ptr(out),
+                                            _bias_grad_ptr(bias_grad, N), stream_ptr()),
+              "aa_dense_small_dw")
+        return out
     d = gemm_desc(A=ptr(x), B=ptr(dz), C=ptr(out), M=K, N=N, K=M, lda=lda, ldb=N, ldc=N,
                   a_mode=AA_A_COL, b_mode=AA_B_ROW, force_cfg=force_cfg,
                   force_splits=force_splits, colsum_out=_bias_grad_ptr(bias_grad, N))

@@ -107,8 +107,10 @@ def build_workload(dev, rank, world, B_env, max_length, S, seed):
 
 
 def kernel_breakdown(w, S, reps=20):
-    """Times the major ops of one train step individually with HIP events on the stream the
-    kernels run on (torch's current stream).  Returns [(name, ms, flops, bytes)]."""
+    """Times the kernels of one iteration individually: each op is captured `reps` times into a
+    HIP graph on torch's current stream and the replay is bracketed by HIP events on that stream,
+    so the figure is GPU time per launch (no Python launch overhead in it).
+    Returns [(name, ms per launch, launches per iteration, flops per launch, bytes per launch)]."""
     from agents_amd import ops
     net = w["net"]
     agent = w["agent"]
@@ -121,16 +123,17 @@ def kernel_breakdown(w, S, reps=20):
     m = fwd_macs_per_sample()
     obs_t = exp.observation[:, 0]
 
-    def ev():
-        return torch.cuda.Event(enable_timing=True)
+    from agents_amd.utils import graph
 
     def timeit(fn):
         fn()
+        c = graph._Captured()      # host mirrors (replay last_id, call counters) follow replays
+        c.capture(lambda: [fn() for _ in range(reps)] and None)
+        c.replay()
         torch.cuda.synchronize()
-        a, b = ev(), ev()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        for _ in range(reps):
-            fn()
+        c.replay()
         b.record()
         torch.cuda.synchronize()
         return a.elapsed_time(b) / reps
@@ -141,41 +144,50 @@ def kernel_breakdown(w, S, reps=20):
     dz1 = torch.randn(S * 400, 32, device=obs_t.device)
     out = []
     f = lambda macs: 2.0 * macs * S
-    out.append(("replay.sample+gather(512 rows)", timeit(lambda: rb.get_next(S, 2)), 0.0,
-                2.0 * S * 2 * ROW_BYTES))
+    # replay: rows of 28,248 B; sample = read + write of 512 rows (+ids), add = 256 rows
+    items = w["env"].current_time_step()
+    from agents_amd.trajectories import trajectory
+    from agents_amd.trajectories import policy_step
+    act = torch.zeros((S,), dtype=torch.int64, device=obs_t.device)
+    traj = trajectory.from_transition(items, policy_step.PolicyStep(act, (), ()), items)
+    out.append(("replay.get_next(sample+gather 512 rows)", timeit(lambda: rb.get_next(S, 2)), 1,
+                0.0, 512 * (2.0 * ROW_BYTES + 24)))
+    out.append(("replay.add_batch(scatter 256 rows)", timeit(lambda: rb.add_batch(traj)), 1, 0.0,
+                256 * (2.0 * ROW_BYTES + 8)))
     out.append(("conv1.fwd(u8)", timeit(lambda: ops.conv_forward(
-        obs_t, kv[0], bv[0], 4, "relu", slot.ys[0], a_div=255.0)), f(m[0]), 0))
+        obs_t, kv[0], bv[0], 4, "relu", slot.ys[0], a_div=255.0)), 3, f(m[0]), 0))
     out.append(("conv2.fwd", timeit(lambda: ops.conv_forward(
-        slot.ys[0], kv[1], bv[1], 2, "relu", slot.ys[1])), f(m[1]), 0))
+        slot.ys[0], kv[1], bv[1], 2, "relu", slot.ys[1])), 3, f(m[1]), 0))
     out.append(("conv3.fwd", timeit(lambda: ops.conv_forward(
-        slot.ys[1], kv[2], bv[2], 1, "relu", slot.ys[2])), f(m[2]), 0))
+        slot.ys[1], kv[2], bv[2], 1, "relu", slot.ys[2])), 3, f(m[2]), 0))
     x3 = slot.ys[2].view(S, -1)
     out.append(("fc1.fwd", timeit(lambda: ops.dense_forward(
-        x3, kv[3], bv[3], "relu", slot.ys[3])), f(m[3]), 0))
+        x3, kv[3], bv[3], "relu", slot.ys[3])), 3, f(m[3]), 0))
     out.append(("fc2.fwd", timeit(lambda: ops.dense_forward(
-        slot.ys[3], kv[4], bv[4], None, slot.ys[4])), f(m[4]), 0))
-    out.append(("fc1.dW", timeit(lambda: ops.dense_dw(x3, dz4, gk[3])), f(m[3]), 0))
+        slot.ys[3], kv[4], bv[4], None, slot.ys[4])), 3, f(m[4]), 0))
+    out.append(("fc1.dW(+bias grad)", timeit(lambda: ops.dense_dw(
+        x3, dz4, gk[3], bias_grad=gb[3])), 1, f(m[3]), 0))
     out.append(("fc1.dX", timeit(lambda: ops.dense_dx(
-        dz4, kv[3], slot.dxs[3].view(S, -1), mask_src=x3, mask_act="relu")), f(m[3]), 0))
-    out.append(("conv3.dW", timeit(lambda: ops.conv_dw(
-        slot.ys[1], dz3, tuple(kv[2].shape), 1, gk[2])), f(m[2]), 0))
+        dz4, kv[3], slot.dxs[3].view(S, -1), mask_src=x3, mask_act="relu")), 1, f(m[3]), 0))
+    out.append(("conv3.dW(+bias grad)", timeit(lambda: ops.conv_dw(
+        slot.ys[1], dz3, tuple(kv[2].shape), 1, gk[2], bias_grad=gb[2])), 1, f(m[2]), 0))
     out.append(("conv3.dX(gemm+col2im)", timeit(lambda: ops.conv_dx(
         dz3, kv[2], tuple(slot.ys[1].shape), 1, slot.dcol, slot.dxs[2], mask_src=slot.ys[1],
-        mask_act="relu")), f(m[2]), 0))
-    out.append(("conv2.dW", timeit(lambda: ops.conv_dw(
-        slot.ys[0], dz2, tuple(kv[1].shape), 2, gk[1])), f(m[1]), 0))
+        mask_act="relu")), 1, f(m[2]), 0))
+    out.append(("conv2.dW(+bias grad)", timeit(lambda: ops.conv_dw(
+        slot.ys[0], dz2, tuple(kv[1].shape), 2, gk[1], bias_grad=gb[1])), 1, f(m[1]), 0))
     out.append(("conv2.dX(gemm+col2im)", timeit(lambda: ops.conv_dx(
         dz2, kv[1], tuple(slot.ys[0].shape), 2, slot.dcol, slot.dxs[1], mask_src=slot.ys[0],
-        mask_act="relu")), f(m[1]), 0))
-    out.append(("conv1.dW(u8)", timeit(lambda: ops.conv_dw(
-        obs_t, dz1, tuple(kv[0].shape), 4, gk[0], a_div=255.0)), f(m[0]), 0))
-    out.append(("bias grads (5 colsums)", timeit(lambda: [
-        ops.colsum(dz1, gb[0]), ops.colsum(dz2, gb[1]), ops.colsum(dz3, gb[2]),
-        ops.colsum(dz4, gb[3])]), 0.0, 4.0 * (dz1.numel() + dz2.numel() + dz3.numel())))
+        mask_act="relu")), 1, f(m[1]), 0))
+    out.append(("conv1.dW(u8,+bias grad)", timeit(lambda: ops.conv_dw(
+        obs_t, dz1, tuple(kv[0].shape), 4, gk[0], a_div=255.0, bias_grad=gb[0])), 1, f(m[0]), 0))
     n_par = net.flat_params.numel()
     opt = agent._optimizer
-    out.append(("rmsprop(centered,mom)", timeit(lambda: opt.apply_flat(
-        net.flat_params.clone(), net.flat_grads)), 0.0, 36.0 * n_par))
+    scratch = net.flat_params.clone()
+    iters = opt.iterations
+    out.append(("rmsprop(centered,mom)", timeit(lambda: opt.apply_flat(scratch, net.flat_grads)),
+                1, 0.0, 36.0 * n_par))
+    opt.iterations = iters
     return out
 
 
@@ -234,7 +246,7 @@ def main():
                     help="replay frames per env (3906 x 256 envs = the 1M-row config)")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--envs", type=int, default=256)
-    ap.add_argument("--cpu-steps", type=int, default=40)
+    ap.add_argument("--cpu-steps", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--prefill", type=int, default=-1, help="frames per env to prefill (-1 = all)")
@@ -327,29 +339,39 @@ def main():
         out["step_mfma_frac"] = flops_step / (dt / args.steps) / 1e12 / MFMA_F32_PEAK_TFLOPS
         if not args.no_breakdown:
             bd = kernel_breakdown(w, S)
-            tot = sum(ms for _, ms, _, _ in bd)
-            log("[bench] per-op breakdown of one train step (HIP events, eager launches):")
-            for name, ms, fl, by in bd:
+            tot = sum(ms * n for _, ms, n, _, _ in bd)
+            log("[bench] per-launch GPU time of the iteration's kernels (HIP events around a "
+                "graph of 20 launches) x launches per iteration:")
+            for name, ms, n, fl, by in bd:
                 extra = f"{fl / ms / 1e9:8.1f} TFLOP/s" if fl else f"{by / ms / 1e6:8.1f} GB/s"
-                log(f"    {name:34s} {ms * 1e3:9.1f} us  {extra}  ({100 * ms / tot:4.1f}%)")
-            name, ms, fl, by = max(bd, key=lambda r: r[1])
-            if fl:
-                ach = fl / ms / 1e9
-                out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": ach,
-                                   "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                                   "avg_launch_ms": ms}
-            else:
+                log(f"    {name:40s} {ms * 1e3:8.1f} us x{n}  {extra}  "
+                    f"({100 * ms * n / tot:4.1f}%)")
+            traffic = {}
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 --pmc passes
+                with open(tpath) as fh:
+                    traffic = json.load(fh).get("bytes_per_launch", {})
+
+            def roof(row):
+                name, ms, n, fl, by = row
+                if fl:
+                    ach = fl / ms / 1e9
+                    return {"kernel": name, "bound": "mfma", "achieved": ach,
+                            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": traffic.get(name),
+                            "algorithmic_flop_per_launch": fl, "avg_launch_ms": ms,
+                            "launches_per_step": n}
                 ach = by / ms / 1e6
-                out["roofline"] = {"kernel": name, "bound": "hbm", "achieved": ach,
-                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                                   "avg_launch_ms": ms}
-            g = next(r for r in bd if r[0].startswith("replay.sample"))
-            out["roofline_replay_gather"] = {"bound": "hbm", "achieved": g[3] / g[1] / 1e6,
-                                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": g[3] / g[1] / 1e6 / HBM_PEAK_GBS,
-                                             "avg_launch_ms": g[1]}
+                return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(name),
+                        "algorithmic_bytes_per_launch": by, "avg_launch_ms": ms,
+                        "launches_per_step": n}
+
+            # dominant kernel = largest share of the iteration's GPU time (duration x launches)
+            out["roofline"] = roof(max(bd, key=lambda r: r[1] * r[2]))
+            out["roofline_replay_gather"] = roof(bd[0])
+            out["roofline_replay_add"] = roof(bd[1])
+            out["kernel_time_sum_ms"] = tot
         if not args.no_cpu_baseline and world == 1:
             # torch-CPU convolutions at batch 256 stop scaling (and collapse when every hardware
             # thread of a 256-core host is used): probe a few thread counts, keep the fastest

@@ -105,7 +105,8 @@ typedef struct aa_gemm_desc {
   const float* mask_src;  /* nullable: forward OUTPUT of the layer whose activation is undone */
   int32_t ldm;
   int32_t mask_kind;
-  int32_t force_cfg;      /* 0 = auto; 1..7 = 128x64, 128x32, 64x64, 128x128, 64x32, 32x64, 32x32 */
+  int32_t force_cfg;      /* 0 = auto; 1..8 = 128x64, 128x32, 64x64, 128x128, 64x32, 32x64, 32x32,
+                           * 256x32 (LDS-DMA operands only) */
   int32_t force_splits;   /* 0 = auto split-K */
   /* nullable, AA_B_ROW only: colsum_out[n] = sum_k B(k,n).  With B = dZ this is the bias
    * gradient (tf.GradientTape of keras BiasAdd), produced by the weight-gradient GEMM that
@@ -126,6 +127,17 @@ typedef struct aa_gemm_desc {
 
 int64_t aa_gemm_f32_workspace_bytes(const aa_gemm_desc* d);
 int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Dense layers with N <= 16 output units (Q-value / value heads: keras Dense(num_actions),
+ * networks/q_network.py:139-150): y = act(x W + b), dx = (dz W^T) * act'(mask_src),
+ * dW = x^T dz with db = column sums of dz (nullable).  W is [K,N] row-major; x rows have pitch ldx.
+ * Latency-tuned kernels used instead of aa_gemm_f32 for these shapes; deterministic. */
+int aa_dense_small_forward(const float* x, int64_t ldx, const float* w, const float* bias,
+                           int32_t act, int64_t M, int32_t K, int32_t N, float* y, void* stream);
+int aa_dense_small_dx(const float* dz, const float* w, const float* mask_src /* [M,K] nullable */,
+                      int32_t mask_kind, int64_t M, int32_t K, int32_t N, float* dx, void* stream);
+int aa_dense_small_dw(const float* x, int64_t ldx, const float* dz, int64_t M, int32_t K,
+                      int32_t N, float* dw, float* db /* nullable */, void* stream);
 
 /* out[n] = sum_m x[m*ld + n]  (bias gradients).  workspace >= aa_colsum_workspace_bytes. */
 int64_t aa_colsum_workspace_bytes(int64_t M, int64_t N);

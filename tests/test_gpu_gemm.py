@@ -378,3 +378,57 @@ def test_splitk_inkernel_reduce_dw_bias_grad(dev, separate_reduce, cfg):
     assert torch.equal(a, bsep)
     close(a[:K * N].view(K, N), x.double().cpu().T @ dz.double().cpu())
     close(a[K * N:], dz.double().cpu().sum(0))
+
+
+# ---- small-N dense kernels (Q / value heads) vs the MFMA GEMM path and the fp64 reference -------
+@pytest.mark.parametrize("M,N,K", [(256, 6, 512), (1, 2, 100), (37, 16, 53), (300, 1, 64),
+                                   (2048, 6, 64), (5, 7, 3), (256, 4, 3136)])
+@pytest.mark.parametrize("act", [None, "tanh"])
+def test_dense_small_n(dev, M, N, K, act):
+    rng = np.random.default_rng(M + 31 * N + K)
+    x, w, b = rnd(rng, M, K), rnd(rng, K, N) * 0.1, rnd(rng, N)
+    dz, h = rnd(rng, M, N), torch.relu(rnd(rng, M, K))
+    assert ops.USE_SMALL_N and N <= ops.SMALL_N
+    out = torch.full((M, N), float("nan"), device=dev)
+    ops.dense_forward(x.to(dev), w.to(dev), b.to(dev), act, out)
+    close(out, act_ref(x.double() @ w.double() + b.double(), act))
+    dx = torch.full((M, K), float("nan"), device=dev)
+    ops.dense_dx(dz.to(dev), w.to(dev), dx, mask_src=h.to(dev), mask_act="relu")
+    close(dx, (dz.double() @ w.double().T) * (h > 0).double())
+    dw = torch.full((K, N), float("nan"), device=dev)
+    db = torch.full((N,), float("nan"), device=dev)
+    ops.dense_dw(x.to(dev), dz.to(dev), dw, bias_grad=db)
+    close(dw, x.double().T @ dz.double())
+    close(db, dz.double().sum(0), tol=5e-6)
+    # and against the GEMM path (same math, different summation order)
+    ops.USE_SMALL_N = False
+    try:
+        out2 = torch.empty(M, N, device=dev)
+        ops.dense_forward(x.to(dev), w.to(dev), b.to(dev), act, out2)
+    finally:
+        ops.USE_SMALL_N = True
+    close(out, out2.cpu(), tol=1e-5)
+
+
+def test_conv1_dw_whole_m_tile(dev):
+    """The Atari conv1 weight gradient (uint8 frames, 8x8x4 patches, 32 filters) takes the 256x32
+    tile with the pixels split over the workgroups; forced and automatic plans agree with the
+    32x32-tile plan and the fp64 reference."""
+    rng = np.random.default_rng(5)
+    B = 32
+    x = torch.from_numpy(rng.integers(0, 256, (B, 84, 84, 4), dtype=np.uint8))
+    dz = rnd(rng, B * 400, 32)
+    res = {}
+    for name, cfg, splits in [("auto", 0, 0), ("c8", 8, 7), ("c7", 7, 16)]:
+        g = torch.full((8, 8, 4, 32), float("nan"), device=dev)
+        gb = torch.full((32,), float("nan"), device=dev)
+        ops.conv_dw(x.to(dev), dz.to(dev), (8, 8, 4, 32), 4, g, a_div=255.0, force_cfg=cfg,
+                    force_splits=splits, bias_grad=gb)
+        res[name] = (g.cpu(), gb.cpu())
+    xf = x.double() / 255.0
+    wd = torch.zeros(8, 8, 4, 32, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(xf.permute(0, 3, 1, 2), wd.permute(3, 2, 0, 1), None, stride=4)
+    ref, = torch.autograd.grad(y, wd, dz.double().view(B, 20, 20, 32).permute(0, 3, 1, 2))
+    for name, (g, gb) in res.items():
+        close(g, ref)
+        close(gb, dz.double().sum(0), tol=5e-6)

@@ -42,6 +42,21 @@ def main():
         dz, gk = r(S * 400, 32), r(8, 8, 4, 32)
         fn = lambda: ops.conv_dw(obs, dz, (8, 8, 4, 32), 4, gk, a_div=255.0, force_cfg=c,
                                  force_splits=s)
+    elif args.name == "replay.gather":
+        # 512 random rows of the Atari trajectory table (28,248 B per row), 4096-row table
+        from agents_amd.replay_buffers import table
+        from agents_amd.specs import tensor_spec
+        specs = [tensor_spec.TensorSpec((), torch.int32), tensor_spec.TensorSpec((84, 84, 4), torch.uint8),
+                 tensor_spec.TensorSpec((), torch.int64), tensor_spec.TensorSpec((), torch.int32),
+                 tensor_spec.TensorSpec((), torch.float32), tensor_spec.TensorSpec((), torch.float32)]
+        tab = table.Table(specs, 65536, device=dev)
+        for v in tab.variables():
+            if v.dtype == torch.uint8:
+                v.random_(0, 256)
+        idt = torch.arange(65536, dtype=torch.int64, device=dev)
+        rows = torch.randint(0, 65536, (256, 2), generator=g).to(dev)
+        ids = torch.empty((256, 2), dtype=torch.int64, device=dev)
+        fn = lambda: tab.read(rows, idt, ids)
     else:
         raise SystemExit("unknown case")
     for _ in range(args.reps):
