@@ -40,7 +40,7 @@ class GemmDesc(Structure):
         ("bias", c_void_p), ("act", c_int32),
         ("mask_src", c_void_p), ("ldm", c_int32), ("mask_kind", c_int32),
         ("force_cfg", c_int32), ("force_splits", c_int32),
-        ("colsum_out", c_void_p), ("no_dma", c_int32), ("ws_counters_zeroed", c_int32),
+        ("colsum_out", c_void_p), ("no_dma", c_int32),
     ]
 
 

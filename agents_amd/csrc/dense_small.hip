@@ -109,9 +109,21 @@ aa_dense_small_dw_kernel(const float* __restrict__ x, int64_t ldx, const float* 
   const int64_t per = (M + 3) / 4;
   const int64_t m_lo = wid * per, m_hi = (m_lo + per < M) ? m_lo + per : M;
   if (k < K) {
-    for (int64_t m = m_lo; m < m_hi; ++m) {
+    int64_t m = m_lo;
+    for (; m + 8 <= m_hi; m += 8) {     // eight independent row loads in flight
+      float xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xv[u] = x[(m + u) * ldx + k];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* dzr = dz + (m + u) * N;   // wave-uniform address: scalar loads
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n] = fmaf(xv[u], dzr[n], acc[n]);
+      }
+    }
+    for (; m < m_hi; ++m) {
       const float xv = x[m * ldx + k];
-      const float* dzr = dz + m * N;   // wave-uniform address: scalar loads
+      const float* dzr = dz + m * N;
 #pragma unroll
       for (int n = 0; n < N; ++n) acc[n] = fmaf(xv, dzr[n], acc[n]);
     }

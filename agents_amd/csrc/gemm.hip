@@ -40,7 +40,6 @@ __device__ static inline void aa_static_for(F&& f) {
 }
 
 #define AA_GEMM_THREADS 256
-#define AA_INKERNEL_MAX_SPLITS 8
 #define AA_BK 32
 
 struct GemmP {
@@ -61,11 +60,6 @@ struct GemmP {
   float* colsum_out; // nullable: sum_k B(k,n) (bias gradient fused into the dW GEMM)
   int k_per_split;
   int splits;
-  int* counters;     // non-null: split-K slabs are reduced in this launch by each output tile's
-                     // last-arriving workgroup (arrival counters, self-resetting)
-  float* Cout;       // final output of the in-kernel reduction (p.C is the slab base then)
-  int ldc_out;
-  int red_vec;       // the in-kernel reduction may use 16-byte accesses
   const float* bias;
   int act;
   const float* mask_src;
@@ -321,73 +315,6 @@ __device__ static inline void store_D_patchT_u8(const StageU8& s, float* tile, c
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// In-kernel split-K reduction.  Every workgroup of output tile (bx, by) has written its raw
-// partial tile into slab z = blockIdx.z; the LAST one to arrive (agent-scope arrival counter,
-// release fence before the increment, acquire fence after observing the final count) sums the
-// `splits` slabs of its tile in fixed z order -- so the result does not depend on which group
-// came last -- applies the epilogue and stores C.  Replaces a separate reduce launch per
-// split-K GEMM (eight per DQN train step).  The counter is reset by the group that consumed it.
-// ------------------------------------------------------------------------------------------
-// Memory ordering without agent-scope fences (a release fence = an L2 write-back per workgroup,
-// measured 2x slower for the whole train step): slab elements are written with agent-scope
-// relaxed atomic stores (write-through to the coherence point, `sc1`), the arrival increment is
-// issued after `s_waitcnt vmcnt(0)` (every lane's stores acknowledged) + a workgroup barrier, and
-// the reducing group reads the slabs with agent-scope relaxed atomic loads (`sc1`: never served
-// from a non-coherent cache line).
-__device__ static inline void aa_slab_store(float* p, float v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ static inline float aa_slab_load(const float* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <int BM, int BN>
-__device__ static inline void aa_splitk_tail(const GemmP& p, int m0, int n0, bool colsum_tile) {
-  __shared__ int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's slab stores are acknowledged
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-    const int prev = __hip_atomic_fetch_add(&p.counters[tile], 1, __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_AGENT);
-    const int last = prev == p.splits - 1;
-    if (last) __hip_atomic_store(&p.counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = last;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  const size_t MN = (size_t)p.M * (size_t)p.N;
-  const float* slab = p.C;
-  const int rows = min(BM, p.M - m0), cols = min(BN, p.N - n0);
-  for (int i = threadIdx.x; i < rows * BN; i += AA_GEMM_THREADS) {
-    const int r = i / BN, c = i - r * BN;
-    if (c >= cols) continue;
-    const int m = m0 + r, n = n0 + c;
-    const float* src = slab + (size_t)m * p.N + n;
-    float v = 0.f;
-    int z = 0;
-    for (; z + 8 <= p.splits; z += 8) {   // eight loads in flight, summed in slab order
-      float t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = aa_slab_load(src + (size_t)(z + u) * MN);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v += t[u];
-    }
-    for (; z < p.splits; ++z) v += aa_slab_load(src + (size_t)z * MN);
-    if (p.bias != nullptr) v += p.bias[n];
-    v = aa_act(v, p.act);
-    if (p.mask_kind != 0) v *= aa_actgrad(p.mask_src[(size_t)m * p.ldm + n], p.mask_kind);
-    p.Cout[(size_t)m * p.ldc_out + n] = v;
-  }
-  if (colsum_tile && threadIdx.x < cols) {   // fused bias gradient: rows [splits][N] after the slabs
-    const float* cs = slab + (size_t)p.splits * MN + n0 + threadIdx.x;
-    float v = 0.f;
-    for (int z = 0; z < p.splits; ++z) v += aa_slab_load(cs + (size_t)z * p.N);
-    p.colsum_out[n0 + threadIdx.x] = v;
-  }
-}
-
 #include "gemm_dma.h"
 
 // ------------------------------------------------------------------------------------------
@@ -563,7 +490,6 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
   }
 
   const bool raw = p.splits > 1;
-  const bool inkernel = raw && p.counters != nullptr;
 
   // ---- fused bias gradient: reduce the per-thread column sums over the k-rows -------------
   if constexpr (BMODE == AA_B_ROW) {
@@ -579,7 +505,7 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
         const int n = n0 + threadIdx.x;
         if (n < p.N) {
           if (raw)  // per-split partial rows after the slabs: [splits][N]
-            aa_slab_store(&p.C[(size_t)p.splits * p.M * p.N + (size_t)blockIdx.z * p.N + n], s);
+            p.C[(size_t)p.splits * p.M * p.N + (size_t)blockIdx.z * p.N + n] = s;
           else
             p.colsum_out[n] = s;
         }
@@ -637,56 +563,88 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
           v = aa_act(v + bv, p.act);
           if (p.mask_kind != 0) v *= aa_actgrad(p.mask_src[(size_t)m * p.ldm + n], p.mask_kind);
         }
-        if (inkernel)
-          aa_slab_store(&C[(size_t)m * ldc + n], v);
-        else
-          C[(size_t)m * ldc + n] = v;
+        C[(size_t)m * ldc + n] = v;
       }
     }
   }
   }
-  if (inkernel) aa_splitk_tail<BM, BN>(p, m0, n0, do_colsum);
 }
 
-// out[m][n] = epilogue( sum_z slab[z][m][n] ), fixed z order => deterministic.  Four consecutive
-// n per thread (16-byte loads) when N % 4 == 0 and C / mask rows are 16-byte aligned.
+// out[m][n] = epilogue( sum_z slab[z][m][n] ), deterministic.  A workgroup owns IPB consecutive
+// float4 (or scalar) items and ZL "z-lanes": lane zl sums slabs zl, zl+ZL, zl+2ZL, ... in that
+// order, four loads in flight, and the ZL partials are then added in lane order through LDS -- a
+// fixed association for a given (splits, ZL), so the result is reproducible run to run.  With one
+// z-lane this is the plain z-order sum.  (A single thread walking 247 slabs of the conv1 weight
+// gradient serially took 60 us for 8 MB; 16 z-lanes bring it to the memory system's pace.)
 // Elements [M*N, M*N + N) of the index space are the fused bias-gradient rows that follow the
 // slabs: colsum_out[n] = sum_z slab_end[z][n].
-template <int VEC>
+template <int VEC, int ZL>
 __global__ void __launch_bounds__(256)
 aa_splitk_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N,
                         float* __restrict__ C, int ldc, const float* __restrict__ bias, int act,
                         const float* __restrict__ mask_src, int ldm, int mask_kind,
                         float* __restrict__ colsum_out) {
+  constexpr int IPB = 256 / ZL;
+  __shared__ float part[ZL][IPB][VEC];
   const size_t MN = (size_t)M * N;
   const size_t total = (MN + (colsum_out != nullptr ? (size_t)N : 0)) / VEC;
   const float* cs_rows = slab + (size_t)splits * MN;
-  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
-       q += (size_t)gridDim.x * blockDim.x) {
+  const int it = threadIdx.x % IPB, zl = threadIdx.x / IPB;
+  for (size_t q0 = (size_t)blockIdx.x * IPB; q0 < total; q0 += (size_t)gridDim.x * IPB) {
+    const size_t q = q0 + it;
+    const bool live = q < total;
     const size_t i = q * VEC;
-    if (i >= MN) {  // bias-gradient tail
-      const size_t n = i - MN;
-      float v[VEC];
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) v[e] = 0.f;
-      for (int z = 0; z < splits; ++z)
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) v[e] += cs_rows[(size_t)z * N + n + e];
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) colsum_out[n + e] = v[e];
-      continue;
-    }
+    const bool tail = live && i >= MN;   // bias-gradient element(s)
+    const float* src = tail ? cs_rows + (i - MN) : slab + i;
+    const size_t zstride = tail ? (size_t)N : MN;
     float v[VEC];
-    if constexpr (VEC == 4) {
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int z = 0; z < splits; ++z) {
-        const float4 t = *reinterpret_cast<const float4*>(slab + (size_t)z * MN + i);
-        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = 0.f;
+    if (live) {
+      int z = zl;
+      for (; z + 3 * ZL < splits; z += 4 * ZL) {
+        float t[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* ps = src + (size_t)(z + u * ZL) * zstride;
+          if constexpr (VEC == 4) {
+            const float4 f = *reinterpret_cast<const float4*>(ps);
+            t[u][0] = f.x; t[u][1] = f.y; t[u][2] = f.z; t[u][3] = f.w;
+          } else {
+            t[u][0] = ps[0];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[e] += t[u][e];
       }
-      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-    } else {
-      v[0] = 0.f;
-      for (int z = 0; z < splits; ++z) v[0] += slab[(size_t)z * MN + i];
+      for (; z < splits; z += ZL) {
+        const float* ps = src + (size_t)z * zstride;
+        if constexpr (VEC == 4) {
+          const float4 f = *reinterpret_cast<const float4*>(ps);
+          v[0] += f.x; v[1] += f.y; v[2] += f.z; v[3] += f.w;
+        } else {
+          v[0] += ps[0];
+        }
+      }
+    }
+    if constexpr (ZL > 1) {
+      __syncthreads();   // previous round's readers are done with `part`
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) part[zl][it][e] = v[e];
+      __syncthreads();
+      if (zl != 0) continue;
+#pragma unroll
+      for (int j = 1; j < ZL; ++j)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] += part[j][it][e];
+    }
+    if (!live) continue;
+    if (tail) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) colsum_out[i - MN + e] = v[e];
+      continue;
     }
     const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
 #pragma unroll
@@ -767,7 +725,7 @@ static int aa_gemm_plan(const aa_gemm_desc* d, AaGemmPlan* pl) {
     if (cfg >= AA_NCFG) return AA_ERR_INVALID;
     if (cfg == 7 && (!aa_desc_dma_ok(d) || d->a_mode != AA_A_PATCH_T_U8)) return AA_ERR_INVALID;
   } else if (tall_reduce) {
-    cfg = 7;
+    cfg = 1;   // 128x32; measured on MI355X: 41 us with 256 splits (256x32 tile: 42-52 us)
   } else {
     cfg = cand[2];
     for (int i = 0; i < 3; ++i) {
@@ -782,8 +740,8 @@ static int aa_gemm_plan(const aa_gemm_desc* d, AaGemmPlan* pl) {
   int splits = 1;
   if (d->force_splits > 0) {
     splits = d->force_splits;
-  } else if (cfg == 7) {
-    splits = (int)(256 / tiles);   // one workgroup per CU, >= 12 K-steps each at conv1's size
+  } else if (tall_reduce || cfg == 7) {
+    splits = (int)(512 / tiles);   // two workgroups per CU, >= 12 K-steps each at conv1's size
     const int max_by_k = (int)(K / (8 * AA_BK));
     if (splits > max_by_k) splits = max_by_k;
     if (splits < 1) splits = 1;
@@ -799,7 +757,7 @@ static int aa_gemm_plan(const aa_gemm_desc* d, AaGemmPlan* pl) {
   pl->splits = splits;
   pl->k_per_split = kps;
   pl->ws_bytes = splits > 1 ? (size_t)splits * (size_t)(M * N + (d->colsum_out ? N : 0)) *
-                                      sizeof(float) + AA_GEMM_COUNTER_BYTES
+                                      sizeof(float)
                             : 0;
   return AA_OK;
 }
@@ -978,26 +936,8 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
   p.mask_src = d->mask_src;
   p.ldm = d->ldm;
   p.mask_kind = d->mask_src != nullptr ? d->mask_kind : 0;
-  // workspace = [arrival counters: AA_GEMM_COUNTER_BYTES][slabs][bias-gradient partial rows]
-  float* slabs = (float*)((char*)workspace + AA_GEMM_COUNTER_BYTES);
+  float* slabs = (float*)workspace;
   p.C = pl.splits > 1 ? slabs : d->C;
-  p.counters = nullptr;
-  p.Cout = d->C;
-  p.ldc_out = d->ldc;
-  p.red_vec = (d->N % 4 == 0 && d->ldc % 4 == 0 && (((uintptr_t)d->C & 15) == 0) &&
-               (d->bias == nullptr || (((uintptr_t)d->bias & 15) == 0)) &&
-               (d->mask_src == nullptr || (d->ldm % 4 == 0 && (((uintptr_t)d->mask_src & 15) == 0))))
-                  ? 1 : 0;
-  {
-    const int64_t tiles = (int64_t)((d->M + pl.bm - 1) / pl.bm) * ((d->N + pl.bn - 1) / pl.bn);
-    // Measured on MI355X: one group summing its tile's slabs beats a second launch only for a
-    // few splits (the sum is a serial chain of coherent loads per output element); with 16-64
-    // splits the parallel reduce kernel wins (train step 472 us vs 519 us in-kernel everywhere).
-    const bool few = pl.splits <= AA_INKERNEL_MAX_SPLITS || d->ws_counters_zeroed == 2;
-    if (pl.splits > 1 && d->ws_counters_zeroed && few &&
-        tiles * (int64_t)sizeof(int) <= AA_GEMM_COUNTER_BYTES)
-      p.counters = (int*)workspace;
-  }
   hipStream_t st = (hipStream_t)stream;
 
   if (d->b_mode != AA_B_ROW && d->b_mode != AA_B_COL) return AA_ERR_INVALID;
@@ -1015,21 +955,25 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
     default: return AA_ERR_INVALID;
   }
   if (rc != AA_OK) return rc;
-  if (pl.splits > 1 && p.counters == nullptr) {
+  if (pl.splits > 1) {
     const size_t MN = (size_t)d->M * d->N;
     const bool vec = d->N % 4 == 0 && d->ldc % 4 == 0 && (((uintptr_t)d->C & 15) == 0) &&
                      (d->mask_src == nullptr || d->ldm % 4 == 0);
     const size_t work = (MN + (d->colsum_out ? d->N : 0)) / (vec ? 4 : 1);
-    int blocks = (int)((work + 255) / 256);
+    // few items and many slabs: spread the slabs of an item over 16 z-lanes of the workgroup
+    const bool deep = pl.splits >= 32 && work <= 65536;
+    const int ipb = deep ? 16 : 256;
+    int blocks = (int)((work + ipb - 1) / ipb);
     if (blocks > 2048) blocks = 2048;
-    if (vec)
-      hipLaunchKernelGGL(aa_splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st,
-                         (const float*)slabs, pl.splits, d->M, d->N, d->C, d->ldc, d->bias,
-                         d->act, d->mask_src, d->ldm, p.mask_kind, d->colsum_out);
-    else
-      hipLaunchKernelGGL(aa_splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st,
-                         (const float*)slabs, pl.splits, d->M, d->N, d->C, d->ldc, d->bias,
-                         d->act, d->mask_src, d->ldm, p.mask_kind, d->colsum_out);
+#define AA_LAUNCH_REDUCE(VEC, ZL)                                                               \
+    hipLaunchKernelGGL((aa_splitk_reduce_kernel<VEC, ZL>), dim3(blocks), dim3(256), 0, st,          \
+                       (const float*)slabs, pl.splits, d->M, d->N, d->C, d->ldc, d->bias, d->act,  \
+                       d->mask_src, d->ldm, p.mask_kind, d->colsum_out)
+    if (vec && deep) AA_LAUNCH_REDUCE(4, 16);
+    else if (vec) AA_LAUNCH_REDUCE(4, 1);
+    else if (deep) AA_LAUNCH_REDUCE(1, 16);
+    else AA_LAUNCH_REDUCE(1, 1);
+#undef AA_LAUNCH_REDUCE
     rc = aa_launch_status();
   }
   return rc;

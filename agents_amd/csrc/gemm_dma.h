@@ -274,13 +274,12 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
   __syncthreads();
 
   const bool raw = p.splits > 1;
-  const bool inkernel = raw && p.counters != nullptr;
   if constexpr (BKIND == AA_KIND_D_DENSE) {
     if (do_colsum && threadIdx.x < BN) {
       const int n = n0 + threadIdx.x;
       if (n < p.N) {
         if (raw)
-          aa_slab_store(&p.C[(size_t)p.splits * p.M * p.N + (size_t)blockIdx.z * p.N + n], csum);
+          p.C[(size_t)p.splits * p.M * p.N + (size_t)blockIdx.z * p.N + n] = csum;
         else
           p.colsum_out[n] = csum;
       }
@@ -334,15 +333,11 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
           v = aa_act(v + bv, p.act);
           if (p.mask_kind != 0) v *= aa_actgrad(p.mask_src[(size_t)m * p.ldm + n], p.mask_kind);
         }
-        if (inkernel)
-          aa_slab_store(&C[(size_t)m * ldc + n], v);
-        else
-          C[(size_t)m * ldc + n] = v;
+        C[(size_t)m * ldc + n] = v;
       }
     }
   }
   }
-  if (inkernel) aa_splitk_tail<BM, BN>(p, m0, n0, do_colsum);
 }
 
 template <int AK, int BKIND, int BM, int BN, int WGM, int WGN, int WGK, int NS>

@@ -37,9 +37,7 @@ class _Workspace:
                     "workspace would grow during graph capture; run one eager step first")
             if buf is not None:
                 self._retired.append(buf)
-            # zero-filled: the head of a GEMM workspace holds split-K arrival counters that the
-            # kernels expect (and leave) zeroed -- aa_gemm_desc.ws_counters_zeroed
-            buf = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
             self._buf[key] = buf
         return buf
 
@@ -104,11 +102,6 @@ FORCE_NO_DMA = False
 # kernels (csrc/dense_small.hip) instead of an MFMA GEMM launch; USE_SMALL_N = False is a test knob.
 SMALL_N = 16
 USE_SMALL_N = True
-# Split-K slabs are summed by a separate reduce launch.  INKERNEL_SPLITK_ALWAYS switches to the
-# in-kernel reduction by each tile's last-arriving workgroup (bit-identical, one launch fewer, but
-# measured slower on MI355X at every split count of the DQN step: 472 -> 519 us per train step).
-SEPARATE_SPLITK_REDUCE = False
-INKERNEL_SPLITK_ALWAYS = False
 # a_mode values whose contractions take the LDS-DMA loop (tuning knob, env AA_DMA_MODES="3,4,5")
 import os as _os
 _DMA_MODES = _os.environ.get("AA_DMA_MODES")
@@ -119,7 +112,6 @@ def gemm(desc, device):
     lib = _lib.load()
     if FORCE_NO_DMA or (_DMA_MODES is not None and desc.a_mode not in _DMA_MODES):
         desc.no_dma = 1
-    desc.ws_counters_zeroed = 2 if (INKERNEL_SPLITK_ALWAYS and not SEPARATE_SPLITK_REDUCE) else 0
     need = lib.aa_gemm_f32_workspace_bytes(ctypes.byref(desc))
     if need < 0:
         raise ValueError("aa_gemm_f32: invalid descriptor (M,N,K must be positive)")

@@ -114,16 +114,7 @@ typedef struct aa_gemm_desc {
   float* colsum_out;
   int32_t no_dma;         /* 1 = force the register-staged main loop (default 0: operands that are
                            * 16-byte regular go HBM -> LDS by buffer_load ... lds DMA) */
-  int32_t ws_counters_zeroed; /* 1 = the first AA_GEMM_COUNTER_BYTES of `workspace` are zero on
-                           * entry and reserved for this library (it leaves them zero): split-K
-                           * partials are then summed inside the GEMM launch by each tile's
-                           * last-arriving workgroup, in fixed slab order (deterministic), instead
-                           * of by a second reduce launch -- used when the plan has at most 8
-                           * splits (beyond that the parallel reduce launch is faster); 2 = use
-                           * it for any split count.  0 = always the separate reduce launch. */
 } aa_gemm_desc;
-
-#define AA_GEMM_COUNTER_BYTES 16384
 
 int64_t aa_gemm_f32_workspace_bytes(const aa_gemm_desc* d);
 int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes, void* stream);

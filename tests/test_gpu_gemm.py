@@ -325,61 +325,6 @@ def test_dma_conv_forward_and_dw(dev, both_loops, cfg, tile):
         close(bg, dz.double().sum((0, 1, 2)), tol=5e-6)
 
 
-# ---- in-kernel split-K reduction (last-arriving workgroup) vs the separate reduce launch ---------
-@pytest.fixture
-def separate_reduce():
-    """Runs a callable twice: in-kernel reduction (default) and the separate reduce kernel."""
-    def run(fn):
-        ops.SEPARATE_SPLITK_REDUCE = False
-        ops.INKERNEL_SPLITK_ALWAYS = True
-        try:
-            a = fn()
-            ops.SEPARATE_SPLITK_REDUCE = True
-            b = fn()
-        finally:
-            ops.SEPARATE_SPLITK_REDUCE = False
-            ops.INKERNEL_SPLITK_ALWAYS = False
-        return a, b
-    return run
-
-
-@pytest.mark.parametrize("M,N,K,splits", [(256, 512, 3136, 0), (256, 6, 512, 4), (200, 70, 300, 3),
-                                          (37, 45, 530, 5), (300, 33, 640, 7), (64, 64, 4096, 16)])
-@pytest.mark.parametrize("act", [None, "relu"])
-def test_splitk_inkernel_reduce_is_bit_identical(dev, separate_reduce, M, N, K, splits, act):
-    rng = np.random.default_rng(M + N + K + splits)
-    x, w, b = rnd(rng, M, K).to(dev), (rnd(rng, K, N) * 0.1).to(dev), rnd(rng, N).to(dev)
-
-    def fwd():
-        out = torch.full((M, N), float("nan"), device=dev)
-        for _ in range(3):   # repeated launches: the arrival counters must come back to zero
-            ops.dense_forward(x, w, b, act, out, force_splits=splits)
-        return out.clone()
-
-    a, bsep = separate_reduce(fwd)
-    assert torch.equal(a, bsep)
-    close(a, act_ref(x.double().cpu() @ w.double().cpu() + b.double().cpu(), act))
-
-
-@pytest.mark.parametrize("cfg", ALL_CFGS)
-def test_splitk_inkernel_reduce_dw_bias_grad(dev, separate_reduce, cfg):
-    rng = np.random.default_rng(cfg)
-    M, N, K = 1000, 70, 130          # dW[K,N] = x^T dz, reduction over M rows
-    x, dz = rnd(rng, M, K).to(dev), rnd(rng, M, N).to(dev)
-
-    def dw():
-        g = torch.full((K, N), float("nan"), device=dev)
-        gb = torch.full((N,), float("nan"), device=dev)
-        for _ in range(2):
-            ops.dense_dw(x, dz, g, bias_grad=gb, force_cfg=cfg, force_splits=4)
-        return torch.cat([g.flatten(), gb])
-
-    a, bsep = separate_reduce(dw)
-    assert torch.equal(a, bsep)
-    close(a[:K * N].view(K, N), x.double().cpu().T @ dz.double().cpu())
-    close(a[K * N:], dz.double().cpu().sum(0))
-
-
 # ---- small-N dense kernels (Q / value heads) vs the MFMA GEMM path and the fp64 reference -------
 @pytest.mark.parametrize("M,N,K", [(256, 6, 512), (1, 2, 100), (37, 16, 53), (300, 1, 64),
                                    (2048, 6, 64), (5, 7, 3), (256, 4, 3136)])
