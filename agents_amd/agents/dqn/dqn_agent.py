@@ -23,7 +23,7 @@ import torch
 from agents_amd import _lib, ops
 from agents_amd.agents import tf_agent
 from agents_amd.policies import q_policy
-from agents_amd.utils import common, nest_utils
+from agents_amd.utils import common, graph, nest_utils
 
 
 class DqnLossInfo(collections.namedtuple("DqnLossInfo", ("td_loss", "td_error"))):
@@ -185,6 +185,7 @@ class DqnAgent(tf_agent.TFAgent):
             obs, mask = self._observation_and_action_constraint_splitter(obs)
         B = experience.discount.shape[0]
         dev = experience.discount.device
+        graph.join_lanes(dev)
         w = self._get_work(B, dev)
         obs_t = obs[:, 0]
         obs_next = obs[:, -1]

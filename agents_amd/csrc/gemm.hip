@@ -681,6 +681,10 @@ static const AaTileCfg kCfgs[] = {
     {256, 32, 4, 1, 1},   // 8  (LDS-DMA loop only: whole-M tile of the conv1 weight gradient)
 };
 #define AA_NCFG 8
+// Tried and dropped (tools/gemm_sweep.py on MI355X): one 32x64 / 64x32 / 64x64 tile per wave with
+// a 4-way intra-workgroup K split (two or four independent accumulator chains per wave) -- never
+// faster than the plans above on the DQN shapes.  At these sizes a launch costs ~10 us of fixed
+// time (dispatch gap, first loads, tail) and runs at a marginal ~115 TFLOP/s beyond that.
 
 struct AaGemmPlan {
   int cfg;

@@ -75,6 +75,7 @@ class RandomTFEnvironment(tf_environment.TFEnvironment):
 
     def _launch(self, cur_step_type, force_first):
         lib = _lib.load()
+        graph.join_lanes(self._device)
         out = self._next_out()
         with torch.cuda.device(self._device):
             st = _lib.stream_ptr()
@@ -89,6 +90,7 @@ class RandomTFEnvironment(tf_environment.TFEnvironment):
         return out
 
     def _current_time_step(self):
+        graph.join_lanes(self._device)
         if self._time_step is None:
             self._time_step = self._reset()
         return self._time_step
@@ -116,6 +118,8 @@ class _TimeStepRing:
         self._ptrs = [ts_.observation.data_ptr() for ts_ in slots]
 
     def slot_of(self, time_step):
+        if time_step is None:
+            return None
         try:
             return self._ptrs.index(time_step.observation.data_ptr())
         except ValueError:

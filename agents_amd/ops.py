@@ -29,7 +29,8 @@ class _Workspace:
         # registered side streams own a scratch each; every other stream (the default stream, a
         # graph-capture stream) is the "main" line of execution and shares one
         sid = torch.cuda.current_stream(device).cuda_stream
-        key = (device.type, device.index, sid if sid in _SIDE_STREAMS else 0)
+        key = (device.type, device.index,
+               _SCOPE if _SCOPE is not None else (sid if sid in _SIDE_STREAMS else 0))
         buf = self._buf.get(key)
         if buf is None or buf.numel() < nbytes:
             if torch.cuda.is_current_stream_capturing():
@@ -42,7 +43,43 @@ class _Workspace:
         return buf
 
 
+    def reserve(self, tag, device):
+        """Gives scope `tag` its own buffer, as large as the main line's current one."""
+        main = self._buf.get((device.type, device.index, 0))
+        key = (device.type, device.index, tag)
+        need = main.numel() if main is not None else 1 << 20
+        if key not in self._buf or self._buf[key].numel() < need:
+            if key in self._buf:
+                self._retired.append(self._buf[key])
+            self._buf[key] = torch.empty(need, dtype=torch.uint8, device=device)
+
+
 _SIDE_STREAMS = set()
+_SCOPE = None
+
+
+class workspace_scope:
+    """Kernels launched (or captured into a HIP graph) inside this context take their split-K /
+    column-sum scratch from a buffer private to `tag` instead of the caller stream's: a graph that
+    will replay concurrently with other GEMM work (the collect graph next to the train graphs,
+    agents_amd/utils/graph.py: Lanes) must not share slabs with it."""
+
+    def __init__(self, tag, device):
+        self._tag, self._device = tag, torch.device(device)
+
+    def __enter__(self):
+        global _SCOPE
+        self._prev = _SCOPE
+        if not torch.cuda.is_current_stream_capturing():
+            _WS.reserve(self._tag, self._device)
+            _WS2.reserve(self._tag, self._device)
+        _SCOPE = self._tag
+        return self
+
+    def __exit__(self, *exc):
+        global _SCOPE
+        _SCOPE = self._prev
+        return False
 
 
 def new_side_stream(device):

@@ -127,6 +127,7 @@ class _DiscretePolicy(tf_policy.TFPolicy):
             mask = None if mask is None else mask.unsqueeze(0)
         B = nest_utils.flatten(obs)[0].shape[0]
         dev = nest_utils.flatten(obs)[0].device
+        graph.join_lanes(dev)
         with torch.cuda.device(dev):
             q = self._q_values(obs, B, dev)
             actions = self.select(q, mask, self._get_epsilon())

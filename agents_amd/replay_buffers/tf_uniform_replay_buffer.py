@@ -116,6 +116,7 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
     def _add_batch(self, items):
         """Writes one frame per env block (:182-209)."""
         lib = _lib.load()
+        graph.join_lanes(self._device)
         flat = self._data_table.check_values(items, self._batch_size)
         p = self._data_table.pack(flat)
         with torch.cuda.device(self._device):
@@ -150,6 +151,7 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
 
     def _get_next(self, sample_batch_size=None, num_steps=None, time_stacked=True):
         """Uniformly sampled items (:211-310).  Returns (data, BufferInfo(ids, probabilities))."""
+        graph.join_lanes(self._device)
         if not graph.capturing():
             self._check_not_empty(num_steps)
         S = 1 if sample_batch_size is None else int(sample_batch_size)
@@ -239,6 +241,7 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
     def _gather_all(self):
         """All valid items, shape [batch_size, n, ...] in id order (:533-557)."""
         lib = _lib.load()
+        graph.join_lanes(self._device)
         lo, hi = _valid_range_ids(self._last_id_host, self._max_length)
         n = hi - lo
         rows = torch.empty((self._batch_size, max(n, 0)), dtype=torch.int64, device=self._device)
@@ -251,6 +254,7 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
 
     def _clear(self, clear_all_variables=False):
         """last_id = -1; tables untouched unless clear_all_variables (:559-579)."""
+        graph.join_lanes(self._device)
         self._last_id.fill_(-1)
         self._last_id_host = -1
         if clear_all_variables:
@@ -265,11 +269,13 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
         return self._last_id_host
 
     def state_dict(self):
+        graph.join_lanes(self._device)
         return {"tables": [v.clone() for v in self._data_table.variables()],
                 "ids": self._id_table.variables()[0].clone(), "last_id": self._last_id_host,
                 "sample_calls": self._sample_calls, "seed": self._seed}
 
     def load_state_dict(self, sd):
+        graph.join_lanes(self._device)
         for v, s in zip(self._data_table.variables(), sd["tables"]):
             v.copy_(s)
         self._id_table.variables()[0].copy_(sd["ids"])

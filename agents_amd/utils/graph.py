@@ -47,6 +47,92 @@ def on_replay(fn):
         _CAPTURE.hooks.append(fn)
 
 
+class Lanes:
+    """Opt-in overlap of the three graphs on separate HIP streams (`enable_overlap(device)`).
+
+    The loop `collect; sample; train` has fewer dependencies than its program order: the policy
+    forward of collect(k) and the forward/backward of train(k) both only READ theta_k, and with a
+    prefetching dataset the batch train(k) consumes was drawn iterations ago.  With overlap on,
+    the collect graph replays on stream C, the sampler on stream S and training stays on the
+    caller's stream M, ordered by events exactly along the true dependencies:
+        C waits  M's frontier (theta_k written by apply(k-1); any eager work) and the last draw
+                 (the replay tables it overwrites are not being gathered)
+        S waits  the last collect (a draw sees every add that precedes it in program order) and
+                 M's frontier (the ring slot it overwrites has been consumed)
+        M waits  the draw that produced its batch before the forward, and the last collect before
+                 the optimizer phase overwrites theta_k
+    so every kernel sees the same inputs as in the single-stream order and results are
+    bit-identical (tests/test_gpu_graphs.py).  Tensors returned by the graphed driver / dataset
+    are produced on C / S: call `join_lanes()` before touching them from other code (the
+    package's own eager entry points do)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.C = torch.cuda.Stream(device)
+        self.S = torch.cuda.Stream(device)
+        self.collect_done = None
+        self.sample_done = None
+        self.ready = {}          # first-leaf data_ptr of a sampler ring slot -> ready Event
+
+    @staticmethod
+    def _event_on(stream):
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        return ev
+
+    def main_frontier(self):
+        return self._event_on(torch.cuda.current_stream(self.device))
+
+    def join(self):
+        """The caller's stream waits for everything enqueued on the collect / sample lanes."""
+        cur = torch.cuda.current_stream(self.device)
+        if self.collect_done is not None:
+            cur.wait_event(self.collect_done)
+        if self.sample_done is not None:
+            cur.wait_event(self.sample_done)
+
+
+_LANES = {}
+
+
+def enable_overlap(device=None):
+    """Turns on stream overlap of the graphed collect / sample / train programs on `device`."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None \
+        else torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _LANES:
+        _LANES[key] = Lanes(torch.device("cuda", key[1]))
+    return _LANES[key]
+
+
+def disable_overlap(device=None):
+    join_lanes(device)
+    if device is None:
+        _LANES.clear()
+    else:
+        device = torch.device(device)
+        _LANES.pop((device.type, device.index), None)
+
+
+def lanes_for(device):
+    if not _LANES:
+        return None
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return _LANES.get((device.type, idx))
+
+
+def join_lanes(device=None):
+    """Orders the current stream after all work on the overlap lanes (no-op without overlap).
+    Eager entry points of the package call this; call it before reading, from your own code,
+    tensors that a graphed driver or dataset returned."""
+    if not _LANES or capturing():
+        return
+    for l in list(_LANES.values()) if device is None else [lanes_for(device)]:
+        if l is not None:
+            l.join()
+
+
 class _Captured:
     """A torch CUDAGraph plus the host hooks registered while it was captured."""
 
@@ -135,6 +221,8 @@ class GraphedTrain:
         e = bound.get(ptrs)
         dev = experience.discount.device
         with torch.cuda.device(dev):
+            if e is None:
+                join_lanes(dev)
             if e is None and not bound:
                 # first graph: captured on private clones; serves every caller through copies
                 e = _Entry()
@@ -156,11 +244,24 @@ class GraphedTrain:
             for dst, src in zip(nest_utils.flatten(e.static_in), nest_utils.flatten(experience)):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src, non_blocking=True)
+            lanes = lanes_for(dev)
+            if lanes is not None:
+                ev = lanes.ready.get(ptrs[0])
+                if ev is not None:       # the draw that filled this ring slot (on lane S)
+                    torch.cuda.current_stream(dev).wait_event(ev)
+                else:
+                    lanes.join()
+            for dst, src in zip(nest_utils.flatten(e.static_in), nest_utils.flatten(experience)):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src, non_blocking=True)
             if e.static_w is not None and e.static_w.data_ptr() != weights.data_ptr():
                 e.static_w.copy_(weights, non_blocking=True)
             e.g_grads.replay()
             if agent.gradient_hook is not None:
                 agent.gradient_hook(agent._q_network.flat_grads)
+            if lanes is not None and lanes.collect_done is not None:
+                # the optimizer overwrites theta_k: the collect policy's forward must be done
+                torch.cuda.current_stream(dev).wait_event(lanes.collect_done)
             e.g_apply.replay()
             agent._optimizer.iterations += 1
             agent._train_phase_host()
@@ -234,6 +335,7 @@ class GraphedSampler:
         c = self._ring[slot]
         with torch.cuda.device(rb.device):
             if c is None:
+                join_lanes(rb.device)
                 c = _Captured()
                 try:
                     c.capture(lambda: rb.get_next(self._S, self._T, time_stacked=True))
@@ -241,7 +343,17 @@ class GraphedSampler:
                     self.enabled = False
                     raise
                 self._ring[slot] = c
-            out = c.replay()
+            lanes = lanes_for(rb.device)
+            if lanes is None:
+                out = c.replay()
+            else:
+                if lanes.collect_done is not None:
+                    lanes.S.wait_event(lanes.collect_done)
+                lanes.S.wait_event(lanes.main_frontier())
+                with torch.cuda.stream(lanes.S):
+                    out = c.replay()
+                    lanes.sample_done = Lanes._event_on(lanes.S)
+                lanes.ready[nest_utils.flatten(out[0])[0].data_ptr()] = lanes.sample_done
         self.replays += 1
         return out
 
@@ -346,7 +458,7 @@ class GraphedDriverRun:
                 if it >= n_min and self._wait_total() >= target:
                     break
                 slot = ring.slot_of(time_step)
-                if slot is None or slot != ring.slot_of(env.current_time_step()):
+                if slot is None or slot != ring.slot_of(env._time_step):
                     # a TimeStep that is not the environment's current ring buffer (first calls,
                     # or a caller-made one): one eager run brings the loop into the ring
                     if it > 0:
@@ -356,15 +468,29 @@ class GraphedDriverRun:
                                            else maximum_iterations - it)
                 c = self._graphs.get(slot)
                 if c is None:
+                    join_lanes(st.device)
                     c = _Captured()
                     ts_in = time_step
+                    from agents_amd import ops
                     try:
-                        c.capture(lambda: self._body(ts_in, policy_state))
+                        # private GEMM scratch: this graph may replay next to the train graphs
+                        with ops.workspace_scope(("collect", id(self)), st.device):
+                            c.capture(lambda: self._body(ts_in, policy_state))
                     except Exception:
                         self.enabled = False
                         raise
                     self._graphs[slot] = c
-                time_step = c.replay()
+                lanes = lanes_for(st.device)
+                if lanes is None:
+                    time_step = c.replay()
+                else:
+                    if it == 0:
+                        lanes.C.wait_event(lanes.main_frontier())
+                        if lanes.sample_done is not None:
+                            lanes.C.wait_event(lanes.sample_done)
+                    with torch.cuda.stream(lanes.C):
+                        time_step = c.replay()
+                        lanes.collect_done = Lanes._event_on(lanes.C)
                 self._seq += 1
                 self.replays += 1
                 it += 1

@@ -157,3 +157,44 @@ def test_full_loop_graphs_match_eager(dev):
     # train graphs were bound to the sampler's ring slots (no per-step input copies)
     bound = next(iter(gt._cache.values()))
     assert len(bound) > 1
+
+
+@pytest.mark.parametrize("B,p_end,num_steps", [(8, 0.2, 1), (2, 0.6, 2), (4, 0.5, 9)])
+def test_stream_overlap_matches_single_stream(dev, B, p_end, num_steps):
+    """collect on lane C, sampling on lane S, training on the caller's stream, ordered by events:
+    bit-identical to the eager single-stream loop (including runs that need extra driver
+    iterations because boundary steps are not counted)."""
+    S = 16
+    env_e, ag_e, rb_e, drv_e, net_e = _stack(dev, B, 64, p_end, num_steps, dataset_ring=0)
+    env_g, ag_g, rb_g, drv_g, net_g = _stack(dev, B, 64, p_end, num_steps)
+    run_g = common.function(drv_g.run)
+    lrn = learner.Learner(None, common.Variable(0), ag_g)
+    for _ in range(4):
+        drv_e.run()
+        run_g()
+    graph.enable_overlap(dev)
+    try:
+        it_g = iter(rb_g.as_dataset(sample_batch_size=S, num_steps=2).prefetch(3))
+        q = []
+        ts_e = ts_g = None
+        for i in range(60):
+            ts_e, _ = drv_e.run(ts_e)
+            while len(q) <= 3:
+                q.append(rb_e.get_next(S, 2))
+            exp_e, _ = q.pop(0)
+            li_e = ag_e.train(exp_e)
+            ts_g, _ = run_g(ts_g)
+            li_g = lrn.run(iterations=1, iterator=it_g)
+            if i % 7 == 0:
+                graph.join_lanes(dev)
+                assert torch.equal(net_e.flat_params, net_g.flat_params), f"step {i}"
+                for a, b in zip(ts_e, ts_g):
+                    assert torch.equal(a, b)
+        graph.join_lanes(dev)
+        torch.cuda.synchronize()
+        assert torch.equal(net_e.flat_params, net_g.flat_params)
+        assert float(li_e.loss) == float(li_g.loss)
+        _same_replay(rb_e, rb_g)
+        assert run_g.replays > 40 and graph.graphed_train(ag_g).replays > 40
+    finally:
+        graph.disable_overlap()

@@ -35,6 +35,10 @@ def main():
         state["ts"], _ = grun(state["ts"])
         lrn.run(iterations=1, iterator=it)
     print("full step (graphs)   %8.1f us" % timed(fullg, n=200, warm=40))
+    from agents_amd.utils import graph
+    graph.enable_overlap(dev)
+    print("full step (overlap)  %8.1f us" % timed(fullg, n=200, warm=40))
+    graph.disable_overlap()
     def collectg():
         state["ts"], _ = grun(state["ts"])
     print("collect (graph)      %8.1f us" % timed(collectg))
