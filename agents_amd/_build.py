@@ -31,7 +31,8 @@ SOURCES = [
     ("value_ops.hip", ["-ffp-contract=off"]),
     ("ppo.hip", ["-ffp-contract=off"]),
 ]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "agents_amd.h")]
+HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
+    [os.path.join(INCLUDE, "agents_amd.h")]
 
 
 def _hipcc():

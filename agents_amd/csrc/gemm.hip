@@ -685,6 +685,11 @@ static const AaTileCfg kCfgs[] = {
 // a 4-way intra-workgroup K split (two or four independent accumulator chains per wave) -- never
 // faster than the plans above on the DQN shapes.  At these sizes a launch costs ~10 us of fixed
 // time (dispatch gap, first loads, tail) and runs at a marginal ~115 TFLOP/s beyond that.
+// Also tried and dropped: a persistent kernel for conv1 with the 32 KiB filter bank resident in LDS
+// and barrier-free waves streaming 32-row tiles through private DMA rings: 42-47 us against 39 us
+// for the tiled plan.  Its ablation (no stores / no DMA / no MFMA) put 27 of the 42 us outside the
+// MFMAs -- launch 5, stores 7, A DMA 3, operand fetch from LDS + the exact uint8 -> float /255
+// (4 VALU per element) ~11 -- which is the floor to attack next, not the tile shape.
 
 struct AaGemmPlan {
   int cfg;
