@@ -1,0 +1,108 @@
+#!/usr/bin/env python
+"""BASELINE.json configs[2] (a parity-test configuration, measured here for the record, not the
+bench.py line): PPO on HalfCheetah-shaped synthetic data -- 2,048 parallel envs, 128-step
+collection, GAE(lambda=0.95), actor/value MLPs (64, 64) tanh, minibatch 4,096, 10 epochs
+(tf_agents/examples/ppo/schulman17/train_eval_lib.py:85-112,200-202).
+
+One iteration = collect 2048 x 129 env steps into the replay table (DynamicStepDriver + collect
+policy: actor forward, Normal sample, value forward) -> preprocess_sequence (value bootstrap, GAE,
+returns, advantage normalisation) -> PPOLearner: 10 epochs x 64 shuffled minibatches of 4,096 frames,
+each one PPOClipAgent.train (actor+value forward, clipped surrogate + value loss, backward, global-
+norm clip 0.5, Adam).  Prints one JSON line.   python tools/bench_ppo.py [--iters 3]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--minibatch", type=int, default=4096)
+    ap.add_argument("--epochs", type=int, default=10)
+    ap.add_argument("--iters", type=int, default=3)
+    args = ap.parse_args()
+    from agents_amd import optimizers
+    from agents_amd.agents.ppo import ppo_actor_network as pan
+    from agents_amd.agents.ppo import ppo_clip_agent
+    from agents_amd.drivers import dynamic_step_driver
+    from agents_amd.environments import random_tf_environment
+    from agents_amd.replay_buffers import tf_uniform_replay_buffer as rb_lib
+    from agents_amd.specs import tensor_spec
+    from agents_amd.train import ppo_learner
+    from agents_amd.trajectories import time_step as ts
+    from agents_amd.utils import common
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    B, T = args.envs, args.steps
+    obs = tensor_spec.BoundedTensorSpec((17,), torch.float32, -1.0, 1.0)
+    act = tensor_spec.BoundedTensorSpec((6,), torch.float32, -1.0, 1.0)
+    tss = ts.time_step_spec(obs)
+    actor = pan.PPOActorNetwork().create_sequential_actor_net((64, 64), act, seed=1)
+    value = pan.value_network((64, 64), "tanh", seed=2)
+    agent = ppo_clip_agent.PPOClipAgent(
+        tss, act, optimizers.Adam(3e-4, epsilon=1e-5), actor_net=actor, value_net=value,
+        importance_ratio_clipping=0.2, lambda_value=0.95, discount_factor=0.99, use_gae=True,
+        num_epochs=1, gradient_clipping=0.5, normalize_observations=False,
+        normalize_rewards=False, compute_value_and_advantage_in_train=False,
+        update_normalizers_in_train=False)
+    agent.initialize()
+    env = random_tf_environment.RandomTFEnvironment(tss, act, batch_size=B,
+                                                    episode_end_probability=1e-3, seed=3, device=dev)
+    rb = rb_lib.TFUniformReplayBuffer(agent.collect_data_spec, batch_size=B, max_length=T + 1,
+                                      device=dev)
+    drv = dynamic_step_driver.DynamicStepDriver(env, agent.collect_policy,
+                                                observers=[rb.add_batch], num_steps=B * (T + 1))
+
+    def dataset_fn():
+        return rb.as_dataset(sample_batch_size=B, num_steps=T + 1,
+                             single_deterministic_pass=True).map(
+            lambda traj, info: (agent.preprocess_sequence(traj), info))
+
+    def one_iteration():
+        t0 = time.perf_counter()
+        rb.clear()
+        drv.run()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        lrn = ppo_learner.PPOLearner(None, common.Variable(0), agent, dataset_fn, dataset_fn,
+                                     num_samples=1, num_epochs=args.epochs,
+                                     minibatch_size=args.minibatch,
+                                     shuffle_buffer_size=B * (T + 1))
+        li = lrn.run()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        n_steps = (lrn.num_frames_for_training // args.minibatch) * args.epochs
+        return t1 - t0, t2 - t1, n_steps, float(li.loss)
+
+    one_iteration()   # warm-up (buffers, workspaces)
+    tc = tt = 0.0
+    steps = 0
+    for _ in range(args.iters):
+        c, t, n, loss = one_iteration()
+        tc += c
+        tt += t
+        steps += n
+    frames = B * (T + 1)
+    out = {"workload": "configs[2]: PPO HalfCheetah-shaped, %d envs x %d steps, minibatch %d, "
+                       "%d epochs, MLP (64,64)" % (B, T, args.minibatch, args.epochs),
+           "collect_env_steps_per_sec": frames * args.iters / tc,
+           "collect_s_per_iteration": tc / args.iters,
+           "train_minibatch_steps_per_sec": steps / tt,
+           "train_frames_per_sec": steps * args.minibatch / tt,
+           "train_s_per_iteration": tt / args.iters,
+           "minibatch_steps_per_iteration": steps // args.iters,
+           "iteration_s": (tc + tt) / args.iters, "final_loss": loss, "n_gpus": 1}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
