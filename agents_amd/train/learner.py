@@ -54,7 +54,8 @@ class Learner:
         self._agent.initialize()
         # learner.py:309-337 runs the step inside tf.function; here: HIP-graph replay
         self._train_fn = self._agent.train
-        if use_graph and hasattr(self._agent, "_train_phase_grads"):
+        if use_graph and (hasattr(self._agent, "_train_phase_grads") or
+                          hasattr(self._agent, "_graph_train_whole")):
             from agents_amd.utils import graph
             self._train_fn = graph.graphed_train(self._agent)
         self._last_checkpoint_step = int(self.train_step) if self.train_step is not None else 0

@@ -59,6 +59,8 @@ class PPOLearner:
         self._seed = seed
         self._train_iter = None
         self._norm_iter = None
+        self._mb_buffers = None
+        self._mb_key = None
 
     # ---- data ------------------------------------------------------------------------------------
     def _take_samples(self):
@@ -100,12 +102,23 @@ class PPOLearner:
         if self._gen is None:
             self._gen = torch.Generator(device=dev)
             self._gen.manual_seed(self._seed)
+        # minibatches are gathered into ONE persistent buffer set: the train step's HIP graph is
+        # bound to these addresses and replays without input copies (utils/graph.py)
+        key = (mb, tuple((tuple(t.shape[1:]), t.dtype) for t in nest_utils.flatten(frames)))
+        if self._mb_buffers is None or self._mb_key != key:
+            self._mb_buffers = nest_utils.map_structure(
+                lambda t: torch.empty((mb,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev),
+                frames)
+            self._mb_key = key
+        bufs = self._mb_buffers
+        views = nest_utils.map_structure(lambda t: t.unsqueeze(1), bufs)
         for _ in range(self._num_epochs):
             perm = torch.randperm(F, device=dev, generator=self._gen)
             for i in range(F // mb):
                 idx = perm[i * mb:(i + 1) * mb]
-                yield nest_utils.map_structure(
-                    lambda t: t.index_select(0, idx).unsqueeze(1), frames), None
+                for src, dst in zip(nest_utils.flatten(frames), nest_utils.flatten(bufs)):
+                    torch.index_select(src, 0, idx, out=dst)
+                yield views, None
 
     def _full_batches(self, samples):
         for _ in range(self._num_epochs):

@@ -22,7 +22,7 @@ def function(*args, **kwargs):
         # `common.function(agent.train)`: the tf.function analogue here is HIP-graph capture
         owner = getattr(fn, "__self__", None)
         if owner is not None and getattr(fn, "__name__", "") == "train" and \
-                hasattr(owner, "_train_phase_grads"):
+                (hasattr(owner, "_train_phase_grads") or hasattr(owner, "_graph_train_whole")):
             from agents_amd.utils import graph
             return graph.graphed_train(owner)
         # `common.function(driver.run)` (train_eval.py:234-237): HIP-graph replay of the loop body

@@ -173,6 +173,7 @@ class _Entry:
         self.static_w = None
         self.g_grads = None
         self.g_apply = None
+        self.captured = None
         self.out = None
 
 
@@ -193,8 +194,13 @@ class GraphedTrain:
         self._cache = {}       # signature -> {input address tuple | None: _Entry}
         self._warm = {}
         self._seen = {}
-        self.enabled = all(hasattr(agent, n) for n in
+        # phase mode: two graphs around the gradient hook (DqnAgent); whole mode: the entire
+        # `_train` in one graph, for agents whose train step has no host-side decisions and no
+        # gradient hook installed (PPOAgent on one replica)
+        self._phases = all(hasattr(agent, n) for n in
                            ("_train_phase_grads", "_train_phase_apply", "_train_phase_host"))
+        self._whole = not self._phases and hasattr(agent, "_graph_train_whole")
+        self.enabled = self._phases or self._whole
         self.replays = 0
 
     @property
@@ -205,13 +211,16 @@ class GraphedTrain:
         agent = self._agent
         if not self.enabled or kwargs or getattr(agent, "check_numerics", False) or capturing():
             return agent.train(experience, weights=weights, **kwargs)
+        if self._whole and getattr(agent, "gradient_hook", None) is not None:
+            return agent.train(experience, weights=weights)
         sig = _sig(experience, weights)
         if self._warm.get(sig, 0) < _WARMUP_CALLS:
             self._warm[sig] = self._warm.get(sig, 0) + 1
             return agent.train(experience, weights=weights)
         if not agent._initialized:
             agent.initialize()
-        agent._check_trajectory(experience)
+        if hasattr(agent, "_check_trajectory"):
+            agent._check_trajectory(experience)
         # Graphs are bound to the ADDRESSES of their inputs.  A sampler that hands out a ring of
         # static buffers (GraphedSampler) gets one captured graph per ring slot -- no copies; any
         # other caller (fresh tensors every step) shares the first graph and pays one copy per
@@ -235,7 +244,7 @@ class GraphedTrain:
                     # an address set that came back (a ring slot): worth its own graph
                     e = _Entry()
                     self._capture(e, experience, weights, clone=False,
-                                  g_apply=bound[None].g_apply)
+                                  g_apply=None if self._whole else bound[None].g_apply)
                     bound[ptrs] = e
                 if len(seen) > 4 * _MAX_BINDINGS:
                     seen.clear()
@@ -256,15 +265,20 @@ class GraphedTrain:
                     dst.copy_(src, non_blocking=True)
             if e.static_w is not None and e.static_w.data_ptr() != weights.data_ptr():
                 e.static_w.copy_(weights, non_blocking=True)
-            e.g_grads.replay()
-            if agent.gradient_hook is not None:
-                agent.gradient_hook(agent._q_network.flat_grads)
-            if lanes is not None and lanes.collect_done is not None:
-                # the optimizer overwrites theta_k: the collect policy's forward must be done
-                torch.cuda.current_stream(dev).wait_event(lanes.collect_done)
-            e.g_apply.replay()
-            agent._optimizer.iterations += 1
-            agent._train_phase_host()
+            if self._whole:
+                if lanes is not None:
+                    lanes.join()
+                e.captured.replay()
+            else:
+                e.g_grads.replay()
+                if agent.gradient_hook is not None:
+                    agent.gradient_hook(agent._q_network.flat_grads)
+                if lanes is not None and lanes.collect_done is not None:
+                    # the optimizer overwrites theta_k: the collect policy's forward must be done
+                    torch.cuda.current_stream(dev).wait_event(lanes.collect_done)
+                e.g_apply.replay()
+                agent._optimizer.iterations += 1
+                agent._train_phase_host()
         self.replays += 1
         return e.out
 
@@ -274,6 +288,10 @@ class GraphedTrain:
             else experience
         e.static_w = weights.clone() if isinstance(weights, torch.Tensor) else None
         w_arg = e.static_w if e.static_w is not None else weights
+        if self._whole:
+            e.captured = _Captured()
+            e.out = e.captured.capture(lambda: agent._graph_train_whole(e.static_in, w_arg))
+            return
         torch.cuda.synchronize()
         iters = agent._optimizer.iterations
         e.g_grads = torch.cuda.CUDAGraph()

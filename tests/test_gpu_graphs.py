@@ -198,3 +198,55 @@ def test_stream_overlap_matches_single_stream(dev, B, p_end, num_steps):
         assert run_g.replays > 40 and graph.graphed_train(ag_g).replays > 40
     finally:
         graph.disable_overlap()
+
+
+def test_ppo_train_graph_matches_eager(dev):
+    """PPOClipAgent.train replayed as one HIP graph by the Learner (minibatches gathered into the
+    graph's static inputs) == the eager train step, parameter for parameter."""
+    from agents_amd.agents.ppo import ppo_actor_network as pan
+    from agents_amd.agents.ppo import ppo_clip_agent
+    from agents_amd.train import ppo_learner
+    obs = tensor_spec.BoundedTensorSpec((17,), torch.float32, -1.0, 1.0)
+    act = tensor_spec.BoundedTensorSpec((6,), torch.float32, -1.0, 1.0)
+    tss = ts.time_step_spec(obs)
+
+    def make():
+        actor = pan.PPOActorNetwork().create_sequential_actor_net((32, 32), act, seed=1)
+        value = pan.value_network((32, 32), "tanh", seed=2)
+        ag = ppo_clip_agent.PPOClipAgent(
+            tss, act, optimizers.Adam(3e-4, epsilon=1e-5), actor_net=actor, value_net=value,
+            importance_ratio_clipping=0.2, use_gae=True, num_epochs=1, gradient_clipping=0.5,
+            normalize_observations=False, normalize_rewards=False,
+            compute_value_and_advantage_in_train=False, update_normalizers_in_train=False)
+        ag.initialize()
+        return ag
+
+    B, T = 16, 12
+    ag_e, ag_g = make(), make()
+    env = random_tf_environment.RandomTFEnvironment(tss, act, batch_size=B,
+                                                    episode_end_probability=0.1, seed=4, device=dev)
+    rb = rb_lib.TFUniformReplayBuffer(ag_e.collect_data_spec, batch_size=B, max_length=T + 1,
+                                      device=dev)
+    dynamic_step_driver.DynamicStepDriver(env, ag_e.collect_policy, observers=[rb.add_batch],
+                                          num_steps=B * (T + 1)).run()
+
+    def run(agent, use_graph):
+        fn = lambda: rb.as_dataset(sample_batch_size=B, num_steps=T + 1,
+                                   single_deterministic_pass=True).map(
+            lambda traj, info: (agent.preprocess_sequence(traj), info))
+        lrn = ppo_learner.PPOLearner(None, common.Variable(0), agent, fn, fn, num_samples=1,
+                                     num_epochs=6, minibatch_size=32,
+                                     shuffle_buffer_size=B * (T + 1), seed=3)
+        if not use_graph:
+            lrn._generic_learner._train_fn = agent.train
+        li = lrn.run()
+        return li, lrn
+
+    li_e, _ = run(ag_e, False)
+    li_g, lrn_g = run(ag_g, True)
+    gt = graph.graphed_train(ag_g)
+    assert gt.replays > 20, "the PPO train graph never replayed"
+    assert torch.equal(ag_e.flat_params, ag_g.flat_params)
+    assert float(li_e.loss) == float(li_g.loss)
+    assert int(ag_e.train_step_counter.numpy()) == int(ag_g.train_step_counter.numpy())
+    assert ag_e._optimizer.iterations == ag_g._optimizer.iterations

@@ -67,16 +67,17 @@ def main():
                              single_deterministic_pass=True).map(
             lambda traj, info: (agent.preprocess_sequence(traj), info))
 
+    lrn = ppo_learner.PPOLearner(None, common.Variable(0), agent, dataset_fn, dataset_fn,
+                                 num_samples=1, num_epochs=args.epochs,
+                                 minibatch_size=args.minibatch, shuffle_buffer_size=B * (T + 1))
+
     def one_iteration():
         t0 = time.perf_counter()
         rb.clear()
         drv.run()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        lrn = ppo_learner.PPOLearner(None, common.Variable(0), agent, dataset_fn, dataset_fn,
-                                     num_samples=1, num_epochs=args.epochs,
-                                     minibatch_size=args.minibatch,
-                                     shuffle_buffer_size=B * (T + 1))
+        lrn._train_iter = lrn._norm_iter = None   # a fresh deterministic pass over the new data
         li = lrn.run()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
