@@ -17,6 +17,7 @@ AA_A_ROW, AA_A_COL, AA_A_PATCH, AA_A_PATCH_U8, AA_A_PATCH_T, AA_A_PATCH_T_U8 = 0
 AA_B_ROW, AA_B_COL = 0, 1
 AA_LOSS_HUBER, AA_LOSS_SQUARED = 0, 1
 AA_OBS_U8, AA_OBS_F32 = 0, 1
+AA_SAC_STD_EXP, AA_SAC_STD_CLIP_EXP = 0, 1
 AA_PPO_NSTATS = 8
 AA_PPO_DIST_STATS = 16 + 6 * 256
 
@@ -113,6 +114,15 @@ _SIGNATURES = {
                                  c_void_p]),
     "aa_ppo_trajectory_mask": (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p]),
     "aa_ppo_update_kl_beta": (c_int, [c_void_p, c_float, c_float, c_void_p, c_void_p]),
+    "aa_sac_sample": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
+                              c_uint64] + [c_void_p] * 7),
+    "aa_sac_head_backward": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32] +
+                             [c_void_p] * 7),
+    "aa_sac_critic_loss": (c_int, [c_void_p] * 9 + [c_float, c_float, c_int32, c_float, c_int64,
+                                                    c_float] + [c_void_p] * 5),
+    "aa_sac_actor_loss": (c_int, [c_void_p] * 5 + [c_float, c_int64, c_float] + [c_void_p] * 5),
+    "aa_sac_alpha_loss": (c_int, [c_void_p] * 3 + [c_float, c_int32, c_float, c_int64, c_float] +
+                          [c_void_p] * 3),
 }
 
 _lib = None

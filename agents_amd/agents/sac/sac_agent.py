@@ -1,0 +1,447 @@
+"""SacAgent on MI355X: twin-Q critics, tanh-squashed Normal actor, learned entropy temperature.
+
+Drop-in for tf_agents/agents/sac/sac_agent.py:61-827 (constructor arguments, `train` / `loss` /
+`critic_loss` / `actor_loss` / `alpha_loss`, `SacLossInfo`, `std_clip_transform`), with every
+data-path step a HIP kernel:
+  _actions_and_log_probs (:533-558)  actor MLP (fp32 MFMA GEMMs) + aa_sac_sample
+  critic_loss (:559-644)             target/online critic MLPs + aa_sac_critic_loss (+ backward)
+  actor_loss  (:646-694)             aa_sac_actor_loss -> critic input gradients (no critic weight
+                                     gradients) -> aa_sac_head_backward -> actor backward
+  alpha_loss  (:696-740)             aa_sac_alpha_loss
+  _apply_gradients (:463-484)        aa_clip_by_norm (per variable, optional) + aa_adam_step x3
+  _get_target_updater (:486-531)     aa_soft_update over the flat critic buffer
+_train (:314-410) keeps the reference's order: critic update, then actor update through the
+UPDATED critics, then alpha with a fresh sample from the UPDATED actor, then the target update.
+Both critics (and both targets) live in one flat parameter buffer, so the critic optimizer, the
+clip and the soft update are single launches.
+
+Networks: `networks.actor_distribution_network.ActorDistributionNetwork` (tanh-Normal projection)
+and `networks.critic_network.CriticNetwork`.  The reference lets callers pass `actor_policy_ctor`;
+here the policy is always `SacPolicy` (an ActorPolicy over the same kernels).
+"""
+import collections
+
+import numpy as np
+import torch
+
+from agents_amd import _lib
+from agents_amd.agents import tf_agent
+from agents_amd.networks import actor_distribution_network as adn
+from agents_amd.policies import tf_policy
+from agents_amd.trajectories import policy_step
+from agents_amd.utils import common, graph, nest_utils
+
+SacLossInfo = collections.namedtuple("SacLossInfo", ("critic_loss", "actor_loss", "alpha_loss"))
+
+std_clip_transform = adn.std_clip_transform
+
+
+def _spec_means_and_magnitudes(spec):
+    """common.spec_means_and_magnitudes (utils/common.py:548-577)."""
+    lo = np.broadcast_to(np.asarray(spec.minimum, np.float32), spec.shape or (1,)).reshape(-1)
+    hi = np.broadcast_to(np.asarray(spec.maximum, np.float32), spec.shape or (1,)).reshape(-1)
+    return ((hi + lo) / 2.0).astype(np.float32), ((hi - lo) / 2.0).astype(np.float32)
+
+
+class SacPolicy(tf_policy.TFPolicy):
+    """ActorPolicy (tf_agents/policies/actor_policy.py) for the tanh-Normal actor: `action` draws
+    one reparameterised sample per call (Philox stream of its own seed / call counter)."""
+
+    def __init__(self, time_step_spec, action_spec, actor_network, training=False, seed=0,
+                 name=None):
+        super().__init__(time_step_spec, action_spec, name=name)
+        self._actor_network = actor_network
+        self._training = training
+        self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._spec = nest_utils.flatten(action_spec)[0]
+        self._A = int(np.prod(self._spec.shape)) or 1
+        self._mean_h, self._mag_h = _spec_means_and_magnitudes(self._spec)
+        self._dev_consts = None
+        self._call_counter = None
+        self._bufs = {}
+
+    def _variables(self):
+        return self._actor_network.variables
+
+    def _consts(self, dev):
+        if self._dev_consts is None:
+            self._dev_consts = (torch.from_numpy(self._mean_h.copy()).to(dev),
+                                torch.from_numpy(self._mag_h.copy()).to(dev))
+            self._call_counter = torch.zeros((1,), dtype=torch.int64, device=dev)
+        return self._dev_consts
+
+    def sample(self, observation, slot, need_grad=False, eps=None, save=None):
+        """(action [B,A], log_pi [B], z) for a batch of observations; `save` = dict of [B,A]
+        buffers (tanh, sigma, eps) kept for the backward pass."""
+        lib = _lib.load()
+        dev = observation.device
+        mean, mag = self._consts(dev)
+        z = self._actor_network.forward(observation, slot=slot, need_grad=need_grad)
+        B = z.shape[0]
+        key = (slot, B)
+        b = self._bufs.get(key)
+        if b is None:
+            b = {"action": torch.empty((B, self._A), dtype=torch.float32, device=dev),
+                 "logp": torch.empty((B,), dtype=torch.float32, device=dev)}
+            self._bufs[key] = b
+        st = _lib.stream_ptr()
+        _lib.check(lib.aa_sac_sample(
+            z.data_ptr(), B, self._A, mean.data_ptr(), mag.data_ptr(),
+            self._actor_network.projection.std_kind, _lib.ptr(eps), self._seed,
+            self._call_counter.data_ptr(), b["action"].data_ptr(), b["logp"].data_ptr(),
+            _lib.ptr(save["tanh"]) if save else None, _lib.ptr(save["sigma"]) if save else None,
+            _lib.ptr(save["eps"]) if save else None, st), "aa_sac_sample")
+        if eps is None:
+            _lib.check(lib.aa_counter_add(self._call_counter.data_ptr(), 1, st), "aa_counter_add")
+        return b["action"], b["logp"], z
+
+    def _action(self, time_step, policy_state, seed):
+        obs = time_step.observation
+        batched = time_step.step_type.dim() > 0
+        if not batched:
+            obs = obs.unsqueeze(0)
+        graph.join_lanes(obs.device)
+        with torch.cuda.device(obs.device):
+            action, _, _ = self.sample(obs, slot="policy")
+            action = action.reshape((obs.shape[0],) + tuple(self._spec.shape)).clone()
+        if not batched:
+            action = action.squeeze(0)
+        return policy_step.PolicyStep(action, policy_state, ())
+
+
+class SacAgent(tf_agent.TFAgent):
+    def __init__(self, time_step_spec, action_spec, critic_network, actor_network,
+                 actor_optimizer, critic_optimizer, alpha_optimizer, actor_loss_weight=1.0,
+                 critic_loss_weight=0.5, alpha_loss_weight=1.0, actor_policy_ctor=None,
+                 critic_network_2=None, target_critic_network=None, target_critic_network_2=None,
+                 target_update_tau=1.0, target_update_period=1,
+                 td_errors_loss_fn=common.element_wise_squared_loss, gamma=1.0,
+                 reward_scale_factor=1.0, initial_log_alpha=0.0, use_log_alpha_in_alpha_loss=True,
+                 target_entropy=None, gradient_clipping=None, debug_summaries=False,
+                 summarize_grads_and_vars=False, train_step_counter=None, name=None, seed=0):
+        flat_spec = nest_utils.flatten(action_spec)
+        for spec in flat_spec:
+            if spec.dtype in (torch.int32, torch.int64):
+                raise NotImplementedError(
+                    "SacAgent does not currently support discrete actions. "
+                    "Action spec: {}".format(action_spec))
+        if actor_policy_ctor is not None:
+            raise NotImplementedError("actor_policy_ctor: the policy is SacPolicy")
+        obs_spec = time_step_spec.observation
+        critic_network.create_variables((obs_spec, action_spec))
+        critic_network_2 = critic_network_2 or critic_network.copy(name="CriticNetwork2")
+        critic_network_2.create_variables((obs_spec, action_spec))
+        target_critic_network = target_critic_network or critic_network.copy(
+            name="TargetCriticNetwork1")
+        target_critic_network.create_variables((obs_spec, action_spec))
+        target_critic_network_2 = target_critic_network_2 or critic_network.copy(
+            name="TargetCriticNetwork2")
+        target_critic_network_2.create_variables((obs_spec, action_spec))
+        actor_network.create_variables(obs_spec)
+        self._critic_network_1, self._critic_network_2 = critic_network, critic_network_2
+        self._target_critic_network_1 = target_critic_network
+        self._target_critic_network_2 = target_critic_network_2
+        self._actor_network = actor_network
+        dev = critic_network.flat_params.device
+        # both critics in one flat buffer (critic optimizer / clip / soft update = one launch each)
+        n1, n2 = critic_network.flat_size, critic_network_2.flat_size
+        self._critic_params = torch.empty((n1 + n2,), dtype=torch.float32, device=dev)
+        self._critic_grads = torch.zeros_like(self._critic_params)
+        critic_network.rebind(self._critic_params[:n1], self._critic_grads[:n1])
+        critic_network_2.rebind(self._critic_params[n1:], self._critic_grads[n1:])
+        self._target_params = torch.empty_like(self._critic_params)
+        tg = torch.zeros_like(self._critic_params)
+        target_critic_network.rebind(self._target_params[:n1], tg[:n1])
+        target_critic_network_2.rebind(self._target_params[n1:], tg[n1:])
+        # log_alpha: one trainable scalar, padded to a 16-byte vector for the fused optimizer
+        self._log_alpha_buf = torch.zeros((4,), dtype=torch.float32, device=dev)
+        self._log_alpha_buf[0] = float(initial_log_alpha)
+        self._log_alpha_grad = torch.zeros((4,), dtype=torch.float32, device=dev)
+        self._spec = flat_spec[0]
+        self._A = int(np.prod(self._spec.shape)) or 1
+        if target_entropy is None:
+            target_entropy = -float(sum(int(np.prod(s.shape)) or 1 for s in flat_spec)) / 2.0
+        self._target_entropy = float(target_entropy)
+        self._use_log_alpha_in_alpha_loss = bool(use_log_alpha_in_alpha_loss)
+        self._target_update_tau = float(target_update_tau)
+        self._target_update_period = int(target_update_period)
+        self._actor_optimizer = actor_optimizer
+        self._critic_optimizer = critic_optimizer
+        self._alpha_optimizer = alpha_optimizer
+        self._actor_loss_weight = float(actor_loss_weight)
+        self._critic_loss_weight = float(critic_loss_weight)
+        self._alpha_loss_weight = float(alpha_loss_weight)
+        self._td_errors_loss_fn = td_errors_loss_fn
+        self._gamma = float(gamma)
+        self._reward_scale_factor = float(reward_scale_factor)
+        self._gradient_clipping = gradient_clipping
+        policy = SacPolicy(time_step_spec, action_spec, actor_network, training=False, seed=seed)
+        self._train_policy = SacPolicy(time_step_spec, action_spec, actor_network, training=True,
+                                       seed=seed + 1)
+        self._update_target = common.Periodically(self._soft_update_targets,
+                                                  self._target_update_period, "update_targets")
+        super().__init__(time_step_spec, action_spec, policy=policy, collect_policy=policy,
+                         train_sequence_length=2, debug_summaries=debug_summaries,
+                         summarize_grads_and_vars=summarize_grads_and_vars,
+                         train_step_counter=train_step_counter)
+        self.num_replicas = 1
+        self.gradient_hook = None
+        self._work = {}
+        self._clip_state = {}
+
+    # ---- accessors ------------------------------------------------------------------------------
+    @property
+    def log_alpha(self):
+        return self._log_alpha_buf[0]
+
+    @property
+    def actor_network(self):
+        return self._actor_network
+
+    @property
+    def critic_networks(self):
+        return self._critic_network_1, self._critic_network_2
+
+    @property
+    def target_critic_networks(self):
+        return self._target_critic_network_1, self._target_critic_network_2
+
+    def _initialize(self):
+        common.soft_variables_update(self._critic_params, self._target_params, tau=1.0)
+
+    def _soft_update_targets(self):
+        common.soft_variables_update(self._critic_params, self._target_params,
+                                     tau=self._target_update_tau)
+
+    def _loss_kind(self):
+        kind = getattr(self._td_errors_loss_fn, "aa_loss_kind", None)
+        if kind is None:
+            raise NotImplementedError(
+                "td_errors_loss_fn must be common.element_wise_squared_loss "
+                "(tf.math.squared_difference) or common.element_wise_huber_loss")
+        return kind
+
+    def _w(self, B, dev):
+        w = self._work.get(B)
+        if w is None:
+            f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+            w = {"closs": f(1), "aloss": f(1), "lloss": f(1), "td": f(B), "dq1": f(B), "dq2": f(B),
+                 "dlogp": f(B), "dz": f(B, 2 * self._A), "da": f(B, self._A),
+                 "save": {"tanh": f(B, self._A), "sigma": f(B, self._A), "eps": f(B, self._A)}}
+            self._work[B] = w
+        return w
+
+    def _weights(self, weights, B, dev):
+        if weights is None:
+            return None
+        if not isinstance(weights, torch.Tensor):
+            return torch.full((B,), float(weights), dtype=torch.float32, device=dev)
+        if weights.dim() == 0:
+            return weights.to(torch.float32).expand(B).contiguous()
+        return weights.to(torch.float32).reshape(B).contiguous()
+
+    def _as_transition(self, experience):
+        """AsTransition(squeeze_time_dim=True) on a [B, 2] trajectory (data_converter.py:300-380):
+        time_steps = frame 0; next_time_steps = frame 1 with reward/discount of frame 0."""
+        obs = experience.observation
+        B = experience.discount.shape[0]
+        act = experience.action[:, 0].reshape(B, -1).to(torch.float32).contiguous()
+        return (obs[:, 0].contiguous(), act, obs[:, 1].contiguous(),
+                experience.reward[:, 0].contiguous(), experience.discount[:, 0].contiguous())
+
+    # ---- the three losses (forward + gradients) --------------------------------------------------
+    def _critic_phase(self, obs, actions, next_obs, reward, discount, weights, need_grad,
+                      eps_next=None):
+        lib = _lib.load()
+        B = obs.shape[0]
+        dev = obs.device
+        w = self._w(B, dev)
+        na, nlogp, _ = self._policy.sample(next_obs, slot="next", eps=eps_next)
+        tq1 = self._target_critic_network_1.forward(next_obs, na, slot="target")
+        tq2 = self._target_critic_network_2.forward(next_obs, na, slot="target")
+        q1 = self._critic_network_1.forward(obs, actions, slot="critic", need_grad=need_grad)
+        q2 = self._critic_network_2.forward(obs, actions, slot="critic", need_grad=need_grad)
+        _lib.check(lib.aa_sac_critic_loss(
+            q1.data_ptr(), q2.data_ptr(), tq1.data_ptr(), tq2.data_ptr(), nlogp.data_ptr(),
+            reward.data_ptr(), discount.data_ptr(), _lib.ptr(weights),
+            self._log_alpha_buf.data_ptr(), self._gamma, self._reward_scale_factor,
+            self._loss_kind(), self._critic_loss_weight, B, float(B * self.num_replicas),
+            w["closs"].data_ptr(), w["td"].data_ptr(),
+            w["dq1"].data_ptr() if need_grad else None, w["dq2"].data_ptr() if need_grad else None,
+            _lib.stream_ptr()), "aa_sac_critic_loss")
+        if need_grad:
+            self._critic_network_1.backward(w["dq1"], slot="critic")
+            self._critic_network_2.backward(w["dq2"], slot="critic")
+        return w["closs"]
+
+    def _actor_phase(self, obs, weights, need_grad, eps=None):
+        lib = _lib.load()
+        B = obs.shape[0]
+        w = self._w(B, obs.device)
+        pol = self._train_policy if need_grad else self._policy
+        a, logp, z = pol.sample(obs, slot="actor", need_grad=need_grad, eps=eps,
+                                save=w["save"] if need_grad else None)
+        q1 = self._critic_network_1.forward(obs, a, slot="actor_q", need_grad=need_grad)
+        q2 = self._critic_network_2.forward(obs, a, slot="actor_q", need_grad=need_grad)
+        _lib.check(lib.aa_sac_actor_loss(
+            q1.data_ptr(), q2.data_ptr(), logp.data_ptr(), _lib.ptr(weights),
+            self._log_alpha_buf.data_ptr(), self._actor_loss_weight, B,
+            float(B * self.num_replicas), w["aloss"].data_ptr(),
+            w["dq1"].data_ptr() if need_grad else None, w["dq2"].data_ptr() if need_grad else None,
+            w["dlogp"].data_ptr() if need_grad else None, _lib.stream_ptr()),
+            "aa_sac_actor_loss")
+        if need_grad:
+            # d loss / d action through BOTH critics (their weights are not touched here)
+            da1 = self._critic_network_1.backward(w["dq1"], slot="actor_q", param_grads=False,
+                                                  want_action_grad=True)
+            da2 = self._critic_network_2.backward(w["dq2"], slot="actor_q", param_grads=False,
+                                                  want_action_grad=True)
+            torch.add(da1, da2, out=w["da"])
+            mag = self._train_policy._consts(obs.device)[1]
+            _lib.check(lib.aa_sac_head_backward(
+                z.data_ptr(), B, self._A, mag.data_ptr(),
+                self._actor_network.projection.std_kind, w["save"]["tanh"].data_ptr(),
+                w["save"]["sigma"].data_ptr(), w["save"]["eps"].data_ptr(), w["da"].data_ptr(),
+                w["dlogp"].data_ptr(), w["dz"].data_ptr(), _lib.stream_ptr()),
+                "aa_sac_head_backward")
+            self._actor_network.backward(w["dz"], slot="actor")
+        return w["aloss"]
+
+    def _alpha_phase(self, obs, weights, need_grad, eps=None):
+        lib = _lib.load()
+        B = obs.shape[0]
+        w = self._w(B, obs.device)
+        _, logp, _ = self._policy.sample(obs, slot="alpha", eps=eps)
+        _lib.check(lib.aa_sac_alpha_loss(
+            logp.data_ptr(), _lib.ptr(weights), self._log_alpha_buf.data_ptr(),
+            self._target_entropy, 1 if self._use_log_alpha_in_alpha_loss else 0,
+            self._alpha_loss_weight, B, float(B * self.num_replicas), w["lloss"].data_ptr(),
+            self._log_alpha_grad.data_ptr() if need_grad else None, _lib.stream_ptr()),
+            "aa_sac_alpha_loss")
+        return w["lloss"]
+
+    # ---- public loss API (sac_agent.py:559-740; values only) ------------------------------------
+    def critic_loss(self, time_steps, actions, next_time_steps, td_errors_loss_fn=None, gamma=None,
+                    reward_scale_factor=None, weights=None, training=False):
+        B = time_steps.observation.shape[0]
+        dev = time_steps.observation.device
+        saved = (self._td_errors_loss_fn, self._gamma, self._reward_scale_factor)
+        if td_errors_loss_fn is not None:
+            self._td_errors_loss_fn = td_errors_loss_fn
+        if gamma is not None:
+            self._gamma = float(gamma)
+        if reward_scale_factor is not None:
+            self._reward_scale_factor = float(reward_scale_factor)
+        weight = self._critic_loss_weight
+        self._critic_loss_weight = 1.0
+        try:
+            with torch.cuda.device(dev):
+                out = self._critic_phase(
+                    time_steps.observation, actions.reshape(B, -1).to(torch.float32).contiguous(),
+                    next_time_steps.observation, next_time_steps.reward.contiguous(),
+                    next_time_steps.discount.contiguous(), self._weights(weights, B, dev),
+                    False).clone().reshape(())
+        finally:
+            self._td_errors_loss_fn, self._gamma, self._reward_scale_factor = saved
+            self._critic_loss_weight = weight
+        return out
+
+    def actor_loss(self, time_steps, weights=None, training=True):
+        B = time_steps.observation.shape[0]
+        dev = time_steps.observation.device
+        weight = self._actor_loss_weight
+        self._actor_loss_weight = 1.0
+        try:
+            with torch.cuda.device(dev):
+                return self._actor_phase(time_steps.observation, self._weights(weights, B, dev),
+                                         False).clone().reshape(())
+        finally:
+            self._actor_loss_weight = weight
+
+    def alpha_loss(self, time_steps, weights=None, training=False):
+        B = time_steps.observation.shape[0]
+        dev = time_steps.observation.device
+        weight = self._alpha_loss_weight
+        self._alpha_loss_weight = 1.0
+        try:
+            with torch.cuda.device(dev):
+                return self._alpha_phase(time_steps.observation, self._weights(weights, B, dev),
+                                         False).clone().reshape(())
+        finally:
+            self._alpha_loss_weight = weight
+
+    # ---- train ----------------------------------------------------------------------------------
+    def _apply(self, optimizer, params, grads, net_for_clip=None):
+        if self._gradient_clipping is not None:
+            self._clip(params, grads, net_for_clip)
+        if self.gradient_hook is not None:
+            self.gradient_hook(grads)
+        optimizer.apply_flat(params, grads)
+
+    def _clip(self, params, grads, nets):
+        """Per-variable tf.clip_by_norm (eager_utils.clip_gradient_norms, eager_utils.py:227-246)."""
+        lib = _lib.load()
+        key = grads.data_ptr()
+        st = self._clip_state.get(key)
+        if st is None:
+            starts, base = [], 0
+            for net in nets or []:
+                starts += [base + s0 for s0, _ in net.segment_offsets()]
+                base += net.flat_size
+            if not nets:
+                starts = [0]
+                base = grads.numel()
+            offs = torch.tensor(starts + [base], dtype=torch.int64, device=grads.device)
+            st = (offs, torch.zeros((len(starts),), dtype=torch.float32, device=grads.device))
+            self._clip_state[key] = st
+        offs, sumsq = st
+        s = _lib.stream_ptr()
+        _lib.check(lib.aa_segment_sumsq(grads.data_ptr(), offs.data_ptr(), sumsq.numel(),
+                                        sumsq.data_ptr(), s), "aa_segment_sumsq")
+        _lib.check(lib.aa_clip_by_norm(grads.data_ptr(), offs.data_ptr(), sumsq.numel(),
+                                       sumsq.data_ptr(), float(self._gradient_clipping), 1, s),
+                   "aa_clip_by_norm")
+
+    def _bump_train_step(self):
+        self._train_step_counter.assign_add(1)
+        self._update_target()
+
+    def _train(self, experience, weights, eps=None):
+        """`eps` (tests): dict of externally supplied N(0,1) noise {"next", "actor", "alpha"}."""
+        eps = eps or {}
+        obs, actions, next_obs, reward, discount = self._as_transition(experience)
+        B = obs.shape[0]
+        dev = obs.device
+        graph.join_lanes(dev)
+        with torch.cuda.device(dev):
+            wts = self._weights(weights, B, dev)
+            closs = self._critic_phase(obs, actions, next_obs, reward, discount, wts, True,
+                                       eps_next=eps.get("next"))
+            self._apply(self._critic_optimizer, self._critic_params, self._critic_grads,
+                        [self._critic_network_1.body, self._critic_network_2.body])
+            aloss = self._actor_phase(obs, wts, True, eps=eps.get("actor"))
+            self._apply(self._actor_optimizer, self._actor_network.flat_params,
+                        self._actor_network.flat_grads, [self._actor_network.body])
+            lloss = self._alpha_phase(obs, wts, True, eps=eps.get("alpha"))
+            self._apply(self._alpha_optimizer, self._log_alpha_buf, self._log_alpha_grad, None)
+            total = (closs + aloss + lloss).reshape(())
+            info = tf_agent.LossInfo(total, SacLossInfo(critic_loss=closs.clone().reshape(()),
+                                                        actor_loss=aloss.clone().reshape(()),
+                                                        alpha_loss=lloss.clone().reshape(())))
+            # counter + (periodic) soft target update: device work of the update is enqueued here
+            self._train_step_counter.assign_add(1)
+            self._update_target()
+        return info
+
+    def _loss(self, experience, weights=None, training=False):
+        obs, actions, next_obs, reward, discount = self._as_transition(experience)
+        B = obs.shape[0]
+        dev = obs.device
+        with torch.cuda.device(dev):
+            wts = self._weights(weights, B, dev)
+            closs = self._critic_phase(obs, actions, next_obs, reward, discount, wts, False).clone()
+            aloss = self._actor_phase(obs, wts, False).clone()
+            lloss = self._alpha_phase(obs, wts, False).clone()
+            total = (closs + aloss + lloss).reshape(())
+        return tf_agent.LossInfo(total, SacLossInfo(closs.reshape(()), aloss.reshape(()),
+                                                    lloss.reshape(())))

@@ -1,0 +1,290 @@
+// SAC: tanh-squashed Normal actor head (sample, log-probability, backward) and the three losses.
+//
+// Follows, op for op (fp32, built with -ffp-contract=off so that the elementwise arithmetic can be
+// compared with the torch-CPU oracle in oracle/sac.py):
+//   TanhNormalProjectionNetwork.call              tf_agents/agents/sac/tanh_normal_projection_network.py:108-143
+//   std_clip_transform                            tf_agents/agents/sac/sac_agent.py:48-57
+//   SquashToSpecNormal (Shift(Scale) o Tanh)      tf_agents/distributions/utils.py:40-160
+//   tanh_bijector_stable forward_log_det_jacobian 2 (log 2 - x - softplus(-2x))
+//   SacAgent._actions_and_log_probs               tf_agents/agents/sac/sac_agent.py:533-558
+//   SacAgent.critic_loss / actor_loss / alpha_loss  :559-740
+//   common.aggregate_losses                       tf_agents/utils/common.py:1400-1476
+// The pre-tanh sample x of a drawn action is kept (TFP's bijector cache does the same when
+// log_prob is asked for a tensor the distribution just sampled), so log pi is evaluated at x, not at
+// atanh(action).
+#include "common.h"
+#include "agents_amd.h"
+#include <math.h>
+
+#define AA_HALF_LOG_2PI_SAC 0.91893853320467274178f
+#define AA_LOG2_SAC 0.69314718055994530942f
+
+__device__ static inline float aa_softplus_f(float t) {
+  return fmaxf(t, 0.f) + log1pf(expf(-fabsf(t)));
+}
+
+// One thread per sample.  z = [mean | raw_std] (the projection Dense output, [B, 2A]).
+// eps_in (nullable): externally supplied N(0,1) noise [B, A]; else Box-Muller on
+// Philox(counter = (b*A+d, call), key = seed) like aa_normal_sample.
+__global__ void __launch_bounds__(256)
+aa_sac_sample_kernel(const float* __restrict__ z, int64_t B, int A,
+                     const float* __restrict__ act_mean, const float* __restrict__ act_mag,
+                     int std_kind, const float* __restrict__ eps_in, uint32_t seed_lo,
+                     uint32_t seed_hi, const int64_t* __restrict__ call_counter,
+                     float* __restrict__ action, float* __restrict__ logp,
+                     float* __restrict__ save_tanh, float* __restrict__ save_sigma,
+                     float* __restrict__ save_eps) {
+  const uint64_t call = call_counter != nullptr ? (uint64_t)call_counter[0] : 0ull;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride) {
+    float lp = 0.f;
+    for (int d = 0; d < A; ++d) {
+      const float mu = z[b * 2 * A + d];
+      float raw = z[b * 2 * A + A + d];
+      if (std_kind == AA_SAC_STD_CLIP_EXP) raw = fminf(fmaxf(raw, -20.f), 2.f);
+      const float sigma = expf(raw);
+      float eps;
+      if (eps_in != nullptr) {
+        eps = eps_in[b * A + d];
+      } else {
+        const uint64_t i = (uint64_t)(b * A + d);
+        const Philox4 r = philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)call,
+                                        (uint32_t)(call >> 32), seed_lo, seed_hi);
+        const float u1 = 1.0f - aa_u01(r.x);
+        const float u2 = aa_u01(r.y);
+        eps = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+      }
+      const float x = mu + sigma * eps;
+      const float t = tanhf(x);
+      const float mag = act_mag[d];
+      action[b * A + d] = act_mean[d] + mag * t;
+      const float e = (x - mu) / sigma;   // what MultivariateNormalDiag.log_prob recomputes
+      const float fldj = 2.0f * (AA_LOG2_SAC - x - aa_softplus_f(-2.0f * x));
+      lp += -0.5f * (e * e) - logf(sigma) - AA_HALF_LOG_2PI_SAC - logf(fabsf(mag)) - fldj;
+      if (save_tanh != nullptr) {
+        save_tanh[b * A + d] = t;
+        save_sigma[b * A + d] = sigma;
+        save_eps[b * A + d] = eps;
+      }
+    }
+    logp[b] = lp;
+  }
+}
+
+// dz[B,2A] from dL/daction [B,A] and dL/dlog_pi [B] (reparameterised sample x = mu + sigma eps):
+//   g_x = da * mag * (1 - t^2) + dlogp * 2t ;  dmu = g_x ;  dsigma = g_x * eps - dlogp / sigma
+//   draw = dsigma * sigma   (exp; zero outside [-20, 2] with the clip transform)
+__global__ void __launch_bounds__(256)
+aa_sac_head_bwd_kernel(const float* __restrict__ z, int64_t B, int A,
+                       const float* __restrict__ act_mag, int std_kind,
+                       const float* __restrict__ save_tanh, const float* __restrict__ save_sigma,
+                       const float* __restrict__ save_eps, const float* __restrict__ daction,
+                       const float* __restrict__ dlogp, float* __restrict__ dz) {
+  const int64_t total = B * A, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t b = i / A;
+    const int d = (int)(i - b * A);
+    const float t = save_tanh[i], sigma = save_sigma[i], eps = save_eps[i];
+    const float dl = dlogp[b];
+    const float da = daction != nullptr ? daction[i] : 0.f;
+    const float gx = da * (act_mag[d] * (1.0f - t * t)) + dl * (2.0f * t);
+    const float dsigma = gx * eps - dl / sigma;
+    const float raw = z[b * 2 * A + A + d];
+    float draw = dsigma * sigma;
+    if (std_kind == AA_SAC_STD_CLIP_EXP && (raw < -20.f || raw > 2.f)) draw = 0.f;
+    dz[b * 2 * A + d] = gx;
+    dz[b * 2 * A + A + d] = draw;
+  }
+}
+
+// critic loss (sac_agent.py:559-644), one workgroup, deterministic.
+__global__ void __launch_bounds__(256)
+aa_sac_critic_loss_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
+                          const float* __restrict__ tq1, const float* __restrict__ tq2,
+                          const float* __restrict__ next_logp, const float* __restrict__ reward,
+                          const float* __restrict__ discount, const float* __restrict__ weights,
+                          const float* __restrict__ log_alpha, float gamma, float reward_scale,
+                          int loss_kind, float loss_weight, int64_t B, float global_batch,
+                          float* __restrict__ loss_out, float* __restrict__ td_target_out,
+                          float* __restrict__ dq1, float* __restrict__ dq2) {
+  __shared__ float red[16];
+  const float alpha = expf(log_alpha[0]);
+  float local = 0.f;
+  for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+    const float tq = fminf(tq1[b], tq2[b]) - alpha * next_logp[b];
+    const float td = reward_scale * reward[b] + (gamma * discount[b]) * tq;
+    float l = 0.f, g1, g2;
+    if (loss_kind == AA_LOSS_SQUARED) {   // tf.math.squared_difference(td_targets, pred)
+      const float e1 = td - q1[b], e2 = td - q2[b];
+      l = e1 * e1 + e2 * e2;
+      g1 = -2.0f * e1;
+      g2 = -2.0f * e2;
+    } else {                              // element_wise_huber_loss
+      const float e1 = q1[b] - td, e2 = q2[b] - td;
+      const float a1 = fabsf(e1), a2 = fabsf(e2);
+      const float c1 = fminf(a1, 1.f), c2 = fminf(a2, 1.f);
+      l = (0.5f * c1 * c1 + (a1 - c1)) + (0.5f * c2 * c2 + (a2 - c2));
+      g1 = e1 > 1.f ? 1.f : (e1 < -1.f ? -1.f : e1);
+      g2 = e2 > 1.f ? 1.f : (e2 < -1.f ? -1.f : e2);
+    }
+    float w = 1.f;
+    float wl = l;
+    if (weights != nullptr) {
+      w = weights[b];
+      wl = (w == 0.f) ? 0.f : l * w;
+    }
+    local += wl;
+    if (td_target_out != nullptr) td_target_out[b] = td;
+    if (dq1 != nullptr) {
+      dq1[b] = (loss_weight * g1 * w) / global_batch;
+      dq2[b] = (loss_weight * g2 * w) / global_batch;
+    }
+  }
+  const float total = aa_block_sum(local, red);
+  if (threadIdx.x == 0) loss_out[0] = loss_weight * (total / global_batch);
+}
+
+// actor loss (sac_agent.py:646-694): mean_b w (alpha log_pi - min(q1, q2)).
+__global__ void __launch_bounds__(256)
+aa_sac_actor_loss_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
+                         const float* __restrict__ logp, const float* __restrict__ weights,
+                         const float* __restrict__ log_alpha, float loss_weight, int64_t B,
+                         float global_batch, float* __restrict__ loss_out,
+                         float* __restrict__ dq1, float* __restrict__ dq2,
+                         float* __restrict__ dlogp) {
+  __shared__ float red[16];
+  const float alpha = expf(log_alpha[0]);
+  float local = 0.f;
+  for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+    const float a = q1[b], c = q2[b];
+    const float l = alpha * logp[b] - fminf(a, c);
+    float w = 1.f, wl = l;
+    if (weights != nullptr) {
+      w = weights[b];
+      wl = (w == 0.f) ? 0.f : l * w;
+    }
+    local += wl;
+    if (dq1 != nullptr) {
+      const float g = (loss_weight * w) / global_batch;
+      // tf.minimum: the gradient goes to x where x <= y, else to y
+      dq1[b] = a <= c ? -g : 0.f;
+      dq2[b] = a <= c ? 0.f : -g;
+      dlogp[b] = alpha * g;
+    }
+  }
+  const float total = aa_block_sum(local, red);
+  if (threadIdx.x == 0) loss_out[0] = loss_weight * (total / global_batch);
+}
+
+// alpha loss (sac_agent.py:696-740): mean_b w * c(log_alpha) * stop_gradient(-log_pi - H),
+// c = log_alpha or exp(log_alpha).  grad_out[0] = d loss / d log_alpha.
+__global__ void __launch_bounds__(256)
+aa_sac_alpha_loss_kernel(const float* __restrict__ logp, const float* __restrict__ weights,
+                         const float* __restrict__ log_alpha, float target_entropy,
+                         int use_log_alpha, float loss_weight, int64_t B, float global_batch,
+                         float* __restrict__ loss_out, float* __restrict__ grad_out) {
+  __shared__ float red[16];
+  const float la = log_alpha[0];
+  const float coef = use_log_alpha ? la : expf(la);
+  float local = 0.f, gsum = 0.f;
+  for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+    const float diff = -logp[b] - target_entropy;
+    const float l = coef * diff;
+    float w = 1.f, wl = l, wd = diff;
+    if (weights != nullptr) {
+      w = weights[b];
+      wl = (w == 0.f) ? 0.f : l * w;
+      wd = (w == 0.f) ? 0.f : diff * w;
+    }
+    local += wl;
+    gsum += wd;
+  }
+  const float total = aa_block_sum(local, red);
+  __syncthreads();
+  const float gtot = aa_block_sum(gsum, red);
+  if (threadIdx.x == 0) {
+    loss_out[0] = loss_weight * (total / global_batch);
+    if (grad_out != nullptr)
+      grad_out[0] = loss_weight * ((use_log_alpha ? 1.0f : expf(la)) * gtot / global_batch);
+  }
+}
+
+extern "C" {
+
+int aa_sac_sample(const float* z, int64_t B, int32_t A, const float* act_mean,
+                  const float* act_mag, int32_t std_kind, const float* eps_in, uint64_t seed,
+                  const int64_t* call_counter_dev, float* action, float* logp, float* save_tanh,
+                  float* save_sigma, float* save_eps, void* stream) {
+  if (!z || !act_mean || !act_mag || !action || !logp || B <= 0 || A <= 0) return AA_ERR_INVALID;
+  if (std_kind != AA_SAC_STD_EXP && std_kind != AA_SAC_STD_CLIP_EXP) return AA_ERR_INVALID;
+  if ((save_tanh == nullptr) != (save_sigma == nullptr) ||
+      (save_tanh == nullptr) != (save_eps == nullptr))
+    return AA_ERR_INVALID;
+  int64_t blocks = (B + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(aa_sac_sample_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, z, B, A, act_mean, act_mag, std_kind, eps_in,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), call_counter_dev, action, logp,
+                     save_tanh, save_sigma, save_eps);
+  return aa_launch_status();
+}
+
+int aa_sac_head_backward(const float* z, int64_t B, int32_t A, const float* act_mag,
+                         int32_t std_kind, const float* save_tanh, const float* save_sigma,
+                         const float* save_eps, const float* daction, const float* dlogp,
+                         float* dz, void* stream) {
+  if (!z || !act_mag || !save_tanh || !save_sigma || !save_eps || !dlogp || !dz || B <= 0 ||
+      A <= 0)
+    return AA_ERR_INVALID;
+  int64_t blocks = (B * A + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(aa_sac_head_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, z, B, A, act_mag, std_kind, save_tanh, save_sigma,
+                     save_eps, daction, dlogp, dz);
+  return aa_launch_status();
+}
+
+int aa_sac_critic_loss(const float* q1, const float* q2, const float* tq1, const float* tq2,
+                       const float* next_logp, const float* reward, const float* discount,
+                       const float* weights, const float* log_alpha_dev, float gamma,
+                       float reward_scale, int32_t loss_kind, float loss_weight, int64_t B,
+                       float global_batch, float* loss_out, float* td_target_out, float* dq1,
+                       float* dq2, void* stream) {
+  if (!q1 || !q2 || !tq1 || !tq2 || !next_logp || !reward || !discount || !log_alpha_dev ||
+      !loss_out || B <= 0 || !(global_batch > 0.f))
+    return AA_ERR_INVALID;
+  if ((dq1 == nullptr) != (dq2 == nullptr)) return AA_ERR_INVALID;
+  if (loss_kind != AA_LOSS_HUBER && loss_kind != AA_LOSS_SQUARED) return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_sac_critic_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, q1, q2,
+                     tq1, tq2, next_logp, reward, discount, weights, log_alpha_dev, gamma,
+                     reward_scale, loss_kind, loss_weight, B, global_batch, loss_out,
+                     td_target_out, dq1, dq2);
+  return aa_launch_status();
+}
+
+int aa_sac_actor_loss(const float* q1, const float* q2, const float* logp, const float* weights,
+                      const float* log_alpha_dev, float loss_weight, int64_t B,
+                      float global_batch, float* loss_out, float* dq1, float* dq2, float* dlogp,
+                      void* stream) {
+  if (!q1 || !q2 || !logp || !log_alpha_dev || !loss_out || B <= 0 || !(global_batch > 0.f))
+    return AA_ERR_INVALID;
+  if ((dq1 == nullptr) != (dq2 == nullptr) || (dq1 == nullptr) != (dlogp == nullptr))
+    return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_sac_actor_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, q1, q2,
+                     logp, weights, log_alpha_dev, loss_weight, B, global_batch, loss_out, dq1, dq2,
+                     dlogp);
+  return aa_launch_status();
+}
+
+int aa_sac_alpha_loss(const float* logp, const float* weights, const float* log_alpha_dev,
+                      float target_entropy, int32_t use_log_alpha, float loss_weight, int64_t B,
+                      float global_batch, float* loss_out, float* grad_out, void* stream) {
+  if (!logp || !log_alpha_dev || !loss_out || B <= 0 || !(global_batch > 0.f))
+    return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_sac_alpha_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logp,
+                     weights, log_alpha_dev, target_entropy, use_log_alpha, loss_weight, B,
+                     global_batch, loss_out, grad_out);
+  return aa_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,120 @@
+"""ActorDistributionNetwork with a tanh-squashed Normal projection, as SAC uses it.
+
+Counterparts: tf_agents/networks/actor_distribution_network.py:50-190 (MLP encoder + projection
+network) and tf_agents/agents/sac/tanh_normal_projection_network.py:38-143 (one Dense emitting
+2*A numbers split into means and raw standard deviations; std = std_transform(raw)).
+No distribution object is materialised: `forward` returns the projection output z = [mean | raw]
+and the agent's kernels (csrc/sac.hip) sample / evaluate / differentiate the squashed Normal.
+"""
+import numpy as np
+import torch
+
+from agents_amd import _lib
+from agents_amd.networks import layers as L
+from agents_amd.networks import network, sequential
+from agents_amd.utils import nest_utils
+
+
+def std_clip_transform(stddevs=None):
+    """sac_agent.std_clip_transform marker: exp(clip(raw, -20, 2)) (sac_agent.py:48-57)."""
+    return "clip_exp"
+
+
+class TanhNormalProjectionNetwork:
+    """Configuration of the projection: `std_transform` is "exp" (the reference default tf.exp) or
+    "clip_exp" (`std_clip_transform`)."""
+
+    def __init__(self, sample_spec=None, activation_fn=None, std_transform="exp",
+                 name="TanhNormalProjectionNetwork"):
+        if callable(std_transform):
+            std_transform = std_transform()
+        if std_transform not in ("exp", "clip_exp"):
+            raise NotImplementedError("std_transform must be 'exp' or 'clip_exp'")
+        if activation_fn is not None:
+            raise NotImplementedError("projection activation_fn is not supported")
+        self.sample_spec = sample_spec
+        self.std_transform = std_transform
+
+    @property
+    def std_kind(self):
+        return _lib.AA_SAC_STD_EXP if self.std_transform == "exp" else _lib.AA_SAC_STD_CLIP_EXP
+
+
+class ActorDistributionNetwork(network.Network):
+    def __init__(self, input_tensor_spec, output_tensor_spec, preprocessing_layers=None,
+                 preprocessing_combiner=None, conv_layer_params=None, fc_layer_params=(200, 100),
+                 dropout_layer_params=None, activation_fn="relu", kernel_initializer=None,
+                 seed_stream_class=None, seed=None, batch_squash=True, dtype=torch.float32,
+                 discrete_projection_net=None,
+                 continuous_projection_net=TanhNormalProjectionNetwork,
+                 name="ActorDistributionNetwork"):
+        super().__init__(input_tensor_spec=input_tensor_spec, state_spec=(), name=name)
+        if preprocessing_layers or preprocessing_combiner or conv_layer_params or \
+                dropout_layer_params:
+            raise NotImplementedError("only fc_layer_params encoders are implemented")
+        flat = nest_utils.flatten(output_tensor_spec)
+        if len(flat) != 1 or flat[0].dtype != torch.float32:
+            raise NotImplementedError("a single continuous (float32) action spec is supported")
+        self._action_spec = flat[0]
+        self._A = int(np.prod(flat[0].shape)) or 1
+        proj = continuous_projection_net
+        if isinstance(proj, type):
+            proj = proj(flat[0])
+        elif callable(proj) and not isinstance(proj, TanhNormalProjectionNetwork):
+            proj = proj(flat[0])
+        if not isinstance(proj, TanhNormalProjectionNetwork):
+            raise NotImplementedError("continuous_projection_net must build a "
+                                      "TanhNormalProjectionNetwork")
+        self._projection = proj
+        ki = kernel_initializer or L.GlorotUniform()
+        layers = [L.Dense(int(n), activation_fn, kernel_initializer=ki)
+                  for n in (fc_layer_params or ())]
+        layers.append(L.Dense(2 * self._A, None, kernel_initializer=L.GlorotUniform()))
+        self._body = sequential.Sequential(layers, input_spec=input_tensor_spec, seed=seed)
+
+    @property
+    def body(self):
+        return self._body
+
+    @property
+    def projection(self):
+        return self._projection
+
+    @property
+    def action_dims(self):
+        return self._A
+
+    def create_variables(self, input_tensor_spec=None, device=None, **kwargs):
+        self._body.create_variables(input_tensor_spec, device=device)
+        self._built = True
+        return {"loc": (self._A,), "scale_diag": (self._A,)}
+
+    @property
+    def flat_params(self):
+        return self._body.flat_params
+
+    @property
+    def flat_grads(self):
+        return self._body.flat_grads
+
+    @property
+    def variables(self):
+        return self._body.variables
+
+    def set_weights(self, arrays):
+        self._body.set_weights(arrays)
+
+    def get_weights(self):
+        return self._body.get_weights()
+
+    def forward(self, observation, slot=0, need_grad=False):
+        """z[B, 2A] = [mean | raw_std] (buffer owned by the network)."""
+        B = observation.shape[0]
+        return self._body.forward(observation.reshape((B,) + tuple(
+            self._body._input_tensor_spec.shape)), slot=slot, need_grad=need_grad)
+
+    def backward(self, dz, slot=0, side_stream=None):
+        self._body.backward(dz, slot=slot, side_stream=side_stream)
+
+    def call(self, inputs, step_type=None, network_state=(), training=False, **kwargs):
+        return self.forward(inputs, slot="call").clone(), network_state

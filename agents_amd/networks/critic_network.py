@@ -1,0 +1,136 @@
+"""CriticNetwork: Q(observation, action) -> scalar, for SAC / DDPG-style agents.
+
+Counterpart of tf_agents/agents/ddpg/critic_network.py:30-190 (the class the SAC example
+instantiates, examples/sac/haarnoja18/sac_train_eval.py:182-190): observation and action are
+concatenated and passed through `joint_fc_layer_params` Dense(relu) layers and a final Dense(1).
+The optional per-input pre-layers (`observation_fc_layer_params`, `action_fc_layer_params`,
+conv layers) are not implemented -- the SAC configuration leaves them at None.
+
+The body is a `networks.sequential.Sequential` on the concatenated input (fp32 MFMA GEMMs, the
+small-N kernels for the 1-unit head).  `backward` can return d Q / d action: SAC's actor loss
+differentiates through the critics.
+"""
+import numpy as np
+import torch
+
+from agents_amd.networks import layers as L
+from agents_amd.networks import network, sequential
+from agents_amd.specs import tensor_spec
+from agents_amd.utils import nest_utils
+
+
+class CriticNetwork(network.Network):
+    def __init__(self, input_tensor_spec, observation_conv_layer_params=None,
+                 observation_fc_layer_params=None, observation_dropout_layer_params=None,
+                 action_fc_layer_params=None, action_dropout_layer_params=None,
+                 joint_fc_layer_params=None, joint_dropout_layer_params=None,
+                 activation_fn="relu", output_activation_fn=None, kernel_initializer=None,
+                 last_kernel_initializer=None, last_layer=None, name="CriticNetwork", seed=None):
+        super().__init__(input_tensor_spec=input_tensor_spec, state_spec=(), name=name)
+        if any(p for p in (observation_conv_layer_params, observation_fc_layer_params,
+                           observation_dropout_layer_params, action_fc_layer_params,
+                           action_dropout_layer_params, joint_dropout_layer_params)):
+            raise NotImplementedError("only joint_fc_layer_params are implemented")
+        if last_layer is not None:
+            raise NotImplementedError("last_layer is not supported")
+        obs_spec, act_spec = input_tensor_spec
+        if len(nest_utils.flatten(act_spec)) > 1:
+            raise ValueError("Only a single action is supported by this network")
+        if len(nest_utils.flatten(obs_spec)) > 1:
+            raise ValueError("Only a single observation is supported by this network.")
+        self._obs_dim = int(np.prod(nest_utils.flatten(obs_spec)[0].shape))
+        self._act_dim = int(np.prod(nest_utils.flatten(act_spec)[0].shape)) or 1
+        self._ctor = dict(input_tensor_spec=input_tensor_spec,
+                          joint_fc_layer_params=joint_fc_layer_params,
+                          activation_fn=activation_fn, output_activation_fn=output_activation_fn,
+                          kernel_initializer=kernel_initializer,
+                          last_kernel_initializer=last_kernel_initializer, name=name)
+        # reference defaults: VarianceScaling(1/3, fan_in, uniform); last layer U(-0.003, 0.003)
+        ki = kernel_initializer or L.VarianceScaling(1.0 / 3.0, "fan_in", "uniform")
+        lki = last_kernel_initializer or L.RandomUniform(-0.003, 0.003)
+        layers = [L.Dense(int(n), activation_fn, kernel_initializer=ki)
+                  for n in (joint_fc_layer_params or ())]
+        layers.append(L.Dense(1, output_activation_fn, kernel_initializer=lki))
+        self._seed = seed
+        self._body = sequential.Sequential(
+            layers, input_spec=tensor_spec.TensorSpec((self._obs_dim + self._act_dim,),
+                                                      torch.float32), seed=seed)
+        self._inputs = {}
+
+    # ---- parameters -------------------------------------------------------------------------
+    @property
+    def body(self):
+        return self._body
+
+    def create_variables(self, input_tensor_spec=None, device=None, **kwargs):
+        self._body.create_variables(device=device)
+        self._built = True
+        return ()
+
+    @property
+    def flat_params(self):
+        return self._body.flat_params
+
+    @property
+    def flat_grads(self):
+        return self._body.flat_grads
+
+    @property
+    def flat_size(self):
+        return self._body.flat_size
+
+    def rebind(self, flat_params, flat_grads):
+        self._body.rebind(flat_params, flat_grads)
+
+    @property
+    def variables(self):
+        return self._body.variables
+
+    @property
+    def has_regularization(self):
+        return self._body.has_regularization
+
+    def copy(self, **kwargs):
+        args = dict(self._ctor)
+        args.update(kwargs)
+        seed = args.pop("seed", None if self._seed is None else self._seed + 1)
+        return CriticNetwork(seed=seed, **args)
+
+    def set_weights(self, arrays):
+        self._body.set_weights(arrays)
+
+    def get_weights(self):
+        return self._body.get_weights()
+
+    # ---- execution ----------------------------------------------------------------------------
+    def _input(self, slot, B, dev):
+        key = (slot, B)
+        buf = self._inputs.get(key)
+        if buf is None:
+            buf = {"x": torch.empty((B, self._obs_dim + self._act_dim), dtype=torch.float32,
+                                    device=dev),
+                   "dx": torch.empty((B, self._obs_dim + self._act_dim), dtype=torch.float32,
+                                     device=dev)}
+            self._inputs[key] = buf
+        return buf
+
+    def forward(self, observation, action, slot=0, need_grad=False):
+        """q[B] for observation [B, *obs] and action [B, *act] (buffer owned by the network)."""
+        B = observation.shape[0]
+        buf = self._input(slot, B, observation.device)
+        buf["x"][:, :self._obs_dim].copy_(observation.reshape(B, -1))
+        buf["x"][:, self._obs_dim:].copy_(action.reshape(B, -1))
+        return self._body.forward(buf["x"], slot=slot, need_grad=need_grad).view(B)
+
+    def backward(self, dq, slot=0, param_grads=True, want_action_grad=False, side_stream=None):
+        """Backpropagates d loss / d q [B]; returns d loss / d action [B, act] if asked."""
+        B = dq.shape[0]
+        buf = self._inputs[(slot, B)]
+        self._body.backward(dq.view(B, 1), slot=slot, side_stream=side_stream,
+                            param_grads=param_grads,
+                            input_grad=buf["dx"] if want_action_grad else None)
+        return buf["dx"][:, self._obs_dim:] if want_action_grad else None
+
+    def call(self, inputs, step_type=None, network_state=(), training=False, **kwargs):
+        obs, act = inputs
+        return self.forward(obs, act, slot="call").clone(), network_state

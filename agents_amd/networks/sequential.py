@@ -318,8 +318,13 @@ class Sequential(network.Network):
                 pi += 1
         return cur
 
-    def backward(self, dout, slot=0, side_stream=None):
+    def backward(self, dout, slot=0, side_stream=None, param_grads=True, input_grad=None):
         """Given d loss / d output [B, out], fills flat_grads (overwrites).
+
+        `param_grads=False` skips every weight/bias gradient (only the input-gradient chain runs:
+        SAC's actor loss differentiates THROUGH the critics without updating them);
+        `input_grad` ([B, in] float32 buffer, Dense first layer only) also receives
+        d loss / d network input.
 
         The input-gradient chain (dX_n -> dX_{n-1} -> ...) is the critical path; every
         weight/bias-gradient GEMM only needs its layer's dZ, so with `side_stream` they are
@@ -358,8 +363,11 @@ class Sequential(network.Network):
             prev_act = self._param_layers[i - 1].activation if i > 0 else None
             if isinstance(l, L.Dense):
                 dz2 = dz.view(B, -1)
-                on_side(lambda: ops.dense_dw(x, dz2, self._gkviews[i],
-                                             bias_grad=self._gbviews[i]))
+                if param_grads:
+                    on_side(lambda: ops.dense_dw(x, dz2, self._gkviews[i],
+                                                 bias_grad=self._gbviews[i]))
+                if i == 0 and input_grad is not None:
+                    ops.dense_dx(dz2, self._kviews[0], input_grad.view(B, -1))
                 if i > 0:
                     dx = s.dxs[i].view(B, -1)
                     ops.dense_dx(dz2, self._kviews[i], dx, mask_src=x if prev_act else None,
@@ -368,9 +376,12 @@ class Sequential(network.Network):
             else:
                 F = ks[3]
                 dz2 = dz.view(-1, F)
-                on_side(lambda: ops.conv_dw(x, dz2, ks, l.stride, self._gkviews[i],
-                                            a_div=self._first_div() if i == 0 else 1.0,
-                                            bias_grad=self._gbviews[i]))
+                if i == 0 and input_grad is not None:
+                    raise NotImplementedError("input_grad is implemented for a Dense first layer")
+                if param_grads:
+                    on_side(lambda: ops.conv_dw(x, dz2, ks, l.stride, self._gkviews[i],
+                                                a_div=self._first_div() if i == 0 else 1.0,
+                                                bias_grad=self._gbviews[i]))
                 if i > 0:
                     ops.conv_dx(dz2, self._kviews[i], tuple(x.shape), l.stride, s.dcol, s.dxs[i],
                                 mask_src=x if prev_act else None, mask_act=prev_act)

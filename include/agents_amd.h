@@ -310,6 +310,45 @@ int aa_ppo_update_kl_beta(const float* mean_kl_dev, float target, float toleranc
 /* g += c * p  (L2 regularisation gradient on a flat parameter range). */
 int aa_add_l2_grad(float* g, const float* p, int64_t n, float c, void* stream);
 
+/* =========================================================================================
+ * SAC  (agents/sac/sac_agent.py:314-410, 533-740; agents/sac/tanh_normal_projection_network.py;
+ *       distributions/utils.py:40-160 SquashToSpecNormal)
+ * ========================================================================================= */
+#define AA_SAC_STD_EXP 0        /* TanhNormalProjectionNetwork default std_transform = tf.exp */
+#define AA_SAC_STD_CLIP_EXP 1   /* sac_agent.std_clip_transform: exp(clip(raw, -20, 2))       */
+/* Actor head: z = [mean | raw_std] ([B,2A], the projection Dense output) -> reparameterised
+ * tanh-squashed sample action = act_mean + act_mag * tanh(mean + sigma*eps) and its log-probability
+ * (Normal log-density at the pre-tanh sample minus log|mag| and the stable tanh log-det-Jacobian).
+ * eps_in nullable: N(0,1) noise supplied by the caller; else drawn from Philox(seed, *counter).
+ * save_* (all or none, [B,A]) keep tanh(x), sigma, eps for aa_sac_head_backward. */
+int aa_sac_sample(const float* z, int64_t B, int32_t A, const float* act_mean,
+                  const float* act_mag, int32_t std_kind, const float* eps_in, uint64_t seed,
+                  const int64_t* call_counter_dev, float* action, float* logp, float* save_tanh,
+                  float* save_sigma, float* save_eps, void* stream);
+/* dz[B,2A] = d loss / d head output from d loss / d action (nullable) and d loss / d log_pi. */
+int aa_sac_head_backward(const float* z, int64_t B, int32_t A, const float* act_mag,
+                         int32_t std_kind, const float* save_tanh, const float* save_sigma,
+                         const float* save_eps, const float* daction, const float* dlogp,
+                         float* dz, void* stream);
+/* critic_loss: td = scale*r + gamma*d*(min(tq1,tq2) - exp(log_alpha)*next_logp);
+ * loss = weight * sum_b w_b (f(td,q1)+f(td,q2)) / global_batch; dq1/dq2 nullable (both or none). */
+int aa_sac_critic_loss(const float* q1, const float* q2, const float* tq1, const float* tq2,
+                       const float* next_logp, const float* reward, const float* discount,
+                       const float* weights, const float* log_alpha_dev, float gamma,
+                       float reward_scale, int32_t loss_kind, float loss_weight, int64_t B,
+                       float global_batch, float* loss_out, float* td_target_out, float* dq1,
+                       float* dq2, void* stream);
+/* actor_loss: weight * sum_b w_b (exp(log_alpha) logp - min(q1,q2)) / global_batch. */
+int aa_sac_actor_loss(const float* q1, const float* q2, const float* logp, const float* weights,
+                      const float* log_alpha_dev, float loss_weight, int64_t B,
+                      float global_batch, float* loss_out, float* dq1, float* dq2, float* dlogp,
+                      void* stream);
+/* alpha_loss: weight * sum_b w_b c(log_alpha) (-logp - target_entropy) / global_batch,
+ * c = log_alpha (use_log_alpha) or exp(log_alpha); grad_out[0] = d loss / d log_alpha. */
+int aa_sac_alpha_loss(const float* logp, const float* weights, const float* log_alpha_dev,
+                      float target_entropy, int32_t use_log_alpha, float loss_weight, int64_t B,
+                      float global_batch, float* loss_out, float* grad_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

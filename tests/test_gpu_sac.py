@@ -1,0 +1,281 @@
+"""GPU: SAC kernels and SacAgent against the torch-CPU oracle (oracle/sac.py, itself pinned on the
+reference's known answers in tests/test_oracle_sac.py) and directly against the reference's numbers
+(tf_agents/agents/sac/sac_agent_test.py:269-396).  Tolerances: 1e-5 relative on losses (north
+star), 2e-5 on gradients / updated parameters (fp32 summation order of the MFMA GEMMs)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from agents_amd import _lib, optimizers
+from agents_amd.agents.sac import sac_agent
+from agents_amd.drivers import dynamic_step_driver
+from agents_amd.environments import random_tf_environment
+from agents_amd.networks import actor_distribution_network as adn
+from agents_amd.networks import critic_network
+from agents_amd.networks import layers as L
+from agents_amd.replay_buffers import tf_uniform_replay_buffer as rb_lib
+from agents_amd.specs import tensor_spec
+from agents_amd.trajectories import time_step as ts
+from agents_amd.trajectories import trajectory
+from agents_amd.utils import common
+from oracle import nets as onets
+from oracle import sac as osac
+
+pytestmark = pytest.mark.gpu
+
+
+def close(got, ref, rtol=1e-5, atol=1e-6):
+    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    ref = ref.detach().cpu().double().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
+    scale = max(np.abs(ref).max(), 1e-30)
+    err = np.abs(got - ref).max()
+    assert err <= rtol * scale + atol, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+def f32(dev, x):
+    return torch.as_tensor(np.asarray(x, np.float32)).to(dev)
+
+
+# ---- the reference's known answers, through the loss kernels --------------------------------------
+def test_critic_loss_kernel_reference_numbers(dev):
+    """testCriticLoss: q = obs[:,1] + a, next action 1, log_pi 10 -> td [7.3, 19.1], loss 2*MSE."""
+    lib = _lib.load()
+    q = f32(dev, [2 + 5, 4 + 6])
+    tq = f32(dev, [6 + 1, 8 + 1])
+    nlogp = f32(dev, [10, 10])
+    out, td = torch.zeros(1, device=dev), torch.zeros(2, device=dev)
+    dq1, dq2 = torch.zeros(2, device=dev), torch.zeros(2, device=dev)
+    la = torch.zeros(4, device=dev)
+    rew, disc = f32(dev, [10, 20]), f32(dev, [0.9, 0.9])   # (kept alive across the launch)
+    _lib.check(lib.aa_sac_critic_loss(q.data_ptr(), q.data_ptr(), tq.data_ptr(), tq.data_ptr(),
+                                      nlogp.data_ptr(), rew.data_ptr(),
+                                      disc.data_ptr(), None, la.data_ptr(), 1.0,
+                                      1.0, _lib.AA_LOSS_SQUARED, 1.0, 2, 2.0, out.data_ptr(),
+                                      td.data_ptr(), dq1.data_ptr(), dq2.data_ptr(),
+                                      _lib.stream_ptr()), "critic")
+    close(td, [7.3, 19.1])
+    close(out, [2 * np.mean((np.array([7.3, 19.1]) - np.array([7.0, 10.0])) ** 2)])
+    close(dq1, [-2 * (7.3 - 7.0) / 2, -2 * (19.1 - 10.0) / 2])
+
+
+def test_actor_and_alpha_loss_kernel_reference_numbers(dev):
+    lib = _lib.load()
+    logp = f32(dev, [10, 10])
+    q = f32(dev, [2 + 1, 4 + 1])
+    la = torch.zeros(4, device=dev)
+    out = torch.zeros(1, device=dev)
+    _lib.check(lib.aa_sac_actor_loss(q.data_ptr(), q.data_ptr(), logp.data_ptr(), None,
+                                     la.data_ptr(), 1.0, 2, 2.0, out.data_ptr(), None, None, None,
+                                     _lib.stream_ptr()), "actor")
+    close(out, [(2 * 10 - (2 + 1) - (4 + 1)) / 2])            # testActorLoss: 6.0
+    la[0] = 4.0
+    g = torch.zeros(4, device=dev)
+    _lib.check(lib.aa_sac_alpha_loss(logp.data_ptr(), None, la.data_ptr(), 3.0, 1, 1.0, 2, 2.0,
+                                     out.data_ptr(), g.data_ptr(), _lib.stream_ptr()), "alpha")
+    close(out, [4.0 * (-10 - 3)])                              # testAlphaLoss: -52
+    close(g[:1], [-13.0])
+
+
+# ---- actor head ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["exp", "clip_exp"])
+@pytest.mark.parametrize("B,A", [(1, 1), (37, 3), (1024, 17)])
+def test_sample_and_head_backward_vs_autograd(dev, kind, B, A):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B + A)
+    z = torch.randn(B, 2 * A, generator=g)
+    z[:, A:] *= 1.5
+    if kind == "clip_exp" and B > 1:
+        z[0, A] = 3.0         # outside the clip range: zero gradient to the raw std
+        z[1, A] = -25.0
+    eps = torch.randn(B, A, generator=g)
+    mean = torch.linspace(-0.5, 0.5, A)
+    mag = torch.linspace(0.5, 2.0, A)
+    zr = z.clone().requires_grad_(True)
+    act_o, logp_o = osac.tanh_normal(zr, eps, mean, mag, kind)
+    da = torch.randn(B, A, generator=g)
+    dl = torch.randn(B, generator=g)
+    ((act_o * da).sum() + (logp_o * dl).sum()).backward()
+    zd, epsd, meand, magd, dad, dld = (t.to(dev) for t in (z, eps, mean, mag, da, dl))
+    action = torch.empty(B, A, device=dev)
+    logp = torch.empty(B, device=dev)
+    sv = [torch.empty(B, A, device=dev) for _ in range(3)]
+    k = _lib.AA_SAC_STD_EXP if kind == "exp" else _lib.AA_SAC_STD_CLIP_EXP
+    _lib.check(lib.aa_sac_sample(zd.data_ptr(), B, A, meand.data_ptr(),
+                                 magd.data_ptr(), k, epsd.data_ptr(), 0, None,
+                                 action.data_ptr(), logp.data_ptr(), sv[0].data_ptr(),
+                                 sv[1].data_ptr(), sv[2].data_ptr(), _lib.stream_ptr()), "sample")
+    close(action, act_o, rtol=2e-6)
+    close(logp, logp_o, rtol=1e-5, atol=1e-5)
+    dz = torch.empty(B, 2 * A, device=dev)
+    _lib.check(lib.aa_sac_head_backward(zd.data_ptr(), B, A, magd.data_ptr(), k,
+                                        sv[0].data_ptr(), sv[1].data_ptr(), sv[2].data_ptr(),
+                                        dad.data_ptr(), dld.data_ptr(),
+                                        dz.data_ptr(), _lib.stream_ptr()), "head bwd")
+    close(dz, zr.grad, rtol=2e-5, atol=1e-5)
+
+
+def test_sample_internal_noise_is_standard_normal_and_advances(dev):
+    lib = _lib.load()
+    B, A = 20000, 4
+    z = torch.zeros(B, 2 * A, device=dev)          # mean 0, sigma 1
+    mean, mag = torch.zeros(A, device=dev), torch.ones(A, device=dev)
+    ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+    outs = []
+    for call in range(2):
+        a = torch.empty(B, A, device=dev)
+        lp = torch.empty(B, device=dev)
+        sv = [torch.empty(B, A, device=dev) for _ in range(3)]
+        _lib.check(lib.aa_sac_sample(z.data_ptr(), B, A, mean.data_ptr(), mag.data_ptr(), 0, None,
+                                     1234, ctr.data_ptr(), a.data_ptr(), lp.data_ptr(),
+                                     sv[0].data_ptr(), sv[1].data_ptr(), sv[2].data_ptr(),
+                                     _lib.stream_ptr()), "sample")
+        ctr += 1
+        outs.append(sv[2].cpu())
+        assert float(a.abs().max()) < 1.0           # tanh-squashed into the spec
+    e = outs[0].double()
+    assert abs(float(e.mean())) < 0.02 and abs(float(e.std()) - 1.0) < 0.02
+    assert not torch.equal(outs[0], outs[1])        # the call counter moves the stream
+
+
+# ---- agent vs oracle -------------------------------------------------------------------------------
+OBS_DIM, A = 11, 3
+OBS = tensor_spec.BoundedTensorSpec((OBS_DIM,), torch.float32, -1.0, 1.0)
+ACT = tensor_spec.BoundedTensorSpec((A,), torch.float32, [-1.0, -2.0, 0.0], [1.0, 2.0, 4.0])
+TSS = ts.time_step_spec(OBS)
+
+
+def make_pair(dev, actor_fc=(32, 32), critic_fc=(32, 32), kind="clip_exp", clip=None, **kw):
+    actor = adn.ActorDistributionNetwork(
+        OBS, ACT, fc_layer_params=actor_fc,
+        continuous_projection_net=lambda spec: adn.TanhNormalProjectionNetwork(
+            spec, std_transform=kind), seed=1)
+    critic = critic_network.CriticNetwork((OBS, ACT), joint_fc_layer_params=critic_fc,
+                                          kernel_initializer=L.GlorotUniform(),
+                                          last_kernel_initializer=L.GlorotUniform(), seed=2)
+    agent = sac_agent.SacAgent(
+        TSS, ACT, critic_network=critic, actor_network=actor,
+        actor_optimizer=optimizers.Adam(3e-3), critic_optimizer=optimizers.Adam(3e-3),
+        alpha_optimizer=optimizers.Adam(3e-3), target_update_tau=0.05, target_update_period=1,
+        td_errors_loss_fn=common.element_wise_squared_loss, gamma=0.99, reward_scale_factor=0.5,
+        gradient_clipping=clip, **kw)
+    agent.initialize()
+    ap = [torch.from_numpy(w.copy()) for w in actor.get_weights()]
+    c1 = [torch.from_numpy(w.copy()) for w in agent.critic_networks[0].get_weights()]
+    c2 = [torch.from_numpy(w.copy()) for w in agent.critic_networks[1].get_weights()]
+    mean, mag = sac_agent._spec_means_and_magnitudes(ACT)
+    oracle = osac.OracleSacAgent(
+        OBS_DIM, A, actor_fc, critic_fc, mean, mag, ap, c1, c2, actor_lr=3e-3, critic_lr=3e-3,
+        alpha_lr=3e-3, gamma=0.99, reward_scale_factor=0.5, tau=0.05, std_kind=kind,
+        initial_log_alpha=kw.get("initial_log_alpha", 0.0),
+        target_entropy=kw.get("target_entropy"),
+        critic_loss_weight=kw.get("critic_loss_weight", 0.5),
+        use_log_alpha_in_alpha_loss=kw.get("use_log_alpha_in_alpha_loss", True))
+    return agent, oracle
+
+
+def batch(dev, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    obs = torch.tanh(r(B, 2, OBS_DIM))
+    mean, mag = sac_agent._spec_means_and_magnitudes(ACT)
+    act = torch.from_numpy(mean) + torch.from_numpy(mag) * torch.tanh(r(B, 2, A))
+    reward = r(B, 2)
+    discount = (torch.rand(B, 2, generator=g) > 0.1).float()
+    exp = trajectory.Trajectory(
+        step_type=torch.ones(B, 2, dtype=torch.int32), observation=obs, action=act,
+        policy_info=(), next_step_type=torch.ones(B, 2, dtype=torch.int32), reward=reward,
+        discount=discount)
+    eps = {k: r(B, A) for k in ("next", "actor", "alpha")}
+    from agents_amd.utils import nest_utils
+    return (nest_utils.map_structure(lambda t: t.to(dev), exp), exp,
+            {k: v.to(dev) for k, v in eps.items()}, eps)
+
+
+@pytest.mark.parametrize("B", [8, 256])
+@pytest.mark.parametrize("cfg", [dict(), dict(initial_log_alpha=0.7, target_entropy=-1.0,
+                                              use_log_alpha_in_alpha_loss=False,
+                                              critic_loss_weight=1.0)])
+def test_train_steps_match_oracle(dev, B, cfg):
+    agent, oracle = make_pair(dev, **cfg)
+    for step in range(3):
+        exp_d, exp_h, eps_d, eps_h = batch(dev, B, 100 + step)
+        li = agent.train(exp_d, eps=eps_d)
+        out = oracle.train(exp_h.observation[:, 0], exp_h.action[:, 0], exp_h.observation[:, 1],
+                           exp_h.reward[:, 0], exp_h.discount[:, 0], eps_h["next"], eps_h["actor"],
+                           eps_h["alpha"])
+        close(li.extra.critic_loss, out["critic_loss"], rtol=1e-5)
+        close(li.extra.actor_loss, out["actor_loss"], rtol=1e-5, atol=1e-5)
+        close(li.extra.alpha_loss, out["alpha_loss"], rtol=1e-5, atol=1e-6)
+        close(li.loss, out["loss"], rtol=1e-5, atol=1e-5)
+        if step == 0:   # gradients of the first step (same weights on both sides)
+            got = agent.actor_network.body.gradients
+            for gd, go in zip(got, out["actor_grads"]):
+                close(gd, go, rtol=5e-5, atol=1e-6)
+            close(agent._log_alpha_grad[:1], [out["alpha_grad"]], rtol=1e-5)
+    for v, o in zip(agent.actor_network.variables, oracle.actor):
+        close(v, o, rtol=2e-4, atol=2e-5)
+    for net, o in zip(agent.critic_networks, (oracle.c1, oracle.c2)):
+        for v, ov in zip(net.variables, o):
+            close(v, ov, rtol=2e-4, atol=2e-5)
+    for net, o in zip(agent.target_critic_networks, (oracle.t1, oracle.t2)):
+        for v, ov in zip(net.variables, o):
+            close(v, ov, rtol=2e-4, atol=2e-5)
+    close(agent.log_alpha.reshape(1), [float(oracle.log_alpha)], rtol=1e-4, atol=1e-6)
+    assert int(agent.train_step_counter.numpy()) == 3
+
+
+def test_loss_values_and_weights(dev):
+    agent, oracle = make_pair(dev)
+    exp_d, exp_h, _, _ = batch(dev, 32, 7)
+    li = agent.loss(exp_d)
+    assert torch.isfinite(li.loss).item()
+    assert li.extra.critic_loss.shape == () and li.extra.alpha_loss.shape == ()
+    # zero weights switch every term off (aggregate_losses with sample_weight = 0)
+    li0 = agent.loss(exp_d, weights=torch.zeros(32, device=dev))
+    assert float(li0.loss) == 0.0
+
+
+def test_gradient_clipping_bounds_update(dev):
+    agent, _ = make_pair(dev, clip=1e-3)
+    exp_d, _, eps_d, _ = batch(dev, 64, 3)
+    agent.train(exp_d, eps=eps_d)
+    for net in agent.critic_networks + (agent.actor_network,):
+        for gvar in net.body.gradients:
+            assert float(gvar.norm()) <= 1e-3 * (1 + 1e-4)
+
+
+def test_collect_train_loop(dev):
+    """DynamicStepDriver + TFUniformReplayBuffer + SacAgent.train end to end (examples/sac/
+    haarnoja18/sac_train_eval.py structure), actions inside the spec bounds."""
+    agent, _ = make_pair(dev)
+    B = 16
+    env = random_tf_environment.RandomTFEnvironment(TSS, ACT, batch_size=B,
+                                                    episode_end_probability=0.05, seed=1,
+                                                    device=dev)
+    rb = rb_lib.TFUniformReplayBuffer(agent.collect_data_spec, batch_size=B, max_length=64,
+                                      device=dev)
+    drv = dynamic_step_driver.DynamicStepDriver(env, agent.collect_policy,
+                                                observers=[rb.add_batch], num_steps=B * 8)
+    drv.run()
+    data = rb.gather_all()
+    lo = torch.tensor([-1.0, -2.0, 0.0], device=dev)
+    hi = torch.tensor([1.0, 2.0, 4.0], device=dev)
+    assert bool(((data.action >= lo) & (data.action <= hi)).all())
+    it = iter(rb.as_dataset(sample_batch_size=32, num_steps=2))
+    before = agent.actor_network.flat_params.clone()
+    losses = []
+    for _ in range(5):
+        exp, _ = next(it)
+        losses.append(float(agent.train(exp).loss))
+    assert all(np.isfinite(losses)) and not torch.equal(before, agent.actor_network.flat_params)
+    assert int(agent.train_step_counter.numpy()) == 5
+
+
+def test_discrete_action_spec_is_rejected(dev):
+    disc = tensor_spec.BoundedTensorSpec((), torch.int64, 0, 3)
+    critic = critic_network.CriticNetwork((OBS, ACT), joint_fc_layer_params=(8,))
+    with pytest.raises(NotImplementedError, match="does not currently support discrete actions"):
+        sac_agent.SacAgent(TSS, disc, critic_network=critic, actor_network=None,
+                           actor_optimizer=None, critic_optimizer=None, alpha_optimizer=None)
