@@ -402,10 +402,6 @@ class SacAgent(tf_agent.TFAgent):
                                        sumsq.data_ptr(), float(self._gradient_clipping), 1, s),
                    "aa_clip_by_norm")
 
-    def _bump_train_step(self):
-        self._train_step_counter.assign_add(1)
-        self._update_target()
-
     def _train(self, experience, weights, eps=None):
         """`eps` (tests): dict of externally supplied N(0,1) noise {"next", "actor", "alpha"}."""
         eps = eps or {}
@@ -429,9 +425,23 @@ class SacAgent(tf_agent.TFAgent):
                                                         actor_loss=aloss.clone().reshape(()),
                                                         alpha_loss=lloss.clone().reshape(())))
             # counter + (periodic) soft target update: device work of the update is enqueued here
-            self._train_step_counter.assign_add(1)
+            graph.on_replay(self._bump_counter)
             self._update_target()
         return info
+
+    def _bump_counter(self):
+        self._train_step_counter.assign_add(1)
+
+    @property
+    def graph_train_whole_ok(self):
+        # the periodic target update is a host decision unless it happens every step
+        return self._target_update_period == 1 and self._gradient_clipping is None or \
+            (self._target_update_period == 1 and bool(self._clip_state))
+
+    def _graph_train_whole(self, experience, weights):
+        """The train step is device work plus host counters registered with graph.on_replay:
+        one HIP graph per input signature (utils/graph.py: GraphedTrain, whole mode)."""
+        return self._train(experience, weights)
 
     def _loss(self, experience, weights=None, training=False):
         obs, actions, next_obs, reward, discount = self._as_transition(experience)

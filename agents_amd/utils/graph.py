@@ -211,7 +211,8 @@ class GraphedTrain:
         agent = self._agent
         if not self.enabled or kwargs or getattr(agent, "check_numerics", False) or capturing():
             return agent.train(experience, weights=weights, **kwargs)
-        if self._whole and getattr(agent, "gradient_hook", None) is not None:
+        if self._whole and (getattr(agent, "gradient_hook", None) is not None or
+                            not getattr(agent, "graph_train_whole_ok", True)):
             return agent.train(experience, weights=weights)
         sig = _sig(experience, weights)
         if self._warm.get(sig, 0) < _WARMUP_CALLS:

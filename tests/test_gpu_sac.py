@@ -279,3 +279,36 @@ def test_discrete_action_spec_is_rejected(dev):
     with pytest.raises(NotImplementedError, match="does not currently support discrete actions"):
         sac_agent.SacAgent(TSS, disc, critic_network=critic, actor_network=None,
                            actor_optimizer=None, critic_optimizer=None, alpha_optimizer=None)
+
+
+def test_sac_train_graph_matches_eager(dev):
+    """SacAgent.train through the Learner (one HIP graph per sampler ring slot) == eager train:
+    same parameters, log_alpha, targets and counters after 30 steps on the same replay stream."""
+    from agents_amd.train import learner
+    from agents_amd.utils import graph
+    stacks = []
+    for _ in range(2):
+        agent, _ = make_pair(dev)
+        env = random_tf_environment.RandomTFEnvironment(TSS, ACT, batch_size=8,
+                                                        episode_end_probability=0.05, seed=1,
+                                                        device=dev)
+        rb = rb_lib.TFUniformReplayBuffer(agent.collect_data_spec, batch_size=8, max_length=64,
+                                          device=dev, seed=5)
+        dynamic_step_driver.DynamicStepDriver(env, agent.collect_policy, observers=[rb.add_batch],
+                                              num_steps=8 * 16).run()
+        stacks.append((agent, rb))
+    (ag_e, rb_e), (ag_g, rb_g) = stacks
+    lrn = learner.Learner(None, common.Variable(0), ag_g)
+    it_g = iter(rb_g.as_dataset(sample_batch_size=32, num_steps=2))
+    for i in range(30):
+        exp_e, _ = rb_e.get_next(32, 2)
+        li_e = ag_e.train(exp_e)
+        li_g = lrn.run(iterations=1, iterator=it_g)
+        assert float(li_e.loss) == float(li_g.loss), f"step {i}"
+    assert graph.graphed_train(ag_g).replays > 15
+    assert torch.equal(ag_e.actor_network.flat_params, ag_g.actor_network.flat_params)
+    assert torch.equal(ag_e._critic_params, ag_g._critic_params)
+    assert torch.equal(ag_e._target_params, ag_g._target_params)
+    assert torch.equal(ag_e._log_alpha_buf, ag_g._log_alpha_buf)
+    assert int(ag_e.train_step_counter.numpy()) == int(ag_g.train_step_counter.numpy()) == 30
+    assert ag_e._actor_optimizer.iterations == ag_g._actor_optimizer.iterations == 30

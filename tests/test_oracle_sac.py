@@ -103,3 +103,15 @@ def test_oracle_train_step_runs_and_updates():
     assert float(ag.log_alpha) != 0.0
     # soft update moved the targets by tau towards the critics
     assert not torch.equal(ag.t1[0], c1[0])
+
+
+def test_golden_file_lists_the_same_numbers():
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden",
+                                    "reference_known_answers.json")))["sac"]
+    td = np.array(g["critic_loss"]["td_targets"])
+    pred = np.array(g["critic_loss"]["pred_td_targets"])
+    np.testing.assert_allclose(2 * np.mean((td - pred) ** 2), g["critic_loss"]["loss_value"],
+                               rtol=1e-9)
+    assert g["actor_loss"]["loss_value"] == 6.0 and g["alpha_loss"]["loss_value"] == -52.0

@@ -1,0 +1,97 @@
+#!/usr/bin/env python
+"""BASELINE.json configs[4] at one GPU (a parity configuration; measured for the record): SAC on
+Humanoid-shaped synthetic data -- obs f32[376], action f32[17], 4,096 parallel envs, replay shard
+4096 x 64 frames, batch 256, actor (256,256) with tanh-Normal projection, twin critics (256,256),
+three Adam(3e-4), tau 0.005 every step (tf_agents/examples/sac/haarnoja18/sac_train_eval.py:182-199;
+SURVEY.md §8d config 5).  One iteration = 1 collect step (4,096 envs) + 1 SacAgent.train.
+    python tools/bench_sac.py [--iters 200]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--max-length", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=200)
+    args = ap.parse_args()
+    from agents_amd import optimizers
+    from agents_amd.agents.sac import sac_agent
+    from agents_amd.drivers import dynamic_step_driver
+    from agents_amd.environments import random_tf_environment
+    from agents_amd.networks import actor_distribution_network as adn
+    from agents_amd.networks import critic_network
+    from agents_amd.networks import layers as L
+    from agents_amd.replay_buffers import tf_uniform_replay_buffer as rb_lib
+    from agents_amd.specs import tensor_spec
+    from agents_amd.train import learner
+    from agents_amd.trajectories import time_step as ts
+    from agents_amd.utils import common, graph
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    obs = tensor_spec.BoundedTensorSpec((376,), torch.float32, -1.0, 1.0)
+    act = tensor_spec.BoundedTensorSpec((17,), torch.float32, -0.4, 0.4)
+    tss = ts.time_step_spec(obs)
+    actor = adn.ActorDistributionNetwork(
+        obs, act, fc_layer_params=(256, 256),
+        continuous_projection_net=lambda spec: adn.TanhNormalProjectionNetwork(
+            spec, std_transform=adn.std_clip_transform), seed=1)
+    critic = critic_network.CriticNetwork((obs, act), joint_fc_layer_params=(256, 256),
+                                          kernel_initializer=L.GlorotUniform(),
+                                          last_kernel_initializer=L.GlorotUniform(), seed=2)
+    agent = sac_agent.SacAgent(
+        tss, act, critic_network=critic, actor_network=actor,
+        actor_optimizer=optimizers.Adam(3e-4), critic_optimizer=optimizers.Adam(3e-4),
+        alpha_optimizer=optimizers.Adam(3e-4), target_update_tau=0.005, target_update_period=1,
+        td_errors_loss_fn=common.element_wise_squared_loss, gamma=0.99, reward_scale_factor=0.1)
+    agent.initialize()
+    env = random_tf_environment.RandomTFEnvironment(tss, act, batch_size=args.envs,
+                                                    episode_end_probability=1e-3, seed=3, device=dev)
+    rb = rb_lib.TFUniformReplayBuffer(agent.collect_data_spec, batch_size=args.envs,
+                                      max_length=args.max_length, device=dev)
+    init = dynamic_step_driver.DynamicStepDriver(env, agent.collect_policy,
+                                                 observers=[rb.add_batch],
+                                                 num_steps=args.envs * args.max_length)
+    init.run()
+    drv = dynamic_step_driver.DynamicStepDriver(env, agent.collect_policy,
+                                                observers=[rb.add_batch], num_steps=1)
+    collect = common.function(drv.run)
+    lrn = learner.Learner(None, common.Variable(0), agent)
+    it = iter(rb.as_dataset(sample_batch_size=args.batch, num_steps=2).prefetch(3))
+    tsx = None
+
+    def step():
+        nonlocal tsx
+        tsx, _ = collect(tsx)
+        return lrn.run(iterations=1, iterator=it)
+
+    for _ in range(40):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        li = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.iters
+    row = 4 + 376 * 4 + 17 * 4 + 4 + 4 + 4
+    print(json.dumps({
+        "workload": "configs[4] at 1 GPU: SAC Humanoid-shaped, %d envs, batch %d, actor/critics "
+                    "(256,256)" % (args.envs, args.batch),
+        "ms_per_iteration": dt * 1e3, "learner_steps_per_sec": 1.0 / dt,
+        "env_steps_per_sec": args.envs / dt, "trained_transitions_per_sec": args.batch / dt,
+        "replay_row_bytes": row, "final_loss": float(li.loss), "n_gpus": 1,
+        "train_graph_replays": graph.graphed_train(agent).replays}))
+
+
+if __name__ == "__main__":
+    main()
