@@ -296,15 +296,26 @@ class DqnAgent(tf_agent.TFAgent):
 
     # ---- checkpointing ---------------------------------------------------------------------------
     def state_dict(self):
+        graph.join_lanes(self._q_network.flat_params.device)
         return {"q": self._q_network.flat_params.clone(),
                 "target": self._target_q_network.flat_params.clone(),
                 "train_step": int(self._train_step_counter),
-                "optimizer": self._optimizer.state_dict() if self._optimizer else None}
+                "target_update_calls": self._update_target._counter,
+                "optimizer": self._optimizer.state_dict() if self._optimizer else None,
+                "collect_policy": self._collect_policy.state_dict()}
 
     def load_state_dict(self, sd):
+        """Restores IN PLACE: captured HIP graphs keep pointing at the same buffers."""
+        graph.join_lanes(self._q_network.flat_params.device)
         self._q_network.flat_params.copy_(sd["q"])
         self._target_q_network.flat_params.copy_(sd["target"])
         self._train_step_counter.assign(sd["train_step"])
+        self._update_target._counter = int(sd.get("target_update_calls", 0))
+        if sd.get("optimizer") is not None and self._optimizer is not None:
+            self._optimizer.load_state_dict(sd["optimizer"])
+        if sd.get("collect_policy") is not None:
+            self._collect_policy.load_state_dict(sd["collect_policy"])
+        self._initialized = True
 
 
 class DdqnAgent(DqnAgent):

@@ -139,6 +139,26 @@ class PPOAgent(tf_agent.TFAgent):
     def _initialize(self):
         pass
 
+    # ---- checkpointing ---------------------------------------------------------------------------
+    def state_dict(self):
+        return {"params": self.flat_params.clone(),
+                "train_step": int(self._train_step_counter),
+                "optimizer": self._optimizer.state_dict() if self._optimizer else None,
+                "adaptive_kl_beta": None if self._adaptive_kl_beta is None
+                else self._adaptive_kl_beta.clone(),
+                "policies": [self._policy.state_dict(), self._collect_policy.state_dict()]}
+
+    def load_state_dict(self, sd):
+        self.flat_params.copy_(sd["params"])
+        self._train_step_counter.assign(sd["train_step"])
+        if sd.get("optimizer") is not None and self._optimizer is not None:
+            self._optimizer.load_state_dict(sd["optimizer"])
+        if sd.get("adaptive_kl_beta") is not None and self._adaptive_kl_beta is not None:
+            self._adaptive_kl_beta.copy_(sd["adaptive_kl_beta"])
+        self._policy.load_state_dict(sd["policies"][0])
+        self._collect_policy.load_state_dict(sd["policies"][1])
+        self._initialized = True
+
     def _st(self):
         return _lib.stream_ptr()
 

@@ -59,6 +59,17 @@ class PPOPolicy(tf_policy.TFPolicy):
     def get_initial_value_state(self, batch_size=None):
         return ()
 
+    def state_dict(self):
+        return {"call_counter": None if self._call_counter is None
+                else int(self._call_counter.item())}
+
+    def load_state_dict(self, sd):
+        if sd.get("call_counter") is not None:
+            if self._call_counter is None:
+                self._call_counter = torch.zeros(
+                    (1,), dtype=torch.int64, device=self._actor_network.body.flat_params.device)
+            self._call_counter.fill_(int(sd["call_counter"]))
+
     def _action(self, time_step, policy_state, seed):
         lib = _lib.load()
         obs = time_step.observation

@@ -95,6 +95,15 @@ class SacPolicy(tf_policy.TFPolicy):
             _lib.check(lib.aa_counter_add(self._call_counter.data_ptr(), 1, st), "aa_counter_add")
         return b["action"], b["logp"], z
 
+    def state_dict(self):
+        return {"call_counter": None if self._call_counter is None
+                else int(self._call_counter.item())}
+
+    def load_state_dict(self, sd):
+        if sd.get("call_counter") is not None:
+            self._consts(self._actor_network.flat_params.device)
+            self._call_counter.fill_(int(sd["call_counter"]))
+
     def _action(self, time_step, policy_state, seed):
         obs = time_step.observation
         batched = time_step.step_type.dim() > 0
@@ -442,6 +451,32 @@ class SacAgent(tf_agent.TFAgent):
         """The train step is device work plus host counters registered with graph.on_replay:
         one HIP graph per input signature (utils/graph.py: GraphedTrain, whole mode)."""
         return self._train(experience, weights)
+
+    # ---- checkpointing ---------------------------------------------------------------------------
+    def state_dict(self):
+        return {"actor": self._actor_network.flat_params.clone(),
+                "critics": self._critic_params.clone(), "targets": self._target_params.clone(),
+                "log_alpha": self._log_alpha_buf.clone(),
+                "train_step": int(self._train_step_counter),
+                "target_update_calls": self._update_target._counter,
+                "optimizers": [o.state_dict() for o in (self._actor_optimizer,
+                                                        self._critic_optimizer,
+                                                        self._alpha_optimizer)],
+                "policies": [self._policy.state_dict(), self._train_policy.state_dict()]}
+
+    def load_state_dict(self, sd):
+        self._actor_network.flat_params.copy_(sd["actor"])
+        self._critic_params.copy_(sd["critics"])
+        self._target_params.copy_(sd["targets"])
+        self._log_alpha_buf.copy_(sd["log_alpha"])
+        self._train_step_counter.assign(sd["train_step"])
+        self._update_target._counter = int(sd["target_update_calls"])
+        for o, osd in zip((self._actor_optimizer, self._critic_optimizer, self._alpha_optimizer),
+                          sd["optimizers"]):
+            o.load_state_dict(osd)
+        self._policy.load_state_dict(sd["policies"][0])
+        self._train_policy.load_state_dict(sd["policies"][1])
+        self._initialized = True
 
     def _loss(self, experience, weights=None, training=False):
         obs, actions, next_obs, reward, discount = self._as_transition(experience)

@@ -89,6 +89,21 @@ class RandomTFEnvironment(tf_environment.TFEnvironment):
                        "aa_counter_add")
         return out
 
+    def state_dict(self):
+        graph.join_lanes(self._device)
+        return {"step_counter": int(self._step_counter.item()),
+                "time_step": None if self._time_step is None else
+                tuple(t.clone() for t in self._time_step)}
+
+    def load_state_dict(self, sd):
+        graph.join_lanes(self._device)
+        self._step_counter.fill_(int(sd["step_counter"]))
+        if sd["time_step"] is not None:
+            if self._time_step is None:
+                self._time_step = self._next_out()
+            for dst, src in zip(self._time_step, sd["time_step"]):
+                dst.copy_(src)
+
     def _current_time_step(self):
         graph.join_lanes(self._device)
         if self._time_step is None:

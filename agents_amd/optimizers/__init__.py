@@ -18,6 +18,7 @@ class Optimizer:
         self._name = name
         self._slots = {}       # id(flat param storage) -> dict of slot tensors
         self.iterations = 0    # host mirror of the device step counter
+        self._pending = []     # restored slot sets not yet claimed (load_state_dict)
 
     def _bump_iterations(self):
         self.iterations += 1
@@ -34,6 +35,9 @@ class Optimizer:
             s = {n: torch.zeros_like(params) for n in names}
             s["step"] = torch.zeros((1,), dtype=torch.int64, device=params.device)
             self._slots[key] = s
+            if self._pending:   # restored state waiting for this (creation-ordered) slot set
+                for k, v in self._pending.pop(0).items():
+                    s[k].copy_(v)
         return s
 
     # -- keras-like API ----------------------------------------------------------------------------
@@ -55,6 +59,19 @@ class Optimizer:
     def state_dict(self):
         return {"iterations": self.iterations,
                 "slots": [{k: v.clone() for k, v in s.items()} for s in self._slots.values()]}
+
+    def load_state_dict(self, sd):
+        """Restores the step count and the slot tensors IN PLACE (captured HIP graphs keep pointing
+        at them).  Slot sets are matched by creation order; sets that do not exist yet (the
+        optimizer has not been applied since construction) are filled when they are created."""
+        self.iterations = int(sd["iterations"])
+        saved = list(sd["slots"])
+        for s in self._slots.values():
+            if not saved:
+                break
+            for k, v in saved.pop(0).items():
+                s[k].copy_(v)
+        self._pending = saved
 
 
 class Adam(Optimizer):

@@ -85,7 +85,8 @@ class _DiscretePolicy(tf_policy.TFPolicy):
         B = q.shape[0]
         dev = q.device
         if self._call_counter is None:
-            self._call_counter = torch.zeros((1,), dtype=torch.int64, device=dev)
+            self._call_counter = torch.full((1,), getattr(self, "_pending_counter", 0),
+                                            dtype=torch.int64, device=dev)
         if out is None:
             out = torch.empty((B,) + tuple(self._spec.shape), dtype=self._spec.dtype, device=dev)
         if mask is not None:
@@ -109,6 +110,19 @@ class _DiscretePolicy(tf_policy.TFPolicy):
             _lib.check(lib.aa_counter_add(self._call_counter.data_ptr(), 1, st),
                        "aa_counter_add")
         return out
+
+    def state_dict(self):
+        return {"call_counter": None if self._call_counter is None
+                else int(self._call_counter.item())}
+
+    def load_state_dict(self, sd):
+        v = sd.get("call_counter")
+        if v is None:
+            return
+        if self._call_counter is None:
+            self._pending_counter = int(v)      # applied when the counter tensor is created
+        else:
+            self._call_counter.fill_(int(v))
 
     def _refresh_epsilon(self):
         e = self._get_epsilon()

@@ -58,7 +58,19 @@ class Learner:
                           hasattr(self._agent, "_graph_train_whole")):
             from agents_amd.utils import graph
             self._train_fn = graph.graphed_train(self._agent)
-        self._last_checkpoint_step = int(self.train_step) if self.train_step is not None else 0
+        # learner.py:206-243: a Checkpointer over (agent, train_step) under root_dir/train, restored
+        # at construction, saved every `checkpoint_interval` train steps by an IntervalTrigger
+        self._checkpointer = None
+        if self._train_dir is not None and hasattr(self._agent, "state_dict"):
+            from agents_amd.train import triggers as triggers_lib
+            from agents_amd.utils import common
+            self._checkpointer = common.Checkpointer(
+                self._train_dir, max_to_keep=max_checkpoints_to_keep, agent=self._agent,
+                train_step=self.train_step)
+            if self.train_step is not None and self._checkpointer.checkpoint_exists:
+                self._agent.train_step_counter.assign(int(self.train_step))
+            self.triggers = list(self.triggers) + [triggers_lib.CheckpointTrigger(
+                self._checkpointer, self._agent.train_step_counter, checkpoint_interval)]
 
     @property
     def train_step_numpy(self):

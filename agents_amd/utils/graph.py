@@ -377,6 +377,9 @@ class GraphedSampler:
         return out
 
 
+_FREE_MAILBOXES = []   # (host ptr, device ptr) of mailboxes whose owner was collected
+
+
 class GraphedDriverRun:
     """`common.function(driver.run)` for a DynamicStepDriver: the loop body
     (dynamic_step_driver.py:118-172) is captured once per environment output buffer (two: the
@@ -406,20 +409,27 @@ class GraphedDriverRun:
         self.replays = 0
 
     def __del__(self):
-        try:
-            if self._mbox_host is not None:
-                from agents_amd import _lib
-                _lib.load().aa_mailbox_destroy(self._mbox_host)
-        except Exception:
-            pass
+        # Back to the free list, NOT hipHostFree: the collector can run this at any point,
+        # including in the middle of another object's stream capture, where a synchronising HIP
+        # call would invalidate the capture (seen as an intermittent crash in the test suite).
+        if self._mbox_host is not None:
+            _FREE_MAILBOXES.append((self._mbox_host, self._mbox_dev))
+            self._mbox_host = None
 
     def _setup(self, dev, B):
         import ctypes
         from agents_amd import _lib
         lib = _lib.load()
-        h, d = ctypes.c_void_p(), ctypes.c_void_p()
-        _lib.check(lib.aa_mailbox_create(2, ctypes.byref(h), ctypes.byref(d)), "aa_mailbox_create")
-        self._mbox_host, self._mbox_dev = h.value, d.value
+        if _FREE_MAILBOXES:
+            self._mbox_host, self._mbox_dev = _FREE_MAILBOXES.pop()
+            torch.cuda.synchronize()              # no kernel of the previous owner is in flight
+            ctypes.memset(self._mbox_host, 0, 16)
+            self._seq = 0
+        else:
+            h, d = ctypes.c_void_p(), ctypes.c_void_p()
+            _lib.check(lib.aa_mailbox_create(2, ctypes.byref(h), ctypes.byref(d)),
+                       "aa_mailbox_create")
+            self._mbox_host, self._mbox_dev = h.value, d.value
         self._total = torch.zeros((1,), dtype=torch.int64, device=dev)
         self._counter = torch.zeros((B,), dtype=torch.int32, device=dev)
 

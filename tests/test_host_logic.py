@@ -187,3 +187,27 @@ def test_initializers():
     np.testing.assert_allclose(q.T @ q, np.eye(64), atol=1e-5)
     assert L.Constant([[2, 1], [1, 1]])((2, 2), rng, 2, 2).tolist() == [[2, 1], [1, 1]]
     assert L.Constant(-0.2)((3,), rng, 1, 3).tolist() == pytest.approx([-0.2] * 3)
+
+
+def test_learner_triggers():
+    from agents_amd.train import interval_trigger, triggers
+    from agents_amd.utils import common
+    calls = []
+    t = interval_trigger.IntervalTrigger(5, lambda: calls.append(1))
+    for v in range(12):
+        t(v)
+    assert len(calls) == 2            # at 5 and 10
+    t(11, force_trigger=True)
+    assert len(calls) == 3
+    t(11, force_trigger=True)         # same value: not again
+    assert len(calls) == 3
+    never = interval_trigger.IntervalTrigger(0, lambda: calls.append(2))
+    never(100)
+    assert 2 not in calls
+    step = common.Variable(0)
+    logs = []
+    sps = triggers.StepPerSecondLogTrigger(step, 3, log_fn=logs.append)
+    for v in range(1, 8):
+        step.assign(v)
+        sps(v)
+    assert len(logs) == 2 and sps.last_steps_per_sec > 0
