@@ -17,6 +17,9 @@ tracing semantics.  Components whose host mirrors must advance per execution (th
 `last_id` mirror, the environment's current-time-step reference, a decaying epsilon) register them
 with `on_replay`, which runs them before every replay.
 """
+import contextlib
+import gc
+
 import torch
 
 from agents_amd.utils import nest_utils
@@ -133,6 +136,22 @@ def join_lanes(device=None):
             l.join()
 
 
+@contextlib.contextmanager
+def _no_gc_during_capture():
+    """Cyclic garbage is collected BEFORE a capture and the collector is paused during it: a
+    finaliser that runs mid-capture (a torch CUDAGraph or pinned-memory owner of some earlier,
+    now unreachable stack being destroyed) issues HIP calls that are illegal while a stream is
+    capturing and corrupt the graph being recorded."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
 class _Captured:
     """A torch CUDAGraph plus the host hooks registered while it was captured."""
 
@@ -150,7 +169,7 @@ class _Captured:
         torch.cuda.synchronize()
         _CAPTURE = ctx
         try:
-            with torch.cuda.graph(g):
+            with _no_gc_during_capture(), torch.cuda.graph(g):
                 self.out = fn()
         finally:
             _CAPTURE = None
@@ -296,13 +315,13 @@ class GraphedTrain:
         torch.cuda.synchronize()
         iters = agent._optimizer.iterations
         e.g_grads = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(e.g_grads):
+        with _no_gc_during_capture(), torch.cuda.graph(e.g_grads):
             e.out = agent._train_phase_grads(e.static_in, w_arg)
         if g_apply is not None:
             e.g_apply = g_apply          # the optimizer phase does not depend on the inputs
         else:
             e.g_apply = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(e.g_apply):
+            with _no_gc_during_capture(), torch.cuda.graph(e.g_apply):
                 agent._train_phase_apply()
         agent._optimizer.iterations = iters  # capture enqueues nothing; undo the host mirror bump
         torch.cuda.synchronize()
