@@ -136,6 +136,11 @@ def join_lanes(device=None):
             l.join()
 
 
+# Other threads of the process (the RCCL watchdog of torch.distributed polls events) must not
+# invalidate a capture on this thread: thread-local capture mode instead of torch's default global.
+_CAPTURE_MODE = "thread_local"
+
+
 @contextlib.contextmanager
 def _no_gc_during_capture():
     """Cyclic garbage is collected BEFORE a capture and the collector is paused during it: a
@@ -169,7 +174,7 @@ class _Captured:
         torch.cuda.synchronize()
         _CAPTURE = ctx
         try:
-            with _no_gc_during_capture(), torch.cuda.graph(g):
+            with _no_gc_during_capture(), torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
                 self.out = fn()
         finally:
             _CAPTURE = None
@@ -315,13 +320,15 @@ class GraphedTrain:
         torch.cuda.synchronize()
         iters = agent._optimizer.iterations
         e.g_grads = torch.cuda.CUDAGraph()
-        with _no_gc_during_capture(), torch.cuda.graph(e.g_grads):
+        with _no_gc_during_capture(), torch.cuda.graph(e.g_grads,
+                                                          capture_error_mode=_CAPTURE_MODE):
             e.out = agent._train_phase_grads(e.static_in, w_arg)
         if g_apply is not None:
             e.g_apply = g_apply          # the optimizer phase does not depend on the inputs
         else:
             e.g_apply = torch.cuda.CUDAGraph()
-            with _no_gc_during_capture(), torch.cuda.graph(e.g_apply):
+            with _no_gc_during_capture(), torch.cuda.graph(e.g_apply,
+                                                              capture_error_mode=_CAPTURE_MODE):
                 agent._train_phase_apply()
         agent._optimizer.iterations = iters  # capture enqueues nothing; undo the host mirror bump
         torch.cuda.synchronize()
