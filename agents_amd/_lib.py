@@ -49,7 +49,7 @@ class GemmDesc(Structure):
 _SIGNATURES = {
     "aa_abi_version": (c_int, []),
     "aa_rb_scatter_rows": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int,
-                                   c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "aa_rb_sample_rows": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_uint64,
                                   c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "aa_rb_gather_rows": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int,
@@ -91,10 +91,11 @@ _SIGNATURES = {
     "aa_mailbox_destroy": (c_int, [c_void_p]),
     "aa_mailbox_wait": (c_int, [c_void_p, c_int64, c_int64, POINTER(c_int64)]),
     "aa_eps_greedy_action": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p,
-                                     c_uint64, c_void_p, c_int64, c_void_p, c_int32, c_void_p]),
+                                     c_uint64, c_void_p, c_void_p, c_int64, c_void_p, c_int32,
+                                     c_void_p]),
     "aa_vecenv_random_step": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_float, c_float,
-                                      c_float, c_uint64, c_void_p, c_int32, c_void_p, c_void_p,
-                                      c_void_p, c_void_p, c_void_p]),
+                                      c_float, c_uint64, c_void_p, c_void_p, c_int32, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "aa_discounted_return": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                      c_int64, c_void_p, c_void_p]),
     "aa_gae": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int64, c_int64,
@@ -147,7 +148,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 3:
+    if lib.aa_abi_version() != 4:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

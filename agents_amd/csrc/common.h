@@ -9,6 +9,7 @@
 #define AA_ERR_LAUNCH (-5)     // EIO-style: HIP launch failure
 
 #define AA_WAVE 64
+#define AA_MAX_ARRIVAL_GROUPS 16   // see aa_advance_when_all_done
 
 // Returns AA_ERR_LAUNCH if the preceding launch failed (does not synchronise).
 static inline int aa_launch_status() {
@@ -80,4 +81,23 @@ __device__ static inline float aa_block_sum(float v, float* smem /* >= 16 floats
     for (int i = 0; i < nw; ++i) r += smem[i];
   }
   return r;
+}
+
+// A device counter that every workgroup of a launch reads at its start (Philox call counter, env
+// step counter, replay last_id) is advanced by the LAST workgroup to finish instead of by a second
+// one-thread launch: *arrival counts finished workgroups (zero before the launch, reset to zero by
+// the last one), so by the time the counter changes every group has consumed the old value.
+__device__ static inline void aa_advance_when_all_done(int64_t* counter, int64_t* arrival,
+                                                       int64_t inc, unsigned n_groups) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long prev = __hip_atomic_fetch_add(
+        reinterpret_cast<unsigned long long*>(arrival), 1ull, __ATOMIC_RELAXED,
+        __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == (unsigned long long)n_groups - 1ull) {
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(arrival), 0ull, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      *counter += inc;
+    }
+  }
 }

@@ -18,12 +18,13 @@ template <bool I64>
 __global__ void aa_eps_greedy_kernel(const float* __restrict__ q, const int32_t* __restrict__ mask,
                                      int64_t B, int A, float epsilon,
                                      const float* __restrict__ epsilon_dev, uint32_t k0,
-                                     uint32_t k1, const int64_t* __restrict__ call_dev,
+                                     uint32_t k1, int64_t* call_dev, int64_t* arrival,
                                      int64_t action_min, void* __restrict__ out) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
   const float eps = epsilon_dev != nullptr ? *epsilon_dev : epsilon;
   const uint64_t call = call_dev != nullptr ? (uint64_t)(*call_dev) : 0ull;
+  if (arrival != nullptr) aa_advance_when_all_done(call_dev, arrival, 1, gridDim.x);
+  if (b >= B) return;
   int best = 0;
   float bestv = 0.f;
   bool any = false;
@@ -74,11 +75,12 @@ __global__ void aa_eps_greedy_kernel(const float* __restrict__ q, const int32_t*
 __global__ void __launch_bounds__(256)
 aa_vecenv_step_kernel(const int32_t* __restrict__ cur_step_type, int64_t B, int64_t obs_elems,
                       int obs_kind, float obs_lo, float obs_hi, float p_end, uint32_t k0,
-                      uint32_t k1, const int64_t* __restrict__ step_dev, int force_first,
+                      uint32_t k1, int64_t* step_dev, int64_t* arrival, int force_first,
                       int32_t* __restrict__ step_type_out, float* __restrict__ reward_out,
                       float* __restrict__ discount_out, void* __restrict__ obs_out,
                       int64_t chunks_per_row) {
   const uint64_t s = step_dev != nullptr ? (uint64_t)(*step_dev) : 0ull;
+  if (arrival != nullptr) aa_advance_when_all_done(step_dev, arrival, 1, gridDim.x);
   const int64_t total = B * chunks_per_row;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -123,6 +125,10 @@ aa_vecenv_step_kernel(const int32_t* __restrict__ cur_step_type, int64_t B, int6
       discount_out[b] = disc;
     }
   }
+}
+
+__global__ void aa_counter_bump_kernel(int64_t* c) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *c += 1;
 }
 
 // DynamicStepDriver loop counter: counter[b] += (step_type[b] != LAST); *total += that sum
@@ -204,28 +210,32 @@ int aa_mailbox_wait(const int64_t* host_ptr, int64_t seq, int64_t timeout_us, in
 }
 
 int aa_eps_greedy_action(const float* q, const int32_t* mask, int64_t B, int32_t A, float epsilon,
-                         const float* epsilon_dev, uint64_t seed, const int64_t* call_counter_dev,
-                         int64_t action_min, void* actions_out, int32_t actions_are_i64,
-                         void* stream) {
+                         const float* epsilon_dev, uint64_t seed, int64_t* call_counter_dev,
+                         int64_t* arrival_dev, int64_t action_min, void* actions_out,
+                         int32_t actions_are_i64, void* stream) {
   if (!q || !actions_out || B <= 0 || A <= 0) return AA_ERR_INVALID;
   const dim3 grid((unsigned)((B + 255) / 256)), block(256);
   hipStream_t st = (hipStream_t)stream;
+  int64_t* arrival = (arrival_dev != nullptr && grid.x <= AA_MAX_ARRIVAL_GROUPS) ? arrival_dev
+                                                                                 : nullptr;
   if (actions_are_i64)
     hipLaunchKernelGGL(aa_eps_greedy_kernel<true>, grid, block, 0, st, q, mask, B, A, epsilon,
                        epsilon_dev, (uint32_t)seed, (uint32_t)(seed >> 32), call_counter_dev,
-                       action_min, actions_out);
+                       arrival, action_min, actions_out);
   else
     hipLaunchKernelGGL(aa_eps_greedy_kernel<false>, grid, block, 0, st, q, mask, B, A, epsilon,
                        epsilon_dev, (uint32_t)seed, (uint32_t)(seed >> 32), call_counter_dev,
-                       action_min, actions_out);
+                       arrival, action_min, actions_out);
+  if (arrival_dev != nullptr && arrival == nullptr)   // large grid: one-thread bump launch
+    hipLaunchKernelGGL(aa_counter_bump_kernel, dim3(1), dim3(64), 0, st, call_counter_dev);
   return aa_launch_status();
 }
 
 int aa_vecenv_random_step(const int32_t* cur_step_type, int64_t B, int64_t obs_elems,
                           int32_t obs_kind, float obs_lo, float obs_hi, float p_end,
-                          uint64_t seed, const int64_t* step_counter_dev, int32_t force_first,
-                          int32_t* step_type_out, float* reward_out, float* discount_out,
-                          void* obs_out, void* stream) {
+                          uint64_t seed, int64_t* step_counter_dev, int64_t* arrival_dev,
+                          int32_t force_first, int32_t* step_type_out, float* reward_out,
+                          float* discount_out, void* obs_out, void* stream) {
   if (B <= 0 || obs_elems <= 0 || !step_type_out || !reward_out || !discount_out || !obs_out)
     return AA_ERR_INVALID;
   if (!force_first && !cur_step_type) return AA_ERR_INVALID;
@@ -240,8 +250,13 @@ int aa_vecenv_random_step(const int32_t* cur_step_type, int64_t B, int64_t obs_e
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(aa_vecenv_step_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      (hipStream_t)stream, cur_step_type, B, obs_elems, obs_kind, obs_lo, obs_hi,
-                     p_end, (uint32_t)seed, (uint32_t)(seed >> 32), step_counter_dev, force_first,
-                     step_type_out, reward_out, discount_out, obs_out, chunks);
+                     p_end, (uint32_t)seed, (uint32_t)(seed >> 32), step_counter_dev,
+                     (arrival_dev != nullptr && blocks <= AA_MAX_ARRIVAL_GROUPS) ? arrival_dev
+                                                                                  : nullptr,
+                     force_first, step_type_out, reward_out, discount_out, obs_out, chunks);
+  if (arrival_dev != nullptr && blocks > AA_MAX_ARRIVAL_GROUPS)
+    hipLaunchKernelGGL(aa_counter_bump_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                       step_counter_dev);
   return aa_launch_status();
 }
 

@@ -41,7 +41,8 @@ class RandomTFEnvironment(tf_environment.TFEnvironment):
         self._p_end = float(episode_end_probability)
         self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self._device = torch.device(device) if device is not None else torch.device("cuda")
-        self._step_counter = torch.zeros((1,), dtype=torch.int64, device=self._device)
+        # [step counter, arrival count of the step kernel's workgroups]
+        self._step_counter = torch.zeros((2,), dtype=torch.int64, device=self._device)
         self._time_step = None
         self._ring = None
 
@@ -82,22 +83,21 @@ class RandomTFEnvironment(tf_environment.TFEnvironment):
             _lib.check(lib.aa_vecenv_random_step(
                 None if cur_step_type is None else cur_step_type.data_ptr(), self._batch_size,
                 self._obs_spec.num_elements, self._obs_kind, self._lo, self._hi, self._p_end,
-                self._seed, self._step_counter.data_ptr(), 1 if force_first else 0,
-                out.step_type.data_ptr(), out.reward.data_ptr(), out.discount.data_ptr(),
-                out.observation.data_ptr(), st), "aa_vecenv_random_step")
-            _lib.check(lib.aa_counter_add(self._step_counter.data_ptr(), 1, st),
-                       "aa_counter_add")
+                self._seed, self._step_counter.data_ptr(), self._step_counter[1:].data_ptr(),
+                1 if force_first else 0, out.step_type.data_ptr(), out.reward.data_ptr(),
+                out.discount.data_ptr(), out.observation.data_ptr(), st),
+                "aa_vecenv_random_step")
         return out
 
     def state_dict(self):
         graph.join_lanes(self._device)
-        return {"step_counter": int(self._step_counter.item()),
+        return {"step_counter": int(self._step_counter[0].item()),
                 "time_step": None if self._time_step is None else
                 tuple(t.clone() for t in self._time_step)}
 
     def load_state_dict(self, sd):
         graph.join_lanes(self._device)
-        self._step_counter.fill_(int(sd["step_counter"]))
+        self._step_counter[0] = int(sd["step_counter"])
         if sd["time_step"] is not None:
             if self._time_step is None:
                 self._time_step = self._next_out()

@@ -85,8 +85,9 @@ class _DiscretePolicy(tf_policy.TFPolicy):
         B = q.shape[0]
         dev = q.device
         if self._call_counter is None:
-            self._call_counter = torch.full((1,), getattr(self, "_pending_counter", 0),
-                                            dtype=torch.int64, device=dev)
+            # [Philox call counter, arrival count of the select kernel's workgroups]
+            self._call_counter = torch.tensor([getattr(self, "_pending_counter", 0), 0],
+                                              dtype=torch.int64).to(dev)
         if out is None:
             out = torch.empty((B,) + tuple(self._spec.shape), dtype=self._spec.dtype, device=dev)
         if mask is not None:
@@ -101,19 +102,18 @@ class _DiscretePolicy(tf_policy.TFPolicy):
                 self._eps_dev = torch.zeros((1,), dtype=torch.float32, device=dev)
             graph.on_replay(self._refresh_epsilon)
             eps_ptr = self._eps_dev.data_ptr()
+        advance = epsilon > 0 or eps_ptr is not None   # the stream moves only when it is consumed
         _lib.check(lib.aa_eps_greedy_action(
             q.data_ptr(), None if mask is None else mask.data_ptr(), B, self._num_actions,
-            float(epsilon), eps_ptr, self._seed, self._call_counter.data_ptr(), self._lo,
+            float(epsilon), eps_ptr, self._seed, self._call_counter.data_ptr(),
+            self._call_counter[1:].data_ptr() if advance else None, self._lo,
             out.data_ptr(), 1 if self._spec.dtype == torch.int64 else 0, st),
             "aa_eps_greedy_action")
-        if epsilon > 0 or eps_ptr is not None:
-            _lib.check(lib.aa_counter_add(self._call_counter.data_ptr(), 1, st),
-                       "aa_counter_add")
         return out
 
     def state_dict(self):
         return {"call_counter": None if self._call_counter is None
-                else int(self._call_counter.item())}
+                else int(self._call_counter[0].item())}
 
     def load_state_dict(self, sd):
         v = sd.get("call_counter")
@@ -122,7 +122,7 @@ class _DiscretePolicy(tf_policy.TFPolicy):
         if self._call_counter is None:
             self._pending_counter = int(v)      # applied when the counter tensor is created
         else:
-            self._call_counter.fill_(int(v))
+            self._call_counter[0] = int(v)
 
     def _refresh_epsilon(self):
         e = self._get_epsilon()

@@ -77,7 +77,9 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
         self._id_spec = tensor_spec.TensorSpec((), torch.int64, name="id")
         self._data_table = table_fn(self._data_spec, capacity, device=self._device)
         self._id_table = table_fn(self._id_spec, capacity, device=self._device)
-        self._last_id = torch.full((1,), -1, dtype=torch.int64, device=self._device)
+        # [last_id, arrival count of the scatter kernel's workgroups]; `_last_id` is the public word
+        self._last_id_store = torch.tensor([-1, 0], dtype=torch.int64).to(self._device)
+        self._last_id = self._last_id_store[:1]
         self._err_flag = torch.zeros((1,), dtype=torch.int32, device=self._device)
         self._last_id_host = -1          # mirror: every add_batch is +1, clear() is -> -1
         self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -122,7 +124,8 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
         with torch.cuda.device(self._device):
             _lib.check(lib.aa_rb_scatter_rows(
                 p.tables, p.ios, p.row_bytes, p.n, self._id_table.variables()[0].data_ptr(),
-                self._last_id.data_ptr(), self._batch_size, self._max_length, _lib.stream_ptr()),
+                self._last_id.data_ptr(), self._last_id_store[1:].data_ptr(), self._batch_size,
+                self._max_length, _lib.stream_ptr()),
                 "aa_rb_scatter_rows")
         graph.on_replay(self._bump_last_id_host)
 

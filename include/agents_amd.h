@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 3
+#define AA_ABI_VERSION 4
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -41,7 +41,15 @@ int aa_abi_version(void);
  * TFUniformReplayBuffer._add_batch (tf_uniform_replay_buffer.py:182-209, 582-607). */
 int aa_rb_scatter_rows(void* const* leaf_tables_h, const void* const* leaf_items_h,
                        const int64_t* leaf_row_bytes_h, int n_leaves, int64_t* id_table,
-                       int64_t* last_id_dev, int64_t batch, int64_t max_len, void* stream);
+                       int64_t* last_id_dev, int64_t* arrival_dev /* nullable, see below */,
+                       int64_t batch, int64_t max_len, void* stream);
+/* `arrival_dev` (here and in aa_eps_greedy_action / aa_vecenv_random_step): one int64 word, zero
+ * before the call and left zero, in which the kernel counts finished workgroups so that the LAST
+ * one advances the counter every group has read (last_id, Philox call counter, env step counter)
+ * -- no second one-thread launch.  Used for launches of at most 16 workgroups (device-scope
+ * atomics on one word from thousands of groups serialise); larger launches, and NULL for the
+ * replay scatter, get the one-thread bump launch from the entry point.  With NULL,
+ * aa_eps_greedy_action / aa_vecenv_random_step leave the counter alone (caller: aa_counter_add). */
 
 /* get_next index sampling: S independent (start id, env block) pairs from the Philox4x32-10
  * stream (counter = (s, call_counter), key = seed), mapped with _valid_range_ids
@@ -200,8 +208,10 @@ int aa_clip_by_norm(float* g, const int64_t* seg_offsets_dev, int32_t n_seg,
  * ========================================================================================= */
 int aa_eps_greedy_action(const float* q, const int32_t* mask /* nullable [B,A] */, int64_t B,
                          int32_t A, float epsilon, const float* epsilon_dev /* nullable */,
-                         uint64_t seed, const int64_t* call_counter_dev, int64_t action_min,
-                         void* actions_out, int32_t actions_are_i64, void* stream);
+                         uint64_t seed, int64_t* call_counter_dev,
+                         int64_t* arrival_dev /* nullable: advance *call_counter_dev in-kernel */,
+                         int64_t action_min, void* actions_out, int32_t actions_are_i64,
+                         void* stream);
 
 /* DynamicStepDriver loop counter: counter[b] += (step_type[b] != LAST); *total_dev += the sum
  * (drivers/dynamic_step_driver.py:113,170).  counter_dev nullable.  mailbox (nullable) is a
@@ -227,9 +237,10 @@ int aa_mailbox_wait(const int64_t* host_ptr, int64_t seq, int64_t timeout_us, in
  * Out: next step_type/reward/discount/observation; cur_step_type is NOT modified. */
 int aa_vecenv_random_step(const int32_t* cur_step_type, int64_t B, int64_t obs_elems,
                           int32_t obs_kind, float obs_lo, float obs_hi, float p_end,
-                          uint64_t seed, const int64_t* step_counter_dev, int32_t force_first,
-                          int32_t* step_type_out, float* reward_out, float* discount_out,
-                          void* obs_out, void* stream);
+                          uint64_t seed, int64_t* step_counter_dev,
+                          int64_t* arrival_dev /* nullable: advance *step_counter_dev in-kernel */,
+                          int32_t force_first, int32_t* step_type_out, float* reward_out,
+                          float* discount_out, void* obs_out, void* stream);
 
 /* =========================================================================================
  * Value ops  (utils/value_ops.py:21-99 discounted_return, :102-164 GAE; ppo_agent.py:100-110)

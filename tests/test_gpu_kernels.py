@@ -217,7 +217,7 @@ def test_vecenv_bit_exact_vs_oracle(dev, kind, elems):
     for force in (0, 1):
         _lib.check(lib.aa_vecenv_random_step(
             dv(cur, dev).data_ptr(), B, elems, 0 if kind == "u8" else 1, -4.0, 4.0, 0.3, 77,
-            counter.data_ptr(), force, st.data_ptr(), rew.data_ptr(), disc.data_ptr(),
+            counter.data_ptr(), None, force, st.data_ptr(), rew.data_ptr(), disc.data_ptr(),
             obs.data_ptr(), _lib.stream_ptr()), "env")
         w_st, w_rew, w_disc, w_obs = oenv.step(cur, B, elems, kind, -4.0, 4.0, 0.3, 77, 5,
                                                bool(force))
@@ -225,6 +225,31 @@ def test_vecenv_bit_exact_vs_oracle(dev, kind, elems):
         np.testing.assert_array_equal(rew.cpu().numpy(), w_rew)
         np.testing.assert_array_equal(disc.cpu().numpy(), w_disc)
         np.testing.assert_array_equal(obs.cpu().numpy(), w_obs)
+
+
+def test_vecenv_advances_its_counter_in_kernel(dev):
+    """With an arrival word the step kernel's last workgroup advances the step counter itself
+    (no separate bump launch): same outputs, counter + 1, arrival word back to zero."""
+    lib = _lib.load()
+    B, elems = 300, 84 * 84 * 4       # many workgroups
+    cur = torch.ones(B, dtype=torch.int32, device=dev)
+    outs = []
+    for arrival in (False, True):
+        counter = torch.tensor([5, 0], dtype=torch.int64).to(dev)
+        st = torch.empty(B, dtype=torch.int32, device=dev)
+        rew, disc = torch.empty(B, device=dev), torch.empty(B, device=dev)
+        obs = torch.empty((B, elems), dtype=torch.uint8, device=dev)
+        for _ in range(3):
+            _lib.check(lib.aa_vecenv_random_step(
+                cur.data_ptr(), B, elems, 0, 0.0, 255.0, 0.3, 77, counter.data_ptr(),
+                counter[1:].data_ptr() if arrival else None, 0, st.data_ptr(), rew.data_ptr(),
+                disc.data_ptr(), obs.data_ptr(), _lib.stream_ptr()), "env")
+            if not arrival:
+                _lib.check(lib.aa_counter_add(counter.data_ptr(), 1, _lib.stream_ptr()), "add")
+        assert counter.cpu().tolist() == [8, 0]
+        outs.append((st.cpu(), rew.cpu(), obs.cpu()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
 
 
 def test_eps_greedy(dev):
