@@ -1,0 +1,61 @@
+"""GPU: the multi-GPU wiring exercised on ONE device with a real RCCL process group (world size 1):
+`torch.distributed` (backend "nccl" == RCCL on ROCm) initialised, the Learner's gradient hook issuing
+`all_reduce` between the two train graphs, HIP-graph captures happening while the process group
+(and its watchdog thread) is alive.  With one rank the all-reduce is the identity, so the run must
+match a run without any process group bit for bit.  (World size 2 semantics are covered on CPU with
+gloo in tests/test_distributed_gloo.py; 8-GPU runs belong to the driver.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from agents_amd.train import learner
+from agents_amd.train.utils import strategy_utils
+from agents_amd.utils import common, graph
+from tests.test_gpu_graphs import _stack
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(dev, strategy, steps=30):
+    env, agent, rb, drv, net = _stack(dev, 8, 64, 0.2, 1)
+    run = common.function(drv.run)
+    lrn = learner.Learner(None, common.Variable(0), agent, strategy=strategy)
+    if strategy is not None:      # one replica: install the hook by hand to exercise the collective
+        agent.gradient_hook = strategy.all_reduce_sum_
+    for _ in range(4):
+        run()
+    it = iter(rb.as_dataset(sample_batch_size=16, num_steps=2).prefetch(3))
+    li = None
+    for _ in range(steps):
+        run()
+        li = lrn.run(iterations=1, iterator=it)
+    torch.cuda.synchronize()
+    return net.flat_params.clone(), float(li.loss), graph.graphed_train(agent).replays
+
+
+def test_rccl_hook_between_train_graphs(dev):
+    ref_params, ref_loss, _ = _run(dev, None)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        strat = strategy_utils.DataParallelStrategy()
+        assert strat.num_replicas_in_sync == 1
+        params, loss, replays = _run(dev, strat)
+        t = torch.ones(4, device=dev)
+        assert torch.equal(strat.all_reduce_sum_(t), torch.ones(4, device=dev))
+    finally:
+        dist.destroy_process_group()
+    assert replays > 15, "train graphs did not replay with the process group alive"
+    assert torch.equal(params, ref_params) and loss == ref_loss
