@@ -111,6 +111,7 @@ class DqnAgent(tf_agent.TFAgent):
         # over (tf.nn.compute_average_loss, utils/common.py:1462-1467) and the gradient all-reduce.
         self.num_replicas = 1
         self.gradient_hook = None
+        self.gradient_hook_async = None   # Work-returning variant (bucketed overlap)
         self.check_numerics = False  # the reference's check_numerics needs a device sync
 
     # ---- construction helpers -----------------------------------------------------------------
@@ -273,6 +274,34 @@ class DqnAgent(tf_agent.TFAgent):
             self._clip_gradients(net)
         return tf_agent.LossInfo(total.reshape(()),
                                  DqnLossInfo(td_loss=w.td_loss, td_error=w.td_error))
+
+    # Two-bucket variant for data-parallel runs: the dense tail (fc1 + fc2 = 95 % of the Atari
+    # net's parameters) finishes its gradients first, so the Learner can start their all-reduce
+    # while the conv layers are still in backward (utils/graph.py: GraphedTrain, bucket mode).
+    def _bucket_split(self):
+        """Layer index where the gradient buffer is split, or None when one bucket is required
+        (per-replica clipping / regularisation run over the whole buffer before the reduce)."""
+        net = self._q_network
+        if net.has_regularization or self._gradient_clipping is not None:
+            return None
+        k = net.dense_tail_start()
+        return k if 0 < k < len(net._param_layers) else None
+
+    def _train_phase_grads_a(self, experience, weights):
+        net = self._q_network
+        w = self._forward_and_loss(experience, self._td_errors_loss_fn, self._gamma,
+                                   self._reward_scale_factor, weights, need_grad=True)
+        self._bucket_B = w.dq.shape[0]
+        net.backward(w.dq, slot="train", side_stream=self._side_stream(w.dq.device),
+                     stop_layer=self._bucket_split())
+        return tf_agent.LossInfo(w.loss.reshape(()),
+                                 DqnLossInfo(td_loss=w.td_loss, td_error=w.td_error))
+
+    def _train_phase_grads_b(self):
+        net = self._q_network
+        net.backward_resume(self._bucket_B, slot="train",
+                            side_stream=self._side_stream(net.flat_grads.device),
+                            from_layer=self._bucket_split())
 
     def _train_phase_apply(self):
         net = self._q_network

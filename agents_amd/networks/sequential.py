@@ -318,13 +318,16 @@ class Sequential(network.Network):
                 pi += 1
         return cur
 
-    def backward(self, dout, slot=0, side_stream=None, param_grads=True, input_grad=None):
+    def backward(self, dout, slot=0, side_stream=None, param_grads=True, input_grad=None,
+                 stop_layer=0):
         """Given d loss / d output [B, out], fills flat_grads (overwrites).
 
         `param_grads=False` skips every weight/bias gradient (only the input-gradient chain runs:
         SAC's actor loss differentiates THROUGH the critics without updating them);
         `input_grad` ([B, in] float32 buffer, Dense first layer only) also receives
-        d loss / d network input.
+        d loss / d network input.  `stop_layer=k > 0` stops after parametrised layer k (its input
+        gradient is computed); `backward_resume` continues with layers k-1 .. 0 -- the Learner
+        starts the all-reduce of the tail's gradients in between (`grad_buckets`).
 
         The input-gradient chain (dX_n -> dX_{n-1} -> ...) is the critical path; every
         weight/bias-gradient GEMM only needs its layer's dZ, so with `side_stream` they are
@@ -345,7 +348,28 @@ class Sequential(network.Network):
             dz = s.dz_top
         else:
             dz = dout.contiguous()
-        main = torch.cuda.current_stream(dout.device)
+        self._backward_range(s, B, dz, n - 1, stop_layer, side_stream, param_grads, input_grad)
+
+    def backward_resume(self, B, slot=0, side_stream=None, from_layer=1):
+        """Continues a `backward(..., stop_layer=from_layer)`: layers from_layer-1 .. 0."""
+        s = self._slots[(slot, B)]
+        self._backward_range(s, B, s.dxs[from_layer], from_layer - 1, 0, side_stream, True, None)
+
+    def grad_buckets(self, split_layer):
+        """(tail, head) views of flat_grads: gradients of layers >= split_layer (complete after
+        `backward(stop_layer=split_layer)`) and of the layers below."""
+        off = self._offsets[split_layer][0]
+        return self.flat_grads[off:], self.flat_grads[:off]
+
+    def dense_tail_start(self):
+        """Index of the first layer of the trailing run of Dense layers (0 if all are Dense)."""
+        k = len(self._param_layers)
+        while k > 0 and isinstance(self._param_layers[k - 1], L.Dense):
+            k -= 1
+        return k
+
+    def _backward_range(self, s, B, dz, hi, lo, side_stream, param_grads, input_grad):
+        main = torch.cuda.current_stream(dz.device)
         if side_stream is None:
             side_stream = main
 
@@ -356,7 +380,7 @@ class Sequential(network.Network):
             with torch.cuda.stream(side_stream):
                 return fn()
 
-        for i in range(n - 1, -1, -1):
+        for i in range(hi, lo - 1, -1):
             l = self._param_layers[i]
             ks = self._shapes[i][0]
             x = s.xs[i]

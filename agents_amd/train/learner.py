@@ -51,6 +51,9 @@ class Learner:
         self._agent.num_replicas = self.strategy.num_replicas_in_sync
         if self.strategy.num_replicas_in_sync > 1:
             self._agent.gradient_hook = self.strategy.all_reduce_sum_
+            # lets the graphed train step overlap the reduce of the dense layers' gradients with
+            # the conv layers' backward (two buckets)
+            self._agent.gradient_hook_async = getattr(self.strategy, "all_reduce_sum_async_", None)
         self._agent.initialize()
         # learner.py:309-337 runs the step inside tf.function; here: HIP-graph replay
         self._train_fn = self._agent.train

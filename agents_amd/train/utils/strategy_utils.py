@@ -43,6 +43,12 @@ class DataParallelStrategy(Strategy):
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self._pg)
         return tensor
 
+    def all_reduce_sum_async_(self, tensor):
+        """Starts an in-place SUM all-reduce and returns its Work handle; `handle.wait()` makes the
+        CURRENT stream wait for it (no host block).  RCCL runs it on its own stream after the work
+        already enqueued on the current stream, so kernels enqueued afterwards overlap with it."""
+        return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self._pg, async_op=True)
+
     def reduce_sum(self, tensor):
         out = tensor.clone()
         dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self._pg)

@@ -25,6 +25,7 @@ import torch
 from agents_amd.utils import nest_utils
 
 _WARMUP_CALLS = 2
+BUCKETED_ALLREDUCE = True   # False: one all-reduce of the whole gradient buffer after backward
 _MAX_BINDINGS = 16   # captured train graphs per input signature (one per sampler ring slot)
 
 # ---- capture context: host bookkeeping that must run once per replay ------------------------
@@ -197,6 +198,7 @@ class _Entry:
         self.static_w = None
         self.g_grads = None
         self.g_apply = None
+        self.g_grads_b = None     # bucket mode: second half of the backward
         self.captured = None
         self.out = None
 
@@ -294,6 +296,20 @@ class GraphedTrain:
                 if lanes is not None:
                     lanes.join()
                 e.captured.replay()
+            elif e.g_grads_b is not None:
+                # bucket mode (data-parallel): [forward + loss + dense-tail backward] -> start the
+                # all-reduce of the tail's gradients -> [conv backward] overlaps it -> all-reduce
+                # of the (small) head -> wait for both -> optimizer
+                tail, head = agent._q_network.grad_buckets(agent._bucket_split())
+                e.g_grads.replay()
+                w1 = agent.gradient_hook_async(tail)
+                e.g_grads_b.replay()
+                w2 = agent.gradient_hook_async(head)
+                w1.wait()
+                w2.wait()
+                e.g_apply.replay()
+                agent._optimizer.iterations += 1
+                agent._train_phase_host()
             else:
                 e.g_grads.replay()
                 if agent.gradient_hook is not None:
@@ -319,10 +335,19 @@ class GraphedTrain:
             return
         torch.cuda.synchronize()
         iters = agent._optimizer.iterations
+        bucketed = (getattr(agent, "gradient_hook_async", None) is not None and
+                    hasattr(agent, "_train_phase_grads_a") and agent._bucket_split() is not None
+                    and BUCKETED_ALLREDUCE)
         e.g_grads = torch.cuda.CUDAGraph()
         with _no_gc_during_capture(), torch.cuda.graph(e.g_grads,
                                                           capture_error_mode=_CAPTURE_MODE):
-            e.out = agent._train_phase_grads(e.static_in, w_arg)
+            e.out = agent._train_phase_grads_a(e.static_in, w_arg) if bucketed else \
+                agent._train_phase_grads(e.static_in, w_arg)
+        if bucketed:
+            e.g_grads_b = torch.cuda.CUDAGraph()
+            with _no_gc_during_capture(), torch.cuda.graph(e.g_grads_b,
+                                                              capture_error_mode=_CAPTURE_MODE):
+                agent._train_phase_grads_b()
         if g_apply is not None:
             e.g_apply = g_apply          # the optimizer phase does not depend on the inputs
         else:

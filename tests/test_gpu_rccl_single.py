@@ -59,3 +59,40 @@ def test_rccl_hook_between_train_graphs(dev):
         dist.destroy_process_group()
     assert replays > 15, "train graphs did not replay with the process group alive"
     assert torch.equal(params, ref_params) and loss == ref_loss
+
+
+def test_bucketed_allreduce_overlap_matches_single_bucket(dev):
+    """Bucket mode of the graphed train step (dense-tail gradients all-reduced asynchronously
+    while the conv layers are still in backward, then the head): same parameters as the single
+    synchronous all-reduce and as no process group at all."""
+    ref_params, ref_loss, _ = _run(dev, None)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        strat = strategy_utils.DataParallelStrategy()
+        results = {}
+        for bucketed in (True, False):
+            graph.BUCKETED_ALLREDUCE = bucketed
+            env, agent, rb, drv, net = _stack(dev, 8, 64, 0.2, 1)
+            run = common.function(drv.run)
+            lrn = learner.Learner(None, common.Variable(0), agent, strategy=strat)
+            agent.gradient_hook = strat.all_reduce_sum_
+            agent.gradient_hook_async = strat.all_reduce_sum_async_
+            assert agent._bucket_split() is not None
+            for _ in range(4):
+                run()
+            it = iter(rb.as_dataset(sample_batch_size=16, num_steps=2).prefetch(3))
+            for _ in range(30):
+                run()
+                li = lrn.run(iterations=1, iterator=it)
+            torch.cuda.synchronize()
+            gt = graph.graphed_train(agent)
+            ents = [e for b in gt._cache.values() for e in b.values()]
+            assert any(e.g_grads_b is not None for e in ents) == bucketed
+            results[bucketed] = (net.flat_params.clone(), float(li.loss))
+    finally:
+        graph.BUCKETED_ALLREDUCE = True
+        dist.destroy_process_group()
+    assert torch.equal(results[True][0], results[False][0])
+    assert torch.equal(results[True][0], ref_params) and results[True][1] == ref_loss
