@@ -116,6 +116,10 @@ def kernel_breakdown(w, S, reps=20):
     agent = w["agent"]
     rb = w["rb"]
     exp, _ = rb.get_next(S, 2)
+    # rank-local measurement: no collective may be issued here (the other ranks are not in it)
+    agent.gradient_hook = None
+    agent.gradient_hook_async = None
+    agent.num_replicas = 1
     agent.train(exp)  # make sure every buffer exists
     torch.cuda.synchronize()
     slot = net._slots[("train", S)]
@@ -261,12 +265,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with that many ranks "
                          f"(WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    # AA_BENCH_BACKEND=gloo AA_BENCH_SHARE_GPU=1: development aid -- runs the N-rank control flow
+    # (hooks, buckets, barriers, rank-0 breakdown) with every rank on GPU 0 when only one GPU exists
+    backend = os.environ.get("AA_BENCH_BACKEND", "nccl")
+    if os.environ.get("AA_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from agents_amd import _lib
     _lib.load()  # fail loudly if the HIP library is missing
