@@ -1,25 +1,38 @@
-"""IntervalTrigger: calls `fn` when the step value has advanced by at least `interval` since the
-last trigger.  Same behaviour as tf_agents/train/interval_trigger.py:24-74 (interval <= 0 never
-triggers; `force_trigger` fires unless the value equals the last trigger value)."""
+"""Step-interval trigger used by the Learner (role of tf_agents/train/interval_trigger.py:24-74).
+
+Behaviour contract taken from the reference:
+  * a non-positive interval disables the trigger altogether;
+  * the callback fires once the observed value is at least `interval` past the value at which it
+    last fired (the first reference point is `start`);
+  * `force_trigger=True` fires regardless of the distance, except when nothing has advanced since
+    the last firing;
+  * `reset()` returns the reference point to the constructor's `start`, `set_start(v)` moves it.
+"""
 
 
 class IntervalTrigger:
     def __init__(self, interval, fn, start=0):
-        self._interval = interval
-        self._original_start_value = start
-        self._last_trigger_value = start
-        self._fn = fn
+        self._every = interval
+        self._callback = fn
+        self._start0 = start
+        self._fired_at = start
+
+    @property
+    def enabled(self):
+        return self._every > 0
+
+    def _due(self, value, forced):
+        advanced = value != self._fired_at
+        far_enough = value - self._fired_at >= self._every
+        return far_enough or (forced and advanced)
 
     def __call__(self, value, force_trigger=False):
-        if self._interval <= 0:
-            return
-        if (force_trigger and value != self._last_trigger_value) or \
-                (value >= self._last_trigger_value + self._interval):
-            self._last_trigger_value = value
-            self._fn()
+        if self.enabled and self._due(value, force_trigger):
+            self._fired_at = value
+            self._callback()
 
     def reset(self):
-        self._last_trigger_value = self._original_start_value
+        self._fired_at = self._start0
 
     def set_start(self, start):
-        self._last_trigger_value = start
+        self._fired_at = start
