@@ -22,6 +22,7 @@ ARCH = "gfx950"
 # that elementwise arithmetic is bit-identical to the numpy oracle.
 SOURCES = [
     ("replay.hip", []),
+    ("prio.hip", []),
     ("gemm.hip", []),
     ("nn.hip", ["-ffp-contract=off"]),
     ("dense_small.hip", []),

@@ -115,6 +115,13 @@ _SIGNATURES = {
                                  c_void_p]),
     "aa_ppo_trajectory_mask": (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p]),
     "aa_ppo_update_kl_beta": (c_int, [c_void_p, c_float, c_float, c_void_p, c_void_p]),
+    "aa_prio_workspace_bytes": (c_int64, [c_int64]),
+    "aa_prio_sample_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                    c_uint64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
+    "aa_prio_set": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_int64, c_void_p,
+                            c_void_p, c_void_p]),
+    "aa_prio_on_add": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "aa_sac_sample": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
                               c_uint64] + [c_void_p] * 7),
     "aa_sac_head_backward": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32] +

@@ -1,0 +1,128 @@
+"""TFPrioritizedReplayBuffer: TFUniformReplayBuffer with proportional prioritized sampling.
+
+The reference has no such class (its prioritized replay is Reverb's, e.g.
+tf_agents/examples/dqn/gymnasium/d3qn_train_eval.py:162); BASELINE.json's north star asks for
+"uniform/segment-tree sampling", and the reference does carry the plumbing a prioritized buffer
+plugs into -- `DqnLossInfo.td_error` (agents/dqn/dqn_agent.py:50-72), `BufferInfo.ids` /
+`probabilities`, and `Learner(after_train_strategy_step_fn=...)` (train/learner.py:362-376):
+
+    rb = TFPrioritizedReplayBuffer(agent.collect_data_spec, batch_size=B, max_length=L)
+    learner = Learner(root, step, agent,
+                      after_train_strategy_step_fn=rb.update_priorities_from_loss)
+
+Everything of TFUniformReplayBuffer is kept (layout, add_batch, gather_all, datasets, validity of
+window starts); only `get_next` differs: start rows are drawn with P(i) = p_i / sum_j p_j
+(Schaul et al., 2016), `BufferInfo.probabilities` carries P(i) so callers can form importance
+weights, new rows enter with the running maximum priority, and `update_priorities` stores
+(|td_error| + eps)^alpha.  Kernels: csrc/prio.hip (flat two-level scan on uint32 fixed-point
+priorities -- exact sums, bit-exact indices against oracle/prioritized.py).
+"""
+import torch
+
+from agents_amd import _lib
+from agents_amd.replay_buffers import tf_uniform_replay_buffer as uniform
+from agents_amd.utils import graph
+
+BufferInfo = uniform.BufferInfo
+
+
+class TFPrioritizedReplayBuffer(uniform.TFUniformReplayBuffer):
+    def __init__(self, data_spec, batch_size, max_length=1000, priority_exponent=0.6,
+                 priority_epsilon=1e-6, initial_priority=1.0, **kwargs):
+        super().__init__(data_spec, batch_size, max_length, **kwargs)
+        self._alpha = float(priority_exponent)
+        self._eps = float(priority_epsilon)
+        dev = self._device
+        # validity of a row is decided by its STORED id here (uniform sampling draws ids, so it
+        # never sees an unwritten row): unwritten rows must not look like "id 0"
+        self._id_table.variables()[0].fill_(-1)
+        self._prio_q = torch.zeros((self._capacity,), dtype=torch.int32, device=dev)  # uint32 bits
+        q0 = min(max(int(round(float(initial_priority) * 65536.0)), 1), 2 ** 31 - 1)
+        self._max_prio_q = torch.full((1,), q0, dtype=torch.int32, device=dev)
+        lib = _lib.load()
+        self._prio_ws = torch.empty((max(int(lib.aa_prio_workspace_bytes(self._capacity)), 8),),
+                                    dtype=torch.uint8, device=dev)
+
+    @property
+    def priority_exponent(self):
+        return self._alpha
+
+    def priorities(self):
+        """Float32 view of the stored priorities ([capacity], 0 for never-written rows)."""
+        return (self._prio_q.to(torch.int64) & 0xFFFFFFFF).to(torch.float32) / 65536.0
+
+    # ---- writes ---------------------------------------------------------------------------------
+    def _add_batch(self, items):
+        super()._add_batch(items)
+        with torch.cuda.device(self._device):
+            _lib.check(_lib.load().aa_prio_on_add(
+                self._last_id.data_ptr(), self._batch_size, self._max_length,
+                self._max_prio_q.data_ptr(), self._prio_q.data_ptr(), _lib.stream_ptr()),
+                "aa_prio_on_add")
+
+    def _clear(self, clear_all_variables=False):
+        super()._clear(clear_all_variables)
+        self._id_table.variables()[0].fill_(-1)
+        self._prio_q.zero_()
+
+    def update_priorities(self, ids, priorities):
+        """p[row] = (|priority| + eps)^alpha.  `ids=None`: the window-start ROWS of the most recent
+        `get_next` (`self.last_sampled_rows`); otherwise explicit row indices (a global frame id
+        alone does not name the env block, so BufferInfo.ids cannot address a row)."""
+        rows = self.last_sampled_rows if ids is None else ids
+        if rows is None:
+            raise RuntimeError("update_priorities: nothing has been sampled yet")
+        rows = rows.reshape(-1).to(torch.int64).contiguous()
+        pr = priorities.reshape(-1).to(torch.float32).contiguous()
+        if rows.numel() != pr.numel():
+            raise ValueError("update_priorities needs one priority per sampled item")
+        graph.join_lanes(self._device)
+        with torch.cuda.device(self._device):
+            _lib.check(_lib.load().aa_prio_set(
+                rows.data_ptr(), pr.data_ptr(), rows.numel(), self._alpha, self._eps,
+                self._capacity, self._prio_q.data_ptr(), self._max_prio_q.data_ptr(),
+                _lib.stream_ptr()), "aa_prio_set")
+
+    def update_priorities_from_loss(self, experience_and_info, loss_info):
+        """Learner.after_train_strategy_step_fn adapter: priorities from DqnLossInfo.td_error of
+        the batch that was just trained on (the most recently sampled one)."""
+        self.update_priorities(None, loss_info.extra.td_error)
+
+    # ---- sampling -------------------------------------------------------------------------------
+    def _sample_rows(self, S, T):
+        lib = _lib.load()
+        rows = torch.empty((S, T), dtype=torch.int64, device=self._device)
+        probs = torch.empty((S,), dtype=torch.float32, device=self._device)
+        _lib.check(lib.aa_prio_sample_rows(
+            self._prio_q.data_ptr(), self._id_table.variables()[0].data_ptr(),
+            self._last_id.data_ptr(), self._batch_size, self._max_length, S, T, self._seed,
+            self._sample_calls_dev.data_ptr(), self._prio_ws.data_ptr(), self._prio_ws.numel(),
+            rows.data_ptr(), probs.data_ptr(), self._err_flag.data_ptr(), _lib.stream_ptr()),
+            "aa_prio_sample_rows")
+        graph.on_replay(self._bump_sample_calls)
+        self.last_sampled_rows = rows[:, 0]
+        return rows, probs
+
+    last_sampled_rows = None
+
+    def _as_dataset(self, sample_batch_size=None, num_steps=None, sequence_preprocess_fn=None,
+                    num_parallel_calls=None):
+        # priorities change between draws and `last_sampled_rows` must name the batch being
+        # trained on: no graph ring, no sampling ahead
+        ring, self._dataset_ring = self._dataset_ring, 0
+        try:
+            return super()._as_dataset(sample_batch_size, num_steps, sequence_preprocess_fn,
+                                       num_parallel_calls)
+        finally:
+            self._dataset_ring = ring
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["prio_q"] = self._prio_q.clone()
+        sd["max_prio_q"] = self._max_prio_q.clone()
+        return sd
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        self._prio_q.copy_(sd["prio_q"])
+        self._max_prio_q.copy_(sd["max_prio_q"])

@@ -322,6 +322,30 @@ int aa_ppo_update_kl_beta(const float* mean_kl_dev, float target, float toleranc
 int aa_add_l2_grad(float* g, const float* p, int64_t n, float c, void* stream);
 
 /* =========================================================================================
+ * Prioritized (proportional) sampling -- the north star's "segment-tree sampling".  No reference
+ * class to mirror (prioritisation exists there only through Reverb); plugs into the reference's
+ * hooks: DqnLossInfo.td_error (agents/dqn/dqn_agent.py:50-72), BufferInfo.ids and
+ * Learner.after_train_strategy_step_fn (train/learner.py:362-376).  Priorities are uint32 fixed
+ * point (2^-16 units): sums are exact uint64, sampled indices are bit-exact against the oracle.
+ * ========================================================================================= */
+int64_t aa_prio_workspace_bytes(int64_t capacity);
+/* S rows with P(row) = prio_q[row] / sum over rows whose stored id is a valid window start
+ * (tf_uniform_replay_buffer.py:610-635); rows_out[s,t] as aa_rb_sample_rows; prob_out[s] = that
+ * probability.  Advances *call_counter_dev by one. */
+int aa_prio_sample_rows(const uint32_t* prio_q, const int64_t* id_table,
+                        const int64_t* last_id_dev, int64_t batch, int64_t max_len, int64_t S,
+                        int64_t T, uint64_t seed, int64_t* call_counter_dev, void* workspace,
+                        int64_t workspace_bytes, int64_t* rows_out, float* prob_out,
+                        int* err_flag_dev, void* stream);
+/* prio_q[rows[i]] = clamp(round((|priorities[i]| + eps)^alpha * 65536), 1, 2^32-1);
+ * *max_prio_q_dev = max(itself, those). */
+int aa_prio_set(const int64_t* rows, const float* priorities, int64_t n, float alpha, float eps,
+                int64_t capacity, uint32_t* prio_q, uint32_t* max_prio_q_dev, void* stream);
+/* the rows add_batch just wrote (frame id *last_id_dev) take the running maximum priority */
+int aa_prio_on_add(const int64_t* last_id_dev, int64_t batch, int64_t max_len,
+                   const uint32_t* max_prio_q_dev, uint32_t* prio_q, void* stream);
+
+/* =========================================================================================
  * SAC  (agents/sac/sac_agent.py:314-410, 533-740; agents/sac/tanh_normal_projection_network.py;
  *       distributions/utils.py:40-160 SquashToSpecNormal)
  * ========================================================================================= */
