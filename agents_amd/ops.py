@@ -138,6 +138,7 @@ FORCE_NO_DMA = False
 # Dense layers with at most SMALL_N output units (Q / value heads) take the dedicated small-N
 # kernels (csrc/dense_small.hip) instead of an MFMA GEMM launch; USE_SMALL_N = False is a test knob.
 SMALL_N = 16
+SMALL_DW_MAX_M = 512
 USE_SMALL_N = True
 # a_mode values whose contractions take the LDS-DMA loop (tuning knob, env AA_DMA_MODES="3,4,5")
 import os as _os
@@ -208,7 +209,9 @@ def dense_dw(x, dz, out, force_cfg=0, force_splits=0, bias_grad=None):
     M2, N = dz.shape
     if M != M2 or tuple(out.shape) != (K, N):
         raise ValueError("dense_dw shape mismatch")
-    if N <= SMALL_N and not force_cfg and not force_splits and USE_SMALL_N:
+    # (one workgroup per 64 weight rows walks all M samples: right for the DQN head's M = 256,
+    # 100 us at PPO's M = 4,096 where the split-K GEMM takes 13 us)
+    if N <= SMALL_N and M <= SMALL_DW_MAX_M and not force_cfg and not force_splits and USE_SMALL_N:
         check(_lib.load().aa_dense_small_dw(ptr(x), lda, ptr(dz), M, K, N, ptr(out),
                                             _bias_grad_ptr(bias_grad, N), stream_ptr()),
               "aa_dense_small_dw")
