@@ -319,13 +319,14 @@ class PPOAgent(tf_agent.TFAgent):
         return w["stats"]
 
     def _loss_info_from_stats(self, stats, l2):
-        s = stats
+        """LossInfo whose fields are views of ONE private copy of the stats vector (the work
+        buffer is overwritten by the next evaluation)."""
+        s = stats[:8].clone()
         total = s[6] + l2
-        return tf_agent.LossInfo(total.reshape(()).clone(), PPOLossInfo(
-            policy_gradient_loss=s[0].clone(), value_estimation_loss=s[1].clone(),
+        return tf_agent.LossInfo(total.reshape(()), PPOLossInfo(
+            policy_gradient_loss=s[0], value_estimation_loss=s[1],
             l2_regularization_loss=l2.clone() if isinstance(l2, torch.Tensor) else l2,
-            entropy_regularization_loss=s[2].clone(), kl_penalty_loss=s[5].clone(),
-            clip_fraction=s[3].clone()))
+            entropy_regularization_loss=s[2], kl_penalty_loss=s[5], clip_fraction=s[3]))
 
     def get_loss(self, time_steps, actions, act_log_probs, returns, normalized_advantages,
                  action_distribution_parameters, weights, train_step=None, debug_summaries=False,
@@ -428,7 +429,7 @@ class PPOAgent(tf_agent.TFAgent):
                 self._optimizer.apply_flat(self.flat_params, self.flat_grads)
                 graph.on_replay(self._bump_train_step)
                 acc = acc + stats[:6]
-            loss_info = self._loss_info_from_stats(stats.clone(), l2)
+            loss_info = self._loss_info_from_stats(stats, l2)
             self._clip_fraction = stats[3].clone()
             if self._initial_adaptive_kl_beta > 0:
                 # mean KL(old || current) * mask after the update epochs -> beta update

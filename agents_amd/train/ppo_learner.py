@@ -18,8 +18,11 @@ shuffle buffer is filled from the repeated stream, so with a large buffer it can
 epochs), and in multi-GPU runs every rank runs all of ITS minibatches (one process per GPU with
 its own replay shard) instead of dividing one dataset's batches by the replica count.
 """
+import ctypes
+
 import torch
 
+from agents_amd import _lib
 from agents_amd.train import learner
 from agents_amd.utils import nest_utils
 
@@ -112,12 +115,22 @@ class PPOLearner:
             self._mb_key = key
         bufs = self._mb_buffers
         views = nest_utils.map_structure(lambda t: t.unsqueeze(1), bufs)
+        # every leaf of the minibatch in ONE row-gather launch (the replay table's gather kernel)
+        srcs = [t.contiguous() for t in nest_utils.flatten(frames)]
+        dsts = nest_utils.flatten(bufs)
+        n = len(srcs)
+        c_src = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs])
+        c_dst = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dsts])
+        c_rb = (ctypes.c_int64 * n)(*[t.element_size() * int(t[0].numel()) for t in srcs])
+        lib = _lib.load()
         for _ in range(self._num_epochs):
             perm = torch.randperm(F, device=dev, generator=self._gen)
             for i in range(F // mb):
                 idx = perm[i * mb:(i + 1) * mb]
-                for src, dst in zip(nest_utils.flatten(frames), nest_utils.flatten(bufs)):
-                    torch.index_select(src, 0, idx, out=dst)
+                with torch.cuda.device(dev):
+                    _lib.check(lib.aa_rb_gather_rows(c_src, c_dst, c_rb, n, None, None,
+                                                     idx.data_ptr(), mb, _lib.stream_ptr()),
+                               "aa_rb_gather_rows")
                 yield views, None
 
     def _full_batches(self, samples):
