@@ -23,50 +23,60 @@ __device__ static inline float aa_softplus_f(float t) {
   return fmaxf(t, 0.f) + log1pf(expf(-fabsf(t)));
 }
 
-// One thread per sample.  z = [mean | raw_std] (the projection Dense output, [B, 2A]).
-// eps_in (nullable): externally supplied N(0,1) noise [B, A]; else Box-Muller on
-// Philox(counter = (b*A+d, call), key = seed) like aa_normal_sample.
+// One thread per (sample, action dimension); the A per-dimension log-density terms of a sample are
+// then summed in dimension order by its d == 0 thread through LDS (deterministic; a thread per
+// sample walking 17 dimensions of exp / log / tanh / Philox took 18 us for 256 samples).
+// z = [mean | raw_std] (the projection Dense output, [B, 2A]).  eps_in (nullable): externally
+// supplied N(0,1) noise [B, A]; else Box-Muller on Philox(counter = (b*A+d, call), key = seed)
+// like aa_normal_sample.  Requires A <= 256 (one sample never straddles a workgroup).
 __global__ void __launch_bounds__(256)
-aa_sac_sample_kernel(const float* __restrict__ z, int64_t B, int A,
+aa_sac_sample_kernel(const float* __restrict__ z, int64_t B, int A, int per_block,
                      const float* __restrict__ act_mean, const float* __restrict__ act_mag,
                      int std_kind, const float* __restrict__ eps_in, uint32_t seed_lo,
                      uint32_t seed_hi, const int64_t* __restrict__ call_counter,
                      float* __restrict__ action, float* __restrict__ logp,
                      float* __restrict__ save_tanh, float* __restrict__ save_sigma,
                      float* __restrict__ save_eps) {
+  __shared__ float terms[256];
   const uint64_t call = call_counter != nullptr ? (uint64_t)call_counter[0] : 0ull;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride) {
-    float lp = 0.f;
-    for (int d = 0; d < A; ++d) {
-      const float mu = z[b * 2 * A + d];
-      float raw = z[b * 2 * A + A + d];
-      if (std_kind == AA_SAC_STD_CLIP_EXP) raw = fminf(fmaxf(raw, -20.f), 2.f);
-      const float sigma = expf(raw);
-      float eps;
-      if (eps_in != nullptr) {
-        eps = eps_in[b * A + d];
-      } else {
-        const uint64_t i = (uint64_t)(b * A + d);
-        const Philox4 r = philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)call,
-                                        (uint32_t)(call >> 32), seed_lo, seed_hi);
-        const float u1 = 1.0f - aa_u01(r.x);
-        const float u2 = aa_u01(r.y);
-        eps = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
-      }
-      const float x = mu + sigma * eps;
-      const float t = tanhf(x);
-      const float mag = act_mag[d];
-      action[b * A + d] = act_mean[d] + mag * t;
-      const float e = (x - mu) / sigma;   // what MultivariateNormalDiag.log_prob recomputes
-      const float fldj = 2.0f * (AA_LOG2_SAC - x - aa_softplus_f(-2.0f * x));
-      lp += -0.5f * (e * e) - logf(sigma) - AA_HALF_LOG_2PI_SAC - logf(fabsf(mag)) - fldj;
-      if (save_tanh != nullptr) {
-        save_tanh[b * A + d] = t;
-        save_sigma[b * A + d] = sigma;
-        save_eps[b * A + d] = eps;
-      }
+  const int local = threadIdx.x / A, d = threadIdx.x - local * A;
+  const int64_t b = (int64_t)blockIdx.x * per_block + local;
+  const bool live = local < per_block && b < B;
+  float term = 0.f;
+  if (live) {
+    const float mu = z[b * 2 * A + d];
+    float raw = z[b * 2 * A + A + d];
+    if (std_kind == AA_SAC_STD_CLIP_EXP) raw = fminf(fmaxf(raw, -20.f), 2.f);
+    const float sigma = expf(raw);
+    float eps;
+    if (eps_in != nullptr) {
+      eps = eps_in[b * A + d];
+    } else {
+      const uint64_t i = (uint64_t)(b * A + d);
+      const Philox4 r = philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)call,
+                                      (uint32_t)(call >> 32), seed_lo, seed_hi);
+      const float u1 = 1.0f - aa_u01(r.x);
+      const float u2 = aa_u01(r.y);
+      eps = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
     }
+    const float x = mu + sigma * eps;
+    const float t = tanhf(x);
+    const float mag = act_mag[d];
+    action[b * A + d] = act_mean[d] + mag * t;
+    const float e = (x - mu) / sigma;   // what MultivariateNormalDiag.log_prob recomputes
+    const float fldj = 2.0f * (AA_LOG2_SAC - x - aa_softplus_f(-2.0f * x));
+    term = -0.5f * (e * e) - logf(sigma) - AA_HALF_LOG_2PI_SAC - logf(fabsf(mag)) - fldj;
+    if (save_tanh != nullptr) {
+      save_tanh[b * A + d] = t;
+      save_sigma[b * A + d] = sigma;
+      save_eps[b * A + d] = eps;
+    }
+  }
+  terms[threadIdx.x] = term;
+  __syncthreads();
+  if (live && d == 0) {
+    float lp = 0.f;
+    for (int k = 0; k < A; ++k) lp += terms[local * A + k];   // dimension order, as before
     logp[b] = lp;
   }
 }
@@ -220,10 +230,12 @@ int aa_sac_sample(const float* z, int64_t B, int32_t A, const float* act_mean,
   if ((save_tanh == nullptr) != (save_sigma == nullptr) ||
       (save_tanh == nullptr) != (save_eps == nullptr))
     return AA_ERR_INVALID;
-  int64_t blocks = (B + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  if (A > 256) return AA_ERR_RANGE;
+  const int per_block = 256 / A;
+  const int64_t blocks = (B + per_block - 1) / per_block;
+  if (blocks > 0x7fffffffLL) return AA_ERR_RANGE;
   hipLaunchKernelGGL(aa_sac_sample_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                     (hipStream_t)stream, z, B, A, act_mean, act_mag, std_kind, eps_in,
+                     (hipStream_t)stream, z, B, A, per_block, act_mean, act_mag, std_kind, eps_in,
                      (uint32_t)seed, (uint32_t)(seed >> 32), call_counter_dev, action, logp,
                      save_tanh, save_sigma, save_eps);
   return aa_launch_status();
