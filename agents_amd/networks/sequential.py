@@ -20,6 +20,9 @@ from agents_amd.networks import network
 from agents_amd.utils import nest_utils
 
 
+DX_FIRST = True   # record a layer's input-gradient launch before its weight-gradient launch
+
+
 def _align4(n):
     return (n + 3) // 4 * 4
 
@@ -373,10 +376,11 @@ class Sequential(network.Network):
         if side_stream is None:
             side_stream = main
 
-        def on_side(fn):
+        def on_side(fn, fork=True):
             if side_stream is main:
                 return fn()
-            side_stream.wait_stream(main)  # dZ of this layer is ready once main gets here
+            if fork:
+                side_stream.wait_stream(main)  # dZ of this layer is ready once main gets here
             with torch.cuda.stream(side_stream):
                 return fn()
 
@@ -385,31 +389,44 @@ class Sequential(network.Network):
             ks = self._shapes[i][0]
             x = s.xs[i]
             prev_act = self._param_layers[i - 1].activation if i > 0 else None
+            # The input gradient (critical chain) is enqueued BEFORE the layer's weight gradient:
+            # both only read this layer's dZ, and the order in which the two branches are recorded
+            # decides which one the HIP-graph executor keeps on the chain's queue.
             if isinstance(l, L.Dense):
                 dz2 = dz.view(B, -1)
-                if param_grads:
-                    on_side(lambda: ops.dense_dw(x, dz2, self._gkviews[i],
-                                                 bias_grad=self._gbviews[i]))
+                dz_next = None
                 if i == 0 and input_grad is not None:
                     ops.dense_dx(dz2, self._kviews[0], input_grad.view(B, -1))
                 if i > 0:
                     dx = s.dxs[i].view(B, -1)
+                    if DX_FIRST:
+                        side_stream.wait_stream(main) if side_stream is not main else None
                     ops.dense_dx(dz2, self._kviews[i], dx, mask_src=x if prev_act else None,
                                  mask_act=prev_act)
-                    dz = s.dxs[i]
+                    dz_next = s.dxs[i]
+                if param_grads:
+                    on_side(lambda: ops.dense_dw(x, dz2, self._gkviews[i],
+                                                 bias_grad=self._gbviews[i]), fork=not DX_FIRST)
+                if dz_next is not None:
+                    dz = dz_next
             else:
                 F = ks[3]
                 dz2 = dz.view(-1, F)
                 if i == 0 and input_grad is not None:
                     raise NotImplementedError("input_grad is implemented for a Dense first layer")
+                dz_next = None
+                if i > 0:
+                    if DX_FIRST:
+                        side_stream.wait_stream(main) if side_stream is not main else None
+                    ops.conv_dx(dz2, self._kviews[i], tuple(x.shape), l.stride, s.dcol, s.dxs[i],
+                                mask_src=x if prev_act else None, mask_act=prev_act)
+                    dz_next = s.dxs[i]
                 if param_grads:
                     on_side(lambda: ops.conv_dw(x, dz2, ks, l.stride, self._gkviews[i],
                                                 a_div=self._first_div() if i == 0 else 1.0,
-                                                bias_grad=self._gbviews[i]))
-                if i > 0:
-                    ops.conv_dx(dz2, self._kviews[i], tuple(x.shape), l.stride, s.dcol, s.dxs[i],
-                                mask_src=x if prev_act else None, mask_act=prev_act)
-                    dz = s.dxs[i]
+                                                bias_grad=self._gbviews[i]), fork=not DX_FIRST)
+                if dz_next is not None:
+                    dz = dz_next
         if side_stream is not main:
             main.wait_stream(side_stream)
 

@@ -10,10 +10,12 @@ torch.cuda.set_device(dev)
 w = bench.build_workload(dev, 0, 1, 256, 64, 256, seed=1)
 w["init_driver"]._num_steps = 256 * 64
 w["init_driver"].run()
+from agents_amd.utils import common
 it = iter(w["dataset"])
+run = common.function(w["collect_driver"].run)
 ts = None
 for _ in range(N):
-    ts, _ = w["collect_driver"].run(ts)
+    ts, _ = run(ts)
     w["learner"].run(iterations=1, iterator=it)
 torch.cuda.synchronize()
 print("done")
