@@ -307,6 +307,8 @@ class GraphedTrain:
                 w2 = agent.gradient_hook_async(head)
                 w1.wait()
                 w2.wait()
+                if lanes is not None and lanes.collect_done is not None:
+                    torch.cuda.current_stream(dev).wait_event(lanes.collect_done)
                 e.g_apply.replay()
                 agent._optimizer.iterations += 1
                 agent._train_phase_host()
