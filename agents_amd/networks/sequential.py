@@ -20,6 +20,7 @@ from agents_amd.networks import network
 from agents_amd.utils import nest_utils
 
 
+SMALL_HEAD_ON_MAIN = True
 DX_FIRST = True   # record a layer's input-gradient launch before its weight-gradient launch
 
 
@@ -405,8 +406,13 @@ class Sequential(network.Network):
                                  mask_act=prev_act)
                     dz_next = s.dxs[i]
                 if param_grads:
-                    on_side(lambda: ops.dense_dw(x, dz2, self._gkviews[i],
-                                                 bias_grad=self._gbviews[i]), fork=not DX_FIRST)
+                    if dz2.shape[1] <= ops.SMALL_N and SMALL_HEAD_ON_MAIN:
+                        # a few-microsecond head kernel: a cross-queue fork costs more than it hides
+                        ops.dense_dw(x, dz2, self._gkviews[i], bias_grad=self._gbviews[i])
+                    else:
+                        on_side(lambda: ops.dense_dw(x, dz2, self._gkviews[i],
+                                                     bias_grad=self._gbviews[i]),
+                                fork=not DX_FIRST)
                 if dz_next is not None:
                     dz = dz_next
             else:
