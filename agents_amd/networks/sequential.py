@@ -392,7 +392,9 @@ class Sequential(network.Network):
             prev_act = self._param_layers[i - 1].activation if i > 0 else None
             # The input gradient (critical chain) is enqueued BEFORE the layer's weight gradient:
             # both only read this layer's dZ, and the order in which the two branches are recorded
-            # decides which one the HIP-graph executor keeps on the chain's queue.
+            # decides which one the HIP-graph executor keeps on the chain's queue.  The side stream
+            # forks from main right BEFORE dX(i) is enqueued (main then holds dX(i+1), the producer
+            # of this layer's dZ); layer 0 has no dX, so its dW forks on its own.
             if isinstance(l, L.Dense):
                 dz2 = dz.view(B, -1)
                 dz_next = None
@@ -412,7 +414,7 @@ class Sequential(network.Network):
                     else:
                         on_side(lambda: ops.dense_dw(x, dz2, self._gkviews[i],
                                                      bias_grad=self._gbviews[i]),
-                                fork=not DX_FIRST)
+                                fork=not (DX_FIRST and i > 0))
                 if dz_next is not None:
                     dz = dz_next
             else:
@@ -430,7 +432,7 @@ class Sequential(network.Network):
                 if param_grads:
                     on_side(lambda: ops.conv_dw(x, dz2, ks, l.stride, self._gkviews[i],
                                                 a_div=self._first_div() if i == 0 else 1.0,
-                                                bias_grad=self._gbviews[i]), fork=not DX_FIRST)
+                                                bias_grad=self._gbviews[i]), fork=not (DX_FIRST and i > 0))
                 if dz_next is not None:
                     dz = dz_next
         if side_stream is not main:
