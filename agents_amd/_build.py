@@ -26,6 +26,7 @@ SOURCES = [
     ("gemm.hip", []),
     ("nn.hip", ["-ffp-contract=off"]),
     ("dense_small.hip", []),
+    ("mlp_small.hip", []),
     ("dqn.hip", ["-ffp-contract=off"]),
     ("optim.hip", ["-ffp-contract=off"]),
     ("rollout.hip", ["-ffp-contract=off"]),

@@ -66,6 +66,14 @@ _SIGNATURES = {
                                   c_void_p, c_void_p]),
     "aa_dense_small_dw": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p,
                                   c_void_p, c_void_p]),
+    "aa_mlp_small_forward": (c_int, [c_void_p, c_int64, c_void_p, c_int32, POINTER(c_int32),
+                                     POINTER(c_int32), POINTER(c_int64), POINTER(c_int64), c_int64,
+                                     POINTER(c_void_p), c_void_p]),
+    "aa_mlp_small_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "aa_mlp_small_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int32, POINTER(c_int32),
+                                      POINTER(c_int32), POINTER(c_int64), POINTER(c_int64), c_int64,
+                                      POINTER(c_void_p), c_void_p, c_void_p, c_int64, c_void_p,
+                                      c_void_p, c_int64, c_void_p]),
     "aa_colsum_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "aa_colsum_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64,
                               c_void_p]),

@@ -11,6 +11,8 @@ second one of identical layout (`flat_grads`) -- kernel then bias per layer, eve
 on a 16-byte boundary -- so the optimizer, the target-network update and the RCCL gradient
 all-reduce are each a single pass over one contiguous range.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -21,6 +23,7 @@ from agents_amd.utils import nest_utils
 
 
 SMALL_HEAD_ON_MAIN = True
+FUSED_SMALL_MLP = True   # whole <=64-wide MLPs in one forward / one backward launch
 DX_FIRST = True   # record a layer's input-gradient launch before its weight-gradient launch
 
 
@@ -288,6 +291,8 @@ class Sequential(network.Network):
                              f"{tuple(spec.shape)}")
         B = x.shape[0]
         s = self._slot(slot, B, need_grad)
+        if self._fused_small_ok() and x.dtype == torch.float32:
+            return self._forward_fused(x, s, B)
         cur = x
         div = None
         pi = 0
@@ -322,6 +327,65 @@ class Sequential(network.Network):
                 pi += 1
         return cur
 
+    # ---- fused small-MLP path (csrc/mlp_small.hip) -----------------------------------------------
+    def _fused_small_ok(self):
+        """Every parametrised layer is Dense, at most 4 of them, every width (and the input) <= 64:
+        the whole stack runs as ONE forward launch and ONE backward launch (+ slab reduce)."""
+        ok = getattr(self, "_fused_ok", None)
+        if ok is None:
+            ok = False
+            if FUSED_SMALL_MLP and self._built and 1 <= len(self._param_layers) <= 4 and \
+                    all(isinstance(l, (L.Dense, L.Flatten)) for l in self._layers):
+                n0 = int(np.prod(self._input_tensor_spec.shape))
+                widths = [n0] + [ks[1] for ks, _ in self._shapes]
+                ok = all(1 <= w_ <= 64 for w_ in widths) and \
+                    all(l.activation in (None, "relu", "tanh") for l in self._param_layers)
+                if ok:
+                    n = len(self._param_layers)
+                    self._f_dims = (ctypes.c_int32 * (n + 1))(*widths)
+                    self._f_acts = (ctypes.c_int32 * n)(*[ops.ACT[l.activation]
+                                                          for l in self._param_layers])
+                    self._f_koff = (ctypes.c_int64 * n)(*[o[0] for o in self._offsets])
+                    self._f_boff = (ctypes.c_int64 * n)(*[o[1] for o in self._offsets])
+                    self._f_ws = {}
+            self._fused_ok = ok
+        return ok and FUSED_SMALL_MLP
+
+    def _fused_ptrs(self, s):
+        n = len(self._param_layers)
+        return (ctypes.c_void_p * n)(*[y.data_ptr() for y in s.ys])
+
+    def _forward_fused(self, x, s, B):
+        x2 = x.reshape(B, -1)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        n = len(self._param_layers)
+        s.xs[0] = x2
+        for i in range(1, n):
+            s.xs[i] = s.ys[i - 1]
+        _lib.check(_lib.load().aa_mlp_small_forward(
+            x2.data_ptr(), x2.shape[1], self.flat_params.data_ptr(), n, self._f_dims,
+            self._f_acts, self._f_koff, self._f_boff, B, self._fused_ptrs(s), _lib.stream_ptr()),
+            "aa_mlp_small_forward")
+        return s.ys[-1]
+
+    def _backward_fused(self, dout, s, B, input_grad):
+        lib = _lib.load()
+        n = len(self._param_layers)
+        total = self.flat_grads.numel()
+        need = int(lib.aa_mlp_small_workspace_bytes(B, total))
+        ws = self._f_ws.get(B)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty((need,), dtype=torch.uint8, device=self.flat_grads.device)
+            self._f_ws[B] = ws
+        x2 = s.xs[0]
+        _lib.check(lib.aa_mlp_small_backward(
+            x2.data_ptr(), x2.shape[1], self.flat_params.data_ptr(), n, self._f_dims,
+            self._f_acts, self._f_koff, self._f_boff, B, self._fused_ptrs(s),
+            dout.contiguous().data_ptr(), self.flat_grads.data_ptr(), total,
+            None if input_grad is None else input_grad.data_ptr(), ws.data_ptr(), ws.numel(),
+            _lib.stream_ptr()), "aa_mlp_small_backward")
+
     def backward(self, dout, slot=0, side_stream=None, param_grads=True, input_grad=None,
                  stop_layer=0):
         """Given d loss / d output [B, out], fills flat_grads (overwrites).
@@ -341,6 +405,9 @@ class Sequential(network.Network):
         s = self._slots.get((slot, B))
         if s is None or s.dz_top is None or s.xs[0] is None:
             raise RuntimeError("backward() needs a preceding forward(..., need_grad=True)")
+        if self._fused_small_ok() and param_grads and stop_layer == 0 and \
+                s.xs[0].dtype == torch.float32 and s.xs[0].dim() == 2:
+            return self._backward_fused(dout, s, B, input_grad)
         lib = _lib.load()
         n = len(self._param_layers)
         top = self._param_layers[-1]

@@ -138,6 +138,24 @@ int aa_dense_small_dx(const float* dz, const float* w, const float* mask_src /* 
 int aa_dense_small_dw(const float* x, int64_t ldx, const float* dz, int64_t M, int32_t K,
                       int32_t N, float* dw, float* db /* nullable */, void* stream);
 
+/* Whole small MLPs (<= 4 Dense layers, every width <= 64: the PPO actor / value networks,
+ * agents/ppo/ppo_actor_network.py:42-113) forward and backward in ONE launch each, activations and
+ * the layer's weights staged in LDS, instead of one GEMM launch (+ reduce, + bias column sum) per
+ * layer.  params / grads: flat fp32 buffers, layer l's kernel [dims[l]][dims[l+1]] at k_off[l], bias
+ * at b_off[l].  y_*_h: host array of n_layers device pointers, layer l's output [B, dims[l+1]].
+ * backward: dy = d loss / d (last layer output); grads is overwritten (deterministic slab sum);
+ * dx_out nullable. */
+#define AA_MLP_MAX_LAYERS 4
+int aa_mlp_small_forward(const float* x, int64_t ldx, const float* params, int32_t n_layers,
+                         const int32_t* dims, const int32_t* acts, const int64_t* k_off,
+                         const int64_t* b_off, int64_t B, float* const* y_out_h, void* stream);
+int64_t aa_mlp_small_workspace_bytes(int64_t B, int64_t total_params);
+int aa_mlp_small_backward(const float* x, int64_t ldx, const float* params, int32_t n_layers,
+                          const int32_t* dims, const int32_t* acts, const int64_t* k_off,
+                          const int64_t* b_off, int64_t B, float* const* y_h, const float* dy,
+                          float* grads, int64_t total_params, float* dx_out, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+
 /* out[n] = sum_m x[m*ld + n]  (bias gradients).  workspace >= aa_colsum_workspace_bytes. */
 int64_t aa_colsum_workspace_bytes(int64_t M, int64_t N);
 int aa_colsum_f32(const float* x, int64_t ld, int64_t M, int64_t N, float* out, void* workspace,
