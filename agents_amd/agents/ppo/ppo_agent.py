@@ -126,6 +126,7 @@ class PPOAgent(tf_agent.TFAgent):
         self.gradient_hook = None
         self._clip_fraction = 0.0
         self._grad_norm = None
+        self._zero = None
 
     # ---- accessors ------------------------------------------------------------------------------
     @property
@@ -414,8 +415,9 @@ class PPOAgent(tf_agent.TFAgent):
                        "aa_normalize_moments")
             old_vpred = info["value_prediction"].reshape(N).contiguous()
             obs = self._flat_obs(processed.observation)
-            acc = torch.zeros((6,), dtype=torch.float32, device=dev)
-            l2 = torch.zeros((), dtype=torch.float32, device=dev)
+            if self._zero is None:
+                self._zero = torch.zeros((), dtype=torch.float32, device=dev)
+            l2 = self._zero
             stats = None
             for _ in range(self._num_epochs):
                 stats = self._loss_forward_backward(
@@ -428,9 +430,8 @@ class PPOAgent(tf_agent.TFAgent):
                     self.gradient_hook(self.flat_grads)
                 self._optimizer.apply_flat(self.flat_params, self.flat_grads)
                 graph.on_replay(self._bump_train_step)
-                acc = acc + stats[:6]
             loss_info = self._loss_info_from_stats(stats, l2)
-            self._clip_fraction = stats[3].clone()
+            self._clip_fraction = loss_info.extra.clip_fraction
             if self._initial_adaptive_kl_beta > 0:
                 # mean KL(old || current) * mask after the update epochs -> beta update
                 s2 = self._loss_forward_backward(

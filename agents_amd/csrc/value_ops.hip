@@ -129,6 +129,37 @@ aa_apply_norm_kernel(const float* __restrict__ x, int64_t n, const float* __rest
     out[i] = x[i] * inv + shift;
 }
 
+// n <= AA_NORM_SMALL (a PPO minibatch): mean, variance and the normalisation in ONE single-block
+// launch instead of five (same two-pass definition; the block-wide sums are in a fixed order).
+#define AA_NORM_SMALL 16384
+__global__ void __launch_bounds__(1024)
+aa_normalize_small_kernel(const float* __restrict__ x, int n, float eps, float* __restrict__ out,
+                          float* __restrict__ stats) {
+  __shared__ float red[16];
+  __shared__ float bc[2];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) s += x[i];
+  float t = aa_block_sum(s, red);
+  if (threadIdx.x == 0) bc[0] = t / (float)n;
+  __syncthreads();
+  const float mean = bc[0];
+  float d = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const float dl = x[i] - mean;
+    d += dl * dl;
+  }
+  t = aa_block_sum(d, red);
+  if (threadIdx.x == 0) {
+    bc[1] = t / (float)n;
+    stats[0] = mean;
+    stats[1] = bc[1];
+  }
+  __syncthreads();
+  const float inv = 1.0f / sqrtf(bc[1] + eps);
+  const float shift = -mean * inv;
+  for (int i = threadIdx.x; i < n; i += 1024) out[i] = x[i] * inv + shift;
+}
+
 #define AA_NORM_P 256
 
 extern "C" {
@@ -160,6 +191,11 @@ int aa_normalize_moments(const float* x, int64_t n, float eps, float* out, float
                          void* stream) {
   if (!x || !out || !stats_out || n <= 0) return AA_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
+  if (n <= AA_NORM_SMALL) {
+    hipLaunchKernelGGL(aa_normalize_small_kernel, dim3(1), dim3(1024), 0, st, x, (int)n, eps, out,
+                       stats_out);
+    return aa_launch_status();
+  }
   float* partial = stats_out + 2;
   int P = (int)((n + 255) / 256);
   if (P > AA_NORM_P) P = AA_NORM_P;
