@@ -1,0 +1,208 @@
+// Conv2D forward on uint8 frames with 32 filters (the Atari conv1 of the Mnih-15 Q-network,
+// examples/dqn/mnih15/dqn_train_eval_atari.py:80-112) on the bf16 matrix cores, at fp32 accuracy.
+//
+//   y[pix][f] = act( (sum_k u8[pix][k] * w[k][f]) / a_div + bias[f] )
+//
+// Why this is as accurate as the fp32 MFMA path: a byte is exactly representable in bf16 (8
+// significant bits); an fp32 weight is EXACTLY the sum of three round-to-nearest bf16 pieces
+// (hi + mid + lo carry 3 x 8 significant bits plus the sign trick of RN residuals); every
+// byte x piece product is exact in fp32 (<= 16 significant bits); so the three MFMA chains
+// accumulate exact products in fp32 -- the only roundings are the accumulations, as in the fp32
+// kernel -- and the Lambda(x / 255) of the reference is applied once to the sum by an IEEE
+// division instead of per element at operand fetch.  v_mfma_f32_32x32x16_bf16 runs at 16x the
+// fp32 MFMA rate, so three pieces cost 3/16 of the fp32 MFMA time, and the byte -> bf16
+// conversion is 1.5 VALU per element (v_cvt_f32_ubyteN + v_perm) against 4 VALU + an LDS
+// round trip for the exact (float)u8 / 255 of the fp32 loader.
+//
+// Layout: a wave owns TPW 32-pixel tiles x all 32 filters.  The A fragments come straight from
+// global memory in MFMA layout: lane (r = lane & 31, h = lane >> 5) loads the 16 bytes
+// [16h, 16h+16) of a 32-byte chunk of patch row ky of pixel r -- two MFMAs' worth (bytes 0-7 and
+// 8-15).  K is permuted accordingly; the filter bank is split and stored in LDS in exactly that
+// permuted fragment order ([piece][chunk*2 + q][h][filter] x 8 bf16 = one conflict-free
+// ds_read_b128 per fragment), once per workgroup, and each fragment is reused by the TPW tiles.
+// No LDS traffic for A, no barrier in the main loop.
+#pragma once
+
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+
+#define AA_CU8_THREADS 256
+#define AA_CU8_MAX_K 320   /* 3 * K * 64 B of LDS <= 60 KiB */
+
+__device__ static inline unsigned aa_bf16_rn_bits(float x) {   // finite x
+  unsigned u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ static inline float aa_bf16_to_f32(unsigned b) { return __uint_as_float(b << 16); }
+
+// four bytes of `d` -> four bf16 (two packed dwords); exact
+__device__ static inline void aa_u8x4_to_bf16(unsigned d, unsigned& lo, unsigned& hi) {
+  // (float)((d >> 8n) & 255) selects v_cvt_f32_ubyte<n>
+  const unsigned f0 = __float_as_uint((float)(d & 255u));
+  const unsigned f1 = __float_as_uint((float)((d >> 8) & 255u));
+  const unsigned f2 = __float_as_uint((float)((d >> 16) & 255u));
+  const unsigned f3 = __float_as_uint((float)(d >> 24));
+  lo = __builtin_amdgcn_perm(f1, f0, 0x07060302u);   // {f1[31:16], f0[31:16]}
+  hi = __builtin_amdgcn_perm(f3, f2, 0x07060302u);
+}
+
+union AaFrag {
+  uint4 q;
+  bf16x8_t v;
+};
+
+template <int TPW, int NCH>
+__global__ void __launch_bounds__(AA_CU8_THREADS)
+aa_conv_u8_bf16x3_kernel(GemmP p, int n_super, int nch_rt) {
+  extern __shared__ __attribute__((aligned(16))) uint4 wfrag[];   // [3][J][2][32]
+  const int nch = NCH > 0 ? NCH : nch_rt;     // 32-byte chunks per patch = KH * seg / 32
+  const int J = nch * 2;
+  const int R = p.seg >> 5;
+  const int tid = threadIdx.x;
+
+  // ---- filter bank: fp32 [K][32] -> three bf16 pieces in fragment order --------------------
+  for (int item = tid; item < (p.K >> 3) * 32; item += AA_CU8_THREADS) {
+    const int c = item & 31, k0 = (item >> 5) << 3;
+    const int ky = k0 / p.seg, rem = k0 - ky * p.seg;
+    const int j = ((ky * R + (rem >> 5)) << 1) | ((rem >> 3) & 1);
+    const int h = (rem >> 4) & 1;
+    unsigned pc[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float w = p.B[(size_t)(k0 + e) * p.ldb + c];
+      const unsigned b0 = aa_bf16_rn_bits(w);
+      const float r1 = w - aa_bf16_to_f32(b0);
+      const unsigned b1 = aa_bf16_rn_bits(r1);
+      const float r2 = r1 - aa_bf16_to_f32(b1);
+      pc[0][e] = b0; pc[1][e] = b1; pc[2][e] = aa_bf16_rn_bits(r2);
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      uint4 q;
+      q.x = pc[s][0] | (pc[s][1] << 16);
+      q.y = pc[s][2] | (pc[s][3] << 16);
+      q.z = pc[s][4] | (pc[s][5] << 16);
+      q.w = pc[s][6] | (pc[s][7] << 16);
+      wfrag[((s * J + j) * 2 + h) * 32 + c] = q;
+    }
+  }
+  __syncthreads();
+
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const unsigned char* A = reinterpret_cast<const unsigned char*>(p.A);
+  const float bv = p.bias != nullptr ? p.bias[r] : 0.f;
+  // XCD-aware: the 8 XCDs take workgroups round-robin; give each a contiguous range of pixels so
+  // the 4x patch overlap of a frame is served by ONE L2.
+  const int per_xcd = (n_super + 7) >> 3;
+  for (int sb = blockIdx.x; sb < per_xcd * 8; sb += gridDim.x) {
+    const int st = (sb & 7) * per_xcd + (sb >> 3);
+    if ((sb >> 3) >= per_xcd || st >= n_super) continue;
+    const int pix0 = (st * 4 + wave) * (32 * TPW);
+    if (pix0 >= p.M) continue;
+    const unsigned char* src[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      int pix = pix0 + t * 32 + r;
+      if (pix >= p.M) pix = p.M - 1;
+      src[t] = A + aa_pix_base(p, pix) + h * 16;
+    }
+    f32x16 acc[3][TPW];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[s][t][e] = 0.f;
+
+    auto chunk_off = [&](int ch) {
+      const int ky = ch / R;
+      return ky * p.rowpitch + ((ch - ky * R) << 5);
+    };
+    auto mma = [&](int ch, const uint4 (&a16)[TPW]) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        AaFrag af[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          const unsigned d0 = q == 0 ? a16[t].x : a16[t].z;
+          const unsigned d1 = q == 0 ? a16[t].y : a16[t].w;
+          aa_u8x4_to_bf16(d0, af[t].q.x, af[t].q.y);
+          aa_u8x4_to_bf16(d1, af[t].q.z, af[t].q.w);
+        }
+        const int j = ch * 2 + q;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          AaFrag bf;
+          bf.q = wfrag[((s * J + j) * 2 + h) * 32 + r];
+#pragma unroll
+          for (int t = 0; t < TPW; ++t)
+            acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t].v, bf.v, acc[s][t], 0, 0, 0);
+        }
+      }
+    };
+
+    if constexpr (NCH > 0) {
+      uint4 a16[NCH][TPW];   // the whole patch of each tile in flight at once
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+          a16[ch][t] = *reinterpret_cast<const uint4*>(src[t] + chunk_off(ch));
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) mma(ch, a16[ch]);
+    } else {
+      uint4 cur[TPW], nxt[TPW];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) cur[t] = *reinterpret_cast<const uint4*>(src[t] + chunk_off(0));
+      for (int ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) {
+#pragma unroll
+          for (int t = 0; t < TPW; ++t)
+            nxt[t] = *reinterpret_cast<const uint4*>(src[t] + chunk_off(ch + 1));
+        }
+        mma(ch, cur);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) cur[t] = nxt[t];
+      }
+    }
+
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int m = pix0 + t * 32 + row;
+        if (m >= p.M) continue;
+        // small pieces first; the quotient is the reference's Lambda(x / 255) applied to the sum
+        float v = ((acc[2][t][e] + acc[1][t][e]) + acc[0][t][e]) / p.a_div;
+        v = aa_act(v + bv, p.act);
+        p.C[(size_t)m * p.ldc + r] = v;
+      }
+    }
+  }
+}
+
+// Shapes this kernel takes (checked by the caller): uint8 forward patches, N == 32 filters,
+// patch rows that are whole 32-byte chunks, K <= AA_CU8_MAX_K, no mask / column-sum epilogue.
+static bool aa_conv_u8_bf16_ok(const aa_gemm_desc* d) {
+  const int seg = d->KW * d->Cin;
+  return d->a_mode == AA_A_PATCH_U8 && d->b_mode == AA_B_ROW && d->N == 32 && seg % 32 == 0 &&
+         d->K == d->KH * seg && d->K <= AA_CU8_MAX_K && d->mask_src == nullptr &&
+         d->colsum_out == nullptr;
+}
+
+static void aa_conv_u8_bf16_launch(const GemmP& p, hipStream_t st) {
+  constexpr int TPW = 2;
+  const int n_super = (p.M + 128 * TPW - 1) / (128 * TPW);
+  const int nch = p.K >> 5;
+  const size_t smem = (size_t)3 * (p.K >> 4) * 2 * 32 * sizeof(uint4);
+  const int per_xcd = (n_super + 7) >> 3;
+  int grid = per_xcd * 8;
+  if (grid > 1024) grid = 1024;
+  if (nch == 8)
+    hipLaunchKernelGGL((aa_conv_u8_bf16x3_kernel<TPW, 8>), dim3(grid), dim3(AA_CU8_THREADS), smem,
+                       st, p, n_super, nch);
+  else
+    hipLaunchKernelGGL((aa_conv_u8_bf16x3_kernel<TPW, 0>), dim3(grid), dim3(AA_CU8_THREADS), smem,
+                       st, p, n_super, nch);
+}

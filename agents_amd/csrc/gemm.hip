@@ -681,6 +681,7 @@ static const AaTileCfg kCfgs[] = {
     {256, 32, 4, 1, 1},   // 8  (LDS-DMA loop only: whole-M tile of the conv1 weight gradient)
 };
 #define AA_NCFG 8
+#define AA_CFG_U8_BF16 9   // force_cfg value of the uint8 x bf16x3 conv forward (conv_u8_bf16.h)
 // Tried and dropped (tools/gemm_sweep.py on MI355X): one 32x64 / 64x32 / 64x64 tile per wave with
 // a 4-way intra-workgroup K split (two or four independent accumulator chains per wave) -- never
 // faster than the plans above on the DQN shapes.  At these sizes a launch costs ~10 us of fixed
@@ -690,6 +691,8 @@ static const AaTileCfg kCfgs[] = {
 // for the tiled plan.  Its ablation (no stores / no DMA / no MFMA) put 27 of the 42 us outside the
 // MFMAs -- launch 5, stores 7, A DMA 3, operand fetch from LDS + the exact uint8 -> float /255
 // (4 VALU per element) ~11 -- which is the floor to attack next, not the tile shape.
+
+#include "conv_u8_bf16.h"
 
 struct AaGemmPlan {
   int cfg;
@@ -729,6 +732,13 @@ static int aa_gemm_plan(const aa_gemm_desc* d, AaGemmPlan* pl) {
   // against 20 MB algorithmic), so one workgroup takes ALL of M and the pixels are split instead.
   const bool tall_reduce = d->a_mode == AA_A_PATCH_T_U8 &&   // (fp32 images: 72 KB of LDS ring)
                            N <= 32 && M > 128 && M <= 256 && K >= 64 * M && aa_desc_dma_ok(d);
+  if (d->force_cfg == AA_CFG_U8_BF16 || (d->force_cfg == 0 && !d->no_dma && aa_conv_u8_bf16_ok(d))) {
+    if (!aa_conv_u8_bf16_ok(d)) return AA_ERR_INVALID;
+    pl->cfg = AA_CFG_U8_BF16 - 1;
+    pl->bm = 256; pl->bn = 32;
+    pl->splits = 1; pl->k_per_split = (int)K; pl->ws_bytes = 0;
+    return AA_OK;
+  }
   if (d->force_cfg > 0) {
     cfg = d->force_cfg - 1;
     if (cfg >= AA_NCFG) return AA_ERR_INVALID;
@@ -958,7 +968,14 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
       break;
     case AA_A_COL: rc = aa_gemm_launch_cfg<AA_A_COL, AA_B_ROW>(p, pl, st); break;
     case AA_A_PATCH: rc = aa_gemm_launch_cfg<AA_A_PATCH, AA_B_ROW>(p, pl, st); break;
-    case AA_A_PATCH_U8: rc = aa_gemm_launch_cfg<AA_A_PATCH_U8, AA_B_ROW>(p, pl, st); break;
+    case AA_A_PATCH_U8:
+      if (pl.cfg == AA_CFG_U8_BF16 - 1) {
+        aa_conv_u8_bf16_launch(p, st);
+        rc = aa_launch_status();
+      } else {
+        rc = aa_gemm_launch_cfg<AA_A_PATCH_U8, AA_B_ROW>(p, pl, st);
+      }
+      break;
     case AA_A_PATCH_T: rc = aa_gemm_launch_cfg<AA_A_PATCH_T, AA_B_ROW>(p, pl, st); break;
     case AA_A_PATCH_T_U8: rc = aa_gemm_launch_cfg<AA_A_PATCH_T_U8, AA_B_ROW>(p, pl, st); break;
     default: return AA_ERR_INVALID;

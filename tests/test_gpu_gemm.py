@@ -377,3 +377,75 @@ def test_conv1_dw_whole_m_tile(dev):
     for name, (g, gb) in res.items():
         close(g, ref)
         close(gb, dz.double().sum(0), tol=5e-6)
+
+
+# ---- uint8 conv forward on the bf16 matrix cores (csrc/conv_u8_bf16.h) -------------------------
+U8_BF16_CONVS = [  # (B, H, W, C, KH, KW, stride, F)
+    (4, 84, 84, 4, 8, 8, 4, 32),     # Atari conv1: unrolled 8-chunk path, 1,600 pixels (ragged)
+    (3, 36, 36, 4, 8, 8, 4, 32),     # 192 pixels: one partial super-tile
+    (2, 20, 36, 4, 4, 8, 4, 32),     # 4 chunks per patch: runtime-loop path
+    (2, 24, 40, 4, 3, 16, 4, 32),    # 64-byte patch rows (two chunks per row), odd KH
+    (1, 8, 8, 4, 8, 8, 4, 32),       # a single pixel
+]
+
+
+@pytest.mark.parametrize("cfg", U8_BF16_CONVS)
+@pytest.mark.parametrize("act", [None, "relu"])
+def test_conv_u8_bf16x3_forward(dev, cfg, act):
+    """Three bf16 pieces of the fp32 filter bank x exact bf16 bytes: same accuracy class as the
+    fp32 MFMA loader (both checked against float64), and the auto plan takes it."""
+    B, H, W, C, KH, KW, s, Fo = cfg
+    rng = np.random.default_rng(sum(cfg))
+    x = torch.from_numpy(rng.integers(0, 256, size=(B, H, W, C), dtype=np.uint8))
+    w = rnd(rng, KH, KW, C, Fo) * 0.1
+    b = rnd(rng, Fo)
+    OH, OW = ops.conv_out_hw(H, W, KH, KW, s)
+    ref = conv_ref(x, w, b, s, 255.0)
+    if act == "relu":
+        ref = torch.relu(ref)
+    outs = {}
+    for name, force in (("bf16x3", 9), ("auto", 0), ("fp32", 2)):
+        out = torch.full((B, OH, OW, Fo), float("nan"), device=dev)
+        ops.conv_forward(x.to(dev), w.to(dev), b.to(dev), s, act, out, a_div=255.0,
+                         force_cfg=force)
+        outs[name] = out.cpu()
+        close(out, ref)
+    assert torch.equal(outs["auto"], outs["bf16x3"])
+    err = lambda o: (o.double() - ref).abs().max().item()
+    assert err(outs["bf16x3"]) <= 2.0 * err(outs["fp32"]) + 1e-7
+
+
+def test_conv_u8_bf16x3_exact_cases(dev):
+    """Integer-valued weights: every product and partial sum is an integer < 2^24, so the result
+    must be the IEEE quotient sum / a_div exactly (no approximation anywhere in the kernel); and
+    weights needing all 24 significand bits survive the three-piece split."""
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.integers(0, 256, size=(2, 36, 36, 4), dtype=np.uint8))
+    w = torch.from_numpy(rng.integers(-7, 8, size=(8, 8, 4, 32)).astype(np.float32))
+    out = torch.empty(2, 8, 8, 32, device=dev)
+    ops.conv_forward(x.to(dev), w.to(dev), None, 4, None, out, a_div=255.0, force_cfg=9)
+    acc = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), stride=4)
+    want = (acc.permute(0, 2, 3, 1).float() / np.float32(255.0))
+    assert torch.equal(out.cpu(), want)
+    # one non-zero tap with a full 24-bit significand: out = fl(u * w) / 255 exactly
+    w2 = torch.zeros(8, 8, 4, 32)
+    w2[3, 5, 2, :] = torch.tensor(np.float32(1.0) + np.float32(2.0 ** -23) * np.arange(32, dtype=np.float32) * 99991 % 8388608 * 0 + np.float32(1.2345678))
+    w2[3, 5, 2, :] += torch.arange(32) * np.float32(2.0 ** -22)
+    ops.conv_forward(x.to(dev), w2.to(dev), None, 4, None, out, a_div=255.0, force_cfg=9)
+    u = x.reshape(2, 36, 36, 4)[:, 3:3 + 32:4, 5:5 + 32:4, 2].float()       # [2, 8, 8]
+    want2 = (u[..., None] * w2[3, 5, 2, :]) / np.float32(255.0)
+    assert torch.equal(out.cpu(), want2)
+
+
+def test_conv_u8_bf16x3_strided_batch_and_ineligible(dev):
+    rng = np.random.default_rng(12)
+    x5 = torch.from_numpy(rng.integers(0, 256, size=(5, 2, 84, 84, 4), dtype=np.uint8)).to(dev)
+    w, b = rnd(rng, 8, 8, 4, 32) * 0.1, rnd(rng, 32)
+    out = torch.empty(5, 20, 20, 32, device=dev)
+    ops.conv_forward(x5[:, 1], w.to(dev), b.to(dev), 4, "relu", out, a_div=255.0, force_cfg=9)
+    close(out, torch.relu(conv_ref(x5[:, 1].cpu(), w, b, 4, 255.0)))
+    # 16 filters / fp32 input: the bf16x3 kernel must refuse instead of computing something else
+    w16 = rnd(rng, 8, 8, 4, 16)
+    with pytest.raises(Exception):
+        ops.conv_forward(x5[:, 1], w16.to(dev), None, 4, None,
+                         torch.empty(5, 20, 20, 16, device=dev), force_cfg=9)

@@ -62,6 +62,21 @@ def main():
     for _ in range(args.reps):
         fn()
     torch.cuda.synchronize()
+    # graph-timed (what the launch costs inside the captured step)
+    g2 = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        fn()
+        with torch.cuda.graph(g2, stream=st):
+            for _ in range(20):
+                fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(5):
+        e0.record(); g2.replay(); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / 20 * 1e3)
+    print(f"{args.name} cfg={c} splits={s}: {best:.2f} us per launch (graph of 20)")
 
 
 if __name__ == "__main__":
