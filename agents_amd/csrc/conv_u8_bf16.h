@@ -34,6 +34,13 @@ __device__ static inline unsigned aa_bf16_rn_bits(float x) {   // finite x
   return u >> 16;
 }
 __device__ static inline float aa_bf16_to_f32(unsigned b) { return __uint_as_float(b << 16); }
+typedef __bf16 aa_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float aa_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ static inline unsigned aa_pk_bf16(float lo, float hi) {   // {bf16_rn(hi), bf16_rn(lo)}
+  aa_f32x2_t f = {lo, hi};
+  aa_bf16x2_t b = __builtin_convertvector(f, aa_bf16x2_t);
+  return __builtin_bit_cast(unsigned, b);
+}
 
 // four bytes of `d` -> four bf16 (two packed dwords); exact
 __device__ static inline void aa_u8x4_to_bf16(unsigned d, unsigned& lo, unsigned& hi) {
@@ -66,25 +73,26 @@ aa_conv_u8_bf16x3_kernel(GemmP p, int n_super, int nch_rt) {
     const int ky = k0 / p.seg, rem = k0 - ky * p.seg;
     const int j = ((ky * R + (rem >> 5)) << 1) | ((rem >> 3) & 1);
     const int h = (rem >> 4) & 1;
-    unsigned pc[3][8];
+    float wv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float w = p.B[(size_t)(k0 + e) * p.ldb + c];
-      const unsigned b0 = aa_bf16_rn_bits(w);
-      const float r1 = w - aa_bf16_to_f32(b0);
-      const unsigned b1 = aa_bf16_rn_bits(r1);
-      const float r2 = r1 - aa_bf16_to_f32(b1);
-      pc[0][e] = b0; pc[1][e] = b1; pc[2][e] = aa_bf16_rn_bits(r2);
+    for (int e = 0; e < 8; ++e) wv[e] = p.B[(size_t)(k0 + e) * p.ldb + c];
+    unsigned pc[3][4];   // packed pairs; v_cvt_pk_bf16_f32 rounds to nearest even
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      float r0 = wv[e], r1 = wv[e + 1];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const unsigned pk = aa_pk_bf16(r0, r1);
+        pc[s][e >> 1] = pk;
+        if (s < 2) {
+          r0 -= __uint_as_float(pk << 16);           // exact residuals
+          r1 -= __uint_as_float(pk & 0xffff0000u);
+        }
+      }
     }
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      uint4 q;
-      q.x = pc[s][0] | (pc[s][1] << 16);
-      q.y = pc[s][2] | (pc[s][3] << 16);
-      q.z = pc[s][4] | (pc[s][5] << 16);
-      q.w = pc[s][6] | (pc[s][7] << 16);
-      wfrag[((s * J + j) * 2 + h) * 32 + c] = q;
-    }
+    for (int s = 0; s < 3; ++s)
+      wfrag[((s * J + j) * 2 + h) * 32 + c] = make_uint4(pc[s][0], pc[s][1], pc[s][2], pc[s][3]);
   }
   __syncthreads();
 
@@ -114,7 +122,8 @@ aa_conv_u8_bf16x3_kernel(GemmP p, int n_super, int nch_rt) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[s][t][e] = 0.f;
 
-    auto chunk_off = [&](int ch) {
+    auto chunk_off = [&](int ch) {   // R == 1 (32-byte patch rows) needs no division
+      if (R == 1) return ch * p.rowpitch;
       const int ky = ch / R;
       return ky * p.rowpitch + ((ch - ky * R) << 5);
     };
@@ -166,19 +175,36 @@ aa_conv_u8_bf16x3_kernel(GemmP p, int n_super, int nch_rt) {
       }
     }
 
+    // epilogue, specialised on the (uniform) activation and on whole-tile stores
+    auto emit = [&](auto actc, auto fullc) {
+      constexpr int ACT = decltype(actc)::value;
+      constexpr bool FULL = decltype(fullc)::value;
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
+      for (int t = 0; t < TPW; ++t) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-        const int m = pix0 + t * 32 + row;
-        if (m >= p.M) continue;
-        // small pieces first; the quotient is the reference's Lambda(x / 255) applied to the sum
-        float v = ((acc[2][t][e] + acc[1][t][e]) + acc[0][t][e]) / p.a_div;
-        v = aa_act(v + bv, p.act);
-        p.C[(size_t)m * p.ldc + r] = v;
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int m = pix0 + t * 32 + row;
+          if (!FULL && m >= p.M) continue;
+          // small pieces first; then the reference's Lambda(x / 255) applied to the sum: the
+          // quotient by Markstein's sequence (q0 = s * RN(1/d); q = q0 + (s - d q0) * RN(1/d)),
+          // the correctly rounded s / d given a correctly rounded reciprocal
+          const float sum = (acc[2][t][e] + acc[1][t][e]) + acc[0][t][e];
+          const float q0 = sum * p.a_rcp;
+          float v = __builtin_fmaf(__builtin_fmaf(-p.a_div, q0, sum), p.a_rcp, q0) + bv;
+          if (ACT == AA_ACT_RELU) v = v > 0.f ? v : 0.f;
+          if (ACT == AA_ACT_TANH) v = tanhf(v);
+          p.C[(size_t)m * p.ldc + r] = v;
+        }
       }
-    }
+    };
+    auto emit_act = [&](auto fullc) {
+      if (p.act == AA_ACT_RELU) emit(std::integral_constant<int, AA_ACT_RELU>{}, fullc);
+      else if (p.act == AA_ACT_TANH) emit(std::integral_constant<int, AA_ACT_TANH>{}, fullc);
+      else emit(std::integral_constant<int, -1>{}, fullc);
+    };
+    if (pix0 + 32 * TPW <= p.M) emit_act(std::true_type{});
+    else emit_act(std::false_type{});
   }
 }
 

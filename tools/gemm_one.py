@@ -19,9 +19,10 @@ def main():
     ap.add_argument("--cfg", type=int, default=0)
     ap.add_argument("--splits", type=int, default=0)
     ap.add_argument("--no-dma", action="store_true")
+    ap.add_argument("--batch", type=int, default=256)
     args = ap.parse_args()
     ops.FORCE_NO_DMA = args.no_dma
-    S = 256
+    S = args.batch
     dev = torch.device("cuda", 0)
     g = torch.Generator(device="cpu").manual_seed(0)
     r = lambda *s: torch.randn(*s, generator=g).to(dev)
@@ -34,6 +35,12 @@ def main():
     elif args.name == "conv2.fwd":
         x, w, b, y = r(S, 20, 20, 32), r(4, 4, 32, 64), r(64), r(S, 9, 9, 64)
         fn = lambda: ops.conv_forward(x, w, b, 2, "relu", y, force_cfg=c, force_splits=s)
+    elif args.name == "conv3.fwd":
+        x, w, b, y = r(S, 9, 9, 64), r(3, 3, 64, 64), r(64), r(S, 7, 7, 64)
+        fn = lambda: ops.conv_forward(x, w, b, 1, "relu", y, force_cfg=c, force_splits=s)
+    elif args.name == "fc1.fwd":
+        x, w, b, y = r(S, 3136), r(3136, 512), r(512), r(S, 512)
+        fn = lambda: ops.dense_forward(x, w, b, "relu", y, force_cfg=c, force_splits=s)
     elif args.name == "fc1.dW":
         x, dz, gk = r(S, 3136), r(S, 512), r(3136, 512)
         fn = lambda: ops.dense_dw(x, dz, gk, force_cfg=c, force_splits=s)
@@ -76,7 +83,7 @@ def main():
     for _ in range(5):
         e0.record(); g2.replay(); e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 20 * 1e3)
-    print(f"{args.name} cfg={c} splits={s}: {best:.2f} us per launch (graph of 20)")
+    print(f"{args.name} B={S} cfg={c} splits={s}: {best:.2f} us per launch (graph of 20)")
 
 
 if __name__ == "__main__":
