@@ -232,3 +232,219 @@ static void aa_conv_u8_bf16_launch(const GemmP& p, hipStream_t st) {
     hipLaunchKernelGGL((aa_conv_u8_bf16x3_kernel<TPW, 0>), dim3(grid), dim3(AA_CU8_THREADS), smem,
                        st, p, n_super, nch);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the same layer: dW[k][f] = (sum_pix u8[pix][k] * dZ[pix][f]) / a_div, with the
+// bias gradient sum_pix dZ[pix][f] fused (tf.GradientTape of keras Conv2D + BiasAdd).
+//
+// The reduction runs over PIXELS, so the MFMA's K is the pixel index: a 16-pixel chunk is one
+// v_mfma_f32_32x32x16_bf16 per (32 patch elements) x (32 filters) x piece.  A workgroup takes whole
+// frames.  Per frame it stages, with every load in flight at once, (a) the frame's bytes into LDS
+// (28 KB at the Atari size) and (b) the frame's dZ rows split into three exact bf16 pieces, stored
+// in B-fragment order (lane = filter, 8 consecutive pixels = one ds_read_b128).  The A fragment
+// of a patch element is its byte at 8 consecutive pixels: 8 ds_read_u8 at the pixels' patch origins
+// (32 lanes = the 32 contiguous bytes of one patch-row chunk).  Wave w owns the patch-row chunks
+// {w, w+4}; the four waves walk the same pixels, so nothing is reduced inside the workgroup.  The
+// workgroup's partial gradient is slab g of the deterministic split reduce
+// (aa_splitk_reduce_kernel); the 1/a_div quotient is applied to each slab.
+// ------------------------------------------------------------------------------------------------
+#define AA_CU8_DW_MT 2          /* patch-row chunks per wave: 32 * 4 * 2 = 256 patch elements max */
+#define AA_CU8_DW_MAX_FRAME 32768   /* frame bytes staged in LDS */
+#define AA_CU8_DW_MAX_OHW 512       /* output pixels per frame (3 * 64 B of LDS each) */
+
+__global__ void __launch_bounds__(AA_CU8_THREADS)
+aa_conv_u8_dw_bf16x3_kernel(GemmP p, int n_img, int frame_bytes, int want_colsum) {
+  extern __shared__ __attribute__((aligned(16))) uint4 dyn[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-uniform branches
+  const int lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int nch = p.M >> 5;                  // patch-row chunks (M = patch elements)
+  const int R = p.seg >> 5;
+  const int OHW = p.OHW;
+  const int n_oct = ((OHW + 15) >> 4) << 1;  // pixel octets per frame, padded to whole chunks
+  uint4* zfrag = dyn;                                      // [3][n_oct][32]
+  int* origin = reinterpret_cast<int*>(dyn + 3 * n_oct * 32);   // [n_oct * 8] patch origins
+  unsigned char* frame = reinterpret_cast<unsigned char*>(origin + n_oct * 8);
+  // patch origin (byte offset inside a frame) of every output pixel; padding pixels alias the
+  // last real one (their dZ pieces are zero)
+  for (int i = tid; i < n_oct * 8; i += AA_CU8_THREADS) {
+    const int pix = i < OHW ? i : OHW - 1;
+    const int oy = pix / p.OW;
+    origin[i] = oy * p.stride * p.rowpitch + (pix - oy * p.OW) * p.stride * p.Cin;
+  }
+  const unsigned char* A = reinterpret_cast<const unsigned char*>(p.A);
+
+  int toff[AA_CU8_DW_MT];                    // byte offset of this lane's patch element
+  bool tlive[AA_CU8_DW_MT];
+#pragma unroll
+  for (int t = 0; t < AA_CU8_DW_MT; ++t) {
+    const int ch = wave + 4 * t;
+    tlive[t] = ch < nch;
+    const int chc = tlive[t] ? ch : 0;
+    const int ky = chc / R;
+    toff[t] = ky * p.rowpitch + ((chc - ky * R) << 5) + r;
+  }
+  f32x16 acc[AA_CU8_DW_MT][3];
+#pragma unroll
+  for (int t = 0; t < AA_CU8_DW_MT; ++t)
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][s][e] = 0.f;
+  float csum = 0.f;   // this thread's share of the bias gradient (staging items are filter-major)
+
+  for (int img = blockIdx.x; img < n_img; img += gridDim.x) {
+    __syncthreads();   // the previous frame's readers are done
+    // (a) frame bytes -> LDS, 16 bytes per load
+    const uint4* fsrc = reinterpret_cast<const uint4*>(A + (size_t)img * p.imgpitch);
+    uint4* fdst = reinterpret_cast<uint4*>(frame);
+    const int n16 = frame_bytes >> 4;
+    int i0 = tid;
+    for (; i0 + 3 * AA_CU8_THREADS < n16; i0 += 4 * AA_CU8_THREADS) {   // 4 loads in flight
+      const uint4 t0 = fsrc[i0], t1 = fsrc[i0 + AA_CU8_THREADS];
+      const uint4 t2 = fsrc[i0 + 2 * AA_CU8_THREADS], t3 = fsrc[i0 + 3 * AA_CU8_THREADS];
+      fdst[i0] = t0; fdst[i0 + AA_CU8_THREADS] = t1;
+      fdst[i0 + 2 * AA_CU8_THREADS] = t2; fdst[i0 + 3 * AA_CU8_THREADS] = t3;
+    }
+    for (; i0 < n16; i0 += AA_CU8_THREADS) fdst[i0] = fsrc[i0];
+    // (b) dZ rows of the frame -> three bf16 planes in fragment order (4 items = 32 loads in flight)
+    const float* dz = p.B + (size_t)img * OHW * p.ldb;
+    const int n_item = n_oct * 32;
+    for (int item0 = tid; item0 < n_item; item0 += AA_CU8_THREADS * 4) {
+      float v[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int item = item0 + u * AA_CU8_THREADS;
+        const int c = item & 31, o = item >> 5;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int pix = o * 8 + e;
+          v[u][e] = (item < n_item && pix < OHW) ? dz[(size_t)pix * p.ldb + c] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int item = item0 + u * AA_CU8_THREADS;
+        if (item >= n_item) continue;
+        const int c = item & 31, o = item >> 5;
+        unsigned pc[3][4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          float r0 = v[u][e], r1 = v[u][e + 1];
+          csum += r0 + r1;
+#pragma unroll
+          for (int s = 0; s < 3; ++s) {
+            const unsigned pk = aa_pk_bf16(r0, r1);
+            pc[s][e >> 1] = pk;
+            if (s < 2) {
+              r0 -= __uint_as_float(pk << 16);
+              r1 -= __uint_as_float(pk & 0xffff0000u);
+            }
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          zfrag[(s * n_oct + o) * 32 + c] = make_uint4(pc[s][0], pc[s][1], pc[s][2], pc[s][3]);
+      }
+    }
+    __syncthreads();
+
+#pragma unroll 2
+    for (int o0 = 0; o0 < n_oct; o0 += 2) {
+      const int o = o0 + h;
+      int base[8];   // this lane's 8 pixels
+      {
+        const int4 b0 = *reinterpret_cast<const int4*>(origin + o * 8);
+        const int4 b1 = *reinterpret_cast<const int4*>(origin + o * 8 + 4);
+        base[0] = b0.x; base[1] = b0.y; base[2] = b0.z; base[3] = b0.w;
+        base[4] = b1.x; base[5] = b1.y; base[6] = b1.z; base[7] = b1.w;
+      }
+      AaFrag bf[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) bf[s].q = zfrag[(s * n_oct + o) * 32 + r];
+#pragma unroll
+      for (int t = 0; t < AA_CU8_DW_MT; ++t) {
+        if (!tlive[t]) continue;
+        unsigned w[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const unsigned f0 = __float_as_uint((float)frame[base[e] + toff[t]]);
+          const unsigned f1 = __float_as_uint((float)frame[base[e + 1] + toff[t]]);
+          w[e >> 1] = __builtin_amdgcn_perm(f1, f0, 0x07060302u);
+        }
+        AaFrag af;
+        af.q = make_uint4(w[0], w[1], w[2], w[3]);
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          acc[t][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, bf[s].v, acc[t][s], 0, 0, 0);
+      }
+    }
+  }
+
+  // slab g: [M][32], then the column-sum rows [splits][32] behind all slabs
+  const int g = blockIdx.x;
+  float* slab = p.C + (size_t)g * p.M * 32;
+#pragma unroll
+  for (int t = 0; t < AA_CU8_DW_MT; ++t) {
+    if (!tlive[t]) continue;
+    const int ch = wave + 4 * t;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+      const float sum = (acc[t][2][e] + acc[t][1][e]) + acc[t][0][e];
+      const float q0 = sum * p.a_rcp;
+      slab[(size_t)(ch * 32 + row) * 32 + r] =
+          __builtin_fmaf(__builtin_fmaf(-p.a_div, q0, sum), p.a_rcp, q0);
+    }
+  }
+  if (want_colsum) {
+    // thread tid staged items tid, tid+256, ...: always filter (tid & 31); fixed-order sum of the
+    // 8 threads of a filter
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(dyn);
+    red[tid] = csum;
+    __syncthreads();
+    if (tid < 32) {
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < AA_CU8_THREADS / 32; ++j) t += red[j * 32 + tid];
+      p.C[(size_t)gridDim.x * p.M * 32 + (size_t)g * 32 + tid] = t;
+    }
+  }
+}
+
+static bool aa_conv_u8_dw_bf16_ok(const aa_gemm_desc* d) {
+  const int seg = d->KW * d->Cin;
+  if (!(d->a_mode == AA_A_PATCH_T_U8 && d->b_mode == AA_B_ROW && d->N == 32 && seg % 32 == 0 &&
+        d->M == d->KH * seg && d->M <= 32 * 4 * AA_CU8_DW_MT && d->mask_src == nullptr &&
+        d->bias == nullptr && d->act == AA_ACT_NONE && d->n_img >= 1 && d->stride >= 1))
+    return false;
+  const int64_t frame = (int64_t)d->H * d->W * d->Cin;
+  const int OH = (d->H - d->KH) / d->stride + 1, OW = (d->W - d->KW) / d->stride + 1;
+  return frame % 16 == 0 && frame <= AA_CU8_DW_MAX_FRAME && OH >= 1 && OW >= 1 &&
+         OH * OW <= AA_CU8_DW_MAX_OHW && (int64_t)d->n_img * OH * OW == d->K;
+}
+// slabs of the split reduce = workgroups; each takes frames g, g + groups, ...
+static int aa_conv_u8_dw_groups(int n_img) {
+  int g = n_img > 256 ? 256 : n_img;
+  return g < 2 ? 2 : g;
+}
+static size_t aa_conv_u8_dw_lds(const GemmP& p, int frame_bytes) {
+  const int n_oct = ((p.OHW + 15) >> 4) << 1;
+  return (size_t)3 * n_oct * 32 * sizeof(uint4) + (size_t)n_oct * 8 * sizeof(int) +
+         (size_t)frame_bytes;
+}
+static int aa_conv_u8_dw_bf16_launch(const GemmP& p, int n_img, int frame_bytes, int groups,
+                                     hipStream_t st) {
+  const size_t smem = aa_conv_u8_dw_lds(p, frame_bytes);
+  static size_t lds_limit = 0;   // dynamic LDS above 64 KiB has to be granted once per process
+  if (smem > lds_limit) {
+    if (hipFuncSetAttribute((const void*)aa_conv_u8_dw_bf16x3_kernel,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return AA_ERR_LAUNCH;
+    lds_limit = smem;
+  }
+  hipLaunchKernelGGL(aa_conv_u8_dw_bf16x3_kernel, dim3(groups), dim3(AA_CU8_THREADS), smem, st, p,
+                     n_img, frame_bytes, p.colsum_out != nullptr ? 1 : 0);
+  return aa_launch_status();
+}

@@ -732,11 +732,23 @@ static int aa_gemm_plan(const aa_gemm_desc* d, AaGemmPlan* pl) {
   // against 20 MB algorithmic), so one workgroup takes ALL of M and the pixels are split instead.
   const bool tall_reduce = d->a_mode == AA_A_PATCH_T_U8 &&   // (fp32 images: 72 KB of LDS ring)
                            N <= 32 && M > 128 && M <= 256 && K >= 64 * M && aa_desc_dma_ok(d);
-  if (d->force_cfg == AA_CFG_U8_BF16 || (d->force_cfg == 0 && !d->no_dma && aa_conv_u8_bf16_ok(d))) {
+  if (d->a_mode == AA_A_PATCH_U8 &&
+      (d->force_cfg == AA_CFG_U8_BF16 || (d->force_cfg == 0 && !d->no_dma && aa_conv_u8_bf16_ok(d)))) {
     if (!aa_conv_u8_bf16_ok(d)) return AA_ERR_INVALID;
     pl->cfg = AA_CFG_U8_BF16 - 1;
     pl->bm = 256; pl->bn = 32;
     pl->splits = 1; pl->k_per_split = (int)K; pl->ws_bytes = 0;
+    return AA_OK;
+  }
+  if (d->a_mode == AA_A_PATCH_T_U8 &&
+      (d->force_cfg == AA_CFG_U8_BF16 ||
+       (d->force_cfg == 0 && d->force_splits == 0 && !d->no_dma && aa_conv_u8_dw_bf16_ok(d)))) {
+    if (!aa_conv_u8_dw_bf16_ok(d)) return AA_ERR_INVALID;
+    pl->cfg = AA_CFG_U8_BF16 - 1;
+    pl->bm = 256; pl->bn = 32;
+    pl->splits = aa_conv_u8_dw_groups(d->n_img);
+    pl->k_per_split = (int)((K + pl->splits - 1) / pl->splits);
+    pl->ws_bytes = (size_t)pl->splits * (size_t)(M * N + (d->colsum_out ? N : 0)) * sizeof(float);
     return AA_OK;
   }
   if (d->force_cfg > 0) {
@@ -977,7 +989,13 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
       }
       break;
     case AA_A_PATCH_T: rc = aa_gemm_launch_cfg<AA_A_PATCH_T, AA_B_ROW>(p, pl, st); break;
-    case AA_A_PATCH_T_U8: rc = aa_gemm_launch_cfg<AA_A_PATCH_T_U8, AA_B_ROW>(p, pl, st); break;
+    case AA_A_PATCH_T_U8:
+      if (pl.cfg == AA_CFG_U8_BF16 - 1) {
+        rc = aa_conv_u8_dw_bf16_launch(p, d->n_img, d->H * d->W * d->Cin, pl.splits, st);
+      } else {
+        rc = aa_gemm_launch_cfg<AA_A_PATCH_T_U8, AA_B_ROW>(p, pl, st);
+      }
+      break;
     default: return AA_ERR_INVALID;
   }
   if (rc != AA_OK) return rc;

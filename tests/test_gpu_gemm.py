@@ -449,3 +449,54 @@ def test_conv_u8_bf16x3_strided_batch_and_ineligible(dev):
     with pytest.raises(Exception):
         ops.conv_forward(x5[:, 1], w16.to(dev), None, 4, None,
                          torch.empty(5, 20, 20, 16, device=dev), force_cfg=9)
+
+
+@pytest.mark.parametrize("cfg", U8_BF16_CONVS)
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_conv_u8_bf16x3_dw(dev, cfg, with_bias):
+    """Weight gradient over uint8 frames with dZ split into three exact bf16 pieces: same accuracy
+    class as the fp32 MFMA plan (both against float64); the automatic plan takes it."""
+    B, H, W, C, KH, KW, s, Fo = cfg
+    rng = np.random.default_rng(sum(cfg) + 3)
+    x = torch.from_numpy(rng.integers(0, 256, size=(B, H, W, C), dtype=np.uint8))
+    OH, OW = ops.conv_out_hw(H, W, KH, KW, s)
+    dz = rnd(rng, B * OH * OW, Fo)
+    xf = x.double() / 255.0
+    wd = torch.zeros(KH, KW, C, Fo, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(xf.permute(0, 3, 1, 2), wd.permute(3, 2, 0, 1), None, stride=s)
+    ref, = torch.autograd.grad(y, wd, dz.double().view(B, OH, OW, Fo).permute(0, 3, 1, 2))
+    res = {}
+    for name, force in (("bf16x3", 9), ("auto", 0), ("fp32", 7)):
+        g = torch.full((KH, KW, C, Fo), float("nan"), device=dev)
+        gb = torch.full((Fo,), float("nan"), device=dev) if with_bias else None
+        ops.conv_dw(x.to(dev), dz.to(dev), (KH, KW, C, Fo), s, g, a_div=255.0, force_cfg=force,
+                    bias_grad=gb)
+        close(g, ref)
+        if with_bias:
+            close(gb, dz.double().sum(0), tol=5e-6)
+        res[name] = g.cpu()
+    assert torch.equal(res["auto"], res["bf16x3"])
+    err = lambda o: (o.double() - ref).abs().max().item()
+    assert err(res["bf16x3"]) <= 2.0 * err(res["fp32"]) + 1e-7
+
+
+def test_conv_u8_bf16x3_dw_exact_and_deterministic(dev):
+    """Integer-valued dZ: every partial sum is an integer below 2^24, so each slab is an exact IEEE
+    quotient and the result equals the float64 one rounded once per slab; two runs are bit-equal."""
+    rng = np.random.default_rng(9)
+    B = 3
+    x = torch.from_numpy(rng.integers(0, 256, size=(B, 36, 36, 4), dtype=np.uint8))
+    dz = torch.from_numpy(rng.integers(-3, 4, size=(B * 64, 32)).astype(np.float32))
+    outs = []
+    for _ in range(2):
+        g = torch.empty(8, 8, 4, 32, device=dev)
+        gb = torch.empty(32, device=dev)
+        ops.conv_dw(x.to(dev), dz.to(dev), (8, 8, 4, 32), 4, g, a_div=1.0, force_cfg=9,
+                    bias_grad=gb)
+        outs.append((g.cpu(), gb.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    wd = torch.zeros(8, 8, 4, 32, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double().permute(0, 3, 1, 2), wd.permute(3, 2, 0, 1), None, stride=4)
+    ref, = torch.autograd.grad(y, wd, dz.double().view(B, 8, 8, 32).permute(0, 3, 1, 2))
+    assert torch.equal(outs[0][0].double(), ref)          # a_div = 1: integers, exact
+    assert torch.equal(outs[0][1].double(), dz.double().sum(0))

@@ -46,9 +46,9 @@ def main():
         fn = lambda: ops.dense_dw(x, dz, gk, force_cfg=c, force_splits=s)
     elif args.name == "conv1.dW":
         obs = torch.randint(0, 256, (S, 84, 84, 4), dtype=torch.uint8, generator=g).to(dev)
-        dz, gk = r(S * 400, 32), r(8, 8, 4, 32)
+        dz, gk, gb = r(S * 400, 32), r(8, 8, 4, 32), r(32)
         fn = lambda: ops.conv_dw(obs, dz, (8, 8, 4, 32), 4, gk, a_div=255.0, force_cfg=c,
-                                 force_splits=s)
+                                 force_splits=s, bias_grad=gb)
     elif args.name == "replay.gather":
         # 512 random rows of the Atari trajectory table (28,248 B per row), 4096-row table
         from agents_amd.replay_buffers import table
