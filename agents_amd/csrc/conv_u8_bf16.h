@@ -248,12 +248,16 @@ static void aa_conv_u8_bf16_launch(const GemmP& p, hipStream_t st) {
 // workgroup's partial gradient is slab g of the deterministic split reduce
 // (aa_splitk_reduce_kernel); the 1/a_div quotient is applied to each slab.
 // ------------------------------------------------------------------------------------------------
-#define AA_CU8_DW_MT 2          /* patch-row chunks per wave: 32 * 4 * 2 = 256 patch elements max */
+#define AA_CU8_DW_MAX_CH 8      /* patch-row chunks: 256 patch elements max */
+#define AA_CU8_DW_WAVES 8
 #define AA_CU8_DW_MAX_FRAME 32768   /* frame bytes staged in LDS */
 #define AA_CU8_DW_MAX_OHW 512       /* output pixels per frame (3 * 64 B of LDS each) */
 
-__global__ void __launch_bounds__(AA_CU8_THREADS)
+template <int NW>   // waves per workgroup; wave w owns the patch-row chunks {w, w + NW, ...}
+__global__ void __launch_bounds__(NW * 64)
 aa_conv_u8_dw_bf16x3_kernel(GemmP p, int n_img, int frame_bytes, int want_colsum) {
+  constexpr int NT = NW * 64;
+  constexpr int MT = AA_CU8_DW_MAX_CH / NW;
   extern __shared__ __attribute__((aligned(16))) uint4 dyn[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-uniform branches
@@ -267,26 +271,26 @@ aa_conv_u8_dw_bf16x3_kernel(GemmP p, int n_img, int frame_bytes, int want_colsum
   unsigned char* frame = reinterpret_cast<unsigned char*>(origin + n_oct * 8);
   // patch origin (byte offset inside a frame) of every output pixel; padding pixels alias the
   // last real one (their dZ pieces are zero)
-  for (int i = tid; i < n_oct * 8; i += AA_CU8_THREADS) {
+  for (int i = tid; i < n_oct * 8; i += NT) {
     const int pix = i < OHW ? i : OHW - 1;
     const int oy = pix / p.OW;
     origin[i] = oy * p.stride * p.rowpitch + (pix - oy * p.OW) * p.stride * p.Cin;
   }
   const unsigned char* A = reinterpret_cast<const unsigned char*>(p.A);
 
-  int toff[AA_CU8_DW_MT];                    // byte offset of this lane's patch element
-  bool tlive[AA_CU8_DW_MT];
+  int toff[MT];                    // byte offset of this lane's patch element
+  bool tlive[MT];
 #pragma unroll
-  for (int t = 0; t < AA_CU8_DW_MT; ++t) {
-    const int ch = wave + 4 * t;
+  for (int t = 0; t < MT; ++t) {
+    const int ch = wave + NW * t;
     tlive[t] = ch < nch;
     const int chc = tlive[t] ? ch : 0;
     const int ky = chc / R;
     toff[t] = ky * p.rowpitch + ((chc - ky * R) << 5) + r;
   }
-  f32x16 acc[AA_CU8_DW_MT][3];
+  f32x16 acc[MT][3];
 #pragma unroll
-  for (int t = 0; t < AA_CU8_DW_MT; ++t)
+  for (int t = 0; t < MT; ++t)
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -300,21 +304,21 @@ aa_conv_u8_dw_bf16x3_kernel(GemmP p, int n_img, int frame_bytes, int want_colsum
     uint4* fdst = reinterpret_cast<uint4*>(frame);
     const int n16 = frame_bytes >> 4;
     int i0 = tid;
-    for (; i0 + 3 * AA_CU8_THREADS < n16; i0 += 4 * AA_CU8_THREADS) {   // 4 loads in flight
-      const uint4 t0 = fsrc[i0], t1 = fsrc[i0 + AA_CU8_THREADS];
-      const uint4 t2 = fsrc[i0 + 2 * AA_CU8_THREADS], t3 = fsrc[i0 + 3 * AA_CU8_THREADS];
-      fdst[i0] = t0; fdst[i0 + AA_CU8_THREADS] = t1;
-      fdst[i0 + 2 * AA_CU8_THREADS] = t2; fdst[i0 + 3 * AA_CU8_THREADS] = t3;
+    for (; i0 + 3 * NT < n16; i0 += 4 * NT) {   // 4 loads in flight
+      const uint4 t0 = fsrc[i0], t1 = fsrc[i0 + NT];
+      const uint4 t2 = fsrc[i0 + 2 * NT], t3 = fsrc[i0 + 3 * NT];
+      fdst[i0] = t0; fdst[i0 + NT] = t1;
+      fdst[i0 + 2 * NT] = t2; fdst[i0 + 3 * NT] = t3;
     }
-    for (; i0 < n16; i0 += AA_CU8_THREADS) fdst[i0] = fsrc[i0];
+    for (; i0 < n16; i0 += NT) fdst[i0] = fsrc[i0];
     // (b) dZ rows of the frame -> three bf16 planes in fragment order (4 items = 32 loads in flight)
     const float* dz = p.B + (size_t)img * OHW * p.ldb;
     const int n_item = n_oct * 32;
-    for (int item0 = tid; item0 < n_item; item0 += AA_CU8_THREADS * 4) {
+    for (int item0 = tid; item0 < n_item; item0 += NT * 4) {
       float v[4][8];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int item = item0 + u * AA_CU8_THREADS;
+        const int item = item0 + u * NT;
         const int c = item & 31, o = item >> 5;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -324,7 +328,7 @@ aa_conv_u8_dw_bf16x3_kernel(GemmP p, int n_img, int frame_bytes, int want_colsum
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int item = item0 + u * AA_CU8_THREADS;
+        const int item = item0 + u * NT;
         if (item >= n_item) continue;
         const int c = item & 31, o = item >> 5;
         unsigned pc[3][4];
@@ -349,7 +353,6 @@ aa_conv_u8_dw_bf16x3_kernel(GemmP p, int n_img, int frame_bytes, int want_colsum
     }
     __syncthreads();
 
-#pragma unroll 2
     for (int o0 = 0; o0 < n_oct; o0 += 2) {
       const int o = o0 + h;
       int base[8];   // this lane's 8 pixels
@@ -363,7 +366,7 @@ aa_conv_u8_dw_bf16x3_kernel(GemmP p, int n_img, int frame_bytes, int want_colsum
 #pragma unroll
       for (int s = 0; s < 3; ++s) bf[s].q = zfrag[(s * n_oct + o) * 32 + r];
 #pragma unroll
-      for (int t = 0; t < AA_CU8_DW_MT; ++t) {
+      for (int t = 0; t < MT; ++t) {
         if (!tlive[t]) continue;
         unsigned w[4];
 #pragma unroll
@@ -385,9 +388,9 @@ aa_conv_u8_dw_bf16x3_kernel(GemmP p, int n_img, int frame_bytes, int want_colsum
   const int g = blockIdx.x;
   float* slab = p.C + (size_t)g * p.M * 32;
 #pragma unroll
-  for (int t = 0; t < AA_CU8_DW_MT; ++t) {
+  for (int t = 0; t < MT; ++t) {
     if (!tlive[t]) continue;
-    const int ch = wave + 4 * t;
+    const int ch = wave + NW * t;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -407,7 +410,7 @@ aa_conv_u8_dw_bf16x3_kernel(GemmP p, int n_img, int frame_bytes, int want_colsum
     if (tid < 32) {
       float t = 0.f;
 #pragma unroll
-      for (int j = 0; j < AA_CU8_THREADS / 32; ++j) t += red[j * 32 + tid];
+      for (int j = 0; j < NT / 32; ++j) t += red[j * 32 + tid];
       p.C[(size_t)gridDim.x * p.M * 32 + (size_t)g * 32 + tid] = t;
     }
   }
@@ -416,7 +419,7 @@ aa_conv_u8_dw_bf16x3_kernel(GemmP p, int n_img, int frame_bytes, int want_colsum
 static bool aa_conv_u8_dw_bf16_ok(const aa_gemm_desc* d) {
   const int seg = d->KW * d->Cin;
   if (!(d->a_mode == AA_A_PATCH_T_U8 && d->b_mode == AA_B_ROW && d->N == 32 && seg % 32 == 0 &&
-        d->M == d->KH * seg && d->M <= 32 * 4 * AA_CU8_DW_MT && d->mask_src == nullptr &&
+        d->M == d->KH * seg && d->M <= 32 * AA_CU8_DW_MAX_CH && d->mask_src == nullptr &&
         d->bias == nullptr && d->act == AA_ACT_NONE && d->n_img >= 1 && d->stride >= 1))
     return false;
   const int64_t frame = (int64_t)d->H * d->W * d->Cin;
@@ -437,14 +440,15 @@ static size_t aa_conv_u8_dw_lds(const GemmP& p, int frame_bytes) {
 static int aa_conv_u8_dw_bf16_launch(const GemmP& p, int n_img, int frame_bytes, int groups,
                                      hipStream_t st) {
   const size_t smem = aa_conv_u8_dw_lds(p, frame_bytes);
+  constexpr int NW = AA_CU8_DW_WAVES;
   static size_t lds_limit = 0;   // dynamic LDS above 64 KiB has to be granted once per process
   if (smem > lds_limit) {
-    if (hipFuncSetAttribute((const void*)aa_conv_u8_dw_bf16x3_kernel,
+    if (hipFuncSetAttribute((const void*)aa_conv_u8_dw_bf16x3_kernel<NW>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return AA_ERR_LAUNCH;
     lds_limit = smem;
   }
-  hipLaunchKernelGGL(aa_conv_u8_dw_bf16x3_kernel, dim3(groups), dim3(AA_CU8_THREADS), smem, st, p,
+  hipLaunchKernelGGL(aa_conv_u8_dw_bf16x3_kernel<NW>, dim3(groups), dim3(NW * 64), smem, st, p,
                      n_img, frame_bytes, p.colsum_out != nullptr ? 1 : 0);
   return aa_launch_status();
 }
