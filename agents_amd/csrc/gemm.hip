@@ -693,6 +693,7 @@ static const AaTileCfg kCfgs[] = {
 // (4 VALU per element) ~11 -- which is the floor to attack next, not the tile shape.
 
 #include "conv_u8_bf16.h"
+#include "gemm_bf16x6.h"
 
 struct AaGemmPlan {
   int cfg;
@@ -738,6 +739,17 @@ static int aa_gemm_plan(const aa_gemm_desc* d, AaGemmPlan* pl) {
     pl->cfg = AA_CFG_U8_BF16 - 1;
     pl->bm = 256; pl->bn = 32;
     pl->splits = 1; pl->k_per_split = (int)K; pl->ws_bytes = 0;
+    return AA_OK;
+  }
+  if ((d->a_mode == AA_A_ROW || d->a_mode == AA_A_PATCH) &&
+      d->force_cfg == AA_CFG_U8_BF16) {   // opt-in only: ties the fp32 plans (gemm_bf16x6.h)
+    if (!aa_fwd_x6_ok(d)) return AA_ERR_INVALID;
+    AaX6Plan x;
+    aa_fwd_x6_plan(d, &x);
+    pl->cfg = AA_CFG_U8_BF16 - 1;
+    pl->bm = 32 * x.nw; pl->bn = 32 * x.tn;
+    pl->splits = x.splits; pl->k_per_split = x.k_per_split;
+    pl->ws_bytes = x.splits > 1 ? (size_t)x.splits * (size_t)(M * N) * sizeof(float) : 0;
     return AA_OK;
   }
   if (d->a_mode == AA_A_PATCH_T_U8 &&
@@ -975,11 +987,25 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
   if (d->b_mode == AA_B_COL && d->a_mode != AA_A_ROW) return AA_ERR_INVALID;
   switch (d->a_mode) {
     case AA_A_ROW:
+      if (pl.cfg == AA_CFG_U8_BF16 - 1) {
+        AaX6Plan x;
+        aa_fwd_x6_plan(d, &x);
+        rc = aa_fwd_x6_launch(p, x, false, st);
+        break;
+      }
       rc = d->b_mode == AA_B_ROW ? aa_gemm_launch_cfg<AA_A_ROW, AA_B_ROW>(p, pl, st)
                                  : aa_gemm_launch_cfg<AA_A_ROW, AA_B_COL>(p, pl, st);
       break;
     case AA_A_COL: rc = aa_gemm_launch_cfg<AA_A_COL, AA_B_ROW>(p, pl, st); break;
-    case AA_A_PATCH: rc = aa_gemm_launch_cfg<AA_A_PATCH, AA_B_ROW>(p, pl, st); break;
+    case AA_A_PATCH:
+      if (pl.cfg == AA_CFG_U8_BF16 - 1) {
+        AaX6Plan x;
+        aa_fwd_x6_plan(d, &x);
+        rc = aa_fwd_x6_launch(p, x, true, st);
+        break;
+      }
+      rc = aa_gemm_launch_cfg<AA_A_PATCH, AA_B_ROW>(p, pl, st);
+      break;
     case AA_A_PATCH_U8:
       if (pl.cfg == AA_CFG_U8_BF16 - 1) {
         aa_conv_u8_bf16_launch(p, st);

@@ -244,7 +244,7 @@ def cpu_baseline(S, steps, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--max-length", type=int, default=3906,
                     help="replay frames per env (3906 x 256 envs = the 1M-row config)")

@@ -113,8 +113,12 @@ typedef struct aa_gemm_desc {
   const float* mask_src;  /* nullable: forward OUTPUT of the layer whose activation is undone */
   int32_t ldm;
   int32_t mask_kind;
-  int32_t force_cfg;      /* 0 = auto; 1..8 = 128x64, 128x32, 64x64, 128x128, 64x32, 32x64, 32x32,
-                           * 256x32 (LDS-DMA operands only) */
+  int32_t force_cfg;      /* 0 = auto; 1..8 = fp32 MFMA tiles 128x64, 128x32, 64x64, 128x128, 64x32,
+                           * 32x64, 32x32, 256x32 (LDS-DMA operands only); 9 = the bf16 matrix-core
+                           * plans with exact 3-piece splits: uint8 conv forward / weight gradient
+                           * with 32 filters (the automatic choice there, csrc/conv_u8_bf16.h) and
+                           * fp32 forward contractions (opt-in, csrc/gemm_bf16x6.h); AA_ERR_INVALID
+                           * when the shape is not eligible */
   int32_t force_splits;   /* 0 = auto split-K */
   /* nullable, AA_B_ROW only: colsum_out[n] = sum_k B(k,n).  With B = dZ this is the bias
    * gradient (tf.GradientTape of keras BiasAdd), produced by the weight-gradient GEMM that
