@@ -24,6 +24,7 @@ SOURCES = [
     ("replay.hip", []),
     ("prio.hip", []),
     ("gemm.hip", []),
+    ("conv_pair.hip", []),
     ("nn.hip", ["-ffp-contract=off"]),
     ("dense_small.hip", []),
     ("mlp_small.hip", []),

@@ -29,6 +29,11 @@ class AgentsAmdError(RuntimeError):
     pass
 
 
+class ConvLayerDesc(Structure):
+    _fields_ = [("w", c_void_p), ("bias", c_void_p), ("y", c_void_p), ("KH", c_int32),
+                ("KW", c_int32), ("stride", c_int32), ("Cout", c_int32), ("act", c_int32)]
+
+
 class GemmDesc(Structure):
     _fields_ = [
         ("A", c_void_p), ("B", c_void_p), ("C", c_void_p),
@@ -60,6 +65,10 @@ _SIGNATURES = {
     "aa_counter_add": (c_int, [c_void_p, c_int64, c_void_p]),
     "aa_gemm_f32_workspace_bytes": (c_int64, [POINTER(GemmDesc)]),
     "aa_gemm_f32": (c_int, [POINTER(GemmDesc), c_void_p, c_int64, c_void_p]),
+    "aa_conv_pair_supported": (c_int, [c_int32, c_int32, c_int32, c_int32, POINTER(ConvLayerDesc),
+                                       POINTER(ConvLayerDesc)]),
+    "aa_conv_pair_forward": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                     POINTER(ConvLayerDesc), POINTER(ConvLayerDesc), c_void_p]),
     "aa_dense_small_forward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64,
                                        c_int32, c_int32, c_void_p, c_void_p]),
     "aa_dense_small_dx": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
@@ -163,7 +172,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 4:
+    if lib.aa_abi_version() != 5:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

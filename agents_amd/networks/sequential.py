@@ -27,6 +27,9 @@ FUSED_SMALL_MLP = True   # whole <=64-wide MLPs in one forward / one backward la
 DX_FIRST = True   # record a layer's input-gradient launch before its weight-gradient launch
 
 
+FUSE_CONV_PAIRS = True   # conv -> conv over LDS-sized fp32 frames in one launch (csrc/conv_pair.hip)
+
+
 def _align4(n):
     return (n + 3) // 4 * 4
 
@@ -296,7 +299,13 @@ class Sequential(network.Network):
         cur = x
         div = None
         pi = 0
-        for l in self._layers:
+        skip = False
+        for li, l in enumerate(self._layers):
+            if skip:        # second conv of a fused pair: already computed
+                skip = False
+                cur = s.ys[pi]
+                pi += 1
+                continue
             if isinstance(l, L.Rescale):
                 div = l.divisor
             elif isinstance(l, L.Flatten):
@@ -310,8 +319,20 @@ class Sequential(network.Network):
                     a_div = 1.0
                 div = None
                 s.xs[pi] = cur
-                ops.conv_forward(cur, self._kviews[pi], self._bviews[pi], l.stride, l.activation,
-                                 s.ys[pi], a_div=a_div)
+                nxt = self._layers[li + 1] if li + 1 < len(self._layers) else None
+                if (FUSE_CONV_PAIRS and cur.dtype == torch.float32 and isinstance(nxt, L.Conv2D)
+                        and ops.conv_pair_supported(cur.shape, self._kviews[pi], l.stride,
+                                                    self._kviews[pi + 1], nxt.stride)):
+                    # two convs over frames that fit LDS: one launch, one workgroup per frame
+                    s.xs[pi + 1] = s.ys[pi]
+                    ops.conv_pair_forward(cur, self._kviews[pi], self._bviews[pi], l.stride,
+                                          l.activation, s.ys[pi], self._kviews[pi + 1],
+                                          self._bviews[pi + 1], nxt.stride, nxt.activation,
+                                          s.ys[pi + 1])
+                    skip = True
+                else:
+                    ops.conv_forward(cur, self._kviews[pi], self._bviews[pi], l.stride,
+                                     l.activation, s.ys[pi], a_div=a_div)
                 cur = s.ys[pi]
                 pi += 1
             elif isinstance(l, L.Dense):

@@ -263,6 +263,60 @@ def conv_forward(x, w, bias, stride, act, out, a_div=255.0, force_cfg=0, force_s
     return out
 
 
+def _pair_descs(w1, b1, s1, act1, y1, w2, b2, s2, act2, y2):
+    d = []
+    for w, b, st, act, y in ((w1, b1, s1, act1, y1), (w2, b2, s2, act2, y2)):
+        KH, KW, _, Cout = w.shape
+        d.append(_lib.ConvLayerDesc(w=ptr(w), bias=ptr(b), y=ptr(y), KH=KH, KW=KW, stride=st,
+                                    Cout=Cout, act=ACT[act]))
+    return d
+
+
+_PAIR_OK = {}
+
+
+def conv_pair_supported(x_shape, w1, s1, w2, s2):
+    """True when two consecutive VALID convs over fp32 NHWC frames of x_shape fit the fused
+    one-workgroup-per-frame kernel (csrc/conv_pair.hip)."""
+    key = (tuple(x_shape), tuple(w1.shape), s1, tuple(w2.shape), s2)
+    ok = _PAIR_OK.get(key)
+    if ok is None:
+        Bn, H, W, C = x_shape
+        if len(w1.shape) != 4 or len(w2.shape) != 4 or w1.shape[2] != C or \
+                w2.shape[2] != w1.shape[3]:
+            ok = False
+        else:
+            d = []
+            for w, st in ((w1, s1), (w2, s2)):
+                d.append(_lib.ConvLayerDesc(w=None, bias=None, y=None, KH=w.shape[0],
+                                            KW=w.shape[1], stride=st, Cout=w.shape[3], act=0))
+            ok = bool(_lib.load().aa_conv_pair_supported(Bn, H, W, C, ctypes.byref(d[0]),
+                                                         ctypes.byref(d[1])))
+        _PAIR_OK[key] = ok
+    return ok
+
+
+def conv_pair_forward(x, w1, b1, s1, act1, y1, w2, b2, s2, act2, y2):
+    """y1 = act1(conv(x, w1) + b1), y2 = act2(conv(y1, w2) + b2) in one launch; both are written."""
+    require_cuda(x, w1, w2, y1, y2)
+    if x.dtype != torch.float32:
+        raise ValueError("conv_pair_forward needs a float32 NHWC input")
+    Bn, H, W, C, KH1, KW1, C1, OH1, OW1 = _conv_common(x, w1, s1)
+    KH2, KW2, Cin2, C2 = w2.shape
+    OH2, OW2 = conv_out_hw(OH1, OW1, KH2, KW2, s2)
+    if Cin2 != C1 or not w2.is_contiguous():
+        raise ValueError("conv_pair_forward: second kernel does not match the first layer")
+    _f32c(w1, "w1"); _f32c(w2, "w2"); _f32c(y1, "y1"); _f32c(y2, "y2")
+    if y1.numel() != Bn * OH1 * OW1 * C1 or y2.numel() != Bn * OH2 * OW2 * C2:
+        raise ValueError("conv_pair_forward: bad output sizes")
+    d = _pair_descs(w1, b1, s1, act1, y1, w2, b2, s2, act2, y2)
+    with torch.cuda.device(x.device):
+        check(_lib.load().aa_conv_pair_forward(ptr(x), _img_pitch(x), Bn, H, W, C,
+                                               ctypes.byref(d[0]), ctypes.byref(d[1]),
+                                               _lib.stream_ptr()), "aa_conv_pair_forward")
+    return y2
+
+
 def conv_dw(x, dz, w_shape, stride, out, a_div=255.0, force_cfg=0, force_splits=0,
             bias_grad=None):
     """out[KH,KW,Cin,Cout] = patches(x)^T @ dz[B*OH*OW, Cout]; bias_grad[Cout] = column sums of

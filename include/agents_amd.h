@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 4
+#define AA_ABI_VERSION 5
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -159,6 +159,25 @@ int aa_mlp_small_backward(const float* x, int64_t ldx, const float* params, int3
                           const int64_t* b_off, int64_t B, float* const* y_h, const float* dy,
                           float* grads, int64_t total_params, float* dx_out, void* workspace,
                           int64_t workspace_bytes, void* stream);
+
+/* Two consecutive VALID Conv2D layers forward in one launch, one workgroup per frame (the
+ * conv2 -> conv3 pair of the Mnih-15 Q-network, examples/dqn/mnih15/dqn_train_eval_atari.py:80-112;
+ * keras Conv2D arithmetic, fp32 MFMA).  x: fp32 NHWC [n_img,H,W,Cin] (img_pitch floats between
+ * frames, 0 = dense); each layer: w HWIO [KH,KW,Cin_l,Cout], bias nullable, y [n_img,OH,OW,Cout]
+ * = act(conv + bias) -- BOTH outputs are written (the backward pass needs the middle one).
+ * Limits: Cin % 32 == 0 (both layers' inputs), Cout % 16 == 0, OH*OW <= 128 per layer, both LDS frames <= 150 KiB
+ * (aa_conv_pair_supported returns 1 when a shape qualifies; otherwise AA_ERR_RANGE). */
+typedef struct aa_conv_layer_desc {
+  const float* w;
+  const float* bias;
+  float* y;
+  int32_t KH, KW, stride, Cout, act;
+} aa_conv_layer_desc;
+int aa_conv_pair_supported(int32_t n_img, int32_t H, int32_t W, int32_t Cin,
+                           const aa_conv_layer_desc* first, const aa_conv_layer_desc* second);
+int aa_conv_pair_forward(const float* x, int64_t img_pitch, int32_t n_img, int32_t H, int32_t W,
+                         int32_t Cin, const aa_conv_layer_desc* first,
+                         const aa_conv_layer_desc* second, void* stream);
 
 /* out[n] = sum_m x[m*ld + n]  (bias gradients).  workspace >= aa_colsum_workspace_bytes. */
 int64_t aa_colsum_workspace_bytes(int64_t M, int64_t N);

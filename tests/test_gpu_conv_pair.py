@@ -1,0 +1,141 @@
+"""Two consecutive Conv2D layers in one launch (csrc/conv_pair.hip) against float64 and against the
+layer-by-layer kernels; the Sequential integration (forward values and the backward pass that
+consumes the middle activation)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from agents_amd import ops
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda", 0)
+
+
+def rnd(rng, *shape):
+    return torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+
+
+def act_ref(x, act):
+    return torch.relu(x) if act == "relu" else torch.tanh(x) if act == "tanh" else x
+
+
+def conv_ref(x, w, b, stride):
+    y = F.conv2d(x.permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1),
+                 None if b is None else b.double(), stride=stride)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def close(got, ref, tol=TOL):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape
+    scale = max(ref.abs().max().item(), 1e-30)
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+PAIRS = [  # (B, H, W, C, (KH1,KW1,s1,F1,act1), (KH2,KW2,s2,F2,act2))
+    (8, 20, 20, 32, (4, 4, 2, 64, "relu"), (3, 3, 1, 64, "relu")),     # Atari conv2 -> conv3
+    (300, 20, 20, 32, (4, 4, 2, 64, "relu"), (3, 3, 1, 64, "relu")),   # more frames than CUs
+    (600, 9, 9, 32, (3, 3, 1, 32, "tanh"), (2, 2, 1, 32, None)),       # frames looped per workgroup
+    (3, 12, 10, 32, (3, 2, 1, 64, None), (2, 3, 2, 48, "relu")),       # rectangular, three column tiles
+    (2, 23, 23, 32, (5, 5, 2, 32, "relu"), (3, 3, 3, 16, "tanh")),     # 100 -> 9 pixels, stride 3
+    (1, 4, 4, 32, (4, 4, 1, 32, None), (1, 1, 1, 16, None)),           # single pixel
+]
+
+
+@pytest.mark.parametrize("cfg", PAIRS)
+@pytest.mark.parametrize("bias", [True, False])
+def test_conv_pair_forward(dev, cfg, bias):
+    B, H, W, C, (KH1, KW1, s1, F1, a1), (KH2, KW2, s2, F2, a2) = cfg
+    rng = np.random.default_rng(B + H + C + F1 + F2)
+    x = rnd(rng, B, H, W, C)
+    w1, w2 = rnd(rng, KH1, KW1, C, F1) * 0.2, rnd(rng, KH2, KW2, F1, F2) * 0.2
+    b1 = rnd(rng, F1) if bias else None
+    b2 = rnd(rng, F2) if bias else None
+    OH1, OW1 = ops.conv_out_hw(H, W, KH1, KW1, s1)
+    OH2, OW2 = ops.conv_out_hw(OH1, OW1, KH2, KW2, s2)
+    assert ops.conv_pair_supported((B, H, W, C), w1, s1, w2, s2)
+    y1 = torch.full((B, OH1, OW1, F1), float("nan"), device=dev)
+    y2 = torch.full((B, OH2, OW2, F2), float("nan"), device=dev)
+    d = lambda t: None if t is None else t.to(dev)
+    ops.conv_pair_forward(d(x), d(w1), d(b1), s1, a1, y1, d(w2), d(b2), s2, a2, y2)
+    r1 = act_ref(conv_ref(x.double(), w1, b1, s1), a1)
+    r2 = act_ref(conv_ref(r1, w2, b2, s2), a2)
+    close(y1, r1)
+    close(y2, r2)
+    # the layer-by-layer kernels agree to the same tolerance
+    z1 = torch.empty_like(y1)
+    z2 = torch.empty_like(y2)
+    ops.conv_forward(d(x), d(w1), d(b1), s1, a1, z1)
+    ops.conv_forward(z1, d(w2), d(b2), s2, a2, z2)
+    close(y1, z1.cpu())
+    close(y2, z2.cpu(), tol=5e-5)
+
+
+def test_conv_pair_strided_batch_and_determinism(dev):
+    rng = np.random.default_rng(4)
+    x5 = rnd(rng, 6, 2, 20, 20, 32).to(dev)
+    w1, w2 = (rnd(rng, 4, 4, 32, 64) * 0.1).to(dev), (rnd(rng, 3, 3, 64, 64) * 0.1).to(dev)
+    b1, b2 = rnd(rng, 64).to(dev), rnd(rng, 64).to(dev)
+    outs = []
+    for _ in range(2):
+        y1 = torch.empty(6, 9, 9, 64, device=dev)
+        y2 = torch.empty(6, 7, 7, 64, device=dev)
+        ops.conv_pair_forward(x5[:, 1], w1, b1, 2, "relu", y1, w2, b2, 1, "relu", y2)
+        outs.append((y1.cpu(), y2.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    r1 = torch.relu(conv_ref(x5[:, 1].cpu().double(), w1.cpu(), b1.cpu(), 2))
+    close(outs[0][1], torch.relu(conv_ref(r1, w2.cpu(), b2.cpu(), 1)))
+
+
+def test_conv_pair_unsupported_shapes(dev):
+    rng = np.random.default_rng(5)
+    w1, w2 = rnd(rng, 8, 8, 4, 32), rnd(rng, 4, 4, 32, 64)
+    assert not ops.conv_pair_supported((4, 84, 84, 4), w1, 4, w2, 2)       # 400 pixels per frame
+    w3, w4 = rnd(rng, 3, 3, 16, 32), rnd(rng, 1, 1, 32, 16)
+    assert not ops.conv_pair_supported((4, 8, 8, 16), w3, 1, w4, 1)        # Cin % 32 != 0
+    w5 = rnd(rng, 1, 1, 32, 20)
+    assert not ops.conv_pair_supported((4, 8, 8, 32), rnd(rng, 3, 3, 32, 32), 1, w5, 1)  # Cout % 16
+    with pytest.raises(Exception):
+        ops.conv_pair_forward(torch.zeros(4, 84, 84, 4, device=dev), w1.to(dev), None, 4, None,
+                              torch.empty(4, 20, 20, 32, device=dev), w2.to(dev), None, 2, None,
+                              torch.empty(4, 9, 9, 64, device=dev))
+
+
+def test_sequential_uses_pair_and_backward_matches(dev):
+    """The Atari Q-network forward/backward with the fused pair equals the layer-by-layer path
+    (same kernels for everything else) to fp32 tolerance."""
+    from agents_amd.networks import sequential, layers as L
+    from agents_amd.specs import tensor_spec
+    spec = tensor_spec.TensorSpec((84, 84, 4), torch.uint8)
+
+    def build():
+        net = sequential.Sequential([
+            L.Rescale(255.0), L.Conv2D(32, 8, 4, activation="relu"),
+            L.Conv2D(64, 4, 2, activation="relu"), L.Conv2D(64, 3, 1, activation="relu"),
+            L.Flatten(), L.Dense(512, activation="relu"), L.Dense(6)], input_spec=spec, seed=3)
+        net.create_variables(spec, device=dev)
+        return net
+
+    g = torch.Generator().manual_seed(1)
+    x = torch.randint(0, 256, (16, 84, 84, 4), dtype=torch.uint8, generator=g).to(dev)
+    dq = torch.randn(16, 6, generator=g).to(dev)
+    res = {}
+    for fuse in (True, False):
+        sequential.FUSE_CONV_PAIRS = fuse
+        try:
+            net = build()
+            q = net.forward(x, slot="t", need_grad=True).clone()
+            net.backward(dq, slot="t")
+            torch.cuda.synchronize()
+            res[fuse] = (q.cpu(), net.flat_grads.clone().cpu())
+        finally:
+            sequential.FUSE_CONV_PAIRS = True
+    close(res[True][0], res[False][0])
+    close(res[True][1], res[False][1], tol=5e-5)

@@ -38,6 +38,10 @@ def main():
     elif args.name == "conv3.fwd":
         x, w, b, y = r(S, 9, 9, 64), r(3, 3, 64, 64), r(64), r(S, 7, 7, 64)
         fn = lambda: ops.conv_forward(x, w, b, 1, "relu", y, force_cfg=c, force_splits=s)
+    elif args.name == "conv23.fwd":
+        x, w2, b2, y2 = r(S, 20, 20, 32), r(4, 4, 32, 64), r(64), r(S, 9, 9, 64)
+        w3, b3, y3 = r(3, 3, 64, 64), r(64), r(S, 7, 7, 64)
+        fn = lambda: ops.conv_pair_forward(x, w2, b2, 2, "relu", y2, w3, b3, 1, "relu", y3)
     elif args.name == "fc1.fwd":
         x, w, b, y = r(S, 3136), r(3136, 512), r(512), r(S, 512)
         fn = lambda: ops.dense_forward(x, w, b, "relu", y, force_cfg=c, force_splits=s)
