@@ -14,6 +14,8 @@ all-reduce are each a single pass over one contiguous range.
 import ctypes
 
 import numpy as np
+import os
+
 import torch
 
 from agents_amd import _lib, ops
@@ -27,7 +29,9 @@ FUSED_SMALL_MLP = True   # whole <=64-wide MLPs in one forward / one backward la
 DX_FIRST = True   # record a layer's input-gradient launch before its weight-gradient launch
 
 
-FUSE_CONV_PAIRS = True   # conv -> conv over LDS-sized fp32 frames in one launch (csrc/conv_pair.hip)
+# conv -> conv over LDS-sized fp32 frames in one launch (csrc/conv_pair.hip); AA_FUSE_CONV_PAIRS=0
+# selects the layer-by-layer kernels (A/B measurements)
+FUSE_CONV_PAIRS = os.environ.get("AA_FUSE_CONV_PAIRS", "1") != "0"
 
 
 def _align4(n):

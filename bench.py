@@ -160,10 +160,17 @@ def kernel_breakdown(w, S, reps=20):
                 256 * (2.0 * ROW_BYTES + 8)))
     out.append(("conv1.fwd(u8)", timeit(lambda: ops.conv_forward(
         obs_t, kv[0], bv[0], 4, "relu", slot.ys[0], a_div=255.0)), 3, f(m[0]), 0))
-    out.append(("conv2.fwd", timeit(lambda: ops.conv_forward(
-        slot.ys[0], kv[1], bv[1], 2, "relu", slot.ys[1])), 3, f(m[1]), 0))
-    out.append(("conv3.fwd", timeit(lambda: ops.conv_forward(
-        slot.ys[1], kv[2], bv[2], 1, "relu", slot.ys[2])), 3, f(m[2]), 0))
+    from agents_amd.networks import sequential as _seq
+    if _seq.FUSE_CONV_PAIRS and ops.conv_pair_supported(tuple(slot.ys[0].shape), kv[1], 2, kv[2], 1):
+        # what the network runs: both layers in one launch (csrc/conv_pair.hip)
+        out.append(("conv2+conv3.fwd(fused)", timeit(lambda: ops.conv_pair_forward(
+            slot.ys[0], kv[1], bv[1], 2, "relu", slot.ys[1], kv[2], bv[2], 1, "relu",
+            slot.ys[2])), 3, f(m[1] + m[2]), 0))
+    else:
+        out.append(("conv2.fwd", timeit(lambda: ops.conv_forward(
+            slot.ys[0], kv[1], bv[1], 2, "relu", slot.ys[1])), 3, f(m[1]), 0))
+        out.append(("conv3.fwd", timeit(lambda: ops.conv_forward(
+            slot.ys[1], kv[2], bv[2], 1, "relu", slot.ys[2])), 3, f(m[2]), 0))
     x3 = slot.ys[2].view(S, -1)
     out.append(("fc1.fwd", timeit(lambda: ops.dense_forward(
         x3, kv[3], bv[3], "relu", slot.ys[3])), 3, f(m[3]), 0))

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--splits", type=int, default=0)
     ap.add_argument("--no-dma", action="store_true")
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--no-time", action="store_true", help="skip the graph timing (profiler runs)")
     args = ap.parse_args()
     ops.FORCE_NO_DMA = args.no_dma
     S = args.batch
@@ -73,6 +74,8 @@ def main():
     for _ in range(args.reps):
         fn()
     torch.cuda.synchronize()
+    if args.no_time:
+        return
     # graph-timed (what the launch costs inside the captured step)
     g2 = torch.cuda.CUDAGraph()
     st = torch.cuda.Stream()

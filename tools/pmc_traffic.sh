@@ -7,10 +7,10 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/pmc
 mkdir -p $OUT
-for case in conv1.fwd conv1.dW conv2.fwd replay.gather; do
+for case in conv1.fwd conv1.dW conv23.fwd replay.gather; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/${case}_$ctr -o r -- \
-      python tools/gemm_one.py $case --reps 10 > $OUT/${case}_$ctr.log 2>&1
+      python tools/gemm_one.py $case --reps 10 --no-time > $OUT/${case}_$ctr.log 2>&1
   done
 done
 python tools/pmc_traffic_summary.py $OUT gpurun_out/pmc_traffic.json

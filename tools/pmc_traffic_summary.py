@@ -8,8 +8,9 @@ import json
 import os
 import sys
 
-CASES = {"conv1.fwd": ("conv1.fwd(u8)", "aa_gemm"),
-         "conv1.dW": ("conv1.dW(u8,+bias grad)", "aa_gemm"),
+CASES = {"conv1.fwd": ("conv1.fwd(u8)", "aa_conv_u8_bf16x3_kernel"),
+         "conv1.dW": ("conv1.dW(u8,+bias grad)", "aa_conv_u8_dw_bf16x3_kernel"),  # main kernel only
+         "conv23.fwd": ("conv2+conv3.fwd(fused)", "aa_conv_pair_kernel"),
          "conv2.fwd": ("conv2.fwd", "aa_gemm"),
          "replay.gather": ("replay.get_next(sample+gather 512 rows)", "aa_rb_gather")}
 
