@@ -34,6 +34,13 @@ class ConvLayerDesc(Structure):
                 ("KW", c_int32), ("stride", c_int32), ("Cout", c_int32), ("act", c_int32)]
 
 
+class ConvDxDesc(Structure):
+    _fields_ = [("dz", c_void_p), ("w", c_void_p), ("mask_src", c_void_p), ("dx", c_void_p),
+                ("n_img", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32),
+                ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("Cout", c_int32),
+                ("mask_kind", c_int32)]
+
+
 class GemmDesc(Structure):
     _fields_ = [
         ("A", c_void_p), ("B", c_void_p), ("C", c_void_p),
@@ -69,6 +76,8 @@ _SIGNATURES = {
                                        POINTER(ConvLayerDesc)]),
     "aa_conv_pair_forward": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                      POINTER(ConvLayerDesc), POINTER(ConvLayerDesc), c_void_p]),
+    "aa_conv_dx_frame_supported": (c_int, [POINTER(ConvDxDesc)]),
+    "aa_conv_dx_frame": (c_int, [POINTER(ConvDxDesc), c_void_p]),
     "aa_dense_small_forward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64,
                                        c_int32, c_int32, c_void_p, c_void_p]),
     "aa_dense_small_dx": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,

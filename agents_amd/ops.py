@@ -351,12 +351,57 @@ def conv_dx(dz, w, x_shape, stride, dcol, out, mask_src=None, mask_act=None):
     _f32c(dz, "dz"); _f32c(w, "w"); _f32c(dcol, "dcol"); _f32c(out, "out")
     if dcol.numel() < M * Kp or out.numel() != Bn * H * W * C:
         raise ValueError("conv_dx: bad sizes")
+    if CONV_DX_FRAME and (mask_src is None or mask_src.is_contiguous()) and \
+            conv_dx_frame_supported(tuple(x_shape), tuple(w.shape), stride):
+        return conv_dx_frame(dz, w, x_shape, stride, out, mask_src=mask_src, mask_act=mask_act)
     d = gemm_desc(A=ptr(dz), B=ptr(w), C=ptr(dcol), M=M, N=Kp, K=Cout, lda=Cout, ldb=Cout,
                   ldc=Kp, a_mode=AA_A_ROW, b_mode=AA_B_COL)
     gemm(d, dz.device)
     check(lib.aa_col2im_f32(ptr(dcol), Bn, H, W, C, KH, KW, stride, ptr(out), ptr(mask_src),
                             ACT[mask_act] if mask_src is not None else 0, stream_ptr()),
           "aa_col2im_f32")
+    return out
+
+
+CONV_DX_FRAME = _os.environ.get("AA_CONV_DX_FRAME", "1") != "0"   # gather-form conv input gradient
+_DXF_OK = {}
+
+
+def _dxf_desc(x_shape, w_shape, stride, dz=None, w=None, mask_src=None, mask_act=None, out=None):
+    Bn, H, W, C = x_shape
+    KH, KW, Cin, Cout = w_shape
+    return _lib.ConvDxDesc(dz=ptr(dz), w=ptr(w), mask_src=ptr(mask_src), dx=ptr(out), n_img=Bn,
+                           H=H, W=W, Cin=C, KH=KH, KW=KW, stride=stride, Cout=Cout,
+                           mask_kind=ACT[mask_act] if mask_src is not None else 0)
+
+
+def conv_dx_frame_supported(x_shape, w_shape, stride):
+    key = (tuple(x_shape), tuple(w_shape), stride)
+    ok = _DXF_OK.get(key)
+    if ok is None:
+        d = _dxf_desc(x_shape, w_shape, stride)
+        ok = x_shape[3] == w_shape[2] and bool(
+            _lib.load().aa_conv_dx_frame_supported(ctypes.byref(d)))
+        _DXF_OK[key] = ok
+    return ok
+
+
+def conv_dx_frame(dz, w, x_shape, stride, out, mask_src=None, mask_act=None):
+    """Input gradient of a VALID conv, one workgroup per frame (csrc/conv_dx_frame.hip)."""
+    require_cuda(dz, w, out, mask_src)
+    Bn, H, W, C = x_shape
+    KH, KW, Cin, Cout = w.shape
+    OH, OW = conv_out_hw(H, W, KH, KW, stride)
+    _f32c(dz, "dz"); _f32c(w, "w"); _f32c(out, "out")
+    if mask_src is not None:
+        _f32c(mask_src, "mask_src")
+        if mask_src.numel() != Bn * H * W * C:
+            raise ValueError("conv_dx_frame: bad mask size")
+    if dz.numel() != Bn * OH * OW * Cout or out.numel() != Bn * H * W * C or Cin != C:
+        raise ValueError("conv_dx_frame: bad sizes")
+    d = _dxf_desc(x_shape, w.shape, stride, dz, w, mask_src, mask_act, out)
+    with torch.cuda.device(dz.device):
+        check(_lib.load().aa_conv_dx_frame(ctypes.byref(d), stream_ptr()), "aa_conv_dx_frame")
     return out
 
 

@@ -179,6 +179,24 @@ int aa_conv_pair_forward(const float* x, int64_t img_pitch, int32_t n_img, int32
                          int32_t Cin, const aa_conv_layer_desc* first,
                          const aa_conv_layer_desc* second, void* stream);
 
+/* Input gradient of a VALID Conv2D in gather form, one workgroup per frame (no column-gradient
+ * slab, no col2im): dx[b,iy,ix,ci] = act'(mask_src[b,iy,ix,ci]) * sum over the patches containing
+ * (iy,ix) of dz[b,oy,ox,:] . w[ky,kx,ci,:]   (tf.GradientTape through keras Conv2D,
+ * agents/dqn/dqn_agent.py:412-426).  dz [n_img,OH,OW,Cout] dense, w HWIO, dx / mask_src
+ * [n_img,H,W,Cin] dense; mask_src nullable (the layer's forward input when it is an activation
+ * output).  Limits: Cin % 16 == 0, Cout % 32 == 0, ceil(H/stride)*ceil(W/stride) <= 128, padded dZ
+ * frame <= 150 KiB of LDS (aa_conv_dx_frame_supported returns 1 when a shape qualifies, else the
+ * call returns AA_ERR_RANGE and aa_gemm_f32 + aa_col2im_f32 remain the general path). */
+typedef struct aa_conv_dx_desc {
+  const float* dz;
+  const float* w;
+  const float* mask_src;
+  float* dx;
+  int32_t n_img, H, W, Cin, KH, KW, stride, Cout, mask_kind;
+} aa_conv_dx_desc;
+int aa_conv_dx_frame_supported(const aa_conv_dx_desc* d);
+int aa_conv_dx_frame(const aa_conv_dx_desc* d, void* stream);
+
 /* out[n] = sum_m x[m*ld + n]  (bias gradients).  workspace >= aa_colsum_workspace_bytes. */
 int64_t aa_colsum_workspace_bytes(int64_t M, int64_t N);
 int aa_colsum_f32(const float* x, int64_t ld, int64_t M, int64_t N, float* out, void* workspace,

@@ -43,6 +43,15 @@ def main():
         x, w2, b2, y2 = r(S, 20, 20, 32), r(4, 4, 32, 64), r(64), r(S, 9, 9, 64)
         w3, b3, y3 = r(3, 3, 64, 64), r(64), r(S, 7, 7, 64)
         fn = lambda: ops.conv_pair_forward(x, w2, b2, 2, "relu", y2, w3, b3, 1, "relu", y3)
+    elif args.name in ("conv2.dX", "conv3.dX"):
+        if args.name == "conv2.dX":
+            xs, wsh, strd, npix = (S, 20, 20, 32), (4, 4, 32, 64), 2, 81
+        else:
+            xs, wsh, strd, npix = (S, 9, 9, 64), (3, 3, 64, 64), 1, 49
+        y, w, dz, dx = r(*xs), r(*wsh), r(S * npix, 64), r(*xs)
+        dcol = torch.empty(S * npix * wsh[0] * wsh[1] * wsh[2], device=dev)
+        ops.CONV_DX_FRAME = not args.no_dma      # --no-dma selects the GEMM + col2im path here
+        fn = lambda: ops.conv_dx(dz, w, xs, strd, dcol, dx, mask_src=y, mask_act="relu")
     elif args.name == "fc1.fwd":
         x, w, b, y = r(S, 3136), r(3136, 512), r(512), r(S, 512)
         fn = lambda: ops.dense_forward(x, w, b, "relu", y, force_cfg=c, force_splits=s)
