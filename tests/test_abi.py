@@ -41,6 +41,38 @@ def test_argument_validation_without_gpu(lib):
     assert lib.aa_colsum_workspace_bytes(1000, 32) > 0
 
 
+def test_shape_qualification_is_host_side(lib):
+    """The per-frame conv kernels decide on the host which shapes they take (no device access):
+    the Atari conv2 -> conv3 pair and both input gradients qualify, the 84x84 first layer does not;
+    the GEMM planner reports workspace for the plans a shape selects."""
+    def layer(kh, kw, s, cout):
+        return _lib.ConvLayerDesc(w=None, bias=None, y=None, KH=kh, KW=kw, stride=s, Cout=cout, act=0)
+    a, b = layer(4, 4, 2, 64), layer(3, 3, 1, 64)
+    assert lib.aa_conv_pair_supported(256, 20, 20, 32, ctypes.byref(a), ctypes.byref(b)) == 1
+    c = layer(8, 8, 4, 32)
+    assert lib.aa_conv_pair_supported(256, 84, 84, 4, ctypes.byref(c), ctypes.byref(a)) == 0
+    assert lib.aa_conv_pair_forward(None, 0, 256, 20, 20, 32, ctypes.byref(a), ctypes.byref(b),
+                                    None) == -22
+    def dx(n, h, w, cin, kh, kw, s, cout):
+        return _lib.ConvDxDesc(dz=None, w=None, mask_src=None, dx=None, n_img=n, H=h, W=w, Cin=cin,
+                               KH=kh, KW=kw, stride=s, Cout=cout, mask_kind=0)
+    assert lib.aa_conv_dx_frame_supported(ctypes.byref(dx(256, 20, 20, 32, 4, 4, 2, 64))) == 1
+    assert lib.aa_conv_dx_frame_supported(ctypes.byref(dx(256, 9, 9, 64, 3, 3, 1, 64))) == 1
+    assert lib.aa_conv_dx_frame_supported(ctypes.byref(dx(256, 84, 84, 4, 8, 8, 4, 32))) == 0
+    assert lib.aa_conv_dx_frame(ctypes.byref(dx(256, 20, 20, 32, 4, 4, 2, 64)), None) == -22
+    assert lib.aa_conv_dx_frame(ctypes.byref(dx(4, 40, 40, 32, 3, 3, 1, 64)), None) == -34
+    # planner: the uint8 conv1 weight gradient takes the bf16 per-frame plan (one slab per frame,
+    # plus the fused bias-gradient rows); force_cfg = 9 on an ineligible shape is rejected
+    g = _lib.GemmDesc(A=1 << 20, B=1 << 21, C=1 << 22, M=256, N=32, K=256 * 400, lda=0, ldb=32,
+                      ldc=32, a_mode=_lib.AA_A_PATCH_T_U8, b_mode=_lib.AA_B_ROW, n_img=256, H=84,
+                      W=84, Cin=4, KH=8, KW=8, stride=4, a_div=255.0, colsum_out=1 << 23)
+    assert lib.aa_gemm_f32_workspace_bytes(ctypes.byref(g)) == 256 * (256 * 32 + 32) * 4
+    g.force_cfg = 9
+    g.N = 64
+    g.ldb = g.ldc = 64
+    assert lib.aa_gemm_f32_workspace_bytes(ctypes.byref(g)) == -1
+
+
 def test_no_product_import_of_oracle():
     """The oracle is test infrastructure: nothing under agents_amd/ may import it."""
     bad = []
