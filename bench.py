@@ -182,12 +182,12 @@ def kernel_breakdown(w, S, reps=20):
         dz4, kv[3], slot.dxs[3].view(S, -1), mask_src=x3, mask_act="relu")), 1, f(m[3]), 0))
     out.append(("conv3.dW(+bias grad)", timeit(lambda: ops.conv_dw(
         slot.ys[1], dz3, tuple(kv[2].shape), 1, gk[2], bias_grad=gb[2])), 1, f(m[2]), 0))
-    out.append(("conv3.dX(gemm+col2im)", timeit(lambda: ops.conv_dx(
+    out.append(("conv3.dX", timeit(lambda: ops.conv_dx(
         dz3, kv[2], tuple(slot.ys[1].shape), 1, slot.dcol, slot.dxs[2], mask_src=slot.ys[1],
         mask_act="relu")), 1, f(m[2]), 0))
     out.append(("conv2.dW(+bias grad)", timeit(lambda: ops.conv_dw(
         slot.ys[0], dz2, tuple(kv[1].shape), 2, gk[1], bias_grad=gb[1])), 1, f(m[1]), 0))
-    out.append(("conv2.dX(gemm+col2im)", timeit(lambda: ops.conv_dx(
+    out.append(("conv2.dX", timeit(lambda: ops.conv_dx(
         dz2, kv[1], tuple(slot.ys[0].shape), 2, slot.dcol, slot.dxs[1], mask_src=slot.ys[0],
         mask_act="relu")), 1, f(m[1]), 0))
     out.append(("conv1.dW(u8,+bias grad)", timeit(lambda: ops.conv_dw(
