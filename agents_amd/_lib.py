@@ -103,6 +103,11 @@ _SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                                c_double, c_double, c_double, c_int32, c_float, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p]),
+    "aa_dqn_td_loss_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                    c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                    c_int32, c_int32, c_double, c_double, c_double, c_int32,
+                                    c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
     "aa_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float,
                              c_float, c_float, c_void_p, c_void_p]),
     "aa_rmsprop_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
@@ -181,7 +186,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 5:
+    if lib.aa_abi_version() != 6:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

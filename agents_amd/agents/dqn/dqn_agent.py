@@ -44,6 +44,7 @@ class _Work:
         self.td_loss = torch.zeros((B,), **f)
         self.td_error = torch.zeros((B,), **f)
         self.dq = torch.zeros((B, A), **f)
+        self.field_sums = torch.zeros((2,), **f)   # sum(td_loss), sum(td_error): Learner's reduce
 
 
 class DqnAgent(tf_agent.TFAgent):
@@ -221,8 +222,20 @@ class DqnAgent(tf_agent.TFAgent):
                         self._gamma, reward_scale_factor,
                         self._loss_kind(td_errors_loss_fn or self._td_errors_loss_fn),
                         float(B * self.num_replicas), w.loss, w.td_loss, w.td_error, w.dq,
-                        gamma_loss=gamma)
+                        gamma_loss=gamma, field_sums_out=w.field_sums)
         return w
+
+    def reduce_loss_info(self, loss_info):
+        """Learner.run sums every LossInfo field over all axes (train/learner.py:322-337).  For the
+        LossInfo of the last train step the loss kernel has already produced those sums: returns a
+        LossInfo of scalars (views of the work buffer), or None for any other LossInfo."""
+        extra = getattr(loss_info, "extra", None)
+        td = getattr(extra, "td_loss", None)
+        for w in self._work.values():
+            if td is w.td_loss and extra.td_error is w.td_error:
+                return tf_agent.LossInfo(loss_info.loss, DqnLossInfo(
+                    td_loss=w.field_sums[0], td_error=w.field_sums[1]))
+        return None
 
     def _loss(self, experience, td_errors_loss_fn=None, gamma=1.0, reward_scale_factor=1.0,
               weights=None, training=False):

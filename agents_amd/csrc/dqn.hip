@@ -32,10 +32,11 @@ aa_dqn_td_loss_kernel(const float* __restrict__ q_online, const float* __restric
                       float gpow, float gamma_loss,
                       float reward_scale, int loss_kind, float global_batch,
                       float* __restrict__ loss_out, float* __restrict__ td_loss_out,
-                      float* __restrict__ td_error_out, float* __restrict__ dq_out) {
+                      float* __restrict__ td_error_out, float* __restrict__ dq_out,
+                      float* __restrict__ field_sums_out) {
   __shared__ float red[16];
   const int n = T - 1;
-  float local = 0.f;
+  float local = 0.f, sum_loss = 0.f, sum_err = 0.f;
   for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
     // ---- n-step return over the first n frames (foldr: acc = acc*disc + r) ------------------
     float ret = 0.f;
@@ -98,14 +99,21 @@ aa_dqn_td_loss_kernel(const float* __restrict__ q_online, const float* __restric
     td_loss_out[b] = loss;
     td_error_out[b] = td_error;
     local += weighted;
+    sum_loss += loss;
+    sum_err += td_error;
     const float gq = (valid * dloss_dq * w) / global_batch;
     for (int a = 0; a < A; ++a) dq_out[b * A + a] = (a == act) ? gq : 0.f;
   }
   const float total = aa_block_sum(local, red);
   if (threadIdx.x == 0) loss_out[0] = total / global_batch;
+  if (field_sums_out != nullptr) {   // the Learner's SUM over all axes of the LossInfo fields
+    const float s0 = aa_block_sum(sum_loss, red);
+    const float s1 = aa_block_sum(sum_err, red);
+    if (threadIdx.x == 0) { field_sums_out[0] = s0; field_sums_out[1] = s1; }
+  }
 }
 
-extern "C" int aa_dqn_td_loss(const float* q_online, const float* q_next_target,
+extern "C" int aa_dqn_td_loss_sums(const float* q_online, const float* q_next_target,
                               const float* q_next_select, const int32_t* next_mask,
                               const void* actions, int32_t actions_are_i64, int64_t action_stride,
                               const float* reward, const float* discount,
@@ -114,7 +122,7 @@ extern "C" int aa_dqn_td_loss(const float* q_online, const float* q_next_target,
                               double reward_scale,
                               int32_t loss_kind, float global_batch, float* loss_out,
                               float* td_loss_out, float* td_error_out, float* dq_out,
-                              void* stream) {
+                              float* field_sums_out, void* stream) {
   if (q_online == nullptr || q_next_target == nullptr || actions == nullptr || reward == nullptr ||
       discount == nullptr || step_type == nullptr || loss_out == nullptr ||
       td_loss_out == nullptr || td_error_out == nullptr || dq_out == nullptr)
@@ -131,12 +139,27 @@ extern "C" int aa_dqn_td_loss(const float* q_online, const float* q_next_target,
                        q_next_target, q_next_select, next_mask, actions, action_stride, reward,
                        discount, step_type, weights, B, T, A, (float)gamma, gpow, (float)gamma_loss,
                        (float)reward_scale, loss_kind,
-                       global_batch, loss_out, td_loss_out, td_error_out, dq_out);
+                       global_batch, loss_out, td_loss_out, td_error_out, dq_out, field_sums_out);
   else
     hipLaunchKernelGGL(aa_dqn_td_loss_kernel<false>, dim3(1), dim3(256), 0, st, q_online,
                        q_next_target, q_next_select, next_mask, actions, action_stride, reward,
                        discount, step_type, weights, B, T, A, (float)gamma, gpow, (float)gamma_loss,
                        (float)reward_scale, loss_kind,
-                       global_batch, loss_out, td_loss_out, td_error_out, dq_out);
+                       global_batch, loss_out, td_loss_out, td_error_out, dq_out, field_sums_out);
   return aa_launch_status();
+}
+
+extern "C" int aa_dqn_td_loss(const float* q_online, const float* q_next_target,
+                              const float* q_next_select, const int32_t* next_mask,
+                              const void* actions, int32_t actions_are_i64, int64_t action_stride,
+                              const float* reward, const float* discount,
+                              const int32_t* step_type, const float* weights, int64_t B,
+                              int32_t T, int32_t A, double gamma, double gamma_loss,
+                              double reward_scale, int32_t loss_kind, float global_batch,
+                              float* loss_out, float* td_loss_out, float* td_error_out,
+                              float* dq_out, void* stream) {
+  return aa_dqn_td_loss_sums(q_online, q_next_target, q_next_select, next_mask, actions,
+                             actions_are_i64, action_stride, reward, discount, step_type, weights,
+                             B, T, A, gamma, gamma_loss, reward_scale, loss_kind, global_batch,
+                             loss_out, td_loss_out, td_error_out, dq_out, nullptr, stream);
 }

@@ -421,7 +421,8 @@ def colsum(x2d, out):
 # ---- DQN loss -------------------------------------------------------------------------------
 def dqn_td_loss(q_online, q_next_target, q_next_select, next_mask, actions, reward, discount,
                 step_type, weights, gamma, reward_scale, loss_kind, global_batch, loss_out,
-                td_loss_out, td_error_out, dq_out, gamma_loss=None):
+                td_loss_out, td_error_out, dq_out, gamma_loss=None, field_sums_out=None):
+    """field_sums_out (optional float32[2]) receives sum(td_loss), sum(td_error)."""
     if gamma_loss is None:
         gamma_loss = gamma
     require_cuda(q_online, q_next_target, actions, reward, discount, step_type)
@@ -439,14 +440,19 @@ def dqn_td_loss(q_online, q_next_target, q_next_select, next_mask, actions, rewa
         action_stride = actions.stride(0)
     else:
         action_stride = actions.stride(0) if actions.numel() > 1 else 1
-    check(lib.aa_dqn_td_loss(ptr(q_online), ptr(q_next_target), ptr(q_next_select), ptr(next_mask),
-                             ptr(actions), 1 if actions.dtype == torch.int64 else 0,
-                             action_stride, ptr(reward), ptr(discount), ptr(step_type),
-                             ptr(weights), B, T, A, float(gamma), float(gamma_loss),
-                             float(reward_scale),
-                             int(loss_kind), float(global_batch), ptr(loss_out),
-                             ptr(td_loss_out), ptr(td_error_out), ptr(dq_out), stream_ptr()),
-          "aa_dqn_td_loss")
+    if field_sums_out is not None:
+        require_cuda(field_sums_out)
+        _f32c(field_sums_out, "field_sums_out")
+        if field_sums_out.numel() < 2:
+            raise ValueError("field_sums_out needs two elements")
+    check(lib.aa_dqn_td_loss_sums(ptr(q_online), ptr(q_next_target), ptr(q_next_select),
+                                  ptr(next_mask), ptr(actions),
+                                  1 if actions.dtype == torch.int64 else 0, action_stride,
+                                  ptr(reward), ptr(discount), ptr(step_type), ptr(weights), B, T, A,
+                                  float(gamma), float(gamma_loss), float(reward_scale),
+                                  int(loss_kind), float(global_batch), ptr(loss_out),
+                                  ptr(td_loss_out), ptr(td_error_out), ptr(dq_out),
+                                  ptr(field_sums_out), stream_ptr()), "aa_dqn_td_loss_sums")
 
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -24,6 +24,10 @@ TRAIN_DIR = "train"
 POLICY_SAVED_MODEL_DIR = "policies"
 
 
+# AA_FIELD_SUMS=0: always reduce LossInfo fields with generic reductions (A/B measurements)
+_FIELD_SUMS = os.environ.get("AA_FIELD_SUMS", "1") != "0"
+
+
 class Learner:
     def __init__(self, root_dir, train_step, agent, experience_dataset_fn=None,
                  after_train_strategy_step_fn=None, triggers=None, checkpoint_interval=100000,
@@ -82,6 +86,11 @@ class Learner:
     def _reduce_loss(self, loss_info):
         """SUM over replicas and over all axes of every LossInfo field (learner.py:322-337).
         All fields travel in ONE all-reduce (a [n_fields] vector) instead of one per field."""
+        hook = getattr(self._agent, "reduce_loss_info", None) if _FIELD_SUMS else None
+        if hook is not None:      # an agent whose loss kernel already holds the per-field sums
+            pre = hook(loss_info)
+            if pre is not None:
+                loss_info = pre
         flat = nest_utils.flatten(loss_info)
         idx = [i for i, t in enumerate(flat) if isinstance(t, torch.Tensor)]
         if not idx:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 5
+#define AA_ABI_VERSION 6
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -235,6 +235,17 @@ int aa_dqn_td_loss(const float* q_online, const float* q_next_target,
                    double reward_scale, int32_t loss_kind, float global_batch,
                    float* loss_out, float* td_loss_out, float* td_error_out, float* dq_out,
                    void* stream);
+/* Same, plus field_sums_out[2] = {sum_b td_loss[b], sum_b td_error[b]} (nullable): the SUM over all
+ * axes that Learner.run applies to every LossInfo field (train/learner.py:322-337), produced by the
+ * loss launch instead of by two reduction launches after the optimizer step. */
+int aa_dqn_td_loss_sums(const float* q_online, const float* q_next_target,
+                        const float* q_next_select, const int32_t* next_mask, const void* actions,
+                        int32_t actions_are_i64, int64_t action_stride, const float* reward,
+                        const float* discount, const int32_t* step_type, const float* weights,
+                        int64_t B, int32_t T, int32_t A, double gamma, double gamma_loss,
+                        double reward_scale, int32_t loss_kind, float global_batch,
+                        float* loss_out, float* td_loss_out, float* td_error_out, float* dq_out,
+                        float* field_sums_out, void* stream);
 
 /* =========================================================================================
  * Optimizers / target update / clipping  (keras optimizers; utils/common.py:250-346;

@@ -28,7 +28,7 @@ def test_binding_covers_header(lib):
 
 
 def test_abi_version(lib):
-    assert lib.aa_abi_version() == 5
+    assert lib.aa_abi_version() == 6
 
 
 def test_argument_validation_without_gpu(lib):

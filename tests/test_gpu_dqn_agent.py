@@ -257,3 +257,31 @@ def test_qnetwork_builder_and_call(dev):
         assert float((out.cpu() - ref).abs().max()) <= 3e-5 * scale
         np.testing.assert_allclose(net.get_weights()[-1], -0.2)  # Q-layer bias init
         assert np.abs(net.get_weights()[-2]).max() <= 0.03
+
+
+def test_learner_field_sums_come_from_the_loss_kernel(dev):
+    """Learner.run returns every LossInfo field summed over all axes (learner.py:322-337).  The
+    loss kernel produces those sums itself; they equal the sums of the per-sample fields, for the
+    train step's LossInfo only (any other LossInfo goes through the generic reduction)."""
+    from agents_amd.train import learner
+    tss, aspec = specs()
+    with torch.cuda.device(dev):
+        net = dummy_net()
+        agent = dqn_agent.DqnAgent(tss, aspec, q_network=net,
+                                   optimizer=optimizers.SGD(learning_rate=0.0),
+                                   td_errors_loss_fn=common.element_wise_squared_loss)
+        agent.initialize()
+        exp = two_frame(dev, [[5, 6], [7, 8]])
+        li = agent.train(exp)
+        pre = agent.reduce_loss_info(li)
+        assert pre is not None and pre.extra.td_loss.dim() == 0
+        np.testing.assert_allclose(pre.extra.td_loss.item(), li.extra.td_loss.double().sum().item(),
+                                   rtol=1e-6)
+        np.testing.assert_allclose(pre.extra.td_error.item(),
+                                   li.extra.td_error.double().sum().item(), rtol=1e-6)
+        assert agent.reduce_loss_info(agent.loss(exp)) is None      # clones: generic path
+        lrn = learner.Learner(None, common.create_variable("train_step"), agent,
+                              experience_dataset_fn=None, use_graph=False)
+        red = lrn._reduce_loss(li)
+        np.testing.assert_allclose(red.extra.td_loss.item(), li.extra.td_loss.sum().item(), rtol=1e-6)
+        np.testing.assert_allclose(red.loss.item(), li.loss.item(), rtol=0)
