@@ -27,6 +27,8 @@ from agents_amd.utils import nest_utils
 SMALL_HEAD_ON_MAIN = True
 FUSED_SMALL_MLP = True   # whole <=64-wide MLPs in one forward / one backward launch
 DX_FIRST = True   # record a layer's input-gradient launch before its weight-gradient launch
+# the first layer's weight gradient on the main stream (AA_LAST_DW_ON_MAIN=0: on the side stream)
+LAST_DW_ON_MAIN = os.environ.get("AA_LAST_DW_ON_MAIN", "1") != "0"
 
 
 # conv -> conv over LDS-sized fp32 frames in one launch (csrc/conv_pair.hip); AA_FUSE_CONV_PAIRS=0
@@ -522,9 +524,16 @@ class Sequential(network.Network):
                                 mask_src=x if prev_act else None, mask_act=prev_act)
                     dz_next = s.dxs[i]
                 if param_grads:
-                    on_side(lambda: ops.conv_dw(x, dz2, ks, l.stride, self._gkviews[i],
-                                                a_div=self._first_div() if i == 0 else 1.0,
-                                                bias_grad=self._gbviews[i]), fork=not (DX_FIRST and i > 0))
+                    dw = lambda: ops.conv_dw(x, dz2, ks, l.stride, self._gkviews[i],
+                                             a_div=self._first_div() if i == 0 else 1.0,
+                                             bias_grad=self._gbviews[i])
+                    if i == 0 and LAST_DW_ON_MAIN:
+                        # layer 0 has no input gradient: main has nothing left to do, while the
+                        # side stream is still finishing layer 1's weight gradient (timeline:
+                        # the launch waited ~15 us behind it for no dependency)
+                        dw()
+                    else:
+                        on_side(dw, fork=not (DX_FIRST and i > 0))
                 if dz_next is not None:
                     dz = dz_next
         if side_stream is not main:
