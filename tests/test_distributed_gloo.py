@@ -128,3 +128,37 @@ def test_single_replica_strategy_is_identity():
     assert s.all_reduce_sum_(t) is t and torch.equal(s.reduce_sum(t), t)
     with pytest.raises(RuntimeError):
         strategy_utils.DataParallelStrategy()
+
+
+def test_learner_uses_the_agents_precomputed_field_sums():
+    """An agent whose loss kernel already holds sum-over-all-axes of its LossInfo fields hands them
+    to Learner.run through `reduce_loss_info` (DqnAgent does); any other LossInfo takes the generic
+    reduction.  Both give the reference's SUM semantics (learner.py:322-337)."""
+    class HookAgent(LinearAgent):
+        def __init__(self, dim):
+            super().__init__(dim)
+            self.last = None
+            self.hook_calls = 0
+
+        def train(self, experience):
+            li = super().train(experience)
+            self.last = li
+            self.sums = li.extra["per_example"].sum()
+            return li
+
+        def reduce_loss_info(self, loss_info):
+            self.hook_calls += 1
+            if loss_info is self.last:
+                return tf_agent.LossInfo(loss_info.loss, {"per_example": self.sums})
+            return None
+
+    x, y = _data(3, 8, 4)
+    agent = HookAgent(4)
+    lrn = learner.Learner(None, agent.train_step_counter, agent,
+                          experience_dataset_fn=lambda: iter(lambda: ((x, y), "info"), None))
+    li = lrn.run(iterations=1)
+    assert agent.hook_calls == 1
+    assert li.extra["per_example"].dim() == 0
+    np.testing.assert_allclose(float(li.extra["per_example"]), float(li.loss), rtol=1e-6)
+    other = lrn.loss(((x, y), "info"))          # not the train step's LossInfo: generic path
+    assert agent.hook_calls == 2 and other.loss.dim() == 0
