@@ -327,6 +327,7 @@ class Sequential(network.Network):
                 s.xs[pi] = cur
                 nxt = self._layers[li + 1] if li + 1 < len(self._layers) else None
                 if (FUSE_CONV_PAIRS and cur.dtype == torch.float32 and isinstance(nxt, L.Conv2D)
+                        and cur.data_ptr() % 16 == 0 and cur.stride(0) % 4 == 0
                         and ops.conv_pair_supported(cur.shape, self._kviews[pi], l.stride,
                                                     self._kviews[pi + 1], nxt.stride)):
                     # two convs over frames that fit LDS: one launch, one workgroup per frame

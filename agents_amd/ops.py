@@ -352,6 +352,7 @@ def conv_dx(dz, w, x_shape, stride, dcol, out, mask_src=None, mask_act=None):
     if dcol.numel() < M * Kp or out.numel() != Bn * H * W * C:
         raise ValueError("conv_dx: bad sizes")
     if CONV_DX_FRAME and (mask_src is None or mask_src.is_contiguous()) and \
+            dz.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and \
             conv_dx_frame_supported(tuple(x_shape), tuple(w.shape), stride):
         return conv_dx_frame(dz, w, x_shape, stride, out, mask_src=mask_src, mask_act=mask_act)
     d = gemm_desc(A=ptr(dz), B=ptr(w), C=ptr(dcol), M=M, N=Kp, K=Cout, lda=Cout, ldb=Cout,
