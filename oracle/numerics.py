@@ -37,6 +37,14 @@ def u8_dot_bf16x3(u8, w):
     return (a @ lo + a @ mid) + a @ hi
 
 
+def u8t_dot_bf16x3(u8, dz):
+    """[P,K] uint8 frames-as-patches, [P,N] fp32 dZ -> [K,N]: the conv1 weight gradient, reduction
+    over pixels, dZ in three exact pieces, small pieces summed first (one chain per piece)."""
+    a = u8.to(torch.float32).t()
+    hi, mid, lo = split3(dz)
+    return (a @ lo + a @ mid) + a @ hi
+
+
 def dot_bf16x6(x, w):
     """[M,K] fp32 x [K,N] fp32 with both operands in pieces: the six largest cross products."""
     x1, x2, x3 = split3(x)

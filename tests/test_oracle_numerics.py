@@ -49,6 +49,20 @@ def test_u8_contraction_matches_fp32_accuracy():
     assert torch.equal(numerics.u8_dot_bf16x3(u8, wi).double(), u8.double() @ wi.double())
 
 
+def test_u8_weight_gradient_contraction():
+    """conv1 dW: reduction over 6,400 pixels of uint8 patch bytes x fp32 dZ split in three pieces."""
+    g = torch.Generator().manual_seed(4)
+    u8 = torch.randint(0, 256, (6400, 256), dtype=torch.uint8, generator=g)
+    dz = torch.randn(6400, 32, generator=g) * 1e-3
+    ref = u8.double().t() @ dz.double()
+    got = numerics.u8t_dot_bf16x3(u8, dz)
+    plain = u8.float().t() @ dz
+    scale = ref.abs().max()
+    assert (got.double() - ref).abs().max() / scale <= 2.0 * (plain.double() - ref).abs().max() / scale + 1e-7
+    dzi = torch.randint(-3, 4, (6400, 32), generator=g).float()
+    assert torch.equal(numerics.u8t_dot_bf16x3(u8, dzi).double(), u8.double().t() @ dzi.double())
+
+
 def test_six_product_contraction_has_fp32_class_error():
     g = torch.Generator().manual_seed(3)
     x, w = torch.randn(512, 512, generator=g), torch.randn(512, 64, generator=g)
