@@ -76,3 +76,37 @@ def conv_dx_gather(dz, w, x_shape, stride):
                     acc += win @ tap.T
             dx[:, py::s, px::s] = acc
     return dx
+
+
+# ---- the fma-refined quotient the conv1 kernels apply to each sum (Lambda(x / 255)) -------------
+def _rn32(x):
+    """Exact rational -> nearest-even fp32 (normal range), as a Fraction."""
+    import math
+    from fractions import Fraction
+    if x == 0:
+        return Fraction(0)
+    sgn = -1 if x < 0 else 1
+    a = abs(x)
+    e = math.floor(math.log2(float(a))) - 23
+    two = Fraction(2)
+    while a / two ** e >= 2 ** 24:
+        e += 1
+    while a / two ** e < 2 ** 23:
+        e -= 1
+    m = a / two ** e
+    fl = m.numerator // m.denominator
+    rem = m - fl
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl % 2 == 1):
+        fl += 1
+    return sgn * fl * two ** e
+
+
+def markstein_quotient(s, d):
+    """q0 = RN(s * RN(1/d)); q = RN(q0 + RN(s - d q0) * RN(1/d)) with every fma rounded once
+    (exact rational arithmetic in between).  Returns (q, RN(s / d)) as Fractions."""
+    from fractions import Fraction
+    s, d = Fraction(float(np.float32(s))), Fraction(float(np.float32(d)))
+    rcp = _rn32(1 / d)
+    q0 = _rn32(s * rcp)
+    r = _rn32(s - d * q0)
+    return _rn32(q0 + r * rcp), _rn32(s / d)

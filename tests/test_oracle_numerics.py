@@ -95,3 +95,16 @@ def test_gather_form_input_gradient_equals_autograd(cfg):
     ref, = torch.autograd.grad(y, x, torch.from_numpy(dz).permute(0, 3, 1, 2))
     got = numerics.conv_dx_gather(dz, w, (B, H, W, Cin), s)
     np.testing.assert_allclose(got, ref.numpy(), rtol=1e-12, atol=1e-12)
+
+
+def test_fma_refined_quotient_is_the_ieee_quotient():
+    """The conv1 kernels divide each sum by a_div with q0 = s * (1/d), q = fma(fma(-d, q0, s), 1/d,
+    q0).  In exact rational arithmetic with one rounding per fma this equals RN(s / d) for the
+    divisors in use (255 and the test divisors), over six decades of s."""
+    import random
+    random.seed(0)
+    for d in (255.0, 3.0, 127.5, 7.0):
+        for _ in range(400):
+            s = random.uniform(-1, 1) * 10.0 ** random.uniform(-3, 5)
+            q, want = numerics.markstein_quotient(s, d)
+            assert q == want, (s, d)
