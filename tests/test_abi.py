@@ -27,6 +27,25 @@ def test_binding_covers_header(lib):
     assert declared_symbols() == _lib.exported_symbols()
 
 
+def declared_arity():
+    """{symbol: number of parameters} parsed from the header prototypes."""
+    src = open(os.path.join(ROOT, "include", "agents_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(aa_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    return out
+
+
+def test_binding_arity_matches_header(lib):
+    """Every ctypes signature in agents_amd/_lib.py has as many parameters as the C prototype."""
+    arity = declared_arity()
+    bad = {n: (len(sig[1]), arity.get(n)) for n, sig in _lib._SIGNATURES.items()
+           if arity.get(n) != len(sig[1])}
+    assert not bad, f"(binding, header) parameter counts differ: {bad}"
+
+
 def test_abi_version(lib):
     assert lib.aa_abi_version() == 6
 
