@@ -46,6 +46,37 @@ def test_binding_arity_matches_header(lib):
     assert not bad, f"(binding, header) parameter counts differ: {bad}"
 
 
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof of the descriptor structs as gcc sees the header == the ctypes mirrors."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("gcc not available")
+    fields = {"aa_gemm_desc": ("GemmDesc", ["A", "M", "a_mode", "img_pitch", "a_div", "bias",
+                                            "mask_src", "force_cfg", "colsum_out", "no_dma"]),
+              "aa_conv_layer_desc": ("ConvLayerDesc", ["w", "y", "KH", "act"]),
+              "aa_conv_dx_desc": ("ConvDxDesc", ["dz", "dx", "n_img", "mask_kind"])}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "agents_amd.h"', 'int main(void){']
+    for cname, (_, fs) in fields.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for f in fs:
+            lines.append(f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+    lines.append("return 0;}")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([gcc, "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    got = dict(line.split() for line in out.strip().splitlines())
+    for cname, (pyname, fs) in fields.items():
+        st = getattr(_lib, pyname)
+        assert int(got[cname]) == ctypes.sizeof(st), cname
+        for f in fs:
+            assert int(got[f"{cname}.{f}"]) == getattr(st, f).offset, f"{cname}.{f}"
+
+
 def test_abi_version(lib):
     assert lib.aa_abi_version() == 6
 
