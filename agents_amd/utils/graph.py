@@ -142,20 +142,50 @@ def join_lanes(device=None):
 _CAPTURE_MODE = "thread_local"
 
 
+_CAPTURES = 0          # captures recorded by this module so far (all objects)
+_BATCH_DEPTH = 0
+_CAPTURE_STREAM = {}
+
+
+def capture_count():
+    """Number of HIP-graph captures this module has recorded.  A caller that wants its timed
+    region free of captures runs its loop until this stops changing (bench.py's priming)."""
+    return _CAPTURES
+
+
 @contextlib.contextmanager
-def _no_gc_during_capture():
-    """Cyclic garbage is collected BEFORE a capture and the collector is paused during it: a
-    finaliser that runs mid-capture (a torch CUDAGraph or pinned-memory owner of some earlier,
-    now unreachable stack being destroyed) issues HIP calls that are illegal while a stream is
-    capturing and corrupt the graph being recorded."""
-    gc.collect()
-    was = gc.isenabled()
-    gc.disable()
+def capture_batch():
+    """Brackets one or MANY captures: device idle + cyclic garbage collected ONCE before, the
+    collector paused during (a finaliser that runs mid-capture -- a torch CUDAGraph or
+    pinned-memory owner of some earlier, now unreachable stack being destroyed -- issues HIP
+    calls that are illegal while a stream is capturing and corrupt the graph being recorded),
+    device idle once after.  Nested uses are free, which is what lets the sampler ring, both
+    driver bodies and every per-slot train graph be captured up front at the price of one."""
+    global _BATCH_DEPTH
+    outer = _BATCH_DEPTH == 0
+    was = False
+    if outer:
+        torch.cuda.synchronize()
+        gc.collect()
+        was = gc.isenabled()
+        gc.disable()
+    _BATCH_DEPTH += 1
     try:
         yield
     finally:
-        if was:
-            gc.enable()
+        _BATCH_DEPTH -= 1
+        if outer:
+            if was:
+                gc.enable()
+            torch.cuda.synchronize()
+
+
+def _capture_stream(device):
+    key = torch.cuda.current_device() if device is None else torch.device(device).index
+    st = _CAPTURE_STREAM.get(key)
+    if st is None:
+        st = _CAPTURE_STREAM[key] = torch.cuda.Stream(key)
+    return st
 
 
 class _Captured:
@@ -167,19 +197,27 @@ class _Captured:
         self.out = None
 
     def capture(self, fn):
-        global _CAPTURE
+        """Records `fn()`.  torch.cuda.graph() is not used: its __enter__ synchronises the device
+        and empties the allocator cache for EVERY capture; `capture_batch` does the former once
+        per batch and the latter is not wanted (it returns the cached blocks the eager warm-up
+        calls just sized to the driver)."""
+        global _CAPTURE, _CAPTURES
         if _CAPTURE is not None:
             raise RuntimeError("nested HIP-graph capture")
         ctx = _CaptureCtx()
         g = torch.cuda.CUDAGraph()
-        torch.cuda.synchronize()
-        _CAPTURE = ctx
-        try:
-            with _no_gc_during_capture(), torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
-                self.out = fn()
-        finally:
-            _CAPTURE = None
-        torch.cuda.synchronize()
+        with capture_batch():
+            _CAPTURE = ctx
+            try:
+                with torch.cuda.stream(_capture_stream(None)):
+                    g.capture_begin(capture_error_mode=_CAPTURE_MODE)
+                    try:
+                        self.out = fn()
+                    finally:
+                        g.capture_end()
+            finally:
+                _CAPTURE = None
+        _CAPTURES += 1
         self.graph = g
         self.hooks = ctx.hooks
         return self.out
@@ -193,13 +231,12 @@ class _Captured:
 
 class _Entry:
     def __init__(self):
-        self.calls = 0
         self.static_in = None
         self.static_w = None
-        self.g_grads = None
-        self.g_apply = None
-        self.g_grads_b = None     # bucket mode: second half of the backward
-        self.captured = None
+        self.g_grads = None       # _Captured: forwards + loss + backward (bucket mode: first half)
+        self.g_apply = None       # _Captured: optimizer (shared by every entry of a signature)
+        self.g_grads_b = None     # _Captured, bucket mode: second half of the backward
+        self.captured = None      # _Captured, whole mode
         self.out = None
 
 
@@ -211,9 +248,29 @@ def _sig(experience, weights):
     return s + (weights,)
 
 
+# first-leaf address of a sampler ring slot -> weakref of the GraphedSampler that owns it: lets
+# GraphedTrain capture one graph per slot of the WHOLE ring the first time it meets one of them
+_RING_OWNER = {}
+
+
+def _ring_of(ptr0):
+    ref = _RING_OWNER.get(ptr0)
+    owner = ref() if ref is not None else None
+    if owner is None:
+        _RING_OWNER.pop(ptr0, None)
+    return owner
+
+
 class GraphedTrain:
     """Callable with the signature of `agent.train`; falls back to the eager path for agents
-    that do not expose graphable phases."""
+    that do not expose graphable phases.
+
+    Graphs are bound to the ADDRESSES of their inputs.  A batch that lives in a GraphedSampler
+    ring slot gets a graph captured on that slot -- no copies -- and the first such batch
+    triggers the capture for EVERY slot of its ring (one pause of a few tens of ms in the third
+    call, none later).  Any other caller (fresh tensors every step) shares one graph captured on
+    private clones and pays one copy per leaf; an unknown address set that comes back a second
+    time (somebody else's static buffers, e.g. PPOLearner's minibatch) gets its own graph."""
 
     def __init__(self, agent):
         self._agent = agent
@@ -233,6 +290,49 @@ class GraphedTrain:
     def agent(self):
         return self._agent
 
+    def _entry_for(self, sig, ptrs, experience, weights, dev):
+        bound = self._cache.setdefault(sig, {})
+        e = bound.get(ptrs)
+        if e is not None:
+            return e
+        shared_apply = next((x.g_apply for x in bound.values() if x.g_apply is not None), None)
+        sampler = _ring_of(ptrs[0])
+        if sampler is not None and len(bound) < _MAX_BINDINGS:
+            # a sampler ring slot: one graph per slot of that ring, all captured now
+            join_lanes(dev)
+            with capture_batch():
+                for exp_k in sampler.ring_experiences():
+                    pk = tuple(t.data_ptr() for t in nest_utils.flatten(exp_k))
+                    if pk in bound or _sig(exp_k, weights) != sig or \
+                            len(bound) >= _MAX_BINDINGS:
+                        continue
+                    ek = _Entry()
+                    self._capture(ek, exp_k, weights, clone=False, g_apply=shared_apply)
+                    shared_apply = ek.g_apply
+                    bound[pk] = ek
+            e = bound.get(ptrs)
+            if e is not None:
+                return e
+        seen = self._seen.setdefault(sig, {})
+        seen[ptrs] = seen.get(ptrs, 0) + 1
+        if len(seen) > 4 * _MAX_BINDINGS:
+            seen.clear()
+        if seen.get(ptrs, 0) >= 2 and len(bound) < _MAX_BINDINGS:
+            # an address set that came back: somebody's static buffers, worth their own graph
+            join_lanes(dev)
+            e = _Entry()
+            self._capture(e, experience, weights, clone=False, g_apply=shared_apply)
+            bound[ptrs] = e
+            return e
+        e = bound.get(None)
+        if e is None:
+            # captured on private clones; serves every other caller through copies
+            join_lanes(dev)
+            e = _Entry()
+            self._capture(e, experience, weights, clone=True, g_apply=shared_apply)
+            bound[None] = e
+        return e
+
     def __call__(self, experience, weights=None, **kwargs):
         agent = self._agent
         if not self.enabled or kwargs or getattr(agent, "check_numerics", False) or capturing():
@@ -248,38 +348,10 @@ class GraphedTrain:
             agent.initialize()
         if hasattr(agent, "_check_trajectory"):
             agent._check_trajectory(experience)
-        # Graphs are bound to the ADDRESSES of their inputs.  A sampler that hands out a ring of
-        # static buffers (GraphedSampler) gets one captured graph per ring slot -- no copies; any
-        # other caller (fresh tensors every step) shares the first graph and pays one copy per
-        # leaf into its static inputs.
         ptrs = tuple(t.data_ptr() for t in nest_utils.flatten(experience))
-        bound = self._cache.setdefault(sig, {})
-        e = bound.get(ptrs)
         dev = experience.discount.device
         with torch.cuda.device(dev):
-            if e is None:
-                join_lanes(dev)
-            if e is None and not bound:
-                # first graph: captured on private clones; serves every caller through copies
-                e = _Entry()
-                self._capture(e, experience, weights, clone=True)
-                bound[None] = e
-            elif e is None:
-                seen = self._seen.setdefault(sig, {})
-                seen[ptrs] = seen.get(ptrs, 0) + 1
-                if seen[ptrs] >= 2 and len(bound) < _MAX_BINDINGS:
-                    # an address set that came back (a ring slot): worth its own graph
-                    e = _Entry()
-                    self._capture(e, experience, weights, clone=False,
-                                  g_apply=None if self._whole else bound[None].g_apply)
-                    bound[ptrs] = e
-                if len(seen) > 4 * _MAX_BINDINGS:
-                    seen.clear()
-            if e is None:
-                e = bound[None]
-            for dst, src in zip(nest_utils.flatten(e.static_in), nest_utils.flatten(experience)):
-                if dst.data_ptr() != src.data_ptr():
-                    dst.copy_(src, non_blocking=True)
+            e = self._entry_for(sig, ptrs, experience, weights, dev)
             lanes = lanes_for(dev)
             if lanes is not None:
                 ev = lanes.ready.get(ptrs[0])
@@ -287,6 +359,7 @@ class GraphedTrain:
                     torch.cuda.current_stream(dev).wait_event(ev)
                 else:
                     lanes.join()
+            # only after the wait above: the source may still be being written on lane S
             for dst, src in zip(nest_utils.flatten(e.static_in), nest_utils.flatten(experience)):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src, non_blocking=True)
@@ -310,7 +383,6 @@ class GraphedTrain:
                 if lanes is not None and lanes.collect_done is not None:
                     torch.cuda.current_stream(dev).wait_event(lanes.collect_done)
                 e.g_apply.replay()
-                agent._optimizer.iterations += 1
                 agent._train_phase_host()
             else:
                 e.g_grads.replay()
@@ -320,45 +392,39 @@ class GraphedTrain:
                     # the optimizer overwrites theta_k: the collect policy's forward must be done
                     torch.cuda.current_stream(dev).wait_event(lanes.collect_done)
                 e.g_apply.replay()
-                agent._optimizer.iterations += 1
                 agent._train_phase_host()
         self.replays += 1
         return e.out
 
     def _capture(self, e, experience, weights, clone=True, g_apply=None):
+        """Records the entry's graphs.  Host bookkeeping the phases do through `on_replay` (the
+        optimizer's `iterations` mirror) is collected as replay hooks, and `capturing()` is true
+        throughout, so nothing in the phases waits on un-captured events (join_lanes is a no-op)."""
         agent = self._agent
         e.static_in = nest_utils.map_structure(lambda t: t.clone(), experience) if clone \
             else experience
         e.static_w = weights.clone() if isinstance(weights, torch.Tensor) else None
         w_arg = e.static_w if e.static_w is not None else weights
-        if self._whole:
-            e.captured = _Captured()
-            e.out = e.captured.capture(lambda: agent._graph_train_whole(e.static_in, w_arg))
-            return
-        torch.cuda.synchronize()
-        iters = agent._optimizer.iterations
-        bucketed = (getattr(agent, "gradient_hook_async", None) is not None and
-                    hasattr(agent, "_train_phase_grads_a") and agent._bucket_split() is not None
-                    and BUCKETED_ALLREDUCE)
-        e.g_grads = torch.cuda.CUDAGraph()
-        with _no_gc_during_capture(), torch.cuda.graph(e.g_grads,
-                                                          capture_error_mode=_CAPTURE_MODE):
-            e.out = agent._train_phase_grads_a(e.static_in, w_arg) if bucketed else \
-                agent._train_phase_grads(e.static_in, w_arg)
-        if bucketed:
-            e.g_grads_b = torch.cuda.CUDAGraph()
-            with _no_gc_during_capture(), torch.cuda.graph(e.g_grads_b,
-                                                              capture_error_mode=_CAPTURE_MODE):
-                agent._train_phase_grads_b()
-        if g_apply is not None:
-            e.g_apply = g_apply          # the optimizer phase does not depend on the inputs
-        else:
-            e.g_apply = torch.cuda.CUDAGraph()
-            with _no_gc_during_capture(), torch.cuda.graph(e.g_apply,
-                                                              capture_error_mode=_CAPTURE_MODE):
-                agent._train_phase_apply()
-        agent._optimizer.iterations = iters  # capture enqueues nothing; undo the host mirror bump
-        torch.cuda.synchronize()
+        with capture_batch():
+            if self._whole:
+                e.captured = _Captured()
+                e.out = e.captured.capture(lambda: agent._graph_train_whole(e.static_in, w_arg))
+                return
+            bucketed = (getattr(agent, "gradient_hook_async", None) is not None and
+                        hasattr(agent, "_train_phase_grads_a") and
+                        agent._bucket_split() is not None and BUCKETED_ALLREDUCE)
+            e.g_grads = _Captured()
+            e.out = e.g_grads.capture(
+                (lambda: agent._train_phase_grads_a(e.static_in, w_arg)) if bucketed else
+                (lambda: agent._train_phase_grads(e.static_in, w_arg)))
+            if bucketed:
+                e.g_grads_b = _Captured()
+                e.g_grads_b.capture(agent._train_phase_grads_b)
+            if g_apply is not None:
+                e.g_apply = g_apply          # the optimizer phase does not depend on the inputs
+            else:
+                e.g_apply = _Captured()
+                e.g_apply.capture(agent._train_phase_apply)
 
     def static_inputs(self, experience_like=None):
         """Static input nest of the (single) captured signature, or None before capture."""
@@ -380,11 +446,12 @@ def graphed_train(agent):
 
 class GraphedSampler:
     """`next()` == `rb.get_next(S, T)` (tf_uniform_replay_buffer.py:211-310), replayed as a HIP
-    graph of the two kernels (index sampling, row gather).  Outputs live in a ring of `ring`
-    static buffer sets: an element stays valid until `ring - 1` further elements have been drawn
-    (the reference's dataset hands out fresh tensors; consumers that keep samples longer than that
+    graph of the sampling + gather launch(es).  Outputs live in a ring of `ring` static buffer
+    sets: an element stays valid until `ring - 1` further elements have been drawn (the
+    reference's dataset hands out fresh tensors; consumers that keep samples longer than that
     should call `get_next` directly).  The Philox call counter is device-resident, so the sampled
-    indices are bit-identical to the eager path's."""
+    indices are bit-identical to the eager path's.  The whole ring is captured at the first
+    graphed call (the third draw), so later draws never pause."""
 
     def __init__(self, rb, sample_batch_size, num_steps, ring=8):
         self._rb = rb
@@ -396,6 +463,35 @@ class GraphedSampler:
         self.enabled = True
         self.replays = 0
 
+    def ring_experiences(self):
+        """The experience nest of every captured ring slot, in slot order."""
+        return [c.out[0] for c in self._ring if c is not None]
+
+    def _prime(self):
+        import weakref
+        rb = self._rb
+        join_lanes(rb.device)
+        try:
+            with capture_batch():
+                for k in range(len(self._ring)):
+                    c = _Captured()
+                    c.capture(lambda: rb.get_next(self._S, self._T, time_stacked=True))
+                    self._ring[k] = c
+        except Exception:
+            self.enabled = False
+            raise
+        ref = weakref.ref(self)
+        for exp in self.ring_experiences():
+            _RING_OWNER[nest_utils.flatten(exp)[0].data_ptr()] = ref
+
+    def __del__(self):
+        try:
+            for c in self._ring:
+                if c is not None and c.out is not None:
+                    _RING_OWNER.pop(nest_utils.flatten(c.out[0])[0].data_ptr(), None)
+        except Exception:      # interpreter shutdown
+            pass
+
     def next(self):
         rb = self._rb
         if not self.enabled or self._warm < _WARMUP_CALLS or capturing():
@@ -404,17 +500,10 @@ class GraphedSampler:
         rb._check_not_empty(self._T)
         slot = self._i % len(self._ring)
         self._i += 1
-        c = self._ring[slot]
         with torch.cuda.device(rb.device):
-            if c is None:
-                join_lanes(rb.device)
-                c = _Captured()
-                try:
-                    c.capture(lambda: rb.get_next(self._S, self._T, time_stacked=True))
-                except Exception:
-                    self.enabled = False
-                    raise
-                self._ring[slot] = c
+            if self._ring[slot] is None:
+                self._prime()
+            c = self._ring[slot]
             lanes = lanes_for(rb.device)
             if lanes is None:
                 out = c.replay()
@@ -519,6 +608,10 @@ class GraphedDriverRun:
             return self._eager_run(time_step, policy_state, maximum_iterations)
         if policy_state is None:
             policy_state = drv.policy.get_initial_state(env.batch_size)
+        if policy_state == ():
+            # from the first call on the environment alternates between its two ring buffers, so
+            # the eager warm-up calls already leave the loop where the graphs will pick it up
+            env.graph_ring()
         if self._warm < _WARMUP_CALLS or policy_state != ():
             self._warm += 1
             return self._eager_run(time_step, policy_state, maximum_iterations)
@@ -550,18 +643,26 @@ class GraphedDriverRun:
                                            else maximum_iterations - it)
                 c = self._graphs.get(slot)
                 if c is None:
+                    # Both loop bodies are captured now (the environment alternates between its
+                    # two output buffers): capturing the body on slot s leaves the environment's
+                    # host-side reference on slot 1-s -- exactly the input of the other body --
+                    # and capturing that one brings it back to s, the true current step.
                     join_lanes(st.device)
-                    c = _Captured()
-                    ts_in = time_step
                     from agents_amd import ops
                     try:
-                        # private GEMM scratch: this graph may replay next to the train graphs
-                        with ops.workspace_scope(("collect", id(self)), st.device):
-                            c.capture(lambda: self._body(ts_in, policy_state))
+                        with capture_batch():
+                            for k in (slot, 1 - slot):
+                                ck = _Captured()
+                                ts_in = ring.slots[k]
+                                # private GEMM scratch: may replay next to the train graphs
+                                with ops.workspace_scope(("collect", id(self)), st.device):
+                                    ck.capture(lambda: self._body(ts_in, policy_state))
+                                self._graphs[k] = ck
                     except Exception:
                         self.enabled = False
+                        self._graphs.clear()
                         raise
-                    self._graphs[slot] = c
+                    c = self._graphs[slot]
                 lanes = lanes_for(st.device)
                 if lanes is None:
                     time_step = c.replay()

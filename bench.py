@@ -324,15 +324,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- priming (untimed, independent of --warmup) ------------------------------------------
+    # The first iterations are not the steady state: two eager calls per program size the buffers,
+    # the third records every HIP graph of the loop (both driver bodies, the whole sampler ring,
+    # one train graph per ring slot: agents_amd/utils/graph.py).  Iterate until no capture has
+    # happened for three consecutive iterations, the way the reference's harness discards its
+    # first log window (tf_agents/benchmark/utils.py:89-180).  Same count on every rank.
+    prime_steps, quiet, seen = 0, 0, graph.capture_count()
+    t_prime = time.perf_counter()
+    while prime_steps < 64 and quiet < 3:
+        step()
+        prime_steps += 1
+        now = graph.capture_count()
+        quiet = quiet + 1 if (now == seen and now > 0) else 0
+        seen = now
+    sync_all()
+    t_prime = time.perf_counter() - t_prime
+    if rank == 0:
+        log(f"[bench] primed in {prime_steps} iterations / {t_prime:.2f}s "
+            f"({seen} HIP-graph captures)")
     for _ in range(args.warmup):
         step()
     sync_all()
+    captures_before = graph.capture_count()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss_info = step()
     graph.join_lanes(dev)
     sync_all()
     dt = time.perf_counter() - t0
+    captures_in_timed_region = graph.capture_count() - captures_before
     graph.disable_overlap()
     if world > 1:
         import torch.distributed as dist
@@ -350,6 +371,8 @@ def main():
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "prime_steps": prime_steps, "prime_seconds": t_prime,
+        "captures_in_timed_region": captures_in_timed_region,
         "learner_steps_per_sec": steps_per_sec,
         "env_steps_per_sec": steps_per_sec * args.envs * world,
         "replay_rows_gathered_per_sec": steps_per_sec * S * 2 * world,

@@ -159,6 +159,39 @@ def test_full_loop_graphs_match_eager(dev):
     assert len(bound) > 1
 
 
+def test_all_graphs_are_captured_in_the_third_iteration(dev):
+    """Cold start: two eager calls per program, then EVERY graph of the loop is recorded in the
+    third iteration (both driver bodies, all sampler ring slots, one train graph per ring slot
+    sharing one optimizer graph); nothing is captured afterwards, whatever the ring position."""
+    B, S, ring = 8, 16, 8
+    env, ag, rb, drv, net = _stack(dev, B, 64, 0.2, 1, dataset_ring=ring)
+    run_g = common.function(drv.run)
+    lrn = learner.Learner(None, common.Variable(0), ag)
+    drv.run()
+    drv.run()
+    it = iter(rb.as_dataset(sample_batch_size=S, num_steps=2).prefetch(3))
+    graph.enable_overlap(dev)
+    try:
+        counts = []
+        ts_ = None
+        for i in range(3 * ring + 5):
+            ts_, _ = run_g(ts_)
+            lrn.run(iterations=1, iterator=it)
+            counts.append(graph.capture_count())
+        graph.join_lanes(dev)
+        torch.cuda.synchronize()
+    finally:
+        graph.disable_overlap()
+    assert counts[2] > counts[1], "nothing was captured in the third iteration"
+    assert counts[-1] == counts[2], f"captures after the third iteration: {counts}"
+    gt = graph.graphed_train(ag)
+    bound = next(iter(gt._cache.values()))
+    assert len(bound) == ring and None not in bound
+    assert len({id(e.g_apply) for e in bound.values()}) == 1
+    assert len(run_g._graphs) == 2
+    assert gt.replays == len(counts) - 2
+
+
 @pytest.mark.parametrize("B,p_end,num_steps", [(8, 0.2, 1), (2, 0.6, 2), (4, 0.5, 9)])
 def test_stream_overlap_matches_single_stream(dev, B, p_end, num_steps):
     """collect on lane C, sampling on lane S, training on the caller's stream, ordered by events:
