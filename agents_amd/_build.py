@@ -35,6 +35,7 @@ SOURCES = [
     ("value_ops.hip", ["-ffp-contract=off"]),
     ("ppo.hip", ["-ffp-contract=off"]),
     ("sac.hip", ["-ffp-contract=off"]),
+    ("normalizer.hip", ["-ffp-contract=off"]),
 ]
 HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
     [os.path.join(INCLUDE, "agents_amd.h")]

@@ -160,6 +160,12 @@ _SIGNATURES = {
     "aa_sac_critic_loss": (c_int, [c_void_p] * 9 + [c_float, c_float, c_int32, c_float, c_int64,
                                                     c_float] + [c_void_p] * 5),
     "aa_sac_actor_loss": (c_int, [c_void_p] * 5 + [c_float, c_int64, c_float] + [c_void_p] * 5),
+    "aa_norm_scratch_floats": (c_int64, [c_int64]),
+    "aa_streaming_norm_update": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "aa_ema_norm_update": (c_int, [c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p,
+                                   c_void_p]),
+    "aa_norm_apply": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_float,
+                              c_float, c_void_p, c_void_p]),
     "aa_sac_alpha_loss": (c_int, [c_void_p] * 3 + [c_float, c_int32, c_float, c_int64, c_float] +
                           [c_void_p] * 3),
 }
@@ -186,7 +192,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 6:
+    if lib.aa_abi_version() != 7:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -14,6 +14,13 @@ next observation for DDQN) -> aa_dqn_td_loss (loss, td_error, dL/dq in one kerne
 GEMMs into the flat gradient buffer -> [gradient hook: the Learner's RCCL all-reduce] -> fused
 optimizer over the flat parameter buffer -> target update.  Nothing syncs the device; LossInfo
 holds device tensors.
+
+Lifetime of the returned LossInfo: `train` returns VIEWS of the agent's persistent work buffers
+(loss, td_loss[B], td_error[B]) -- also through the HIP-graph replay -- which the next train step
+of the same batch size overwrites.  Consume them (or `.clone()`) before the next `train`; a
+prioritized replay's `update_priorities(td_error)` enqueued right after `train` is ordered before
+the next step on the stream and is safe.  `loss()` and `Learner.run` return tensors that own their
+storage.
 """
 import collections
 
@@ -335,6 +342,12 @@ class DqnAgent(tf_agent.TFAgent):
             self._train_phase_apply()
             self._train_phase_host()
         return loss_info
+
+    def replicated_state(self):
+        """Tensors every data-parallel replica must hold identically (train.Learner broadcasts
+        rank 0's at construction): online and target parameters, existing optimizer slots."""
+        return [self._q_network.flat_params, self._target_q_network.flat_params] + \
+            (self._optimizer.variables() if self._optimizer is not None else [])
 
     # ---- checkpointing ---------------------------------------------------------------------------
     def state_dict(self):

@@ -12,8 +12,9 @@ feed-forward actor / value networks with a diagonal-Normal action distribution:
   kl_penalty_loss & friends       :1514-1690 fused in aa_ppo_loss_dist; aa_ppo_update_kl_beta
 Actor, std bias and value parameters live in ONE flat fp32 buffer (gradients likewise), so the
 global-norm clip, the optimizer step and the Learner's RCCL all-reduce are single passes.
-Not implemented yet (raise NotImplementedError): reward / observation normalisers, RNN networks,
-discrete action distributions.
+Reward / observation normalisers (:347-366, 650-652, 991-993, 1078-1086) are
+utils/tensor_normalizer.StreamingTensorNormalizer (csrc/normalizer.hip).
+Not implemented (raise NotImplementedError): RNN networks, discrete action distributions.
 """
 import collections
 
@@ -25,7 +26,7 @@ from agents_amd.agents import tf_agent
 from agents_amd.agents.ppo import ppo_policy
 from agents_amd.networks import network
 from agents_amd.specs import tensor_spec
-from agents_amd.utils import common, graph, nest_utils
+from agents_amd.utils import common, graph, nest_utils, tensor_normalizer
 
 PPOLossInfo = collections.namedtuple(
     "PPOLossInfo", ("policy_gradient_loss", "value_estimation_loss", "l2_regularization_loss",
@@ -49,11 +50,6 @@ class PPOAgent(tf_agent.TFAgent):
             raise TypeError("actor_net must be an instance of a network.Network.")
         if not isinstance(value_net, network.Network):
             raise TypeError("value_net must be an instance of a network.Network.")
-        if normalize_rewards or normalize_observations:
-            raise NotImplementedError(
-                "StreamingTensorNormalizer (normalize_rewards / normalize_observations) is not "
-                "implemented yet; pass normalize_rewards=False, normalize_observations=False as "
-                "agents/ppo/examples/v2/train_eval_clip_agent.py:197-198 does")
         if shared_vars_l2_reg:
             raise NotImplementedError("networks with shared variables are not supported")
         if not aggregate_losses_across_replicas:
@@ -98,11 +94,23 @@ class PPOAgent(tf_agent.TFAgent):
             self._adaptive_kl_beta = torch.full((1,), float(initial_adaptive_kl_beta),
                                                 dtype=torch.float32, device=dev)
         self._device = dev
+        # ppo_agent.py:347-360
+        self._reward_norm_clipping = float(reward_norm_clipping)
+        self._reward_normalizer = None
+        if normalize_rewards:
+            self._reward_normalizer = tensor_normalizer.StreamingTensorNormalizer(
+                tensor_spec.TensorSpec((), torch.float32), scope="normalize_reward", device=dev)
+        self._observation_normalizer = None
+        if normalize_observations:
+            self._observation_normalizer = tensor_normalizer.StreamingTensorNormalizer(
+                time_step_spec.observation, scope="normalize_observations", device=dev)
 
         policy = ppo_policy.PPOPolicy(time_step_spec, action_spec, actor_net, value_net,
+                                      observation_normalizer=self._observation_normalizer,
                                       clip=False, collect=False, greedy=greedy_eval, seed=seed)
         collect_policy = ppo_policy.PPOPolicy(
-            time_step_spec, action_spec, actor_net, value_net, clip=False, collect=True,
+            time_step_spec, action_spec, actor_net, value_net,
+            observation_normalizer=self._observation_normalizer, clip=False, collect=True,
             compute_value_and_advantage_in_train=compute_value_and_advantage_in_train,
             seed=seed + 1)
         if compute_value_and_advantage_in_train:
@@ -140,6 +148,16 @@ class PPOAgent(tf_agent.TFAgent):
     def _initialize(self):
         pass
 
+    def replicated_state(self):
+        """Tensors every data-parallel replica must hold identically (train.Learner broadcasts
+        rank 0's at construction)."""
+        out = [self.flat_params, self._adaptive_kl_beta]
+        out += self._optimizer.variables() if self._optimizer is not None else []
+        for n in (self._reward_normalizer, self._observation_normalizer):
+            if n is not None:
+                out += list(n._state)
+        return out
+
     # ---- checkpointing ---------------------------------------------------------------------------
     def state_dict(self):
         return {"params": self.flat_params.clone(),
@@ -147,7 +165,9 @@ class PPOAgent(tf_agent.TFAgent):
                 "optimizer": self._optimizer.state_dict() if self._optimizer else None,
                 "adaptive_kl_beta": None if self._adaptive_kl_beta is None
                 else self._adaptive_kl_beta.clone(),
-                "policies": [self._policy.state_dict(), self._collect_policy.state_dict()]}
+                "policies": [self._policy.state_dict(), self._collect_policy.state_dict()],
+                "normalizers": [None if n is None else n.state_dict() for n in
+                                (self._reward_normalizer, self._observation_normalizer)]}
 
     def load_state_dict(self, sd):
         self.flat_params.copy_(sd["params"])
@@ -158,6 +178,10 @@ class PPOAgent(tf_agent.TFAgent):
             self._adaptive_kl_beta.copy_(sd["adaptive_kl_beta"])
         self._policy.load_state_dict(sd["policies"][0])
         self._collect_policy.load_state_dict(sd["policies"][1])
+        for n, nsd in zip((self._reward_normalizer, self._observation_normalizer),
+                          sd.get("normalizers", (None, None))):
+            if n is not None and nsd is not None:
+                n.load_state_dict(nsd)
         self._initialized = True
 
     def _st(self):
@@ -200,6 +224,9 @@ class PPOAgent(tf_agent.TFAgent):
         B, T = next_time_steps.discount.shape
         dev = value_preds.device
         rewards = next_time_steps.reward.contiguous()
+        if self._reward_normalizer is not None:     # ppo_agent.py:650-654
+            rewards = self._reward_normalizer.normalize(
+                rewards, center_mean=False, clip_value=self._reward_norm_clipping)
         # discount * gamma * episode_mask on a [B, T] view: pad the kernel's [B, T+1] contract
         disc_in = torch.empty((B, T + 1), dtype=torch.float32, device=dev)
         disc_in[:, :T].copy_(next_time_steps.discount)
@@ -288,6 +315,22 @@ class PPOAgent(tf_agent.TFAgent):
     def _flat_obs(self, obs):
         return obs.reshape((-1,) + tuple(obs.shape[obs.dim() - self._obs_rank:]))
 
+    def _normalized_obs(self, obs_flat):
+        """What PPOPolicy._apply_actor_network / apply_value_network feed the networks
+        (ppo_policy.py:231-241).  The statistics do not change during the update epochs (they are
+        updated after them, ppo_agent.py:991-993), so `_train` normalises once."""
+        if self._observation_normalizer is None:
+            return obs_flat
+        return self._observation_normalizer.normalize(obs_flat)
+
+    def update_observation_normalizer(self, batched_observations):   # ppo_agent.py:1078-1082
+        if self._observation_normalizer is not None:
+            self._observation_normalizer.update(batched_observations, outer_dims=[0, 1])
+
+    def update_reward_normalizer(self, batched_rewards):             # ppo_agent.py:1084-1086
+        if self._reward_normalizer is not None:
+            self._reward_normalizer.update(batched_rewards, outer_dims=[0, 1])
+
     def _loss_forward_backward(self, obs_flat, actions, old_logp, returns, adv, old_loc, old_scale,
                                weights, old_vpred, training, slot):
         """One evaluation of get_loss on N flattened samples; with training=True also fills
@@ -335,7 +378,7 @@ class PPOAgent(tf_agent.TFAgent):
         """LossInfo for a batch with ONE or TWO outer dims (ppo_agent.py:481-615)."""
         dev = time_steps.discount.device
         with torch.cuda.device(dev):
-            obs = self._flat_obs(time_steps.observation)
+            obs = self._normalized_obs(self._flat_obs(time_steps.observation))
             N = obs.shape[0]
             f = lambda t: t.reshape(N, -1).to(torch.float32).contiguous()
             v = lambda t: t.reshape(N).to(torch.float32).contiguous()
@@ -414,7 +457,7 @@ class PPOAgent(tf_agent.TFAgent):
                                                 w["norm_stats"].data_ptr(), self._st()),
                        "aa_normalize_moments")
             old_vpred = info["value_prediction"].reshape(N).contiguous()
-            obs = self._flat_obs(processed.observation)
+            obs = self._normalized_obs(self._flat_obs(processed.observation))
             if self._zero is None:
                 self._zero = torch.zeros((), dtype=torch.float32, device=dev)
             l2 = self._zero
@@ -441,6 +484,9 @@ class PPOAgent(tf_agent.TFAgent):
                                                      self._adaptive_kl_tolerance,
                                                      self._adaptive_kl_beta.data_ptr(),
                                                      self._st()), "aa_ppo_update_kl_beta")
+            if self.update_normalizers_in_train:      # ppo_agent.py:991-993
+                self.update_observation_normalizer(processed.observation)
+                self.update_reward_normalizer(processed.reward)
         return loss_info
 
     def kl_cutoff_loss(self, kl_divergence, debug_summaries=False):

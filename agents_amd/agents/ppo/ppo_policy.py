@@ -21,8 +21,8 @@ class PPOPolicy(tf_policy.TFPolicy):
     def __init__(self, time_step_spec, action_spec, actor_network, value_network,
                  observation_normalizer=None, clip=True, collect=True,
                  compute_value_and_advantage_in_train=False, seed=0, greedy=False, name=None):
-        if observation_normalizer is not None:
-            raise NotImplementedError("observation normalisation is not implemented yet")
+        # ppo_policy.py:231-241: both networks see normalizer.normalize(observation)
+        self._observation_normalizer = observation_normalizer
         self._actor_network = actor_network
         self._value_network = value_network
         self._collect = collect
@@ -46,13 +46,22 @@ class PPOPolicy(tf_policy.TFPolicy):
         self._lo = self._hi = None
 
     def _variables(self):
-        return self._actor_network.variables + self._value_network.variables
+        var_list = self._actor_network.variables + self._value_network.variables
+        if self._observation_normalizer is not None:       # ppo_policy.py:249-254
+            var_list = var_list + list(nest_utils.flatten(self._observation_normalizer.variables))
+        return var_list
+
+    def _normalized(self, observations):
+        if self._observation_normalizer is None:
+            return observations
+        return self._observation_normalizer.normalize(observations)
 
     def apply_value_network(self, observations, step_types=None, value_state=None, training=False):
         """[B, T, ...] or [N, ...] observations -> value predictions of the same outer shape."""
         obs_rank = len(self._time_step_spec.observation.shape)
         outer = tuple(observations.shape[:observations.dim() - obs_rank])
-        flat = observations.reshape((-1,) + tuple(observations.shape[len(outer):]))
+        flat = self._normalized(
+            observations.reshape((-1,) + tuple(observations.shape[len(outer):])))
         v = self._value_network.forward(flat, slot=("value", training), need_grad=training)
         return v.view(outer), ()
 
@@ -78,6 +87,7 @@ class PPOPolicy(tf_policy.TFPolicy):
             obs = obs.unsqueeze(0)
         dev = obs.device
         with torch.cuda.device(dev):
+            obs = self._normalized(obs)
             loc, scale = self._actor_network.forward(obs, slot="policy")
             N = loc.shape[0]
             if self._greedy:

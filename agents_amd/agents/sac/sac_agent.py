@@ -453,6 +453,16 @@ class SacAgent(tf_agent.TFAgent):
         return self._train(experience, weights)
 
     # ---- checkpointing ---------------------------------------------------------------------------
+    def replicated_state(self):
+        """Tensors every data-parallel replica must hold identically (train.Learner broadcasts
+        rank 0's at construction)."""
+        out = [self._actor_network.flat_params, self._critic_params, self._target_params,
+               self._log_alpha_buf]
+        for o in (self._actor_optimizer, self._critic_optimizer, self._alpha_optimizer):
+            if o is not None:
+                out += o.variables()
+        return out
+
     def state_dict(self):
         return {"actor": self._actor_network.flat_params.clone(),
                 "critics": self._critic_params.clone(), "targets": self._target_params.clone(),

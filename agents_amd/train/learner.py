@@ -9,8 +9,13 @@ Data parallelism: each rank owns a replay shard and samples it 
 per-replica loss is divided by B_local * num_replicas (tf.nn.compute_average_loss,
 utils/common.py:1462-1467) and the flat gradient buffer is SUM all-reduced once per step through
 `agent.gradient_hook`; every rank then applies the identical optimizer step, so replicas stay in
-lock-step without any weight broadcast.  LossInfo fields are SUM-reduced over replicas and over
-all axes like strategy.reduce(SUM) (:322-337).
+lock-step.  They START in lock-step because the constructor broadcasts rank 0's replicated state
+(parameters, target networks, optimizer slots, normaliser statistics: `agent.replicated_state()`)
+to every rank after the checkpoint restore -- MirroredStrategy's mirrored variables; networks
+default to an unseeded initialiser, so without this each process would train its own weights.
+LossInfo fields are SUM-reduced over replicas and over all axes like strategy.reduce(SUM)
+(:322-337); the returned LossInfo owns its storage (one small copy per `run`), unlike the LossInfo
+`agent.train` returns, whose fields are views of work buffers the next train step overwrites.
 """
 import os
 
@@ -78,6 +83,36 @@ class Learner:
                 self._agent.train_step_counter.assign(int(self.train_step))
             self.triggers = list(self.triggers) + [triggers_lib.CheckpointTrigger(
                 self._checkpointer, self._agent.train_step_counter, checkpoint_interval)]
+        self.sync_replicas()
+
+    def sync_replicas(self):
+        """Every replica takes rank 0's replicated state (no-op on one replica).  Call it again
+        after restoring or editing the agent's weights on a subset of the ranks."""
+        if self.strategy.num_replicas_in_sync <= 1:
+            return
+        state = getattr(self._agent, "replicated_state", None)
+        if state is None:
+            return
+        tensors = [t for t in state() if t is not None]
+        dev = next((t.device for t in tensors if t.is_cuda), None)
+        if dev is not None:
+            from agents_amd.utils import graph
+            graph.join_lanes(dev)
+        # the ranks must agree on WHAT is replicated before the collectives are issued (optimizer
+        # slots exist only after the first step or a restore): sum(n) and sum(n^2) over the
+        # replicas pin every rank's n to the same value
+        n, world = len(tensors), self.strategy.num_replicas_in_sync
+        chk = self.strategy.reduce_sum(torch.tensor(
+            [float(n), float(n * n)], dtype=torch.float64, device=dev or "cpu"))
+        if int(chk[0]) != n * world or int(chk[1]) != n * n * world:
+            raise RuntimeError(
+                "Learner.sync_replicas: the replicas hold different numbers of replicated tensors "
+                f"(this rank: {n}); restore the same checkpoint on every rank")
+        self.strategy.broadcast_(tensors, src=0)
+        step = torch.tensor([int(self._agent.train_step_counter)], dtype=torch.int64,
+                            device=dev or "cpu")
+        self.strategy.broadcast_([step], src=0)
+        self._agent.train_step_counter.assign(int(step.item()))
 
     @property
     def train_step_numpy(self):
@@ -97,9 +132,12 @@ class Learner:
             return loss_info
         sums = [flat[i].sum().reshape(1) if flat[i].dim() > 0 else flat[i].reshape(1)
                 for i in idx]
+        # one packed copy: the result owns its storage (the inputs may be views of buffers the
+        # next train step overwrites) and travels in one all-reduce
+        vec = torch.cat([s.to(torch.float32) for s in sums])
         if self.strategy.num_replicas_in_sync > 1:
-            vec = self.strategy.reduce_sum(torch.cat([s.to(torch.float32) for s in sums]))
-            sums = [vec[j:j + 1] for j in range(len(idx))]
+            vec = self.strategy.all_reduce_sum_(vec)
+        sums = [vec[j:j + 1] for j in range(len(idx))]
         for j, i in enumerate(idx):
             flat[i] = sums[j].reshape(())
         return nest_utils.pack_sequence_as(loss_info, flat)

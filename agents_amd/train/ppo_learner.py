@@ -74,14 +74,17 @@ class PPOLearner:
             out.append(next(self._train_iter))
         return out
 
-    def _count_frames(self):
-        """_update_normalizers (:307-335): the agent has no normalisers here, so this only counts
-        the frames of `num_samples` elements of the normalisation dataset."""
+    def _update_normalizers(self):
+        """ppo_learner.py:310-335: the agent's observation / reward normalisers are updated with
+        `num_samples` elements of the normalisation dataset (the agent itself must not update
+        them, :185-189), and the frames of those elements are counted."""
         if self._norm_iter is None:
             self._norm_iter = iter(self._normalization_dataset_fn())
         frames = 0
         for _ in range(self._num_samples):
             traj, _ = next(self._norm_iter)
+            self._agent.update_observation_normalizer(traj.observation)
+            self._agent.update_reward_normalizer(traj.reward)
             n = 1
             for d in traj.reward.shape[:2]:
                 n *= int(d)
@@ -140,10 +143,24 @@ class PPOLearner:
 
     # ---- run -------------------------------------------------------------------------------------
     def run(self, parallel_iterations=10):
-        num_frames = self._count_frames()
+        num_frames = self._update_normalizers()
         self.num_frames_for_training = num_frames
         samples = self._take_samples()
         if self._minibatch_size:
+            # the reference sizes the run from the NORMALISATION dataset's frame count (:281-291)
+            # and lets tf.data raise OutOfRange if the train dataset is shorter; here the mismatch
+            # is reported up front
+            train_frames = 0
+            for traj, _ in samples:
+                n = 1
+                for d in traj.discount.shape[:2]:
+                    n *= int(d)
+                train_frames += n
+            if train_frames != num_frames:
+                raise ValueError(
+                    "PPOLearner: the normalization dataset yielded {} frames but the experience "
+                    "dataset {} for num_samples={}; both must describe the same collected "
+                    "sequences.".format(num_frames, train_frames, self._num_samples))
             num_total_batches = int(num_frames / self._minibatch_size) * self._num_epochs
             it = self._minibatches(samples)
         else:

@@ -23,6 +23,9 @@ class Strategy:
     def reduce_sum(self, tensor):
         return tensor
 
+    def broadcast_(self, tensors, src=0):
+        return tensors
+
     def barrier(self):
         pass
 
@@ -53,6 +56,13 @@ class DataParallelStrategy(Strategy):
         out = tensor.clone()
         dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self._pg)
         return out
+
+    def broadcast_(self, tensors, src=0):
+        """In-place broadcast of every tensor from rank `src`: what MirroredStrategy does when it
+        creates mirrored variables (every replica starts from replica 0's values)."""
+        for t in tensors:
+            dist.broadcast(t, src=src, group=self._pg)
+        return tensors
 
     def barrier(self):
         dist.barrier(group=self._pg)

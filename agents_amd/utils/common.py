@@ -157,34 +157,65 @@ class Periodically:
 class Checkpointer:
     """Saves/restores objects exposing state_dict()/load_state_dict() (agent, replay buffer,
     optimizer) plus plain values; restores the latest checkpoint in the constructor like the
-    reference's (common.py:1045-1100).  On-disk format is torch.save, not TF checkpoints."""
+    reference's (common.py:1045-1100).  On-disk format is torch.save of tensors / numbers /
+    containers (loaded with weights_only=True: a checkpoint directory is data, not code).
+
+    Data-parallel runs: every rank constructs the Checkpointer on the same directory and calls
+    `save` at the same step; rank 0 writes (to a temporary file, then an atomic rename -- a crash
+    mid-write never leaves a truncated `ckpt-N.pt`) and prunes, the others wait at a barrier.  A
+    checkpoint that fails to load is skipped in favour of the previous one."""
 
     def __init__(self, ckpt_dir, max_to_keep=20, **kwargs):
         self._dir = ckpt_dir
         self._max_to_keep = max_to_keep
         self._objects = kwargs
         os.makedirs(ckpt_dir, exist_ok=True)
-        self.checkpoint_exists = bool(self._list())
-        if self.checkpoint_exists:
-            self._restore(self._list()[-1])
+        self.checkpoint_exists = False
+        self.restored_from = None
+        for fname in reversed(self._list()):
+            try:
+                self._restore(fname)
+            except Exception as e:  # truncated / foreign file: fall back to the previous one
+                import warnings
+                warnings.warn(f"Checkpointer: could not load {fname} ({type(e).__name__}: {e}); "
+                              "trying the previous checkpoint")
+                continue
+            self.checkpoint_exists = True
+            self.restored_from = fname
+            break
 
     def _list(self):
-        fs = [f for f in os.listdir(self._dir) if f.startswith("ckpt-") and f.endswith(".pt")]
+        fs = [f for f in os.listdir(self._dir) if f.startswith("ckpt-") and f.endswith(".pt")
+              and f[5:-3].isdigit()]
         return sorted(fs, key=lambda f: int(f[5:-3]))
+
+    @staticmethod
+    def _dist():
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist
+        return None
 
     def save(self, global_step):
         step = int(global_step)
-        blob = {}
-        for k, o in self._objects.items():
-            blob[k] = o.state_dict() if hasattr(o, "state_dict") else (
-                int(o) if isinstance(o, Variable) else o)
-        torch.save(blob, os.path.join(self._dir, f"ckpt-{step}.pt"))
-        fs = self._list()
-        while self._max_to_keep and len(fs) > self._max_to_keep:
-            os.remove(os.path.join(self._dir, fs.pop(0)))
+        dist = self._dist()
+        if dist is None or dist.get_rank() == 0:
+            blob = {}
+            for k, o in self._objects.items():
+                blob[k] = o.state_dict() if hasattr(o, "state_dict") else (
+                    int(o) if isinstance(o, Variable) else o)
+            final = os.path.join(self._dir, f"ckpt-{step}.pt")
+            tmp = final + f".tmp{os.getpid()}"
+            torch.save(blob, tmp)
+            os.replace(tmp, final)
+            fs = self._list()
+            while self._max_to_keep and len(fs) > self._max_to_keep:
+                os.remove(os.path.join(self._dir, fs.pop(0)))
+        if dist is not None:
+            dist.barrier()
 
     def _restore(self, fname):
-        blob = torch.load(os.path.join(self._dir, fname), weights_only=False)
+        blob = torch.load(os.path.join(self._dir, fname), weights_only=True)
         for k, o in self._objects.items():
             if k not in blob:
                 continue

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 6
+#define AA_ABI_VERSION 7
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -453,6 +453,29 @@ int aa_sac_actor_loss(const float* q1, const float* q2, const float* logp, const
 int aa_sac_alpha_loss(const float* logp, const float* weights, const float* log_alpha_dev,
                       float target_entropy, int32_t use_log_alpha, float loss_weight, int64_t B,
                       float global_batch, float* loss_out, float* grad_out, void* stream);
+
+/* =========================================================================================
+ * Tensor normalisers   (tf_agents/utils/tensor_normalizer.py)
+ *   x is [n_outer, n_inner] fp32, the n_inner elements of one tensor-spec leaf fastest.
+ * ========================================================================================= */
+/* Floats of caller-provided scratch the two update entries need for a leaf of n_inner elements. */
+int64_t aa_norm_scratch_floats(int64_t n_inner);
+/* StreamingTensorNormalizer._update_ops (:288-348): batch (n, mean, M2) merged into the running
+ * state by parallel_variance_calculation + kahan_summation (:397-474).
+ * state = 4 rows of n_inner floats: count (initialised to 1e-8), avg, m2, m2_carry (:288-312). */
+int aa_streaming_norm_update(const float* x, int64_t n_outer, int64_t n_inner, float* state,
+                             float* scratch, void* stream);
+/* EMATensorNormalizer._update_ops (:236-281): state = 2 rows of n_inner floats: mean (init 0),
+ * var (init 1); var's batch statistic is taken about the OLD moving mean. */
+int aa_ema_norm_update(const float* x, int64_t n_outer, int64_t n_inner, float rate, float* state,
+                       float* scratch, void* stream);
+/* TensorNormalizer.normalize (:134-206) = tf.nn.batch_normalization without scale / offset:
+ * out = clip(x * inv + (-mean * inv)), inv = 1/sqrt(var + variance_epsilon),
+ * var = var_num / var_den (var_den nullable: var = var_num); mean nullable (center_mean=False);
+ * clip_value <= 0 disables clipping. */
+int aa_norm_apply(const float* x, int64_t n_outer, int64_t n_inner, const float* mean,
+                  const float* var_num, const float* var_den, float variance_epsilon,
+                  float clip_value, float* out, void* stream);
 
 #ifdef __cplusplus
 }

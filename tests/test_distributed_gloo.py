@@ -37,6 +37,9 @@ class LinearAgent:
     def initialize(self):
         self.initialized = True
 
+    def replicated_state(self):
+        return [self.w]
+
     def train(self, experience):
         x, y = experience
         denom = x.shape[0] * self.num_replicas
@@ -77,8 +80,10 @@ def _worker(rank, world, port, steps, out):
         x, y = _data(0, 16, 5)
         shard = (x[rank::world], y[rank::world])            # every rank owns its own shard
         agent = LinearAgent(5)
+        agent.w += float(rank)     # replicas that start apart (default, unseeded initialisers) ...
         lrn = learner.Learner(None, agent.train_step_counter, agent,
                               experience_dataset_fn=lambda: iter(lambda: (shard, "info"), None))
+        assert float(agent.w.abs().max()) == 0.0   # ... start from rank 0's weights (broadcast)
         assert isinstance(lrn.strategy, strategy_utils.DataParallelStrategy)
         assert agent.num_replicas == world and agent.gradient_hook is not None
         losses = []

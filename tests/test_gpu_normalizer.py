@@ -1,0 +1,377 @@
+"""GPU: agents_amd.utils.tensor_normalizer (csrc/normalizer.hip) against oracle/tensor_normalizer.py
+and the reference's own cases (tf_agents/utils/tensor_normalizer_test.py), then the PPO call sites
+(agents/ppo/ppo_agent.py:347-366, 650-654, 991-993; ppo_policy.py:231-241;
+train/ppo_learner.py:310-335).
+
+Tolerances: `normalize` is bit-exact given the same statistics (same fp32 expression, correctly
+rounded sqrt and divide).  `update` reduces the batch in a different ORDER than numpy's pairwise
+sums (per-workgroup two-pass moments merged with Chan's identity), so count is exact and avg / m2
+are compared at tf.test's assertAllClose defaults (rtol = atol = 1e-6) on the reference's cases and
+at rtol 2e-5 on large random batches.
+"""
+import numpy as np
+import pytest
+import torch
+
+from agents_amd.specs import tensor_spec
+from agents_amd.utils import tensor_normalizer as tn
+from oracle import ppo as oppo
+from oracle import tensor_normalizer as otn
+
+pytestmark = pytest.mark.gpu
+
+ARR = np.asarray([[1.3, 4.2, 7.5], [8.3, 2.2, 9.5], [3.3, 5.2, 6.5]], np.float32)
+
+
+def close(a, b, rtol=1e-6, atol=1e-6):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol,
+                               atol=atol)
+
+
+def t(x, dev):
+    return torch.as_tensor(np.asarray(x, np.float32), device=dev)
+
+
+def spec3():
+    return tensor_spec.TensorSpec((3,), torch.float32, "obs")
+
+
+# ---- kernels vs the oracle ---------------------------------------------------------------------
+@pytest.mark.parametrize("outer,inner", [((3,), (3,)), ((6, 2), (3,)), ((5000,), ()),
+                                         ((2048, 129), ()), ((264, 129), (17,)),
+                                         ((1000,), (376,)), ((7,), (300,)), ((33, 5), (4, 7)),
+                                         ((100000,), (17,)), ((1,), (3,))])
+def test_streaming_update_matches_oracle(dev, outer, inner):
+    rng = np.random.default_rng(len(outer) * 100 + len(inner))
+    nrm = tn.StreamingTensorNormalizer(tensor_spec.TensorSpec(inner, torch.float32), device=dev)
+    onrm = otn.StreamingNormalizer(inner)
+    for k in range(3):
+        x = (rng.standard_normal(outer + inner) * (1 + k) + 3.0 * k).astype(np.float32)
+        nrm.update(t(x, dev))
+        onrm.update(x)
+        count, avg, m2, carry = nrm.variables
+        assert np.array_equal(count.cpu().numpy(), onrm.count)
+        close(avg, onrm.avg, rtol=2e-5, atol=2e-6)
+        close(m2, onrm.m2, rtol=2e-5, atol=1e-5)
+        # against float64 moments of everything seen so far: the state is what it claims to be
+    mean, var = onrm.mean_var()
+    got = nrm.normalize(t(x, dev), clip_value=-1.0, variance_epsilon=1e-6)
+    close(got, onrm.normalize(x, clip_value=-1.0, variance_epsilon=1e-6), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("center,clip,eps", [(True, 5.0, 1e-3), (False, 10.0, 1e-3),
+                                             (True, -1.0, 1e-6), (False, 0.0, 0.0)])
+def test_normalize_is_bit_exact_given_the_statistics(dev, center, clip, eps):
+    rng = np.random.default_rng(7)
+    nrm = tn.StreamingTensorNormalizer(tensor_spec.TensorSpec((17,), torch.float32), device=dev)
+    onrm = otn.StreamingNormalizer((17,))
+    onrm.update(rng.standard_normal((500, 17)).astype(np.float32) * 3 + 1)
+    nrm.load_state_dict({"state": [t(np.stack([onrm.count, onrm.avg, onrm.m2, onrm.m2_carry]),
+                                     dev)]})
+    x = (rng.standard_normal((64, 9, 17)) * 4).astype(np.float32)
+    got = nrm.normalize(t(x, dev), clip_value=clip, center_mean=center, variance_epsilon=eps)
+    want = onrm.normalize(x, clip_value=clip, center_mean=center, variance_epsilon=eps)
+    assert got.shape == x.shape
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_fresh_normalizer_scales_by_rsqrt_epsilon(dev):
+    """count = 1e-8, m2 = 0 -> var = 0: rewards are multiplied by 1/sqrt(1e-3) and clipped to +-10
+    until the first update (what the reference's PPO does in its first iteration)."""
+    nrm = tn.StreamingTensorNormalizer(tensor_spec.TensorSpec((), torch.float32), device=dev)
+    r = t([[0.1, -0.2, 5.0]], dev)
+    got = nrm.normalize(r, center_mean=False, clip_value=10.0)
+    want = np.clip(np.asarray([[0.1, -0.2, 5.0]], np.float32) *
+                   (np.float32(1) / np.sqrt(np.float32(1e-3))), -10, 10)
+    assert np.array_equal(got.cpu().numpy(), want.astype(np.float32))
+
+
+# ---- the reference's own cases through the GPU classes --------------------------------------
+def test_get_variables_and_reset(dev):                  # :217-257
+    nrm = tn.StreamingTensorNormalizer(spec3(), device=dev)
+    assert len(nrm.variables) == 4
+    for v in nrm.variables:
+        assert tuple(v.shape) == (3,) and v.dtype == torch.float32
+    orig = [v.clone() for v in nrm.variables]
+    nrm.update(t(ARR, dev))
+    assert not torch.equal(nrm.variables[1], orig[1])
+    nrm.reset()
+    for a, b in zip(orig, nrm.variables):
+        assert torch.equal(a, b)
+    close(nrm.variables[0], [1e-8] * 3, atol=0, rtol=1e-6)
+
+
+def test_update_dict_nest(dev):                           # :263-318
+    spec = {"a": spec3(), "b": spec3()}
+    nrm = tn.StreamingTensorNormalizer(spec, device=dev)
+    data = ARR
+    for k, delta in enumerate([0.0, 1.0, -1.0]):
+        x = t(ARR + np.float32(delta), dev)
+        nrm.update({"a": x, "b": x.clone()})
+        if k:
+            data = np.concatenate([data, ARR + np.float32(delta)], 0)
+        count, avg, m2, _ = nrm.variables
+        n = data.shape[0]
+        for key in ("a", "b"):
+            close(count[key], [n] * 3)
+            close(avg[key], data.mean(0))
+            close(m2[key], data.var(0) * n)
+
+
+def test_normalization_dict_nest(dev):                    # :324-357
+    rng = np.random.default_rng(3)
+    spec = {"a": spec3(), "b": spec3()}
+    nrm = tn.StreamingTensorNormalizer(spec, device=dev)
+    norm_obs = {k: rng.standard_normal((6, 2, 3)) for k in spec}
+    nrm.update({k: t(v, dev) for k, v in norm_obs.items()})
+    view = {k: rng.standard_normal((4, 3)) for k in spec}
+    got = nrm.normalize({k: t(v, dev) for k, v in view.items()}, clip_value=-1,
+                        variance_epsilon=1e-6)
+    for k in spec:
+        close(got[k], (view[k] - norm_obs[k].mean((0, 1))) / norm_obs[k].std((0, 1)),
+              rtol=1e-5, atol=1e-5)
+
+
+def test_normalize_vs_numpy_and_mean_variance(dev):       # :363-411
+    nrm = tn.StreamingTensorNormalizer(spec3(), device=dev)
+    nrm.update(t(ARR, dev))
+    eps = 1e-6
+    close(nrm.normalize(t(ARR, dev), variance_epsilon=eps),
+          (ARR - ARR.mean(0)) / (ARR.std(0) + eps))
+    count, avg, m2, _ = nrm.variables
+    close(avg, ARR.mean(0))
+    close(m2 / count, ARR.var(0))
+
+
+@pytest.mark.parametrize("case,iters", [("incremental_mean", 62), ("fixed_mean", 41),
+                                        ("incremental_variance", 383), ("fixed_variance", 54)])
+def test_long_runs_at_the_references_fp32_limits(dev, case, iters):    # :403-497
+    nrm = tn.StreamingTensorNormalizer(spec3(), device=dev)
+    arr = ARR if case != "fixed_variance" else np.asarray(
+        [[-1.3, 4.2, 7.5], [8.3, -2.2, 9.5], [3.3, 5.2, -6.5]], np.float32)
+    states = []
+    chunks = []
+    for i in range(iters):
+        step = arr + np.float32(100 * i) if case.startswith("incremental") else arr
+        nrm.update(t(step, dev))
+        chunks.append(step.astype(np.float64))
+        count, avg, m2, _ = nrm.variables
+        states.append((avg.clone(), (m2 / count)))
+    for i, (avg, var) in enumerate(states):               # one host sync at the end
+        full = np.concatenate(chunks[:i + 1], 0)
+        if case.endswith("mean"):
+            close(avg, full.mean(0))
+        else:
+            close(var, full.var(0))
+
+
+def test_wrong_dtype_or_shape_raises(dev):
+    nrm = tn.StreamingTensorNormalizer(spec3(), device=dev)
+    with pytest.raises(ValueError):
+        nrm.update(torch.zeros((4, 3), dtype=torch.float64, device=dev))
+    with pytest.raises(ValueError):
+        nrm.normalize(torch.zeros((4, 5), device=dev))
+
+
+# ---- EMA ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("outer", [1, 2])
+def test_ema_normalization(dev, outer):                    # :157-180, 201-213
+    nrm = tn.EMATensorNormalizer(spec3(), device=dev)
+    nrm.load_state_dict({"state": [t([[10.0] * 3, [0.1] * 3], dev)]})
+    vec, exp = [9.0, 10.0, 11.0], [-3.1622776601, 0.0, 3.1622776601]
+    for _ in range(outer - 1):
+        vec, exp = [vec] * 2, [exp] * 2
+    close(nrm.normalize(t(vec, dev), variance_epsilon=0.0), exp, atol=1e-4)
+    nrm.load_state_dict({"state": [t([[10.0] * 3, [0.01] * 3], dev)]})
+    close(nrm.normalize(t([[9.0, 10.0, 11.0]], dev), center_mean=False, variance_epsilon=0.0,
+                        clip_value=0.0), [[90.0, 100.0, 110.0]])
+
+
+def test_ema_update_matches_oracle(dev):                   # :236-281
+    rng = np.random.default_rng(11)
+    nrm = tn.EMATensorNormalizer(spec3(), norm_update_rate=0.05, device=dev)
+    onrm = otn.EMANormalizer((3,), 0.05)
+    m0, v0 = [v.clone() for v in nrm.variables]
+    for _ in range(5):
+        x = rng.standard_normal((40, 3)).astype(np.float32) * 2 + 1
+        nrm.update(t(x, dev))
+        onrm.update(x)
+        mean, var = nrm.variables
+        close(mean, onrm.mean, rtol=1e-5)
+        close(var, onrm.var, rtol=1e-5)
+    assert not torch.equal(m0, nrm.variables[0]) and not torch.equal(v0, nrm.variables[1])
+
+
+# ---- PPO call sites ------------------------------------------------------------------------------
+def test_ppo_reward_normalisation_in_return_and_advantage(dev):
+    """compute_return_and_advantage normalises the rewards first (no centring, clip +-10)."""
+    import test_gpu_ppo_agent as tpa
+    agent, _, _ = tpa.build_tanh_agent(dev, use_gae=True, normalize_rewards=True,
+                                       initial_adaptive_kl_beta=0.0, kl_cutoff_factor=0.0)
+    rng = np.random.default_rng(21)
+    B, T1 = 7, 9
+    warm = (rng.standard_normal((B, T1)) * 3 + 0.5).astype(np.float32)
+    agent.update_reward_normalizer(t(warm, dev))
+    onrm = otn.StreamingNormalizer(())
+    onrm.update(warm)
+    traj, h = tpa.make_experience(rng, B, T1, 5, 3, dev, agent)
+    a, sb, v = tpa.oracle_params(agent)
+    with torch.no_grad():
+        _, _, val = tpa.oracle_forward(a, sb, v, torch.from_numpy(h["obs"].reshape(-1, 5)))
+    vp = val.numpy().reshape(B, T1)
+    rew_n = onrm.normalize(h["rew"], clip_value=10.0, center_mean=False)
+    ret, adv = oppo.compute_return_and_advantage(rew_n, h["disc"], h["nst"], vp, 0.99, 0.95,
+                                                 True, False)
+    out = agent._preprocess(traj)
+    tpa.close(out.policy_info["return"], oppo.pad_last(ret), rtol=5e-5, atol=5e-6)
+    tpa.close(out.policy_info["advantage"], oppo.pad_last(adv), rtol=5e-5, atol=5e-6)
+    assert torch.equal(out.reward, traj.reward)      # the stored reward stays raw (:787-806)
+
+
+def test_ppo_train_with_normalizers_matches_oracle(dev):
+    """PPOClipAgent.train with the reference's DEFAULT flags (normalize_rewards,
+    normalize_observations, update_normalizers_in_train): networks see normalised observations,
+    returns come from normalised rewards, both normalisers are updated AFTER the epochs with the
+    raw batch (ppo_agent.py:991-993).  Two consecutive train calls, so the second one runs on the
+    statistics the first one produced."""
+    import test_gpu_ppo_agent as tpa
+    from agents_amd import optimizers
+    from agents_amd.agents.ppo import ppo_actor_network as pan
+    from agents_amd.agents.ppo import ppo_clip_agent
+    from agents_amd.trajectories import time_step as ts
+    from oracle import optim as ooptim
+    obs_spec = tensor_spec.TensorSpec((5,), torch.float32)
+    act_spec = tensor_spec.BoundedTensorSpec((3,), torch.float32, -2.0, 3.0)
+    actor = pan.PPOActorNetwork().create_sequential_actor_net((16, 8), act_spec, seed=3)
+    value = pan.value_network((12,), "tanh", seed=4)
+    agent = ppo_clip_agent.PPOClipAgent(
+        ts.time_step_spec(obs_spec), act_spec, optimizers.Adam(3e-3, epsilon=1e-5),
+        actor_net=actor, value_net=value, importance_ratio_clipping=0.2, use_gae=True,
+        num_epochs=2, gradient_clipping=0.5, entropy_regularization=0.01)
+    assert agent.update_normalizers_in_train
+    rng = np.random.default_rng(9)
+    B, T1, D = 6, 8, 3
+    a, sb, v = tpa.oracle_params(agent)
+    params = a + [sb] + v
+    opt = ooptim.Adam(3e-3, eps=1e-5)
+    o_obs, o_rew = otn.StreamingNormalizer((5,)), otn.StreamingNormalizer(())
+    for call in range(2):
+        traj, h = tpa.make_experience(rng, B, T1, 5, D, dev, agent)
+        traj = traj.replace(observation=traj.observation * 2.0 + 1.0)
+        h["obs"] = h["obs"] * np.float32(2.0) + np.float32(1.0)
+        obs_n = o_obs.normalize(h["obs"].reshape(-1, 5))            # clip 5, centred
+        obs_t = torch.from_numpy(obs_n)
+        with torch.no_grad():
+            _, _, val = tpa.oracle_forward(a, sb, v, obs_t)
+        vp = val.numpy().reshape(B, T1)
+        rew_n = o_rew.normalize(h["rew"], clip_value=10.0, center_mean=False)
+        ret, adv = oppo.compute_return_and_advantage(rew_n, h["disc"], h["nst"], vp, 0.99, 0.95,
+                                                     True, False)
+        ret_p, adv_p = oppo.pad_last(ret), oppo.pad_last(adv)
+        mask = oppo.trajectory_mask(h["st"], ret_p, adv_p).reshape(-1)
+        adv_n = oppo.normalize_advantages(adv_p).reshape(-1)
+        old_loc = torch.from_numpy(h["loc"].reshape(-1, D))
+        old_scale = torch.from_numpy(h["scale"].reshape(-1, D))
+        acts = torch.from_numpy(h["act"].reshape(-1, D))
+        old_logp = oppo.normal_log_prob(old_loc, old_scale, acts)
+        last = None
+        for _ in range(2):
+            loc, scale, val = tpa.oracle_forward(a, sb, v, obs_t)
+            out = oppo.losses(loc, scale, acts, old_logp, torch.from_numpy(adv_n),
+                              torch.from_numpy(ret_p.reshape(-1)), val, torch.from_numpy(mask),
+                              clip_eps=0.2, c_v=0.5, c_e=0.01)
+            grads = torch.autograd.grad(out["total"], params)
+            gn = torch.sqrt(sum((g ** 2).sum() for g in grads))
+            sc = 0.5 * min(1.0 / float(gn), 1.0 / 0.5)
+            opt.step(params, [g * sc for g in grads])
+            last = out
+        o_obs.update(h["obs"])
+        o_rew.update(h["rew"])
+        li = agent.train(traj)
+        tpa.close(li.loss, float(last["total"]), rtol=2e-4)
+        count, avg, m2, _ = agent._observation_normalizer.variables
+        assert np.array_equal(count.cpu().numpy(), o_obs.count)
+        close(avg, o_obs.avg, rtol=1e-5, atol=1e-6)
+        close(m2, o_obs.m2, rtol=1e-5, atol=1e-5)
+        rc, ravg, rm2, _ = agent._reward_normalizer.variables
+        assert float(rc) == float(o_rew.count)
+        close(ravg, o_rew.avg, rtol=1e-5, atol=1e-6)
+        close(rm2, o_rew.m2, rtol=1e-5, atol=1e-5)
+    for got, want in zip(agent.actor_net.body.variables + [agent.actor_net.std_bias] +
+                         agent._value_net.body.variables, params):
+        scale_p = max(float(want.abs().max()), 1e-6)
+        assert float((got.cpu() - want.detach()).abs().max()) <= 3e-4 * scale_p
+
+
+def test_ppo_policy_normalises_observations(dev):
+    """PPOPolicy feeds both networks normalizer.normalize(observation) (ppo_policy.py:231-241)."""
+    import test_gpu_ppo_agent as tpa
+    agent, _, _ = tpa.build_tanh_agent(dev, normalize_observations=True,
+                                       initial_adaptive_kl_beta=0.0, kl_cutoff_factor=0.0,
+                                       compute_value_and_advantage_in_train=False)
+    rng = np.random.default_rng(4)
+    warm = (rng.standard_normal((64, 3, 5)) * 2 + 1).astype(np.float32)
+    agent.update_observation_normalizer(t(warm, dev))
+    onrm = otn.StreamingNormalizer((5,))
+    onrm.update(warm)
+    from agents_amd.trajectories import time_step as ts
+    obs = (rng.standard_normal((32, 5)) * 3).astype(np.float32)
+    step = agent.collect_policy.action(ts.restart(t(obs, dev), batch_size=32))
+    a, sb, v = tpa.oracle_params(agent)
+    with torch.no_grad():
+        oloc, oscale, oval = tpa.oracle_forward(a, sb, v, torch.from_numpy(onrm.normalize(obs)))
+    tpa.close(step.info["dist_params"]["loc"], oloc.numpy(), rtol=2e-5, atol=2e-6)
+    tpa.close(step.info["value_prediction"], oval.numpy(), rtol=2e-5, atol=2e-6)
+    vals, _ = agent.collect_policy.apply_value_network(t(obs, dev))
+    tpa.close(vals, oval.numpy(), rtol=2e-5, atol=2e-6)
+    assert any(x.data_ptr() == agent._observation_normalizer.variables[1].data_ptr()
+               for x in agent.collect_policy.variables())
+
+
+def test_ppo_checkpoint_carries_normalizers(dev):
+    import test_gpu_ppo_agent as tpa
+    a1, _, _ = tpa.build_tanh_agent(dev, normalize_observations=True, normalize_rewards=True)
+    a2, _, _ = tpa.build_tanh_agent(dev, normalize_observations=True, normalize_rewards=True)
+    a1.update_observation_normalizer(torch.randn(10, 4, 5, device=dev))
+    a1.update_reward_normalizer(torch.randn(10, 4, device=dev))
+    a2.load_state_dict(a1.state_dict())
+    for n1, n2 in ((a1._observation_normalizer, a2._observation_normalizer),
+                   (a1._reward_normalizer, a2._reward_normalizer)):
+        for x, y in zip(n1.variables, n2.variables):
+            assert torch.equal(x, y)
+
+
+def test_ppo_learner_updates_normalizers(dev):
+    """PPOLearner.run updates the agent's normalisers from the normalisation dataset before it
+    trains (train/ppo_learner.py:281, 310-335) -- and the agent does not update them itself."""
+    import test_gpu_ppo_learner as tpl
+    from agents_amd.train import ppo_learner
+    from agents_amd.utils import common
+    agent = tpl.make_agent(num_epochs=1, compute_value_and_advantage_in_train=False,
+                           update_normalizers_in_train=False, gradient_clipping=0.5,
+                           normalize_observations=True, normalize_rewards=True)
+    agent.initialize()
+    B, T = 16, 9
+    rb = tpl.collect_into_replay(agent, dev, B, T)
+
+    def dataset_fn():
+        return rb.as_dataset(sample_batch_size=B, num_steps=T + 1,
+                             single_deterministic_pass=True).map(
+            lambda traj, info: (agent.preprocess_sequence(traj), info))
+
+    lrn = ppo_learner.PPOLearner(None, common.Variable(0), agent, dataset_fn, dataset_fn,
+                                 num_samples=1, num_epochs=2, minibatch_size=40,
+                                 shuffle_buffer_size=B * (T + 1))
+    lrn.run()
+    frames = B * (T + 1)
+    traj = rb.gather_all()
+    count, avg, m2, _ = agent._observation_normalizer.variables
+    close(count, [frames] * 17)
+    obs = traj.observation.cpu().numpy().reshape(-1, 17).astype(np.float64)
+    close(avg, obs.mean(0), rtol=1e-5, atol=1e-6)
+    close(m2 / count, obs.var(0), rtol=1e-4, atol=1e-6)
+    rc, ravg, _, _ = agent._reward_normalizer.variables
+    assert float(rc) == frames
+    close(ravg, traj.reward.cpu().numpy().astype(np.float64).mean(), rtol=1e-5, atol=1e-6)
+    assert int(agent.train_step_counter.numpy()) == (frames // 40) * 2

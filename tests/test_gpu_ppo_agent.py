@@ -346,9 +346,9 @@ def test_constructor_errors(dev):
     actor, value = dummy_nets()
     with pytest.raises(TypeError):
         ppo_agent.PPOAgent(TS_SPEC, ACT_SPEC, optimizers.Adam(), actor_net=None, value_net=value)
-    with pytest.raises(NotImplementedError):
-        ppo_agent.PPOAgent(TS_SPEC, ACT_SPEC, optimizers.Adam(), actor_net=actor,
-                           value_net=value)  # normalisers default to True in the reference
+    agent = ppo_agent.PPOAgent(TS_SPEC, ACT_SPEC, optimizers.Adam(), actor_net=actor,
+                               value_net=value)  # normalisers default to True in the reference
+    assert agent._reward_normalizer is not None and agent._observation_normalizer is not None
 
 
 def test_classic_ppo_loop_replay_driver_train_clear(dev):
