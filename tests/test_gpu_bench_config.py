@@ -9,9 +9,12 @@ Three stacks run side by side on identical seeds:
   graphed  what bench.py times: the collect / sample / train HIP graphs on three streams
            (`graph.enable_overlap`), train graphs bound to the sampler's ring slots
 Checks, per iteration: sampled rows and ids eager == oracle bit for bit; loss eager vs oracle to
-1e-5 relative (dqn_agent.py:412-449 restated in oracle/dqn.py); graphed == eager bit for bit
-(parameters, loss, replay tables).  At the end: parameters vs the oracle after all steps, replay
-tables eager == oracle == graphed.
+1e-5 relative and the parameters after the step to 5e-5 x max|p| (dqn_agent.py:412-449 restated
+in oracle/dqn.py), BOTH taken from the same pre-step parameters -- the oracle's parameters are
+reset to the GPU's before every step, because a free-running pair drifts apart chaotically (ReLU
+boundaries amplify last-bit differences of the fp32 sums: measured 4e-5 on the loss after 13
+steps), which says nothing about either implementation; graphed == eager bit for bit (parameters,
+loss, replay tables).  At the end: replay tables eager == oracle == graphed.
 """
 import numpy as np
 import pytest
@@ -28,10 +31,9 @@ from oracle import replay as oreplay
 pytestmark = pytest.mark.gpu
 
 B_ENV, L_RING, S, ITERS = 256, 8, 256, 24
-# Parameters after ITERS optimizer steps, relative to max|p| of the tensor.  Each step's update is
-# lr * g / sqrt(ms - mg^2 + eps) with fp32 gradients that differ from the oracle's in the last
-# bits (different summation order in the MFMA tiles), so the bound is per-step rounding x steps.
-TOL_PARAM = 1e-4
+# Parameters after ONE optimizer step from identical parameters, relative to max|p| of the tensor
+# (the tolerance of tests/test_gpu_dqn_agent.py's Atari case).
+TOL_PARAM = 5e-5
 
 
 def _stack(dev, eager):
@@ -76,7 +78,7 @@ def test_bench_configuration_matches_oracle_and_eager(dev):
         try:
             q = []
             ts_e = ts_g = None
-            max_loss_rel = 0.0
+            max_loss_rel = worst = 0.0
             for i in range(ITERS):
                 # eager + oracle
                 ts_e, _ = w_e["collect_driver"].run(ts_e)
@@ -87,6 +89,9 @@ def test_bench_configuration_matches_oracle_and_eager(dev):
                     assert np.array_equal(g_leaf.cpu().numpy(), o_leaf), f"rows differ, step {i}"
                 assert np.array_equal(info_e.ids.cpu().numpy(), oids)
                 assert np.array_equal(info_e.probabilities.cpu().numpy(), oprobs)
+                with torch.no_grad():       # same pre-step parameters on both sides
+                    for ov, a in zip(oagent.params, net_e.get_weights()):
+                        ov.copy_(torch.from_numpy(np.asarray(a)))
                 li_e = w_e["agent"].train(exp_e)
                 o_st, o_obs, o_act, o_nst, o_rew, o_disc = odata
                 ototal, aux, _ = oagent.train(torch.from_numpy(o_obs), o_act, o_rew, o_disc, o_st)
@@ -94,6 +99,11 @@ def test_bench_configuration_matches_oracle_and_eager(dev):
                 np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-7,
                                            err_msg=f"loss at step {i}")
                 max_loss_rel = max(max_loss_rel, abs(got - want) / max(abs(want), 1e-12))
+                for v, ov in zip(net_e.variables, oagent.params):
+                    scale = max(float(ov.detach().abs().max()), 1e-12)
+                    err = float((v.cpu() - ov.detach()).abs().max()) / scale
+                    worst = max(worst, err)
+                    assert err <= TOL_PARAM, f"param mismatch {err:.2e} after step {i}"
                 # graphed (the timed configuration)
                 ts_g, _ = run_g(ts_g)
                 li_g = w_g["learner"].run(iterations=1, iterator=it_g)
@@ -119,11 +129,5 @@ def test_bench_configuration_matches_oracle_and_eager(dev):
             got = tab.cpu().numpy().reshape(-1)
             assert np.array_equal(got.view(np.uint8), otab.reshape(-1).view(np.uint8))
         assert np.array_equal(rb_e._id_table.variables()[0].cpu().numpy(), orb.id_table)
-        # parameters after ITERS steps
-        worst = 0.0
-        for v, ov in zip(net_e.variables, oagent.params):
-            scale = max(float(ov.detach().abs().max()), 1e-12)
-            worst = max(worst, float((v.cpu() - ov.detach()).abs().max()) / scale)
-        print(f"bench-config parity: max loss rel err {max_loss_rel:.2e}, "
-              f"max param err {worst:.2e} of max|p| after {ITERS} steps")
-        assert worst <= TOL_PARAM, f"param mismatch {worst:.2e}"
+        print(f"bench-config parity: max loss rel err {max_loss_rel:.2e}, max one-step param err "
+              f"{worst:.2e} of max|p| over {ITERS} steps")

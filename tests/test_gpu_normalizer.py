@@ -46,16 +46,22 @@ def test_streaming_update_matches_oracle(dev, outer, inner):
     rng = np.random.default_rng(len(outer) * 100 + len(inner))
     nrm = tn.StreamingTensorNormalizer(tensor_spec.TensorSpec(inner, torch.float32), device=dev)
     onrm = otn.StreamingNormalizer(inner)
+    seen = []
     for k in range(3):
         x = (rng.standard_normal(outer + inner) * (1 + k) + 3.0 * k).astype(np.float32)
         nrm.update(t(x, dev))
         onrm.update(x)
+        seen.append(x.reshape((-1,) + inner).astype(np.float64))
         count, avg, m2, carry = nrm.variables
         assert np.array_equal(count.cpu().numpy(), onrm.count)
-        close(avg, onrm.avg, rtol=2e-5, atol=2e-6)
-        close(m2, onrm.m2, rtol=2e-5, atol=1e-5)
-        # against float64 moments of everything seen so far: the state is what it claims to be
-    mean, var = onrm.mean_var()
+        # vs the oracle: numpy's axis-0 sums are sequential in fp32, so on 1e5-row batches the
+        # ORACLE is the less accurate side (its own error vs float64 is ~2e-5)
+        close(avg, onrm.avg, rtol=1e-4, atol=1e-5)
+        close(m2, onrm.m2, rtol=1e-4, atol=1e-4)
+        # vs float64 moments of everything seen so far: the state is what it claims to be
+        full = np.concatenate(seen, 0)
+        close(avg, full.mean(0), rtol=5e-6, atol=2e-6)
+        close(m2, full.var(0) * full.shape[0], rtol=1e-5, atol=1e-5)
     got = nrm.normalize(t(x, dev), clip_value=-1.0, variance_epsilon=1e-6)
     close(got, onrm.normalize(x, clip_value=-1.0, variance_epsilon=1e-6), rtol=1e-4, atol=1e-4)
 
