@@ -25,6 +25,7 @@ SOURCES = [
     ("prio.hip", []),
     ("gemm.hip", []),
     ("conv_pair.hip", []),
+    ("conv_pair_x6.hip", []),
     ("conv_dx_frame.hip", []),
     ("nn.hip", ["-ffp-contract=off"]),
     ("dense_small.hip", []),

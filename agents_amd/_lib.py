@@ -76,6 +76,11 @@ _SIGNATURES = {
                                        POINTER(ConvLayerDesc)]),
     "aa_conv_pair_forward": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                      POINTER(ConvLayerDesc), POINTER(ConvLayerDesc), c_void_p]),
+    "aa_conv_pair_x6_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32,
+                                                  POINTER(ConvLayerDesc), POINTER(ConvLayerDesc)]),
+    "aa_conv_pair_x6_forward": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                        POINTER(ConvLayerDesc), POINTER(ConvLayerDesc), c_void_p,
+                                        c_int64, c_void_p]),
     "aa_conv_dx_frame_supported": (c_int, [POINTER(ConvDxDesc)]),
     "aa_conv_dx_frame": (c_int, [POINTER(ConvDxDesc), c_void_p]),
     "aa_dense_small_forward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64,

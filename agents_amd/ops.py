@@ -73,6 +73,7 @@ class workspace_scope:
         if not torch.cuda.is_current_stream_capturing():
             _WS.reserve(self._tag, self._device)
             _WS2.reserve(self._tag, self._device)
+            _WS3.reserve(self._tag, self._device)
         _SCOPE = self._tag
         return self
 
@@ -92,6 +93,8 @@ def new_side_stream(device):
 _WS = _Workspace()
 # Separate scratch for column-sum partials so a bias-grad launch never aliases a live split-K slab
 _WS2 = _Workspace()
+# split filter planes of the bf16x6 conv pair (read by a whole launch: never shared with slabs)
+_WS3 = _Workspace()
 
 
 def _f32c(t, name):
@@ -273,6 +276,9 @@ def _pair_descs(w1, b1, s1, act1, y1, w2, b2, s2, act2, y2):
 
 
 _PAIR_OK = {}
+_PAIR_X6_WS = {}
+# AA_CONV_PAIR_X6=0: keep the fused conv pair on the fp32 MFMA kernel (A/B measurements)
+CONV_PAIR_X6 = _os.environ.get("AA_CONV_PAIR_X6", "1") != "0"
 
 
 def conv_pair_supported(x_shape, w1, s1, w2, s2):
@@ -310,10 +316,27 @@ def conv_pair_forward(x, w1, b1, s1, act1, y1, w2, b2, s2, act2, y2):
     if y1.numel() != Bn * OH1 * OW1 * C1 or y2.numel() != Bn * OH2 * OW2 * C2:
         raise ValueError("conv_pair_forward: bad output sizes")
     d = _pair_descs(w1, b1, s1, act1, y1, w2, b2, s2, act2, y2)
+    lib = _lib.load()
     with torch.cuda.device(x.device):
-        check(_lib.load().aa_conv_pair_forward(ptr(x), _img_pitch(x), Bn, H, W, C,
-                                               ctypes.byref(d[0]), ctypes.byref(d[1]),
-                                               _lib.stream_ptr()), "aa_conv_pair_forward")
+        key = (Bn, H, W, C, tuple(w1.shape), s1, tuple(w2.shape), s2)
+        ws_bytes = _PAIR_X6_WS.get(key)
+        if ws_bytes is None:
+            ws_bytes = int(lib.aa_conv_pair_x6_workspace_bytes(
+                Bn, H, W, C, ctypes.byref(d[0]), ctypes.byref(d[1]))) if CONV_PAIR_X6 else 0
+            _PAIR_X6_WS[key] = ws_bytes
+        if ws_bytes > 0:
+            # bf16 matrix cores, fp32 accuracy (csrc/conv_pair_x6.hip); the split filter planes
+            # live in the calling stream's scratch (concurrent forwards on other streams -- target
+            # network, collect graph -- own theirs)
+            ws = _WS3.get(ws_bytes, x.device)
+            check(lib.aa_conv_pair_x6_forward(ptr(x), _img_pitch(x), Bn, H, W, C,
+                                              ctypes.byref(d[0]), ctypes.byref(d[1]), ptr(ws),
+                                              ws.numel(), _lib.stream_ptr()),
+                  "aa_conv_pair_x6_forward")
+        else:
+            check(lib.aa_conv_pair_forward(ptr(x), _img_pitch(x), Bn, H, W, C,
+                                           ctypes.byref(d[0]), ctypes.byref(d[1]),
+                                           _lib.stream_ptr()), "aa_conv_pair_forward")
     return y2
 
 

@@ -179,6 +179,22 @@ int aa_conv_pair_forward(const float* x, int64_t img_pitch, int32_t n_img, int32
                          int32_t Cin, const aa_conv_layer_desc* first,
                          const aa_conv_layer_desc* second, void* stream);
 
+/* The same pair on the bf16 matrix cores at fp32 accuracy (csrc/conv_pair_x6.hip): every fp32
+ * operand is split exactly into three bf16 pieces ONCE (the frame while it is staged into LDS, the
+ * middle activation in the first layer's epilogue, the filters by a pre-pass of this call into
+ * `workspace`), six of the nine piece products are accumulated in fp32.  Same arguments and
+ * outputs as aa_conv_pair_forward plus the scratch; limits: Cin % 32 == 0 (both layers' inputs),
+ * Cout % 16 == 0, OH*OW <= 128 per layer, 3 bf16 planes of both padded LDS frames <= 160 KiB
+ * (aa_conv_pair_x6_workspace_bytes returns 0 when a shape does not qualify; the forward call then
+ * returns AA_ERR_RANGE). */
+int64_t aa_conv_pair_x6_workspace_bytes(int32_t n_img, int32_t H, int32_t W, int32_t Cin,
+                                        const aa_conv_layer_desc* first,
+                                        const aa_conv_layer_desc* second);
+int aa_conv_pair_x6_forward(const float* x, int64_t img_pitch, int32_t n_img, int32_t H, int32_t W,
+                            int32_t Cin, const aa_conv_layer_desc* first,
+                            const aa_conv_layer_desc* second, void* workspace,
+                            int64_t workspace_bytes, void* stream);
+
 /* Input gradient of a VALID Conv2D in gather form, one workgroup per frame (no column-gradient
  * slab, no col2im): dx[b,iy,ix,ci] = act'(mask_src[b,iy,ix,ci]) * sum over the patches containing
  * (iy,ix) of dz[b,oy,ox,:] . w[ky,kx,ci,:]   (tf.GradientTape through keras Conv2D,

@@ -49,9 +49,32 @@ PAIRS = [  # (B, H, W, C, (KH1,KW1,s1,F1,act1), (KH2,KW2,s2,F2,act2))
 ]
 
 
+@pytest.fixture(params=[True, False], ids=["bf16x6", "fp32mfma"])
+def x6(request):
+    """Both implementations of the pair: csrc/conv_pair_x6.hip (default where the shape fits) and
+    csrc/conv_pair.hip."""
+    prev = ops.CONV_PAIR_X6
+    ops.CONV_PAIR_X6 = request.param
+    ops._PAIR_X6_WS.clear()
+    yield request.param
+    ops.CONV_PAIR_X6 = prev
+    ops._PAIR_X6_WS.clear()
+
+
+def test_atari_pair_takes_the_bf16_kernel(dev):
+    import ctypes
+    from agents_amd import _lib
+    d = [_lib.ConvLayerDesc(w=None, bias=None, y=None, KH=k, KW=k, stride=st, Cout=64, act=1)
+         for k, st in ((4, 2), (3, 1))]
+    lib = _lib.load()
+    ws = lib.aa_conv_pair_x6_workspace_bytes(256, 20, 20, 32, ctypes.byref(d[0]), ctypes.byref(d[1]))
+    assert ws == (16 * 4 + 18 * 4) * 3 * 64 * 16       # k-steps x column tiles x planes x 1 KiB
+    assert ops.CONV_PAIR_X6
+
+
 @pytest.mark.parametrize("cfg", PAIRS)
 @pytest.mark.parametrize("bias", [True, False])
-def test_conv_pair_forward(dev, cfg, bias):
+def test_conv_pair_forward(dev, cfg, bias, x6):
     B, H, W, C, (KH1, KW1, s1, F1, a1), (KH2, KW2, s2, F2, a2) = cfg
     rng = np.random.default_rng(B + H + C + F1 + F2)
     x = rnd(rng, B, H, W, C)
@@ -76,6 +99,25 @@ def test_conv_pair_forward(dev, cfg, bias):
     ops.conv_forward(z1, d(w2), d(b2), s2, a2, z2)
     close(y1, z1.cpu())
     close(y2, z2.cpu(), tol=5e-5)
+
+
+def test_conv_pair_x6_exact_on_bf16_representable_operands(dev):
+    """Integer-valued operands below 2^8 are single bf16 pieces: every product and (for these
+    magnitudes) every partial sum is exact in fp32, so the kernel must reproduce the float64
+    reference bit for bit -- any fragment / K-order mismatch between the A and B sides shows."""
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy(rng.integers(-8, 9, (5, 20, 20, 32)).astype(np.float32))
+    w1 = torch.from_numpy(rng.integers(-3, 4, (4, 4, 32, 64)).astype(np.float32))
+    w2 = torch.from_numpy(rng.integers(-2, 3, (3, 3, 64, 64)).astype(np.float32))
+    b1 = torch.from_numpy(rng.integers(-5, 6, (64,)).astype(np.float32))
+    y1 = torch.empty(5, 9, 9, 64, device=dev)
+    y2 = torch.empty(5, 7, 7, 64, device=dev)
+    ops.conv_pair_forward(x.to(dev), w1.to(dev), b1.to(dev), 2, "relu", y1, w2.to(dev), None, 1,
+                          None, y2)
+    r1 = torch.relu(conv_ref(x.double(), w1, b1, 2))
+    r2 = conv_ref(r1, w2, None, 1)
+    assert float(r2.abs().max()) < 2 ** 24
+    assert torch.equal(y1.cpu().double(), r1) and torch.equal(y2.cpu().double(), r2)
 
 
 def test_conv_pair_strided_batch_and_determinism(dev):
