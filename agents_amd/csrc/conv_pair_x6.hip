@@ -31,6 +31,7 @@
 #include "common.h"
 #include "agents_amd.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 typedef float cx_f32x4 __attribute__((ext_vector_type(4)));
@@ -45,6 +46,7 @@ union CxFrag {
 
 #define AA_CX_THREADS 512
 #define AA_CX_MAX_RT 8
+#define AA_CX_MAX_KS 64       /* k-steps (32 input channels of one tap) per layer */
 
 __device__ static inline unsigned cx_pk_bf16(float lo, float hi) {   // {bf16_rn(hi), bf16_rn(lo)}
   cx_f32x2 f = {lo, hi};
@@ -80,14 +82,38 @@ struct CxLayer {
   int H, W, Cin, KH, KW, stride, OH, OW, Cout, act;
   int pitch, rowp, plane;   // bytes per input pixel / input row / plane of this layer's LDS frame
   int ksteps, cgs;          // KH*KW*Cin/32 MFMA steps, Cin/32 of them per tap
+  unsigned m_ow, m_w;       // ceil(2^16 / OW), ceil(2^16 / W): n / d == (n * m) >> 16 for the
+                            // pixel indices of a frame (n * d < 2^16: both < 2^8 here, checked)
+  int tap[AA_CX_MAX_KS];    // byte offset of every k-step inside a patch (host-built: the main
+                            // loop is then free of tap / channel-group bookkeeping and branches)
 };
+
+// n / d for n, d < 256 with m = ceil(2^16 / d): exact because n * (d m - 2^16) < n d < 2^16
+__device__ static inline int cx_div(int n, unsigned m) { return (int)(((unsigned)n * m) >> 16); }
 
 struct CxParams {
   const float* x;      // [n_img][H*W*Cin], image pitch img_pitch floats
   int64_t img_pitch;
   int n_img;
   CxLayer l[2];
+#ifdef AA_CX_STAMPS
+  long long* stamps;   // tools/cx_probe.hip: [workgroup][wave][8] wall_clock64 ticks (10 ns)
+#endif
 };
+
+#ifdef AA_CX_STAMPS
+static long long* g_cx_stamps = nullptr;
+__device__ long long* d_cx_stamps = nullptr;    // same buffer, reachable from cx_layer
+#define CX_STAMP_L(i)                                                                      \
+  if (d_cx_stamps != nullptr && (threadIdx.x & 63) == 0)                                   \
+    d_cx_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64();
+#define CX_STAMP(i)                                                                        \
+  if (P.stamps != nullptr && (threadIdx.x & 63) == 0)                                      \
+    P.stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64();
+#else
+#define CX_STAMP(i)
+#define CX_STAMP_L(i)
+#endif
 
 __device__ static inline float cx_act(float v, int act) {
   if (act == AA_ACT_RELU) return v > 0.f ? v : 0.f;
@@ -137,7 +163,7 @@ __device__ static inline void cx_layer(const CxLayer& L, const char* __restrict_
   for (int rt = 0; rt < RT; ++rt) {
     int p = (rt0 + rt) * 16 + lr;
     if (p >= OHW) p = OHW - 1;
-    const int oy = p / L.OW, ox = p - oy * L.OW;
+    const int oy = cx_div(p, L.m_ow), ox = p - oy * L.OW;
     pb[rt] = oy * L.stride * L.rowp + ox * L.stride * L.pitch + lg * 16;
   }
   // where this lane's four output pixels of every row tile go (epilogue)
@@ -149,7 +175,7 @@ __device__ static inline void cx_layer(const CxLayer& L, const char* __restrict_
       for (int e = 0; e < 4; ++e) {
         int p = (rt0 + rt) * 16 + 4 * lg + e;
         if (p >= OHW) p = OHW - 1;
-        const int py = p / L.OW, px = p - py * L.OW;
+        const int py = cx_div(p, L.m_ow), px = p - py * L.OW;
         dpix[rt][e] = py * Ln.rowp + px * Ln.pitch;
       }
   }
@@ -162,16 +188,9 @@ __device__ static inline void cx_layer(const CxLayer& L, const char* __restrict_
       small[rt] = cx_f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const uint4* wp = L.wf + (size_t)ct * 3 * 64 + lane;
-    CxFrag b0[3], b1[3];
     auto load_b = [&](CxFrag (&b)[3], int ks) {
 #pragma unroll
       for (int s = 0; s < 3; ++s) b[s].q = wp[(size_t)ks * wstep + s * 64];
-    };
-    int ky = 0, kx = 0, cg = 0;
-    auto tap_off = [&]() {     // byte offset of the current k-step inside a patch; then advance
-      const int off = ky * L.rowp + kx * L.pitch + cg * 64;
-      if (++cg == L.cgs) { cg = 0; if (++kx == L.KW) { kx = 0; ++ky; } }
-      return off;
     };
     auto load_a = [&](CxFrag (&a)[RT][3], int off) {
 #pragma unroll
@@ -201,77 +220,113 @@ __device__ static inline void cx_layer(const CxLayer& L, const char* __restrict_
       for (int rt = 0; rt < RT; ++rt)
         big[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][0].v, b[0].v, big[rt], 0, 0, 0);
     };
-    const int S = L.ksteps;
-    CxFrag a0[RT][3], a1[RT][3];
-    load_b(b0, 0);
-    if (S > 1) load_b(b1, 1);
-    load_a(a0, tap_off());
-    for (int ks = 0; ks < S; ks += 2) {
-      if (ks + 1 < S) load_a(a1, tap_off());
-      mma(a0, b0);
-      if (ks + 2 < S) load_b(b0, ks + 2);
-      if (ks + 1 < S) {
-        if (ks + 2 < S) load_a(a0, tap_off());
-        mma(a1, b1);
-        if (ks + 3 < S) load_b(b1, ks + 3);
+    if (dst != nullptr) { CX_STAMP_L(6) }
+    // Filter fragments run FOUR k-steps ahead in a register ring (an L2 hit under load is
+    // ~500-800 cycles, two k-steps of MFMA issue), patch fragments one step ahead (LDS).  All
+    // refills are unconditional, with the index clamped to the last k-step: no branches in the
+    // body.  Ring slot = k-step & 3; the 0-3 leftover steps reuse the slots in order.
+    const int S = L.ksteps, last = S - 1;
+    CxFrag a0[RT][3], a1[RT][3], b[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) load_b(b[j], j < last ? j : last);
+    load_a(a0, L.tap[0]);
+    auto step = [&](auto jc, int ks) {
+      constexpr int J = decltype(jc)::value;
+      const int kn = ks + J + 1 < last ? ks + J + 1 : last;
+      const int kb = ks + J + 4 < last ? ks + J + 4 : last;
+      if (J & 1) {
+        load_a(a0, L.tap[kn]);
+        mma(a1, b[J]);
+      } else {
+        load_a(a1, L.tap[kn]);
+        mma(a0, b[J]);
       }
+      load_b(b[J], kb);
+    };
+    int ks = 0;
+    for (; ks + 3 < S; ks += 4) {
+      step(std::integral_constant<int, 0>{}, ks);
+      step(std::integral_constant<int, 1>{}, ks);
+      step(std::integral_constant<int, 2>{}, ks);
+      step(std::integral_constant<int, 3>{}, ks);
     }
+    if (ks < S) step(std::integral_constant<int, 0>{}, ks);
+    if (ks + 1 < S) step(std::integral_constant<int, 1>{}, ks);
+    if (ks + 2 < S) step(std::integral_constant<int, 2>{}, ks);
+    if (dst != nullptr) { CX_STAMP_L(7) }
     const int co = ct * 16 + lr;
     const float bv = L.bias != nullptr ? L.bias[co] : 0.f;
-    float* yimg = L.y + (size_t)img * OHW * L.Cout;
+    float* yimg = L.y + (size_t)img * OHW * L.Cout + co;
+    // the activation kind and "feeds a next layer" are resolved ONCE, outside the element loop
+    auto emit = [&](auto actc, auto splitc) {
+      constexpr int ACT = decltype(actc)::value;
+      constexpr bool SPLIT = decltype(splitc)::value;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
+      for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int p = (rt0 + rt) * 16 + 4 * lg + e;
-        if (p >= OHW) continue;
-        const float v = cx_act((big[rt][e] + small[rt][e]) + bv, L.act);
-        yimg[(size_t)p * L.Cout + co] = v;
-        if (dst != nullptr) {
-          // v = hi + mid + lo exactly; one 2-byte store per plane at [pixel][channel]
-          const unsigned h = cx_pk_bf16(v, 0.f) & 0xffffu;
-          const float r1 = v - __uint_as_float(h << 16);
-          const unsigned m = cx_pk_bf16(r1, 0.f) & 0xffffu;
-          const float r2 = r1 - __uint_as_float(m << 16);
-          const unsigned l = cx_pk_bf16(r2, 0.f) & 0xffffu;
-          char* d = dst + dpix[rt][e] + co * 2;
-          *reinterpret_cast<unsigned short*>(d) = (unsigned short)h;
-          *reinterpret_cast<unsigned short*>(d + Ln.plane) = (unsigned short)m;
-          *reinterpret_cast<unsigned short*>(d + 2 * Ln.plane) = (unsigned short)l;
+        for (int e = 0; e < 4; ++e) {
+          const int p = (rt0 + rt) * 16 + 4 * lg + e;
+          if (p >= OHW) continue;
+          float v = (big[rt][e] + small[rt][e]) + bv;
+          if (ACT == AA_ACT_RELU) v = v > 0.f ? v : 0.f;
+          if (ACT == AA_ACT_TANH) v = tanhf(v);
+          yimg[p * L.Cout] = v;
+          if (SPLIT) {
+            // v = hi + mid + lo exactly; one 2-byte store per plane at [pixel][channel]
+            const unsigned h = cx_pk_bf16(v, 0.f) & 0xffffu;
+            const float r1 = v - __uint_as_float(h << 16);
+            const unsigned m = cx_pk_bf16(r1, 0.f) & 0xffffu;
+            const float r2 = r1 - __uint_as_float(m << 16);
+            const unsigned l = cx_pk_bf16(r2, 0.f) & 0xffffu;
+            char* d = dst + dpix[rt][e] + co * 2;
+            *reinterpret_cast<unsigned short*>(d) = (unsigned short)h;
+            *reinterpret_cast<unsigned short*>(d + Ln.plane) = (unsigned short)m;
+            *reinterpret_cast<unsigned short*>(d + 2 * Ln.plane) = (unsigned short)l;
+          }
         }
       }
-    }
+    };
+    auto emit_act = [&](auto splitc) {
+      if (L.act == AA_ACT_RELU) emit(std::integral_constant<int, AA_ACT_RELU>{}, splitc);
+      else if (L.act == AA_ACT_TANH) emit(std::integral_constant<int, AA_ACT_TANH>{}, splitc);
+      else emit(std::integral_constant<int, AA_ACT_NONE>{}, splitc);
+    };
+    if (dst != nullptr) emit_act(std::true_type{});
+    else emit_act(std::false_type{});
   }
 }
 
-template <int RT0, int RT1>
-__global__ void __launch_bounds__(AA_CX_THREADS) aa_conv_pair_x6_kernel(CxParams P) {
+template <int RT0, int RT1, int NW>
+__global__ void __launch_bounds__(NW * 64) aa_conv_pair_x6_kernel(CxParams P) {
+  constexpr int NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) char cx_lds[];
   const CxLayer& L0 = P.l[0];
   const CxLayer& L1 = P.l[1];
   char* s_in = cx_lds;
   char* s_mid = cx_lds + 3 * (size_t)L0.plane;
   const int tid = threadIdx.x;
-  const int octs = L0.Cin >> 3;                 // channel octets per pixel
+  const int octs = L0.Cin >> 3;                 // channel octets per pixel (a power of two)
+  const int oct_sh = 31 - __builtin_clz(octs);
   const int n_item = L0.H * L0.W * octs;
   for (int img = blockIdx.x; img < P.n_img; img += gridDim.x) {
     __syncthreads();   // the previous frame's readers are done
+    CX_STAMP(0)
     const float4* xs = reinterpret_cast<const float4*>(P.x + (size_t)img * P.img_pitch);
-    for (int it0 = tid; it0 < n_item; it0 += 2 * AA_CX_THREADS) {   // 4 x 16-byte loads in flight
+    for (int it0 = tid; it0 < n_item; it0 += 2 * NT) {   // 4 x 16-byte loads in flight
       float4 v[2][2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        int it = it0 + u * AA_CX_THREADS;
+        int it = it0 + u * NT;
         if (it >= n_item) it = n_item - 1;
         v[u][0] = xs[2 * it];
         v[u][1] = xs[2 * it + 1];
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const int it = it0 + u * AA_CX_THREADS;
+        const int it = it0 + u * NT;
         if (it >= n_item) continue;
-        const int q = it / octs, j = it - q * octs;
-        const int qy = q / L0.W, qx = q - qy * L0.W;
+        const int q = it >> oct_sh, j = it & (octs - 1);
+        const int qy = cx_div(q, L0.m_w), qx = q - qy * L0.W;
         const float a[8] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][0].w,
                             v[u][1].x, v[u][1].y, v[u][1].z, v[u][1].w};
         uint4 f[3];
@@ -281,10 +336,15 @@ __global__ void __launch_bounds__(AA_CX_THREADS) aa_conv_pair_x6_kernel(CxParams
         for (int s = 0; s < 3; ++s) *reinterpret_cast<uint4*>(d + s * L0.plane) = f[s];
       }
     }
+    CX_STAMP(1)
     __syncthreads();
-    cx_layer<RT0 / 2>(L0, s_in, img, s_mid, L1);
+    CX_STAMP(2)
+    cx_layer<RT0 * 4 / NW>(L0, s_in, img, s_mid, L1);
+    CX_STAMP(3)
     __syncthreads();
-    cx_layer<RT1 / 2>(L1, s_mid, img, nullptr, L1);
+    CX_STAMP(4)
+    cx_layer<RT1 * 4 / NW>(L1, s_mid, img, nullptr, L1);
+    CX_STAMP(5)
   }
 }
 
@@ -362,6 +422,11 @@ static int cx_check(int n_img, int H, int W, int Cin, const aa_conv_layer_desc* 
     L.OH = OH; L.OW = OW; L.Cout = d[i]->Cout; L.act = d[i]->act;
     L.cgs = c / 32;
     L.ksteps = L.KH * L.KW * L.cgs;
+    if (L.ksteps > AA_CX_MAX_KS) return AA_ERR_RANGE;
+    L.m_ow = (65536u + OW - 1) / OW;
+    L.m_w = (65536u + w - 1) / w;
+    // the frame index arithmetic divides by multiply-shift (cx_div): n * d < 2^16
+    if (h * w > 65535 / w || (c & (c - 1)) != 0) return AA_ERR_RANGE;
     // the pitch search is a pure function of the shape: cache the last few results
     struct Key { int c, h, w, ow, s, ohw, pitch, rowp; };
     static Key cache[8];
@@ -377,6 +442,10 @@ static int cx_check(int n_img, int H, int W, int Cin, const aa_conv_layer_desc* 
       if (n_cache < 8) cache[n_cache++] = Key{c, h, w, OW, L.stride, OH * OW, L.pitch, L.rowp};
     }
     L.plane = h * L.rowp;
+    for (int ks = 0; ks < L.ksteps; ++ks) {
+      const int tp = ks / L.cgs, cg = ks - tp * L.cgs, ky = tp / L.KW, kx = tp - ky * L.KW;
+      L.tap[ks] = ky * L.rowp + kx * L.pitch + cg * 64;
+    }
     lds += 3 * (size_t)L.plane;
     ws += (size_t)L.ksteps * (L.Cout / 16) * 3 * 64 * sizeof(uint4);
     h = OH; w = OW; c = d[i]->Cout;
@@ -414,6 +483,9 @@ int aa_conv_pair_x6_forward(const float* x, int64_t img_pitch, int32_t n_img, in
   P.img_pitch = img_pitch > 0 ? img_pitch : dense;
   if (P.img_pitch < dense || P.img_pitch % 4 != 0 || ((uintptr_t)x & 15) != 0) return AA_ERR_INVALID;
   P.n_img = n_img;
+#ifdef AA_CX_STAMPS
+  P.stamps = g_cx_stamps;
+#endif
   P.l[0].wf = reinterpret_cast<uint4*>(workspace);
   P.l[1].wf = P.l[0].wf + (size_t)P.l[0].ksteps * (P.l[0].Cout / 16) * 3 * 64;
   hipStream_t st = (hipStream_t)stream;
@@ -428,22 +500,29 @@ int aa_conv_pair_x6_forward(const float* x, int64_t img_pitch, int32_t n_img, in
   if (grid > 512) grid = 512;
   auto up = [](int ohw) { const int t = (ohw + 15) / 16; return t <= 2 ? 2 : t <= 4 ? 4 : t <= 6 ? 6 : 8; };
   const int r0 = up(P.l[0].OH * P.l[0].OW), r1 = up(P.l[1].OH * P.l[1].OW);
-  static size_t lds_limit[16] = {0};   // dynamic LDS above 64 KiB is granted once per kernel
+  static int nw = 0;
+  if (nw == 0) {
+    const char* e = getenv("AA_CX_WAVES");      // tuning knob: 4 or 8 waves per workgroup
+    nw = (e != nullptr && atoi(e) == 4) ? 4 : 8;
+  }
+  static size_t lds_limit[32] = {0};   // dynamic LDS above 64 KiB is granted once per kernel
   int rc2 = AA_ERR_INVALID;
-#define AA_CX_CASE(A_, B_)                                                                      \
-  if (r0 == A_ && r1 == B_) {                                                                   \
-    size_t& lim = lds_limit[(A_ / 2 - 1) * 4 + (B_ / 2 - 1)];                                   \
+#define AA_CX_CASE(A_, B_, W_)                                                                  \
+  if (r0 == A_ && r1 == B_ && nw == W_) {                                                       \
+    size_t& lim = lds_limit[((A_ / 2 - 1) * 4 + (B_ / 2 - 1)) * 2 + (W_ == 8)];                 \
     if (lds > 65536 && lds > lim) {                                                             \
-      if (hipFuncSetAttribute((const void*)aa_conv_pair_x6_kernel<A_, B_>,                      \
+      if (hipFuncSetAttribute((const void*)aa_conv_pair_x6_kernel<A_, B_, W_>,                  \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
         return AA_ERR_LAUNCH;                                                                   \
       lim = lds;                                                                                \
     }                                                                                           \
-    hipLaunchKernelGGL((aa_conv_pair_x6_kernel<A_, B_>), dim3(grid), dim3(AA_CX_THREADS), lds,  \
+    hipLaunchKernelGGL((aa_conv_pair_x6_kernel<A_, B_, W_>), dim3(grid), dim3(W_ * 64), lds,    \
                        st, P);                                                                  \
     rc2 = AA_OK;                                                                                \
   }
-#define AA_CX_ROW(A_) AA_CX_CASE(A_, 2) AA_CX_CASE(A_, 4) AA_CX_CASE(A_, 6) AA_CX_CASE(A_, 8)
+#define AA_CX_ROW(A_)                                                               \
+  AA_CX_CASE(A_, 2, 8) AA_CX_CASE(A_, 4, 8) AA_CX_CASE(A_, 6, 8) AA_CX_CASE(A_, 8, 8) \
+  AA_CX_CASE(A_, 2, 4) AA_CX_CASE(A_, 4, 4) AA_CX_CASE(A_, 6, 4) AA_CX_CASE(A_, 8, 4)
   AA_CX_ROW(2) AA_CX_ROW(4) AA_CX_ROW(6) AA_CX_ROW(8)
 #undef AA_CX_ROW
 #undef AA_CX_CASE
