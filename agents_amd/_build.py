@@ -27,6 +27,7 @@ SOURCES = [
     ("conv_pair.hip", []),
     ("conv_pair_x6.hip", []),
     ("conv_dx_frame.hip", []),
+    ("conv_dx_frame_x6.hip", []),
     ("nn.hip", ["-ffp-contract=off"]),
     ("dense_small.hip", []),
     ("mlp_small.hip", []),

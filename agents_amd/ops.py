@@ -389,6 +389,9 @@ def conv_dx(dz, w, x_shape, stride, dcol, out, mask_src=None, mask_act=None):
 
 CONV_DX_FRAME = _os.environ.get("AA_CONV_DX_FRAME", "1") != "0"   # gather-form conv input gradient
 _DXF_OK = {}
+_DXF_X6_WS = {}
+# AA_CONV_DX_X6=0: keep the gather-form conv input gradient on the fp32 MFMA kernel (A/B)
+CONV_DX_X6 = _os.environ.get("AA_CONV_DX_X6", "1") != "0"
 
 
 def _dxf_desc(x_shape, w_shape, stride, dz=None, w=None, mask_src=None, mask_act=None, out=None):
@@ -424,8 +427,22 @@ def conv_dx_frame(dz, w, x_shape, stride, out, mask_src=None, mask_act=None):
     if dz.numel() != Bn * OH * OW * Cout or out.numel() != Bn * H * W * C or Cin != C:
         raise ValueError("conv_dx_frame: bad sizes")
     d = _dxf_desc(x_shape, w.shape, stride, dz, w, mask_src, mask_act, out)
+    lib = _lib.load()
     with torch.cuda.device(dz.device):
-        check(_lib.load().aa_conv_dx_frame(ctypes.byref(d), stream_ptr()), "aa_conv_dx_frame")
+        key = (tuple(x_shape), tuple(w.shape), stride)
+        ws_bytes = _DXF_X6_WS.get(key)
+        if ws_bytes is None:
+            ws_bytes = int(lib.aa_conv_dx_frame_x6_workspace_bytes(ctypes.byref(d))) \
+                if CONV_DX_X6 else 0
+            _DXF_X6_WS[key] = ws_bytes
+        if ws_bytes > 0:
+            # bf16 matrix cores, fp32 accuracy (csrc/conv_dx_frame_x6.hip); split filter planes in
+            # the calling stream's scratch
+            ws = _WS3.get(ws_bytes, dz.device)
+            check(lib.aa_conv_dx_frame_x6(ctypes.byref(d), ptr(ws), ws.numel(), stream_ptr()),
+                  "aa_conv_dx_frame_x6")
+        else:
+            check(lib.aa_conv_dx_frame(ctypes.byref(d), stream_ptr()), "aa_conv_dx_frame")
     return out
 
 

@@ -213,6 +213,16 @@ typedef struct aa_conv_dx_desc {
 int aa_conv_dx_frame_supported(const aa_conv_dx_desc* d);
 int aa_conv_dx_frame(const aa_conv_dx_desc* d, void* stream);
 
+/* The same gradient on the bf16 matrix cores at fp32 accuracy (csrc/conv_dx_frame_x6.hip): dZ is
+ * split exactly into three bf16 pieces while it is staged into LDS, the filters by a pre-pass of
+ * this call into `workspace` (which also receives the per-class k-step tables); six of the nine
+ * piece products are accumulated in fp32.  Limits: Cin % 16 == 0, Cout a power of two >= 32,
+ * stride <= 4, largest sub-pixel class <= 128 pixels, padded dZ planes <= 160 KiB of LDS
+ * (aa_conv_dx_frame_x6_workspace_bytes returns 0 when a shape does not qualify). */
+int64_t aa_conv_dx_frame_x6_workspace_bytes(const aa_conv_dx_desc* d);
+int aa_conv_dx_frame_x6(const aa_conv_dx_desc* d, void* workspace, int64_t workspace_bytes,
+                        void* stream);
+
 /* out[n] = sum_m x[m*ld + n]  (bias gradients).  workspace >= aa_colsum_workspace_bytes. */
 int64_t aa_colsum_workspace_bytes(int64_t M, int64_t N);
 int aa_colsum_f32(const float* x, int64_t ld, int64_t M, int64_t N, float* out, void* workspace,

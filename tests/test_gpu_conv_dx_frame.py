@@ -45,9 +45,48 @@ CASES = [  # (B, H, W, Cin, KH, KW, stride, Cout)
 ]
 
 
+@pytest.fixture(params=[True, False], ids=["bf16x6", "fp32mfma"])
+def x6(request):
+    """Both implementations: csrc/conv_dx_frame_x6.hip (default where the shape fits) and
+    csrc/conv_dx_frame.hip."""
+    prev = ops.CONV_DX_X6
+    ops.CONV_DX_X6 = request.param
+    ops._DXF_X6_WS.clear()
+    yield request.param
+    ops.CONV_DX_X6 = prev
+    ops._DXF_X6_WS.clear()
+
+
+def test_atari_shapes_take_the_bf16_kernel(dev):
+    import ctypes
+    from agents_amd import _lib
+    lib = _lib.load()
+    for x_shape, w_shape, s in (((256, 20, 20, 32), (4, 4, 32, 64), 2),
+                                ((256, 9, 9, 64), (3, 3, 64, 64), 1)):
+        d = ops._dxf_desc(x_shape, w_shape, s)
+        assert lib.aa_conv_dx_frame_x6_workspace_bytes(ctypes.byref(d)) > 0
+    assert ops.CONV_DX_X6
+
+
+def test_conv_dx_x6_exact_on_bf16_representable_operands(dev):
+    """Small-integer operands are single bf16 pieces and every partial sum is exact in fp32: the
+    kernel must reproduce float64 bit for bit (any fragment / K-order mismatch shows)."""
+    rng = np.random.default_rng(3)
+    for (B, H, W, C, KH, KW, s, Fo) in CASES[:4]:
+        w = torch.from_numpy(rng.integers(-3, 4, (KH, KW, C, Fo)).astype(np.float32))
+        OH, OW = ops.conv_out_hw(H, W, KH, KW, s)
+        dz = torch.from_numpy(rng.integers(-4, 5, (B, OH, OW, Fo)).astype(np.float32))
+        out = torch.full((B, H, W, C), float("nan"), device=dev)
+        ops.conv_dx_frame(dz.to(dev).view(-1, Fo), w.to(dev), (B, H, W, C), s, out)
+        xd = torch.zeros(B, H, W, C, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(xd.permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), None, stride=s)
+        g, = torch.autograd.grad(y, xd, dz.double().permute(0, 3, 1, 2))
+        assert torch.equal(out.cpu().double(), g)
+
+
 @pytest.mark.parametrize("cfg", CASES)
 @pytest.mark.parametrize("act", [None, "relu", "tanh"])
-def test_conv_dx_frame(dev, cfg, act):
+def test_conv_dx_frame(dev, cfg, act, x6):
     B, H, W, C, KH, KW, s, Fo = cfg
     rng = np.random.default_rng(sum(cfg))
     x = torch.tanh(rnd(rng, B, H, W, C))           # a plausible activation output (mask source)
