@@ -12,15 +12,24 @@
 // data spec, capacity = batch_size * max_length; env b owns rows [b*L, (b+1)*L).  A parallel
 // int64 id table [capacity] and one int64 `last_id` word live next to them.
 //
-// Design: one launch moves ALL leaves.  grid = n_rows * n_chunks, a workgroup owns one
-// (row, 8 KiB chunk); every lane moves 16-byte vectors (global_load_dwordx4 /
-// global_store_dwordx4, both loads of the chunk issued before the stores) so a wave
-// instruction covers 1 KiB of a row.  Narrow leaves (scalars) ride in the chunk-0 workgroup.
+// Design: one launch moves ALL leaves -- and, for get_next, also DRAWS the rows (every workgroup
+// recomputes its sample's Philox draw: 10 rounds of integer arithmetic against a 28 KB row copy)
+// and advances the device-resident call counter / last_id itself, so add_batch and get_next are
+// ONE launch each (they were 2 and 2-3: a 256-thread sampling launch, the copy, a 1-thread counter
+// bump).  grid = n_rows * n_chunks, a workgroup owns one (row, 32 KiB chunk): an Atari row
+// (28,248 B) is one workgroup whose lanes each have up to EIGHT 16-byte loads in flight before the
+// first store (2 before: the copies ran at 1.7-1.9 TB/s, bound by bytes in flight per CU, not by
+// HBM).  A wave instruction covers 1 KiB of a row.  Table-side accesses are non-temporal (a 28 GB
+// table is streamed, never re-read soon); the batch side stays cacheable (conv1 reads it next).
+// Narrow leaves (scalars) ride in the chunk-0 workgroup.
 #include "common.h"
 
 #define AA_MAX_LEAVES 24
-#define AA_RB_CHUNK 8192  // bytes of one row handled per workgroup per leaf
+#define AA_RB_CHUNK 32768  // bytes of one row handled per workgroup per leaf
 #define AA_RB_THREADS 256
+#define AA_RB_INFLIGHT 8   // vectors per lane loaded before the first store
+#define AA_RB_ARRIVAL_STRIDE 16  // int64 words between arrival counters: one 128-byte line each
+#define AA_RB_ARRIVAL_WORDS (9 * AA_RB_ARRIVAL_STRIDE)   // 8 shards + 1 top
 
 struct AaLeafSet {
   int n;
@@ -29,25 +38,37 @@ struct AaLeafSet {
   int64_t row_bytes[AA_MAX_LEAVES];
 };
 
-template <typename V>
+// NT_SRC / NT_DST: the table side of the copy is streamed with non-temporal accesses
+template <typename V, bool NT_SRC, bool NT_DST>
 __device__ static inline void aa_copy_span(const char* __restrict__ src, char* __restrict__ dst,
                                            int64_t len) {
-  // len bytes, multiple of sizeof(V); src/dst aligned to sizeof(V).  At most
-  // AA_RB_CHUNK bytes, i.e. <= 2 vectors per lane at V = 16 B: issue both loads first.
-  const int64_t n = len / (int64_t)sizeof(V);
+  // len bytes (<= AA_RB_CHUNK), multiple of sizeof(V); src/dst aligned to sizeof(V).  All loads of
+  // a pass are issued before its stores.
+  const int n = (int)(len / (int64_t)sizeof(V));
   const V* s = reinterpret_cast<const V*>(src);
   V* d = reinterpret_cast<V*>(dst);
-  for (int64_t i = threadIdx.x; i < n; i += 2 * AA_RB_THREADS) {
-    const int64_t j = i + AA_RB_THREADS;
-    V a = s[i];
-    V b;
-    const bool hb = j < n;
-    if (hb) b = s[j];
-    d[i] = a;
-    if (hb) d[j] = b;
+  for (int base = threadIdx.x; base < n; base += AA_RB_INFLIGHT * AA_RB_THREADS) {
+    V v[AA_RB_INFLIGHT];
+#pragma unroll
+    for (int u = 0; u < AA_RB_INFLIGHT; ++u) {
+      const int i = base + u * AA_RB_THREADS;
+      if (i < n) v[u] = NT_SRC ? __builtin_nontemporal_load(s + i) : s[i];
+    }
+#pragma unroll
+    for (int u = 0; u < AA_RB_INFLIGHT; ++u) {
+      const int i = base + u * AA_RB_THREADS;
+      if (i < n) {
+        if (NT_DST) __builtin_nontemporal_store(v[u], d + i);
+        else d[i] = v[u];
+      }
+    }
   }
 }
 
+typedef unsigned int aa_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int aa_u32x2 __attribute__((ext_vector_type(2)));
+
+template <bool NT_SRC, bool NT_DST>
 __device__ static inline void aa_copy_row_chunk(const char* src, char* dst, int64_t row_bytes,
                                                 int chunk) {
   const int64_t off = (int64_t)chunk * AA_RB_CHUNK;
@@ -58,13 +79,43 @@ __device__ static inline void aa_copy_row_chunk(const char* src, char* dst, int6
   dst += off;
   const uintptr_t al = (uintptr_t)src | (uintptr_t)dst | (uintptr_t)len;
   if ((al & 15) == 0) {
-    aa_copy_span<uint4>(src, dst, len);
+    aa_copy_span<aa_u32x4, NT_SRC, NT_DST>(src, dst, len);
   } else if ((al & 7) == 0) {
-    aa_copy_span<uint2>(src, dst, len);
+    aa_copy_span<aa_u32x2, NT_SRC, NT_DST>(src, dst, len);
   } else if ((al & 3) == 0) {
-    aa_copy_span<uint32_t>(src, dst, len);
+    aa_copy_span<uint32_t, NT_SRC, NT_DST>(src, dst, len);
   } else {
-    aa_copy_span<uint8_t>(src, dst, len);
+    aa_copy_span<uint8_t, NT_SRC, NT_DST>(src, dst, len);
+  }
+}
+
+// aa_advance_when_all_done (common.h) for grids of hundreds to thousands of workgroups: arrivals
+// are counted on 8 words (blockIdx & 7 -- one per XCD under the usual round-robin placement), the
+// last arriver of each shard reports to a ninth: no word sees more than n/8 (+8) atomics, where
+// one word serialised ~2,000 of them at ~11 ns each.  The nine words sit on nine different
+// 128-byte lines (atomics on one line serialise in its L2 channel whatever the word) and are zero
+// between launches.
+__device__ static inline void aa_advance_sharded(int64_t* counter, int64_t* arrival, int64_t inc,
+                                                 unsigned n_groups) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned k = blockIdx.x & 7u;
+    const unsigned long long in_shard = (n_groups + 7u - k) >> 3;
+    unsigned long long* a = reinterpret_cast<unsigned long long*>(arrival);
+    unsigned long long* mine = a + k * AA_RB_ARRIVAL_STRIDE;
+    unsigned long long* top = a + 8 * AA_RB_ARRIVAL_STRIDE;
+    const unsigned long long prev =
+        __hip_atomic_fetch_add(mine, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == in_shard - 1ull) {
+      __hip_atomic_store(mine, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long n_shards = n_groups < 8u ? n_groups : 8u;
+      const unsigned long long p2 =
+          __hip_atomic_fetch_add(top, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (p2 == n_shards - 1ull) {
+        __hip_atomic_store(top, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *counter += inc;
+      }
+    }
   }
 }
 
@@ -79,10 +130,10 @@ aa_rb_scatter_kernel(AaLeafSet leaves, int64_t* __restrict__ id_table, int64_t* 
   const int64_t row = b * max_len + (id % max_len);
   for (int l = 0; l < leaves.n; ++l) {
     const int64_t rb = leaves.row_bytes[l];
-    aa_copy_row_chunk(leaves.io[l] + b * rb, leaves.table[l] + row * rb, rb, chunk);
+    aa_copy_row_chunk<false, true>(leaves.io[l] + b * rb, leaves.table[l] + row * rb, rb, chunk);
   }
   if (chunk == 0 && threadIdx.x == 0) id_table[row] = id;
-  if (arrival != nullptr) aa_advance_when_all_done(last_id, arrival, 1, gridDim.x);
+  if (arrival != nullptr) aa_advance_sharded(last_id, arrival, 1, gridDim.x);
 }
 
 __global__ void aa_rb_bump_kernel(int64_t* last_id, int64_t inc) {
@@ -99,7 +150,7 @@ aa_rb_gather_kernel(AaLeafSet leaves, const int64_t* __restrict__ id_table,
   const int64_t row = rows[r];
   for (int l = 0; l < leaves.n; ++l) {
     const int64_t rb = leaves.row_bytes[l];
-    aa_copy_row_chunk(leaves.table[l] + row * rb, leaves.io[l] + r * rb, rb, chunk);
+    aa_copy_row_chunk<true, false>(leaves.table[l] + row * rb, leaves.io[l] + r * rb, rb, chunk);
   }
   if (chunk == 0 && threadIdx.x == 0 && ids_out != nullptr) ids_out[r] = id_table[row];
 }
@@ -112,7 +163,7 @@ aa_rb_write_kernel(AaLeafSet leaves, const int64_t* __restrict__ rows, int n_chu
   const int64_t row = rows[r];
   for (int l = 0; l < leaves.n; ++l) {
     const int64_t rb = leaves.row_bytes[l];
-    aa_copy_row_chunk(leaves.io[l] + r * rb, leaves.table[l] + row * rb, rb, chunk);
+    aa_copy_row_chunk<false, true>(leaves.io[l] + r * rb, leaves.table[l] + row * rb, rb, chunk);
   }
 }
 
@@ -122,6 +173,31 @@ aa_rb_write_kernel(AaLeafSet leaves, const int64_t* __restrict__ rows, int n_chu
 //   id   = min_id + ((x1<<32 | x0) mod (max_id - min_id))     -- TF-style modulo map, no rejection
 //   seg  =           (x3<<32 | x2) mod batch
 //   rows[s,t] = (id + t) mod L + seg*L ;  prob = 1 / float32((max_id-min_id)*batch)
+// One sample's draw: start id, env block and probability; false when the buffer has no valid id.
+__device__ static inline bool aa_rb_draw(int64_t last_id, int64_t batch, int64_t max_len, int64_t T,
+                                         int64_t s, uint64_t call, uint32_t k0, uint32_t k1,
+                                         int64_t* id, int64_t* seg, float* prob) {
+  int64_t min_id, max_id;
+  if (last_id < max_len) {
+    min_id = 0;
+    max_id = last_id + 1 - T + 1;
+    if (max_id < 0) max_id = 0;
+  } else {
+    min_id = last_id + 1 - max_len;
+    max_id = last_id + 1 - T + 1;
+  }
+  const int64_t num_ids = max_id - min_id;
+  if (num_ids <= 0) return false;
+  const Philox4 r = philox4x32_10((uint32_t)s, (uint32_t)((uint64_t)s >> 32), (uint32_t)call,
+                                  (uint32_t)(call >> 32), k0, k1);
+  const uint64_t a = ((uint64_t)r.y << 32) | r.x;
+  const uint64_t c = ((uint64_t)r.w << 32) | r.z;
+  *id = min_id + (int64_t)(a % (uint64_t)num_ids);
+  *seg = (int64_t)(c % (uint64_t)batch);
+  *prob = 1.0f / (float)(num_ids * batch);
+  return true;
+}
+
 __global__ void aa_rb_sample_kernel(const int64_t* __restrict__ last_id_p, int64_t batch,
                                     int64_t max_len, int64_t S, int64_t T, uint32_t k0,
                                     uint32_t k1, uint64_t call,
@@ -136,31 +212,46 @@ __global__ void aa_rb_sample_kernel(const int64_t* __restrict__ last_id_p, int64
     if (threadIdx.x == 0) *call_dev += 1;
   }
   if (s >= S) return;
-  const int64_t last_id = *last_id_p;
-  int64_t min_id, max_id;
-  if (last_id < max_len) {
-    min_id = 0;
-    max_id = last_id + 1 - T + 1;
-    if (max_id < 0) max_id = 0;
-  } else {
-    min_id = last_id + 1 - max_len;
-    max_id = last_id + 1 - T + 1;
-  }
-  const int64_t num_ids = max_id - min_id;
-  if (num_ids <= 0) {
+  int64_t id, seg;
+  float prob;
+  if (!aa_rb_draw(*last_id_p, batch, max_len, T, s, call, k0, k1, &id, &seg, &prob)) {
     if (s == 0 && err != nullptr) *err = 1;
     for (int64_t t = 0; t < T; ++t) rows[s * T + t] = 0;
     if (probs) probs[s] = 0.f;
     return;
   }
-  const Philox4 r = philox4x32_10((uint32_t)s, (uint32_t)((uint64_t)s >> 32), (uint32_t)call,
-                                  (uint32_t)(call >> 32), k0, k1);
-  const uint64_t a = ((uint64_t)r.y << 32) | r.x;
-  const uint64_t c = ((uint64_t)r.w << 32) | r.z;
-  const int64_t id = min_id + (int64_t)(a % (uint64_t)num_ids);
-  const int64_t seg = (int64_t)(c % (uint64_t)batch);
   for (int64_t t = 0; t < T; ++t) rows[s * T + t] = (id + t) % max_len + seg * max_len;
-  if (probs) probs[s] = 1.0f / (float)(num_ids * batch);
+  if (probs) probs[s] = prob;
+}
+
+// ---- get_next in ONE launch: workgroup (r = s*T + t, chunk) draws sample s itself, copies row
+// (id + t) mod L + seg*L of every leaf, and the last workgroup to finish advances the call
+// counter (every workgroup has read it by then) ---------------------------------------------------
+__global__ void __launch_bounds__(AA_RB_THREADS)
+aa_rb_sample_gather_kernel(AaLeafSet leaves, const int64_t* __restrict__ id_table,
+                           int64_t* __restrict__ ids_out, float* __restrict__ probs,
+                           const int64_t* __restrict__ last_id_p, int64_t batch, int64_t max_len,
+                           int64_t T, uint32_t k0, uint32_t k1, uint64_t call,
+                           int64_t* call_dev, int64_t* arrival, int* __restrict__ err,
+                           int n_chunks) {
+  const int64_t r = blockIdx.x / n_chunks;
+  const int chunk = blockIdx.x % n_chunks;
+  const int64_t s = r / T, t = r - s * T;
+  if (call_dev != nullptr) call += (uint64_t)*call_dev;
+  int64_t id = 0, seg = 0;
+  float prob = 0.f;
+  const bool ok = aa_rb_draw(*last_id_p, batch, max_len, T, s, call, k0, k1, &id, &seg, &prob);
+  const int64_t row = ok ? (id + t) % max_len + seg * max_len : 0;
+  for (int l = 0; l < leaves.n; ++l) {
+    const int64_t rb = leaves.row_bytes[l];
+    aa_copy_row_chunk<true, false>(leaves.table[l] + row * rb, leaves.io[l] + r * rb, rb, chunk);
+  }
+  if (chunk == 0 && threadIdx.x == 0) {
+    if (ids_out != nullptr) ids_out[r] = id_table[row];
+    if (t == 0 && probs != nullptr) probs[s] = prob;
+    if (!ok && r == 0 && err != nullptr) *err = 1;
+  }
+  if (call_dev != nullptr) aa_advance_sharded(call_dev, arrival, 1, gridDim.x);
 }
 
 // rows[b, i] = (start_id + i) mod L + b*L   (gather_all and deterministic passes)
@@ -207,9 +298,8 @@ int aa_rb_scatter_rows(void* const* leaf_tables_h, const void* const* leaf_items
   const int64_t grid = batch * n_chunks;
   if (grid > 0x7fffffffLL) return AA_ERR_RANGE;
   hipStream_t st = (hipStream_t)stream;
-  // in-kernel advance only for small grids: thousands of workgroups hitting one arrival word with
-  // device-scope atomics serialise (measured +26 us on the 1,024-group Atari scatter)
-  int64_t* arrival = (arrival_dev != nullptr && grid <= AA_MAX_ARRIVAL_GROUPS) ? arrival_dev : nullptr;
+  // last_id advances inside the launch (sharded arrival counters: AA_RB_ARRIVAL_WORDS = 144 zero words)
+  int64_t* arrival = arrival_dev;
   hipLaunchKernelGGL(aa_rb_scatter_kernel, dim3((unsigned)grid), dim3(AA_RB_THREADS), 0, st, ls,
                      id_table, last_id_dev, arrival, max_len, n_chunks);
   if (arrival == nullptr)
@@ -235,6 +325,32 @@ int aa_rb_sample_rows(const int64_t* last_id_dev, int64_t batch, int64_t max_len
   if (call_counter_dev != nullptr && grid != 1)
     hipLaunchKernelGGL(aa_rb_bump_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
                        call_counter_dev, (int64_t)1);
+  return aa_launch_status();
+}
+
+int aa_rb_sample_gather(const void* const* leaf_tables_h, void* const* leaf_out_h,
+                        const int64_t* leaf_row_bytes_h, int n_leaves, const int64_t* id_table,
+                        int64_t* ids_out, float* prob_out, const int64_t* last_id_dev,
+                        int64_t batch, int64_t max_len, int64_t S, int64_t T, uint64_t seed,
+                        uint64_t call_counter, int64_t* call_counter_dev, int64_t* arrival_dev,
+                        int* err_flag_dev, void* stream) {
+  if (S <= 0 || T <= 0 || batch <= 0 || max_len <= 0 || last_id_dev == nullptr)
+    return AA_ERR_INVALID;
+  if (call_counter_dev != nullptr && arrival_dev == nullptr) return AA_ERR_INVALID;
+  if (ids_out != nullptr && id_table == nullptr) return AA_ERR_INVALID;
+  AaLeafSet ls;
+  int64_t max_rb = 0;
+  int rc = aa_fill_leaves(ls, (void* const*)leaf_tables_h, leaf_out_h, leaf_row_bytes_h,
+                          n_leaves, &max_rb);
+  if (rc != AA_OK) return rc;
+  int n_chunks = (int)((max_rb + AA_RB_CHUNK - 1) / AA_RB_CHUNK);
+  if (n_chunks < 1) n_chunks = 1;
+  const int64_t grid = S * T * n_chunks;
+  if (grid > 0x7fffffffLL) return AA_ERR_RANGE;
+  hipLaunchKernelGGL(aa_rb_sample_gather_kernel, dim3((unsigned)grid), dim3(AA_RB_THREADS), 0,
+                     (hipStream_t)stream, ls, id_table, ids_out, prob_out, last_id_dev, batch,
+                     max_len, T, (uint32_t)seed, (uint32_t)(seed >> 32), call_counter,
+                     call_counter_dev, arrival_dev, err_flag_dev, n_chunks);
   return aa_launch_status();
 }
 

@@ -5,7 +5,8 @@ methods, layout (B blocks of L frames, one shared `last_id`), valid-id ranges, B
 every data-path operation a HIP kernel from csrc/replay.hip:
 
   add_batch   -> aa_rb_scatter_rows   (all leaves + id table in one launch, then last_id += 1)
-  get_next    -> aa_rb_sample_rows    (Philox4x32-10 ids/blocks -> rows, probabilities)
+  get_next    -> aa_rb_sample_gather  (Philox4x32-10 ids/blocks -> rows, probabilities, row
+                                       gather of every leaf, call counter: one launch)
                  aa_rb_gather_rows    (all leaves + ids in one launch)
   gather_all  -> aa_rb_range_rows + aa_rb_gather_rows
 
@@ -77,9 +78,10 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
         self._id_spec = tensor_spec.TensorSpec((), torch.int64, name="id")
         self._data_table = table_fn(self._data_spec, capacity, device=self._device)
         self._id_table = table_fn(self._id_spec, capacity, device=self._device)
-        # [last_id, arrival count of the scatter kernel's workgroups]; `_last_id` is the public word
-        self._last_id_store = torch.tensor([-1, 0], dtype=torch.int64).to(self._device)
-        self._last_id = self._last_id_store[:1]
+        self._last_id = torch.full((1,), -1, dtype=torch.int64, device=self._device)
+        # arrival counters of the scatter / sample-and-gather launches (9 x one 128-byte line each)
+        self._scatter_arrival = torch.zeros((144,), dtype=torch.int64, device=self._device)
+        self._sample_arrival = torch.zeros((144,), dtype=torch.int64, device=self._device)
         self._err_flag = torch.zeros((1,), dtype=torch.int32, device=self._device)
         self._last_id_host = -1          # mirror: every add_batch is +1, clear() is -> -1
         self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -124,7 +126,7 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
         with torch.cuda.device(self._device):
             _lib.check(lib.aa_rb_scatter_rows(
                 p.tables, p.ios, p.row_bytes, p.n, self._id_table.variables()[0].data_ptr(),
-                self._last_id.data_ptr(), self._last_id_store[1:].data_ptr(), self._batch_size,
+                self._last_id.data_ptr(), self._scatter_arrival.data_ptr(), self._batch_size,
                 self._max_length, _lib.stream_ptr()),
                 "aa_rb_scatter_rows")
         graph.on_replay(self._bump_last_id_host)
@@ -160,9 +162,25 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
         S = 1 if sample_batch_size is None else int(sample_batch_size)
         T = 1 if num_steps is None else int(num_steps)
         with torch.cuda.device(self._device):
-            rows, probs = self._sample_rows(S, T)
-            ids = torch.empty((S, T), dtype=torch.int64, device=self._device)
-            data = self._data_table.read(rows, self._id_table.variables()[0], ids)
+            if type(self)._sample_rows is TFUniformReplayBuffer._sample_rows:
+                # draw + gather + counter advance in ONE launch (csrc/replay.hip)
+                lib = _lib.load()
+                ids = torch.empty((S, T), dtype=torch.int64, device=self._device)
+                probs = torch.empty((S,), dtype=torch.float32, device=self._device)
+                outs = self._data_table.alloc_out((S, T))
+                p = self._data_table.pack(outs)
+                _lib.check(lib.aa_rb_sample_gather(
+                    p.tables, p.ios, p.row_bytes, p.n, self._id_table.variables()[0].data_ptr(),
+                    ids.data_ptr(), probs.data_ptr(), self._last_id.data_ptr(), self._batch_size,
+                    self._max_length, S, T, self._seed, 0, self._sample_calls_dev.data_ptr(),
+                    self._sample_arrival.data_ptr(), self._err_flag.data_ptr(),
+                    _lib.stream_ptr()), "aa_rb_sample_gather")
+                graph.on_replay(self._bump_sample_calls)
+                data = nest_utils.pack_sequence_as(self._data_spec, outs)
+            else:       # a subclass with its own index sampler (prioritized replay)
+                rows, probs = self._sample_rows(S, T)
+                ids = torch.empty((S, T), dtype=torch.int64, device=self._device)
+                data = self._data_table.read(rows, self._id_table.variables()[0], ids)
 
         def squeeze(t):
             if num_steps is None:

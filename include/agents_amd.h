@@ -43,13 +43,15 @@ int aa_rb_scatter_rows(void* const* leaf_tables_h, const void* const* leaf_items
                        const int64_t* leaf_row_bytes_h, int n_leaves, int64_t* id_table,
                        int64_t* last_id_dev, int64_t* arrival_dev /* nullable, see below */,
                        int64_t batch, int64_t max_len, void* stream);
-/* `arrival_dev` (here and in aa_eps_greedy_action / aa_vecenv_random_step): one int64 word, zero
- * before the call and left zero, in which the kernel counts finished workgroups so that the LAST
- * one advances the counter every group has read (last_id, Philox call counter, env step counter)
- * -- no second one-thread launch.  Used for launches of at most 16 workgroups (device-scope
- * atomics on one word from thousands of groups serialise); larger launches, and NULL for the
- * replay scatter, get the one-thread bump launch from the entry point.  With NULL,
- * aa_eps_greedy_action / aa_vecenv_random_step leave the counter alone (caller: aa_counter_add). */
+/* `arrival_dev`: zero before the call and left zero; the kernel counts finished workgroups in it
+ * so that the LAST one advances the counter every group has read (last_id, Philox call counter,
+ * env step counter) -- no second one-thread launch.
+ *   aa_eps_greedy_action / aa_vecenv_random_step: ONE int64 word, used for launches of at most 16
+ *     workgroups (NULL or larger: the counter is left alone, caller: aa_counter_add);
+ *   aa_rb_scatter_rows / aa_rb_sample_gather: 144 int64 words, 128-byte aligned = nine counters
+ *     on nine cache lines (arrivals sharded over eight by workgroup index, their last arrivers
+ *     meet on the ninth: thousands of device-scope atomics on one word -- or one line --
+ *     serialise); NULL for the scatter = a one-thread bump launch from the entry point. */
 
 /* get_next index sampling: S independent (start id, env block) pairs from the Philox4x32-10
  * stream (counter = (s, call_counter), key = seed), mapped with _valid_range_ids
@@ -62,6 +64,19 @@ int aa_rb_sample_rows(const int64_t* last_id_dev, int64_t batch, int64_t max_len
                       call_counter and then incremented by one on the device, so a captured HIP
                       graph advances the stream without new kernel arguments */,
                       int64_t* rows_out, float* prob_out, int* err_flag_dev, void* stream);
+
+/* get_next in ONE launch: the draw of aa_rb_sample_rows (same Philox stream, same mapping, bit for
+ * bit) is recomputed by every workgroup of sample s, which then copies row (id+t) mod L + block*L
+ * of every leaf into out[s*T + t]; ids_out[s*T+t] = id_table[row] (nullable), prob_out[s]
+ * (nullable); the last workgroup advances *call_counter_dev (nullable: then `call_counter` alone
+ * numbers the call).  Replaces aa_rb_sample_rows + aa_rb_gather_rows (+ the counter bump) on the
+ * get_next path (tf_uniform_replay_buffer.py:211-310, table.py:86-110). */
+int aa_rb_sample_gather(const void* const* leaf_tables_h, void* const* leaf_out_h,
+                        const int64_t* leaf_row_bytes_h, int n_leaves, const int64_t* id_table,
+                        int64_t* ids_out, float* prob_out, const int64_t* last_id_dev,
+                        int64_t batch, int64_t max_len, int64_t S, int64_t T, uint64_t seed,
+                        uint64_t call_counter, int64_t* call_counter_dev, int64_t* arrival_dev,
+                        int* err_flag_dev, void* stream);
 
 /* Row gather of every leaf + the id table: out[r] = table[rows[r]].
  * Replaces Table.read / ResourceVariable.sparse_read per leaf (table.py:86-110). */

@@ -9,13 +9,17 @@ Three stacks run side by side on identical seeds:
   graphed  what bench.py times: the collect / sample / train HIP graphs on three streams
            (`graph.enable_overlap`), train graphs bound to the sampler's ring slots
 Checks, per iteration: sampled rows and ids eager == oracle bit for bit; loss eager vs oracle to
-1e-5 relative and the parameters after the step to 5e-5 x max|p| (dqn_agent.py:412-449 restated
-in oracle/dqn.py), BOTH taken from the same pre-step parameters -- the oracle's parameters are
-reset to the GPU's before every step, because a free-running pair drifts apart chaotically (ReLU
-boundaries amplify last-bit differences of the fp32 sums: measured 4e-5 on the loss after 13
-steps), which says nothing about either implementation; graphed == eager bit for bit (parameters,
+1e-5 relative, gradients and the parameters after the step per tensor (median over the steps at
+fp32 rounding, maximum at the size of a ReLU boundary flip: see TOL_*; dqn_agent.py:412-449 restated
+in oracle/dqn.py), BOTH taken from the same pre-step parameters and optimizer slots -- the
+oracle's are reset to the GPU's before every step, because a free-running pair drifts apart
+chaotically (ReLU boundaries amplify last-bit differences of the fp32 sums: measured 4e-5 on the
+loss after 13 steps; the momentum slot carries the history into every later "one step"), which
+says nothing about either implementation; graphed == eager bit for bit (parameters,
 loss, replay tables).  At the end: replay tables eager == oracle == graphed.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -33,7 +37,17 @@ pytestmark = pytest.mark.gpu
 B_ENV, L_RING, S, ITERS = 256, 8, 256, 24
 # Parameters after ONE optimizer step from identical parameters, relative to max|p| of the tensor
 # (the tolerance of tests/test_gpu_dqn_agent.py's Atari case).
-TOL_PARAM = 5e-5
+# Per-tensor bounds.  Two implementations of a ReLU network cannot agree element for element at every
+# step: a pre-activation within an ulp of zero lands on different sides of the ReLU (conv1 computes
+# (sum u8 w) / 255 where the oracle sums (u8 / 255) w; the MFMA tiles add in another order than
+# torch-CPU), and then a whole dZ element appears in / vanishes from that layer's weight gradient
+# and everything upstream of it.  Measured on MI355X over 24 steps, identically with the fp32-MFMA
+# and the bf16x6 kernels: relative L2 error of a gradient tensor 2e-7 ... 1e-6 at almost every
+# step, with isolated spikes of 1e-5 ... 7e-4 on single tensors.  So the MEDIAN over the steps is
+# held to fp32 rounding (a systematic error would sit in every step) and the maximum to the size
+# of a boundary flip.
+TOL_GRAD_MEDIAN, TOL_GRAD_MAX = 2e-6, 3e-3        # relative L2 per gradient tensor
+TOL_PARAM_MEDIAN, TOL_PARAM_MAX = 2e-6, 5e-4      # one optimizer step, relative to max|p|
 
 
 def _stack(dev, eager):
@@ -78,7 +92,8 @@ def test_bench_configuration_matches_oracle_and_eager(dev):
         try:
             q = []
             ts_e = ts_g = None
-            max_loss_rel = worst = 0.0
+            max_loss_rel = worst = worst_g = worst_l2 = 0.0
+            g_err, p_err = {}, {}
             for i in range(ITERS):
                 # eager + oracle
                 ts_e, _ = w_e["collect_driver"].run(ts_e)
@@ -89,21 +104,43 @@ def test_bench_configuration_matches_oracle_and_eager(dev):
                     assert np.array_equal(g_leaf.cpu().numpy(), o_leaf), f"rows differ, step {i}"
                 assert np.array_equal(info_e.ids.cpu().numpy(), oids)
                 assert np.array_equal(info_e.probabilities.cpu().numpy(), oprobs)
-                with torch.no_grad():       # same pre-step parameters on both sides
+                with torch.no_grad():       # same pre-step parameters AND optimizer slots
                     for ov, a in zip(oagent.params, net_e.get_weights()):
                         ov.copy_(torch.from_numpy(np.asarray(a)))
+                    slots = w_e["agent"]._optimizer._slots.get(net_e.flat_params.data_ptr())
+                    if slots is not None and oagent.opt.ms is not None:
+                        for k, (s0, s1) in enumerate(net_e.segment_offsets()):
+                            for mine, theirs in ((oagent.opt.ms, "ms"), (oagent.opt.mg, "mg"),
+                                                 (oagent.opt.mo, "mom")):
+                                mine[k].copy_(slots[theirs][s0:s1].cpu().view(mine[k].shape))
                 li_e = w_e["agent"].train(exp_e)
                 o_st, o_obs, o_act, o_nst, o_rew, o_disc = odata
-                ototal, aux, _ = oagent.train(torch.from_numpy(o_obs), o_act, o_rew, o_disc, o_st)
+                ototal, aux, ograds = oagent.train(torch.from_numpy(o_obs), o_act, o_rew, o_disc,
+                                                   o_st)
+                for k, (g, og) in enumerate(zip(net_e.gradients, ograds)):
+                    gc = g.cpu().double()
+                    gerr = float((gc - og.double()).norm() / max(float(og.double().norm()), 1e-30))
+                    worst_g = max(worst_g, gerr)
+                    if os.environ.get("AA_TEST_VERBOSE"):
+                        mx = float((gc - og.double()).abs().max() / og.double().abs().max())
+                        print(f"step {i} grad {k} {tuple(g.shape)}: relL2 {gerr:.2e} max {mx:.2e} "
+                              f"|g| {float(og.double().norm()):.3e}")
+                    g_err.setdefault(k, []).append(gerr)
+                    assert gerr <= TOL_GRAD_MAX, f"gradient {k} mismatch {gerr:.2e} at step {i}"
                 got, want = float(li_e.loss), float(ototal)
                 np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-7,
                                            err_msg=f"loss at step {i}")
                 max_loss_rel = max(max_loss_rel, abs(got - want) / max(abs(want), 1e-12))
-                for v, ov in zip(net_e.variables, oagent.params):
+                for k, (v, ov) in enumerate(zip(net_e.variables, oagent.params)):
                     scale = max(float(ov.detach().abs().max()), 1e-12)
+                    pdelta = (v.cpu().double() - ov.detach().double())
+                    worst_l2 = max(worst_l2, float(pdelta.norm() / ov.detach().double().norm()))
                     err = float((v.cpu() - ov.detach()).abs().max()) / scale
                     worst = max(worst, err)
-                    assert err <= TOL_PARAM, f"param mismatch {err:.2e} after step {i}"
+                    p_err.setdefault(k, []).append(err)
+                    assert err <= TOL_PARAM_MAX, \
+                        f"param {k} {tuple(v.shape)} mismatch {err:.2e} (scale {scale:.2e}) " \
+                        f"after step {i}; worst gradient err so far {worst_g:.2e}"
                 # graphed (the timed configuration)
                 ts_g, _ = run_g(ts_g)
                 li_g = w_g["learner"].run(iterations=1, iterator=it_g)
@@ -129,5 +166,12 @@ def test_bench_configuration_matches_oracle_and_eager(dev):
             got = tab.cpu().numpy().reshape(-1)
             assert np.array_equal(got.view(np.uint8), otab.reshape(-1).view(np.uint8))
         assert np.array_equal(rb_e._id_table.variables()[0].cpu().numpy(), orb.id_table)
-        print(f"bench-config parity: max loss rel err {max_loss_rel:.2e}, max one-step param err "
-              f"{worst:.2e} of max|p| over {ITERS} steps")
+        med_g = max(float(np.median(v)) for v in g_err.values())
+        med_p = max(float(np.median(v)) for v in p_err.values())
+        assert med_g <= TOL_GRAD_MEDIAN, f"median gradient error {med_g:.2e}"
+        assert med_p <= TOL_PARAM_MEDIAN, f"median one-step parameter error {med_p:.2e}"
+        print(f"bench-config parity: median over steps (worst tensor): gradient {med_g:.2e} relative "
+              f"L2, parameters {med_p:.2e} of max|p|")
+        print(f"bench-config parity: max loss rel err {max_loss_rel:.2e}, max gradient err "
+              f"{worst_g:.2e} (relative L2), max one-step param err {worst:.2e} of max|p| "
+              f"({worst_l2:.2e} relative L2) over {ITERS} steps")

@@ -224,3 +224,59 @@ def test_full_size_atari_properties(dev):
                                   (envs + 0.5 * ids).astype(np.float32))
     np.testing.assert_array_equal(data.step_type.cpu().numpy(), (ids % 3).astype(np.int32))
     assert np.float32(info.probabilities[0].item()) == np.float32(1.0) / np.float32((L - 1) * B)
+
+
+@pytest.mark.parametrize("obs_elems,B,L,S,T", [
+    (7056, 16, 6, 300, 2),        # Atari-sized rows: one workgroup per row, 600 workgroups
+    (20000, 3, 9, 700, 3),        # 80,000-byte rows: three 32 KiB chunks, 6,300 workgroups
+    (3, 1000, 4, 4096, 1),        # tiny rows, 1,000 envs: 1,000-workgroup scatter
+])
+def test_one_launch_get_next_and_add_batch_at_scale(dev, obs_elems, B, L, S, T):
+    """add_batch and get_next are ONE launch each: the draw is recomputed per workgroup, the
+    counters advance inside the launch through sharded arrival words (csrc/replay.hip).  Against
+    the oracle bit for bit at grids of thousands of workgroups and multi-chunk rows; the arrival
+    words are back to zero and the device counters equal the host mirrors after every call."""
+    spec = tensor_spec.TensorSpec((obs_elems,), torch.float32, "obs")
+    rb = rb_lib.TFUniformReplayBuffer(spec, batch_size=B, max_length=L, device=dev, seed=77)
+    orc = oracle_replay.OracleReplayBuffer([(obs_elems,)], [np.float32], B, L, seed=77)
+    rng = np.random.default_rng(5)
+    for i in range(L + 3):
+        x = rng.standard_normal((B, obs_elems)).astype(np.float32)
+        rb.add_batch(torch.as_tensor(x, device=dev))
+        orc.add_batch([x])
+        assert int(rb._last_id.item()) == i and not bool(rb._scatter_arrival.any())
+        if i + 1 >= T:
+            data, info = rb.get_next(S, T)
+            odata, oids, oprobs = orc.get_next(S, T)
+            assert np.array_equal(data.cpu().numpy(), odata[0])
+            assert np.array_equal(info.ids.cpu().numpy(), oids)
+            assert np.array_equal(info.probabilities.cpu().numpy(), oprobs)
+            assert int(rb._sample_calls_dev.item()) == rb._sample_calls
+            assert not bool(rb._sample_arrival.any())
+    assert np.array_equal(rb.variables()[0].cpu().numpy(), orc.tables[0])
+
+
+def test_fused_get_next_equals_the_two_launch_path(dev):
+    """aa_rb_sample_gather == aa_rb_sample_rows + aa_rb_gather_rows on the same call counter."""
+    from agents_amd import _lib
+    lib = _lib.load()
+    spec = _traj_spec((84, 84, 4), torch.uint8)
+    B, L, S, T = 8, 5, 64, 2
+    rb = rb_lib.TFUniformReplayBuffer(spec, batch_size=B, max_length=L, device=dev, seed=3)
+    rng = np.random.RandomState(1)
+    from agents_amd.utils import nest_utils
+    for _ in range(L + 2):
+        rb.add_batch(nest_utils.map_structure(lambda a: torch.as_tensor(a, device=dev),
+                                              _rand_items(rng, spec, B)))
+    for call in range(3):
+        data, info = rb.get_next(S, T)
+        rows = torch.empty((S, T), dtype=torch.int64, device=dev)
+        probs = torch.empty((S,), dtype=torch.float32, device=dev)
+        _lib.check(lib.aa_rb_sample_rows(rb._last_id.data_ptr(), B, L, S, T, rb._seed, call, None,
+                                         rows.data_ptr(), probs.data_ptr(), None,
+                                         _lib.stream_ptr()), "aa_rb_sample_rows")
+        ids = torch.empty((S, T), dtype=torch.int64, device=dev)
+        ref = rb._data_table.read(rows, rb._id_table.variables()[0], ids)
+        for a, b in zip(nest_utils.flatten(data), nest_utils.flatten(ref)):
+            assert torch.equal(a, b)
+        assert torch.equal(info.ids, ids) and torch.equal(info.probabilities, probs)
