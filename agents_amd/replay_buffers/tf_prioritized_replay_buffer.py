@@ -108,13 +108,10 @@ class TFPrioritizedReplayBuffer(uniform.TFUniformReplayBuffer):
     def _as_dataset(self, sample_batch_size=None, num_steps=None, sequence_preprocess_fn=None,
                     num_parallel_calls=None):
         # priorities change between draws and `last_sampled_rows` must name the batch being
-        # trained on: no graph ring, no sampling ahead
-        ring, self._dataset_ring = self._dataset_ring, 0
-        try:
-            return super()._as_dataset(sample_batch_size, num_steps, sequence_preprocess_fn,
-                                       num_parallel_calls)
-        finally:
-            self._dataset_ring = ring
+        # trained on: no graph ring (a replayed draw would leave `last_sampled_rows` pointing at
+        # whichever slot was captured last), no sampling ahead
+        return super()._as_dataset(sample_batch_size, num_steps, sequence_preprocess_fn,
+                                   num_parallel_calls, ring=0)
 
     def state_dict(self):
         sd = super().state_dict()

@@ -210,20 +210,22 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
                                   single_deterministic_pass=single_deterministic_pass)
 
     def _as_dataset(self, sample_batch_size=None, num_steps=None, sequence_preprocess_fn=None,
-                    num_parallel_calls=None):
+                    num_parallel_calls=None, ring=None):
         """Infinite stream of get_next (:329-367).  num_parallel_calls is accepted and ignored:
-        sampling kernels are already asynchronous on the stream."""
+        sampling kernels are already asynchronous on the stream.  `ring` (subclasses): size of the
+        graphed sampler's output ring, 0 = every element is a fresh eager get_next; None = the
+        buffer's `dataset_ring`, read when the dataset is iterated."""
         if sequence_preprocess_fn is not None:
             raise NotImplementedError("sequence_preprocess_fn is not supported.")
 
         def gen():
             # the iterator replays a HIP graph of (sample, gather) after two eager draws; its
             # elements live in a ring of static buffers (graph.GraphedSampler)
-            if self._dataset_ring <= 0:
+            n_ring = self._dataset_ring if ring is None else ring
+            if n_ring <= 0:
                 while True:
                     yield self.get_next(sample_batch_size, num_steps, time_stacked=True)
-            sampler = graph.GraphedSampler(self, sample_batch_size, num_steps,
-                                           ring=self._dataset_ring)
+            sampler = graph.GraphedSampler(self, sample_batch_size, num_steps, ring=n_ring)
             while True:
                 yield sampler.next()
 

@@ -460,6 +460,7 @@ class GraphedSampler:
         self._ring = [None] * max(int(ring), 2)
         self._i = 0
         self._warm = 0
+        self._ref = None
         self.enabled = True
         self.replays = 0
 
@@ -480,15 +481,19 @@ class GraphedSampler:
         except Exception:
             self.enabled = False
             raise
-        ref = weakref.ref(self)
+        self._ref = weakref.ref(self)
         for exp in self.ring_experiences():
-            _RING_OWNER[nest_utils.flatten(exp)[0].data_ptr()] = ref
+            _RING_OWNER[nest_utils.flatten(exp)[0].data_ptr()] = self._ref
 
     def __del__(self):
+        # only OUR registrations: the addresses may have been reused by a younger ring since
         try:
+            ref = getattr(self, "_ref", None)
             for c in self._ring:
                 if c is not None and c.out is not None:
-                    _RING_OWNER.pop(nest_utils.flatten(c.out[0])[0].data_ptr(), None)
+                    p0 = nest_utils.flatten(c.out[0])[0].data_ptr()
+                    if ref is not None and _RING_OWNER.get(p0) is ref:
+                        del _RING_OWNER[p0]
         except Exception:      # interpreter shutdown
             pass
 

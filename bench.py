@@ -106,6 +106,10 @@ def build_workload(dev, rank, world, B_env, max_length, S, seed):
                 collect_driver=collect_driver, dataset=dataset, learner=lrn, net=net)
 
 
+def args_envs(w):
+    return w["env"].batch_size
+
+
 def kernel_breakdown(w, S, reps=20):
     """Times the kernels of one iteration individually: each op is captured `reps` times into a
     HIP graph on torch's current stream and the replay is bracketed by HIP events on that stream,
@@ -192,6 +196,45 @@ def kernel_breakdown(w, S, reps=20):
         mask_act="relu")), 1, f(m[1]), 0))
     out.append(("conv1.dW(u8,+bias grad)", timeit(lambda: ops.conv_dw(
         obs_t, dz1, tuple(kv[0].shape), 4, gk[0], a_div=255.0, bias_grad=gb[0])), 1, f(m[0]), 0))
+    # ---- the small launches of the iteration (heads, loss, rollout tail) -----------------------
+    A = NUM_ACTIONS
+    dq = torch.randn(S, A, device=obs_t.device)
+    out.append(("fc2.dW(+bias grad)", timeit(lambda: ops.dense_dw(
+        slot.ys[3], dq, gk[4], bias_grad=gb[4])), 1, f(m[4]), 0))
+    out.append(("fc2.dX", timeit(lambda: ops.dense_dx(
+        dq, kv[4], slot.dxs[4].view(S, -1) if slot.dxs[4] is not None else dz4,
+        mask_src=slot.ys[3], mask_act="relu")), 1, f(m[4]), 0))
+    wk = agent._get_work(S, obs_t.device)
+    q_on, q_tg = slot.ys[4], torch.randn(S, A, device=obs_t.device)
+    out.append(("dqn.td_loss(+dL/dq, field sums)", timeit(lambda: ops.dqn_td_loss(
+        q_on, q_tg, None, None, exp.action, exp.reward.contiguous(), exp.discount.contiguous(),
+        exp.step_type.contiguous(), None, 0.99, 1.0, agent._loss_kind(agent._td_errors_loss_fn),
+        float(S), wk.loss, wk.td_loss, wk.td_error, wk.dq, gamma_loss=0.99,
+        field_sums_out=wk.field_sums)), 1, 0.0, 100.0 * S))
+    pol = agent.collect_policy
+    qpol = getattr(pol, "_wrapped_policy", pol)
+    qpol = getattr(qpol, "_wrapped_policy", qpol)
+    sel = getattr(qpol, "select", None)
+    if sel is not None:
+        act_out = torch.empty((args_envs(w),), dtype=torch.int64, device=obs_t.device)
+        out.append(("policy.eps_greedy_select", timeit(lambda: sel(q_on[:args_envs(w)], None, 0.1,
+                                                                   out=act_out)),
+                    1, 0.0, args_envs(w) * (4.0 * A + 8)))
+    env = w["env"]
+    act_env = torch.zeros((env.batch_size,), dtype=torch.int64, device=obs_t.device)
+    out.append(("env.step(256 envs, synthetic)", timeit(lambda: env.step(act_env)), 1, 0.0,
+                env.batch_size * (28224.0 + 12)))
+    from agents_amd import _lib as _l
+    lib = _l.load()
+    cnt = torch.zeros((env.batch_size,), dtype=torch.int32, device=obs_t.device)
+    tot_c = torch.zeros((1,), dtype=torch.int64, device=obs_t.device)
+    st_ = env.current_time_step().step_type
+
+    def count_steps():
+        with torch.cuda.device(obs_t.device):
+            _l.check(lib.aa_count_steps(st_.data_ptr(), st_.numel(), cnt.data_ptr(),
+                                        tot_c.data_ptr(), None, _l.stream_ptr()), "aa_count_steps")
+    out.append(("driver.count_steps", timeit(count_steps), 1, 0.0, env.batch_size * 8.0))
     n_par = net.flat_params.numel()
     opt = agent._optimizer
     scratch = net.flat_params.clone()

@@ -63,6 +63,29 @@ def main():
         dz, gk, gb = r(S * 400, 32), r(8, 8, 4, 32), r(32)
         fn = lambda: ops.conv_dw(obs, dz, (8, 8, 4, 32), 4, gk, a_div=255.0, force_cfg=c,
                                  force_splits=s, bias_grad=gb)
+    elif args.name == "fc1.dX":
+        x, w, dz, dx = r(S, 3136), r(3136, 512), r(S, 512), r(S, 3136)
+        fn = lambda: ops.dense_dx(dz, w, dx, mask_src=x, mask_act="relu", force_cfg=c,
+                                  force_splits=s)
+    elif args.name == "replay.get_next":
+        # the fused draw + gather launch of TFUniformReplayBuffer.get_next on Atari rows
+        from agents_amd.replay_buffers import tf_uniform_replay_buffer as rb_lib
+        from agents_amd.specs import tensor_spec
+        from agents_amd.trajectories import trajectory
+        spec = trajectory.Trajectory(
+            step_type=tensor_spec.TensorSpec((), torch.int32),
+            observation=tensor_spec.TensorSpec((84, 84, 4), torch.uint8),
+            action=tensor_spec.TensorSpec((), torch.int64), policy_info=(),
+            next_step_type=tensor_spec.TensorSpec((), torch.int32),
+            reward=tensor_spec.TensorSpec((), torch.float32),
+            discount=tensor_spec.TensorSpec((), torch.float32))
+        rb = rb_lib.TFUniformReplayBuffer(spec, batch_size=256, max_length=256, device=dev)
+        for v in rb._data_table.variables():
+            if v.dtype == torch.uint8:
+                v.random_(0, 256)
+        rb._last_id.fill_(255)
+        rb._last_id_host = 255
+        fn = lambda: rb.get_next(S, 2)
     elif args.name == "replay.gather":
         # 512 random rows of the Atari trajectory table (28,248 B per row), 4096-row table
         from agents_amd.replay_buffers import table
