@@ -23,6 +23,7 @@
 // during the MFMAs of tile t, one barrier per K-step (BK = 32).  Split-K over blockIdx.z writes
 // fp32 partial slabs that aa_splitk_reduce_kernel sums deterministically with the epilogue.
 #include "common.h"
+#include <stdlib.h>
 #include "agents_amd.h"
 
 #include <type_traits>
@@ -66,7 +67,51 @@ struct GemmP {
   int ldm;
   int mask_kind;
   int a_vec, b_vec;  // 16-byte vector path usable for dense operands
+  // XCD-aware block order (aa_block_of): 0 = the launch's own (x, y, z); 1 / 2 / 3 = a 1-D launch
+  // whose blocks are dealt to the 8 XCDs in contiguous runs of the K-split / N-tile / M-tile index
+  int xcd_mode, gx, gy, gz;
 };
+
+// Which (M tile, N tile, K split) a workgroup computes.  Hardware deals consecutive workgroups to
+// consecutive XCDs, each with its own L2: in launch order (x fastest) every XCD ends up touching
+// ALL of the operand that x does not index -- fc1 forward (8 M tiles x 8 N tiles x 8 K splits)
+// fetched W once per XCD, 59 MB for 9.6 MB of operands (rocprofv3 FETCH_SIZE/WRITE_SIZE).  With
+// xcd_mode != 0 the launch is 1-D, XCD c = block & 7 takes the contiguous index range
+// [c * per, (c + 1) * per), and the index is decomposed with the dimension that partitions the
+// most operand bytes slowest, so an XCD's L2 sees one slice of it.  Pure relabelling: every
+// (x, y, z) is computed exactly once by the same code, results are bit-identical.
+struct AaBlk { int x, y, z; };
+__device__ static inline bool aa_block_of(const GemmP& p, AaBlk* b) {
+  if (p.xcd_mode == 0) {
+    b->x = blockIdx.x; b->y = blockIdx.y; b->z = blockIdx.z;
+    return true;
+  }
+  const int n = p.gx * p.gy * p.gz;
+  const int per = (n + 7) >> 3;
+  const int L = blockIdx.x;
+  const int idx = (L & 7) * per + (L >> 3);
+  if (idx >= n) return false;
+  if (p.xcd_mode == 1) {
+    const int t = p.gx * p.gy;
+    b->z = idx / t;
+    const int r = idx - b->z * t;
+    b->y = r / p.gx;
+    b->x = r - b->y * p.gx;
+  } else if (p.xcd_mode == 2) {
+    const int t = p.gx * p.gz;
+    b->y = idx / t;
+    const int r = idx - b->y * t;
+    b->z = r / p.gx;
+    b->x = r - b->z * p.gx;
+  } else {
+    const int t = p.gy * p.gz;
+    b->x = idx / t;
+    const int r = idx - b->x * t;
+    b->z = r / p.gy;
+    b->y = r - b->z * p.gy;
+  }
+  return true;
+}
 
 __device__ static inline float aa_act(float v, int act) {
   if (act == AA_ACT_RELU) return v > 0.f ? v : 0.f;
@@ -331,9 +376,11 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
   float* As = smem;                          // [2][BK][LDA_S]
   float* Bs = smem + 2 * AA_BK * LDA_S;      // [2][BK][LDB_S]
 
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
-  const int k_begin = blockIdx.z * p.k_per_split;
+  AaBlk blk;
+  if (!aa_block_of(p, &blk)) return;
+  const int m0 = blk.x * BM;
+  const int n0 = blk.y * BN;
+  const int k_begin = blk.z * p.k_per_split;
   int k_end = k_begin + p.k_per_split;
   if (k_end > p.K) k_end = p.K;
   const int nk = (k_end - k_begin + AA_BK - 1) / AA_BK;
@@ -374,7 +421,7 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
     ioff = iin ? aa_patch_off(p, i) : 0;
   }
   // fused bias gradient: column sums of the B operand, taken by the first M-tile's workgroups
-  const bool do_colsum = (BMODE == AA_B_ROW) && p.colsum_out != nullptr && blockIdx.x == 0;
+  const bool do_colsum = (BMODE == AA_B_ROW) && p.colsum_out != nullptr && blk.x == 0;
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
 
   const aa_rsrc rA = aa_make_rsrc(p.A, p.a_bytes);
@@ -505,7 +552,7 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
         const int n = n0 + threadIdx.x;
         if (n < p.N) {
           if (raw)  // per-split partial rows after the slabs: [splits][N]
-            p.C[(size_t)p.splits * p.M * p.N + (size_t)blockIdx.z * p.N + n] = s;
+            p.C[(size_t)p.splits * p.M * p.N + (size_t)blk.z * p.N + n] = s;
           else
             p.colsum_out[n] = s;
         }
@@ -543,7 +590,7 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
   }
 
   // ---- epilogue ------------------------------------------------------------------------
-  float* C = raw ? p.C + (size_t)blockIdx.z * (size_t)p.M * (size_t)p.N : p.C;
+  float* C = raw ? p.C + (size_t)blk.z * (size_t)p.M * (size_t)p.N : p.C;
   const int ldc = raw ? p.N : p.ldc;
   if (WGK == 1 || wk == 0) {
 #pragma unroll
@@ -694,6 +741,8 @@ static const AaTileCfg kCfgs[] = {
 
 #include "conv_u8_bf16.h"
 #include "gemm_bf16x6.h"
+#include "gemm_x6d.h"
+#define AA_CFG_X6D 10      // force_cfg value of the dense bf16x6 plan (gemm_x6d.h)
 
 struct AaGemmPlan {
   int cfg;
@@ -763,6 +812,27 @@ static int aa_gemm_plan(const aa_gemm_desc* d, AaGemmPlan* pl) {
     pl->ws_bytes = (size_t)pl->splits * (size_t)(M * N + (d->colsum_out ? N : 0)) * sizeof(float);
     return AA_OK;
   }
+  {
+    // dense layers of fc1's size and up: bf16 matrix cores at fp32 accuracy (gemm_x6d.h).
+    // AA_GEMM_X6D=0 keeps them on the fp32-MFMA plans (A/B measurements).
+    static int x6d_enabled = -1;
+    if (x6d_enabled < 0) {
+      const char* e = getenv("AA_GEMM_X6D");
+      x6d_enabled = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    const bool big = M >= 64 && N >= 64 && M * N * K >= 100000000LL;
+    if (d->force_cfg == AA_CFG_X6D ||
+        (d->force_cfg == 0 && x6d_enabled && big && aa_x6d_ok(d))) {
+      if (!aa_x6d_ok(d)) return AA_ERR_INVALID;
+      pl->cfg = AA_CFG_X6D - 1;
+      pl->bm = AA_X6D_BM; pl->bn = AA_X6D_BN;
+      aa_x6d_plan(d, &pl->splits, &pl->k_per_split);
+      pl->ws_bytes = pl->splits > 1 ? (size_t)pl->splits *
+                                          (size_t)(M * N + (d->colsum_out ? N : 0)) * sizeof(float)
+                                    : 0;
+      return AA_OK;
+    }
+  }
   if (d->force_cfg > 0) {
     cfg = d->force_cfg - 1;
     if (cfg >= AA_NCFG) return AA_ERR_INVALID;
@@ -808,6 +878,7 @@ static int aa_gemm_plan(const aa_gemm_desc* d, AaGemmPlan* pl) {
 template <int AM, int BMODE, int BM, int BN, int WGM, int WGN, int WGK, int PD, int VEC>
 static void aa_gemm_launch_pd(const GemmP& p, const AaGemmPlan& pl, hipStream_t st) {
   dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, pl.splits);
+  if (p.xcd_mode != 0) grid = dim3(((p.gx * p.gy * p.gz + 7) / 8) * 8, 1, 1);
   constexpr bool A_IS_T = (AM == AA_A_ROW || AM == AA_A_PATCH || AM == AA_A_PATCH_U8);
   constexpr bool B_IS_T = (BMODE == AA_B_COL);
   constexpr int lda_s = BM + (A_IS_T ? 1 : 4), ldb_s = BN + (B_IS_T ? 1 : 4);
@@ -974,6 +1045,34 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
   p.use_dma = aa_desc_dma_ok(d) ? 1 : 0;
   p.k_per_split = pl.k_per_split;
   p.splits = pl.splits;
+  // XCD-aware block order (aa_block_of) for the dense contractions: partition across the 8 L2s
+  // along the tile dimension that minimises the bytes every XCD has to fetch.  An operand NOT
+  // indexed by the partitioned dimension is fetched by all 8 XCDs, a partitioned one by
+  // 8 / min(8, tiles) of them.  AA_GEMM_XCD=0 restores the launch order (A/B measurements).
+  p.xcd_mode = 0;
+  p.gx = (d->M + pl.bm - 1) / pl.bm;
+  p.gy = (d->N + pl.bn - 1) / pl.bn;
+  p.gz = pl.splits;
+  {
+    static int enabled = -1;
+    if (enabled < 0) {
+      const char* e = getenv("AA_GEMM_XCD");
+      enabled = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    const bool dense = d->a_mode == AA_A_ROW || d->a_mode == AA_A_COL;
+    const int64_t n_blocks = (int64_t)p.gx * p.gy * p.gz;
+    if (enabled && dense && pl.cfg != AA_CFG_U8_BF16 - 1 && n_blocks >= 64 &&
+        n_blocks < (1 << 24)) {
+      const double a_bytes = 4.0 * d->M * d->K, b_bytes = 4.0 * d->K * d->N;
+      auto share = [](int g) { return 8.0 / (g < 8 ? g : 8); };   // XCDs per slice
+      const double cost_m = a_bytes * share(p.gx) + b_bytes * 8.0;   // = launch order
+      const double cost_n = a_bytes * 8.0 + b_bytes * share(p.gy);
+      const double cost_k = (a_bytes + b_bytes) * share(p.gz);
+      if (cost_k <= cost_n && cost_k < cost_m) p.xcd_mode = 1;
+      else if (cost_n < cost_m) p.xcd_mode = 2;
+      else if (p.gx % 8 != 0) p.xcd_mode = 3;      // launch order already partitions M when 8 | gx
+    }
+  }
   p.bias = d->bias;
   p.act = d->act;
   p.mask_src = d->mask_src;
@@ -993,10 +1092,20 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
         rc = aa_fwd_x6_launch(p, x, false, st);
         break;
       }
+      if (pl.cfg == AA_CFG_X6D - 1) {
+        rc = aa_x6d_launch(p, true, d->b_mode == AA_B_COL, st);
+        break;
+      }
       rc = d->b_mode == AA_B_ROW ? aa_gemm_launch_cfg<AA_A_ROW, AA_B_ROW>(p, pl, st)
                                  : aa_gemm_launch_cfg<AA_A_ROW, AA_B_COL>(p, pl, st);
       break;
-    case AA_A_COL: rc = aa_gemm_launch_cfg<AA_A_COL, AA_B_ROW>(p, pl, st); break;
+    case AA_A_COL:
+      if (pl.cfg == AA_CFG_X6D - 1) {
+        rc = aa_x6d_launch(p, false, false, st);
+        break;
+      }
+      rc = aa_gemm_launch_cfg<AA_A_COL, AA_B_ROW>(p, pl, st);
+      break;
     case AA_A_PATCH:
       if (pl.cfg == AA_CFG_U8_BF16 - 1) {
         AaX6Plan x;

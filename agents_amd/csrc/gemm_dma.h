@@ -193,9 +193,11 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
 
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
-  const int k_begin = blockIdx.z * p.k_per_split;
+  AaBlk blk;
+  if (!aa_block_of(p, &blk)) return;
+  const int m0 = blk.x * BM;
+  const int n0 = blk.y * BN;
+  const int k_begin = blk.z * p.k_per_split;
   int k_end = k_begin + p.k_per_split;
   if (k_end > p.K) k_end = p.K;
   const int nk = (k_end - k_begin + AA_BK - 1) / AA_BK;
@@ -222,7 +224,7 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const bool do_colsum = (BKIND == AA_KIND_D_DENSE) && p.colsum_out != nullptr && blockIdx.x == 0;
+  const bool do_colsum = (BKIND == AA_KIND_D_DENSE) && p.colsum_out != nullptr && blk.x == 0;
   float csum = 0.f;
 
   auto issue_tile = [&](int t) {  // K-tile t -> ring slot t % NS (tiles past nk are all-zero)
@@ -279,7 +281,7 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
       const int n = n0 + threadIdx.x;
       if (n < p.N) {
         if (raw)
-          p.C[(size_t)p.splits * p.M * p.N + (size_t)blockIdx.z * p.N + n] = csum;
+          p.C[(size_t)p.splits * p.M * p.N + (size_t)blk.z * p.N + n] = csum;
         else
           p.colsum_out[n] = csum;
       }
@@ -313,7 +315,7 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
     }
   }
 
-  float* C = raw ? p.C + (size_t)blockIdx.z * (size_t)p.M * (size_t)p.N : p.C;
+  float* C = raw ? p.C + (size_t)blk.z * (size_t)p.M * (size_t)p.N : p.C;
   const int ldc = raw ? p.N : p.ldc;
   if (WGK == 1 || wk == 0) {
 #pragma unroll
@@ -346,6 +348,7 @@ static void aa_gemm_dma_launch(const GemmP& p, int splits, hipStream_t st) {
   using OB = DmaOp<BKIND, BN>;
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, splits);
+  if (p.xcd_mode != 0) grid = dim3(((p.gx * p.gy * p.gz + 7) / 8) * 8, 1, 1);
   size_t smem = (size_t)NS * (OA::kPadded + OB::kPadded);
   const size_t red = (size_t)(WGK - 1) * WGM * WGN * TM * TN * 1024 * sizeof(float);
   if (red > smem) smem = red;

@@ -132,8 +132,11 @@ typedef struct aa_gemm_desc {
                            * 32x64, 32x32, 256x32 (LDS-DMA operands only); 9 = the bf16 matrix-core
                            * plans with exact 3-piece splits: uint8 conv forward / weight gradient
                            * with 32 filters (the automatic choice there, csrc/conv_u8_bf16.h) and
-                           * fp32 forward contractions (opt-in, csrc/gemm_bf16x6.h); AA_ERR_INVALID
-                           * when the shape is not eligible */
+                           * fp32 forward contractions (opt-in, csrc/gemm_bf16x6.h); 10 = the dense
+                           * bf16x6 plan (csrc/gemm_x6d.h: both operands split on their way into
+                           * LDS, 64x64 tiles; K % 32 == 0; the automatic choice for dense
+                           * contractions of M*N*K >= 1e8); AA_ERR_INVALID when the shape is not
+                           * eligible */
   int32_t force_splits;   /* 0 = auto split-K */
   /* nullable, AA_B_ROW only: colsum_out[n] = sum_k B(k,n).  With B = dZ this is the bias
    * gradient (tf.GradientTape of keras BiasAdd), produced by the weight-gradient GEMM that
