@@ -813,12 +813,17 @@ static int aa_gemm_plan(const aa_gemm_desc* d, AaGemmPlan* pl) {
     return AA_OK;
   }
   {
-    // dense layers of fc1's size and up: bf16 matrix cores at fp32 accuracy (gemm_x6d.h).
-    // AA_GEMM_X6D=0 keeps them on the fp32-MFMA plans (A/B measurements).
+    // dense layers of fc1's size and up on the bf16 matrix cores at fp32 accuracy (gemm_x6d.h):
+    // OPT-IN (force_cfg = 10 or AA_GEMM_X6D=1).  Measured on MI355X: in isolation it beats the
+    // fp32-MFMA plans (fc1 forward 18.8 vs 19.3 us, input gradient 17.0 vs 18.5, weight gradient
+    // 15.1 vs 20.5), inside the DQN iteration it does not (0.4009 vs 0.3970 ms, two alternating
+    // pairs on one box): with ~200 workgroups of one wave per SIMD its k loop is instruction-issue
+    // bound (~220 instructions per 24 MFMAs), and its 72 KiB of LDS keep the other streams'
+    // workgroups off the CU.
     static int x6d_enabled = -1;
     if (x6d_enabled < 0) {
       const char* e = getenv("AA_GEMM_X6D");
-      x6d_enabled = (e != nullptr && e[0] == '0') ? 0 : 1;
+      x6d_enabled = (e != nullptr && e[0] == '1') ? 1 : 0;
     }
     const bool big = M >= 64 && N >= 64 && M * N * K >= 100000000LL;
     if (d->force_cfg == AA_CFG_X6D ||

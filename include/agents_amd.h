@@ -134,8 +134,8 @@ typedef struct aa_gemm_desc {
                            * with 32 filters (the automatic choice there, csrc/conv_u8_bf16.h) and
                            * fp32 forward contractions (opt-in, csrc/gemm_bf16x6.h); 10 = the dense
                            * bf16x6 plan (csrc/gemm_x6d.h: both operands split on their way into
-                           * LDS, 64x64 tiles; K % 32 == 0; the automatic choice for dense
-                           * contractions of M*N*K >= 1e8); AA_ERR_INVALID when the shape is not
+                           * LDS, 64x64 tiles; K % 32 == 0; opt-in: it wins in isolation, not inside
+                           * the DQN iteration); AA_ERR_INVALID when the shape is not
                            * eligible */
   int32_t force_splits;   /* 0 = auto split-K */
   /* nullable, AA_B_ROW only: colsum_out[n] = sum_k B(k,n).  With B = dZ this is the bias

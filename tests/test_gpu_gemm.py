@@ -63,7 +63,7 @@ def test_dense_forward_forced_configs(dev, cfg, splits):
     close(out, torch.relu(x.double() @ w.double() + b.double()))
 
 
-X6D = 10     # force_cfg of the dense bf16x6 plan (csrc/gemm_x6d.h); the default at fc1's size
+X6D = 10     # force_cfg of the dense bf16x6 plan (csrc/gemm_x6d.h); opt-in
 
 
 @pytest.mark.parametrize("splits", [0, 1, 3, 5])
@@ -114,14 +114,14 @@ def test_dense_x6d_exact_on_small_integers_and_ineligible_shapes(dev):
     w = torch.from_numpy(rng.integers(-3, 4, (K, N)).astype(np.float32))
     dz = torch.from_numpy(rng.integers(-4, 5, (M, N)).astype(np.float32))
     y = torch.empty(M, N, device=dev)
-    ops.dense_forward(x.to(dev), w.to(dev), None, None, y)
+    ops.dense_forward(x.to(dev), w.to(dev), None, None, y, force_cfg=X6D)
     assert torch.equal(y.cpu().double(), x.double() @ w.double())
     dx = torch.empty(M, K, device=dev)
-    ops.dense_dx(dz.to(dev), w.to(dev), dx)
+    ops.dense_dx(dz.to(dev), w.to(dev), dx, force_cfg=X6D)
     assert torch.equal(dx.cpu().double(), dz.double() @ w.double().T)
     dw = torch.empty(K, N, device=dev)
     bg = torch.empty(N, device=dev)
-    ops.dense_dw(x.to(dev), dz.to(dev), dw, bias_grad=bg)
+    ops.dense_dw(x.to(dev), dz.to(dev), dw, bias_grad=bg, force_cfg=X6D)
     assert torch.equal(dw.cpu().double(), x.double().T @ dz.double())
     assert torch.equal(bg.cpu().double(), dz.double().sum(0))
     with pytest.raises(Exception):
