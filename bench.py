@@ -441,31 +441,61 @@ def main():
                 extra = f"{fl / ms / 1e9:8.1f} TFLOP/s" if fl else f"{by / ms / 1e6:8.1f} GB/s"
                 log(f"    {name:40s} {ms * 1e3:8.1f} us x{n}  {extra}  "
                     f"({100 * ms * n / tot:4.1f}%)")
-            traffic = {}
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 --pmc passes
-                with open(tpath) as fh:
-                    traffic = json.load(fh).get("bytes_per_launch", {})
+            # HBM bytes and matrix-pipe busy per launch from the committed rocprofv3 --pmc passes of
+            # this tree (tools/pmc_r02.sh -> profiles/r02_pmc.json): all kernels of the case summed
+            # for the traffic (pre-passes, reduces), the dominant kernel's counters for mfma_busy
+            pmc_case = {"conv2+conv3.fwd(fused)": "conv23.fwd", "fc1.fwd": "fc1.fwd",
+                        "fc1.dX": "fc1.dX", "fc1.dW(+bias grad)": "fc1.dW",
+                        "conv2.dX": "conv2.dX", "conv3.dX": "conv3.dX",
+                        "conv1.fwd(u8)": "conv1.fwd",
+                        "replay.get_next(sample+gather 512 rows)": "replay.get_next"}
+            pmc = {}
+            ppath = os.path.join(ROOT, "profiles", "r02_pmc.json")
+            if os.path.exists(ppath):
+                with open(ppath) as fh:
+                    pmc = json.load(fh).get("cases", {})
+
+            def pmc_of(name):
+                c = pmc.get(pmc_case.get(name, ""), None)
+                if not c:
+                    return None, None, None
+                ks = c["kernels"]
+                tot = [k.get("hbm_bytes_per_launch") for k in ks.values()]
+                traffic_b = sum(t for t in tot if t is not None) if any(
+                    t is not None for t in tot) else None
+                dom = ks[c["dominant_kernel"]]
+                return traffic_b, dom.get("mfma_busy"), c["dominant_kernel"]
 
             def roof(row):
                 name, ms, n, fl, by = row
+                traffic_b, busy, dom = pmc_of(name)
                 if fl:
                     ach = fl / ms / 1e9
-                    return {"kernel": name, "bound": "mfma", "achieved": ach,
-                            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": traffic.get(name),
-                            "algorithmic_flop_per_launch": fl, "avg_launch_ms": ms,
-                            "launches_per_step": n}
+                    r = {"kernel": name, "bound": "mfma", "achieved": ach,
+                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": traffic_b,
+                         "algorithmic_flop_per_launch": fl, "avg_launch_ms": ms,
+                         "launches_per_step": n, "mfma_busy": busy, "device_kernel": dom,
+                         "peak_note": "algorithmic fp32 flop against the fp32-input MFMA peak "
+                                      "(157.3 TFLOP/s: the dtype of the contraction); the bf16x6 "
+                                      "kernels execute 6 bf16 MFMA products per fp32 product at "
+                                      "the 2.5 PFLOP/s bf16 rate, mfma_busy (rocprofv3 "
+                                      "SQ_VALU_MFMA_BUSY_CYCLES over kernel cycles x 1024 SIMDs) "
+                                      "is their matrix-pipe utilisation"}
+                    return r
                 ach = by / ms / 1e6
                 return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(name),
+                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic_b,
                         "algorithmic_bytes_per_launch": by, "avg_launch_ms": ms,
-                        "launches_per_step": n}
+                        "launches_per_step": n, "device_kernel": dom}
 
             # dominant kernel = largest share of the iteration's GPU time (duration x launches)
             out["roofline"] = roof(max(bd, key=lambda r: r[1] * r[2]))
             out["roofline_replay_gather"] = roof(bd[0])
             out["roofline_replay_add"] = roof(bd[1])
+            # every kernel of the iteration, same fields (without the long note)
+            out["roofline_all"] = [{k: v for k, v in roof(r).items() if k != "peak_note"}
+                                   for r in bd]
             out["kernel_time_sum_ms"] = tot
         if not args.no_cpu_baseline and world == 1:
             # torch-CPU convolutions at batch 256 stop scaling (and collapse when every hardware
