@@ -72,6 +72,7 @@ _SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "aa_rb_write_rows": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int,
                                  c_void_p, c_int64, c_void_p]),
+    "aa_random_permutation": (c_int, [c_int64, c_uint64, c_uint64, c_void_p, c_void_p]),
     "aa_rb_range_rows": (c_int, [c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "aa_counter_add": (c_int, [c_void_p, c_int64, c_void_p]),
     "aa_gemm_f32_workspace_bytes": (c_int64, [POINTER(GemmDesc)]),
@@ -145,6 +146,10 @@ _SIGNATURES = {
     "aa_normalize_moments": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
     "aa_ppo_loss": (c_int, [c_void_p] * 11 + [c_int64, c_int32] + [c_float] * 6 + [c_int32] +
                     [c_void_p] * 5),
+    "aa_pack_small_f32": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
+    "aa_pack_sum3_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "aa_add_strided_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                   c_void_p]),
     "aa_add_l2_grad": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "aa_ppo_loss_dist": (c_int, [c_void_p] * 11 + [c_int64, c_int32] + [c_float] * 6 +
                          [c_void_p, c_float, c_float] + [c_void_p] * 5),

@@ -364,12 +364,14 @@ class PPOAgent(tf_agent.TFAgent):
 
     def _loss_info_from_stats(self, stats, l2):
         """LossInfo whose fields are views of ONE private copy of the stats vector (the work
-        buffer is overwritten by the next evaluation)."""
-        s = stats[:8].clone()
-        total = s[6] + l2
-        return tf_agent.LossInfo(total.reshape(()), PPOLossInfo(
-            policy_gradient_loss=s[0], value_estimation_loss=s[1],
-            l2_regularization_loss=l2.clone() if isinstance(l2, torch.Tensor) else l2,
+        buffer is overwritten by the next evaluation); the copy and `total = stats[6] + l2` are one
+        launch (aa_pack_small_f32)."""
+        s = torch.empty((9,), dtype=torch.float32, device=stats.device)
+        _lib.check(_lib.load().aa_pack_small_f32(
+            stats.data_ptr(), 8, l2.data_ptr() if isinstance(l2, torch.Tensor) else None, 6,
+            s.data_ptr(), self._st()), "aa_pack_small_f32")
+        return tf_agent.LossInfo(s[6], PPOLossInfo(
+            policy_gradient_loss=s[0], value_estimation_loss=s[1], l2_regularization_loss=s[8],
             entropy_regularization_loss=s[2], kl_penalty_loss=s[5], clip_fraction=s[3]))
 
     def get_loss(self, time_steps, actions, act_log_probs, returns, normalized_advantages,

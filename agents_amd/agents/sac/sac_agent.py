@@ -305,7 +305,10 @@ class SacAgent(tf_agent.TFAgent):
                                                   want_action_grad=True)
             da2 = self._critic_network_2.backward(w["dq2"], slot="actor_q", param_grads=False,
                                                   want_action_grad=True)
-            torch.add(da1, da2, out=w["da"])
+            # da = da1 + da2: both are column slices of the critics' input-gradient buffers
+            _lib.check(lib.aa_add_strided_f32(da1.data_ptr(), da1.stride(0), da2.data_ptr(),
+                                              da2.stride(0), B, self._A, w["da"].data_ptr(),
+                                              _lib.stream_ptr()), "aa_add_strided_f32")
             mag = self._train_policy._consts(obs.device)[1]
             _lib.check(lib.aa_sac_head_backward(
                 z.data_ptr(), B, self._A, mag.data_ptr(),
@@ -429,10 +432,14 @@ class SacAgent(tf_agent.TFAgent):
                         self._actor_network.flat_grads, [self._actor_network.body])
             lloss = self._alpha_phase(obs, wts, True, eps=eps.get("alpha"))
             self._apply(self._alpha_optimizer, self._log_alpha_buf, self._log_alpha_grad, None)
-            total = (closs + aloss + lloss).reshape(())
-            info = tf_agent.LossInfo(total, SacLossInfo(critic_loss=closs.clone().reshape(()),
-                                                        actor_loss=aloss.clone().reshape(()),
-                                                        alpha_loss=lloss.clone().reshape(())))
+            # total + storage of its own for the three terms: one launch
+            packed = torch.empty((4,), dtype=torch.float32, device=dev)
+            _lib.check(_lib.load().aa_pack_sum3_f32(closs.data_ptr(), aloss.data_ptr(),
+                                                    lloss.data_ptr(), packed.data_ptr(),
+                                                    _lib.stream_ptr()), "aa_pack_sum3_f32")
+            info = tf_agent.LossInfo(packed[0], SacLossInfo(critic_loss=packed[1],
+                                                            actor_loss=packed[2],
+                                                            alpha_loss=packed[3]))
             # counter + (periodic) soft target update: device work of the update is enqueued here
             graph.on_replay(self._bump_counter)
             self._update_target()

@@ -151,6 +151,34 @@ __global__ void aa_ppo_finish_kernel(const float* __restrict__ partial, int P, f
   stats[7] = 0.f;
 }
 
+__global__ void aa_pack_small_kernel(const float* __restrict__ src, int n,
+                                     const float* __restrict__ addend, int add_at,
+                                     float* __restrict__ out) {
+  const int i = threadIdx.x;
+  const float ad = addend != nullptr ? addend[0] : 0.f;
+  if (i < n) out[i] = i == add_at ? src[i] + ad : src[i];
+  if (i == n) out[n] = ad;
+}
+
+__global__ void __launch_bounds__(256)
+aa_add_strided_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
+                      int64_t ldb, int64_t rows, int64_t cols, float* __restrict__ out) {
+  const int64_t n = rows * cols, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t r = i / cols, c = i - r * cols;
+    out[i] = a[r * lda + c] + b[r * ldb + c];
+  }
+}
+
+__global__ void aa_pack_sum3_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                    const float* __restrict__ c, float* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    const float x = a[0], y = b[0], z = c[0];
+    out[0] = (x + y) + z;
+    out[1] = x; out[2] = y; out[3] = z;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 aa_axpy_kernel(float* __restrict__ g, const float* __restrict__ p, int64_t n, float c) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -467,6 +495,37 @@ int aa_ppo_loss(const float* z, const float* std_bias, const float* act_mean,
                      partial);
   hipLaunchKernelGGL(aa_ppo_finish_kernel, dim3(1), dim3(64), 0, st, (const float*)partial, P,
                      denom, (float)N, c_v, c_e, stats);
+  return aa_launch_status();
+}
+
+// out[0..n) = src[0..n); out[n] = addend ? *addend : 0; out[add_at] += out[n].  One launch that
+// gives a LossInfo storage of its own (the loss kernels' stats vector is overwritten by the next
+// evaluation) and folds the regularisation term into the total -- instead of clone + add + clone.
+int aa_pack_small_f32(const float* src, int32_t n, const float* addend, int32_t add_at, float* out,
+                      void* stream) {
+  if (!src || !out || n <= 0 || n > 255 || add_at < 0 || add_at >= n) return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_pack_small_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, src, n,
+                     addend, add_at, out);
+  return aa_launch_status();
+}
+
+// out[r, c] = a[r * lda + c] + b[r * ldb + c], out dense [rows, cols]: the action gradient through
+// the two critics of SAC (column slices of their input-gradient buffers) summed into the buffer
+// the head's backward reads
+int aa_add_strided_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows,
+                       int64_t cols, float* out, void* stream) {
+  if (!a || !b || !out || rows <= 0 || cols <= 0 || lda < cols || ldb < cols) return AA_ERR_INVALID;
+  int64_t blocks = (rows * cols + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(aa_add_strided_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, a, lda, b, ldb, rows, cols, out);
+  return aa_launch_status();
+}
+
+// out = [a + b + c, a, b, c]: SacAgent's LossInfo (total, critic, actor, alpha) in one launch
+int aa_pack_sum3_f32(const float* a, const float* b, const float* c, float* out4, void* stream) {
+  if (!a || !b || !c || !out4) return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_pack_sum3_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, c, out4);
   return aa_launch_status();
 }
 

@@ -254,6 +254,37 @@ aa_rb_sample_gather_kernel(AaLeafSet leaves, const int64_t* __restrict__ id_tabl
   if (call_dev != nullptr) aa_advance_sharded(call_dev, arrival, 1, gridDim.x);
 }
 
+// ---- pseudo-random permutation of [0, n) without a sort -------------------------------------------
+// perm[i] = the image of i under a 4-round balanced Feistel network on 2h bits (2^(2h) >= n, h >= 1)
+// whose round function is Philox4x32-10(counter = (half, round, call_lo, call_hi), key = seed),
+// cycle-walked back into [0, n): a Feistel network is a bijection of [0, 2^(2h)), and following
+// the orbit of i until it re-enters [0, n) restricts it to a bijection of [0, n).  Every index is
+// computed independently (expected < 4 applications: 2^(2h) < 4 n): no radix sort, no host
+// round trip, and the CPU oracle (oracle/perm.py) reproduces it bit for bit.  Replaces the
+// tf.data shuffle of train/ppo_learner.py:228-247, whose order the reference does not pin.
+__global__ void __launch_bounds__(256)
+aa_feistel_perm_kernel(int64_t n, int h, uint32_t k0, uint32_t k1, uint64_t call,
+                       int64_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const uint64_t mask = (1ull << h) - 1ull;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    uint64_t x = (uint64_t)i;
+    do {
+      uint64_t l = x >> h, r = x & mask;
+#pragma unroll
+      for (uint32_t round = 0; round < 4; ++round) {
+        const Philox4 f = philox4x32_10((uint32_t)r, round, (uint32_t)call, (uint32_t)(call >> 32),
+                                        k0, k1);
+        const uint64_t t = l ^ ((((uint64_t)f.y << 32) | f.x) & mask);
+        l = r;
+        r = t;
+      }
+      x = (l << h) | r;
+    } while (x >= (uint64_t)n);
+    out[i] = (int64_t)x;
+  }
+}
+
 // rows[b, i] = (start_id + i) mod L + b*L   (gather_all and deterministic passes)
 __global__ void aa_rb_range_rows_kernel(int64_t start_id, int64_t n_ids, int64_t batch,
                                         int64_t max_len, int64_t* __restrict__ rows) {
@@ -390,6 +421,17 @@ int aa_rb_write_rows(void* const* leaf_tables_h, const void* const* leaf_values_
   if (grid > 0x7fffffffLL) return AA_ERR_RANGE;
   hipLaunchKernelGGL(aa_rb_write_kernel, dim3((unsigned)grid), dim3(AA_RB_THREADS), 0,
                      (hipStream_t)stream, ls, rows, n_chunks);
+  return aa_launch_status();
+}
+
+int aa_random_permutation(int64_t n, uint64_t seed, uint64_t call, int64_t* out, void* stream) {
+  if (n <= 0 || out == nullptr || n > (1ll << 60)) return AA_ERR_INVALID;
+  int h = 1;
+  while ((1ull << (2 * h)) < (uint64_t)n) ++h;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(aa_feistel_perm_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, n, h, (uint32_t)seed, (uint32_t)(seed >> 32), call, out);
   return aa_launch_status();
 }
 

@@ -15,7 +15,8 @@ gathers `minibatch_size` rows per step, each handed to `agent.train` as a [minib
 trajectory -- what batch(1).batch(minibatch_size) produces.  Differences, both in the data
 pipeline (whose random order no reference test pins): the permutation is per epoch (tf.data's
 shuffle buffer is filled from the repeated stream, so with a large buffer it can mix consecutive
-epochs), and in multi-GPU runs every rank runs all of ITS minibatches (one process per GPU with
+epochs) and comes from the package's own documented generator (aa_random_permutation: a Feistel
+network keyed by Philox4x32-10(seed, epoch counter), restated in oracle/perm.py), and in multi-GPU runs every rank runs all of ITS minibatches (one process per GPU with
 its own replay shard) instead of dividing one dataset's batches by the replica count.
 """
 import ctypes
@@ -58,7 +59,8 @@ class PPOLearner:
             use_kwargs_in_agent_train=use_kwargs_in_agent_train, strategy=strategy)
         self.num_replicas = self._generic_learner.strategy.num_replicas_in_sync
         self.num_frames_for_training = 0
-        self._gen = None
+        self._perm = None
+        self._perm_calls = 0      # Philox call counter of the shuffle: one permutation per epoch
         self._seed = seed
         self._train_iter = None
         self._norm_iter = None
@@ -105,9 +107,8 @@ class PPOLearner:
             frames = nest_utils.map_structure(lambda *ts_: torch.cat(ts_, dim=0), *flat)
         F = int(frames.discount.shape[0])
         dev = frames.discount.device
-        if self._gen is None:
-            self._gen = torch.Generator(device=dev)
-            self._gen.manual_seed(self._seed)
+        if self._perm is None or self._perm.numel() != F:
+            self._perm = torch.empty((F,), dtype=torch.int64, device=dev)
         # minibatches are gathered into ONE persistent buffer set: the train step's HIP graph is
         # bound to these addresses and replays without input copies (utils/graph.py)
         key = (mb, tuple((tuple(t.shape[1:]), t.dtype) for t in nest_utils.flatten(frames)))
@@ -126,8 +127,16 @@ class PPOLearner:
         c_dst = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dsts])
         c_rb = (ctypes.c_int64 * n)(*[t.element_size() * int(t[0].numel()) for t in srcs])
         lib = _lib.load()
+        perm = self._perm
         for _ in range(self._num_epochs):
-            perm = torch.randperm(F, device=dev, generator=self._gen)
+            # one pseudo-random permutation of the F frames per epoch, computed index by index on
+            # the device (csrc/replay.hip: Feistel network keyed by Philox; oracle/perm.py) -- no
+            # sort, no torch arithmetic
+            with torch.cuda.device(dev):
+                _lib.check(lib.aa_random_permutation(F, self._seed & 0xFFFFFFFFFFFFFFFF,
+                                                     self._perm_calls, perm.data_ptr(),
+                                                     _lib.stream_ptr()), "aa_random_permutation")
+            self._perm_calls += 1
             for i in range(F // mb):
                 idx = perm[i * mb:(i + 1) * mb]
                 with torch.cuda.device(dev):

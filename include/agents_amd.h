@@ -84,6 +84,12 @@ int aa_rb_gather_rows(const void* const* leaf_tables_h, void* const* leaf_out_h,
                       const int64_t* leaf_row_bytes_h, int n_leaves, const int64_t* id_table,
                       int64_t* ids_out, const int64_t* rows, int64_t n_rows, void* stream);
 
+/* out[i], i in [0, n): a pseudo-random permutation of [0, n) computed index by index (4-round
+ * Feistel network keyed by Philox4x32-10(seed, call), cycle-walked into range; oracle/perm.py) --
+ * the per-epoch shuffle of PPOLearner's minibatches (train/ppo_learner.py:228-247: tf.data
+ * shuffle, order unpinned by the reference) without a device sort. */
+int aa_random_permutation(int64_t n, uint64_t seed, uint64_t call, int64_t* out, void* stream);
+
 /* Table.write with explicit rows: table[rows[r]] = values[r] for every leaf (table.py:112-137).
  * Rows must be distinct. */
 int aa_rb_write_rows(void* const* leaf_tables_h, const void* const* leaf_values_h,
@@ -497,6 +503,18 @@ int aa_sac_actor_loss(const float* q1, const float* q2, const float* logp, const
 int aa_sac_alpha_loss(const float* logp, const float* weights, const float* log_alpha_dev,
                       float target_entropy, int32_t use_log_alpha, float loss_weight, int64_t B,
                       float global_batch, float* loss_out, float* grad_out, void* stream);
+
+/* LossInfo packing (one launch instead of clone + add + clone on the agents' train paths):
+ * aa_pack_small_f32: out[0..n) = src[0..n), out[n] = addend ? *addend : 0, out[add_at] += out[n]
+ *   (PPOAgent: the loss kernel's stats vector + the l2 regularisation term, ppo_agent.py:566-615);
+ * aa_pack_sum3_f32: out4 = [a + b + c, a, b, c] (SacAgent._train total, sac_agent.py:296-330). */
+int aa_pack_small_f32(const float* src, int32_t n, const float* addend, int32_t add_at, float* out,
+                      void* stream);
+int aa_pack_sum3_f32(const float* a, const float* b, const float* c, float* out4, void* stream);
+/* out[r, c] = a[r*lda + c] + b[r*ldb + c] (out dense [rows, cols]): d loss / d action through the
+ * twin critics of SAC, summed (sac_agent.py:599-640: tape.gradient through both Q networks). */
+int aa_add_strided_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows,
+                       int64_t cols, float* out, void* stream);
 
 /* =========================================================================================
  * Tensor normalisers   (tf_agents/utils/tensor_normalizer.py)

@@ -352,3 +352,20 @@ def test_ppo_loss_vs_autograd(dev, N, D, vclip):
     np.testing.assert_allclose(dvv.cpu().numpy(), gv, rtol=1e-5, atol=1e-9)
     got_sb = db.cpu().double().sum(0).numpy()
     np.testing.assert_allclose(got_sb, gsb, rtol=2e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 4096, 26419, 264192])
+def test_random_permutation_matches_oracle(dev, n):
+    """aa_random_permutation (PPOLearner's per-epoch shuffle) == oracle/perm.py bit for bit, and is
+    a permutation."""
+    from agents_amd import _lib
+    from oracle import perm as operm
+    lib = _lib.load()
+    out = torch.empty((n,), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        for call in (0, 3):
+            _lib.check(lib.aa_random_permutation(n, 0xDEADBEEF12345, call, out.data_ptr(),
+                                                 _lib.stream_ptr()), "aa_random_permutation")
+            got = out.cpu().numpy()
+            assert np.array_equal(got, operm.random_permutation(n, 0xDEADBEEF12345, call))
+            assert np.array_equal(np.sort(got), np.arange(n))

@@ -21,14 +21,57 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--envs", type=int, default=2048)
-    ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--minibatch", type=int, default=4096)
-    ap.add_argument("--epochs", type=int, default=10)
-    ap.add_argument("--iters", type=int, default=3)
-    args = ap.parse_args()
+def cpu_baseline(minibatch, steps, threads):
+    """torch-CPU restatement of one PPOClipAgent minibatch step (oracle/ppo.py losses, autograd,
+    global-norm clip, oracle Adam) on the same (64, 64) tanh MLPs and shapes: steps/s."""
+    import numpy as np
+    from oracle import optim as ooptim
+    from oracle import ppo as oppo
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(0)
+    N, D = minibatch, 6
+
+    def mlp(sizes):
+        ps = []
+        for a, b in zip(sizes[:-1], sizes[1:]):
+            ps += [(torch.randn(a, b, generator=g) / a ** 0.5).requires_grad_(True),
+                   torch.zeros(b, requires_grad=True)]
+        return ps
+    actor, value = mlp([17, 64, 64, D]), mlp([17, 64, 64, 1])
+    sb = torch.zeros(D, requires_grad=True)
+    params = actor + [sb] + value
+    opt = ooptim.Adam(3e-4, eps=1e-5)
+    obs = torch.randn(N, 17, generator=g)
+    acts, old_loc = torch.randn(N, D, generator=g), torch.randn(N, D, generator=g) * 0.1
+    old_scale = torch.ones(N, D)
+    old_logp = oppo.normal_log_prob(old_loc, old_scale, acts)
+    adv, ret = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    w = torch.ones(N)
+
+    def fwd(ps, x):
+        h = x
+        for i in range(0, len(ps) - 2, 2):
+            h = torch.tanh(h @ ps[i] + ps[i + 1])
+        return h @ ps[-2] + ps[-1]
+
+    def one():
+        loc = torch.tanh(fwd(actor, obs))
+        scale = torch.nn.functional.softplus(sb).expand_as(loc)
+        val = fwd(value, obs)[:, 0]
+        out = oppo.losses(loc, scale, acts, old_logp, adv, ret, val, w, clip_eps=0.2, c_v=0.5)
+        grads = torch.autograd.grad(out["total"], params)
+        gn = torch.sqrt(sum((x ** 2).sum() for x in grads))
+        sc = 0.5 * min(1.0 / float(gn), 1.0 / 0.5)
+        opt.step(params, [x * sc for x in grads])
+
+    one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    return steps / (time.perf_counter() - t0)
+
+
+def run(args):
     from agents_amd import optimizers
     from agents_amd.agents.ppo import ppo_actor_network as pan
     from agents_amd.agents.ppo import ppo_clip_agent
@@ -51,9 +94,9 @@ def main():
     agent = ppo_clip_agent.PPOClipAgent(
         tss, act, optimizers.Adam(3e-4, epsilon=1e-5), actor_net=actor, value_net=value,
         importance_ratio_clipping=0.2, lambda_value=0.95, discount_factor=0.99, use_gae=True,
-        num_epochs=1, gradient_clipping=0.5, normalize_observations=False,
-        normalize_rewards=False, compute_value_and_advantage_in_train=False,
-        update_normalizers_in_train=False)
+        num_epochs=1, gradient_clipping=0.5, normalize_observations=True,
+        normalize_rewards=True, compute_value_and_advantage_in_train=False,
+        update_normalizers_in_train=False)     # schulman17/train_eval_lib.py:197-226 defaults
     agent.initialize()
     env = random_tf_environment.RandomTFEnvironment(tss, act, batch_size=B,
                                                     episode_end_probability=1e-3, seed=3, device=dev)
@@ -102,6 +145,20 @@ def main():
            "train_s_per_iteration": tt / args.iters,
            "minibatch_steps_per_iteration": steps // args.iters,
            "iteration_s": (tc + tt) / args.iters, "final_loss": loss, "n_gpus": 1}
+    out["frames_per_iteration"] = frames
+    out["agent"] = agent
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--minibatch", type=int, default=4096)
+    ap.add_argument("--epochs", type=int, default=10)
+    ap.add_argument("--iters", type=int, default=3)
+    out = run(ap.parse_args())
+    out.pop("agent")
     print(json.dumps(out))
 
 

@@ -17,13 +17,35 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--envs", type=int, default=4096)
-    ap.add_argument("--max-length", type=int, default=64)
-    ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--iters", type=int, default=200)
-    args = ap.parse_args()
+def cpu_baseline(batch, steps, threads):
+    """oracle/sac.py's OracleSacAgent.train (torch-CPU autograd, three Adam steps, soft target
+    update) on the same shapes: learner steps/s."""
+    from oracle import nets as onets
+    from oracle import sac as osac
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(0)
+    O, A, B = 376, 17, batch
+    al, cl = onets.mlp_q_layers((256, 256), 2 * A, "relu"), onets.mlp_q_layers((256, 256), 1, "relu")
+    ag = osac.OracleSacAgent(O, A, (256, 256), (256, 256), [0.0] * A, [0.4] * A,
+                             onets.init_params(al, (O,), seed=1),
+                             onets.init_params(cl, (O + A,), seed=2),
+                             onets.init_params(cl, (O + A,), seed=3), reward_scale_factor=0.1,
+                             std_kind="clip_exp")
+    r = lambda *s: torch.randn(*s, generator=g)
+    obs, nobs, act = r(B, O), r(B, O), r(B, A).clamp(-0.4, 0.4)
+    rew, disc = r(B), torch.ones(B)
+
+    def one():
+        ag.train(obs, act, nobs, rew, disc, r(B, A), r(B, A), r(B, A))
+
+    one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    return steps / (time.perf_counter() - t0)
+
+
+def run(args):
     from agents_amd import optimizers
     from agents_amd.agents.sac import sac_agent
     from agents_amd.drivers import dynamic_step_driver
@@ -84,13 +106,22 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.iters
     row = 4 + 376 * 4 + 17 * 4 + 4 + 4 + 4
-    print(json.dumps({
+    return ({
         "workload": "configs[4] at 1 GPU: SAC Humanoid-shaped, %d envs, batch %d, actor/critics "
                     "(256,256)" % (args.envs, args.batch),
         "ms_per_iteration": dt * 1e3, "learner_steps_per_sec": 1.0 / dt,
         "env_steps_per_sec": args.envs / dt, "trained_transitions_per_sec": args.batch / dt,
         "replay_row_bytes": row, "final_loss": float(li.loss), "n_gpus": 1,
-        "train_graph_replays": graph.graphed_train(agent).replays}))
+        "train_graph_replays": graph.graphed_train(agent).replays})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--max-length", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=200)
+    print(json.dumps(run(ap.parse_args())))
 
 
 if __name__ == "__main__":
