@@ -72,11 +72,18 @@ _SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "aa_rb_write_rows": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int,
                                  c_void_p, c_int64, c_void_p]),
+    "aa_rb_compact_append": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int,
+                                     c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p,
+                                     c_void_p]),
+    "aa_rb_compact_take": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int,
+                                   c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "aa_random_permutation": (c_int, [c_int64, c_uint64, c_uint64, c_void_p, c_void_p]),
     "aa_rb_range_rows": (c_int, [c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "aa_counter_add": (c_int, [c_void_p, c_int64, c_void_p]),
     "aa_gemm_f32_workspace_bytes": (c_int64, [POINTER(GemmDesc)]),
     "aa_gemm_f32": (c_int, [POINTER(GemmDesc), c_void_p, c_int64, c_void_p]),
+    "aa_gemm_f32_slabs": (c_int, [POINTER(GemmDesc), c_void_p, c_int64, POINTER(c_int32),
+                                  c_void_p]),
     "aa_conv_pair_supported": (c_int, [c_int32, c_int32, c_int32, c_int32, POINTER(ConvLayerDesc),
                                        POINTER(ConvLayerDesc)]),
     "aa_conv_pair_forward": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
@@ -92,6 +99,9 @@ _SIGNATURES = {
     "aa_conv_dx_frame_x6": (c_int, [POINTER(ConvDxDesc), c_void_p, c_int64, c_void_p]),
     "aa_dense_small_forward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64,
                                        c_int32, c_int32, c_void_p, c_void_p]),
+    "aa_dense_small_forward_slabs": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int32,
+                                             c_void_p, c_int64, c_void_p, c_void_p, c_int32,
+                                             c_int32, c_void_p, c_void_p]),
     "aa_dense_small_dx": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
                                   c_void_p, c_void_p]),
     "aa_dense_small_dw": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p,
@@ -208,7 +218,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 7:
+    if lib.aa_abi_version() != 8:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -203,7 +203,7 @@ class DqnAgent(tf_agent.TFAgent):
         main = torch.cuda.current_stream(dev)
         side = self._side_stream(dev)
         side.wait_stream(main)
-        with torch.cuda.stream(side):
+        with ops.side_line(side):
             q_next_target = self._target_q_network.forward(obs_next, slot="train")
         q_online = self._q_network.forward(obs_t, slot="train", need_grad=need_grad)
         q_next_select = None

@@ -74,6 +74,72 @@ aa_dense_small_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float*
   }
 }
 
+// The same head, reading its input as the raw split-K slabs of the layer below:
+//   h[m,k] = act1( sum_z slab[z][m][k] + bias1[k] )  (written out: the backward pass needs it)
+//   y[m,n] = act2( sum_k h[m,k] W[k,n] + b[n] )
+// The slab sum is the "launch-boundary reduce" done in the consumer's prologue: the separate
+// aa_splitk_reduce launch (and its round trip of h through memory before the head reads it) goes
+// away.  z-order sum from 0.f, bias, activation: the arithmetic of aa_splitk_reduce_kernel<*,1>;
+// the head's accumulation order is aa_dense_small_fwd_kernel's -- both results are bit-identical
+// to the two-launch path.  One wave per row, one row per workgroup (256 rows -> 256 CUs).
+template <int N>
+__global__ void __launch_bounds__(64)
+aa_dense_small_fwd_slabs_kernel(const float* __restrict__ slab, int splits, int64_t M, int K,
+                                const float* __restrict__ bias1, int act1,
+                                float* __restrict__ h, int64_t ldh, const float* __restrict__ w,
+                                const float* __restrict__ bias, int act, float* __restrict__ y) {
+  const int lane = threadIdx.x;
+  const int64_t m = blockIdx.x;
+  const size_t MK = (size_t)M * K;
+  float acc[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) acc[n] = 0.f;
+  for (int k = 4 * lane; k < K; k += 256) {
+    const float* src = slab + (size_t)m * K + k;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    int z = 0;
+    for (; z + 3 < splits; z += 4) {   // four slab loads in flight, added in z order
+      float4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const float4*>(src + (size_t)(z + u) * MK);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
+    }
+    for (; z < splits; ++z) {
+      const float4 t = *reinterpret_cast<const float4*>(src + (size_t)z * MK);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (bias1 != nullptr) {
+      v.x += bias1[k]; v.y += bias1[k + 1]; v.z += bias1[k + 2]; v.w += bias1[k + 3];
+    }
+    v.x = aa_sm_act(v.x, act1); v.y = aa_sm_act(v.y, act1);
+    v.z = aa_sm_act(v.z, act1); v.w = aa_sm_act(v.w, act1);
+    *reinterpret_cast<float4*>(h + m * ldh + k) = v;
+    const float* wk = w + (size_t)k * N;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      acc[n] = fmaf(v.x, wk[n], acc[n]);
+      acc[n] = fmaf(v.y, wk[N + n], acc[n]);
+      acc[n] = fmaf(v.z, wk[2 * N + n], acc[n]);
+      acc[n] = fmaf(v.w, wk[3 * N + n], acc[n]);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    float v = acc[n];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    acc[n] = v;
+  }
+  if (lane < N) {
+    float v = 0.f;
+#pragma unroll
+    for (int n = 0; n < N; ++n) v = (lane == n) ? acc[n] : v;
+    if (bias != nullptr) v += bias[lane];
+    y[m * N + lane] = aa_sm_act(v, act);
+  }
+}
+
 template <int N>
 __global__ void __launch_bounds__(256)
 aa_dense_small_dx_kernel(const float* __restrict__ dz, const float* __restrict__ w,
@@ -198,6 +264,32 @@ int aa_dense_small_forward(const float* x, int64_t ldx, const float* w, const fl
   if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0 || ldx < K) return AA_ERR_INVALID;
   if (N > AA_SMALLN_MAX) return AA_ERR_RANGE;
   return aa_small_dispatch(N, 0, x, ldx, w, bias, act, M, K, y, nullptr, (hipStream_t)stream);
+}
+
+int aa_dense_small_forward_slabs(const float* slabs, int32_t splits, int64_t M, int32_t K,
+                                 const float* bias1, int32_t act1, float* h, int64_t ldh,
+                                 const float* w, const float* bias, int32_t act, int32_t N,
+                                 float* y, void* stream) {
+  if (!slabs || !h || !w || !y || splits < 1 || M <= 0 || K <= 0 || N <= 0 || ldh < K)
+    return AA_ERR_INVALID;
+  if (N > AA_SMALLN_MAX || M > 0x7fffffffLL) return AA_ERR_RANGE;
+  // 16-byte rows everywhere: the slab sum is a float4 stream
+  if ((K & 3) != 0 || (ldh & 3) != 0 || (((uintptr_t)slabs | (uintptr_t)h) & 15) != 0)
+    return AA_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  switch (N) {
+#define AA_SM_TAIL(NN)                                                                          \
+    case NN:                                                                                    \
+      hipLaunchKernelGGL((aa_dense_small_fwd_slabs_kernel<NN>), dim3((unsigned)M), dim3(64), 0, \
+                         st, slabs, splits, M, K, bias1, act1, h, ldh, w, bias, act, y);        \
+      break;
+    AA_SM_TAIL(1) AA_SM_TAIL(2) AA_SM_TAIL(3) AA_SM_TAIL(4) AA_SM_TAIL(5) AA_SM_TAIL(6)
+    AA_SM_TAIL(7) AA_SM_TAIL(8) AA_SM_TAIL(9) AA_SM_TAIL(10) AA_SM_TAIL(11) AA_SM_TAIL(12)
+    AA_SM_TAIL(13) AA_SM_TAIL(14) AA_SM_TAIL(15) AA_SM_TAIL(16)
+#undef AA_SM_TAIL
+    default: return AA_ERR_RANGE;
+  }
+  return aa_launch_status();
 }
 
 int aa_dense_small_dx(const float* dz, const float* w, const float* mask_src, int32_t mask_kind,

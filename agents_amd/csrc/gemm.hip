@@ -954,7 +954,11 @@ int64_t aa_gemm_f32_workspace_bytes(const aa_gemm_desc* d) {
   return (int64_t)pl.ws_bytes;
 }
 
-int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes, void* stream) {
+// defer_splits != nullptr: when the plan is split-K, stop after the main launch -- the raw slabs
+// [splits][M][N] stay at the start of `workspace` for a consumer that sums them in its own prologue
+// (*defer_splits = splits); with one split the finished result is in C (*defer_splits = 1).
+static int aa_gemm_f32_impl(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
+                            void* stream, int* defer_splits) {
   if (d == nullptr || d->A == nullptr || d->B == nullptr || d->C == nullptr) return AA_ERR_INVALID;
   AaGemmPlan pl;
   int rc = aa_gemm_plan(d, &pl);
@@ -1139,6 +1143,10 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
     default: return AA_ERR_INVALID;
   }
   if (rc != AA_OK) return rc;
+  if (defer_splits != nullptr) {
+    *defer_splits = pl.splits;
+    return rc;
+  }
   if (pl.splits > 1) {
     const size_t MN = (size_t)d->M * d->N;
     const bool vec = d->N % 4 == 0 && d->ldc % 4 == 0 && (((uintptr_t)d->C & 15) == 0) &&
@@ -1160,6 +1168,22 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
 #undef AA_LAUNCH_REDUCE
     rc = aa_launch_status();
   }
+  return rc;
+}
+
+int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes, void* stream) {
+  return aa_gemm_f32_impl(d, workspace, workspace_bytes, stream, nullptr);
+}
+
+int aa_gemm_f32_slabs(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
+                      int32_t* splits_out, void* stream) {
+  if (d == nullptr || splits_out == nullptr) return AA_ERR_INVALID;
+  // the consumer applies bias / activation itself; fused column sums and masks belong to the
+  // backward contractions, which keep the reduce launch
+  if (d->colsum_out != nullptr || d->mask_src != nullptr) return AA_ERR_INVALID;
+  int splits = 0;
+  const int rc = aa_gemm_f32_impl(d, workspace, workspace_bytes, stream, &splits);
+  *splits_out = splits;
   return rc;
 }
 

@@ -167,6 +167,48 @@ aa_rb_write_kernel(AaLeafSet leaves, const int64_t* __restrict__ rows, int n_chu
   }
 }
 
+// ---- tf.data `.unbatch().filter(pred).batch(n)` on device (stream compaction) ----------------------
+// The SAC script drops sampled transitions whose first step is an episode boundary and re-batches
+// the survivors (agents/sac/examples/v2/train_eval.py:285-296).  keep[s] is the predicate of
+// sample s; survivor number k of this batch (k = #keep[0..s)) lands in row (tail + k) mod capacity
+// of a ring of pending rows, in source order; the take kernel copies rows head.. out.  The host
+// keeps head / tail (it has to learn the survivor count anyway to know when a batch is complete).
+__global__ void __launch_bounds__(AA_RB_THREADS)
+aa_rb_compact_append_kernel(AaLeafSet leaves, const uint8_t* __restrict__ keep, int64_t n_src,
+                            int64_t tail, int64_t capacity, int64_t* __restrict__ kept_out,
+                            int n_chunks) {
+  __shared__ int part[AA_RB_THREADS / 64];
+  const int64_t s = blockIdx.x / n_chunks;
+  const int chunk = blockIdx.x % n_chunks;
+  int before = 0;
+  for (int64_t i = threadIdx.x; i < s; i += AA_RB_THREADS) before += keep[i] != 0;
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = before;
+  __syncthreads();
+  int64_t pos = 0;
+  for (int w = 0; w < AA_RB_THREADS / 64; ++w) pos += part[w];
+  const bool mine = keep[s] != 0;
+  if (chunk == 0 && threadIdx.x == 0 && s == n_src - 1 && kept_out != nullptr)
+    *kept_out = pos + (mine ? 1 : 0);
+  if (!mine) return;
+  const int64_t row = (tail + pos) % capacity;
+  for (int l = 0; l < leaves.n; ++l) {
+    const int64_t rb = leaves.row_bytes[l];
+    aa_copy_row_chunk<false, false>(leaves.io[l] + s * rb, leaves.table[l] + row * rb, rb, chunk);
+  }
+}
+
+__global__ void __launch_bounds__(AA_RB_THREADS)
+aa_rb_compact_take_kernel(AaLeafSet leaves, int64_t head, int64_t capacity, int n_chunks) {
+  const int64_t r = blockIdx.x / n_chunks;
+  const int chunk = blockIdx.x % n_chunks;
+  const int64_t row = (head + r) % capacity;
+  for (int l = 0; l < leaves.n; ++l) {
+    const int64_t rb = leaves.row_bytes[l];
+    aa_copy_row_chunk<false, false>(leaves.table[l] + row * rb, leaves.io[l] + r * rb, rb, chunk);
+  }
+}
+
 // ---- uniform sampling of (start id, env block) pairs -----------------------------------------
 // Stream definition (canonical for this package; see oracle/replay.py):
 //   (x0,x1,x2,x3) = Philox4x32-10(counter = (s_lo, s_hi, call_lo, call_hi), key = (seed_lo, seed_hi))
@@ -402,6 +444,46 @@ int aa_rb_gather_rows(const void* const* leaf_tables_h, void* const* leaf_out_h,
   if (grid > 0x7fffffffLL) return AA_ERR_RANGE;
   hipLaunchKernelGGL(aa_rb_gather_kernel, dim3((unsigned)grid), dim3(AA_RB_THREADS), 0,
                      (hipStream_t)stream, ls, id_table, ids_out, rows, n_chunks);
+  return aa_launch_status();
+}
+
+int aa_rb_compact_append(void* const* pending_h, const void* const* src_h,
+                         const int64_t* leaf_row_bytes_h, int n_leaves, const uint8_t* keep,
+                         int64_t n_src, int64_t tail, int64_t count, int64_t capacity,
+                         int64_t* kept_out_dev, void* stream) {
+  if (n_src < 0 || capacity <= 0 || tail < 0 || tail >= capacity || count < 0) return AA_ERR_INVALID;
+  if (count + n_src > capacity) return AA_ERR_RANGE;  // every source row may survive
+  if (n_src == 0) return AA_OK;
+  if (keep == nullptr) return AA_ERR_INVALID;
+  AaLeafSet ls;
+  int64_t max_rb = 0;
+  int rc = aa_fill_leaves(ls, pending_h, (void* const*)src_h, leaf_row_bytes_h, n_leaves, &max_rb);
+  if (rc != AA_OK) return rc;
+  int n_chunks = (int)((max_rb + AA_RB_CHUNK - 1) / AA_RB_CHUNK);
+  if (n_chunks < 1) n_chunks = 1;
+  const int64_t grid = n_src * n_chunks;
+  if (grid > 0x7fffffffLL) return AA_ERR_RANGE;
+  hipLaunchKernelGGL(aa_rb_compact_append_kernel, dim3((unsigned)grid), dim3(AA_RB_THREADS), 0,
+                     (hipStream_t)stream, ls, keep, n_src, tail, capacity, kept_out_dev, n_chunks);
+  return aa_launch_status();
+}
+
+int aa_rb_compact_take(const void* const* pending_h, void* const* out_h,
+                       const int64_t* leaf_row_bytes_h, int n_leaves, int64_t head, int64_t n_rows,
+                       int64_t count, int64_t capacity, void* stream) {
+  if (n_rows < 0 || capacity <= 0 || head < 0 || head >= capacity) return AA_ERR_INVALID;
+  if (n_rows > count || count > capacity) return AA_ERR_RANGE;
+  if (n_rows == 0) return AA_OK;
+  AaLeafSet ls;
+  int64_t max_rb = 0;
+  int rc = aa_fill_leaves(ls, (void* const*)pending_h, out_h, leaf_row_bytes_h, n_leaves, &max_rb);
+  if (rc != AA_OK) return rc;
+  int n_chunks = (int)((max_rb + AA_RB_CHUNK - 1) / AA_RB_CHUNK);
+  if (n_chunks < 1) n_chunks = 1;
+  const int64_t grid = n_rows * n_chunks;
+  if (grid > 0x7fffffffLL) return AA_ERR_RANGE;
+  hipLaunchKernelGGL(aa_rb_compact_take_kernel, dim3((unsigned)grid), dim3(AA_RB_THREADS), 0,
+                     (hipStream_t)stream, ls, head, capacity, n_chunks);
   return aa_launch_status();
 }
 

@@ -349,8 +349,18 @@ class Sequential(network.Network):
                         "leading Conv2D only)")
                 cur2 = cur.reshape(B, -1)
                 s.xs[pi] = cur2
-                ops.dense_forward(cur2, self._kviews[pi], self._bviews[pi], l.activation,
-                                  s.ys[pi])
+                nxt = self._layers[li + 1] if li + 1 < len(self._layers) else None
+                if (isinstance(nxt, L.Dense) and pi + 1 < len(self._kviews)
+                        and ops.dense_tail_supported(cur2, self._kviews[pi], self._kviews[pi + 1])):
+                    # hidden layer + small head: the head sums the hidden layer's split-K slabs
+                    s.xs[pi + 1] = s.ys[pi]
+                    ops.dense_tail_forward(cur2, self._kviews[pi], self._bviews[pi], l.activation,
+                                           s.ys[pi], self._kviews[pi + 1], self._bviews[pi + 1],
+                                           nxt.activation, s.ys[pi + 1])
+                    skip = True
+                else:
+                    ops.dense_forward(cur2, self._kviews[pi], self._bviews[pi], l.activation,
+                                      s.ys[pi])
                 cur = s.ys[pi]
                 pi += 1
         return cur
@@ -477,7 +487,7 @@ class Sequential(network.Network):
                 return fn()
             if fork:
                 side_stream.wait_stream(main)  # dZ of this layer is ready once main gets here
-            with torch.cuda.stream(side_stream):
+            with ops.side_line(side_stream):
                 return fn()
 
         for i in range(hi, lo - 1, -1):

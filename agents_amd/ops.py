@@ -4,6 +4,7 @@ These take torch device tensors, validate shape / dtype / contiguity, and enqueu
 torch's current stream.  No arithmetic happens in torch; there is no CPU fallback.
 """
 import ctypes
+import itertools
 
 import torch
 
@@ -18,19 +19,18 @@ ACT = {None: AA_ACT_NONE, "none": AA_ACT_NONE, "linear": AA_ACT_NONE, "relu": AA
 
 
 class _Workspace:
-    """Grow-only scratch buffer per (device, stream): split-K slabs, column-sum partials.  GEMMs
-    enqueued on different streams run concurrently, so each stream owns its scratch."""
+    """Grow-only scratch buffer per (device, scope, line of execution): split-K slabs, column-sum
+    partials.  GEMMs enqueued on a side line (`side_line`) run concurrently with the caller's, so
+    each line owns its scratch; so does each `workspace_scope`.  Lines are named by the code that
+    forks them, not by the stream handle: torch hands out stream handles from a small pool, so a
+    graph-capture stream may well share its handle with some agent's side stream."""
 
     def __init__(self):
         self._buf = {}
         self._retired = []  # outgrown buffers stay alive: captured HIP graphs may point at them
 
     def get(self, nbytes, device):
-        # registered side streams own a scratch each; every other stream (the default stream, a
-        # graph-capture stream) is the "main" line of execution and shares one
-        sid = torch.cuda.current_stream(device).cuda_stream
-        key = (device.type, device.index,
-               _SCOPE if _SCOPE is not None else (sid if sid in _SIDE_STREAMS else 0))
+        key = (device.type, device.index, _SCOPE, _LINE)
         buf = self._buf.get(key)
         if buf is None or buf.numel() < nbytes:
             if torch.cuda.is_current_stream_capturing():
@@ -42,11 +42,10 @@ class _Workspace:
             self._buf[key] = buf
         return buf
 
-
     def reserve(self, tag, device):
         """Gives scope `tag` its own buffer, as large as the main line's current one."""
-        main = self._buf.get((device.type, device.index, 0))
-        key = (device.type, device.index, tag)
+        main = self._buf.get((device.type, device.index, None, None))
+        key = (device.type, device.index, tag, None)
         need = main.numel() if main is not None else 1 << 20
         if key not in self._buf or self._buf[key].numel() < need:
             if key in self._buf:
@@ -54,18 +53,21 @@ class _Workspace:
             self._buf[key] = torch.empty(need, dtype=torch.uint8, device=device)
 
 
-_SIDE_STREAMS = set()
 _SCOPE = None
+_LINE = None
+_LINE_IDS = itertools.count(1)
 
 
 class workspace_scope:
     """Kernels launched (or captured into a HIP graph) inside this context take their split-K /
-    column-sum scratch from a buffer private to `tag` instead of the caller stream's: a graph that
-    will replay concurrently with other GEMM work (the collect graph next to the train graphs,
+    column-sum scratch from a buffer private to `tag` instead of the caller's: a graph that will
+    replay concurrently with other GEMM work (the collect graph next to the train graphs,
     agents_amd/utils/graph.py: Lanes) must not share slabs with it."""
 
     def __init__(self, tag, device):
         self._tag, self._device = tag, torch.device(device)
+        if self._device.type == "cuda" and self._device.index is None:
+            self._device = torch.device("cuda", torch.cuda.current_device())
 
     def __enter__(self):
         global _SCOPE
@@ -83,11 +85,37 @@ class workspace_scope:
         return False
 
 
+class SideStream(torch.cuda.Stream):
+    """A stream for work that overlaps with the caller's stream (fork / join by wait_stream); enter
+    it with `side_line` so that its kernels take their scratch from the line's own buffers."""
+
+
 def new_side_stream(device):
-    """A stream for work that overlaps with the caller's stream (fork/join by wait_stream)."""
-    st = torch.cuda.Stream(device=device)
-    _SIDE_STREAMS.add(st.cuda_stream)
+    st = SideStream(device=device)
+    st.aa_line = next(_LINE_IDS)
     return st
+
+
+class side_line:
+    """`with side_line(stream):` = `with torch.cuda.stream(stream):` + the workspaces of that line."""
+
+    def __init__(self, stream):
+        self._stream = stream
+        self._ctx = torch.cuda.stream(stream)
+
+    def __enter__(self):
+        global _LINE
+        self._prev = _LINE
+        line = getattr(self._stream, "aa_line", None)
+        _LINE = line if line is not None else ("handle", self._stream.cuda_stream)
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        global _LINE
+        self._ctx.__exit__(*exc)
+        _LINE = self._prev
+        return False
 
 
 _WS = _Workspace()
@@ -180,6 +208,50 @@ def dense_forward(x, w, bias, act, out, a_div=None, force_cfg=0, force_splits=0)
                   force_cfg=force_cfg, force_splits=force_splits)
     gemm(d, x.device)
     return out
+
+
+# Dense(hidden) -> Dense(<= SMALL_N units): the head sums the hidden layer's split-K slabs itself
+# (one launch less per forward pass and no round trip of the hidden activation); test / A-B knob
+FUSE_DENSE_TAIL = _os.environ.get("AA_FUSE_DENSE_TAIL", "1") != "0"
+
+
+def dense_tail_supported(x, w1, w2):
+    K1, H = w1.shape
+    return (FUSE_DENSE_TAIL and USE_SMALL_N and w2.shape[0] == H and w2.shape[1] <= SMALL_N
+            and H > SMALL_N and H % 4 == 0 and x.dtype == torch.float32)
+
+
+def dense_tail_forward(x, w1, b1, act1, h, w2, b2, act2, y):
+    """h[M,H] = act1(x[M,K] @ w1 + b1); y[M,N] = act2(h @ w2 + b2), N <= SMALL_N.  Two launches
+    when the first contraction is split-K (GEMM main loop, then the head summing the slabs in its
+    prologue), otherwise the plain pair; bit-identical to dense_forward twice either way."""
+    require_cuda(x, w1, h, w2, y)
+    lda = _rows_ok(x, "x"); _f32c(w1, "w1"); _f32c(h, "h"); _f32c(w2, "w2"); _f32c(y, "y")
+    M, K = x.shape
+    K2, H = w1.shape
+    H2, N = w2.shape
+    if K != K2 or H != H2 or tuple(h.shape) != (M, H) or tuple(y.shape) != (M, N):
+        raise ValueError("dense_tail_forward shape mismatch")
+    lib = _lib.load()
+    d = gemm_desc(A=ptr(x), B=ptr(w1), C=ptr(h), M=M, N=H, K=K, lda=lda, ldb=H, ldc=H,
+                  a_mode=AA_A_ROW, b_mode=AA_B_ROW, bias=ptr(b1), act=ACT[act1])
+    if FORCE_NO_DMA or (_DMA_MODES is not None and d.a_mode not in _DMA_MODES):
+        d.no_dma = 1
+    need = lib.aa_gemm_f32_workspace_bytes(ctypes.byref(d))
+    if need < 0:
+        raise ValueError("aa_gemm_f32: invalid descriptor (M,N,K must be positive)")
+    ws = _WS.get(need, x.device) if need > 0 else None
+    splits = ctypes.c_int32(0)
+    check(lib.aa_gemm_f32_slabs(ctypes.byref(d), ptr(ws), ws.numel() if ws is not None else 0,
+                                ctypes.byref(splits), stream_ptr()), "aa_gemm_f32_slabs")
+    if splits.value > 1:
+        check(lib.aa_dense_small_forward_slabs(
+            ptr(ws), splits.value, M, H, ptr(b1), ACT[act1], ptr(h), H, ptr(w2), ptr(b2),
+            ACT[act2], N, ptr(y), stream_ptr()), "aa_dense_small_forward_slabs")
+    else:
+        check(lib.aa_dense_small_forward(ptr(h), H, ptr(w2), ptr(b2), ACT[act2], M, H, N, ptr(y),
+                                         stream_ptr()), "aa_dense_small_forward")
+    return y
 
 
 def dense_dx(dz, w, out, mask_src=None, mask_act=None, force_cfg=0, force_splits=0):

@@ -6,18 +6,210 @@ The scripts chain a few combinators on it: `.prefetch(3)` then `iter()` (DQN tra
 `.take/.cache/.repeat/.map/.shuffle/.batch` (train/ppo_learner.py:220-248).  Elements are nests of
 device tensors; `prefetch(n)` enqueues n elements ahead on the HIP stream (sampling kernels are
 asynchronous, so running ahead is what hides their latency).
+
+`.unbatch().filter(pred).batch(n)` over batches of device tensors does not touch single elements:
+the predicate is evaluated once per sampled batch (batch axis moved last, so a predicate written
+for one element -- `~trajectories.is_boundary()[0]` -- yields one flag per sample), the surviving
+rows are compacted into a device ring by one HIP launch over all leaves and leave it n at a time
+(csrc/replay.hip: aa_rb_compact_append / aa_rb_compact_take).  The host learns one number per
+sampled batch (how many rows survived), where the element-wise combinators read every flag.
 """
 import collections
+import ctypes
+import itertools
 
 import torch
 
+from agents_amd import _lib
 from agents_amd.utils import nest_utils
+
+
+def _call(fn, e):
+    return fn(*e) if isinstance(e, tuple) and not hasattr(e, "_fields") else fn(e)
+
+
+def _is_t(l):
+    return isinstance(l, torch.Tensor)
+
+
+def _unbatched(e):
+    leaves = [l for l in nest_utils.flatten(e) if _is_t(l)]
+    for i in range(leaves[0].shape[0]):
+        yield nest_utils.map_structure(lambda l: l[i] if _is_t(l) else l, e)
+
+
+def _filtered(elems, pred):
+    for e in elems:
+        keep = _call(pred, e)
+        if _is_t(keep):
+            keep = bool(keep.item())
+        if keep:
+            yield e
+
+
+def _batched(elems, batch_size, drop_remainder):
+    buf = []
+    for e in elems:
+        buf.append(e)
+        if len(buf) == batch_size:
+            yield nest_utils.map_structure(
+                lambda *ls: torch.stack(ls, 0) if _is_t(ls[0]) else ls[0], *buf)
+            buf = []
+    if buf and not drop_remainder:
+        yield nest_utils.map_structure(
+            lambda *ls: torch.stack(ls, 0) if _is_t(ls[0]) else ls[0], *buf)
+
+
+class _RowCompactor:
+    """Ring of pending rows per tensor leaf + the host-side head / count of the stream compaction."""
+
+    MAX_LEAVES = 24  # AA_MAX_LEAVES
+
+    def __init__(self, leaves, n_out):
+        self._n_out = int(n_out)
+        self._like = [(tuple(l.shape[1:]), l.dtype) for l in leaves]
+        self._device = leaves[0].device
+        self._row_bytes = [int(l[0].numel()) * l.element_size() if l.shape[0] else 0 for l in leaves]
+        self._cap = 0
+        self._rings = None
+        self.head = 0
+        self.count = 0
+        self._kept_dev = torch.zeros(1, dtype=torch.int64, device=self._device)
+        self._kept_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self._event = torch.cuda.Event()
+        self._grow(self._n_out + int(leaves[0].shape[0]))
+
+    def matches(self, leaves):
+        return (len(leaves) == len(self._like)
+                and all(tuple(l.shape[1:]) == sh and l.dtype == dt and l.device == self._device
+                        for l, (sh, dt) in zip(leaves, self._like)))
+
+    def _alloc(self, rows):
+        return [torch.empty((rows,) + sh, dtype=dt, device=self._device) for sh, dt in self._like]
+
+    def _pack(self, tables, ios):
+        n = len(tables)
+        t = (ctypes.c_void_p * n)(*[x.data_ptr() for x in tables])
+        o = (ctypes.c_void_p * n)(*[x.data_ptr() for x in ios])
+        rb = (ctypes.c_int64 * n)(*self._row_bytes)
+        return t, o, rb, n
+
+    def _grow(self, cap):
+        if cap <= self._cap:
+            return
+        new = self._alloc(cap)
+        if self.count:
+            self._take_into(new, self.count)  # rows keep their order, now from row 0
+        self._rings, self._cap, self.head = new, cap, 0
+
+    def _take_into(self, outs, n_rows):
+        t, o, rb, n = self._pack(self._rings, outs)
+        _lib.check(_lib.load().aa_rb_compact_take(t, o, rb, n, self.head, n_rows, self.count,
+                                                  self._cap, _lib.stream_ptr()),
+                   "aa_rb_compact_take")
+
+    def append(self, leaves, keep_u8):
+        """Appends the rows of `leaves` whose flag is set; returns how many survived (one host
+        read: the caller cannot know whether a batch is complete without it)."""
+        n_src = int(leaves[0].shape[0])
+        if n_src == 0:
+            return 0
+        self._grow(self.count + n_src)
+        t, o, rb, n = self._pack(self._rings, leaves)
+        tail = (self.head + self.count) % self._cap
+        _lib.check(_lib.load().aa_rb_compact_append(
+            t, o, rb, n, keep_u8.data_ptr(), n_src, tail, self.count, self._cap,
+            self._kept_dev.data_ptr(), _lib.stream_ptr()), "aa_rb_compact_append")
+        self._kept_host.copy_(self._kept_dev, non_blocking=True)
+        self._event.record()
+        self._event.synchronize()
+        kept = int(self._kept_host[0])
+        self.count += kept
+        return kept
+
+    def take(self, n_rows):
+        outs = self._alloc(n_rows)
+        self._take_into(outs, n_rows)
+        self.head = (self.head + n_rows) % self._cap
+        self.count -= n_rows
+        return outs
+
+
+def _vector_keep(pred, e, n_src):
+    """The element predicate applied to a whole batch: with the batch axis moved LAST, indexing and
+    elementwise operations written for one element broadcast over the samples.  None when the
+    predicate does not produce one bool per sample that way."""
+    moved = nest_utils.map_structure(lambda l: l.movedim(0, -1) if _is_t(l) else l, e)
+    try:
+        k = _call(pred, moved)
+    except Exception:  # noqa: BLE001 - any failure just means "not vectorisable"
+        return None
+    if not _is_t(k) or k.dtype != torch.bool or tuple(k.shape) != (n_src,):
+        return None
+    return k.contiguous()
+
+
+def _compacted(src, pred, batch_size, drop_remainder):
+    """`.unbatch().filter(pred).batch(batch_size)` of `src`'s batched elements."""
+    it = iter(src)
+    try:
+        first = next(it)
+    except StopIteration:
+        return
+    flat = nest_utils.flatten(first)
+    leaves = [l for l in flat if _is_t(l)]
+    n_src = int(leaves[0].shape[0]) if leaves else 0
+    ok = (leaves and all(l.is_cuda and l.dim() >= 1 and l.shape[0] == n_src for l in leaves)
+          and len(leaves) <= _RowCompactor.MAX_LEAVES)
+    keep = _vector_keep(pred, first, n_src) if ok else None
+    if keep is not None and n_src > 0:
+        # trust the batched evaluation only after it reproduced the element-wise one once
+        flags = [_call(pred, e) for e in _unbatched(first)]
+        ref = torch.stack([f.reshape(()) if _is_t(f) else torch.tensor(bool(f), device=keep.device)
+                           for f in flags]).to(torch.bool)
+        if not torch.equal(ref, keep):
+            keep = None
+    if keep is None:
+        elems = itertools.chain.from_iterable(_unbatched(e) for e in itertools.chain([first], it))
+        yield from _batched(_filtered(elems, pred), batch_size, drop_remainder)
+        return
+    comp = _RowCompactor(leaves, batch_size)
+    template = first
+    for e in itertools.chain([first], it):
+        flat = nest_utils.flatten(e)
+        leaves = [l.contiguous() for l in flat if _is_t(l)]
+        if not comp.matches(leaves):
+            raise ValueError("unbatch().filter().batch(): element structure changed mid-stream")
+        n_src = int(leaves[0].shape[0])
+        if e is not first:
+            keep = _vector_keep(pred, e, n_src)
+            if keep is None:
+                raise ValueError("filter predicate stopped producing one flag per sample")
+        template = e
+        comp.append(leaves, keep.view(torch.uint8))
+        while comp.count >= batch_size:
+            yield _repack(template, comp.take(batch_size))
+    if comp.count and not drop_remainder:
+        yield _repack(template, comp.take(comp.count))
+
+
+def _repack(template, outs):
+    it = iter(outs)
+    flat = [next(it) if _is_t(l) else l for l in nest_utils.flatten(template)]
+    return nest_utils.pack_sequence_as(template, flat)
+
+
+# `.unbatch().filter().batch()` compacts on the device when the elements allow it (tests switch it
+# off to compare with the element-wise combinators)
+DEVICE_COMPACTION = True
 
 
 class Dataset:
     def __init__(self, make_iter, infinite=False):
         self._make_iter = make_iter
         self._infinite = infinite
+        self._unbatch_of = None   # set by unbatch(): the dataset of batched elements
+        self._filter_of = None    # set by unbatch().filter(pred): (batched dataset, pred)
 
     def __iter__(self):
         return iter(self._make_iter())
@@ -48,22 +240,16 @@ class Dataset:
 
         def gen():
             for e in src:
-                yield fn(*e) if isinstance(e, tuple) and not hasattr(e, "_fields") else fn(e)
+                yield _call(fn, e)
 
         return Dataset(gen, self._infinite)
 
     def filter(self, pred):
         src = self
-
-        def gen():
-            for e in src:
-                keep = pred(*e) if isinstance(e, tuple) and not hasattr(e, "_fields") else pred(e)
-                if isinstance(keep, torch.Tensor):
-                    keep = bool(keep.item())
-                if keep:
-                    yield e
-
-        return Dataset(gen, self._infinite)
+        ds = Dataset(lambda: _filtered(src, pred), self._infinite)
+        if self._unbatch_of is not None:
+            ds._filter_of = (self._unbatch_of, pred)  # .batch(n) may compact on device
+        return ds
 
     def take(self, count):
         src = self
@@ -112,31 +298,18 @@ class Dataset:
 
     def unbatch(self):
         src = self
-
-        def gen():
-            for e in src:
-                leaves = [l for l in nest_utils.flatten(e) if isinstance(l, torch.Tensor)]
-                n = leaves[0].shape[0]
-                for i in range(n):
-                    yield nest_utils.map_structure(
-                        lambda l: l[i] if isinstance(l, torch.Tensor) else l, e)
-
-        return Dataset(gen, self._infinite)
+        ds = Dataset(lambda: itertools.chain.from_iterable(_unbatched(e) for e in src),
+                     self._infinite)
+        ds._unbatch_of = src
+        return ds
 
     def batch(self, batch_size, drop_remainder=False):
         src = self
-
-        def gen():
-            buf = []
-            for e in src:
-                buf.append(e)
-                if len(buf) == batch_size:
-                    yield nest_utils.map_structure(lambda *ls: torch.stack(ls, 0), *buf)
-                    buf = []
-            if buf and not drop_remainder:
-                yield nest_utils.map_structure(lambda *ls: torch.stack(ls, 0), *buf)
-
-        return Dataset(gen, self._infinite)
+        if self._filter_of is not None and DEVICE_COMPACTION:
+            batched_src, pred = self._filter_of
+            return Dataset(lambda: _compacted(batched_src, pred, int(batch_size), drop_remainder),
+                           self._infinite)
+        return Dataset(lambda: _batched(src, int(batch_size), drop_remainder), self._infinite)
 
     def shuffle(self, buffer_size, seed=None, reshuffle_each_iteration=True):
         src = self

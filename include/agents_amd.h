@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 7
+#define AA_ABI_VERSION 8
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -90,6 +90,21 @@ int aa_rb_gather_rows(const void* const* leaf_tables_h, void* const* leaf_out_h,
  * shuffle, order unpinned by the reference) without a device sort. */
 int aa_random_permutation(int64_t n, uint64_t seed, uint64_t call, int64_t* out, void* stream);
 
+/* Device-side `.unbatch().filter(pred).batch(n)` of a sampled batch (the SAC script's dataset
+ * pipeline, agents/sac/examples/v2/train_eval.py:285-296; tf.data unbatch / filter / batch).
+ * append: for the n_src rows of a batch, row s with keep[s] != 0 is copied, in source order, to row
+ *   (tail + #keep[0..s)) mod capacity of the pending ring of every leaf; *kept_out_dev = number of
+ *   survivors.  `count` = rows pending before the call; AA_ERR_RANGE when count + n_src > capacity.
+ * take: out[r] = pending[(head + r) mod capacity], r < n_rows <= count.
+ * The caller owns head / tail / count (replay_buffers/dataset.py). */
+int aa_rb_compact_append(void* const* pending_h, const void* const* src_h,
+                         const int64_t* leaf_row_bytes_h, int n_leaves, const uint8_t* keep,
+                         int64_t n_src, int64_t tail, int64_t count, int64_t capacity,
+                         int64_t* kept_out_dev, void* stream);
+int aa_rb_compact_take(const void* const* pending_h, void* const* out_h,
+                       const int64_t* leaf_row_bytes_h, int n_leaves, int64_t head, int64_t n_rows,
+                       int64_t count, int64_t capacity, void* stream);
+
 /* Table.write with explicit rows: table[rows[r]] = values[r] for every leaf (table.py:112-137).
  * Rows must be distinct. */
 int aa_rb_write_rows(void* const* leaf_tables_h, const void* const* leaf_values_h,
@@ -154,6 +169,12 @@ typedef struct aa_gemm_desc {
 
 int64_t aa_gemm_f32_workspace_bytes(const aa_gemm_desc* d);
 int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes, void* stream);
+/* aa_gemm_f32 without the split-K reduce launch, for a consumer that sums the partial products in
+ * its own prologue (aa_dense_small_forward_slabs): *splits_out = s > 1 -> `workspace` starts with
+ * the raw fp32 slabs [s][M][N] (no bias, no activation) and C is untouched; *splits_out = 1 -> the
+ * plan was not split and C holds the finished result.  colsum_out / mask_src must be NULL. */
+int aa_gemm_f32_slabs(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
+                      int32_t* splits_out, void* stream);
 
 /* Dense layers with N <= 16 output units (Q-value / value heads: keras Dense(num_actions),
  * networks/q_network.py:139-150): y = act(x W + b), dx = (dz W^T) * act'(mask_src),
@@ -161,6 +182,16 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
  * Latency-tuned kernels used instead of aa_gemm_f32 for these shapes; deterministic. */
 int aa_dense_small_forward(const float* x, int64_t ldx, const float* w, const float* bias,
                            int32_t act, int64_t M, int32_t K, int32_t N, float* y, void* stream);
+/* The head reading its input as the split-K slabs of the layer below (keras Dense(hidden) ->
+ * Dense(num_actions), networks/q_network.py:139-150, in two launches instead of four):
+ *   h[m,k] = act1(sum_z slabs[z][m][k] + bias1[k])   (stored, pitch ldh: the backward pass reads it)
+ *   y[m,n] = act(sum_k h[m,k] w[k,n] + bias[n])
+ * Same arithmetic, in the same order, as aa_gemm_f32's reduce followed by aa_dense_small_forward.
+ * K % 4 == 0, ldh % 4 == 0, slabs / h 16-byte aligned. */
+int aa_dense_small_forward_slabs(const float* slabs, int32_t splits, int64_t M, int32_t K,
+                                 const float* bias1 /* nullable */, int32_t act1, float* h,
+                                 int64_t ldh, const float* w, const float* bias /* nullable */,
+                                 int32_t act, int32_t N, float* y, void* stream);
 int aa_dense_small_dx(const float* dz, const float* w, const float* mask_src /* [M,K] nullable */,
                       int32_t mask_kind, int64_t M, int32_t K, int32_t N, float* dx, void* stream);
 int aa_dense_small_dw(const float* x, int64_t ldx, const float* dz, int64_t M, int32_t K,

@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from agents_amd import ops
+from agents_amd import _lib, ops
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
@@ -421,6 +421,56 @@ def test_dense_small_n(dev, M, N, K, act):
     close(out, out2.cpu(), tol=1e-5)
 
 
+# ---- hidden layer + head with the split-K sum in the head's prologue ------------------------------
+@pytest.mark.parametrize("M,K,H,N", [(256, 3136, 512, 6), (256, 3136, 512, 1), (32, 3136, 512, 6),
+                                     (7, 1000, 64, 16), (256, 64, 32, 3), (100, 2052, 260, 5)])
+@pytest.mark.parametrize("act1", ["relu", "tanh", None])
+def test_dense_tail_is_bit_identical_to_the_two_launch_pair(dev, M, K, H, N, act1):
+    """aa_gemm_f32_slabs + aa_dense_small_forward_slabs (csrc/gemm.hip, dense_small.hip) must give
+    the SAME bits as aa_gemm_f32 (main loop + reduce launch) followed by aa_dense_small_forward --
+    same slab order, same head accumulation order -- and both agree with float64."""
+    rng = np.random.default_rng(M + K + H + N)
+    x = torch.relu(rnd(rng, M, K)).to(dev)
+    w1, b1 = (rnd(rng, K, H) * 0.05).to(dev), rnd(rng, H).to(dev)
+    w2, b2 = (rnd(rng, H, N) * 0.1).to(dev), rnd(rng, N).to(dev)
+    assert ops.dense_tail_supported(x, w1, w2)
+    h_a = torch.full((M, H), float("nan"), device=dev)
+    y_a = torch.full((M, N), float("nan"), device=dev)
+    ops.dense_tail_forward(x, w1, b1, act1, h_a, w2, b2, None, y_a)
+    h_b = torch.full((M, H), float("nan"), device=dev)
+    y_b = torch.full((M, N), float("nan"), device=dev)
+    ops.dense_forward(x, w1, b1, act1, h_b)
+    ops.dense_forward(h_b, w2, b2, None, y_b)
+    assert torch.equal(h_a, h_b)
+    assert torch.equal(y_a, y_b)
+    href = act_ref(x.cpu().double() @ w1.cpu().double() + b1.cpu().double(), act1)
+    close(h_a, href)
+    close(y_a, href @ w2.cpu().double() + b2.cpu().double(), tol=2e-5)
+
+
+def test_dense_tail_refuses_bad_arguments(dev):
+    import ctypes
+    lib = _lib.load()
+    z = torch.zeros(4, 8, device=dev)
+    w = torch.zeros(8, 2, device=dev)
+    y = torch.zeros(4, 2, device=dev)
+    st = _lib.stream_ptr()
+    ok = lib.aa_dense_small_forward_slabs(z.data_ptr(), 1, 4, 8, None, 0, z.data_ptr(), 8,
+                                          w.data_ptr(), None, 0, 2, y.data_ptr(), st)
+    assert ok == 0
+    assert lib.aa_dense_small_forward_slabs(z.data_ptr(), 0, 4, 8, None, 0, z.data_ptr(), 8,
+                                            w.data_ptr(), None, 0, 2, y.data_ptr(), st) != 0
+    assert lib.aa_dense_small_forward_slabs(z.data_ptr(), 1, 4, 6, None, 0, z.data_ptr(), 8,
+                                            w.data_ptr(), None, 0, 2, y.data_ptr(), st) != 0
+    assert lib.aa_dense_small_forward_slabs(z.data_ptr(), 1, 4, 8, None, 0, z.data_ptr(), 8,
+                                            w.data_ptr(), None, 0, 17, y.data_ptr(), st) != 0
+    d = ops.gemm_desc(A=z.data_ptr(), B=w.data_ptr(), C=y.data_ptr(), M=4, N=2, K=8, lda=8, ldb=2,
+                      ldc=2, a_mode=_lib.AA_A_ROW, b_mode=_lib.AA_B_ROW, colsum_out=y.data_ptr())
+    sp = ctypes.c_int32(0)
+    assert lib.aa_gemm_f32_slabs(ctypes.byref(d), None, 0, ctypes.byref(sp), st) != 0
+    torch.cuda.synchronize()
+
+
 def test_conv1_dw_whole_m_tile(dev):
     """The Atari conv1 weight gradient (uint8 frames, 8x8x4 patches, 32 filters) takes the 256x32
     tile with the pixels split over the workgroups; forced and automatic plans agree with the
@@ -643,3 +693,36 @@ def test_bf16x6_refuses_ineligible(dev):
     with pytest.raises(Exception):
         ops.dense_forward(x.to(dev), w.to(dev), None, None, torch.empty(64, 32, device=dev),
                           force_cfg=9)
+
+
+def test_sequential_dense_tail_equals_layer_by_layer(dev):
+    """The Atari Q-network with the head summing fc1's split-K slabs: outputs, stored activations and
+    gradients are bit-identical to the layer-by-layer forward (ops.FUSE_DENSE_TAIL off)."""
+    from agents_amd.networks import sequential, layers as L
+    from agents_amd.specs import tensor_spec
+    spec = tensor_spec.TensorSpec((84, 84, 4), torch.uint8)
+
+    def build():
+        net = sequential.Sequential([
+            L.Rescale(255.0), L.Conv2D(32, 8, 4, activation="relu"),
+            L.Conv2D(64, 4, 2, activation="relu"), L.Conv2D(64, 3, 1, activation="relu"),
+            L.Flatten(), L.Dense(512, activation="relu"), L.Dense(6)], input_spec=spec, seed=3)
+        net.create_variables(spec, device=dev)
+        return net
+
+    g = torch.Generator().manual_seed(2)
+    x = torch.randint(0, 256, (64, 84, 84, 4), dtype=torch.uint8, generator=g).to(dev)
+    dq = torch.randn(64, 6, generator=g).to(dev)
+    res = {}
+    for fuse in (True, False):
+        ops.FUSE_DENSE_TAIL = fuse
+        try:
+            net = build()
+            q = net.forward(x, slot="t", need_grad=True).clone()
+            net.backward(dq, slot="t")
+            torch.cuda.synchronize()
+            res[fuse] = (q, net.flat_grads.clone())
+        finally:
+            ops.FUSE_DENSE_TAIL = True
+    assert torch.equal(res[True][0], res[False][0])
+    assert torch.equal(res[True][1], res[False][1])

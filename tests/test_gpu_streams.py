@@ -68,3 +68,28 @@ def test_two_stream_backward_equals_single_stream(dev, dx_first, monkeypatch):
             assert all(torch.equal(a, b) for a, b in zip(net.gradients, ref)), f"repetition {rep}"
     finally:
         sequential.DX_FIRST = old
+
+
+def test_workspaces_follow_the_line_of_execution_not_the_stream_handle(dev):
+    """torch hands out stream handles from a pool of 32: after enough agents have made side streams,
+    a graph-capture stream shares its handle with one of them.  Scratch buffers are keyed by the
+    line of execution (`ops.side_line`), so a kernel on such a capture stream still gets the main
+    line's buffer (which the eager warm-up sized) -- keyed by handle it got a side stream's smaller
+    one and the capture died with "workspace would grow during graph capture"."""
+    main_buf = ops._WS.get(3 << 20, dev)
+    sides = [ops.new_side_stream(dev) for _ in range(40)]
+    handles = {s.cuda_stream for s in sides}
+    with ops.side_line(sides[0]):
+        side_buf = ops._WS.get(1 << 10, dev)
+        assert side_buf.data_ptr() != main_buf.data_ptr()
+        with ops.side_line(sides[1]):
+            assert ops._WS.get(1 << 10, dev).data_ptr() not in (side_buf.data_ptr(),
+                                                                main_buf.data_ptr())
+        assert ops._WS.get(1 << 10, dev) is side_buf
+    hit = False
+    for _ in range(40):
+        st = torch.cuda.Stream(dev)
+        hit = hit or st.cuda_stream in handles
+        with torch.cuda.stream(st):
+            assert ops._WS.get(3 << 20, dev) is main_buf
+    assert hit, "expected the stream pool to wrap around"
