@@ -23,6 +23,7 @@ the next step on the stream and is safe.  `loss()` and `Learner.run` return tens
 storage.
 """
 import collections
+import os
 
 import numpy as np
 import torch
@@ -31,6 +32,11 @@ from agents_amd import _lib, ops
 from agents_amd.agents import tf_agent
 from agents_amd.policies import q_policy
 from agents_amd.utils import common, graph, nest_utils
+
+
+# A/B knob: AA_TRAIN_SINGLE_STREAM=1 keeps the whole train step on the caller's stream (no target /
+# weight-gradient side stream): fewer branches for the HIP-graph launch, no kernel overlap
+_SINGLE_STREAM = os.environ.get("AA_TRAIN_SINGLE_STREAM", "0") == "1"
 
 
 class DqnLossInfo(collections.namedtuple("DqnLossInfo", ("td_loss", "td_error"))):
@@ -165,6 +171,8 @@ class DqnAgent(tf_agent.TFAgent):
                                      self._target_q_network.flat_params, tau=1.0)
 
     def _side_stream(self, device):
+        if _SINGLE_STREAM:
+            return None
         key = (device.type, device.index)
         st = self._side_streams.get(key)
         if st is None:
@@ -202,14 +210,20 @@ class DqnAgent(tf_agent.TFAgent):
         # target one on a side stream so the two overlap (fork / join, also under graph capture).
         main = torch.cuda.current_stream(dev)
         side = self._side_stream(dev)
-        side.wait_stream(main)
-        with ops.side_line(side):
+        if side is None:
             q_next_target = self._target_q_network.forward(obs_next, slot="train")
+        else:
+            if hasattr(self._target_q_network, "prepare_forward"):
+                self._target_q_network.prepare_forward(obs_next.shape[0], slot="train")
+            side.wait_stream(main)
+            with ops.side_line(side):
+                q_next_target = self._target_q_network.forward(obs_next, slot="train")
         q_online = self._q_network.forward(obs_t, slot="train", need_grad=need_grad)
         q_next_select = None
         if self._double_q:
             q_next_select = self._q_network.forward(obs_next, slot="next")
-        main.wait_stream(side)
+        if side is not None:
+            main.wait_stream(side)
         next_mask = None
         if mask is not None:
             next_mask = mask[:, -1].to(torch.int32).contiguous()

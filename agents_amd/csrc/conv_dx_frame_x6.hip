@@ -299,15 +299,18 @@ int64_t aa_conv_dx_frame_x6_workspace_bytes(const aa_conv_dx_desc* d) {
   return dx6_check(d, &P, &lds, &ws, &rt) == AA_OK ? (int64_t)ws : 0;
 }
 
-int aa_conv_dx_frame_x6(const aa_conv_dx_desc* d, void* workspace, int64_t workspace_bytes,
-                        void* stream) {
+// phases: 1 = filter fragments + per-class k-step tables into `workspace` (depends on the
+// weights only), 2 = the per-frame kernel over a prepared workspace, 3 = both.
+int aa_conv_dx_frame_x6_phase(const aa_conv_dx_desc* d, void* workspace, int64_t workspace_bytes,
+                              int32_t phases, void* stream) {
+  if (phases < 1 || phases > 3) return AA_ERR_INVALID;
   Dx6P P;
   size_t lds = 0, ws = 0;
   int rt = 0;
   const int rc = dx6_check(d, &P, &lds, &ws, &rt);
   if (rc != AA_OK) return rc;
-  if (d->dz == nullptr || d->w == nullptr || d->dx == nullptr || workspace == nullptr)
-    return AA_ERR_INVALID;
+  if (d->w == nullptr || workspace == nullptr) return AA_ERR_INVALID;
+  if ((phases & 2) && (d->dz == nullptr || d->dx == nullptr)) return AA_ERR_INVALID;
   if (((uintptr_t)d->dz & 15) != 0 || ((uintptr_t)d->w & 15) != 0 ||
       ((uintptr_t)workspace & 15) != 0)
     return AA_ERR_INVALID;
@@ -319,13 +322,14 @@ int aa_conv_dx_frame_x6(const aa_conv_dx_desc* d, void* workspace, int64_t works
   const size_t frag = (size_t)d->KH * d->KW * P.gpt * (d->Cin / 16) * 3 * 64;
   P.tab = reinterpret_cast<int2*>(P.wf + frag);
   hipStream_t st = (hipStream_t)stream;
-  {
+  if (phases & 1) {
     const int items = d->KH * d->KW * P.gpt * (d->Cin / 16) * 64 +
                       d->stride * d->stride * AA_DX6_MAX_KS;
     int blocks = (items + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(aa_conv_dx6_prep_kernel, dim3(blocks), dim3(256), 0, st, P);
   }
+  if (!(phases & 2)) return aa_launch_status();
   int grid = d->n_img > 512 ? 512 : d->n_img;
   static size_t lds_limit[AA_DX6_MAX_RT + 1] = {0};   // > 64 KiB of dynamic LDS: granted per kernel
   int done = 0;
@@ -345,6 +349,11 @@ int aa_conv_dx_frame_x6(const aa_conv_dx_desc* d, void* workspace, int64_t works
 #undef AA_DX6_CASE
   if (!done) return AA_ERR_RANGE;
   return aa_launch_status();
+}
+
+int aa_conv_dx_frame_x6(const aa_conv_dx_desc* d, void* workspace, int64_t workspace_bytes,
+                        void* stream) {
+  return aa_conv_dx_frame_x6_phase(d, workspace, workspace_bytes, 3, stream);
 }
 
 }  // extern "C"

@@ -376,22 +376,27 @@ int64_t aa_conv_pair_x6_workspace_bytes(int32_t n_img, int32_t H, int32_t W, int
   return cx_check(n_img, H, W, Cin, first, second, &P, &lds, &ws) == AA_OK ? (int64_t)ws : 0;
 }
 
-int aa_conv_pair_x6_forward(const float* x, int64_t img_pitch, int32_t n_img, int32_t H, int32_t W,
-                            int32_t Cin, const aa_conv_layer_desc* first,
-                            const aa_conv_layer_desc* second, void* workspace,
-                            int64_t workspace_bytes, void* stream) {
-  if (x == nullptr || workspace == nullptr) return AA_ERR_INVALID;
+// phases: 1 = split the filter banks into `workspace` (depends on the weights only), 2 = the
+// per-frame kernel over prepared planes, 3 = both.
+int aa_conv_pair_x6_phase(const float* x, int64_t img_pitch, int32_t n_img, int32_t H, int32_t W,
+                          int32_t Cin, const aa_conv_layer_desc* first,
+                          const aa_conv_layer_desc* second, void* workspace,
+                          int64_t workspace_bytes, int32_t phases, void* stream) {
+  if (workspace == nullptr || phases < 1 || phases > 3) return AA_ERR_INVALID;
+  if ((phases & 2) && x == nullptr) return AA_ERR_INVALID;
   CxParams P;
   size_t lds = 0, ws = 0;
   const int rc = cx_check(n_img, H, W, Cin, first, second, &P, &lds, &ws);
   if (rc != AA_OK) return rc;
-  if (first->w == nullptr || second->w == nullptr || first->y == nullptr || second->y == nullptr)
-    return AA_ERR_INVALID;
+  if (first->w == nullptr || second->w == nullptr) return AA_ERR_INVALID;
+  if ((phases & 2) && (first->y == nullptr || second->y == nullptr)) return AA_ERR_INVALID;
   if ((int64_t)ws > workspace_bytes || ((uintptr_t)workspace & 15) != 0) return AA_ERR_RANGE;
   const int64_t dense = (int64_t)H * W * Cin;
   P.x = x;
   P.img_pitch = img_pitch > 0 ? img_pitch : dense;
-  if (P.img_pitch < dense || P.img_pitch % 4 != 0 || ((uintptr_t)x & 15) != 0) return AA_ERR_INVALID;
+  if ((phases & 2) &&
+      (P.img_pitch < dense || P.img_pitch % 4 != 0 || ((uintptr_t)x & 15) != 0))
+    return AA_ERR_INVALID;
   P.n_img = n_img;
 #ifdef AA_CX_STAMPS
   P.stamps = g_cx_stamps;
@@ -399,13 +404,14 @@ int aa_conv_pair_x6_forward(const float* x, int64_t img_pitch, int32_t n_img, in
   P.l[0].wf = reinterpret_cast<uint4*>(workspace);
   P.l[1].wf = P.l[0].wf + (size_t)P.l[0].ksteps * (P.l[0].Cout / 16) * 3 * 64;
   hipStream_t st = (hipStream_t)stream;
-  {
+  if (phases & 1) {
     const int items = (P.l[0].ksteps * (P.l[0].Cout / 16) + P.l[1].ksteps * (P.l[1].Cout / 16)) * 64;
     int blocks = (items + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(aa_conv_pair_x6_split_kernel, dim3(blocks), dim3(256), 0, st, P.l[0],
                        P.l[1]);
   }
+  if (!(phases & 2)) return aa_launch_status();
   int grid = n_img;
   if (grid > 512) grid = 512;
   auto up = [](int ohw) { const int t = (ohw + 15) / 16; return t <= 2 ? 2 : t <= 4 ? 4 : t <= 6 ? 6 : 8; };
@@ -438,6 +444,14 @@ int aa_conv_pair_x6_forward(const float* x, int64_t img_pitch, int32_t n_img, in
 #undef AA_CX_CASE
   if (rc2 != AA_OK) return rc2;
   return aa_launch_status();
+}
+
+int aa_conv_pair_x6_forward(const float* x, int64_t img_pitch, int32_t n_img, int32_t H, int32_t W,
+                            int32_t Cin, const aa_conv_layer_desc* first,
+                            const aa_conv_layer_desc* second, void* workspace,
+                            int64_t workspace_bytes, void* stream) {
+  return aa_conv_pair_x6_phase(x, img_pitch, n_img, H, W, Cin, first, second, workspace,
+                               workspace_bytes, 3, stream);
 }
 
 }  // extern "C"

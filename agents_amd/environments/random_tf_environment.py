@@ -45,6 +45,10 @@ class RandomTFEnvironment(tf_environment.TFEnvironment):
         self._step_counter = torch.zeros((2,), dtype=torch.int64, device=self._device)
         self._time_step = None
         self._ring = None
+        # Bumped by every step / reset / restore issued from Python (not by HIP-graph replays of a
+        # captured step): a graphed driver uses it to tell whether the time step it last saw is
+        # still the environment's (agents_amd/utils/graph.py: GraphedDriverRun).
+        self.host_epoch = 0
 
     def _alloc(self):
         B = self._batch_size
@@ -77,6 +81,8 @@ class RandomTFEnvironment(tf_environment.TFEnvironment):
     def _launch(self, cur_step_type, force_first):
         lib = _lib.load()
         graph.join_lanes(self._device)
+        if not graph.capturing():
+            self.host_epoch += 1
         out = self._next_out()
         with torch.cuda.device(self._device):
             st = _lib.stream_ptr()
@@ -98,6 +104,7 @@ class RandomTFEnvironment(tf_environment.TFEnvironment):
     def load_state_dict(self, sd):
         graph.join_lanes(self._device)
         self._step_counter[0] = int(sd["step_counter"])
+        self.host_epoch += 1
         if sd["time_step"] is not None:
             if self._time_step is None:
                 self._time_step = self._next_out()

@@ -34,6 +34,19 @@ LAST_DW_ON_MAIN = os.environ.get("AA_LAST_DW_ON_MAIN", "1") != "0"
 # conv -> conv over LDS-sized fp32 frames in one launch (csrc/conv_pair.hip); AA_FUSE_CONV_PAIRS=0
 # selects the layer-by-layer kernels (A/B measurements)
 FUSE_CONV_PAIRS = os.environ.get("AA_FUSE_CONV_PAIRS", "1") != "0"
+# The bf16x6 convolutions split their filter banks in a pre-pass that depends on the weights only.
+# It can be issued on the network's own side stream ahead of the kernel that needs it:
+#   AA_HOIST_PREP=3 (default)  backward only: the two input-gradient pre-passes run next to the
+#                              dense layers' backward instead of on the dX chain
+#   AA_HOIST_PREP=1            forward too (next to the layer in front of the pair)
+#   AA_HOIST_PREP=0            nowhere (each kernel call splits for itself)
+# Measured inside the DQN iteration on MI355X (same box, alternating runs): 3 = 0.421 ms,
+# 0 = 0.461 ms, 1 = 0.502 ms -- the forward fork adds a graph branch at the point where three
+# forward chains (collect, online, target) already compete for the four hardware queues.
+_HOIST = os.environ.get("AA_HOIST_PREP", "3")
+HOIST_PREP = _HOIST != "0"
+_HOIST_FWD = _HOIST in ("1", "2")
+_HOIST_BWD = _HOIST in ("1", "3")
 
 
 def _align4(n):
@@ -49,6 +62,9 @@ class _Slot:
         self.dxs = []     # gradient wrt input of each parametrised layer (None for the first)
         self.dcol = None  # column-gradient scratch for conv input gradients
         self.dz_top = None
+        self.pair_prep = None   # {param index of a fused pair's first conv: filter-plane scratch}
+        self.prep_issued = None  # pairs whose pre-pass prepare_forward already put on the prep stream
+        self.dx_prep = None     # {param index of a conv: input-gradient filter scratch}
 
 
 class Sequential(network.Network):
@@ -306,6 +322,9 @@ class Sequential(network.Network):
         div = None
         pi = 0
         skip = False
+        prep_pending, s.prep_issued = s.prep_issued, None
+        if prep_pending is None:
+            prep_pending = self._hoist_pair_prep(s, B)
         for li, l in enumerate(self._layers):
             if skip:        # second conv of a fused pair: already computed
                 skip = False
@@ -332,10 +351,14 @@ class Sequential(network.Network):
                                                     self._kviews[pi + 1], nxt.stride)):
                     # two convs over frames that fit LDS: one launch, one workgroup per frame
                     s.xs[pi + 1] = s.ys[pi]
+                    prepared = s.pair_prep.get(pi) if prep_pending is not None else None
+                    if prepared is not None and prep_pending:
+                        torch.cuda.current_stream(cur.device).wait_stream(self._prep_stream)
+                        prep_pending.clear()
                     ops.conv_pair_forward(cur, self._kviews[pi], self._bviews[pi], l.stride,
                                           l.activation, s.ys[pi], self._kviews[pi + 1],
                                           self._bviews[pi + 1], nxt.stride, nxt.activation,
-                                          s.ys[pi + 1])
+                                          s.ys[pi + 1], prepared=prepared)
                     skip = True
                 else:
                     ops.conv_forward(cur, self._kviews[pi], self._bviews[pi], l.stride,
@@ -363,7 +386,106 @@ class Sequential(network.Network):
                                       s.ys[pi])
                 cur = s.ys[pi]
                 pi += 1
+        if prep_pending:   # a planned pair was not reached (cannot happen; keeps captures joined)
+            torch.cuda.current_stream(cur.device).wait_stream(self._prep_stream)
         return cur
+
+    # ---- weights-only pre-passes of the bf16x6 convolutions, off the critical chain -----------
+    def _prep(self, device):
+        st = getattr(self, "_prep_stream", None)
+        if st is None:
+            st = self._prep_stream = ops.new_side_stream(device)
+        return st
+
+    def _conv_param_pairs(self):
+        """Param indices pi such that parametrised layers pi, pi+1 are adjacent Conv2D layers."""
+        out = []
+        pi = 0
+        for li, l in enumerate(self._layers):
+            if not l.has_params:
+                continue
+            nxt = self._layers[li + 1] if li + 1 < len(self._layers) else None
+            if isinstance(l, L.Conv2D) and isinstance(nxt, L.Conv2D):
+                out.append(pi)
+            pi += 1
+        return out
+
+    def prepare_forward(self, B, slot=0, need_grad=False):
+        """Issues, from the CALLER's stream, the weights-only pre-passes of the next
+        `forward(x[B], slot)`: for a forward that will itself run on a side line (the DQN target
+        network), where forking a second time is not possible under graph capture."""
+        self._require_built()
+        s = self._slot(slot, B, need_grad)
+        if s.prep_issued is None and not self._fused_small_ok():
+            s.prep_issued = self._hoist_pair_prep(s, B)
+
+    def _hoist_pair_prep(self, s, B):
+        """Issues the filter split of every fused conv pair of this forward on the prep stream and
+        returns the list of pending pairs (None: nothing hoisted, the pair call splits itself)."""
+        if not (HOIST_PREP and _HOIST_FWD and FUSE_CONV_PAIRS):
+            return None
+        if ops._LINE is not None:
+            # Already on a side line: that line may have joined a graph capture through an event
+            # recorded before the capture had any node, and forking again from such a point makes
+            # ROCm 7's hipStreamEndCapture crash.  Callers that run a forward on a side line issue
+            # the pre-pass from the origin stream first (prepare_forward).
+            return None
+        dev = self.flat_params.device
+        if s.pair_prep is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None     # planned (and its scratch allocated) by an eager call only
+            plan = {}
+            for pi in self._conv_param_pairs():
+                if pi == 0 or pi in plan or (pi - 1) in plan:
+                    continue    # a pair fed by the caller's tensor has nothing to overlap with
+                l, nxt = self._param_layers[pi], self._param_layers[pi + 1]
+                shape = (B,) + tuple(self._info[pi][2])
+                w1, w2 = self._kviews[pi], self._kviews[pi + 1]
+                if int(np.prod(shape[1:])) % 4 == 0 and \
+                        ops.conv_pair_supported(shape, w1, l.stride, w2, nxt.stride):
+                    nbytes = ops.conv_pair_prepare_bytes(shape, w1, l.stride, w2, nxt.stride)
+                    if nbytes > 0:
+                        plan[pi] = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+            s.pair_prep = plan
+        if not s.pair_prep:
+            return None
+        prep = self._prep(dev)
+        prep.wait_stream(torch.cuda.current_stream(dev))
+        with ops.side_line(prep):
+            for pi, ws in s.pair_prep.items():
+                l, nxt = self._param_layers[pi], self._param_layers[pi + 1]
+                ops.conv_pair_prepare((B,) + tuple(self._info[pi][2]), self._kviews[pi], l.stride,
+                                      self._kviews[pi + 1], nxt.stride, ws)
+        return list(s.pair_prep)
+
+    def _hoist_dx_prep(self, s, B, hi, lo):
+        """Same for the conv input gradients of layers lo..hi of this backward pass: True when
+        something was issued (the caller joins the prep stream before the first of them)."""
+        if not (HOIST_PREP and _HOIST_BWD):
+            return False
+        dev = self.flat_params.device
+        if s.dx_prep is None:
+            if torch.cuda.is_current_stream_capturing():
+                return False
+            plan = {}
+            for i, l in enumerate(self._param_layers):
+                if i == 0 or not isinstance(l, L.Conv2D):
+                    continue
+                shape = (B,) + tuple(self._info[i][2])
+                nbytes = ops.conv_dx_prepare_bytes(shape, self._kviews[i], l.stride)
+                if nbytes > 0:
+                    plan[i] = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+            s.dx_prep = plan
+        todo = [i for i in s.dx_prep if lo <= i <= hi]
+        if not todo:
+            return False
+        prep = self._prep(dev)
+        prep.wait_stream(torch.cuda.current_stream(dev))
+        with ops.side_line(prep):
+            for i in todo:
+                ops.conv_dx_prepare((B,) + tuple(self._info[i][2]), self._kviews[i],
+                                    self._param_layers[i].stride, s.dx_prep[i])
+        return True
 
     # ---- fused small-MLP path (csrc/mlp_small.hip) -----------------------------------------------
     def _fused_small_ok(self):
@@ -482,6 +604,8 @@ class Sequential(network.Network):
         if side_stream is None:
             side_stream = main
 
+        dx_prep_pending = self._hoist_dx_prep(s, B, hi, lo)
+
         def on_side(fn, fork=True):
             if side_stream is main:
                 return fn()
@@ -531,8 +655,13 @@ class Sequential(network.Network):
                 if i > 0:
                     if DX_FIRST:
                         side_stream.wait_stream(main) if side_stream is not main else None
+                    prepared = s.dx_prep.get(i) if s.dx_prep else None
+                    if prepared is not None and dx_prep_pending:
+                        main.wait_stream(self._prep_stream)
+                        dx_prep_pending = False
                     ops.conv_dx(dz2, self._kviews[i], tuple(x.shape), l.stride, s.dcol, s.dxs[i],
-                                mask_src=x if prev_act else None, mask_act=prev_act)
+                                mask_src=x if prev_act else None, mask_act=prev_act,
+                                prepared=prepared if HOIST_PREP else None)
                     dz_next = s.dxs[i]
                 if param_grads:
                     dw = lambda: ops.conv_dw(x, dz2, ks, l.stride, self._gkviews[i],
@@ -547,6 +676,8 @@ class Sequential(network.Network):
                         on_side(dw, fork=not (DX_FIRST and i > 0))
                 if dz_next is not None:
                     dz = dz_next
+        if dx_prep_pending:
+            main.wait_stream(self._prep_stream)
         if side_stream is not main:
             main.wait_stream(side_stream)
 

@@ -374,8 +374,38 @@ def conv_pair_supported(x_shape, w1, s1, w2, s2):
     return ok
 
 
-def conv_pair_forward(x, w1, b1, s1, act1, y1, w2, b2, s2, act2, y2):
-    """y1 = act1(conv(x, w1) + b1), y2 = act2(conv(y1, w2) + b2) in one launch; both are written."""
+def conv_pair_prepare_bytes(x_shape, w1, s1, w2, s2):
+    """Bytes of filter-plane scratch of the bf16x6 pair for these shapes; 0 when the pair takes the
+    fp32 kernel (nothing to prepare)."""
+    Bn, H, W, C = x_shape
+    key = (Bn, H, W, C, tuple(w1.shape), s1, tuple(w2.shape), s2)
+    ws_bytes = _PAIR_X6_WS.get(key)
+    if ws_bytes is None:
+        d = []
+        for w, st in ((w1, s1), (w2, s2)):
+            d.append(_lib.ConvLayerDesc(w=None, bias=None, y=None, KH=w.shape[0], KW=w.shape[1],
+                                        stride=st, Cout=w.shape[3], act=0))
+        ws_bytes = int(_lib.load().aa_conv_pair_x6_workspace_bytes(
+            Bn, H, W, C, ctypes.byref(d[0]), ctypes.byref(d[1]))) if CONV_PAIR_X6 else 0
+        _PAIR_X6_WS[key] = ws_bytes
+    return ws_bytes
+
+
+def conv_pair_prepare(x_shape, w1, s1, w2, s2, ws):
+    """The weights-only half of conv_pair_forward (filter banks split into `ws`): issue it early,
+    on another stream, and pass `prepared=ws` to conv_pair_forward."""
+    require_cuda(w1, w2, ws)
+    Bn, H, W, C = x_shape
+    d = _pair_descs(w1, None, s1, None, None, w2, None, s2, None, None)
+    with torch.cuda.device(ws.device):
+        check(_lib.load().aa_conv_pair_x6_phase(None, 0, Bn, H, W, C, ctypes.byref(d[0]),
+                                                ctypes.byref(d[1]), ptr(ws), ws.numel(), 1,
+                                                _lib.stream_ptr()), "aa_conv_pair_x6_phase(1)")
+
+
+def conv_pair_forward(x, w1, b1, s1, act1, y1, w2, b2, s2, act2, y2, prepared=None):
+    """y1 = act1(conv(x, w1) + b1), y2 = act2(conv(y1, w2) + b2) in one launch; both are written.
+    prepared: scratch that conv_pair_prepare filled for these weights."""
     require_cuda(x, w1, w2, y1, y2)
     if x.dtype != torch.float32:
         raise ValueError("conv_pair_forward needs a float32 NHWC input")
@@ -390,21 +420,16 @@ def conv_pair_forward(x, w1, b1, s1, act1, y1, w2, b2, s2, act2, y2):
     d = _pair_descs(w1, b1, s1, act1, y1, w2, b2, s2, act2, y2)
     lib = _lib.load()
     with torch.cuda.device(x.device):
-        key = (Bn, H, W, C, tuple(w1.shape), s1, tuple(w2.shape), s2)
-        ws_bytes = _PAIR_X6_WS.get(key)
-        if ws_bytes is None:
-            ws_bytes = int(lib.aa_conv_pair_x6_workspace_bytes(
-                Bn, H, W, C, ctypes.byref(d[0]), ctypes.byref(d[1]))) if CONV_PAIR_X6 else 0
-            _PAIR_X6_WS[key] = ws_bytes
+        ws_bytes = conv_pair_prepare_bytes((Bn, H, W, C), w1, s1, w2, s2)
         if ws_bytes > 0:
             # bf16 matrix cores, fp32 accuracy (csrc/conv_pair_x6.hip); the split filter planes
-            # live in the calling stream's scratch (concurrent forwards on other streams -- target
-            # network, collect graph -- own theirs)
-            ws = _WS3.get(ws_bytes, x.device)
-            check(lib.aa_conv_pair_x6_forward(ptr(x), _img_pitch(x), Bn, H, W, C,
-                                              ctypes.byref(d[0]), ctypes.byref(d[1]), ptr(ws),
-                                              ws.numel(), _lib.stream_ptr()),
-                  "aa_conv_pair_x6_forward")
+            # live in the calling line's scratch (concurrent forwards on other streams -- target
+            # network, collect graph -- own theirs) unless the caller prepared them already
+            ws = prepared if prepared is not None else _WS3.get(ws_bytes, x.device)
+            check(lib.aa_conv_pair_x6_phase(ptr(x), _img_pitch(x), Bn, H, W, C,
+                                            ctypes.byref(d[0]), ctypes.byref(d[1]), ptr(ws),
+                                            ws.numel(), 2 if prepared is not None else 3,
+                                            _lib.stream_ptr()), "aa_conv_pair_x6_phase")
         else:
             check(lib.aa_conv_pair_forward(ptr(x), _img_pitch(x), Bn, H, W, C,
                                            ctypes.byref(d[0]), ctypes.byref(d[1]),
@@ -434,8 +459,9 @@ def conv_dw(x, dz, w_shape, stride, out, a_div=255.0, force_cfg=0, force_splits=
     return out
 
 
-def conv_dx(dz, w, x_shape, stride, dcol, out, mask_src=None, mask_act=None):
-    """Input gradient of a VALID conv: dcol = dz @ w^T (GEMM), out = col2im(dcol) * act'(mask)."""
+def conv_dx(dz, w, x_shape, stride, dcol, out, mask_src=None, mask_act=None, prepared=None):
+    """Input gradient of a VALID conv: dcol = dz @ w^T (GEMM), out = col2im(dcol) * act'(mask).
+    prepared: scratch filled by conv_dx_prepare for these weights (gather-form bf16x6 path)."""
     require_cuda(dz, w, dcol, out, mask_src)
     lib = _lib.load()
     Bn, H, W, C = x_shape
@@ -449,7 +475,8 @@ def conv_dx(dz, w, x_shape, stride, dcol, out, mask_src=None, mask_act=None):
     if CONV_DX_FRAME and (mask_src is None or mask_src.is_contiguous()) and \
             dz.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and \
             conv_dx_frame_supported(tuple(x_shape), tuple(w.shape), stride):
-        return conv_dx_frame(dz, w, x_shape, stride, out, mask_src=mask_src, mask_act=mask_act)
+        return conv_dx_frame(dz, w, x_shape, stride, out, mask_src=mask_src, mask_act=mask_act,
+                             prepared=prepared)
     d = gemm_desc(A=ptr(dz), B=ptr(w), C=ptr(dcol), M=M, N=Kp, K=Cout, lda=Cout, ldb=Cout,
                   ldc=Kp, a_mode=AA_A_ROW, b_mode=AA_B_COL)
     gemm(d, dz.device)
@@ -485,7 +512,32 @@ def conv_dx_frame_supported(x_shape, w_shape, stride):
     return ok
 
 
-def conv_dx_frame(dz, w, x_shape, stride, out, mask_src=None, mask_act=None):
+def conv_dx_prepare_bytes(x_shape, w, stride):
+    """Bytes of scratch the bf16x6 gather-form input gradient prepares from the weights for these
+    shapes; 0 when conv_dx would not take that path (nothing to prepare)."""
+    if not (CONV_DX_FRAME and CONV_DX_X6 and w.data_ptr() % 16 == 0 and
+            conv_dx_frame_supported(tuple(x_shape), tuple(w.shape), stride)):
+        return 0
+    key = (tuple(x_shape), tuple(w.shape), stride)
+    ws_bytes = _DXF_X6_WS.get(key)
+    if ws_bytes is None:
+        d = _dxf_desc(x_shape, w.shape, stride)
+        ws_bytes = int(_lib.load().aa_conv_dx_frame_x6_workspace_bytes(ctypes.byref(d)))
+        _DXF_X6_WS[key] = ws_bytes
+    return ws_bytes
+
+
+def conv_dx_prepare(x_shape, w, stride, ws):
+    """The weights-only half of the bf16x6 input gradient (filter fragments + k-step tables into
+    `ws`): issue it early, on another stream, and pass `prepared=ws` to conv_dx."""
+    require_cuda(w, ws)
+    d = _dxf_desc(x_shape, w.shape, stride, w=w)
+    with torch.cuda.device(ws.device):
+        check(_lib.load().aa_conv_dx_frame_x6_phase(ctypes.byref(d), ptr(ws), ws.numel(), 1,
+                                                    stream_ptr()), "aa_conv_dx_frame_x6_phase(1)")
+
+
+def conv_dx_frame(dz, w, x_shape, stride, out, mask_src=None, mask_act=None, prepared=None):
     """Input gradient of a VALID conv, one workgroup per frame (csrc/conv_dx_frame.hip)."""
     require_cuda(dz, w, out, mask_src)
     Bn, H, W, C = x_shape
@@ -510,9 +562,10 @@ def conv_dx_frame(dz, w, x_shape, stride, out, mask_src=None, mask_act=None):
         if ws_bytes > 0:
             # bf16 matrix cores, fp32 accuracy (csrc/conv_dx_frame_x6.hip); split filter planes in
             # the calling stream's scratch
-            ws = _WS3.get(ws_bytes, dz.device)
-            check(lib.aa_conv_dx_frame_x6(ctypes.byref(d), ptr(ws), ws.numel(), stream_ptr()),
-                  "aa_conv_dx_frame_x6")
+            ws = prepared if prepared is not None else _WS3.get(ws_bytes, dz.device)
+            check(lib.aa_conv_dx_frame_x6_phase(ctypes.byref(d), ptr(ws), ws.numel(),
+                                                2 if prepared is not None else 3, stream_ptr()),
+                  "aa_conv_dx_frame_x6_phase")
         else:
             check(lib.aa_conv_dx_frame(ctypes.byref(d), stream_ptr()), "aa_conv_dx_frame")
     return out

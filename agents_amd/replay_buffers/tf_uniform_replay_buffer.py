@@ -52,6 +52,8 @@ def _resolve_device(device):
         idx = device.split(":")[-1]
         return torch.device("cuda", int(idx)) if idx.isdigit() else torch.device("cuda")
     d = torch.device(device) if not isinstance(device, torch.device) else device
+    if d.type == "cuda" and d.index is None and torch.cuda.is_available():
+        d = torch.device("cuda", torch.cuda.current_device())
     return d
 
 

@@ -19,6 +19,8 @@ with `on_replay`, which runs them before every replay.
 """
 import contextlib
 import gc
+import os
+import time
 
 import torch
 
@@ -51,6 +53,10 @@ def on_replay(fn):
         _CAPTURE.hooks.append(fn)
 
 
+# A/B knob: replay the optimizer phase as its own HIP graph (0) or launch it directly (1)
+APPLY_EAGER = os.environ.get("AA_APPLY_EAGER", "1") != "0"
+
+
 class Lanes:
     """Opt-in overlap of the three graphs on separate HIP streams (`enable_overlap(device)`).
 
@@ -77,6 +83,18 @@ class Lanes:
         self.collect_done = None
         self.sample_done = None
         self.ready = {}          # first-leaf data_ptr of a sampler ring slot -> ready Event
+        # Events are recycled round robin (creating and destroying four per iteration showed in
+        # the host profile of the loop).  A holder of a recycled event waits for its NEWER record,
+        # i.e. for more than it asked for -- never for less, and never for work enqueued after
+        # the waiter -- 64 records (16 iterations) after it was handed out.
+        self._pool = [torch.cuda.Event() for _ in range(64)]
+        self._pool_i = 0
+
+    def event_on(self, stream):
+        ev = self._pool[self._pool_i]
+        self._pool_i = (self._pool_i + 1) & 63
+        ev.record(stream)
+        return ev
 
     @staticmethod
     def _event_on(stream):
@@ -85,7 +103,7 @@ class Lanes:
         return ev
 
     def main_frontier(self):
-        return self._event_on(torch.cuda.current_stream(self.device))
+        return self.event_on(torch.cuda.current_stream(self.device))
 
     def join(self):
         """The caller's stream waits for everything enqueued on the collect / sample lanes."""
@@ -180,6 +198,14 @@ def capture_batch():
             torch.cuda.synchronize()
 
 
+def _device_ctx(dev):
+    """torch.cuda.device(dev), or nothing when dev is already the current device (the context
+    manager costs two device queries and two switches per use)."""
+    if torch.cuda.current_device() == dev.index:
+        return contextlib.nullcontext()
+    return torch.cuda.device(dev)
+
+
 def _capture_stream(device):
     key = torch.cuda.current_device() if device is None else torch.device(device).index
     st = _CAPTURE_STREAM.get(key)
@@ -188,13 +214,25 @@ def _capture_stream(device):
     return st
 
 
+REPLAY_TIMERS = None    # set to {} to accumulate {kind: [launches, host seconds]}
+TIMELINE = None         # set to [] to collect (tag, timing event) marks around the graph launches
+
+
+def _mark(tag, stream=None):
+    if TIMELINE is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream if stream is not None else torch.cuda.current_stream())
+        TIMELINE.append((tag, ev))
+
+
 class _Captured:
     """A torch CUDAGraph plus the host hooks registered while it was captured."""
 
-    def __init__(self):
+    def __init__(self, kind="graph"):
         self.graph = None
         self.hooks = []
         self.out = None
+        self.kind = kind
 
     def capture(self, fn):
         """Records `fn()`.  torch.cuda.graph() is not used: its __enter__ synchronises the device
@@ -225,7 +263,14 @@ class _Captured:
     def replay(self):
         for h in self.hooks:
             h()
-        self.graph.replay()
+        if REPLAY_TIMERS is None:
+            self.graph.replay()
+        else:     # host cost of the launch per kind of graph (bench.py --host-profile)
+            t0 = time.perf_counter()
+            self.graph.replay()
+            acc = REPLAY_TIMERS.setdefault(self.kind, [0, 0.0])
+            acc[0] += 1
+            acc[1] += time.perf_counter() - t0
         return self.out
 
 
@@ -277,6 +322,7 @@ class GraphedTrain:
         self._cache = {}       # signature -> {input address tuple | None: _Entry}
         self._warm = {}
         self._seen = {}
+        self._fast = {}        # id(experience) -> (experience, entry, device, first address, True)
         # phase mode: two graphs around the gradient hook (DqnAgent); whole mode: the entire
         # `_train` in one graph, for agents whose train step has no host-side decisions and no
         # gradient hook installed (PPOAgent on one replica)
@@ -340,29 +386,48 @@ class GraphedTrain:
         if self._whole and (getattr(agent, "gradient_hook", None) is not None or
                             not getattr(agent, "graph_train_whole_ok", True)):
             return agent.train(experience, weights=weights)
-        sig = _sig(experience, weights)
-        if self._warm.get(sig, 0) < _WARMUP_CALLS:
-            self._warm[sig] = self._warm.get(sig, 0) + 1
-            return agent.train(experience, weights=weights)
-        if not agent._initialized:
-            agent.initialize()
-        if hasattr(agent, "_check_trajectory"):
-            agent._check_trajectory(experience)
-        ptrs = tuple(t.data_ptr() for t in nest_utils.flatten(experience))
-        dev = experience.discount.device
-        with torch.cuda.device(dev):
-            e = self._entry_for(sig, ptrs, experience, weights, dev)
-            lanes = lanes_for(dev)
+        # Steady state: the very same experience object (a sampler ring slot) as on an earlier
+        # call whose graph reads it in place -- signature, trajectory checks and address tuple
+        # were established then (this lookup replaces ~40 us of host work per step).
+        hit = self._fast.get(id(experience)) if weights is None else None
+        if hit is not None and hit[0] is experience:
+            _, e, dev, ptr0, in_place = hit
+        else:
+            sig = _sig(experience, weights)
+            if self._warm.get(sig, 0) < _WARMUP_CALLS:
+                self._warm[sig] = self._warm.get(sig, 0) + 1
+                return agent.train(experience, weights=weights)
+            if not agent._initialized:
+                agent.initialize()
+            if hasattr(agent, "_check_trajectory"):
+                agent._check_trajectory(experience)
+            ptrs = tuple(t.data_ptr() for t in nest_utils.flatten(experience))
+            dev = experience.discount.device
+            if dev.index is None:
+                dev = torch.device("cuda", torch.cuda.current_device())
+            with torch.cuda.device(dev):
+                e = self._entry_for(sig, ptrs, experience, weights, dev)
+            ptr0 = ptrs[0]
+            in_place = all(d.data_ptr() == p for d, p in
+                           zip(nest_utils.flatten(e.static_in), ptrs))
+            if weights is None and in_place and e.static_w is None:
+                if len(self._fast) > 256:
+                    self._fast.clear()
+                self._fast[id(experience)] = (experience, e, dev, ptr0, True)   # keeps it alive
+        with _device_ctx(dev):
+            lanes = _LANES.get((dev.type, dev.index)) if _LANES else None
             if lanes is not None:
-                ev = lanes.ready.get(ptrs[0])
+                ev = lanes.ready.get(ptr0)
                 if ev is not None:       # the draw that filled this ring slot (on lane S)
                     torch.cuda.current_stream(dev).wait_event(ev)
                 else:
                     lanes.join()
-            # only after the wait above: the source may still be being written on lane S
-            for dst, src in zip(nest_utils.flatten(e.static_in), nest_utils.flatten(experience)):
-                if dst.data_ptr() != src.data_ptr():
-                    dst.copy_(src, non_blocking=True)
+            if not in_place:
+                # only after the wait above: the source may still be being written on lane S
+                for dst, src in zip(nest_utils.flatten(e.static_in),
+                                    nest_utils.flatten(experience)):
+                    if dst.data_ptr() != src.data_ptr():
+                        dst.copy_(src, non_blocking=True)
             if e.static_w is not None and e.static_w.data_ptr() != weights.data_ptr():
                 e.static_w.copy_(weights, non_blocking=True)
             if self._whole:
@@ -385,13 +450,21 @@ class GraphedTrain:
                 e.g_apply.replay()
                 agent._train_phase_host()
             else:
+                _mark("train.begin")
                 e.g_grads.replay()
+                _mark("train.grads_done")
                 if agent.gradient_hook is not None:
                     agent.gradient_hook(agent._q_network.flat_grads)
                 if lanes is not None and lanes.collect_done is not None:
                     # the optimizer overwrites theta_k: the collect policy's forward must be done
                     torch.cuda.current_stream(dev).wait_event(lanes.collect_done)
-                e.g_apply.replay()
+                if APPLY_EAGER:
+                    # the optimizer phase is one or two launches: issued directly they follow the
+                    # gradient graph without a second graph-launch boundary on the critical stream
+                    agent._train_phase_apply()
+                else:
+                    e.g_apply.replay()
+                _mark("train.apply_done")
                 agent._train_phase_host()
         self.replays += 1
         return e.out
@@ -407,23 +480,23 @@ class GraphedTrain:
         w_arg = e.static_w if e.static_w is not None else weights
         with capture_batch():
             if self._whole:
-                e.captured = _Captured()
+                e.captured = _Captured("train.whole")
                 e.out = e.captured.capture(lambda: agent._graph_train_whole(e.static_in, w_arg))
                 return
             bucketed = (getattr(agent, "gradient_hook_async", None) is not None and
                         hasattr(agent, "_train_phase_grads_a") and
                         agent._bucket_split() is not None and BUCKETED_ALLREDUCE)
-            e.g_grads = _Captured()
+            e.g_grads = _Captured("train.grads")
             e.out = e.g_grads.capture(
                 (lambda: agent._train_phase_grads_a(e.static_in, w_arg)) if bucketed else
                 (lambda: agent._train_phase_grads(e.static_in, w_arg)))
             if bucketed:
-                e.g_grads_b = _Captured()
+                e.g_grads_b = _Captured("train.grads_b")
                 e.g_grads_b.capture(agent._train_phase_grads_b)
             if g_apply is not None:
                 e.g_apply = g_apply          # the optimizer phase does not depend on the inputs
             else:
-                e.g_apply = _Captured()
+                e.g_apply = _Captured("train.apply")
                 e.g_apply.capture(agent._train_phase_apply)
 
     def static_inputs(self, experience_like=None):
@@ -475,7 +548,7 @@ class GraphedSampler:
         try:
             with capture_batch():
                 for k in range(len(self._ring)):
-                    c = _Captured()
+                    c = _Captured("sample")
                     c.capture(lambda: rb.get_next(self._S, self._T, time_stacked=True))
                     self._ring[k] = c
         except Exception:
@@ -505,11 +578,13 @@ class GraphedSampler:
         rb._check_not_empty(self._T)
         slot = self._i % len(self._ring)
         self._i += 1
-        with torch.cuda.device(rb.device):
+        dev = rb.device
+        with _device_ctx(dev):
             if self._ring[slot] is None:
                 self._prime()
+                self._ptr0 = [nest_utils.flatten(c.out[0])[0].data_ptr() for c in self._ring]
             c = self._ring[slot]
-            lanes = lanes_for(rb.device)
+            lanes = _LANES.get((dev.type, dev.index)) if _LANES else None
             if lanes is None:
                 out = c.replay()
             else:
@@ -517,9 +592,11 @@ class GraphedSampler:
                     lanes.S.wait_event(lanes.collect_done)
                 lanes.S.wait_event(lanes.main_frontier())
                 with torch.cuda.stream(lanes.S):
+                    _mark("sample.begin", lanes.S)
                     out = c.replay()
-                    lanes.sample_done = Lanes._event_on(lanes.S)
-                lanes.ready[nest_utils.flatten(out[0])[0].data_ptr()] = lanes.sample_done
+                    lanes.sample_done = lanes.event_on(lanes.S)
+                    _mark("sample.done", lanes.S)
+                lanes.ready[self._ptr0[slot]] = lanes.sample_done
         self.replays += 1
         return out
 
@@ -531,11 +608,18 @@ class GraphedDriverRun:
     """`common.function(driver.run)` for a DynamicStepDriver: the loop body
     (dynamic_step_driver.py:118-172) is captured once per environment output buffer (two: the
     environment alternates between them) and replayed; the loop condition
-    `sum(counter) < num_steps` (:113) is evaluated on the host from a pinned-memory mailbox the
-    step-counter kernel writes at the START of each body (the count only depends on the incoming
-    step types), so the host learns whether another iteration is needed while the GPU is still
-    executing the body -- no stream synchronisation, and the same iteration count as the
-    reference's in-graph while_loop in every case.
+    `sum(counter) < num_steps` (:113) is evaluated on the host, AHEAD of the body it concerns:
+    a body's contribution `~traj.is_boundary()` (:170) only depends on the step types it
+    receives, i.e. on the previous body's output, so the step-counter kernel runs at the END of
+    each body on the time step just produced and posts "the total if one more body runs" to a
+    pinned-memory mailbox.  Before launching a body the host therefore already knows whether it
+    will be the last one of the run: in the usual case (the run needs exactly ceil(num_steps/B)
+    bodies) `run()` returns without waiting for the GPU at all -- the value it needs was posted
+    by the previous run's last body, an iteration ago -- and only a run that has to make up for
+    boundary steps waits for its own bodies.  (Counting at the START of the body and waiting for
+    it, as round 1 did, put the host in lock-step with the GPU: it could not enqueue train(k)
+    before the GPU had finished train(k-1).)  Same iteration count as the reference's in-graph
+    while_loop in every case.
 
     Requirements, checked at first use: the environment supports `graph_ring()`, the policy has no
     state, observers are device-side (the replay buffer's add_batch) or tolerate tf.function-style
@@ -546,8 +630,10 @@ class GraphedDriverRun:
         self._eager_run = driver.run          # bound method, captured before any patching
         self._graphs = {}
         self._warm = 0
-        self._seq = 0                          # replays issued == mailbox sequence expected
-        self._total_host = 0                   # exact device total at the start of the next run
+        self._seq = 0                          # mailbox posts issued so far
+        self._t_counted = 0                    # counted steps of every body launched so far
+        self._pub = None                       # (env host_epoch, ring slot) the last post describes
+        self.wait_seconds = 0.0                # host time spent waiting for mailbox posts
         self._total = None
         self._counter = None
         self._mbox_host = None
@@ -580,31 +666,40 @@ class GraphedDriverRun:
         self._total = torch.zeros((1,), dtype=torch.int64, device=dev)
         self._counter = torch.zeros((B,), dtype=torch.int32, device=dev)
 
-    def _body(self, time_step, policy_state):
-        """One loop body; the step count comes first (it only needs time_step.step_type)."""
+    def _count(self, step_type):
+        """Posts (mailbox) the counted total if a body consumes a time step of these types."""
         from agents_amd import _lib
+        _lib.check(_lib.load().aa_count_steps(step_type.data_ptr(), step_type.numel(),
+                                              self._counter.data_ptr(), self._total.data_ptr(),
+                                              self._mbox_dev, _lib.stream_ptr()),
+                   "aa_count_steps")
+
+    def _body(self, time_step, policy_state):
+        """One loop body, followed by the step count of the NEXT one (see the class docstring)."""
         from agents_amd.trajectories import trajectory
         drv = self._driver
-        lib = _lib.load()
-        st = time_step.step_type
-        _lib.check(lib.aa_count_steps(st.data_ptr(), st.numel(), self._counter.data_ptr(),
-                                      self._total.data_ptr(), self._mbox_dev, _lib.stream_ptr()),
-                   "aa_count_steps")
         action_step = drv.policy.action(time_step, policy_state)
         next_time_step = drv.env.step(action_step.action)
+        # as early as possible: the host of the NEXT run is waiting for this post
+        self._count(next_time_step.step_type)
         traj = trajectory.from_transition(time_step, action_step, next_time_step)
         for observer in drv._observers:
             observer(traj)
         return next_time_step
 
-    def _wait_total(self):
+    def _read_post(self):
+        """Value of the latest post (waits for it if the GPU has not got there yet)."""
         import ctypes
         from agents_amd import _lib
         v = ctypes.c_int64(0)
+        t0 = time.perf_counter()
         _lib.check(_lib.load().aa_mailbox_wait(self._mbox_host, self._seq, 60_000_000,
                                                ctypes.byref(v)), "aa_mailbox_wait")
-        self._total_host = int(v.value)
-        return self._total_host
+        self.wait_seconds += time.perf_counter() - t0
+        return int(v.value)
+
+    def _epoch(self):
+        return getattr(self._driver.env, "host_epoch", None)
 
     def __call__(self, time_step=None, policy_state=None, maximum_iterations=None):
         drv = self._driver
@@ -626,23 +721,23 @@ class GraphedDriverRun:
         if st.dim() != 1 or st.dtype != torch.int32 or not st.is_cuda:
             return self._eager_run(time_step, policy_state, maximum_iterations)
         B = st.numel()
-        with torch.cuda.device(st.device):
+        with _device_ctx(st.device):
             if self._total is None:
                 self._setup(st.device, B)
             ring = env.graph_ring()
             num_steps = drv._num_steps
-            target = self._total_host + num_steps
             n_min = -(-num_steps // B)
+            lanes = lanes_for(st.device)
+            base = None
             it = 0
             while maximum_iterations is None or it < maximum_iterations:
-                if it >= n_min and self._wait_total() >= target:
+                if it >= n_min and self._t_counted - base >= num_steps:
                     break
                 slot = ring.slot_of(time_step)
                 if slot is None or slot != ring.slot_of(env._time_step):
                     # a TimeStep that is not the environment's current ring buffer (first calls,
                     # or a caller-made one): one eager run brings the loop into the ring
-                    if it > 0:
-                        self._wait_total()
+                    self._pub = None
                     return self._eager_run(time_step, policy_state,
                                            None if maximum_iterations is None
                                            else maximum_iterations - it)
@@ -657,7 +752,7 @@ class GraphedDriverRun:
                     try:
                         with capture_batch():
                             for k in (slot, 1 - slot):
-                                ck = _Captured()
+                                ck = _Captured("collect")
                                 ts_in = ring.slots[k]
                                 # private GEMM scratch: may replay next to the train graphs
                                 with ops.workspace_scope(("collect", id(self)), st.device):
@@ -668,22 +763,35 @@ class GraphedDriverRun:
                         self._graphs.clear()
                         raise
                     c = self._graphs[slot]
-                lanes = lanes_for(st.device)
+                if lanes is not None and it == 0:
+                    lanes.C.wait_event(lanes.main_frontier())
+                    if lanes.sample_done is not None:
+                        lanes.C.wait_event(lanes.sample_done)
+                if self._pub != (self._epoch(), slot) or self._epoch() is None:
+                    # nothing has posted the count of THIS time step (first graphed run, an eager
+                    # step in between, an environment without `host_epoch`): post it now.  What
+                    # the abandoned post had added to the device total counts as consumed.
+                    self._t_counted = self._read_post()
+                    with torch.cuda.stream(lanes.C) if lanes is not None \
+                            else contextlib.nullcontext():
+                        self._count(time_step.step_type)
+                    self._seq += 1
+                if base is None:
+                    base = self._t_counted
+                # the body about to be launched is counted by the latest post
+                self._t_counted = self._read_post()
                 if lanes is None:
                     time_step = c.replay()
                 else:
-                    if it == 0:
-                        lanes.C.wait_event(lanes.main_frontier())
-                        if lanes.sample_done is not None:
-                            lanes.C.wait_event(lanes.sample_done)
                     with torch.cuda.stream(lanes.C):
+                        _mark("collect.begin", lanes.C)
                         time_step = c.replay()
-                        lanes.collect_done = Lanes._event_on(lanes.C)
+                        lanes.collect_done = lanes.event_on(lanes.C)
+                        _mark("collect.done", lanes.C)
                 self._seq += 1
+                self._pub = (self._epoch(), ring.slot_of(time_step))
                 self.replays += 1
                 it += 1
-            else:
-                self._wait_total()
         return time_step, policy_state
 
 

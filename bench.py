@@ -405,6 +405,8 @@ def main():
                     help="replay the collect / sample / train graphs on ONE stream (default: three "
                          "streams ordered by events)")
     ap.add_argument("--prefill", type=int, default=-1, help="frames per env to prefill (-1 = all)")
+    ap.add_argument("--host-profile", type=int, default=0,
+                    help="cProfile this many extra steps after the timed region (stderr)")
     args = ap.parse_args()
     args.steps_given = any(a == "--steps" or a.startswith("--steps=") for a in sys.argv[1:])
     if args.config != "dqn":
@@ -497,10 +499,76 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss_info = step()
+    t_enqueue = time.perf_counter() - t0     # host time to issue the steps (the GPU trails behind)
     graph.join_lanes(dev)
     sync_all()
     dt = time.perf_counter() - t0
     captures_in_timed_region = graph.capture_count() - captures_before
+    if args.host_profile and rank == 0:
+        # plain timers first (cProfile inflates Python frames): host time inside the two calls
+        tc = tt = 0.0
+        n_hp = args.host_profile
+        wait0 = getattr(collect_run, "wait_seconds", 0.0)
+        graph.REPLAY_TIMERS = {}
+        for _ in range(n_hp):
+            a = time.perf_counter()
+            time_step, _ = collect_run(time_step)
+            b = time.perf_counter()
+            lrn.run(iterations=1, iterator=it)
+            c = time.perf_counter()
+            tc += b - a
+            tt += c - b
+        sync_all()
+        wait_us = (getattr(collect_run, "wait_seconds", 0.0) - wait0) / n_hp * 1e6
+        log(f"[bench] host time per iteration: driver.run {tc / n_hp * 1e6:.1f} us "
+            f"(of which waiting for the step-count post {wait_us:.1f} us), "
+            f"learner.run {tt / n_hp * 1e6:.1f} us; HIP-graph launches: " +
+            ", ".join(f"{k} {v[1] / max(v[0], 1) * 1e6:.1f} us x{v[0] / n_hp:.0f}"
+                      for k, v in sorted(graph.REPLAY_TIMERS.items())))
+        graph.REPLAY_TIMERS = None
+        # GPU-side timeline of the last iterations (timing events between the graph launches):
+        # offsets in us from the end of the previous optimizer step
+        graph.TIMELINE = []
+        for _ in range(40):
+            step()
+        sync_all()
+        marks, graph.TIMELINE = graph.TIMELINE, None
+        iters, cur = [], None
+        for tag, ev in marks:
+            if tag == "collect.begin":
+                cur = {}
+                iters.append(cur)
+            if cur is not None:
+                cur[tag] = ev
+        rows = []
+        for a, b in zip(iters[8:-1], iters[9:]):
+            if "train.apply_done" not in a or "train.apply_done" not in b:
+                continue
+            t0 = a["train.apply_done"]
+            rows.append({k: t0.elapsed_time(v) * 1e3 for k, v in b.items()})
+        if rows:
+            keys = ["collect.begin", "collect.done", "sample.begin", "sample.done", "train.begin",
+                    "train.grads_done", "train.apply_done"]
+            log("[bench] GPU timeline of an iteration, us after the previous optimizer step "
+                "(mean over %d): " % len(rows) +
+                ", ".join(f"{k} {sum(r[k] for r in rows if k in r) / len(rows):.0f}"
+                          for k in keys))
+        # where the HOST spends an iteration (the loop is enqueue-bound when host_enqueue_ms_per_step
+        # equals ms_per_step): cProfile over further steps, top entries by own time
+        import cProfile
+        import io
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(args.host_profile):
+            step()
+        pr.disable()
+        sync_all()
+        buf = io.StringIO()
+        st = pstats.Stats(pr, stream=buf)
+        st.sort_stats("tottime").print_stats(28)
+        st.sort_stats("cumulative").print_stats(28)
+        log(buf.getvalue())
     graph.disable_overlap()
     if world > 1:
         import torch.distributed as dist
@@ -520,6 +588,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "prime_steps": prime_steps, "prime_seconds": t_prime,
         "captures_in_timed_region": captures_in_timed_region,
+        "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3,
         "learner_steps_per_sec": steps_per_sec,
         "env_steps_per_sec": steps_per_sec * args.envs * world,
         "replay_rows_gathered_per_sec": steps_per_sec * S * 2 * world,

@@ -249,6 +249,14 @@ int aa_conv_pair_x6_forward(const float* x, int64_t img_pitch, int32_t n_img, in
                             int32_t Cin, const aa_conv_layer_desc* first,
                             const aa_conv_layer_desc* second, void* workspace,
                             int64_t workspace_bytes, void* stream);
+/* The same call in two halves, so that the half that depends on the weights only can be issued
+ * early on another stream (networks/sequential.py does, next to the layer in front of the pair):
+ * phases = 1 splits the filter banks into `workspace` (x, y may be NULL), 2 runs the per-frame
+ * kernel over a workspace prepared for the same weights and shapes, 3 = aa_conv_pair_x6_forward. */
+int aa_conv_pair_x6_phase(const float* x, int64_t img_pitch, int32_t n_img, int32_t H, int32_t W,
+                          int32_t Cin, const aa_conv_layer_desc* first,
+                          const aa_conv_layer_desc* second, void* workspace,
+                          int64_t workspace_bytes, int32_t phases, void* stream);
 
 /* Input gradient of a VALID Conv2D in gather form, one workgroup per frame (no column-gradient
  * slab, no col2im): dx[b,iy,ix,ci] = act'(mask_src[b,iy,ix,ci]) * sum over the patches containing
@@ -277,6 +285,10 @@ int aa_conv_dx_frame(const aa_conv_dx_desc* d, void* stream);
 int64_t aa_conv_dx_frame_x6_workspace_bytes(const aa_conv_dx_desc* d);
 int aa_conv_dx_frame_x6(const aa_conv_dx_desc* d, void* workspace, int64_t workspace_bytes,
                         void* stream);
+/* phases = 1: filter fragments + k-step tables into `workspace` (weights only; dz, dx may be
+ * NULL), 2: the per-frame kernel over a prepared workspace, 3 = aa_conv_dx_frame_x6. */
+int aa_conv_dx_frame_x6_phase(const aa_conv_dx_desc* d, void* workspace, int64_t workspace_bytes,
+                              int32_t phases, void* stream);
 
 /* out[n] = sum_m x[m*ld + n]  (bias gradients).  workspace >= aa_colsum_workspace_bytes. */
 int64_t aa_colsum_workspace_bytes(int64_t M, int64_t N);

@@ -181,3 +181,59 @@ def test_sequential_uses_pair_and_backward_matches(dev):
             sequential.FUSE_CONV_PAIRS = True
     close(res[True][0], res[False][0])
     close(res[True][1], res[False][1], tol=5e-5)
+
+
+def test_hoisted_filter_prepasses_are_bit_identical(dev):
+    """networks/sequential.py issues the weights-only pre-passes of the bf16x6 kernels (filter split
+    of the conv pair; fragments + tables of the conv input gradients) early, on the network's own
+    stream, into per-slot scratch (aa_conv_pair_x6_phase / aa_conv_dx_frame_x6_phase): outputs and
+    gradients must equal the in-place pre-pass bit for bit, also when the weights change between
+    calls (a stale scratch would show) and when forward and backward run on a side stream."""
+    from agents_amd.networks import sequential, layers as L
+    from agents_amd.specs import tensor_spec
+    spec = tensor_spec.TensorSpec((84, 84, 4), torch.uint8)
+
+    def build():
+        net = sequential.Sequential([
+            L.Rescale(255.0), L.Conv2D(32, 8, 4, activation="relu"),
+            L.Conv2D(64, 4, 2, activation="relu"), L.Conv2D(64, 3, 1, activation="relu"),
+            L.Flatten(), L.Dense(512, activation="relu"), L.Dense(6)], input_spec=spec, seed=3)
+        net.create_variables(spec, device=dev)
+        return net
+
+    g = torch.Generator().manual_seed(4)
+    x = torch.randint(0, 256, (32, 84, 84, 4), dtype=torch.uint8, generator=g).to(dev)
+    dq = torch.randn(32, 6, generator=g).to(dev)
+    bump = torch.randn(1, generator=g).item() * 1e-3
+    res = {}
+    saved = (sequential.HOIST_PREP, sequential._HOIST_FWD, sequential._HOIST_BWD)
+    for hoist in (True, False):
+        # both halves on (the default hoists the backward pre-passes only)
+        sequential.HOIST_PREP = sequential._HOIST_FWD = sequential._HOIST_BWD = hoist
+        try:
+            net = build()
+            side = ops.new_side_stream(dev)
+            outs = []
+            for rep in range(3):
+                if rep == 2:   # new weights: the scratch of the previous call is stale now
+                    net.flat_params.mul_(1.0 + bump)
+                if rep == 1:
+                    side.wait_stream(torch.cuda.current_stream())
+                    with ops.side_line(side):
+                        q = net.forward(x, slot="t", need_grad=True).clone()
+                        net.backward(dq, slot="t")
+                    torch.cuda.current_stream().wait_stream(side)
+                else:
+                    q = net.forward(x, slot="t", need_grad=True).clone()
+                    net.backward(dq, slot="t", side_stream=side)
+                torch.cuda.synchronize()
+                outs.append((q, net.flat_grads.clone()))
+            s = net._slots[("t", 32)]
+            assert bool(s.pair_prep) == hoist and bool(s.dx_prep) == hoist
+            res[hoist] = outs
+        finally:
+            sequential.HOIST_PREP, sequential._HOIST_FWD, sequential._HOIST_BWD = saved
+    for (qa, ga), (qb, gb) in zip(res[True], res[False]):
+        assert torch.equal(qa, qb)
+        assert torch.equal(ga, gb)
+    assert not torch.equal(res[True][0][0], res[True][2][0])
