@@ -107,6 +107,9 @@ _SIGNATURES = {
     "aa_dense_small_forward_slabs": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int32,
                                              c_void_p, c_int64, c_void_p, c_void_p, c_int32,
                                              c_int32, c_void_p, c_void_p]),
+    "aa_dense_small_backward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32,
+                                        c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                        c_void_p]),
     "aa_dense_small_dx": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
                                   c_void_p, c_void_p]),
     "aa_dense_small_dw": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p,

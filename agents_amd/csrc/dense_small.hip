@@ -141,14 +141,15 @@ aa_dense_small_fwd_slabs_kernel(const float* __restrict__ slab, int splits, int6
 }
 
 template <int N>
-__global__ void __launch_bounds__(256)
-aa_dense_small_dx_kernel(const float* __restrict__ dz, const float* __restrict__ w,
-                         const float* __restrict__ mask_src, int mask_kind, int64_t M, int K,
-                         float* __restrict__ dx) {
-  // one row per workgroup-row: blockIdx.y = row block of 4, threads sweep k
+__device__ static inline void aa_dense_small_dx_body(const float* __restrict__ dz,
+                                                     const float* __restrict__ w,
+                                                     const float* __restrict__ mask_src,
+                                                     int mask_kind, int64_t M, int K,
+                                                     float* __restrict__ dx, unsigned block,
+                                                     unsigned n_blocks) {
   const int64_t total = M * (int64_t)K;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = (int64_t)block * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)n_blocks * blockDim.x) {
     const int64_t m = i / K;
     const int k = (int)(i - m * K);
     const float* dzr = dz + m * N;
@@ -163,11 +164,21 @@ aa_dense_small_dx_kernel(const float* __restrict__ dz, const float* __restrict__
 
 template <int N>
 __global__ void __launch_bounds__(256)
-aa_dense_small_dw_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dz,
-                         int64_t M, int K, float* __restrict__ dw, float* __restrict__ db) {
+aa_dense_small_dx_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                         const float* __restrict__ mask_src, int mask_kind, int64_t M, int K,
+                         float* __restrict__ dx) {
+  aa_dense_small_dx_body<N>(dz, w, mask_src, mask_kind, M, K, dx, blockIdx.x, gridDim.x);
+}
+
+template <int N>
+__device__ static inline void aa_dense_small_dw_body(const float* __restrict__ x, int64_t ldx,
+                                                     const float* __restrict__ dz, int64_t M,
+                                                     int K, float* __restrict__ dw,
+                                                     float* __restrict__ db, unsigned block,
+                                                     unsigned n_blocks) {
   __shared__ float red[3][64][N];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int k = blockIdx.x * 64 + lane;
+  const int k = block * 64 + lane;
   float acc[N];
 #pragma unroll
   for (int n = 0; n < N; ++n) acc[n] = 0.f;
@@ -208,7 +219,7 @@ aa_dense_small_dw_kernel(const float* __restrict__ x, int64_t ldx, const float* 
     for (int n = 0; n < N; ++n) dw[(size_t)k * N + n] = acc[n];
   }
   // bias gradient: db[n] = sum_m dz[m,n], by the last workgroup's spare wave in fixed m order
-  if (db != nullptr && blockIdx.x == gridDim.x - 1 && wid == 1) {
+  if (db != nullptr && block == n_blocks - 1 && wid == 1) {
     float s[N];
 #pragma unroll
     for (int n = 0; n < N; ++n) s[n] = 0.f;
@@ -224,6 +235,29 @@ aa_dense_small_dw_kernel(const float* __restrict__ x, int64_t ldx, const float* 
       if (lane == 0) db[n] = v;
     }
   }
+}
+
+template <int N>
+__global__ void __launch_bounds__(256)
+aa_dense_small_dw_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dz,
+                         int64_t M, int K, float* __restrict__ dw, float* __restrict__ db) {
+  aa_dense_small_dw_body<N>(x, ldx, dz, M, K, dw, db, blockIdx.x, gridDim.x);
+}
+
+// dX and dW / db of the head in ONE launch: the first n_dw workgroups are the weight-gradient
+// ones (few and long: they go first), the rest sweep the input gradient.  Same bodies, same
+// results as the two separate launches.
+template <int N>
+__global__ void __launch_bounds__(256)
+aa_dense_small_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dz,
+                          const float* __restrict__ w, const float* __restrict__ mask_src,
+                          int mask_kind, int64_t M, int K, float* __restrict__ dx,
+                          float* __restrict__ dw, float* __restrict__ db, unsigned n_dw) {
+  if (blockIdx.x < n_dw)   // uniform per workgroup: the barrier inside the body is safe
+    aa_dense_small_dw_body<N>(x, ldx, dz, M, K, dw, db, blockIdx.x, n_dw);
+  else
+    aa_dense_small_dx_body<N>(dz, w, mask_src, mask_kind, M, K, dx, blockIdx.x - n_dw,
+                              gridDim.x - n_dw);
 }
 
 template <int N>
@@ -298,6 +332,32 @@ int aa_dense_small_dx(const float* dz, const float* w, const float* mask_src, in
   if (N > AA_SMALLN_MAX) return AA_ERR_RANGE;
   return aa_small_dispatch(N, 1, dz, 0, w, mask_src, mask_src ? mask_kind : 0, M, K, dx, nullptr,
                            (hipStream_t)stream);
+}
+
+int aa_dense_small_backward(const float* x, int64_t ldx, const float* dz, const float* w,
+                            const float* mask_src, int32_t mask_kind, int64_t M, int32_t K,
+                            int32_t N, float* dx, float* dw, float* db, void* stream) {
+  if (!x || !dz || !w || !dx || !dw || M <= 0 || K <= 0 || N <= 0 || ldx < K)
+    return AA_ERR_INVALID;
+  if (N > AA_SMALLN_MAX) return AA_ERR_RANGE;
+  const unsigned n_dw = (unsigned)((K + 63) / 64);
+  int64_t n_dx = (M * K + 255) / 256;
+  if (n_dx > 2048) n_dx = 2048;
+  const int mk = mask_src ? mask_kind : 0;
+  hipStream_t st = (hipStream_t)stream;
+  switch (N) {
+#define AA_SM_BWD(NN)                                                                          \
+    case NN:                                                                                   \
+      hipLaunchKernelGGL((aa_dense_small_bwd_kernel<NN>), dim3(n_dw + (unsigned)n_dx),         \
+                         dim3(256), 0, st, x, ldx, dz, w, mask_src, mk, M, K, dx, dw, db, n_dw); \
+      break;
+    AA_SM_BWD(1) AA_SM_BWD(2) AA_SM_BWD(3) AA_SM_BWD(4) AA_SM_BWD(5) AA_SM_BWD(6) AA_SM_BWD(7)
+    AA_SM_BWD(8) AA_SM_BWD(9) AA_SM_BWD(10) AA_SM_BWD(11) AA_SM_BWD(12) AA_SM_BWD(13)
+    AA_SM_BWD(14) AA_SM_BWD(15) AA_SM_BWD(16)
+#undef AA_SM_BWD
+    default: return AA_ERR_RANGE;
+  }
+  return aa_launch_status();
 }
 
 int aa_dense_small_dw(const float* x, int64_t ldx, const float* dz, int64_t M, int32_t K,

@@ -28,8 +28,7 @@
 #define AA_RB_CHUNK 32768  // bytes of one row handled per workgroup per leaf
 #define AA_RB_THREADS 256
 #define AA_RB_INFLIGHT 8   // vectors per lane loaded before the first store
-#define AA_RB_ARRIVAL_STRIDE 16  // int64 words between arrival counters: one 128-byte line each
-#define AA_RB_ARRIVAL_WORDS (9 * AA_RB_ARRIVAL_STRIDE)   // 8 shards + 1 top
+// AA_RB_ARRIVAL_STRIDE / AA_RB_ARRIVAL_WORDS and aa_advance_sharded: common.h
 
 struct AaLeafSet {
   int n;
@@ -86,36 +85,6 @@ __device__ static inline void aa_copy_row_chunk(const char* src, char* dst, int6
     aa_copy_span<uint32_t, NT_SRC, NT_DST>(src, dst, len);
   } else {
     aa_copy_span<uint8_t, NT_SRC, NT_DST>(src, dst, len);
-  }
-}
-
-// aa_advance_when_all_done (common.h) for grids of hundreds to thousands of workgroups: arrivals
-// are counted on 8 words (blockIdx & 7 -- one per XCD under the usual round-robin placement), the
-// last arriver of each shard reports to a ninth: no word sees more than n/8 (+8) atomics, where
-// one word serialised ~2,000 of them at ~11 ns each.  The nine words sit on nine different
-// 128-byte lines (atomics on one line serialise in its L2 channel whatever the word) and are zero
-// between launches.
-__device__ static inline void aa_advance_sharded(int64_t* counter, int64_t* arrival, int64_t inc,
-                                                 unsigned n_groups) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned k = blockIdx.x & 7u;
-    const unsigned long long in_shard = (n_groups + 7u - k) >> 3;
-    unsigned long long* a = reinterpret_cast<unsigned long long*>(arrival);
-    unsigned long long* mine = a + k * AA_RB_ARRIVAL_STRIDE;
-    unsigned long long* top = a + 8 * AA_RB_ARRIVAL_STRIDE;
-    const unsigned long long prev =
-        __hip_atomic_fetch_add(mine, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == in_shard - 1ull) {
-      __hip_atomic_store(mine, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long n_shards = n_groups < 8u ? n_groups : 8u;
-      const unsigned long long p2 =
-          __hip_atomic_fetch_add(top, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (p2 == n_shards - 1ull) {
-        __hip_atomic_store(top, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *counter += inc;
-      }
-    }
   }
 }
 

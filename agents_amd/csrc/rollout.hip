@@ -80,7 +80,9 @@ aa_vecenv_step_kernel(const int32_t* __restrict__ cur_step_type, int64_t B, int6
                       float* __restrict__ discount_out, void* __restrict__ obs_out,
                       int64_t chunks_per_row) {
   const uint64_t s = step_dev != nullptr ? (uint64_t)(*step_dev) : 0ull;
-  if (arrival != nullptr) aa_advance_when_all_done(step_dev, arrival, 1, gridDim.x);
+  // every workgroup has the old value by the time the last arriver moves the counter (sharded
+  // arrival words, common.h: a grid of ~1,800 groups on one word would serialise 20 us of atomics)
+  if (arrival != nullptr) aa_advance_sharded(step_dev, arrival, 1, gridDim.x);
   const int64_t total = B * chunks_per_row;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -250,13 +252,8 @@ int aa_vecenv_random_step(const int32_t* cur_step_type, int64_t B, int64_t obs_e
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(aa_vecenv_step_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      (hipStream_t)stream, cur_step_type, B, obs_elems, obs_kind, obs_lo, obs_hi,
-                     p_end, (uint32_t)seed, (uint32_t)(seed >> 32), step_counter_dev,
-                     (arrival_dev != nullptr && blocks <= AA_MAX_ARRIVAL_GROUPS) ? arrival_dev
-                                                                                  : nullptr,
+                     p_end, (uint32_t)seed, (uint32_t)(seed >> 32), step_counter_dev, arrival_dev,
                      force_first, step_type_out, reward_out, discount_out, obs_out, chunks);
-  if (arrival_dev != nullptr && blocks > AA_MAX_ARRIVAL_GROUPS)
-    hipLaunchKernelGGL(aa_counter_bump_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
-                       step_counter_dev);
   return aa_launch_status();
 }
 

@@ -41,8 +41,10 @@ class RandomTFEnvironment(tf_environment.TFEnvironment):
         self._p_end = float(episode_end_probability)
         self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self._device = torch.device(device) if device is not None else torch.device("cuda")
-        # [step counter, arrival count of the step kernel's workgroups]
-        self._step_counter = torch.zeros((2,), dtype=torch.int64, device=self._device)
+        self._step_counter = torch.zeros((1,), dtype=torch.int64, device=self._device)
+        # arrival counters of the step kernel's workgroups (9 x one 128-byte line; the last
+        # workgroup to arrive advances the step counter inside the launch)
+        self._arrival = torch.zeros((144,), dtype=torch.int64, device=self._device)
         self._time_step = None
         self._ring = None
         # Bumped by every step / reset / restore issued from Python (not by HIP-graph replays of a
@@ -89,7 +91,7 @@ class RandomTFEnvironment(tf_environment.TFEnvironment):
             _lib.check(lib.aa_vecenv_random_step(
                 None if cur_step_type is None else cur_step_type.data_ptr(), self._batch_size,
                 self._obs_spec.num_elements, self._obs_kind, self._lo, self._hi, self._p_end,
-                self._seed, self._step_counter.data_ptr(), self._step_counter[1:].data_ptr(),
+                self._seed, self._step_counter.data_ptr(), self._arrival.data_ptr(),
                 1 if force_first else 0, out.step_type.data_ptr(), out.reward.data_ptr(),
                 out.discount.data_ptr(), out.observation.data_ptr(), st),
                 "aa_vecenv_random_step")

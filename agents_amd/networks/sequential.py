@@ -25,6 +25,7 @@ from agents_amd.utils import nest_utils
 
 
 SMALL_HEAD_ON_MAIN = True
+FUSE_HEAD_BACKWARD = os.environ.get("AA_FUSE_HEAD_BACKWARD", "1") != "0"   # dX + dW of a small head: one launch
 FUSED_SMALL_MLP = True   # whole <=64-wide MLPs in one forward / one backward launch
 DX_FIRST = True   # record a layer's input-gradient launch before its weight-gradient launch
 # the first layer's weight gradient on the main stream (AA_LAST_DW_ON_MAIN=0: on the side stream)
@@ -629,6 +630,17 @@ class Sequential(network.Network):
                 dz_next = None
                 if i == 0 and input_grad is not None:
                     ops.dense_dx(dz2, self._kviews[0], input_grad.view(B, -1))
+                fused_head = (i > 0 and param_grads and SMALL_HEAD_ON_MAIN and FUSE_HEAD_BACKWARD
+                              and ops.dense_small_backward_ok(x, dz2, x if prev_act else None))
+                if fused_head:
+                    # the head's input and weight gradients in one launch (both a few us)
+                    if DX_FIRST and side_stream is not main:
+                        side_stream.wait_stream(main)
+                    ops.dense_small_backward(x, dz2, self._kviews[i], s.dxs[i].view(B, -1),
+                                             self._gkviews[i], mask_src=x if prev_act else None,
+                                             mask_act=prev_act, bias_grad=self._gbviews[i])
+                    dz = s.dxs[i]
+                    continue
                 if i > 0:
                     dx = s.dxs[i].view(B, -1)
                     if DX_FIRST:

@@ -276,6 +276,28 @@ def dense_dx(dz, w, out, mask_src=None, mask_act=None, force_cfg=0, force_splits
     return out
 
 
+def dense_small_backward_ok(x, dz, mask_src):
+    M, N = dz.shape
+    return (USE_SMALL_N and N <= SMALL_N and M <= SMALL_DW_MAX_M and
+            (mask_src is None or mask_src.is_contiguous()))
+
+
+def dense_small_backward(x, dz, w, dx, dw, mask_src=None, mask_act=None, bias_grad=None):
+    """dense_dx + dense_dw (+ bias gradient) of a head with N <= SMALL_N units in one launch."""
+    require_cuda(x, dz, w, dx, dw, mask_src)
+    lda = _rows_ok(x, "x"); _f32c(dz, "dz"); _f32c(w, "w"); _f32c(dx, "dx"); _f32c(dw, "dw")
+    M, K = x.shape
+    M2, N = dz.shape
+    if M != M2 or tuple(w.shape) != (K, N) or tuple(dx.shape) != (M, K) or \
+            tuple(dw.shape) != (K, N):
+        raise ValueError("dense_small_backward shape mismatch")
+    check(_lib.load().aa_dense_small_backward(
+        ptr(x), lda, ptr(dz), ptr(w), ptr(mask_src),
+        ACT[mask_act] if mask_src is not None else 0, M, K, N, ptr(dx), ptr(dw),
+        _bias_grad_ptr(bias_grad, N), stream_ptr()), "aa_dense_small_backward")
+    return dx
+
+
 def dense_dw(x, dz, out, force_cfg=0, force_splits=0, bias_grad=None):
     """out[K,N] = x[M,K]^T @ dz[M,N]; bias_grad[N] = sum_m dz[m, :] (fused, optional)."""
     require_cuda(x, dz, out)

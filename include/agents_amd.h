@@ -46,9 +46,10 @@ int aa_rb_scatter_rows(void* const* leaf_tables_h, const void* const* leaf_items
 /* `arrival_dev`: zero before the call and left zero; the kernel counts finished workgroups in it
  * so that the LAST one advances the counter every group has read (last_id, Philox call counter,
  * env step counter) -- no second one-thread launch.
- *   aa_eps_greedy_action / aa_vecenv_random_step: ONE int64 word, used for launches of at most 16
- *     workgroups (NULL or larger: the counter is left alone, caller: aa_counter_add);
- *   aa_rb_scatter_rows / aa_rb_sample_gather: 144 int64 words, 128-byte aligned = nine counters
+ *   aa_eps_greedy_action: ONE int64 word, used for launches of at most 16 workgroups (NULL or
+ *     larger: a one-thread bump launch follows);
+ *   aa_rb_scatter_rows / aa_rb_sample_gather / aa_vecenv_random_step (NULL = the step counter is
+ *     left alone): 144 int64 words, 128-byte aligned = nine counters
  *     on nine cache lines (arrivals sharded over eight by workgroup index, their last arrivers
  *     meet on the ninth: thousands of device-scope atomics on one word -- or one line --
  *     serialise); NULL for the scatter = a one-thread bump launch from the entry point. */
@@ -194,6 +195,12 @@ int aa_dense_small_forward_slabs(const float* slabs, int32_t splits, int64_t M, 
                                  int32_t act, int32_t N, float* y, void* stream);
 int aa_dense_small_dx(const float* dz, const float* w, const float* mask_src /* [M,K] nullable */,
                       int32_t mask_kind, int64_t M, int32_t K, int32_t N, float* dx, void* stream);
+/* aa_dense_small_dx and aa_dense_small_dw in one launch (same results): the backward pass of the
+ * head, dx [M,K] = (dz w^T) * act'(mask_src), dw [K,N] = x^T dz, db [N] (nullable). */
+int aa_dense_small_backward(const float* x, int64_t ldx, const float* dz, const float* w,
+                            const float* mask_src /* [M,K] nullable */, int32_t mask_kind,
+                            int64_t M, int32_t K, int32_t N, float* dx, float* dw, float* db,
+                            void* stream);
 int aa_dense_small_dw(const float* x, int64_t ldx, const float* dz, int64_t M, int32_t K,
                       int32_t N, float* dw, float* db /* nullable */, void* stream);
 

@@ -411,6 +411,14 @@ def test_dense_small_n(dev, M, N, K, act):
     ops.dense_dw(x.to(dev), dz.to(dev), dw, bias_grad=db)
     close(dw, x.double().T @ dz.double())
     close(db, dz.double().sum(0), tol=5e-6)
+    # dX and dW (+ db) of the head in one launch: the same bits
+    if ops.dense_small_backward_ok(x.to(dev), dz.to(dev), h.to(dev)):
+        dx2 = torch.full((M, K), float("nan"), device=dev)
+        dw2 = torch.full((K, N), float("nan"), device=dev)
+        db2 = torch.full((N,), float("nan"), device=dev)
+        ops.dense_small_backward(x.to(dev), dz.to(dev), w.to(dev), dx2, dw2, mask_src=h.to(dev),
+                                 mask_act="relu", bias_grad=db2)
+        assert torch.equal(dx2, dx) and torch.equal(dw2, dw) and torch.equal(db2, db)
     # and against the GEMM path (same math, different summation order)
     ops.USE_SMALL_N = False
     try:

@@ -228,25 +228,28 @@ def test_vecenv_bit_exact_vs_oracle(dev, kind, elems):
 
 
 def test_vecenv_advances_its_counter_in_kernel(dev):
-    """With an arrival word the step kernel's last workgroup advances the step counter itself
-    (no separate bump launch): same outputs, counter + 1, arrival word back to zero."""
+    """With arrival words (144: nine counters on nine cache lines) the step kernel's last workgroup
+    advances the step counter itself, whatever the grid size (no separate bump launch): same
+    outputs, counter + 1, arrival words back to zero."""
     lib = _lib.load()
     B, elems = 300, 84 * 84 * 4       # many workgroups
     cur = torch.ones(B, dtype=torch.int32, device=dev)
     outs = []
     for arrival in (False, True):
         counter = torch.tensor([5, 0], dtype=torch.int64).to(dev)
+        words = torch.zeros(144, dtype=torch.int64, device=dev)
         st = torch.empty(B, dtype=torch.int32, device=dev)
         rew, disc = torch.empty(B, device=dev), torch.empty(B, device=dev)
         obs = torch.empty((B, elems), dtype=torch.uint8, device=dev)
         for _ in range(3):
             _lib.check(lib.aa_vecenv_random_step(
                 cur.data_ptr(), B, elems, 0, 0.0, 255.0, 0.3, 77, counter.data_ptr(),
-                counter[1:].data_ptr() if arrival else None, 0, st.data_ptr(), rew.data_ptr(),
+                words.data_ptr() if arrival else None, 0, st.data_ptr(), rew.data_ptr(),
                 disc.data_ptr(), obs.data_ptr(), _lib.stream_ptr()), "env")
             if not arrival:
                 _lib.check(lib.aa_counter_add(counter.data_ptr(), 1, _lib.stream_ptr()), "add")
         assert counter.cpu().tolist() == [8, 0]
+        assert int(words.abs().sum().item()) == 0
         outs.append((st.cpu(), rew.cpu(), obs.cpu()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
