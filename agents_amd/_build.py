@@ -28,6 +28,7 @@ SOURCES = [
     ("conv_pair_x6.hip", []),
     ("conv_dx_frame.hip", []),
     ("conv_dx_frame_x6.hip", []),
+    ("conv_dw_frame_x6.hip", []),
     ("nn.hip", ["-ffp-contract=off"]),
     ("dense_small.hip", []),
     ("mlp_small.hip", []),

@@ -102,6 +102,9 @@ _SIGNATURES = {
     "aa_conv_dx_frame_x6": (c_int, [POINTER(ConvDxDesc), c_void_p, c_int64, c_void_p]),
     "aa_conv_dx_frame_x6_phase": (c_int, [POINTER(ConvDxDesc), c_void_p, c_int64, c_int32,
                                           c_void_p]),
+    "aa_conv_dw_frame_x6_workspace_bytes": (c_int64, [POINTER(ConvDxDesc)]),
+    "aa_conv_dw_frame_x6": (c_int, [POINTER(ConvDxDesc), c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int64, c_void_p]),
     "aa_dense_small_forward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64,
                                        c_int32, c_int32, c_void_p, c_void_p]),
     "aa_dense_small_forward_slabs": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int32,

@@ -25,6 +25,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include "agents_amd.h"
+#include "splitk_reduce.h"
 
 #include <type_traits>
 #include <utility>
@@ -111,18 +112,6 @@ __device__ static inline bool aa_block_of(const GemmP& p, AaBlk* b) {
     b->y = r - b->z * p.gy;
   }
   return true;
-}
-
-__device__ static inline float aa_act(float v, int act) {
-  if (act == AA_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == AA_ACT_TANH) return tanhf(v);
-  return v;
-}
-__device__ static inline float aa_actgrad(float y, int kind) {
-  // derivative of the activation expressed through its OUTPUT y
-  if (kind == AA_ACT_RELU) return y > 0.f ? 1.f : 0.f;
-  if (kind == AA_ACT_TANH) return 1.f - y * y;
-  return 1.f;
 }
 
 // Pixel index (b, oy, ox) -> element offset of the patch origin in the NHWC input.
@@ -614,99 +603,6 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_kernel(GemmP p) {
       }
     }
   }
-  }
-}
-
-// out[m][n] = epilogue( sum_z slab[z][m][n] ), deterministic.  A workgroup owns IPB consecutive
-// float4 (or scalar) items and ZL "z-lanes": lane zl sums slabs zl, zl+ZL, zl+2ZL, ... in that
-// order, four loads in flight, and the ZL partials are then added in lane order through LDS -- a
-// fixed association for a given (splits, ZL), so the result is reproducible run to run.  With one
-// z-lane this is the plain z-order sum.  (A single thread walking 247 slabs of the conv1 weight
-// gradient serially took 60 us for 8 MB; 16 z-lanes bring it to the memory system's pace.)
-// Elements [M*N, M*N + N) of the index space are the fused bias-gradient rows that follow the
-// slabs: colsum_out[n] = sum_z slab_end[z][n].
-template <int VEC, int ZL>
-__global__ void __launch_bounds__(256)
-aa_splitk_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N,
-                        float* __restrict__ C, int ldc, const float* __restrict__ bias, int act,
-                        const float* __restrict__ mask_src, int ldm, int mask_kind,
-                        float* __restrict__ colsum_out) {
-  constexpr int IPB = 256 / ZL;
-  __shared__ float part[ZL][IPB][VEC];
-  const size_t MN = (size_t)M * N;
-  const size_t total = (MN + (colsum_out != nullptr ? (size_t)N : 0)) / VEC;
-  const float* cs_rows = slab + (size_t)splits * MN;
-  const int it = threadIdx.x % IPB, zl = threadIdx.x / IPB;
-  for (size_t q0 = (size_t)blockIdx.x * IPB; q0 < total; q0 += (size_t)gridDim.x * IPB) {
-    const size_t q = q0 + it;
-    const bool live = q < total;
-    const size_t i = q * VEC;
-    const bool tail = live && i >= MN;   // bias-gradient element(s)
-    const float* src = tail ? cs_rows + (i - MN) : slab + i;
-    const size_t zstride = tail ? (size_t)N : MN;
-    float v[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) v[e] = 0.f;
-    if (live) {
-      int z = zl;
-      for (; z + 3 * ZL < splits; z += 4 * ZL) {
-        float t[4][VEC];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float* ps = src + (size_t)(z + u * ZL) * zstride;
-          if constexpr (VEC == 4) {
-            const float4 f = *reinterpret_cast<const float4*>(ps);
-            t[u][0] = f.x; t[u][1] = f.y; t[u][2] = f.z; t[u][3] = f.w;
-          } else {
-            t[u][0] = ps[0];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) v[e] += t[u][e];
-      }
-      for (; z < splits; z += ZL) {
-        const float* ps = src + (size_t)z * zstride;
-        if constexpr (VEC == 4) {
-          const float4 f = *reinterpret_cast<const float4*>(ps);
-          v[0] += f.x; v[1] += f.y; v[2] += f.z; v[3] += f.w;
-        } else {
-          v[0] += ps[0];
-        }
-      }
-    }
-    if constexpr (ZL > 1) {
-      __syncthreads();   // previous round's readers are done with `part`
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) part[zl][it][e] = v[e];
-      __syncthreads();
-      if (zl != 0) continue;
-#pragma unroll
-      for (int j = 1; j < ZL; ++j)
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) v[e] += part[j][it][e];
-    }
-    if (!live) continue;
-    if (tail) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) colsum_out[i - MN + e] = v[e];
-      continue;
-    }
-    const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      float x = v[e];
-      if (bias != nullptr) x += bias[n + e];
-      x = aa_act(x, act);
-      if (mask_kind != 0) x *= aa_actgrad(mask_src[(size_t)m * ldm + n + e], mask_kind);
-      v[e] = x;
-    }
-    if constexpr (VEC == 4) {
-      *reinterpret_cast<float4*>(C + (size_t)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-      C[(size_t)m * ldc + n] = v[0];
-    }
   }
 }
 

@@ -459,6 +459,11 @@ def conv_pair_forward(x, w1, b1, s1, act1, y1, w2, b2, s2, act2, y2, prepared=No
     return y2
 
 
+# AA_CONV_DW_X6=0: keep the conv weight gradients of fp32 layers on the fp32 MFMA GEMM (A/B)
+CONV_DW_X6 = _os.environ.get("AA_CONV_DW_X6", "1") != "0"
+_DW_X6_WS = {}
+
+
 def conv_dw(x, dz, w_shape, stride, out, a_div=255.0, force_cfg=0, force_splits=0,
             bias_grad=None):
     """out[KH,KW,Cin,Cout] = patches(x)^T @ dz[B*OH*OW, Cout]; bias_grad[Cout] = column sums of
@@ -472,6 +477,24 @@ def conv_dw(x, dz, w_shape, stride, out, a_div=255.0, force_cfg=0, force_splits=
     Kp = KH * KW * C
     if dz.numel() != Bn * OH * OW * Cout or out.numel() != Kp * Cout:
         raise ValueError("conv_dw: bad sizes")
+    if CONV_DW_X6 and x.dtype == torch.float32 and not force_cfg and not force_splits and \
+            float(a_div) == 1.0 and x.is_contiguous() and x.data_ptr() % 16 == 0 and \
+            dz.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0:
+        key = (Bn, H, W, C, KH, KW, stride, Cout)
+        ws_bytes = _DW_X6_WS.get(key)
+        dd = _dxf_desc((Bn, H, W, C), (KH, KW, C, Cout), stride, dz=dz)
+        if ws_bytes is None:
+            ws_bytes = int(_lib.load().aa_conv_dw_frame_x6_workspace_bytes(ctypes.byref(dd)))
+            _DW_X6_WS[key] = ws_bytes
+        if ws_bytes > 0:
+            # per-frame kernel on the bf16 matrix cores at fp32 accuracy (csrc/conv_dw_frame_x6.hip);
+            # its slabs live in the calling line's scratch like the GEMM's
+            ws = _WS.get(ws_bytes, x.device)
+            with torch.cuda.device(x.device):
+                check(_lib.load().aa_conv_dw_frame_x6(
+                    ctypes.byref(dd), ptr(x), ptr(out), _bias_grad_ptr(bias_grad, Cout), ptr(ws),
+                    ws.numel(), stream_ptr()), "aa_conv_dw_frame_x6")
+            return out
     d = gemm_desc(A=ptr(x), B=ptr(dz), C=ptr(out), M=Kp, N=Cout, K=Bn * OH * OW, lda=0, ldb=Cout,
                   ldc=Cout, a_mode=mode, b_mode=AA_B_ROW, n_img=Bn, H=H, W=W, Cin=C, KH=KH, KW=KW,
                   stride=stride, img_pitch=_img_pitch(x), a_div=float(a_div),

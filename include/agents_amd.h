@@ -297,6 +297,20 @@ int aa_conv_dx_frame_x6(const aa_conv_dx_desc* d, void* workspace, int64_t works
 int aa_conv_dx_frame_x6_phase(const aa_conv_dx_desc* d, void* workspace, int64_t workspace_bytes,
                               int32_t phases, void* stream);
 
+/* Weight (and bias) gradient of a VALID Conv2D over fp32 NHWC frames on the bf16 matrix cores at
+ * fp32 accuracy (csrc/conv_dw_frame_x6.hip; tf.GradientTape through keras Conv2D,
+ * agents/dqn/dqn_agent.py:412-426):  dw[ky,kx,ci,co] = sum x[b,oy*s+ky,ox*s+kx,ci] dz[b,oy,ox,co],
+ * db[co] = sum dz (nullable).  `d` describes the layer as for the input gradient (d->dz, shapes;
+ * w / mask_src / dx unused); x is the layer's forward input [n_img,H,W,Cin] dense.  Operands are
+ * split once into three bf16 pieces as their frame is staged in LDS (natural [pixel][channel]
+ * layout) and read as MFMA fragments with ds_read_b64_tr_b16; workgroup = (group of frames, ky);
+ * per-group slabs in `workspace` are summed in fixed order.  Limits: Cout == 64, Cin a power of two
+ * >= 16, KW*Cin/16 in {4, 8, 12, 16}, OH*OW <= 128 (aa_conv_dw_frame_x6_workspace_bytes returns 0
+ * when a shape does not qualify and the call AA_ERR_RANGE: aa_gemm_f32 is the general path). */
+int64_t aa_conv_dw_frame_x6_workspace_bytes(const aa_conv_dx_desc* d);
+int aa_conv_dw_frame_x6(const aa_conv_dx_desc* d, const float* x, float* dw, float* db,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+
 /* out[n] = sum_m x[m*ld + n]  (bias gradients).  workspace >= aa_colsum_workspace_bytes. */
 int64_t aa_colsum_workspace_bytes(int64_t M, int64_t N);
 int aa_colsum_f32(const float* x, int64_t ld, int64_t M, int64_t N, float* out, void* workspace,

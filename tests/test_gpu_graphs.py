@@ -74,6 +74,67 @@ def test_graphed_driver_matches_eager(dev, B, num_steps, p_end):
     assert rb_g._get_last_id() + 1 >= 12 * -(-num_steps // B)
 
 
+@pytest.mark.parametrize("hide_epoch", [False, True])
+def test_graphed_driver_with_eager_steps_in_between(dev, hide_epoch):
+    """The graphed loop knows, before it launches a body, how many steps that body will count: the
+    previous body posted it.  Whatever moves the environment in between -- an eager `driver.run`,
+    a direct `env.step`, a reset -- invalidates that post (the environment's `host_epoch` tells),
+    and the next graphed run has to count its first time step itself.  Same replay contents, time
+    steps and iteration counts as the all-eager stack throughout; an environment without
+    `host_epoch` takes the counting path on every run."""
+    env_e, _, rb_e, drv_e, _ = _stack(dev, 8, 64, 0.4, 8)
+    env_g, _, rb_g, drv_g, _ = _stack(dev, 8, 64, 0.4, 8)
+    if hide_epoch:
+        class NoEpoch:     # same environment, minus the attribute
+            def __init__(self, env):
+                object.__setattr__(self, "_env", env)
+
+            def __getattr__(self, name):
+                if name == "host_epoch":
+                    raise AttributeError(name)
+                return getattr(self._env, name)
+
+            def __setattr__(self, name, value):
+                setattr(self._env, name, value)
+        drv_g._env = NoEpoch(env_g)
+    run_g = common.function(drv_g.run)
+    ts_e = ts_g = None
+    for i in range(16):
+        ts_e, _ = drv_e.run(ts_e)
+        ts_g, _ = run_g(ts_g)
+        if i in (5, 9):        # an eager run of the same driver object
+            ts_e, _ = drv_e.run(ts_e)
+            ts_g, _ = drv_g.run(ts_g)
+        if i == 7:             # somebody steps the environment directly
+            act = torch.zeros(8, dtype=torch.int64, device=dev)
+            ts_e, ts_g = env_e.step(act), env_g.step(act)
+        if i == 12:
+            ts_e, ts_g = env_e.reset(), env_g.reset()
+        _same_replay(rb_e, rb_g)
+        for a, b in zip(ts_e, ts_g):
+            assert torch.equal(a, b)
+    assert run_g.replays >= 8
+
+
+def test_graphed_driver_look_ahead_bookkeeping(dev):
+    """p_end = 0: every run needs exactly one body and none of them has to post a count itself
+    (the previous body did): replays == runs, one mailbox post per body, the host-side mirror of
+    the counted steps equals runs x num_steps, and the replay buffer holds one row per body."""
+    _, _, rb, drv, _ = _stack(dev, 16, 64, 0.0, 16)
+    run_g = common.function(drv.run)
+    t = None
+    for _ in range(4):
+        t, _ = run_g(t)
+    r0, c0, s0, id0 = run_g.replays, run_g._t_counted, run_g._seq, rb._get_last_id()
+    for _ in range(40):
+        t, _ = run_g(t)
+    torch.cuda.synchronize()
+    assert run_g.replays - r0 == 40
+    assert run_g._seq - s0 == 40              # no extra (bootstrap) posts
+    assert run_g._t_counted - c0 == 40 * 16   # every step of every body counted
+    assert rb._get_last_id() - id0 == 40
+
+
 def test_graphed_driver_maximum_iterations(dev):
     _, _, rb_e, drv_e, _ = _stack(dev, 4, 64, 0.5, 40)
     _, _, rb_g, drv_g, _ = _stack(dev, 4, 64, 0.5, 40)
