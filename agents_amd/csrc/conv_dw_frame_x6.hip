@@ -11,7 +11,7 @@
 // planes that keep the natural [pixel][channel] layout, and the fragments are read with gfx950's
 // LDS transpose read: for an operand image whose rows are k (pixels) and whose 16 columns are the
 // tile's channels, lane (g = l >> 4, j = l & 15) issues two ds_read_b64_tr_b16 at
-//     row 8 g + 4 h + (j >> 2), column quad (j & 3)          h = 0, 1
+//     row k = 8 g + 4 h + (j >> 2), column quad (j & 3)          h = 0, 1
 // and receives exactly the MFMA operand of v_mfma_f32_16x16x32_bf16 (8 consecutive k of channel
 // l & 15; tools/tr16_probe.hip pins the mapping).  The row address is per lane, so the implicit
 // im2col (pixel -> input position of the tap, any stride) costs one add per tap.
@@ -50,7 +50,7 @@ struct Dw6P {
 };
 #ifdef AA_DW6_DEBUG
 #define AA_DW6_DBG(P, bit) (((P).dbg & (bit)) != 0)
-static int g_dw6_dbg = 0, g_dw6_xpad = 16, g_dw6_zpad = 16;
+static int g_dw6_dbg = 0, g_dw6_xpad = -1, g_dw6_zpad = -1;
 #else
 #define AA_DW6_DBG(P, bit) false
 #endif
@@ -111,7 +111,12 @@ __global__ void __launch_bounds__(AA_DW6_THREADS) aa_conv_dw_frame_x6_kernel(Dw6
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int p = 32 * ks + 8 * g + 4 * h + (j >> 2);
+      // Which pixel is "k" is free as long as both operands agree.  LDS serves a transpose read
+      // in two halves of 32 lanes = two 16-lane groups = 8 rows of 32 bytes: with k = 8 g + 4 h + r
+      // mapped to pixel 16 h + 4 g + r those are 8 CONSECUTIVE pixels, and a pixel stride of
+      // 32 (mod 64) bytes spreads them over all 64 banks (k -> 8 g + 4 h + r itself would put
+      // pixels p and p + 8 in one half: same banks whatever the pitch).
+      const int p = 32 * ks + 16 * h + 4 * g + (j >> 2);
       const int pc = p < OHW ? p : OHW - 1;       // pad pixels: any valid x row (their dZ is 0)
       const int oy = cx_div(pc, P.m_ow), ox = pc - oy * P.OW;
       xoff[ks][h] = (oy * P.W + ox * P.stride) * P.xpitch + (j & 3) * 8;
@@ -337,12 +342,18 @@ static int dw6_plan(const aa_conv_dx_desc* d, Dw6Plan* pl) {
   P.xsh = 0;
   while ((8 << P.xsh) < d->Cin) ++P.xsh;
   P.zsh = 3;                                                           // Cout = 64
+  // pixel pitches: a multiple of 16 bytes (16-byte staging stores) whose stride between
+  // consecutive output pixels (s pitches for x, one for dZ) is 32 mod 64 bytes -- see the kernel
+  auto pick = [](int bytes, int stride) {
+    for (int pad = 0; pad <= 112; pad += 16)
+      if (((bytes + pad) * stride) % 64 == 32) return bytes + pad;
+    return bytes + 16;
+  };
+  P.xpitch = pick(d->Cin * 2, s);
+  P.zpitch = pick(d->Cout * 2, 1);
 #ifdef AA_DW6_DEBUG
-  P.xpitch = d->Cin * 2 + g_dw6_xpad;
-  P.zpitch = d->Cout * 2 + g_dw6_zpad;
-#else
-  P.xpitch = d->Cin * 2 + 16;
-  P.zpitch = d->Cout * 2 + 16;
+  if (g_dw6_xpad >= 0) P.xpitch = d->Cin * 2 + g_dw6_xpad;
+  if (g_dw6_zpad >= 0) P.zpitch = d->Cout * 2 + g_dw6_zpad;
 #endif
   P.xplane = P.OH * d->W * P.xpitch;
   P.zplane = pl->ks * 32 * P.zpitch;

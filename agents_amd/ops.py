@@ -477,8 +477,9 @@ def conv_dw(x, dz, w_shape, stride, out, a_div=255.0, force_cfg=0, force_splits=
     Kp = KH * KW * C
     if dz.numel() != Bn * OH * OW * Cout or out.numel() != Kp * Cout:
         raise ValueError("conv_dw: bad sizes")
+    # (a_div rescales uint8 inputs only)
     if CONV_DW_X6 and x.dtype == torch.float32 and not force_cfg and not force_splits and \
-            float(a_div) == 1.0 and x.is_contiguous() and x.data_ptr() % 16 == 0 and \
+            x.is_contiguous() and x.data_ptr() % 16 == 0 and \
             dz.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0:
         key = (Bn, H, W, C, KH, KW, stride, Cout)
         ws_bytes = _DW_X6_WS.get(key)

@@ -176,10 +176,16 @@ def kernel_breakdown(w, S, reps=20):
         out.append(("conv3.fwd", timeit(lambda: ops.conv_forward(
             slot.ys[1], kv[2], bv[2], 1, "relu", slot.ys[2])), 3, f(m[2]), 0))
     x3 = slot.ys[2].view(S, -1)
-    out.append(("fc1.fwd", timeit(lambda: ops.dense_forward(
-        x3, kv[3], bv[3], "relu", slot.ys[3])), 3, f(m[3]), 0))
-    out.append(("fc2.fwd", timeit(lambda: ops.dense_forward(
-        slot.ys[3], kv[4], bv[4], None, slot.ys[4])), 3, f(m[4]), 0))
+    if ops.dense_tail_supported(x3, kv[3], kv[4]):
+        # what the network runs: the fc1 main loop, then the head summing fc1's split-K slabs
+        out.append(("fc1+fc2.fwd(head sums fc1's slabs)", timeit(lambda: ops.dense_tail_forward(
+            x3, kv[3], bv[3], "relu", slot.ys[3], kv[4], bv[4], None, slot.ys[4])), 3,
+            f(m[3] + m[4]), 0))
+    else:
+        out.append(("fc1.fwd", timeit(lambda: ops.dense_forward(
+            x3, kv[3], bv[3], "relu", slot.ys[3])), 3, f(m[3]), 0))
+        out.append(("fc2.fwd", timeit(lambda: ops.dense_forward(
+            slot.ys[3], kv[4], bv[4], None, slot.ys[4])), 3, f(m[4]), 0))
     out.append(("fc1.dW(+bias grad)", timeit(lambda: ops.dense_dw(
         x3, dz4, gk[3], bias_grad=gb[3])), 1, f(m[3]), 0))
     out.append(("fc1.dX", timeit(lambda: ops.dense_dx(
@@ -199,11 +205,16 @@ def kernel_breakdown(w, S, reps=20):
     # ---- the small launches of the iteration (heads, loss, rollout tail) -----------------------
     A = NUM_ACTIONS
     dq = torch.randn(S, A, device=obs_t.device)
-    out.append(("fc2.dW(+bias grad)", timeit(lambda: ops.dense_dw(
-        slot.ys[3], dq, gk[4], bias_grad=gb[4])), 1, f(m[4]), 0))
-    out.append(("fc2.dX", timeit(lambda: ops.dense_dx(
-        dq, kv[4], slot.dxs[4].view(S, -1) if slot.dxs[4] is not None else dz4,
-        mask_src=slot.ys[3], mask_act="relu")), 1, f(m[4]), 0))
+    dx4 = slot.dxs[4].view(S, -1) if slot.dxs[4] is not None else dz4
+    if _seq.FUSE_HEAD_BACKWARD and ops.dense_small_backward_ok(slot.ys[3], dq, slot.ys[3]):
+        out.append(("fc2.dX+dW(+bias grad)", timeit(lambda: ops.dense_small_backward(
+            slot.ys[3], dq, kv[4], dx4, gk[4], mask_src=slot.ys[3], mask_act="relu",
+            bias_grad=gb[4])), 1, 2 * f(m[4]), 0))
+    else:
+        out.append(("fc2.dW(+bias grad)", timeit(lambda: ops.dense_dw(
+            slot.ys[3], dq, gk[4], bias_grad=gb[4])), 1, f(m[4]), 0))
+        out.append(("fc2.dX", timeit(lambda: ops.dense_dx(
+            dq, kv[4], dx4, mask_src=slot.ys[3], mask_act="relu")), 1, f(m[4]), 0))
     wk = agent._get_work(S, obs_t.device)
     q_on, q_tg = slot.ys[4], torch.randn(S, A, device=obs_t.device)
     out.append(("dqn.td_loss(+dL/dq, field sums)", timeit(lambda: ops.dqn_td_loss(
@@ -618,8 +629,10 @@ def main():
             # this tree (tools/pmc_r02.sh -> profiles/r02_pmc.json): all kernels of the case summed
             # for the traffic (pre-passes, reduces), the dominant kernel's counters for mfma_busy
             pmc_case = {"conv2+conv3.fwd(fused)": "conv23.fwd", "fc1.fwd": "fc1.fwd",
+                        "fc1+fc2.fwd(head sums fc1's slabs)": "fc1.fwd",
                         "fc1.dX": "fc1.dX", "fc1.dW(+bias grad)": "fc1.dW",
                         "conv2.dX": "conv2.dX", "conv3.dX": "conv3.dX",
+                        "conv2.dW(+bias grad)": "conv2.dW", "conv3.dW(+bias grad)": "conv3.dW",
                         "conv1.fwd(u8)": "conv1.fwd",
                         "replay.get_next(sample+gather 512 rows)": "replay.get_next"}
             pmc = {}

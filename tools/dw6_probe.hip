@@ -81,19 +81,19 @@ static void run(const char* name, int n, int H, int W, int Cin, int K, int s, in
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 256;
   if (argc > 2 && argv[2][0] == 'p') {   // LDS pitch sweep: pad bytes per pixel row (x, dZ)
-    for (int xp : {0, 8, 16, 24, 32, 40, 48, 64})
-      for (int zp : {16}) {
+    for (int xp : {-1, 0, 16, 32, 48})
+      for (int zp : {-1}) {
         g_dw6_xpad = xp; g_dw6_zpad = zp; g_dw6_dbg = 0;
         printf("xpad %d zpad %d: ", xp, zp);
         run("conv2.dW", n, 20, 20, 32, 4, 2, 64, true);
         printf("xpad %d zpad %d: ", xp, zp);
         run("conv3.dW", n, 9, 9, 64, 3, 1, 64, true);
       }
-    for (int zp : {0, 8, 24, 32, 40, 48, 64}) {
-      g_dw6_xpad = 16; g_dw6_zpad = zp;
-      printf("xpad 16 zpad %d: ", zp);
+    for (int zp : {0, 16, 32, 48}) {
+      g_dw6_xpad = -1; g_dw6_zpad = zp;
+      printf("xpad auto zpad %d: ", zp);
       run("conv2.dW", n, 20, 20, 32, 4, 2, 64, true);
-      printf("xpad 16 zpad %d: ", zp);
+      printf("xpad auto zpad %d: ", zp);
       run("conv3.dW", n, 9, 9, 64, 3, 1, 64, true);
     }
     return 0;

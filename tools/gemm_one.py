@@ -54,10 +54,22 @@ def main():
         fn = lambda: ops.conv_dx(dz, w, xs, strd, dcol, dx, mask_src=y, mask_act="relu")
     elif args.name == "fc1.fwd":
         x, w, b, y = r(S, 3136), r(3136, 512), r(512), r(S, 512)
-        fn = lambda: ops.dense_forward(x, w, b, "relu", y, force_cfg=c, force_splits=s)
+        w2, b2, q = r(512, 6), r(6), r(S, 6)
+        if c or s:
+            fn = lambda: ops.dense_forward(x, w, b, "relu", y, force_cfg=c, force_splits=s)
+        else:   # what the network runs: fc1's main loop + the head summing its split-K slabs
+            fn = lambda: ops.dense_tail_forward(x, w, b, "relu", y, w2, b2, None, q)
     elif args.name == "fc1.dW":
         x, dz, gk = r(S, 3136), r(S, 512), r(3136, 512)
         fn = lambda: ops.dense_dw(x, dz, gk, force_cfg=c, force_splits=s)
+    elif args.name in ("conv2.dW", "conv3.dW"):
+        if args.name == "conv2.dW":
+            xs, wsh, strd, npix = (S, 20, 20, 32), (4, 4, 32, 64), 2, 81
+        else:
+            xs, wsh, strd, npix = (S, 9, 9, 64), (3, 3, 64, 64), 1, 49
+        x, dz, gk, gb = torch.relu(r(*xs)), r(S * npix, 64), r(*wsh), r(64)
+        fn = lambda: ops.conv_dw(x, dz, wsh, strd, gk, a_div=1.0, force_cfg=c, force_splits=s,
+                                 bias_grad=gb)
     elif args.name == "conv1.dW":
         obs = torch.randint(0, 256, (S, 84, 84, 4), dtype=torch.uint8, generator=g).to(dev)
         dz, gk, gb = r(S * 400, 32), r(8, 8, 4, 32), r(32)
