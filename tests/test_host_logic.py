@@ -98,6 +98,28 @@ def test_dataset_combinators():
     assert [next(it) for _ in range(4)] == [0, 1, 2, 3]
 
 
+def test_dataset_unbatch_filter_batch_on_cpu_tensors():
+    """The SAC script's `.unbatch().filter(pred).batch(n)` chain on CPU tensors takes the element-wise
+    combinators (the device compaction needs HIP tensors): survivors in source order, cut into runs
+    of n, non-tensor leaves passed through, remainder kept unless drop_remainder."""
+    import collections
+    T = collections.namedtuple("T", "a b")
+
+    def src():
+        for k in range(5):
+            yield (T(torch.arange(k * 4, (k + 1) * 4).view(4, 1).repeat(1, 2),
+                     torch.arange(k * 4, (k + 1) * 4)), None)
+    ds = ds_lib.Dataset(src)
+    chain = ds.unbatch().filter(lambda t, _: t.b % 3 != 0)
+    out = list(chain.batch(5))
+    assert [o[0].b.tolist() for o in out] == [[1, 2, 4, 5, 7], [8, 10, 11, 13, 14], [16, 17, 19]]
+    assert all(o[1] is None for o in out) and out[0][0].a.shape == (5, 2)
+    assert [o[0].b.tolist() for o in chain.batch(5, drop_remainder=True)] == \
+        [[1, 2, 4, 5, 7], [8, 10, 11, 13, 14]]
+    # the chain is re-iterable and the plain combinators still compose after it
+    assert len(list(chain.batch(5).take(1))) == 1 and len(list(chain)) == 13
+
+
 def test_time_step_constructors_and_from_transition():
     obs = torch.tensor([[1.0, 2.0], [3.0, 4.0]])
     r = ts.restart(obs, batch_size=2)
