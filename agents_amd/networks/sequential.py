@@ -50,6 +50,36 @@ _HOIST_FWD = _HOIST in ("1", "2")
 _HOIST_BWD = _HOIST in ("1", "3")
 
 
+# Prepared weights (opt-in per network, `Sequential.enable_prepared_weights`): the weights-only
+# pre-passes of the bf16x6 convolutions (filter split of a fused pair, fragments + tables of the
+# conv input gradients) are run by whoever WRITES the weights -- the agent right after its
+# optimizer step, after a target update, after a restore -- into buffers owned by the network, and
+# every forward / backward that reads those weights (policy forward of the collect graph, online
+# forward, backward) skips its own pre-pass.  OFF by default (AA_PREPARED_WEIGHTS=1 makes DqnAgent
+# opt in): measured in the DQN iteration on MI355X it LOSES 12 % (0.404 vs 0.359 ms, same box) --
+# the three pre-pass launches after the optimizer step sit on the one point of the iteration that
+# every lane waits for (theta_k+1), while the per-call pre-passes they replace run as first nodes
+# of three parallel branches, where launch-latency-bound kernels overlap for free.  It would need
+# the pre-passes as ONE launch (or inside the optimizer kernel) to pay.
+PREPARED_WEIGHTS = os.environ.get("AA_PREPARED_WEIGHTS", "0") == "1"
+_PREPARED_NETS = []      # weak references to the networks that opted in
+
+
+def ensure_prepared():
+    """Re-runs the pre-passes of every opted-in network whose weights were written behind its back
+    (torch in-place ops bump the parameter tensor's version).  Called by the HIP-graph wrappers
+    before a replay: a captured forward reads the prepared buffers unconditionally."""
+    dead = False
+    for ref in _PREPARED_NETS:
+        net = ref()
+        if net is None:
+            dead = True
+        elif net._pw is not None and net.flat_params._version != net._pw["torch_version"]:
+            net.refresh_prepared()
+    if dead:
+        _PREPARED_NETS[:] = [r for r in _PREPARED_NETS if r() is not None]
+
+
 def _align4(n):
     return (n + 3) // 4 * 4
 
@@ -87,6 +117,7 @@ class Sequential(network.Network):
         self._offsets = None    # [(k_off, b_off)]
         self._kviews = self._bviews = self._gkviews = self._gbviews = None
         self._reg_scratch = None
+        self._pw = None         # prepared weights (enable_prepared_weights)
 
     # ---- construction -------------------------------------------------------------------------
     @property
@@ -323,8 +354,9 @@ class Sequential(network.Network):
         div = None
         pi = 0
         skip = False
+        pw_pair = self._pw["pair"] if self._prepared_ok() else None
         prep_pending, s.prep_issued = s.prep_issued, None
-        if prep_pending is None:
+        if prep_pending is None and pw_pair is None:
             prep_pending = self._hoist_pair_prep(s, B)
         for li, l in enumerate(self._layers):
             if skip:        # second conv of a fused pair: already computed
@@ -353,7 +385,9 @@ class Sequential(network.Network):
                     # two convs over frames that fit LDS: one launch, one workgroup per frame
                     s.xs[pi + 1] = s.ys[pi]
                     prepared = s.pair_prep.get(pi) if prep_pending is not None else None
-                    if prepared is not None and prep_pending:
+                    if pw_pair is not None and pi in pw_pair:
+                        prepared = pw_pair[pi]      # split by whoever wrote the weights
+                    elif prepared is not None and prep_pending:
                         torch.cuda.current_stream(cur.device).wait_stream(self._prep_stream)
                         prep_pending.clear()
                     ops.conv_pair_forward(cur, self._kviews[pi], self._bviews[pi], l.stride,
@@ -411,13 +445,66 @@ class Sequential(network.Network):
             pi += 1
         return out
 
+    def enable_prepared_weights(self):
+        """Opts this network into prepared weights (see PREPARED_WEIGHTS above).  The caller takes
+        over the duty of calling `refresh_prepared()` after every write to the parameters that does
+        not go through a torch in-place op (optimizer / soft-update kernels)."""
+        import weakref
+        self._require_built()
+        if self._pw is not None or self._fused_small_ok():
+            return self._pw is not None
+        dev = self.flat_params.device
+        pair, dx = {}, {}
+        if FUSE_CONV_PAIRS:
+            for pi in self._conv_param_pairs():
+                if pi in pair or (pi - 1) in pair:
+                    continue
+                l, nxt = self._param_layers[pi], self._param_layers[pi + 1]
+                shape = (1,) + tuple(self._info[pi][2])
+                w1, w2 = self._kviews[pi], self._kviews[pi + 1]
+                if pi > 0 and int(np.prod(shape[1:])) % 4 == 0 and \
+                        ops.conv_pair_supported(shape, w1, l.stride, w2, nxt.stride):
+                    n = ops.conv_pair_prepare_bytes(shape, w1, l.stride, w2, nxt.stride)
+                    if n > 0:
+                        pair[pi] = torch.empty((n,), dtype=torch.uint8, device=dev)
+        for i, l in enumerate(self._param_layers):
+            if i == 0 or not isinstance(l, L.Conv2D):
+                continue
+            n = ops.conv_dx_prepare_bytes((1,) + tuple(self._info[i][2]), self._kviews[i], l.stride)
+            if n > 0:
+                dx[i] = torch.empty((n,), dtype=torch.uint8, device=dev)
+        if not pair and not dx:
+            return False
+        self._pw = {"pair": pair, "dx": dx, "torch_version": -1}
+        _PREPARED_NETS.append(weakref.ref(self))
+        self.refresh_prepared()
+        return True
+
+    def refresh_prepared(self):
+        """Runs the pre-passes for the CURRENT weights on the caller's stream (capturable)."""
+        pw = self._pw
+        if pw is None:
+            return
+        for pi, ws in pw["pair"].items():
+            l, nxt = self._param_layers[pi], self._param_layers[pi + 1]
+            ops.conv_pair_prepare((1,) + tuple(self._info[pi][2]), self._kviews[pi], l.stride,
+                                  self._kviews[pi + 1], nxt.stride, ws)
+        for i, ws in pw["dx"].items():
+            ops.conv_dx_prepare((1,) + tuple(self._info[i][2]), self._kviews[i],
+                                self._param_layers[i].stride, ws)
+        pw["torch_version"] = self.flat_params._version
+
+    def _prepared_ok(self):
+        pw = self._pw
+        return pw is not None and pw["torch_version"] == self.flat_params._version
+
     def prepare_forward(self, B, slot=0, need_grad=False):
         """Issues, from the CALLER's stream, the weights-only pre-passes of the next
         `forward(x[B], slot)`: for a forward that will itself run on a side line (the DQN target
         network), where forking a second time is not possible under graph capture."""
         self._require_built()
         s = self._slot(slot, B, need_grad)
-        if s.prep_issued is None and not self._fused_small_ok():
+        if s.prep_issued is None and not self._fused_small_ok() and not self._prepared_ok():
             s.prep_issued = self._hoist_pair_prep(s, B)
 
     def _hoist_pair_prep(self, s, B):
@@ -605,7 +692,8 @@ class Sequential(network.Network):
         if side_stream is None:
             side_stream = main
 
-        dx_prep_pending = self._hoist_dx_prep(s, B, hi, lo)
+        pw_dx = self._pw["dx"] if self._prepared_ok() else None
+        dx_prep_pending = False if pw_dx is not None else self._hoist_dx_prep(s, B, hi, lo)
 
         def on_side(fn, fork=True):
             if side_stream is main:
@@ -667,13 +755,15 @@ class Sequential(network.Network):
                 if i > 0:
                     if DX_FIRST:
                         side_stream.wait_stream(main) if side_stream is not main else None
-                    prepared = s.dx_prep.get(i) if s.dx_prep else None
-                    if prepared is not None and dx_prep_pending:
+                    prepared = s.dx_prep.get(i) if (s.dx_prep and HOIST_PREP) else None
+                    if pw_dx is not None:
+                        prepared = pw_dx.get(i)
+                    elif prepared is not None and dx_prep_pending:
                         main.wait_stream(self._prep_stream)
                         dx_prep_pending = False
                     ops.conv_dx(dz2, self._kviews[i], tuple(x.shape), l.stride, s.dcol, s.dxs[i],
                                 mask_src=x if prev_act else None, mask_act=prev_act,
-                                prepared=prepared if HOIST_PREP else None)
+                                prepared=prepared)
                     dz_next = s.dxs[i]
                 if param_grads:
                     dw = lambda: ops.conv_dw(x, dz2, ks, l.stride, self._gkviews[i],

@@ -113,6 +113,9 @@ class Learner:
                             device=dev or "cpu")
         self.strategy.broadcast_([step], src=0)
         self._agent.train_step_counter.assign(int(step.item()))
+        hook = getattr(self._agent, "post_replicated_state_update", None)
+        if hook is not None:      # state derived from the parameters (prepared filter planes)
+            hook()
 
     @property
     def train_step_numpy(self):
