@@ -169,6 +169,8 @@ _SIGNATURES = {
                     [c_void_p] * 5),
     "aa_pack_small_f32": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
     "aa_pack_sum3_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "aa_copy_segments": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64),
+                                 POINTER(c_int64), POINTER(c_int32), c_int32, c_int64, c_void_p]),
     "aa_add_strided_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p,
                                    c_void_p]),
     "aa_add_l2_grad": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),

@@ -24,7 +24,7 @@ import collections
 import numpy as np
 import torch
 
-from agents_amd import _lib
+from agents_amd import _lib, ops
 from agents_amd.agents import tf_agent
 from agents_amd.networks import actor_distribution_network as adn
 from agents_amd.policies import tf_policy
@@ -196,6 +196,10 @@ class SacAgent(tf_agent.TFAgent):
         self.num_replicas = 1
         self.gradient_hook = None
         self._work = {}
+        self._trans = {}      # B -> buffers of the unpacked transition + the critics' inputs
+        self._xcat = None     # those of the batch being trained on (None: generic path)
+        obs_spec = nest_utils.flatten(time_step_spec.observation)
+        self._O = int(np.prod(obs_spec[0].shape)) if len(obs_spec) == 1 else -1
         self._clip_state = {}
 
     # ---- accessors ------------------------------------------------------------------------------
@@ -251,12 +255,40 @@ class SacAgent(tf_agent.TFAgent):
 
     def _as_transition(self, experience):
         """AsTransition(squeeze_time_dim=True) on a [B, 2] trajectory (data_converter.py:300-380):
-        time_steps = frame 0; next_time_steps = frame 1 with reward/discount of frame 0."""
+        time_steps = frame 0; next_time_steps = frame 1 with reward/discount of frame 0.
+        ONE launch (ops.copy_segments) writes the five slices into buffers of their own and, at
+        the same time, the observation halves of the three [observation | action] critic inputs
+        of the train step (self._xcat)."""
         obs = experience.observation
         B = experience.discount.shape[0]
-        act = experience.action[:, 0].reshape(B, -1).to(torch.float32).contiguous()
-        return (obs[:, 0].contiguous(), act, obs[:, 1].contiguous(),
-                experience.reward[:, 0].contiguous(), experience.discount[:, 0].contiguous())
+        dev = obs.device
+        act_src = experience.action[:, 0].reshape(B, -1)
+        O = int(np.prod(obs.shape[2:]))
+        ok = (obs.dtype == torch.float32 and act_src.dtype == torch.float32 and
+              experience.reward.dtype == torch.float32 and
+              experience.discount.dtype == torch.float32 and obs.is_cuda and obs[:, 0].reshape(B, -1).stride(-1) == 1
+              and O == self._O and act_src.shape[1] == self._A)
+        if not ok:
+            self._xcat = None
+            act = act_src.to(torch.float32).contiguous()
+            return (obs[:, 0].contiguous(), act, obs[:, 1].contiguous(),
+                    experience.reward[:, 0].contiguous(), experience.discount[:, 0].contiguous())
+        t = self._trans.get(B)
+        if t is None:
+            f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+            t = {"obs0": f(B, O), "obs1": f(B, O), "act": f(B, self._A), "rew": f(B), "disc": f(B),
+                 "x_sa": f(B, O + self._A), "x_next": f(B, O + self._A), "x_pi": f(B, O + self._A)}
+            self._trans[B] = t
+        o0, o1 = obs[:, 0].reshape(B, -1), obs[:, 1].reshape(B, -1)
+        with torch.cuda.device(dev):
+            ops.copy_segments([
+                (o0, t["obs0"]), (o0, t["x_sa"][:, :O]), (o0, t["x_pi"][:, :O]),
+                (act_src, t["x_sa"][:, O:]), (o1, t["obs1"]), (o1, t["x_next"][:, :O]),
+                (experience.reward[:, :1], t["rew"].view(B, 1)),
+                (experience.discount[:, :1], t["disc"].view(B, 1))])
+        self._xcat = t
+        return (t["obs0"].view((B,) + tuple(obs.shape[2:])), t["x_sa"][:, O:],
+                t["obs1"].view((B,) + tuple(obs.shape[2:])), t["rew"], t["disc"])
 
     # ---- the three losses (forward + gradients) --------------------------------------------------
     def _critic_phase(self, obs, actions, next_obs, reward, discount, weights, need_grad,
@@ -266,10 +298,19 @@ class SacAgent(tf_agent.TFAgent):
         dev = obs.device
         w = self._w(B, dev)
         na, nlogp, _ = self._policy.sample(next_obs, slot="next", eps=eps_next)
-        tq1 = self._target_critic_network_1.forward(next_obs, na, slot="target")
-        tq2 = self._target_critic_network_2.forward(next_obs, na, slot="target")
-        q1 = self._critic_network_1.forward(obs, actions, slot="critic", need_grad=need_grad)
-        q2 = self._critic_network_2.forward(obs, actions, slot="critic", need_grad=need_grad)
+        x_next = x_sa = None
+        xc = self._xcat
+        if xc is not None and xc["obs1"].data_ptr() == next_obs.data_ptr() and \
+                xc["obs0"].data_ptr() == obs.data_ptr():
+            # [observation | action] once for both twin critics; the observation halves are there
+            x_next, x_sa = xc["x_next"], xc["x_sa"]
+            ops.copy_segments([(na.reshape(B, -1), x_next[:, self._O:])])
+        tq1 = self._target_critic_network_1.forward(next_obs, na, slot="target", x_cat=x_next)
+        tq2 = self._target_critic_network_2.forward(next_obs, na, slot="target", x_cat=x_next)
+        q1 = self._critic_network_1.forward(obs, actions, slot="critic", need_grad=need_grad,
+                                            x_cat=x_sa)
+        q2 = self._critic_network_2.forward(obs, actions, slot="critic", need_grad=need_grad,
+                                            x_cat=x_sa)
         _lib.check(lib.aa_sac_critic_loss(
             q1.data_ptr(), q2.data_ptr(), tq1.data_ptr(), tq2.data_ptr(), nlogp.data_ptr(),
             reward.data_ptr(), discount.data_ptr(), _lib.ptr(weights),
@@ -290,8 +331,13 @@ class SacAgent(tf_agent.TFAgent):
         pol = self._train_policy if need_grad else self._policy
         a, logp, z = pol.sample(obs, slot="actor", need_grad=need_grad, eps=eps,
                                 save=w["save"] if need_grad else None)
-        q1 = self._critic_network_1.forward(obs, a, slot="actor_q", need_grad=need_grad)
-        q2 = self._critic_network_2.forward(obs, a, slot="actor_q", need_grad=need_grad)
+        x_pi = None
+        xc = self._xcat
+        if xc is not None and xc["obs0"].data_ptr() == obs.data_ptr():
+            x_pi = xc["x_pi"]
+            ops.copy_segments([(a.reshape(B, -1), x_pi[:, self._O:])])
+        q1 = self._critic_network_1.forward(obs, a, slot="actor_q", need_grad=need_grad, x_cat=x_pi)
+        q2 = self._critic_network_2.forward(obs, a, slot="actor_q", need_grad=need_grad, x_cat=x_pi)
         _lib.check(lib.aa_sac_actor_loss(
             q1.data_ptr(), q2.data_ptr(), logp.data_ptr(), _lib.ptr(weights),
             self._log_alpha_buf.data_ptr(), self._actor_loss_weight, B,

@@ -512,6 +512,54 @@ int aa_pack_small_f32(const float* src, int32_t n, const float* addend, int32_t 
 // out[r, c] = a[r * lda + c] + b[r * ldb + c], out dense [rows, cols]: the action gradient through
 // the two critics of SAC (column slices of their input-gradient buffers) summed into the buffer
 // the head's backward reads
+// ---- several strided row copies in one launch ------------------------------------------------
+// dst_i[r, c] = src_i[r, c] for up to 8 (src, dst) pairs of 4-byte-element matrices with `rows`
+// rows each: the AsTransition slices of a [B, 2, ...] SAC batch (observation / action / reward /
+// discount of frame 0, observation of frame 1) and the [observation | action] inputs of the twin
+// critics are assembled by ONE launch instead of one torch copy kernel per slice and per critic
+// (17 per train step: agents/sac/sac_agent.py:533-640, data_converter.py:300-380).
+struct AaCopySegs {
+  int n;
+  const uint32_t* src[8];
+  uint32_t* dst[8];
+  int64_t src_pitch[8], dst_pitch[8];   // in elements
+  int cols[8];
+};
+
+__global__ void __launch_bounds__(256) aa_copy_segments_kernel(AaCopySegs S, int64_t rows) {
+  const int seg = blockIdx.x;
+  const uint32_t* src = S.src[seg];
+  uint32_t* dst = S.dst[seg];
+  const int cols = S.cols[seg];
+  const int64_t sp = S.src_pitch[seg], dp = S.dst_pitch[seg];
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y)
+    for (int c = threadIdx.x; c < cols; c += 256) dst[r * dp + c] = src[r * sp + c];
+}
+
+extern "C" int aa_copy_segments(const void* const* src_h, void* const* dst_h,
+                                const int64_t* src_pitch_h, const int64_t* dst_pitch_h,
+                                const int32_t* cols_h, int32_t n_segments, int64_t rows,
+                                void* stream) {
+  if (n_segments < 1 || n_segments > 8 || rows <= 0) return AA_ERR_INVALID;
+  AaCopySegs S;
+  S.n = n_segments;
+  for (int i = 0; i < n_segments; ++i) {
+    if (src_h[i] == nullptr || dst_h[i] == nullptr || cols_h[i] <= 0 || src_pitch_h[i] < cols_h[i] ||
+        dst_pitch_h[i] < cols_h[i])
+      return AA_ERR_INVALID;
+    if ((((uintptr_t)src_h[i] | (uintptr_t)dst_h[i]) & 3) != 0) return AA_ERR_INVALID;
+    S.src[i] = (const uint32_t*)src_h[i];
+    S.dst[i] = (uint32_t*)dst_h[i];
+    S.src_pitch[i] = src_pitch_h[i];
+    S.dst_pitch[i] = dst_pitch_h[i];
+    S.cols[i] = cols_h[i];
+  }
+  const unsigned gy = rows < 256 ? (unsigned)rows : 256u;
+  hipLaunchKernelGGL(aa_copy_segments_kernel, dim3((unsigned)n_segments, gy), dim3(256), 0,
+                     (hipStream_t)stream, S, rows);
+  return aa_launch_status();
+}
+
 int aa_add_strided_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows,
                        int64_t cols, float* out, void* stream) {
   if (!a || !b || !out || rows <= 0 || cols <= 0 || lda < cols || ldb < cols) return AA_ERR_INVALID;

@@ -13,6 +13,8 @@ differentiates through the critics.
 import numpy as np
 import torch
 
+from agents_amd import ops
+
 from agents_amd.networks import layers as L
 from agents_amd.networks import network, sequential
 from agents_amd.specs import tensor_spec
@@ -114,12 +116,20 @@ class CriticNetwork(network.Network):
             self._inputs[key] = buf
         return buf
 
-    def forward(self, observation, action, slot=0, need_grad=False):
-        """q[B] for observation [B, *obs] and action [B, *act] (buffer owned by the network)."""
+    def forward(self, observation, action, slot=0, need_grad=False, x_cat=None):
+        """q[B] for observation [B, *obs] and action [B, *act] (buffer owned by the network).
+        x_cat: the caller's own [B, obs + act] concatenation of the two (SacAgent builds one per
+        phase for both twin critics in a single launch): used as is, must stay untouched until the
+        backward pass of this slot."""
         B = observation.shape[0]
         buf = self._input(slot, B, observation.device)
-        buf["x"][:, :self._obs_dim].copy_(observation.reshape(B, -1))
-        buf["x"][:, self._obs_dim:].copy_(action.reshape(B, -1))
+        if x_cat is not None:
+            if tuple(x_cat.shape) != (B, self._obs_dim + self._act_dim) or \
+                    not x_cat.is_contiguous() or x_cat.dtype != torch.float32:
+                raise ValueError("x_cat must be a contiguous float32 [B, obs + act] tensor")
+            return self._body.forward(x_cat, slot=slot, need_grad=need_grad).view(B)
+        ops.copy_segments([(observation.reshape(B, -1), buf["x"][:, :self._obs_dim]),
+                           (action.reshape(B, -1), buf["x"][:, self._obs_dim:])])
         return self._body.forward(buf["x"], slot=slot, need_grad=need_grad).view(B)
 
     def backward(self, dq, slot=0, param_grads=True, want_action_grad=False, side_stream=None):

@@ -630,6 +630,32 @@ def colsum(x2d, out):
     return out
 
 
+def copy_segments(pairs):
+    """[(src, dst), ...] (at most 8): 2-D views [rows, cols_i] of 4-byte-element tensors whose
+    last axis is contiguous (rows may be strided: slices of a time axis, column blocks of a wider
+    buffer); every dst gets its src in ONE launch (csrc/ppo.hip: aa_copy_segments)."""
+    n = len(pairs)
+    if not 1 <= n <= 8:
+        raise ValueError("copy_segments takes 1..8 (src, dst) pairs")
+    rows = pairs[0][0].shape[0]
+    src = (ctypes.c_void_p * n)()
+    dst = (ctypes.c_void_p * n)()
+    sp = (ctypes.c_int64 * n)()
+    dp = (ctypes.c_int64 * n)()
+    cols = (ctypes.c_int32 * n)()
+    for i, (a, b) in enumerate(pairs):
+        require_cuda(a, b)
+        if a.dim() != 2 or b.dim() != 2 or a.shape != b.shape or a.shape[0] != rows or \
+                a.dtype != b.dtype or a.element_size() != 4 or \
+                (a.shape[1] > 1 and (a.stride(1) != 1 or b.stride(1) != 1)):
+            raise ValueError(f"copy_segments: bad pair {i}: {tuple(a.shape)} {a.dtype} "
+                             f"strides {a.stride()} -> {tuple(b.shape)} {b.dtype} {b.stride()}")
+        src[i], dst[i] = a.data_ptr(), b.data_ptr()
+        sp[i], dp[i], cols[i] = max(a.stride(0), a.shape[1]), max(b.stride(0), b.shape[1]), a.shape[1]
+    check(_lib.load().aa_copy_segments(src, dst, sp, dp, cols, n, rows, stream_ptr()),
+          "aa_copy_segments")
+
+
 # ---- DQN loss -------------------------------------------------------------------------------
 def dqn_td_loss(q_online, q_next_target, q_next_select, next_mask, actions, reward, discount,
                 step_type, weights, gamma, reward_scale, loss_kind, global_batch, loss_out,

@@ -575,6 +575,13 @@ int aa_sac_alpha_loss(const float* logp, const float* weights, const float* log_
 int aa_pack_small_f32(const float* src, int32_t n, const float* addend, int32_t add_at, float* out,
                       void* stream);
 int aa_pack_sum3_f32(const float* a, const float* b, const float* c, float* out4, void* stream);
+/* Up to 8 strided row copies of 4-byte-element matrices in one launch: dst_i[r*dst_pitch_i + c] =
+ * src_i[r*src_pitch_i + c], r < rows, c < cols_i (pitches in elements).  Assembles the AsTransition
+ * slices of a [B, 2, ...] batch and the [observation | action] inputs of SAC's twin critics
+ * (data_converter.py:300-380, agents/sac/sac_agent.py:533-640) instead of one copy per slice. */
+int aa_copy_segments(const void* const* src_h, void* const* dst_h, const int64_t* src_pitch_h,
+                     const int64_t* dst_pitch_h, const int32_t* cols_h, int32_t n_segments,
+                     int64_t rows, void* stream);
 /* out[r, c] = a[r*lda + c] + b[r*ldb + c] (out dense [rows, cols]): d loss / d action through the
  * twin critics of SAC, summed (sac_agent.py:599-640: tape.gradient through both Q networks). */
 int aa_add_strided_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows,
