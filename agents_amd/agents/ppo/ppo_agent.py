@@ -323,13 +323,26 @@ class PPOAgent(tf_agent.TFAgent):
             return obs_flat
         return self._observation_normalizer.normalize(obs_flat)
 
+    def _global_batch(self, nest):
+        """Data-parallel runs: the normalisers are replicated state (MirroredStrategy variables
+        updated in cross-replica context), so every replica updates them with the batches of ALL
+        replicas, gathered in rank order -- the statistics stay identical everywhere.  The hook is
+        installed by train.Learner (strategy.all_gather_batch); one small all-gather per
+        collected batch, off the minibatch loop."""
+        hook = getattr(self, "batch_gather_hook", None)
+        if hook is None or self.num_replicas <= 1:
+            return nest
+        return nest_utils.map_structure(hook, nest)
+
     def update_observation_normalizer(self, batched_observations):   # ppo_agent.py:1078-1082
         if self._observation_normalizer is not None:
-            self._observation_normalizer.update(batched_observations, outer_dims=[0, 1])
+            self._observation_normalizer.update(self._global_batch(batched_observations),
+                                                outer_dims=[0, 1])
 
     def update_reward_normalizer(self, batched_rewards):             # ppo_agent.py:1084-1086
         if self._reward_normalizer is not None:
-            self._reward_normalizer.update(batched_rewards, outer_dims=[0, 1])
+            self._reward_normalizer.update(self._global_batch(batched_rewards),
+                                           outer_dims=[0, 1])
 
     def _loss_forward_backward(self, obs_flat, actions, old_logp, returns, adv, old_loc, old_scale,
                                weights, old_vpred, training, slot):

@@ -76,6 +76,8 @@ class SacPolicy(tf_policy.TFPolicy):
         lib = _lib.load()
         dev = observation.device
         mean, mag = self._consts(dev)
+        if observation.dtype != torch.float32:     # float64 / integer observation specs
+            observation = observation.to(torch.float32)
         z = self._actor_network.forward(observation, slot=slot, need_grad=need_grad)
         B = z.shape[0]
         key = (slot, B)
@@ -201,6 +203,10 @@ class SacAgent(tf_agent.TFAgent):
         obs_spec = nest_utils.flatten(time_step_spec.observation)
         self._O = int(np.prod(obs_spec[0].shape)) if len(obs_spec) == 1 else -1
         self._clip_state = {}
+        # Test hook: keep the N(0,1) draws of the "next action" and "alpha" samples as well (the
+        # actor phase always keeps its own for the backward pass), so that a CPU oracle can be fed
+        # the very noise a (graphed) train step used.  Set before the first train call.
+        self.record_noise = False
 
     # ---- accessors ------------------------------------------------------------------------------
     @property
@@ -241,6 +247,9 @@ class SacAgent(tf_agent.TFAgent):
             w = {"closs": f(1), "aloss": f(1), "lloss": f(1), "td": f(B), "dq1": f(B), "dq2": f(B),
                  "dlogp": f(B), "dz": f(B, 2 * self._A), "da": f(B, self._A),
                  "save": {"tanh": f(B, self._A), "sigma": f(B, self._A), "eps": f(B, self._A)}}
+            if self.record_noise:
+                for k in ("save_next", "save_alpha"):
+                    w[k] = {"tanh": f(B, self._A), "sigma": f(B, self._A), "eps": f(B, self._A)}
             self._work[B] = w
         return w
 
@@ -270,9 +279,11 @@ class SacAgent(tf_agent.TFAgent):
               and O == self._O and act_src.shape[1] == self._A)
         if not ok:
             self._xcat = None
-            act = act_src.to(torch.float32).contiguous()
-            return (obs[:, 0].contiguous(), act, obs[:, 1].contiguous(),
-                    experience.reward[:, 0].contiguous(), experience.discount[:, 0].contiguous())
+            # generic path: the networks compute in float32 (the reference casts observations and
+            # actions, critic_network.py:150-170): float64 / integer specs are converted here
+            f32 = lambda t: t.to(torch.float32).contiguous()
+            return (f32(obs[:, 0]), f32(act_src), f32(obs[:, 1]),
+                    f32(experience.reward[:, 0]), f32(experience.discount[:, 0]))
         t = self._trans.get(B)
         if t is None:
             f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
@@ -297,7 +308,8 @@ class SacAgent(tf_agent.TFAgent):
         B = obs.shape[0]
         dev = obs.device
         w = self._w(B, dev)
-        na, nlogp, _ = self._policy.sample(next_obs, slot="next", eps=eps_next)
+        na, nlogp, _ = self._policy.sample(next_obs, slot="next", eps=eps_next,
+                                           save=w.get("save_next"))
         x_next = x_sa = None
         xc = self._xcat
         if xc is not None and xc["obs1"].data_ptr() == next_obs.data_ptr() and \
@@ -369,7 +381,7 @@ class SacAgent(tf_agent.TFAgent):
         lib = _lib.load()
         B = obs.shape[0]
         w = self._w(B, obs.device)
-        _, logp, _ = self._policy.sample(obs, slot="alpha", eps=eps)
+        _, logp, _ = self._policy.sample(obs, slot="alpha", eps=eps, save=w.get("save_alpha"))
         _lib.check(lib.aa_sac_alpha_loss(
             logp.data_ptr(), _lib.ptr(weights), self._log_alpha_buf.data_ptr(),
             self._target_entropy, 1 if self._use_log_alpha_in_alpha_loss else 0,

@@ -128,8 +128,16 @@ class CriticNetwork(network.Network):
                     not x_cat.is_contiguous() or x_cat.dtype != torch.float32:
                 raise ValueError("x_cat must be a contiguous float32 [B, obs + act] tensor")
             return self._body.forward(x_cat, slot=slot, need_grad=need_grad).view(B)
-        ops.copy_segments([(observation.reshape(B, -1), buf["x"][:, :self._obs_dim]),
-                           (action.reshape(B, -1), buf["x"][:, self._obs_dim:])])
+        o2, a2 = observation.reshape(B, -1), action.reshape(B, -1)
+        if o2.dtype == torch.float32 and a2.dtype == torch.float32 and \
+                o2.stride(-1) == 1 and a2.stride(-1) == 1:
+            ops.copy_segments([(o2, buf["x"][:, :self._obs_dim]),
+                               (a2, buf["x"][:, self._obs_dim:])])
+        else:
+            # tf.cast(..., tf.float32) of the reference (critic_network.py:150-170): float64 /
+            # integer observation or action specs
+            buf["x"][:, :self._obs_dim].copy_(o2)
+            buf["x"][:, self._obs_dim:].copy_(a2)
         return self._body.forward(buf["x"], slot=slot, need_grad=need_grad).view(B)
 
     def backward(self, dq, slot=0, param_grads=True, want_action_grad=False, side_stream=None):

@@ -63,6 +63,9 @@ class Learner:
             # lets the graphed train step overlap the reduce of the dense layers' gradients with
             # the conv layers' backward (two buckets)
             self._agent.gradient_hook_async = getattr(self.strategy, "all_reduce_sum_async_", None)
+            # replicated statistics updated from data (PPO's tensor normalisers) see the GLOBAL
+            # batch, as mirrored variables updated in cross-replica context do
+            self._agent.batch_gather_hook = self.strategy.all_gather_batch
         self._agent.initialize()
         # learner.py:309-337 runs the step inside tf.function; here: HIP-graph replay
         self._train_fn = self._agent.train

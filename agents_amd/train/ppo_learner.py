@@ -157,19 +157,28 @@ class PPOLearner:
         samples = self._take_samples()
         if self._minibatch_size:
             # the reference sizes the run from the NORMALISATION dataset's frame count (:281-291)
-            # and lets tf.data raise OutOfRange if the train dataset is shorter; here the mismatch
-            # is reported up front
+            # and lets tf.data raise OutOfRange if the train dataset is shorter; here a train
+            # dataset that cannot fill the run is reported up front, any other mismatch is
+            # accepted with a warning like the reference accepts it
             train_frames = 0
             for traj, _ in samples:
                 n = 1
                 for d in traj.discount.shape[:2]:
                     n *= int(d)
                 train_frames += n
-            if train_frames != num_frames:
+            needed = int(num_frames / self._minibatch_size) * self._minibatch_size
+            if train_frames < needed:
                 raise ValueError(
                     "PPOLearner: the normalization dataset yielded {} frames but the experience "
-                    "dataset {} for num_samples={}; both must describe the same collected "
-                    "sequences.".format(num_frames, train_frames, self._num_samples))
+                    "dataset only {} for num_samples={}: not enough to fill the {} frames of "
+                    "minibatches per epoch the run is sized for.".format(
+                        num_frames, train_frames, self._num_samples, needed))
+            if train_frames != num_frames:
+                import warnings
+                warnings.warn(
+                    "PPOLearner: the normalization dataset yielded {} frames, the experience "
+                    "dataset {}; the run is sized from the former (ppo_learner.py:281-291)".format(
+                        num_frames, train_frames))
             num_total_batches = int(num_frames / self._minibatch_size) * self._num_epochs
             it = self._minibatches(samples)
         else:

@@ -26,6 +26,9 @@ class Strategy:
     def broadcast_(self, tensors, src=0):
         return tensors
 
+    def all_gather_batch(self, tensor):
+        return tensor
+
     def barrier(self):
         pass
 
@@ -63,6 +66,24 @@ class DataParallelStrategy(Strategy):
         for t in tensors:
             dist.broadcast(t, src=src, group=self._pg)
         return tensors
+
+    def all_gather_batch(self, tensor):
+        """[B, ...] on every rank -> [world * B, ...] (rank order) on every rank: the global batch
+        a mirrored variable's update sees in cross-replica context (the PPO tensor normalisers,
+        tf_agents/agents/ppo/ppo_agent.py:1078-1086 under MirroredStrategy).  Every rank must pass
+        the same shape."""
+        world = self.num_replicas_in_sync
+        x = tensor.contiguous()
+        if dist.get_backend(self._pg) == "nccl":
+            out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype,
+                              device=x.device)
+            dist.all_gather_into_tensor(out, x, group=self._pg)
+            return out
+        # gloo (CPU tests, two ranks sharing one GPU): gathers host tensors
+        host = x.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=self._pg)
+        return torch.cat(parts, dim=0).to(x.device)
 
     def barrier(self):
         dist.barrier(group=self._pg)

@@ -9,6 +9,7 @@
 """
 import functools
 import os
+import pickle
 
 import torch
 
@@ -163,7 +164,12 @@ class Checkpointer:
     Data-parallel runs: every rank constructs the Checkpointer on the same directory and calls
     `save` at the same step; rank 0 writes (to a temporary file, then an atomic rename -- a crash
     mid-write never leaves a truncated `ckpt-N.pt`) and prunes, the others wait at a barrier.  A
-    checkpoint that fails to load is skipped in favour of the previous one."""
+    checkpoint FILE that cannot be read (truncated, not a torch archive) is skipped in favour of
+    the previous one; an error while APPLYING a readable checkpoint (`load_state_dict`: a shape
+    that no longer fits, a bug) propagates -- falling back silently would train from older weights
+    or from scratch and later prune the good checkpoints, and a failure part-way would leave some
+    objects restored from one file and the rest from another.  If files exist and none is readable
+    the constructor raises instead of starting from scratch."""
 
     def __init__(self, ckpt_dir, max_to_keep=20, **kwargs):
         self._dir = ckpt_dir
@@ -172,17 +178,29 @@ class Checkpointer:
         os.makedirs(ckpt_dir, exist_ok=True)
         self.checkpoint_exists = False
         self.restored_from = None
-        for fname in reversed(self._list()):
+        files = self._list()
+        unreadable = []
+        for fname in reversed(files):
             try:
-                self._restore(fname)
-            except Exception as e:  # truncated / foreign file: fall back to the previous one
+                blob = torch.load(os.path.join(self._dir, fname), weights_only=True)
+            except (OSError, EOFError, RuntimeError, ValueError, pickle.UnpicklingError) as e:
+                # the FILE is bad (truncated / foreign): the previous one may still be whole
                 import warnings
-                warnings.warn(f"Checkpointer: could not load {fname} ({type(e).__name__}: {e}); "
+                warnings.warn(f"Checkpointer: could not read {fname} ({type(e).__name__}: {e}); "
                               "trying the previous checkpoint")
+                unreadable.append(fname)
                 continue
+            if not isinstance(blob, dict):
+                unreadable.append(fname)
+                continue
+            self._apply(blob)           # errors here propagate (see the class docstring)
             self.checkpoint_exists = True
             self.restored_from = fname
             break
+        if files and not self.checkpoint_exists:
+            raise RuntimeError(
+                f"Checkpointer: {len(files)} checkpoint file(s) in {ckpt_dir} and none could be "
+                f"read ({', '.join(unreadable)}); refusing to start from scratch over them")
 
     def _list(self):
         fs = [f for f in os.listdir(self._dir) if f.startswith("ckpt-") and f.endswith(".pt")
@@ -215,7 +233,9 @@ class Checkpointer:
             dist.barrier()
 
     def _restore(self, fname):
-        blob = torch.load(os.path.join(self._dir, fname), weights_only=True)
+        self._apply(torch.load(os.path.join(self._dir, fname), weights_only=True))
+
+    def _apply(self, blob):
         for k, o in self._objects.items():
             if k not in blob:
                 continue

@@ -741,6 +741,8 @@ class GraphedDriverRun:
             base = None
             it = 0
             while maximum_iterations is None or it < maximum_iterations:
+                if num_steps <= 0:
+                    break         # `counter < num_steps` is false from the start: no body runs
                 if it >= n_min and self._t_counted - base >= num_steps:
                     break
                 slot = ring.slot_of(time_step)

@@ -51,7 +51,7 @@ class TensorNormalizer:
             for r, v in enumerate(init):
                 st[r].fill_(v)
             self._state.append(st)
-        scratch = max(int(lib.aa_norm_scratch_floats(n)) for n in self._n)
+        scratch = max((int(lib.aa_norm_scratch_floats(n)) for n in self._n), default=1)
         self._scratch = torch.empty((scratch,), dtype=torch.float32, device=self._device)
 
     def _row_nest(self, r):
@@ -99,14 +99,24 @@ class TensorNormalizer:
         raise NotImplementedError
 
     # ---- API ---------------------------------------------------------------------------------
+    _CHECK_OUTER_DIMS = False
+
     def update(self, tensor, outer_dims=(0,)):
-        """Updates the statistics with a batch; every dim in front of the spec's shape is a batch
-        dim (the streaming normaliser ignores `outer_dims` like the reference, :325-333; the EMA
-        normaliser reduces over exactly those leading dims)."""
+        """Updates the statistics with a batch.  Both normalisers reduce over ALL dims in front of
+        the spec's shape: the streaming normaliser ignores `outer_dims` exactly like the reference
+        (:325-333); the reference's EMA normaliser reduces over `outer_dims` only
+        (tf.reduce_mean(axis=outer_dims), :236-281), so for it anything other than "all leading
+        dims" -- e.g. a [B, T, ...] input with outer_dims=(0,) -- is rejected here instead of
+        silently computing a different statistic."""
         lib = _lib.load()
         with torch.cuda.device(self._device):
             stream = _lib.stream_ptr()
-            for (x, _), st in zip(self._flat_inputs(tensor, "tensor"), self._state):
+            for (x, outer), st in zip(self._flat_inputs(tensor, "tensor"), self._state):
+                if self._CHECK_OUTER_DIMS and \
+                        sorted(int(d) for d in outer_dims) != list(range(len(outer))):
+                    raise NotImplementedError(
+                        f"EMATensorNormalizer.update reduces over all {len(outer)} leading "
+                        f"dim(s) of the input; outer_dims={tuple(outer_dims)} is not supported")
                 if x.shape[0] == 0:
                     continue
                 self._update_leaf(lib, x, st, stream)
@@ -132,6 +142,7 @@ class TensorNormalizer:
 class EMATensorNormalizer(TensorNormalizer):
     """Exponential moving average of mean and variance (:209-285)."""
     _ROWS = 2
+    _CHECK_OUTER_DIMS = True
 
     def __init__(self, tensor_spec, scope="normalize_tensor", norm_update_rate=0.001,
                  device=None):

@@ -61,18 +61,19 @@ def init_params(layers, input_shape, seed=0, scale=2.0):
     return params
 
 
-def forward(layers, params, x):
-    """x: [B, *input_shape] (uint8 or float32).  Returns [B, out]."""
+def forward(layers, params, x, dtype=torch.float32):
+    """x: [B, *input_shape] (uint8 or float32).  Returns [B, out].  `dtype=torch.float64` (with
+    float64 params) is the arbiter the parity tests rank two fp32 implementations against."""
     it = iter(params)
     h = x
     for l in layers:
         k = l["kind"]
         if k == "rescale":
-            h = h.to(torch.float32) / l["div"]
+            h = h.to(dtype) / l["div"]
         elif k == "conv":
             w = next(it)
             b = next(it)
-            h = h.to(torch.float32)
+            h = h.to(dtype)
             y = F.conv2d(h.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), b, stride=l["stride"])
             h = _act(y.permute(0, 2, 3, 1), l["act"])
         elif k == "flatten":
@@ -80,7 +81,7 @@ def forward(layers, params, x):
         elif k == "dense":
             w = next(it)
             b = next(it)
-            h = _act(h.to(torch.float32) @ w + b, l["act"])
+            h = _act(h.to(dtype) @ w + b, l["act"])
     return h
 
 
@@ -101,3 +102,41 @@ def atari_q_layers(num_actions):
 def mlp_q_layers(fc, num_actions, act="relu"):
     return [{"kind": "dense", "units": u, "act": act} for u in fc] + \
            [{"kind": "dense", "units": num_actions, "act": None}]
+
+
+def forward_branch(layers, params, x, masks=None, dtype=torch.float64):
+    """The same stack as `forward`, returning (output, [pre-activation of every parametrised
+    layer]).  With `masks` (one 0/1 tensor per parametrised layer, None for layers without an
+    activation) every ReLU is replaced by a multiplication with the given mask: the network is
+    evaluated -- and differentiated by autograd -- on the linear branch some OTHER implementation
+    took.  The float64 arbiter of tests/test_gpu_bench_config.py uses this to separate the two
+    ways in which fp32 implementations of a ReLU network differ: rounding of the sums (small,
+    every step) and units whose exact pre-activation is within rounding of zero landing on
+    different sides of the ReLU (rare, but each one removes a whole term from a gradient sum)."""
+    it = iter(params)
+    h = x
+    pre = []
+    pi = 0
+    for l in layers:
+        k = l["kind"]
+        if k == "rescale":
+            h = h.to(dtype) / l["div"]
+            continue
+        if k == "flatten":
+            h = h.reshape(h.shape[0], -1)
+            continue
+        w = next(it)
+        b = next(it)
+        h = h.to(dtype)
+        if k == "conv":
+            z = F.conv2d(h.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), b,
+                         stride=l["stride"]).permute(0, 2, 3, 1)
+        else:
+            z = h @ w + b
+        pre.append(z)
+        if masks is not None and masks[pi] is not None and l["act"] == "relu":
+            h = z * masks[pi].to(dtype)
+        else:
+            h = _act(z, l["act"])
+        pi += 1
+    return h, pre

@@ -126,39 +126,74 @@ class OracleSacAgent:
         self.use_log_alpha = use_log_alpha_in_alpha_loss
         self.steps = 0
 
-    def q(self, params, obs, act):
-        return nets.forward(self.critic_layers, params, torch.cat([obs, act], -1)).reshape(-1)
+    def _mlp(self, layers, params, x, masks=None, tag=""):
+        """nets.forward, or -- with `masks` (another implementation's ReLU activation pattern, one
+        0/1 tensor per hidden layer, None for the head) -- the same stack on THAT linear branch
+        (nets.forward_branch); units where the pattern differs from this evaluation's own are
+        logged in self.flips as (tag, count, largest |z| / max|z|): legitimate only if the
+        pre-activation is numerically zero (oracle/arbiter.py explains why this matters)."""
+        if masks is None:
+            return nets.forward(layers, params, x)
+        out, pre = nets.forward_branch(layers, params, x, masks=masks, dtype=torch.float32)
+        for z, m in zip(pre, masks):
+            if m is None:
+                continue
+            z = z.detach()
+            diff = (z > 0) != m.to(torch.bool)
+            if bool(diff.any()):
+                self.flips.append((tag, int(diff.sum()),
+                                   float(z[diff].abs().max() / z.abs().max())))
+        return out
 
-    def pi(self, obs, eps):
-        z = nets.forward(self.actor_layers, self.actor, obs)
+    def q(self, params, obs, act, masks=None, tag=""):
+        return self._mlp(self.critic_layers, params, torch.cat([obs, act], -1), masks,
+                         tag).reshape(-1)
+
+    def pi(self, obs, eps, masks=None, tag=""):
+        z = self._mlp(self.actor_layers, self.actor, obs, masks, tag)
         return tanh_normal(z, eps, self.act_mean, self.act_mag, self.kind)
 
     def train(self, obs, actions, next_obs, reward, discount, eps_next, eps_actor, eps_alpha,
-              weights=None):
-        """One SacAgent._train step with the three noise draws supplied by the caller."""
+              weights=None, grads_override=None, masks=None):
+        """One SacAgent._train step with the three noise draws supplied by the caller.
+        `grads_override` = dict(critic=[...], actor=[...], alpha=float): the optimizer steps are
+        taken with THESE gradients (another implementation's) while this agent's own are still
+        returned -- the two then enter every later phase from (rounding-)identical parameters, so
+        each phase's gradients and each optimizer step can be compared at a tight tolerance
+        without the chaotic drift of two free-running trainings.
+        `masks` = {"c1.critic", "c2.critic", "c1.actor_q", "c2.actor_q", "actor": [...]}: ReLU
+        activation patterns of the other implementation for the five DIFFERENTIATED forwards (see
+        `_mlp`; the forwards that only produce values are continuous in a boundary flip)."""
+        masks = masks or {}
+        self.flips = []
         with torch.no_grad():
             na = self.pi(next_obs, eps_next)
-        closs, _ = critic_loss(lambda o, a: self.q(self.c1, o, a), lambda o, a: self.q(self.c2, o, a),
-                               lambda o, a: self.q(self.t1, o, a), lambda o, a: self.q(self.t2, o, a),
-                               na, self.log_alpha.detach(), obs, actions, next_obs, reward,
-                               discount, self.loss_fn, self.gamma, self.scale, weights)
+        closs, _ = critic_loss(
+            lambda o, a: self.q(self.c1, o, a, masks.get("c1.critic"), "c1.critic"),
+            lambda o, a: self.q(self.c2, o, a, masks.get("c2.critic"), "c2.critic"),
+            lambda o, a: self.q(self.t1, o, a), lambda o, a: self.q(self.t2, o, a),
+            na, self.log_alpha.detach(), obs, actions, next_obs, reward,
+            discount, self.loss_fn, self.gamma, self.scale, weights)
         closs = self.wc * closs
         cparams = self.c1 + self.c2
         cgrads = torch.autograd.grad(closs, cparams)
-        self.opt_critic.step(cparams, cgrads)
+        self.opt_critic.step(cparams, grads_override["critic"] if grads_override else cgrads)
 
-        aloss = self.wa * actor_loss(lambda o, a: self.q(self.c1, o, a),
-                                     lambda o, a: self.q(self.c2, o, a), self.pi(obs, eps_actor),
-                                     self.log_alpha.detach(), obs, weights)
+        aloss = self.wa * actor_loss(
+            lambda o, a: self.q(self.c1, o, a, masks.get("c1.actor_q"), "c1.actor_q"),
+            lambda o, a: self.q(self.c2, o, a, masks.get("c2.actor_q"), "c2.actor_q"),
+            self.pi(obs, eps_actor, masks.get("actor"), "actor"),
+            self.log_alpha.detach(), obs, weights)
         agrads = torch.autograd.grad(aloss, self.actor)
-        self.opt_actor.step(self.actor, agrads)
+        self.opt_actor.step(self.actor, grads_override["actor"] if grads_override else agrads)
 
         with torch.no_grad():
             _, logp = self.pi(obs, eps_alpha)
         lloss = self.wl * alpha_loss(logp, self.log_alpha, self.target_entropy,
                                      self.use_log_alpha, weights)
         lgrad = torch.autograd.grad(lloss, [self.log_alpha])
-        self.opt_alpha.step([self.log_alpha], lgrad)
+        self.opt_alpha.step([self.log_alpha], [torch.tensor(float(grads_override["alpha"]))]
+                            if grads_override else lgrad)
 
         self.steps += 1
         if self.steps % self.period == 0:

@@ -275,7 +275,47 @@ def test_checkpointer_atomic_save_prune_and_fallback(tmp_path):
         warnings.simplefilter("always")
         ck3 = common.Checkpointer(d, obj=o3, step=common.Variable(0))
     assert ck3.restored_from == "ckpt-3.pt" and o3.n == 3
-    assert any("could not load ckpt-9.pt" in str(x.message) for x in w)
+    assert any("could not read ckpt-9.pt" in str(x.message) for x in w)
     # stray temp files of a crashed writer are ignored
     open(os.path.join(d, "ckpt-10.pt.tmp123"), "wb").close()
     assert common.Checkpointer(d, obj=_Obj(), step=common.Variable(0)).restored_from == "ckpt-3.pt"
+
+
+def test_checkpointer_does_not_hide_load_state_dict_errors(tmp_path):
+    """A readable checkpoint that no longer FITS (config change, bug in load_state_dict) must
+    raise: falling back would silently train from older weights -- or from scratch -- and later
+    saves would prune the good files; and files that exist but cannot be read at all must not be
+    mistaken for "no checkpoint"."""
+    import os
+    import pytest
+    import warnings
+    from agents_amd.utils import common
+    d = str(tmp_path / "ck")
+    o = _Obj()
+    ck = common.Checkpointer(d, obj=o, step=common.Variable(0))
+    for k in (1, 2):
+        o.n = k
+        ck.save(k)
+
+    class _Other(_Obj):
+        def __init__(self):
+            self.t = torch.zeros(7)       # shape changed since the checkpoint was written
+            self.n = 0
+            self.loaded = []
+
+        def load_state_dict(self, sd):
+            self.loaded.append(int(sd["n"]))
+            super().load_state_dict(sd)
+
+    bad = _Other()
+    with pytest.raises(RuntimeError):
+        common.Checkpointer(d, obj=bad, step=common.Variable(0))
+    assert bad.loaded == [2]              # the older file was NOT tried behind the caller's back
+    assert sorted(os.listdir(d)) == ["ckpt-1.pt", "ckpt-2.pt"]
+    for f in os.listdir(d):               # every file unreadable: refuse to start from scratch
+        with open(os.path.join(d, f), "wb") as fh:
+            fh.write(b"garbage")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(RuntimeError, match="none could be read"):
+            common.Checkpointer(d, obj=_Obj(), step=common.Variable(0))

@@ -71,7 +71,10 @@ def cpu_baseline(minibatch, steps, threads):
     return steps / (time.perf_counter() - t0)
 
 
-def run(args):
+def build(dev, envs=2048, steps=128, minibatch=4096, epochs=10, after_train_step_fn=None,
+          episode_end_probability=1e-3):
+    """configs[2] as this benchmark runs it (also what tests/test_gpu_bench_config_ppo.py checks
+    against oracle/ppo.py + oracle/tensor_normalizer.py)."""
     from agents_amd import optimizers
     from agents_amd.agents.ppo import ppo_actor_network as pan
     from agents_amd.agents.ppo import ppo_clip_agent
@@ -83,9 +86,7 @@ def run(args):
     from agents_amd.trajectories import time_step as ts
     from agents_amd.utils import common
 
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
-    B, T = args.envs, args.steps
+    B, T = envs, steps
     obs = tensor_spec.BoundedTensorSpec((17,), torch.float32, -1.0, 1.0)
     act = tensor_spec.BoundedTensorSpec((6,), torch.float32, -1.0, 1.0)
     tss = ts.time_step_spec(obs)
@@ -99,20 +100,34 @@ def run(args):
         update_normalizers_in_train=False)     # schulman17/train_eval_lib.py:197-226 defaults
     agent.initialize()
     env = random_tf_environment.RandomTFEnvironment(tss, act, batch_size=B,
-                                                    episode_end_probability=1e-3, seed=3, device=dev)
+                                                    episode_end_probability=episode_end_probability,
+                                                    seed=3, device=dev)
     rb = rb_lib.TFUniformReplayBuffer(agent.collect_data_spec, batch_size=B, max_length=T + 1,
                                       device=dev)
     drv = dynamic_step_driver.DynamicStepDriver(env, agent.collect_policy,
                                                 observers=[rb.add_batch], num_steps=B * (T + 1))
 
+    def raw_dataset_fn():
+        return rb.as_dataset(sample_batch_size=B, num_steps=T + 1, single_deterministic_pass=True)
+
     def dataset_fn():
-        return rb.as_dataset(sample_batch_size=B, num_steps=T + 1,
-                             single_deterministic_pass=True).map(
+        return raw_dataset_fn().map(
             lambda traj, info: (agent.preprocess_sequence(traj), info))
 
     lrn = ppo_learner.PPOLearner(None, common.Variable(0), agent, dataset_fn, dataset_fn,
-                                 num_samples=1, num_epochs=args.epochs,
-                                 minibatch_size=args.minibatch, shuffle_buffer_size=B * (T + 1))
+                                 num_samples=1, num_epochs=epochs,
+                                 minibatch_size=minibatch, shuffle_buffer_size=B * (T + 1),
+                                 after_train_strategy_step_fn=after_train_step_fn)
+    return dict(agent=agent, actor=actor, value=value, env=env, rb=rb, collect_driver=drv,
+                learner=lrn, raw_dataset_fn=raw_dataset_fn, obs_spec=obs, action_spec=act)
+
+
+def run(args):
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    B, T = args.envs, args.steps
+    w = build(dev, B, T, args.minibatch, args.epochs)
+    agent, rb, drv, lrn = w["agent"], w["rb"], w["collect_driver"], w["learner"]
 
     def one_iteration():
         t0 = time.perf_counter()

@@ -45,7 +45,9 @@ def cpu_baseline(batch, steps, threads):
     return steps / (time.perf_counter() - t0)
 
 
-def run(args):
+def build(dev, envs=4096, max_length=64, batch=256, record_noise=False, prefill=True):
+    """configs[4] at one GPU as this benchmark runs it (also what
+    tests/test_gpu_bench_config_sac.py checks against oracle/sac.py)."""
     from agents_amd import optimizers
     from agents_amd.agents.sac import sac_agent
     from agents_amd.drivers import dynamic_step_driver
@@ -57,10 +59,8 @@ def run(args):
     from agents_amd.specs import tensor_spec
     from agents_amd.train import learner
     from agents_amd.trajectories import time_step as ts
-    from agents_amd.utils import common, graph
+    from agents_amd.utils import common
 
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
     obs = tensor_spec.BoundedTensorSpec((376,), torch.float32, -1.0, 1.0)
     act = tensor_spec.BoundedTensorSpec((17,), torch.float32, -0.4, 0.4)
     tss = ts.time_step_spec(obs)
@@ -76,20 +76,35 @@ def run(args):
         actor_optimizer=optimizers.Adam(3e-4), critic_optimizer=optimizers.Adam(3e-4),
         alpha_optimizer=optimizers.Adam(3e-4), target_update_tau=0.005, target_update_period=1,
         td_errors_loss_fn=common.element_wise_squared_loss, gamma=0.99, reward_scale_factor=0.1)
+    agent.record_noise = record_noise
     agent.initialize()
-    env = random_tf_environment.RandomTFEnvironment(tss, act, batch_size=args.envs,
+    env = random_tf_environment.RandomTFEnvironment(tss, act, batch_size=envs,
                                                     episode_end_probability=1e-3, seed=3, device=dev)
-    rb = rb_lib.TFUniformReplayBuffer(agent.collect_data_spec, batch_size=args.envs,
-                                      max_length=args.max_length, device=dev)
+    rb = rb_lib.TFUniformReplayBuffer(agent.collect_data_spec, batch_size=envs,
+                                      max_length=max_length, device=dev)
     init = dynamic_step_driver.DynamicStepDriver(env, agent.collect_policy,
                                                  observers=[rb.add_batch],
-                                                 num_steps=args.envs * args.max_length)
-    init.run()
+                                                 num_steps=envs * max_length)
+    if prefill:
+        init.run()
     drv = dynamic_step_driver.DynamicStepDriver(env, agent.collect_policy,
                                                 observers=[rb.add_batch], num_steps=1)
     collect = common.function(drv.run)
     lrn = learner.Learner(None, common.Variable(0), agent)
-    it = iter(rb.as_dataset(sample_batch_size=args.batch, num_steps=2).prefetch(3))
+    dataset = rb.as_dataset(sample_batch_size=batch, num_steps=2).prefetch(3)
+    return dict(agent=agent, actor=actor, critic=critic, env=env, rb=rb, init_driver=init,
+                collect_driver=drv, collect=collect, learner=lrn, dataset=dataset,
+                obs_spec=obs, action_spec=act)
+
+
+def run(args):
+    from agents_amd.utils import graph
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    w = build(dev, args.envs, args.max_length, args.batch)
+    agent, collect, lrn = w["agent"], w["collect"], w["learner"]
+    it = iter(w["dataset"])
     tsx = None
 
     def step():
