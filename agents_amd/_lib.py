@@ -80,6 +80,7 @@ _SIGNATURES = {
     "aa_random_permutation": (c_int, [c_int64, c_uint64, c_uint64, c_void_p, c_void_p]),
     "aa_rb_range_rows": (c_int, [c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "aa_counter_add": (c_int, [c_void_p, c_int64, c_void_p]),
+    "aa_marker": (c_int, [c_int32, c_void_p]),
     "aa_gemm_f32_workspace_bytes": (c_int64, [POINTER(GemmDesc)]),
     "aa_gemm_f32": (c_int, [POINTER(GemmDesc), c_void_p, c_int64, c_void_p]),
     "aa_gemm_f32_slabs": (c_int, [POINTER(GemmDesc), c_void_p, c_int64, POINTER(c_int32),

@@ -139,8 +139,16 @@ class Learner:
         sums = [flat[i].sum().reshape(1) if flat[i].dim() > 0 else flat[i].reshape(1)
                 for i in idx]
         # one packed copy: the result owns its storage (the inputs may be views of buffers the
-        # next train step overwrites) and travels in one all-reduce
-        vec = torch.cat([s.to(torch.float32) for s in sums])
+        # next train step overwrites) and travels in one all-reduce.  Up to 8 float32 device
+        # scalars are packed by ONE aa_copy_segments launch (no torch kernel on the timed path)
+        if len(sums) <= 8 and all(s.dtype == torch.float32 and s.is_cuda for s in sums):
+            from agents_amd import ops
+            vec = torch.empty((len(sums),), dtype=torch.float32, device=sums[0].device)
+            with torch.cuda.device(vec.device):
+                ops.copy_segments([(s.view(1, 1), vec[j:j + 1].view(1, 1))
+                                   for j, s in enumerate(sums)])
+        else:
+            vec = torch.cat([s.to(torch.float32) for s in sums])
         if self.strategy.num_replicas_in_sync > 1:
             vec = self.strategy.all_reduce_sum_(vec)
         sums = [vec[j:j + 1] for j in range(len(idx))]

@@ -7,6 +7,8 @@ ONE sum all-reduce of the flat fp32 gradient buffer (the reference's implicit gr
 inside optimizer.apply_gradients under strategy.run), plus a sum of the LossInfo scalars
 (learner.py:322-337).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -43,6 +45,18 @@ class DataParallelStrategy(Strategy):
         self._pg = process_group
         self.num_replicas_in_sync = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
+        # the launcher's view must agree with the communicator's: a rank that silently fell out
+        # of the group (or a second group of size 1) would train on its own
+        ws = os.environ.get("WORLD_SIZE")
+        if process_group is None and ws is not None and int(ws) != self.num_replicas_in_sync:
+            raise RuntimeError(
+                f"DataParallelStrategy: the process group has {self.num_replicas_in_sync} ranks "
+                f"but the launcher started WORLD_SIZE={ws}")
+        self.backend = dist.get_backend(process_group)
+
+    def describe(self):
+        return (f"{self.num_replicas_in_sync} replicas over {self.backend} "
+                f"(rank {self.rank})")
 
     def all_reduce_sum_(self, tensor):
         """In-place SUM all-reduce (ncclAllReduce over xGMI on GPUs)."""

@@ -32,6 +32,24 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
+PMC_FILE = os.path.join("profiles", "r03_pmc.json")   # committed rocprofv3 --pmc passes (isolated)
+# Set in the child of the in-loop profiling pass (see inloop_profile): the run brackets its timed
+# region and every isolated kernel case with aa_marker launches and reports their labels in order.
+TRACE_CHILD = os.environ.get("AA_BENCH_TRACE_CHILD") == "1"
+MARKS = []
+
+
+def mark(label):
+    """Child of the profiling pass only: one aa_marker dispatch on the current stream, fenced by
+    device synchronisation on both sides so that its position in the trace is unambiguous."""
+    if not TRACE_CHILD:
+        return
+    from agents_amd import _lib
+    torch.cuda.synchronize()
+    _lib.check(_lib.load().aa_marker(len(MARKS), _lib.stream_ptr()), "aa_marker")
+    torch.cuda.synchronize()
+    MARKS.append(label)
 OBS_SHAPE = (84, 84, 4)
 NUM_ACTIONS = 6
 ROW_BYTES = 4 + 28224 + 8 + 4 + 4 + 4   # Trajectory row (SURVEY.md §8): 28,248 B
@@ -114,7 +132,10 @@ def kernel_breakdown(w, S, reps=20):
     """Times the kernels of one iteration individually: each op is captured `reps` times into a
     HIP graph on torch's current stream and the replay is bracketed by HIP events on that stream,
     so the figure is GPU time per launch (no Python launch overhead in it).
-    Returns [(name, ms per launch, launches per iteration, flops per launch, bytes per launch)]."""
+    Returns [(name, ms per launch, launches per iteration, flops per launch, bytes per launch,
+    bf16 products per fp32 product)]: the last is 6 for the bf16x6 kernels (every fp32 operand =
+    three exact bf16 pieces, six of the nine piece products accumulated), 3 for the uint8 layer
+    (a byte is exact in bf16, only the filter is split), None for fp32-MFMA / non-matrix kernels."""
     from agents_amd import ops
     net = w["net"]
     agent = w["agent"]
@@ -134,6 +155,7 @@ def kernel_breakdown(w, S, reps=20):
     from agents_amd.utils import graph
 
     def timeit(fn):
+        mark("op.begin")           # (profiling-pass child: the case's launches sit between marks)
         fn()
         c = graph._Captured()      # host mirrors (replay last_id, call counters) follow replays
         c.capture(lambda: [fn() for _ in range(reps)] and None)
@@ -144,6 +166,7 @@ def kernel_breakdown(w, S, reps=20):
         c.replay()
         b.record()
         torch.cuda.synchronize()
+        mark("op.end")
         return a.elapsed_time(b) / reps
 
     dz4 = torch.randn(S, 512, device=obs_t.device)
@@ -253,7 +276,142 @@ def kernel_breakdown(w, S, reps=20):
     out.append(("rmsprop(centered,mom)", timeit(lambda: opt.apply_flat(scratch, net.flat_grads)),
                 1, 0.0, 36.0 * n_par))
     opt.iterations = iters
+
+    def products(name):
+        if name.startswith("conv1."):
+            return 3
+        if name == "conv2+conv3.fwd(fused)":
+            return 6 if ops.conv_pair_prepare_bytes(tuple(slot.ys[0].shape), kv[1], 2, kv[2],
+                                                    1) > 0 else None
+        if name in ("conv2.dX", "conv3.dX"):
+            i = 1 if name[4] == "2" else 2
+            return 6 if ops.conv_dx_prepare_bytes(tuple(slot.ys[i - 1].shape), kv[i],
+                                                  2 if i == 1 else 1) > 0 else None
+        if name.startswith(("conv2.dW", "conv3.dW")):
+            return 6 if ops.CONV_DW_X6 else None
+        return None
+    return [r + (products(r[0]),) for r in out]
+
+
+# ---- in-loop kernel durations: a rocprofv3 --kernel-trace pass of this very loop ------------------
+def _read_kernel_trace(out_dir):
+    """[(kernel name, start ns, end ns)] sorted by start, from whatever rocprofv3 wrote under
+    out_dir: a rocpd sqlite database (ROCm 7 default) or a *_kernel_trace.csv."""
+    import csv
+    import glob
+    import sqlite3
+    rows = []
+    for db in glob.glob(os.path.join(out_dir, "**", "*.db"), recursive=True):
+        c = sqlite3.connect(db)
+        cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+        if not cols:
+            continue
+        name_col = "name" if "name" in cols else [x for x in cols if "name" in x][0]
+        rows += c.execute(f"select {name_col}, start, end from kernels").fetchall()
+        c.close()
+    if not rows:
+        for path in glob.glob(os.path.join(out_dir, "**", "*kernel_trace.csv"), recursive=True):
+            with open(path) as fh:
+                for r in csv.DictReader(fh):
+                    rows.append((r["Kernel_Name"], int(r["Start_Timestamp"]),
+                                 int(r["End_Timestamp"])))
+    return sorted(rows, key=lambda r: r[1])
+
+
+def inloop_profile(args, trace_out=None, timeout=420):
+    """Re-runs this benchmark's loop under `rocprofv3 --kernel-trace` in a child process and
+    returns per-kernel durations INSIDE the loop (three streams, every kernel competing with its
+    neighbours) -- what an isolated 20-launch graph flatters by 1.2-1.7x.  The child brackets its
+    timed region, and each isolated case of kernel_breakdown, with aa_marker dispatches; this reads
+    the trace by position between them.  Returns a dict, or {"error": ...}."""
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return {"error": "rocprofv3 not found"}
+    tmp = tempfile.mkdtemp(prefix="aa_inloop_", dir="/tmp")
+    steps = max(args.inloop_steps, 10)
+    cmd = [prof, "--kernel-trace", "-d", tmp, "-o", "inloop", "--", sys.executable,
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(steps), "--warmup", "10",
+           "--max-length", str(args.max_length), "--batch", str(args.batch), "--envs",
+           str(args.envs), "--prefill", str(args.prefill), "--no-cpu-baseline", "--no-inloop",
+           "--no-other-configs"] + (["--no-overlap"] if args.no_overlap else [])
+    env = dict(os.environ, AA_BENCH_TRACE_CHILD="1", TMPDIR="/tmp")
+    try:
+        r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True,
+                           timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": f"profiling pass exceeded {timeout}s"}
+    child = None
+    for line in reversed(r.stdout.strip().splitlines()):
+        if line.startswith("{") and "trace_child" in line:
+            child = json.loads(line)
+            break
+    if r.returncode != 0 or child is None:
+        return {"error": f"profiling pass failed (rc {r.returncode}): {r.stderr[-400:]}"}
+    try:
+        trace = _read_kernel_trace(tmp)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    marks = [i for i, k in enumerate(trace) if "aa_marker_kernel" in k[0]]
+    labels = child["marks"]
+    if len(marks) != len(labels) or not trace:
+        return {"error": f"{len(marks)} marker dispatches in the trace for {len(labels)} marks"}
+
+    def region(a, b):
+        """per kernel name: [launches, total ns] between marker dispatches a and b."""
+        acc = {}
+        for name, st, en in trace[marks[a] + 1:marks[b]]:
+            e = acc.setdefault(name, [0, 0])
+            e[0] += 1
+            e[1] += en - st
+        return acc
+
+    i0, i1 = labels.index("loop.begin"), labels.index("loop.end")
+    loop = region(i0, i1)
+    n_steps = child["steps"]
+    kernels = {n: {"launches_per_step": c / n_steps, "avg_us": t / c / 1e3}
+               for n, (c, t) in loop.items()}
+    ops_ = {}
+    op_marks = [i for i, l in enumerate(labels) if l == "op.begin"]
+    execs = 1 + 2 * child["reps"]            # one eager call + two replays of the `reps`-graph
+    for name, ib in zip(child["ops"], op_marks):
+        reg = region(ib, ib + 1)
+        per_launch = {n: c / execs for n, (c, t) in reg.items() if "Memset" not in n}
+        in_loop = sum(k * kernels[n]["avg_us"] for n, k in per_launch.items() if n in kernels)
+        missing = [n for n in per_launch if n not in kernels]
+        alone = sum(t for n, (c, t) in reg.items()) / execs / 1e3
+        ops_[name] = {"device_kernels": {n: round(k, 3) for n, k in per_launch.items()},
+                      "inloop_us": in_loop if not missing else None,
+                      "profiled_alone_us": alone, "not_in_loop": missing}
+    wall = (trace[marks[i1]][1] - trace[marks[i0]][2]) / n_steps / 1e3
+    out = {"steps": n_steps, "ms_per_step_under_profiler": child["ms_per_step"],
+           "kernel_time_sum_us_per_step": sum(t for c, t in loop.values()) / n_steps / 1e3,
+           "launches_per_step": sum(c for c, t in loop.values()) / n_steps,
+           "gpu_wall_us_per_step": wall, "kernels": kernels, "ops": ops_}
+    if trace_out:
+        with open(trace_out, "w") as fh:
+            fh.write("name,launches_per_step,avg_us,us_per_step\n")
+            for n, k in sorted(kernels.items(),
+                               key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches_per_step"]):
+                fh.write(f"\"{n}\",{k['launches_per_step']:.3f},{k['avg_us']:.3f},"
+                         f"{k['avg_us'] * k['launches_per_step']:.3f}\n")
     return out
+
+
+def run_other_config(name, steps, timeout=300):
+    """`bench.py --config ppo|sac` in a child process: its JSON line (or {"error": ...})."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", name, "--steps", str(steps)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": f"--config {name} exceeded {timeout}s"}
+    for line in reversed(r.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    return {"error": f"--config {name} failed (rc {r.returncode}): {r.stderr[-300:]}"}
 
 
 def cpu_baseline(S, steps, threads):
@@ -418,6 +576,14 @@ def main():
     ap.add_argument("--prefill", type=int, default=-1, help="frames per env to prefill (-1 = all)")
     ap.add_argument("--host-profile", type=int, default=0,
                     help="cProfile this many extra steps after the timed region (stderr)")
+    ap.add_argument("--no-inloop", action="store_true",
+                    help="skip the rocprofv3 --kernel-trace pass that measures kernel durations "
+                         "inside the loop (the roofline then falls back to isolated launches)")
+    ap.add_argument("--inloop-steps", type=int, default=100)
+    ap.add_argument("--trace-out", default=None,
+                    help="write the in-loop per-kernel table (CSV) here")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short --config ppo / --config sac runs appended to the line")
     args = ap.parse_args()
     args.steps_given = any(a == "--steps" or a.startswith("--steps=") for a in sys.argv[1:])
     if args.config != "dqn":
@@ -447,6 +613,12 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus says "
+                             f"{args.gpus}")
+        if rank == 0:
+            log(f"[bench] process group up: backend {dist.get_backend()}, "
+                f"{dist.get_world_size()} ranks, one rank per GPU (this rank: {dev})")
 
     from agents_amd import _lib
     _lib.load()  # fail loudly if the HIP library is missing
@@ -507,6 +679,7 @@ def main():
         step()
     sync_all()
     captures_before = graph.capture_count()
+    mark("loop.begin")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss_info = step()
@@ -514,7 +687,17 @@ def main():
     graph.join_lanes(dev)
     sync_all()
     dt = time.perf_counter() - t0
+    mark("loop.end")
     captures_in_timed_region = graph.capture_count() - captures_before
+    if TRACE_CHILD:
+        # child of inloop_profile(): the isolated cases once more, bracketed by markers, so that
+        # the parent learns which device kernels each case launches; then one JSON line
+        graph.disable_overlap()
+        bd = kernel_breakdown(w, S)
+        print(json.dumps({"trace_child": True, "marks": MARKS, "ops": [r[0] for r in bd],
+                          "reps": 20, "steps": args.steps,
+                          "ms_per_step": dt / args.steps * 1e3}), flush=True)
+        return
     if args.host_profile and rank == 0:
         # plain timers first (cProfile inflates Python frames): host time inside the two calls
         tc = tt = 0.0
@@ -618,16 +801,31 @@ def main():
         out["step_mfma_frac"] = flops_step / (dt / args.steps) / 1e12 / MFMA_F32_PEAK_TFLOPS
         if not args.no_breakdown:
             bd = kernel_breakdown(w, S)
-            tot = sum(ms * n for _, ms, n, _, _ in bd)
-            log("[bench] per-launch GPU time of the iteration's kernels (HIP events around a "
-                "graph of 20 launches) x launches per iteration:")
-            for name, ms, n, fl, by in bd:
-                extra = f"{fl / ms / 1e9:8.1f} TFLOP/s" if fl else f"{by / ms / 1e6:8.1f} GB/s"
-                log(f"    {name:40s} {ms * 1e3:8.1f} us x{n}  {extra}  "
-                    f"({100 * ms * n / tot:4.1f}%)")
-            # HBM bytes and matrix-pipe busy per launch from the committed rocprofv3 --pmc passes of
-            # this tree (tools/pmc_r02.sh -> profiles/r02_pmc.json): all kernels of the case summed
-            # for the traffic (pre-passes, reduces), the dominant kernel's counters for mfma_busy
+            tot = sum(r[1] * r[2] for r in bd)
+            # ---- kernel durations INSIDE the loop (rocprofv3 --kernel-trace pass of this loop) ----
+            inloop = None
+            if world == 1 and not args.no_inloop:
+                t_il = time.perf_counter()
+                inloop = inloop_profile(args, trace_out=args.trace_out)
+                if "error" in inloop:
+                    log(f"[bench] in-loop profiling pass unavailable: {inloop['error']}")
+                else:
+                    log(f"[bench] in-loop pass: {inloop['steps']} steps under rocprofv3 in "
+                        f"{time.perf_counter() - t_il:.0f}s; {inloop['launches_per_step']:.1f} "
+                        f"launches / step, kernel time {inloop['kernel_time_sum_us_per_step']:.0f} "
+                        f"us inside {inloop['gpu_wall_us_per_step']:.0f} us of GPU wall per step")
+            il_ops = inloop.get("ops", {}) if inloop and "error" not in inloop else {}
+            log("[bench] per-launch GPU time of the iteration's kernels: isolated (HIP events "
+                "around a graph of 20 launches) | in the loop (rocprofv3) x launches per step:")
+            for name, ms, n, fl, by, prod in bd:
+                il = il_ops.get(name, {}).get("inloop_us")
+                t_us = il if il else ms * 1e3
+                extra = f"{fl / t_us / 1e6:8.1f} TFLOP/s" if fl else f"{by / t_us / 1e3:8.1f} GB/s"
+                log(f"    {name:40s} {ms * 1e3:8.1f} | "
+                    f"{(f'{il:8.1f}' if il else '     n/a')} us x{n}  {extra}")
+            # HBM bytes and matrix-pipe busy per launch come from COMMITTED rocprofv3 --pmc passes
+            # (isolated launches, one counter set per pass: tools/pmc_r03.sh); they are not
+            # re-measured by this run and are labelled so
             pmc_case = {"conv2+conv3.fwd(fused)": "conv23.fwd", "fc1.fwd": "fc1.fwd",
                         "fc1+fc2.fwd(head sums fc1's slabs)": "fc1.fwd",
                         "fc1.dX": "fc1.dX", "fc1.dW(+bias grad)": "fc1.dW",
@@ -635,54 +833,86 @@ def main():
                         "conv2.dW(+bias grad)": "conv2.dW", "conv3.dW(+bias grad)": "conv3.dW",
                         "conv1.fwd(u8)": "conv1.fwd",
                         "replay.get_next(sample+gather 512 rows)": "replay.get_next"}
-            pmc = {}
-            ppath = os.path.join(ROOT, "profiles", "r02_pmc.json")
-            if os.path.exists(ppath):
-                with open(ppath) as fh:
-                    pmc = json.load(fh).get("cases", {})
+            pmc, pmc_src = {}, None
+            for cand in (PMC_FILE, os.path.join("profiles", "r02_pmc.json")):
+                if os.path.exists(os.path.join(ROOT, cand)):
+                    with open(os.path.join(ROOT, cand)) as fh:
+                        pmc = json.load(fh).get("cases", {})
+                    pmc_src = cand
+                    break
 
             def pmc_of(name):
                 c = pmc.get(pmc_case.get(name, ""), None)
                 if not c:
                     return None, None, None
                 ks = c["kernels"]
-                tot = [k.get("hbm_bytes_per_launch") for k in ks.values()]
-                traffic_b = sum(t for t in tot if t is not None) if any(
-                    t is not None for t in tot) else None
+                tb = [k.get("hbm_bytes_per_launch") for k in ks.values()]
+                traffic_b = sum(t for t in tb if t is not None) if any(
+                    t is not None for t in tb) else None
                 dom = ks[c["dominant_kernel"]]
                 return traffic_b, dom.get("mfma_busy"), c["dominant_kernel"]
 
             def roof(row):
-                name, ms, n, fl, by = row
+                """`achieved` / `frac` use the IN-LOOP duration when the profiling pass gave one
+                (`duration_source` says which); `isolated_ms` is always the HIP-event figure."""
+                name, ms, n, fl, by, prod = row
                 traffic_b, busy, dom = pmc_of(name)
+                il = il_ops.get(name, {})
+                t_ms = il["inloop_us"] / 1e3 if il.get("inloop_us") else ms
+                src = "in-loop (rocprofv3 --kernel-trace pass of this loop, run by bench.py)" \
+                    if il.get("inloop_us") else "isolated (graph of 20 launches, HIP events)"
+                common_ = {"kernel": name, "avg_launch_ms": t_ms, "isolated_ms": ms,
+                           "duration_source": src, "launches_per_step": n,
+                           "device_kernels": il.get("device_kernels", dom),
+                           "traffic": traffic_b,
+                           "traffic_source": None if traffic_b is None else
+                           f"{pmc_src} (committed --pmc passes of isolated launches; not "
+                           "measured in this run)"}
                 if fl:
-                    ach = fl / ms / 1e9
-                    r = {"kernel": name, "bound": "mfma", "achieved": ach,
-                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": traffic_b,
-                         "algorithmic_flop_per_launch": fl, "avg_launch_ms": ms,
-                         "launches_per_step": n, "mfma_busy": busy, "device_kernel": dom,
-                         "peak_note": "algorithmic fp32 flop against the fp32-input MFMA peak "
-                                      "(157.3 TFLOP/s: the dtype of the contraction); the bf16x6 "
-                                      "kernels execute 6 bf16 MFMA products per fp32 product at "
-                                      "the 2.5 PFLOP/s bf16 rate, mfma_busy (rocprofv3 "
-                                      "SQ_VALU_MFMA_BUSY_CYCLES over kernel cycles x 1024 SIMDs) "
-                                      "is their matrix-pipe utilisation"}
+                    ach = fl / t_ms / 1e9
+                    r = dict(common_, bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TFLOPS,
+                             unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TFLOPS,
+                             frac_isolated=fl / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
+                             algorithmic_flop_per_launch=fl, mfma_busy=busy,
+                             mfma_busy_source=None if busy is None else pmc_src)
+                    if prod:
+                        # the kernel executes `prod` bf16 MFMA products per fp32 product on the
+                        # 2.5 PFLOP/s pipe: against 157.3 TFLOP/s its ceiling is 2500/(prod*157.3)
+                        r.update(bf16_products_per_fp32_product=prod,
+                                 pipe_frac=prod * fl / t_ms / 1e9 / MFMA_BF16_PEAK_TFLOPS,
+                                 frac_ceiling=MFMA_BF16_PEAK_TFLOPS / (prod * MFMA_F32_PEAK_TFLOPS))
+                    r["peak_note"] = (
+                        "frac = algorithmic fp32 flop / in-loop launch time / 157.3 TFLOP/s (the "
+                        "fp32-input MFMA peak: the dtype of the contraction).  Kernels with "
+                        "bf16_products_per_fp32_product run on the bf16 pipe, where frac can "
+                        "reach frac_ceiling (2.65 for six products); pipe_frac = products x flop "
+                        "/ time / 2,500 TFLOP/s is their utilisation of the pipe they use")
                     return r
-                ach = by / ms / 1e6
-                return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic_b,
-                        "algorithmic_bytes_per_launch": by, "avg_launch_ms": ms,
-                        "launches_per_step": n, "device_kernel": dom}
+                ach = by / t_ms / 1e6
+                return dict(common_, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=ach / HBM_PEAK_GBS, frac_isolated=by / ms / 1e6 / HBM_PEAK_GBS,
+                            algorithmic_bytes_per_launch=by)
 
+            rows = [roof(r) for r in bd]
             # dominant kernel = largest share of the iteration's GPU time (duration x launches)
-            out["roofline"] = roof(max(bd, key=lambda r: r[1] * r[2]))
-            out["roofline_replay_gather"] = roof(bd[0])
-            out["roofline_replay_add"] = roof(bd[1])
-            # every kernel of the iteration, same fields (without the long note)
-            out["roofline_all"] = [{k: v for k, v in roof(r).items() if k != "peak_note"}
-                                   for r in bd]
+            out["roofline"] = max(rows, key=lambda r: r["avg_launch_ms"] * r["launches_per_step"])
+            out["roofline_replay_gather"] = rows[0]
+            out["roofline_replay_add"] = rows[1]
+            out["roofline_all"] = [{k: v for k, v in r.items() if k != "peak_note"} for r in rows]
             out["kernel_time_sum_ms"] = tot
+            if inloop is not None:
+                out["inloop"] = {k: v for k, v in inloop.items() if k not in ("ops", "kernels")}
+                if "kernels" in inloop:
+                    top = sorted(inloop["kernels"].items(),
+                                 key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches_per_step"])
+                    out["inloop"]["kernels"] = [
+                        {"name": n_[:96], "launches_per_step": round(k["launches_per_step"], 3),
+                         "avg_us": round(k["avg_us"], 2)} for n_, k in top[:40]]
+        if world == 1 and not args.no_other_configs:
+            # BASELINE.json configs[2] / configs[4] at one GPU, observed by whoever runs this
+            # command (short runs: 2 PPO iterations, 150 SAC iterations; own roofline + cpu_baseline)
+            out["other_configs"] = {"ppo": run_other_config("ppo", 2),
+                                    "sac": run_other_config("sac", 150)}
         if not args.no_cpu_baseline and world == 1:
             # torch-CPU convolutions at batch 256 stop scaling (and collapse when every hardware
             # thread of a 256-core host is used): probe a few thread counts, keep the fastest

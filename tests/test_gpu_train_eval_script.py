@@ -1,0 +1,69 @@
+"""GPU: BASELINE.json configs[0] (the reference's own CPU-runnable case) through the script a
+TF-Agents user would run: agents_amd/agents/dqn/examples/v2/train_eval.py mirrors
+tf_agents/agents/dqn/examples/v2/train_eval.py:86-339 (same `train_eval` arguments and loop), run
+here at the sizes of tf_agents/benchmark/dqn_benchmark_test.py:45-146: CartPole shapes, QNetwork
+fc=(100,), replay max_length 1,000 prefilled by 1,000 random-policy steps, batch 64, 110 train
+steps, and -- like that harness (benchmark/utils.py:216-227) -- the check that the network's
+variables moved."""
+import inspect
+import os
+
+import numpy as np
+import pytest
+import torch
+
+REFERENCE_ARGS = [   # tf_agents/agents/dqn/examples/v2/train_eval.py:86-126, in order
+    "root_dir", "env_name", "num_iterations", "train_sequence_length", "fc_layer_params",
+    "input_fc_layer_params", "lstm_size", "output_fc_layer_params", "initial_collect_steps",
+    "collect_steps_per_iteration", "epsilon_greedy", "replay_buffer_capacity",
+    "target_update_tau", "target_update_period", "train_steps_per_iteration", "batch_size",
+    "learning_rate", "n_step_update", "gamma", "reward_scale_factor", "gradient_clipping",
+    "use_tf_functions", "num_eval_episodes", "eval_interval", "train_checkpoint_interval",
+    "policy_checkpoint_interval", "rb_checkpoint_interval", "log_interval", "summary_interval",
+    "summaries_flush_secs", "debug_summaries", "summarize_grads_and_vars",
+    "eval_metrics_callback"]
+
+
+def test_signature_is_the_reference_scripts():
+    from agents_amd.agents.dqn.examples.v2 import train_eval as te
+    params = list(inspect.signature(te.train_eval).parameters)
+    assert params[:len(REFERENCE_ARGS)] == REFERENCE_ARGS
+    d = inspect.signature(te.train_eval).parameters
+    assert d["env_name"].default == "CartPole-v0" and d["batch_size"].default == 64
+    assert d["target_update_tau"].default == 0.05 and d["target_update_period"].default == 5
+    assert d["fc_layer_params"].default == (100,) and d["learning_rate"].default == 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_tf_functions", [True, False])
+def test_config_1_through_the_script(dev, tmp_path, use_tf_functions):
+    from agents_amd.agents.dqn.examples.v2 import train_eval as te
+    from agents_amd.utils import graph
+    evals = []
+    with torch.cuda.device(dev):
+        loss = te.train_eval(
+            str(tmp_path), env_name="CartPole-v0", num_iterations=110,
+            initial_collect_steps=1000, replay_buffer_capacity=1000, batch_size=64,
+            fc_layer_params=(100,), log_interval=10, eval_interval=55, num_eval_episodes=3,
+            train_checkpoint_interval=50, policy_checkpoint_interval=100,
+            rb_checkpoint_interval=100, use_tf_functions=use_tf_functions,
+            eval_metrics_callback=lambda results, step: evals.append((step, results)))
+        run = te.train_eval.last_run
+        agent, rb, q_net = run["agent"], run["replay_buffer"], run["q_net"]
+        torch.cuda.synchronize()
+        assert np.isfinite(float(loss.loss)) and float(loss.loss) > 0
+        assert int(run["global_step"]) == 110 == int(agent.train_step_counter.numpy())
+        assert rb.num_frames() == 1000                         # full ring: 1,000 + 110 adds
+        assert run["train_metrics"][1].result() >= 1000        # EnvironmentSteps counted
+        assert [s for s, _ in evals] == [0, 55, 110]
+        assert all(np.isfinite(r["AverageReturn"]) for _, r in evals)
+        fresh = te.create_feedforward_network((100,), 2, q_net._input_tensor_spec)
+        assert q_net.flat_params.numel() == 4 * 100 + 100 + 100 * 2 + 2
+        # the harness's "variables changed" check: the logits bias started at -0.2
+        assert not torch.allclose(q_net.variables[-1], torch.full_like(q_net.variables[-1], -0.2))
+        if use_tf_functions:
+            assert graph.graphed_train(agent).replays >= 100
+        ck = sorted(os.listdir(os.path.join(str(tmp_path), "train")))
+        assert "ckpt-50.pt" in ck and "ckpt-100.pt" in ck and "policy" in ck
+        assert os.listdir(os.path.join(str(tmp_path), "train", "replay_buffer")) == ["ckpt-100.pt"]
+        del fresh
