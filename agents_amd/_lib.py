@@ -41,6 +41,12 @@ class ConvDxDesc(Structure):
                 ("mask_kind", c_int32)]
 
 
+class PlaneScatter(Structure):
+    """aa_plane_scatter (include/agents_amd.h)."""
+    _fields_ = [("n", c_int32), ("stride", c_int32 * 4), ("lo", c_int64 * 4), ("hi", c_int64 * 4),
+                ("pos", c_void_p * 4), ("planes", c_void_p * 4)]
+
+
 class GemmDesc(Structure):
     _fields_ = [
         ("A", c_void_p), ("B", c_void_p), ("C", c_void_p),
@@ -142,10 +148,22 @@ _SIGNATURES = {
                                     c_int32, c_int32, c_double, c_double, c_double, c_int32,
                                     c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),
+    "aa_dqn_loss_head_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int64, c_int32, c_int32, c_double, c_double, c_double,
+                                          c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32,
+                                          c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "aa_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float,
                              c_float, c_float, c_void_p, c_void_p]),
     "aa_rmsprop_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                 c_float, c_float, c_float, c_float, c_void_p]),
+    "aa_adam_step_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
+                                    c_float, c_float, c_float, c_void_p, POINTER(PlaneScatter),
+                                    c_void_p]),
+    "aa_rmsprop_step_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                       c_float, c_float, c_float, c_float, POINTER(PlaneScatter),
+                                       c_void_p]),
     "aa_sgd_step": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "aa_soft_update": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "aa_segment_sumsq": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),

@@ -57,6 +57,7 @@ class _Work:
         self.td_loss = torch.zeros((B,), **f)
         self.td_error = torch.zeros((B,), **f)
         self.dq = torch.zeros((B, A), **f)
+        self.head_done = False      # the last loss launch also ran the Q head's backward pass
         self.field_sums = torch.zeros((2,), **f)   # sum(td_loss), sum(td_error): Learner's reduce
 
 
@@ -262,13 +263,19 @@ class DqnAgent(tf_agent.TFAgent):
         st = experience.step_type
         if st.dtype != torch.int32:
             st = st.to(torch.int32)
+        # training: the Q head's backward pass rides in the loss launch (dL/dq of a sample only
+        # needs that sample: csrc/dqn.hip), one launch less on the critical chain
+        head = None
+        if need_grad and hasattr(self._q_network, "fusable_head"):
+            head = self._q_network.fusable_head(B, "train")
+        w.head_done = head is not None
         ops.dqn_td_loss(q_online, q_next_target, q_next_select, next_mask,
                         experience.action, experience.reward.contiguous(),
                         experience.discount.contiguous(), st.contiguous(), weights,
                         self._gamma, reward_scale_factor,
                         self._loss_kind(td_errors_loss_fn or self._td_errors_loss_fn),
                         float(B * self.num_replicas), w.loss, w.td_loss, w.td_error, w.dq,
-                        gamma_loss=gamma, field_sums_out=w.field_sums)
+                        gamma_loss=gamma, field_sums_out=w.field_sums, head=head)
         return w
 
     def reduce_loss_info(self, loss_info):
@@ -324,7 +331,8 @@ class DqnAgent(tf_agent.TFAgent):
         net = self._q_network
         w = self._forward_and_loss(experience, self._td_errors_loss_fn, self._gamma,
                                    self._reward_scale_factor, weights, need_grad=True)
-        net.backward(w.dq, slot="train", side_stream=self._side_stream(w.dq.device))
+        net.backward(w.dq, slot="train", side_stream=self._side_stream(w.dq.device),
+                     head_done=w.head_done)
         total = w.loss
         if net.has_regularization:
             net.add_regularization_grads(1.0 / self.num_replicas)
@@ -352,7 +360,7 @@ class DqnAgent(tf_agent.TFAgent):
                                    self._reward_scale_factor, weights, need_grad=True)
         self._bucket_B = w.dq.shape[0]
         net.backward(w.dq, slot="train", side_stream=self._side_stream(w.dq.device),
-                     stop_layer=self._bucket_split())
+                     stop_layer=self._bucket_split(), head_done=w.head_done)
         return tf_agent.LossInfo(w.loss.reshape(()),
                                  DqnLossInfo(td_loss=w.td_loss, td_error=w.td_error))
 
@@ -364,8 +372,13 @@ class DqnAgent(tf_agent.TFAgent):
 
     def _train_phase_apply(self):
         net = self._q_network
-        self._optimizer.apply_flat(net.flat_params, net.flat_grads)
-        self._refresh_prepared(net)
+        planes = net.plane_scatter() if hasattr(net, "plane_scatter") else None
+        if planes is not None and getattr(self._optimizer, "supports_planes", False):
+            # the optimizer kernel writes the new filters' bf16 pieces into the prepared planes
+            self._optimizer.apply_flat(net.flat_params, net.flat_grads, planes=planes)
+        else:
+            self._optimizer.apply_flat(net.flat_params, net.flat_grads)
+            self._refresh_prepared(net)
 
     def _train_phase_host(self):
         self._train_step_counter.assign_add(1)

@@ -8,8 +8,45 @@
 //   tf.clip_by_global_norm          tf_agents/agents/ppo/ppo_agent.py:948-949
 #include "common.h"
 #include "agents_amd.h"
+#include "x6_common.h"
 
 #define AA_EW_THREADS 256
+
+// ---- split planes kept current by the optimizer ------------------------------------------------
+// The bf16x6 convolutions read their filters as three bf16 planes in MFMA-fragment order
+// (conv_pair_x6.hip / conv_dx_frame_x6.hip: "split once").  Re-splitting in a pre-pass per forward /
+// backward costs five launches per DQN iteration; re-splitting in launches of their own after the
+// optimizer step costs three on the one point every stream waits for (measured: -12 %).  Here the
+// optimizer kernel, which holds every new parameter value in a register anyway, writes its three
+// pieces straight to where each consumer will read them: pos[i - lo] is the bf16 index of the hi
+// piece of parameter i in `planes`, the mid / lo pieces follow at +stride / +2*stride (-1: this
+// parameter is not part of the target).  Same rounding sequence as cx_split8.
+__device__ static inline void aa_planes_put(const aa_plane_scatter& S, int64_t i, float v) {
+#pragma unroll
+  for (int t = 0; t < AA_MAX_PLANE_TARGETS; ++t) {
+    if (t < S.n && i >= S.lo[t] && i < S.hi[t]) {
+      const int32_t pos = S.pos[t][i - S.lo[t]];
+      if (pos >= 0) {
+        uint16_t* base = S.planes[t] + pos;
+        float r = v;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const unsigned pk = cx_pk_bf16(r, 0.f);
+          base[(int64_t)s * S.stride[t]] = (uint16_t)(pk & 0xffffu);
+          r -= __uint_as_float(pk << 16);
+        }
+      }
+    }
+  }
+}
+
+__device__ static inline bool aa_planes_touch(const aa_plane_scatter& S, int64_t i0, int64_t i1) {
+  bool hit = false;
+#pragma unroll
+  for (int t = 0; t < AA_MAX_PLANE_TARGETS; ++t)
+    hit = hit || (t < S.n && i1 > S.lo[t] && i0 < S.hi[t]);
+  return hit;
+}
 static inline unsigned aa_ew_blocks(int64_t n_vec) {
   int64_t b = (n_vec + AA_EW_THREADS - 1) / AA_EW_THREADS;
   if (b > 2048) b = 2048;  // 256 CUs x 8
@@ -25,10 +62,11 @@ __device__ static inline float adam_elem(float& p, float g, float& m, float& v, 
   return p;
 }
 
+template <bool PLANES>
 __global__ void __launch_bounds__(AA_EW_THREADS)
 aa_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps,
-               const int64_t* __restrict__ step_dev) {
+               const int64_t* __restrict__ step_dev, aa_plane_scatter S) {
   __shared__ float s_alpha;
   if (threadIdx.x == 0) {
     const float t = (float)(*step_dev);
@@ -51,9 +89,15 @@ aa_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __rest
     reinterpret_cast<float4*>(p)[i] = pp;
     reinterpret_cast<float4*>(m)[i] = mm;
     reinterpret_cast<float4*>(v)[i] = vv;
+    if (PLANES && aa_planes_touch(S, 4 * i, 4 * i + 4)) {
+      aa_planes_put(S, 4 * i, pp.x); aa_planes_put(S, 4 * i + 1, pp.y);
+      aa_planes_put(S, 4 * i + 2, pp.z); aa_planes_put(S, 4 * i + 3, pp.w);
+    }
   }
-  for (int64_t i = nv * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    adam_elem(p[i], g[i], m[i], v[i], alpha, omb1, omb2, eps);
+  for (int64_t i = nv * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float pn = adam_elem(p[i], g[i], m[i], v[i], alpha, omb1, omb2, eps);
+    if (PLANES) aa_planes_put(S, i, pn);
+  }
 }
 
 template <bool CENTERED, bool MOMENTUM>
@@ -77,11 +121,11 @@ __device__ static inline void rms_elem(float& p, float g, float& ms, float* mg, 
   }
 }
 
-template <bool CENTERED, bool MOMENTUM>
+template <bool CENTERED, bool MOMENTUM, bool PLANES>
 __global__ void __launch_bounds__(AA_EW_THREADS)
 aa_rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ ms,
                   float* __restrict__ mg, float* __restrict__ mom, int64_t n, float lr, float rho,
-                  float momentum, float eps) {
+                  float momentum, float eps, aa_plane_scatter S) {
   const float omr = 1.0f - rho;
   const int64_t nv = n / 4;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -100,12 +144,17 @@ aa_rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __r
     reinterpret_cast<float4*>(ms)[i] = s;
     if (CENTERED) reinterpret_cast<float4*>(mg)[i] = a;
     if (MOMENTUM) reinterpret_cast<float4*>(mom)[i] = mo;
+    if (PLANES && aa_planes_touch(S, 4 * i, 4 * i + 4)) {
+      aa_planes_put(S, 4 * i, pp.x); aa_planes_put(S, 4 * i + 1, pp.y);
+      aa_planes_put(S, 4 * i + 2, pp.z); aa_planes_put(S, 4 * i + 3, pp.w);
+    }
   }
   for (int64_t i = nv * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float a = CENTERED ? mg[i] : 0.f, mo = MOMENTUM ? mom[i] : 0.f;
     rms_elem<CENTERED, MOMENTUM>(p[i], g[i], ms[i], &a, &mo, lr, rho, omr, momentum, eps);
     if (CENTERED) mg[i] = a;
     if (MOMENTUM) mom[i] = mo;
+    if (PLANES) aa_planes_put(S, i, p[i]);
   }
 }
 
@@ -170,36 +219,69 @@ aa_clip_kernel(float* __restrict__ g, const int64_t* __restrict__ off, int n_seg
 
 extern "C" {
 
-int aa_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                 float beta2, float eps, const int64_t* step_dev, void* stream) {
+static int aa_planes_check(const aa_plane_scatter* S, int64_t n) {
+  if (S == nullptr) return AA_OK;
+  if (S->n < 0 || S->n > AA_MAX_PLANE_TARGETS) return AA_ERR_INVALID;
+  for (int t = 0; t < S->n; ++t)
+    if (S->pos[t] == nullptr || S->planes[t] == nullptr || S->lo[t] < 0 || S->hi[t] > n ||
+        S->lo[t] >= S->hi[t] || S->stride[t] <= 0)
+      return AA_ERR_INVALID;
+  return AA_OK;
+}
+
+int aa_adam_step_planes(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                        float beta1, float beta2, float eps, const int64_t* step_dev,
+                        const aa_plane_scatter* planes, void* stream) {
   if (!p || !g || !m || !v || !step_dev || n <= 0) return AA_ERR_INVALID;
   if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0)
     return AA_ERR_INVALID;
-  hipLaunchKernelGGL(aa_adam_kernel, dim3(aa_ew_blocks(n / 4)), dim3(AA_EW_THREADS), 0,
-                     (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, step_dev);
+  if (aa_planes_check(planes, n) != AA_OK) return AA_ERR_INVALID;
+  const dim3 grid(aa_ew_blocks(n / 4)), block(AA_EW_THREADS);
+  if (planes != nullptr && planes->n > 0)
+    hipLaunchKernelGGL(aa_adam_kernel<true>, grid, block, 0, (hipStream_t)stream, p, g, m, v, n,
+                       lr, beta1, beta2, eps, step_dev, *planes);
+  else
+    hipLaunchKernelGGL(aa_adam_kernel<false>, grid, block, 0, (hipStream_t)stream, p, g, m, v, n,
+                       lr, beta1, beta2, eps, step_dev, aa_plane_scatter{});
+  return aa_launch_status();
+}
+
+int aa_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                 float beta2, float eps, const int64_t* step_dev, void* stream) {
+  return aa_adam_step_planes(p, g, m, v, n, lr, beta1, beta2, eps, step_dev, nullptr, stream);
+}
+
+int aa_rmsprop_step_planes(float* p, const float* g, float* ms, float* mg, float* mom, int64_t n,
+                           float lr, float rho, float momentum, float eps,
+                           const aa_plane_scatter* planes, void* stream) {
+  if (!p || !g || !ms || n <= 0) return AA_ERR_INVALID;
+  if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)ms | (uintptr_t)mg | (uintptr_t)mom) & 15) != 0)
+    return AA_ERR_INVALID;
+  if (aa_planes_check(planes, n) != AA_OK) return AA_ERR_INVALID;
+  const dim3 grid(aa_ew_blocks(n / 4)), block(AA_EW_THREADS);
+  hipStream_t st = (hipStream_t)stream;
+  const bool pl = planes != nullptr && planes->n > 0;
+  const aa_plane_scatter S = pl ? *planes : aa_plane_scatter{};
+#define AA_RMS(C_, M_)                                                                          \
+  do {                                                                                          \
+    if (pl)                                                                                     \
+      hipLaunchKernelGGL((aa_rmsprop_kernel<C_, M_, true>), grid, block, 0, st, p, g, ms, mg,   \
+                         mom, n, lr, rho, momentum, eps, S);                                    \
+    else                                                                                        \
+      hipLaunchKernelGGL((aa_rmsprop_kernel<C_, M_, false>), grid, block, 0, st, p, g, ms, mg,  \
+                         mom, n, lr, rho, momentum, eps, S);                                    \
+  } while (0)
+  if (mg && mom) AA_RMS(true, true);
+  else if (mg) AA_RMS(true, false);
+  else if (mom) AA_RMS(false, true);
+  else AA_RMS(false, false);
+#undef AA_RMS
   return aa_launch_status();
 }
 
 int aa_rmsprop_step(float* p, const float* g, float* ms, float* mg, float* mom, int64_t n,
                     float lr, float rho, float momentum, float eps, void* stream) {
-  if (!p || !g || !ms || n <= 0) return AA_ERR_INVALID;
-  if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)ms | (uintptr_t)mg | (uintptr_t)mom) & 15) != 0)
-    return AA_ERR_INVALID;
-  const dim3 grid(aa_ew_blocks(n / 4)), block(AA_EW_THREADS);
-  hipStream_t st = (hipStream_t)stream;
-  if (mg && mom)
-    hipLaunchKernelGGL((aa_rmsprop_kernel<true, true>), grid, block, 0, st, p, g, ms, mg, mom, n,
-                       lr, rho, momentum, eps);
-  else if (mg)
-    hipLaunchKernelGGL((aa_rmsprop_kernel<true, false>), grid, block, 0, st, p, g, ms, mg, mom, n,
-                       lr, rho, momentum, eps);
-  else if (mom)
-    hipLaunchKernelGGL((aa_rmsprop_kernel<false, true>), grid, block, 0, st, p, g, ms, mg, mom, n,
-                       lr, rho, momentum, eps);
-  else
-    hipLaunchKernelGGL((aa_rmsprop_kernel<false, false>), grid, block, 0, st, p, g, ms, mg, mom,
-                       n, lr, rho, momentum, eps);
-  return aa_launch_status();
+  return aa_rmsprop_step_planes(p, g, ms, mg, mom, n, lr, rho, momentum, eps, nullptr, stream);
 }
 
 int aa_sgd_step(float* p, const float* g, int64_t n, float lr, void* stream) {

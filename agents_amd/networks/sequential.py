@@ -54,16 +54,17 @@ _HOIST_BWD = _HOIST in ("1", "3")
 
 # Prepared weights (opt-in per network, `Sequential.enable_prepared_weights`): the weights-only
 # pre-passes of the bf16x6 convolutions (filter split of a fused pair, fragments + tables of the
-# conv input gradients) are run by whoever WRITES the weights -- the agent right after its
-# optimizer step, after a target update, after a restore -- into buffers owned by the network, and
-# every forward / backward that reads those weights (policy forward of the collect graph, online
-# forward, backward) skips its own pre-pass.  OFF by default (AA_PREPARED_WEIGHTS=1 makes DqnAgent
-# opt in): measured in the DQN iteration on MI355X it LOSES 12 % (0.404 vs 0.359 ms, same box) --
-# the three pre-pass launches after the optimizer step sit on the one point of the iteration that
-# every lane waits for (theta_k+1), while the per-call pre-passes they replace run as first nodes
-# of three parallel branches, where launch-latency-bound kernels overlap for free.  It would need
-# the pre-passes as ONE launch (or inside the optimizer kernel) to pay.
-PREPARED_WEIGHTS = os.environ.get("AA_PREPARED_WEIGHTS", "0") == "1"
+# conv input gradients) are run by whoever WRITES the weights -- the agent's optimizer step, a
+# target update, a restore -- into buffers owned by the network, and every forward / backward that
+# reads those weights (policy forward of the collect graph, online forward, backward) skips its
+# own pre-pass.  Round 2 refreshed them with the pre-pass LAUNCHES after the optimizer step and lost
+# 12 % (0.404 vs 0.359 ms, same box): three launches on the one point of the iteration that every
+# lane waits for (theta_k+1), against per-call pre-passes that run as first nodes of three parallel
+# branches.  Round 3: the optimizer kernel itself writes the three bf16 pieces of every new filter
+# value to its place in every plane set (`plane_scatter`, csrc/optim.hip: aa_*_step_planes) -- no
+# launch at all, five fewer kernels and one fewer graph branch per DQN iteration -- so DqnAgent now
+# opts in by default (AA_PREPARED_WEIGHTS=0: every call splits for itself again).
+PREPARED_WEIGHTS = os.environ.get("AA_PREPARED_WEIGHTS", "1") == "1"
 _PREPARED_NETS = []      # weak references to the networks that opted in
 
 
@@ -477,10 +478,74 @@ class Sequential(network.Network):
                 dx[i] = torch.empty((n,), dtype=torch.uint8, device=dev)
         if not pair and not dx:
             return False
-        self._pw = {"pair": pair, "dx": dx, "torch_version": -1}
+        self._pw = {"pair": pair, "dx": dx, "torch_version": -1, "scatter": None}
         _PREPARED_NETS.append(weakref.ref(self))
         self.refresh_prepared()
+        self._pw["scatter"] = self._build_plane_scatter()
         return True
+
+    def _build_plane_scatter(self):
+        """Where the optimizer has to put the bf16 pieces of every filter value so that the
+        prepared planes stay current without pre-pass launches (csrc/optim.hip).  The layouts are
+        read off the pre-pass kernels themselves: the parameters are set to 1, 2, 3, ... (exact in
+        three bf16 pieces below 2^24), the pre-passes run, and hi + mid + lo at every plane position
+        names the parameter that lives there.  Returns a _lib.PlaneScatter (tables kept alive in
+        self._pw), or None when the layout cannot be expressed (then the agent falls back to the
+        pre-pass launches)."""
+        pw = self._pw
+        n = self.flat_params.numel()
+        targets = []
+        for kind in ("pair", "dx"):
+            for pi, ws in pw[kind].items():
+                nw = int(np.prod(self._shapes[pi][0]))
+                if kind == "pair":
+                    nw += int(np.prod(self._shapes[pi + 1][0]))
+                targets.append((ws, nw))
+        if not targets or len(targets) > 4 or n >= (1 << 24):
+            return None
+        saved = self.flat_params.clone()
+        try:
+            self.flat_params.copy_(torch.arange(1, n + 1, dtype=torch.float32,
+                                                device=self.flat_params.device))
+            self.refresh_prepared()
+            desc = _lib.PlaneScatter()
+            tables = []
+            for t, (ws, nw) in enumerate(targets):
+                # fragment layout of both pre-passes: [tile][plane][lane][8] bf16 -> 512 per plane
+                if (nw * 6) % (3 * 512 * 2) != 0 or ws.numel() < nw * 6:
+                    return None
+                frag = ws[:nw * 6].view(torch.bfloat16).view(-1, 3, 512).to(torch.float32)
+                src = (frag[:, 0] + frag[:, 1] + frag[:, 2]).round().to(torch.int64) - 1
+                tiles = src.shape[0]
+                pos = (torch.arange(tiles, device=src.device)[:, None] * 1536 +
+                       torch.arange(512, device=src.device)[None, :])
+                valid = src >= 0
+                srcv, posv = src[valid], pos[valid]
+                if srcv.numel() != nw or torch.unique(srcv).numel() != nw:
+                    return None            # not one plane position per weight
+                lo, hi = int(srcv.min()), int(srcv.max()) + 1
+                table = torch.full((hi - lo,), -1, dtype=torch.int32, device=src.device)
+                table[srcv - lo] = posv.to(torch.int32)
+                tables.append(table)
+                desc.stride[t] = 512
+                desc.lo[t], desc.hi[t] = lo, hi
+                desc.pos[t] = table.data_ptr()
+                desc.planes[t] = ws.data_ptr()
+            desc.n = len(targets)
+            pw["scatter_tables"] = tables
+            return desc
+        finally:
+            self.flat_params.copy_(saved)
+            self.refresh_prepared()
+
+    def plane_scatter(self):
+        """The descriptor an optimizer's apply_flat(..., planes=) takes to keep the prepared planes
+        current, or None (no prepared weights / they are stale: somebody wrote the parameters with
+        a torch op and the next refresh_prepared() has not run yet)."""
+        pw = self._pw
+        if pw is None or pw.get("scatter") is None or not self._prepared_ok():
+            return None
+        return pw["scatter"]
 
     def refresh_prepared(self):
         """Runs the pre-passes for the CURRENT weights on the caller's stream (capturable)."""
@@ -636,15 +701,39 @@ class Sequential(network.Network):
             None if input_grad is None else input_grad.data_ptr(), ws.data_ptr(), ws.numel(),
             _lib.stream_ptr()), "aa_mlp_small_backward")
 
+    def fusable_head(self, B, slot):
+        """The operands of the LAST layer's backward pass when it is a small Dense head without
+        activation behind another parametrised layer (the Q head): dict(x, w, dx, dw, mask_src,
+        mask_act, bias_grad) for a loss kernel that runs the head's backward in its own launch
+        (ops.dqn_td_loss(head=...)), else None.  Needs the slot's gradient buffers (a forward with
+        need_grad=True, or any earlier backward on this slot)."""
+        s = self._slots.get((slot, B))
+        n = len(self._param_layers)
+        if s is None or s.dz_top is None or n < 2 or self._fused_small_ok():
+            return None
+        top = self._param_layers[-1]
+        if not isinstance(top, L.Dense) or top.activation is not None or s.dxs[n - 1] is None:
+            return None
+        x = s.ys[n - 2].view(B, -1)
+        prev_act = self._param_layers[n - 2].activation
+        if not (SMALL_HEAD_ON_MAIN and FUSE_HEAD_BACKWARD and
+                ops.dense_loss_head_ok(B, self._shapes[n - 1][0][1], x if prev_act else None)):
+            return None
+        return dict(x=x, w=self._kviews[n - 1], dx=s.dxs[n - 1].view(B, -1),
+                    dw=self._gkviews[n - 1], mask_src=x if prev_act else None, mask_act=prev_act,
+                    bias_grad=self._gbviews[n - 1])
+
     def backward(self, dout, slot=0, side_stream=None, param_grads=True, input_grad=None,
-                 stop_layer=0):
+                 stop_layer=0, head_done=False):
         """Given d loss / d output [B, out], fills flat_grads (overwrites).
 
         `param_grads=False` skips every weight/bias gradient (only the input-gradient chain runs:
         SAC's actor loss differentiates THROUGH the critics without updating them);
         `input_grad` ([B, in] float32 buffer, Dense first layer only) also receives
-        d loss / d network input.  `stop_layer=k > 0` stops after parametrised layer k (its input
-        gradient is computed); `backward_resume` continues with layers k-1 .. 0 -- the Learner
+        d loss / d network input.  `head_done=True`: the last layer's backward (its dX into this
+        slot's buffer, dW, db) has already been produced by the caller's loss launch
+        (`fusable_head`); the walk starts at the layer below.
+        `stop_layer=k > 0` stops after parametrised layer k (its input gradient is computed); `backward_resume` continues with layers k-1 .. 0 -- the Learner
         starts the all-reduce of the tail's gradients in between (`grad_buckets`).
 
         The input-gradient chain (dX_n -> dX_{n-1} -> ...) is the critical path; every
@@ -669,6 +758,13 @@ class Sequential(network.Network):
             dz = s.dz_top
         else:
             dz = dout.contiguous()
+        if head_done:
+            if n < 2 or stop_layer > n - 1 or not param_grads:
+                raise ValueError("head_done needs a head on top of another parametrised layer")
+            if stop_layer <= n - 2:
+                self._backward_range(s, B, s.dxs[n - 1], n - 2, stop_layer, side_stream,
+                                     param_grads, input_grad)
+            return
         self._backward_range(s, B, dz, n - 1, stop_layer, side_stream, param_grads, input_grad)
 
     def backward_resume(self, B, slot=0, side_stream=None, from_layer=1):

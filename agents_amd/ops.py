@@ -657,10 +657,18 @@ def copy_segments(pairs):
 
 
 # ---- DQN loss -------------------------------------------------------------------------------
+# TD loss + backward of the Q head in one launch (csrc/dqn.hip: aa_dqn_loss_head_backward); A/B knob
+FUSE_LOSS_HEAD = _os.environ.get("AA_FUSE_LOSS_HEAD", "1") != "0"
+
+
 def dqn_td_loss(q_online, q_next_target, q_next_select, next_mask, actions, reward, discount,
                 step_type, weights, gamma, reward_scale, loss_kind, global_batch, loss_out,
-                td_loss_out, td_error_out, dq_out, gamma_loss=None, field_sums_out=None):
-    """field_sums_out (optional float32[2]) receives sum(td_loss), sum(td_error)."""
+                td_loss_out, td_error_out, dq_out, gamma_loss=None, field_sums_out=None,
+                head=None):
+    """field_sums_out (optional float32[2]) receives sum(td_loss), sum(td_error).
+    head = dict(x, w, dx, dw, mask_src, mask_act, bias_grad): also runs the backward pass of the
+    Q head (the Dense layer that produced q_online from x) in the same launch -- same results as
+    this call without `head` followed by dense_small_backward(x, dq_out, w, dx, dw, ...)."""
     if gamma_loss is None:
         gamma_loss = gamma
     require_cuda(q_online, q_next_target, actions, reward, discount, step_type)
@@ -683,14 +691,31 @@ def dqn_td_loss(q_online, q_next_target, q_next_select, next_mask, actions, rewa
         _f32c(field_sums_out, "field_sums_out")
         if field_sums_out.numel() < 2:
             raise ValueError("field_sums_out needs two elements")
-    check(lib.aa_dqn_td_loss_sums(ptr(q_online), ptr(q_next_target), ptr(q_next_select),
-                                  ptr(next_mask), ptr(actions),
-                                  1 if actions.dtype == torch.int64 else 0, action_stride,
-                                  ptr(reward), ptr(discount), ptr(step_type), ptr(weights), B, T, A,
-                                  float(gamma), float(gamma_loss), float(reward_scale),
-                                  int(loss_kind), float(global_batch), ptr(loss_out),
-                                  ptr(td_loss_out), ptr(td_error_out), ptr(dq_out),
-                                  ptr(field_sums_out), stream_ptr()), "aa_dqn_td_loss_sums")
+    common_ = (ptr(q_online), ptr(q_next_target), ptr(q_next_select), ptr(next_mask), ptr(actions),
+               1 if actions.dtype == torch.int64 else 0, action_stride, ptr(reward), ptr(discount),
+               ptr(step_type), ptr(weights), B, T, A, float(gamma), float(gamma_loss),
+               float(reward_scale), int(loss_kind), float(global_batch), ptr(loss_out),
+               ptr(td_loss_out), ptr(td_error_out), ptr(dq_out), ptr(field_sums_out))
+    if head is None:
+        check(lib.aa_dqn_td_loss_sums(*common_, stream_ptr()), "aa_dqn_td_loss_sums")
+        return
+    x, w, dx, dw = head["x"], head["w"], head["dx"], head["dw"]
+    mask_src = head.get("mask_src")
+    require_cuda(x, w, dx, dw, mask_src)
+    lda = _rows_ok(x, "x"); _f32c(w, "w"); _f32c(dx, "dx"); _f32c(dw, "dw")
+    K = x.shape[1]
+    if x.shape[0] != B or tuple(w.shape) != (K, A) or tuple(dx.shape) != (B, K) or \
+            tuple(dw.shape) != (K, A) or not dense_loss_head_ok(B, A, mask_src):
+        raise ValueError("dqn_td_loss(head=...): shapes do not describe the Q head")
+    check(lib.aa_dqn_loss_head_backward(
+        *common_, ptr(x), lda, ptr(w), ptr(mask_src),
+        ACT[head.get("mask_act")] if mask_src is not None else 0, K, ptr(dx), ptr(dw),
+        _bias_grad_ptr(head.get("bias_grad"), A), stream_ptr()), "aa_dqn_loss_head_backward")
+
+
+def dense_loss_head_ok(B, A, mask_src):
+    return (FUSE_LOSS_HEAD and USE_SMALL_N and A <= SMALL_N and B <= SMALL_DW_MAX_M and
+            (mask_src is None or mask_src.is_contiguous()))
 
 
 __all__ = [n for n in dir() if not n.startswith("_")]

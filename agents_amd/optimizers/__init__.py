@@ -24,7 +24,11 @@ class Optimizer:
         self.iterations += 1
 
     # -- flat API (used by agents) -------------------------------------------------------------
-    def apply_flat(self, params, grads):
+    # True: apply_flat(..., planes=<_lib.PlaneScatter>) also keeps the bf16 filter planes of the
+    # bf16x6 convolutions current (networks/sequential.py: plane_scatter)
+    supports_planes = False
+
+    def apply_flat(self, params, grads, planes=None):
         """One fused update of the flat fp32 `params` with `grads` (same layout)."""
         raise NotImplementedError
 
@@ -82,16 +86,20 @@ class Adam(Optimizer):
         self.learning_rate, self.beta_1, self.beta_2, self.epsilon = \
             float(learning_rate), float(beta_1), float(beta_2), float(epsilon)
 
-    def apply_flat(self, params, grads):
+    supports_planes = True
+
+    def apply_flat(self, params, grads, planes=None):
+        import ctypes
         lib = _lib.load()
         _lib.require_cuda(params, grads)
         s = self._slot(params, ("m", "v"))
         st = _lib.stream_ptr()
         _lib.check(lib.aa_counter_add(s["step"].data_ptr(), 1, st), "aa_counter_add")
-        _lib.check(lib.aa_adam_step(params.data_ptr(), grads.data_ptr(), s["m"].data_ptr(),
-                                    s["v"].data_ptr(), params.numel(), self.learning_rate,
-                                    self.beta_1, self.beta_2, self.epsilon, s["step"].data_ptr(),
-                                    st), "aa_adam_step")
+        _lib.check(lib.aa_adam_step_planes(
+            params.data_ptr(), grads.data_ptr(), s["m"].data_ptr(), s["v"].data_ptr(),
+            params.numel(), self.learning_rate, self.beta_1, self.beta_2, self.epsilon,
+            s["step"].data_ptr(), None if planes is None else ctypes.byref(planes), st),
+            "aa_adam_step_planes")
         graph.on_replay(self._bump_iterations)
 
 
@@ -110,17 +118,21 @@ class RMSprop(Optimizer):
         self.learning_rate, self.rho, self.momentum, self.epsilon, self.centered = \
             float(learning_rate), float(rho), float(momentum), float(epsilon), bool(centered)
 
-    def apply_flat(self, params, grads):
+    supports_planes = True
+
+    def apply_flat(self, params, grads, planes=None):
+        import ctypes
         lib = _lib.load()
         _lib.require_cuda(params, grads)
         names = ["ms"] + (["mg"] if self.centered else []) + (["mom"] if self.momentum > 0 else [])
         s = self._slot(params, names)
-        _lib.check(lib.aa_rmsprop_step(
+        _lib.check(lib.aa_rmsprop_step_planes(
             params.data_ptr(), grads.data_ptr(), s["ms"].data_ptr(),
             s["mg"].data_ptr() if self.centered else None,
             s["mom"].data_ptr() if self.momentum > 0 else None, params.numel(),
-            self.learning_rate, self.rho, self.momentum, self.epsilon, _lib.stream_ptr()),
-            "aa_rmsprop_step")
+            self.learning_rate, self.rho, self.momentum, self.epsilon,
+            None if planes is None else ctypes.byref(planes), _lib.stream_ptr()),
+            "aa_rmsprop_step_planes")
         graph.on_replay(self._bump_iterations)
 
 
@@ -129,7 +141,7 @@ class SGD(Optimizer):
         super().__init__(name)
         self.learning_rate = float(learning_rate)
 
-    def apply_flat(self, params, grads):
+    def apply_flat(self, params, grads, planes=None):
         lib = _lib.load()
         _lib.require_cuda(params, grads)
         _lib.check(lib.aa_sgd_step(params.data_ptr(), grads.data_ptr(), params.numel(),

@@ -366,6 +366,23 @@ int aa_dqn_td_loss_sums(const float* q_online, const float* q_next_target,
                         double reward_scale, int32_t loss_kind, float global_batch,
                         float* loss_out, float* td_loss_out, float* td_error_out, float* dq_out,
                         float* field_sums_out, void* stream);
+/* aa_dqn_td_loss_sums and the backward pass of the Q head (the last Dense layer of the Q-network:
+ * tf.GradientTape through keras Dense(num_actions), dqn_agent.py:412-426) in ONE launch: dL/dq of a
+ * sample only depends on that sample, so every workgroup of the head's backward recomputes the
+ * [B, A] rows it needs in LDS.  x[B, K] (row pitch ldx) = the head's input, w[K, A] its kernel,
+ * mask_src / mask_kind = the derivative of the previous layer's activation (nullable),
+ * dx[B, K], dw[K, A], db[A] (nullable).  Same bits as the two separate calls.  B <= 512, A <= 16. */
+int aa_dqn_loss_head_backward(const float* q_online, const float* q_next_target,
+                              const float* q_next_select, const int32_t* next_mask,
+                              const void* actions, int32_t actions_are_i64, int64_t action_stride,
+                              const float* reward, const float* discount,
+                              const int32_t* step_type, const float* weights, int64_t B, int32_t T,
+                              int32_t A, double gamma, double gamma_loss, double reward_scale,
+                              int32_t loss_kind, float global_batch, float* loss_out,
+                              float* td_loss_out, float* td_error_out, float* dq_out,
+                              float* field_sums_out, const float* x, int64_t ldx, const float* w,
+                              const float* mask_src, int32_t mask_kind, int32_t K, float* dx,
+                              float* dw, float* db, void* stream);
 
 /* =========================================================================================
  * Optimizers / target update / clipping  (keras optimizers; utils/common.py:250-346;
@@ -380,6 +397,28 @@ int aa_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
 int aa_rmsprop_step(float* p, const float* g, float* ms, float* mg /* nullable: centered */,
                     float* mom /* nullable: momentum */, int64_t n, float lr, float rho,
                     float momentum, float eps, void* stream);
+/* The same two steps, additionally keeping up to four sets of "split planes" current: the bf16x6
+ * convolutions read each fp32 filter as three bf16 pieces (hi, mid, lo) stored in MFMA-fragment
+ * order (aa_conv_pair_x6_phase / aa_conv_dx_frame_x6_phase, phase 1); the optimizer holds every
+ * new value in a register anyway and writes its pieces to where each consumer reads them, so no
+ * pre-pass launch is needed after -- or before -- the variables change (the keras apply op has no
+ * such side output: the reference re-reads fp32 variables in every op).  For parameter index i in
+ * [lo[t], hi[t]): pos[t][i - lo[t]] = bf16 index of the hi piece inside planes[t], or -1; the mid
+ * and lo pieces follow at + stride[t] and + 2 * stride[t].  pos / planes are device pointers. */
+#define AA_MAX_PLANE_TARGETS 4
+typedef struct {
+  int32_t n;
+  int32_t stride[AA_MAX_PLANE_TARGETS];
+  int64_t lo[AA_MAX_PLANE_TARGETS], hi[AA_MAX_PLANE_TARGETS];
+  const int32_t* pos[AA_MAX_PLANE_TARGETS];
+  uint16_t* planes[AA_MAX_PLANE_TARGETS];
+} aa_plane_scatter;
+int aa_adam_step_planes(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                        float beta1, float beta2, float eps, const int64_t* step_dev,
+                        const aa_plane_scatter* planes /* nullable */, void* stream);
+int aa_rmsprop_step_planes(float* p, const float* g, float* ms, float* mg, float* mom, int64_t n,
+                           float lr, float rho, float momentum, float eps,
+                           const aa_plane_scatter* planes /* nullable */, void* stream);
 int aa_sgd_step(float* p, const float* g, int64_t n, float lr, void* stream);
 /* t = (1-tau)*t + tau*s  (soft_variables_update, utils/common.py:314-346) */
 int aa_soft_update(float* target, const float* source, int64_t n, float tau, void* stream);

@@ -57,7 +57,8 @@ def test_struct_layouts_match_the_header(tmp_path):
     fields = {"aa_gemm_desc": ("GemmDesc", ["A", "M", "a_mode", "img_pitch", "a_div", "bias",
                                             "mask_src", "force_cfg", "colsum_out", "no_dma"]),
               "aa_conv_layer_desc": ("ConvLayerDesc", ["w", "y", "KH", "act"]),
-              "aa_conv_dx_desc": ("ConvDxDesc", ["dz", "dx", "n_img", "mask_kind"])}
+              "aa_conv_dx_desc": ("ConvDxDesc", ["dz", "dx", "n_img", "mask_kind"]),
+              "aa_plane_scatter": ("PlaneScatter", ["n", "stride", "lo", "hi", "pos", "planes"])}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "agents_amd.h"', 'int main(void){']
     for cname, (_, fs) in fields.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

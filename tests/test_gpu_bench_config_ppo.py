@@ -112,11 +112,21 @@ def test_ppo_bench_configuration_matches_oracle(dev):
         # ---- normalisers -------------------------------------------------------------------------
         o_obs.update(h["obs"])
         o_rew.update(h["rew"])
+        # At 264,192 frames numpy's fp32 reduction over the LEADING axes is a sequential sum (its
+        # pairwise scheme only covers the contiguous axis): measured 6e-5 off on M2 against the
+        # GPU's two-pass-per-workgroup + Chan merge.  So the moments are pinned on float64 and
+        # the oracle continues from those, rounded to fp32 (count: 1e-8 + N rounds to N).
+        for o, x in ((o_obs, h["obs"].reshape(-1, OBS)), (o_rew, h["rew"].reshape(-1))):
+            x64 = x.astype(np.float64)
+            mean64 = x64.mean(axis=0)
+            o.avg = np.asarray(mean64, np.float32)
+            o.m2 = np.asarray(((x64 - mean64) ** 2).sum(axis=0), np.float32)
+            assert np.all(np.asarray(o.count) == np.float32(x.shape[0]))
         for nrm, o in ((agent._observation_normalizer, o_obs), (agent._reward_normalizer, o_rew)):
             count, avg, m2, _ = nrm.variables
             assert np.array_equal(count.cpu().numpy().reshape(-1), np.asarray(o.count).reshape(-1))
-            _close(avg, o.avg, rtol=1e-5, atol=1e-6, what="normaliser mean")
-            _close(m2, o.m2, rtol=2e-5, atol=1e-4, what="normaliser M2")
+            _close(avg, o.avg, rtol=1e-5, atol=2e-7, what="normaliser mean vs float64")
+            _close(m2, o.m2, rtol=5e-6, what="normaliser M2 vs float64")
         # ---- preprocess: returns / advantages from normalised rewards ----------------------------
         rew_n = o_rew.normalize(h["rew"], clip_value=10.0, center_mean=False)
         ret, adv = oppo.compute_return_and_advantage(rew_n, h["disc"], h["nst"], h["vp"], 0.99,

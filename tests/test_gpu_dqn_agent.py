@@ -285,3 +285,67 @@ def test_learner_field_sums_come_from_the_loss_kernel(dev):
         red = lrn._reduce_loss(li)
         np.testing.assert_allclose(red.extra.td_loss.item(), li.extra.td_loss.sum().item(), rtol=1e-6)
         np.testing.assert_allclose(red.loss.item(), li.loss.item(), rtol=0)
+
+
+# ---- TD loss + Q-head backward in one launch ------------------------------------------------------
+@pytest.mark.parametrize("double_q,loss", [(False, "huber"), (True, "squared")])
+def test_fused_loss_head_backward_is_bit_identical(dev, double_q, loss):
+    """csrc/dqn.hip: aa_dqn_loss_head_backward == aa_dqn_td_loss_sums + aa_dense_small_backward
+    (every workgroup of the head's backward recomputes dL/dq in LDS): loss, td fields, dq, every
+    gradient and the parameters after the optimizer step, bit for bit, eager and graphed."""
+    from agents_amd import ops
+    from agents_amd.utils import graph
+    cls = dqn_agent.DdqnAgent if double_q else dqn_agent.DqnAgent
+    obs_spec = tensor_spec.TensorSpec((20, 20, 4), torch.uint8)
+    aspec = tensor_spec.BoundedTensorSpec((), torch.int64, 0, 4)
+    tss = ts.time_step_spec(obs_spec)
+
+    def make():
+        net = sequential.Sequential([L.Rescale(255.0), L.Conv2D(8, 4, 4, "relu"),
+                                     L.Conv2D(16, 3, 1, "relu"), L.Flatten(),
+                                     L.Dense(64, "relu"), L.Dense(5)], seed=11)
+        fn = common.element_wise_huber_loss if loss == "huber" else \
+            common.element_wise_squared_loss
+        return cls(tss, aspec, q_network=net, optimizer=optimizers.RMSprop(1e-3, 0.95, 0.9, 0.01,
+                                                                           True),
+                   td_errors_loss_fn=fn, gamma=0.97, target_update_period=2, n_step_update=2), net
+
+    rng = np.random.default_rng(3)
+    B = 48
+
+    def batch():
+        return trajectory.Trajectory(
+            step_type=torch.as_tensor(rng.integers(0, 3, (B, 3)).astype(np.int32), device=dev),
+            observation=torch.as_tensor(rng.integers(0, 256, (B, 3, 20, 20, 4), dtype=np.uint8),
+                                        device=dev),
+            action=torch.as_tensor(rng.integers(0, 5, (B, 3)).astype(np.int64), device=dev),
+            policy_info=(),
+            next_step_type=torch.as_tensor(rng.integers(0, 3, (B, 3)).astype(np.int32),
+                                           device=dev),
+            reward=torch.as_tensor(rng.standard_normal((B, 3)).astype(np.float32), device=dev),
+            discount=torch.as_tensor((rng.random((B, 3)) > 0.2).astype(np.float32), device=dev))
+
+    with torch.cuda.device(dev):
+        (a_f, n_f), (a_s, n_s) = make(), make()
+        a_f.initialize()
+        a_s.initialize()
+        train_f = graph.graphed_train(a_f)
+        for step in range(5):
+            exp = batch()
+            w = torch.as_tensor(rng.uniform(0.5, 1.5, B).astype(np.float32), device=dev) \
+                if step % 2 else None
+            ops.FUSE_LOSS_HEAD = True
+            li_f = train_f(exp, weights=w) if w is None else a_f.train(exp, weights=w)
+            assert a_f._get_work(B, dev).head_done
+            ops.FUSE_LOSS_HEAD = False
+            try:
+                li_s = a_s.train(exp, weights=w)
+            finally:
+                ops.FUSE_LOSS_HEAD = True
+            assert not a_s._get_work(B, dev).head_done
+            assert torch.equal(li_f.loss, li_s.loss)
+            assert torch.equal(li_f.extra.td_loss, li_s.extra.td_loss)
+            assert torch.equal(li_f.extra.td_error, li_s.extra.td_error)
+            assert torch.equal(a_f._get_work(B, dev).dq, a_s._get_work(B, dev).dq)
+            assert torch.equal(n_f.flat_grads, n_s.flat_grads), f"step {step}"
+            assert torch.equal(n_f.flat_params, n_s.flat_params)

@@ -57,8 +57,7 @@ def test_config_1_through_the_script(dev, tmp_path, use_tf_functions):
         assert run["train_metrics"][1].result() >= 1000        # EnvironmentSteps counted
         assert [s for s, _ in evals] == [0, 55, 110]
         assert all(np.isfinite(r["AverageReturn"]) for _, r in evals)
-        fresh = te.create_feedforward_network((100,), 2, q_net._input_tensor_spec)
-        assert q_net.flat_params.numel() == 4 * 100 + 100 + 100 * 2 + 2
+        assert sum(v.numel() for v in q_net.variables) == 4 * 100 + 100 + 100 * 2 + 2
         # the harness's "variables changed" check: the logits bias started at -0.2
         assert not torch.allclose(q_net.variables[-1], torch.full_like(q_net.variables[-1], -0.2))
         if use_tf_functions:
@@ -66,4 +65,3 @@ def test_config_1_through_the_script(dev, tmp_path, use_tf_functions):
         ck = sorted(os.listdir(os.path.join(str(tmp_path), "train")))
         assert "ckpt-50.pt" in ck and "ckpt-100.pt" in ck and "policy" in ck
         assert os.listdir(os.path.join(str(tmp_path), "train", "replay_buffer")) == ["ckpt-100.pt"]
-        del fresh
