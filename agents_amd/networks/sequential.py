@@ -65,6 +65,15 @@ _HOIST_BWD = _HOIST in ("1", "3")
 # launch at all, five fewer kernels and one fewer graph branch per DQN iteration -- so DqnAgent now
 # opts in by default (AA_PREPARED_WEIGHTS=0: every call splits for itself again).
 PREPARED_WEIGHTS = os.environ.get("AA_PREPARED_WEIGHTS", "1") == "1"
+# Which plane sets are prepared: "pair" = the fused conv pair's forward filters (default), "dx" =
+# the conv input gradients' fragments (opt-in, AA_PW_KINDS=pair,dx).  Measured in the DQN iteration
+# on MI355X, alternating runs on one box (tools/ab_matrix.py): none 0.3745 ms, pair 0.3739,
+# pair+dx 0.4003, dx 0.4035 -- with the three streams of the default loop the two backward
+# pre-passes are worth keeping as a side BRANCH of the train graph (without it the HIP-graph
+# executor schedules the weight-gradient branch worse), although they are pure overhead on a
+# single stream (`bench.py --no-overlap`: none 0.4058, pair+dx 0.3703).  The forward pair planes
+# remove three launches (and 7 us of host time per iteration) at no cost either way.
+_PW_KINDS = tuple(k for k in os.environ.get("AA_PW_KINDS", "pair").split(",") if k)
 _PREPARED_NETS = []      # weak references to the networks that opted in
 
 
@@ -357,7 +366,7 @@ class Sequential(network.Network):
         div = None
         pi = 0
         skip = False
-        pw_pair = self._pw["pair"] if self._prepared_ok() else None
+        pw_pair = self._pw["pair"] if (self._prepared_ok() and self._pw["pair"]) else None
         prep_pending, s.prep_issued = s.prep_issued, None
         if prep_pending is None and pw_pair is None:
             prep_pending = self._hoist_pair_prep(s, B)
@@ -458,7 +467,7 @@ class Sequential(network.Network):
             return self._pw is not None
         dev = self.flat_params.device
         pair, dx = {}, {}
-        if FUSE_CONV_PAIRS:
+        if FUSE_CONV_PAIRS and "pair" in _PW_KINDS:
             for pi in self._conv_param_pairs():
                 if pi in pair or (pi - 1) in pair:
                     continue
@@ -471,7 +480,7 @@ class Sequential(network.Network):
                     if n > 0:
                         pair[pi] = torch.empty((n,), dtype=torch.uint8, device=dev)
         for i, l in enumerate(self._param_layers):
-            if i == 0 or not isinstance(l, L.Conv2D):
+            if i == 0 or not isinstance(l, L.Conv2D) or "dx" not in _PW_KINDS:
                 continue
             n = ops.conv_dx_prepare_bytes((1,) + tuple(self._info[i][2]), self._kviews[i], l.stride)
             if n > 0:
@@ -790,7 +799,7 @@ class Sequential(network.Network):
         if side_stream is None:
             side_stream = main
 
-        pw_dx = self._pw["dx"] if self._prepared_ok() else None
+        pw_dx = self._pw["dx"] if (self._prepared_ok() and self._pw["dx"]) else None
         dx_prep_pending = False if pw_dx is not None else self._hoist_dx_prep(s, B, hi, lo)
 
         def on_side(fn, fork=True):

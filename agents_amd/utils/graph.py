@@ -78,7 +78,14 @@ class Lanes:
 
     def __init__(self, device):
         self.device = device
-        self.C = torch.cuda.Stream(device)
+        # A/B knob AA_COLLECT_PRIORITY: HIP stream priority of the collect lane (0 = default; a
+        # positive number = lower priority where the runtime offers one) -- the policy forward is
+        # the one chain of the iteration with slack
+        pri = int(os.environ.get("AA_COLLECT_PRIORITY", "0"))
+        try:
+            self.C = torch.cuda.Stream(device, priority=pri) if pri else torch.cuda.Stream(device)
+        except Exception:
+            self.C = torch.cuda.Stream(device)
         self.S = torch.cuda.Stream(device)
         self.collect_done = None
         self.sample_done = None
