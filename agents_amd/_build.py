@@ -37,6 +37,7 @@ SOURCES = [
     ("rollout.hip", ["-ffp-contract=off"]),
     ("value_ops.hip", ["-ffp-contract=off"]),
     ("ppo.hip", ["-ffp-contract=off"]),
+    ("ppo_fused.hip", ["-ffp-contract=off"]),
     ("sac.hip", ["-ffp-contract=off"]),
     ("normalizer.hip", ["-ffp-contract=off"]),
 ]

@@ -47,6 +47,28 @@ class PlaneScatter(Structure):
                 ("pos", c_void_p * 4), ("planes", c_void_p * 4)]
 
 
+class MlpLayout(Structure):
+    """aa_mlp_layout."""
+    _fields_ = [("n_layers", c_int32), ("dims", c_int32 * 5), ("acts", c_int32 * 4),
+                ("k_off", c_int64 * 4), ("b_off", c_int64 * 4)]
+
+
+class PpoFusedDesc(Structure):
+    """aa_ppo_fused_desc (include/agents_amd.h)."""
+    _fields_ = [("obs", c_void_p), ("ld_obs", c_int64), ("obs_dim", c_int32), ("D", c_int32),
+                ("actions", c_void_p), ("old_loc", c_void_p), ("old_scale", c_void_p),
+                ("returns", c_void_p), ("adv", c_void_p), ("old_vpred", c_void_p),
+                ("step_type", c_void_p), ("weights", c_void_p), ("N", c_int64),
+                ("nrm_count", c_void_p), ("nrm_avg", c_void_p), ("nrm_m2", c_void_p),
+                ("nrm_eps", c_float), ("nrm_clip", c_float),
+                ("params", c_void_p), ("total", c_int64), ("head_off", c_int64),
+                ("actor", MlpLayout), ("value", MlpLayout),
+                ("act_mean", c_void_p), ("act_mag", c_void_p),
+                ("clip_eps", c_float), ("value_clip", c_float), ("c_v", c_float),
+                ("c_e", c_float), ("denom", c_float), ("logp_clip", c_float),
+                ("adv_eps", c_float)]
+
+
 class GemmDesc(Structure):
     _fields_ = [
         ("A", c_void_p), ("B", c_void_p), ("C", c_void_p),
@@ -154,6 +176,10 @@ _SIGNATURES = {
                                           c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32,
                                           c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "aa_ppo_fused_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "aa_ppo_fused_step": (c_int, [POINTER(PpoFusedDesc), c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p,
+                                  c_void_p, c_int64, c_void_p]),
     "aa_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float,
                              c_float, c_float, c_void_p, c_void_p]),
     "aa_rmsprop_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,

@@ -17,6 +17,7 @@ utils/tensor_normalizer.StreamingTensorNormalizer (csrc/normalizer.hip).
 Not implemented (raise NotImplementedError): RNN networks, discrete action distributions.
 """
 import collections
+import os
 
 import numpy as np
 import torch
@@ -27,6 +28,10 @@ from agents_amd.agents.ppo import ppo_policy
 from agents_amd.networks import network
 from agents_amd.specs import tensor_spec
 from agents_amd.utils import common, graph, nest_utils, tensor_normalizer
+
+# AA_PPO_FUSED=0: the layer-by-layer train step (A/B measurements; also the path for shapes the
+# fused step does not take)
+FUSED_STEP = os.environ.get("AA_PPO_FUSED", "1") != "0"
 
 PPOLossInfo = collections.namedtuple(
     "PPOLossInfo", ("policy_gradient_loss", "value_estimation_loss", "l2_regularization_loss",
@@ -455,6 +460,9 @@ class PPOAgent(tf_agent.TFAgent):
             if weights is not None:
                 wts = torch.as_tensor(weights, dtype=torch.float32, device=dev)
                 wts = wts.expand(B, T1).reshape(N).contiguous()
+            if self._fused_step_ok() and processed.observation.dtype == torch.float32:
+                # three launches per epoch instead of ~28 (csrc/ppo_fused.hip)
+                return self._train_fused(processed, returns, advantages, step_type, wts, N)
             _lib.check(lib.aa_ppo_trajectory_mask(step_type.data_ptr(), returns.data_ptr(),
                                                   advantages.data_ptr(), _lib.ptr(wts), N,
                                                   w["mask"].data_ptr(), self._st()),
@@ -502,6 +510,111 @@ class PPOAgent(tf_agent.TFAgent):
             if self.update_normalizers_in_train:      # ppo_agent.py:991-993
                 self.update_observation_normalizer(processed.observation)
                 self.update_reward_normalizer(processed.reward)
+        return loss_info
+
+    # ---- the fused minibatch step (csrc/ppo_fused.hip) ---------------------------------------------
+    def _fused_step_ok(self):
+        """The train step can run as aa_ppo_fused_step: tanh-Normal actor + value MLP with every
+        layer <= 64 wide and <= 3 layers, no KL / L2 terms, Adam, one replica."""
+        ok = getattr(self, "_fused_ok", None)
+        if ok is None:
+            from agents_amd import optimizers
+            from agents_amd.agents.ppo import ppo_actor_network as pan
+            a, v = self._actor_net, self._value_net
+            ok = bool(
+                FUSED_STEP and isinstance(a, pan.TanhNormalActorNet) and isinstance(v, pan.ValueNet)
+                and a.body._fused_small_ok() and v.body._fused_small_ok()
+                and len(a.body._param_layers) <= 3 and len(v.body._param_layers) <= 3
+                and a.body._param_layers[-1].activation is None
+                and v.body._param_layers[-1].activation is None
+                and self._D <= 16 and self._obs_rank == 1
+                and self._initial_adaptive_kl_beta == 0 and self._kl_cutoff_factor == 0
+                and self._policy_l2_reg == 0 and self._value_function_l2_reg == 0
+                and type(self._optimizer) in (optimizers.Adam, optimizers.AdamOptimizer))
+            self._fused_ok = ok
+        return ok and self.gradient_hook is None and self.num_replicas == 1
+
+    @staticmethod
+    def _mlp_layout(body, base):
+        from agents_amd import ops
+        lay = _lib.MlpLayout()
+        n = len(body._param_layers)
+        lay.n_layers = n
+        lay.dims[0] = int(np.prod(body._input_tensor_spec.shape))
+        for i, ((ks, _), (k_off, b_off), l) in enumerate(zip(body._shapes, body._offsets,
+                                                             body._param_layers)):
+            lay.dims[i + 1] = int(ks[1])
+            lay.acts[i] = ops.ACT[l.activation]
+            lay.k_off[i] = base + k_off
+            lay.b_off[i] = base + b_off
+        return lay
+
+    def _train_fused(self, processed, returns, advantages, step_type, wts, N):
+        import ctypes
+        lib = _lib.load()
+        dev = self._device
+        D = self._D
+        info = processed.policy_info
+        f2 = lambda t: t.reshape(N, D).to(torch.float32).contiguous()
+        old_loc, old_scale = f2(info["dist_params"]["loc"]), f2(info["dist_params"]["scale"])
+        actions = f2(processed.action)
+        old_vpred = info["value_prediction"].reshape(N).contiguous()
+        obs = self._flat_obs(processed.observation)
+        if obs.stride(-1) != 1:
+            obs = obs.contiguous()
+        w = self._w(N)
+        fw = w.get("fused")
+        total = self.flat_params.numel()
+        if fw is None:
+            nbytes = int(lib.aa_ppo_fused_workspace_bytes(N, total))
+            fw = {"ws": torch.zeros((nbytes,), dtype=torch.uint8, device=dev),   # zeroed ONCE
+                  "stats": torch.zeros((9,), dtype=torch.float32, device=dev)}
+            w["fused"] = fw
+        if self._norm_seg is None:
+            self._norm_seg = torch.tensor([0, total], dtype=torch.int64, device=dev)
+            self._norm_sumsq = torch.zeros((1,), dtype=torch.float32, device=dev)
+        a, v = self._actor_net, self._value_net
+        d = _lib.PpoFusedDesc()
+        d.obs, d.ld_obs, d.obs_dim, d.D = obs.data_ptr(), obs.stride(0), obs.shape[1], D
+        d.actions, d.old_loc, d.old_scale = actions.data_ptr(), old_loc.data_ptr(), \
+            old_scale.data_ptr()
+        d.returns, d.adv, d.old_vpred = returns.data_ptr(), advantages.data_ptr(), \
+            old_vpred.data_ptr()
+        d.step_type, d.weights, d.N = step_type.data_ptr(), _lib.ptr(wts), N
+        nrm = self._observation_normalizer
+        if nrm is not None:
+            st = nrm._state[0]
+            d.nrm_count, d.nrm_avg, d.nrm_m2 = st[0].data_ptr(), st[1].data_ptr(), \
+                st[2].data_ptr()
+            d.nrm_eps, d.nrm_clip = 1e-3, 5.0        # TensorNormalizer.normalize defaults
+        d.params, d.total, d.head_off = self.flat_params.data_ptr(), total, a.body.flat_size
+        d.actor = self._mlp_layout(a.body, 0)
+        d.value = self._mlp_layout(v.body, a.flat_size)
+        d.act_mean, d.act_mag = _lib.ptr(a._mean), _lib.ptr(a._mag)
+        d.clip_eps, d.value_clip = self._importance_ratio_clipping, self._value_clipping
+        d.c_v, d.c_e = self._value_pred_loss_coef, self._entropy_regularization
+        d.denom, d.logp_clip, d.adv_eps = float(N * self.num_replicas), \
+            self._log_prob_clipping, 1e-8
+        opt = self._optimizer
+        slot = opt._slot(self.flat_params, ("m", "v"))
+        for _ in range(self._num_epochs):
+            _lib.check(lib.aa_ppo_fused_step(
+                ctypes.byref(d), self.flat_grads.data_ptr(), slot["m"].data_ptr(),
+                slot["v"].data_ptr(), slot["step"].data_ptr(), opt.learning_rate, opt.beta_1,
+                opt.beta_2, opt.epsilon, self._gradient_clipping, fw["stats"].data_ptr(),
+                self._norm_sumsq.data_ptr(), fw["ws"].data_ptr(), fw["ws"].numel(), self._st()),
+                "aa_ppo_fused_step")
+            graph.on_replay(opt._bump_iterations)
+            graph.on_replay(self._bump_train_step)
+        self._grad_norm = self._norm_sumsq
+        s = fw["stats"]
+        loss_info = tf_agent.LossInfo(s[6], PPOLossInfo(
+            policy_gradient_loss=s[0], value_estimation_loss=s[1], l2_regularization_loss=s[8],
+            entropy_regularization_loss=s[2], kl_penalty_loss=s[5], clip_fraction=s[3]))
+        self._clip_fraction = loss_info.extra.clip_fraction
+        if self.update_normalizers_in_train:      # ppo_agent.py:991-993
+            self.update_observation_normalizer(processed.observation)
+            self.update_reward_normalizer(processed.reward)
         return loss_info
 
     def kl_cutoff_loss(self, kl_divergence, debug_summaries=False):

@@ -1,0 +1,539 @@
+// One PPO minibatch train step in THREE launches (tf_agents/agents/ppo/ppo_agent.py:834-1076 for a
+// feed-forward actor / value pair; ppo_agent.py:481-615 get_loss; tf_agents/train/ppo_learner.py:
+// 220-248 hands it the minibatch):
+//
+//   K1  aa_ppo_fused_step_kernel    one workgroup per 16 samples: advantage normalisation over the
+//                                   whole minibatch (_normalize_advantages :100-110, recomputed by
+//                                   every workgroup from the 16 KB of advantages: no launch, no
+//                                   cross-workgroup dependency), trajectory mask (ppo_utils.py:35-59),
+//                                   old log-prob (common.log_probability), observation normaliser
+//                                   (TensorNormalizer.normalize), actor AND value MLP forward, the
+//                                   clipped-surrogate / value / entropy loss with the tanh-Normal head
+//                                   (:1159-1512), both backward passes -> this workgroup's gradient
+//                                   slab + five loss partial sums
+//   K2  aa_ppo_fused_reduce_kernel  slabs -> flat gradient (fixed order), per-workgroup sum of
+//                                   squares, LossInfo scalars, Adam step counter
+//   K3  aa_ppo_fused_apply_kernel   tf.clip_by_global_norm (:948-949) + Adam (TF ApplyAdam)
+//
+// against ~28 launches of the layer-by-layer path (mask, log-prob, moments, normaliser, 2 x MLP
+// forward, head forward, loss, head backward, column sums, 2 x MLP backward + slab reduces,
+// segment sum of squares, clip, counter, Adam, pack): at 4,096 samples x (64, 64) the step is pure
+// launch latency (0.21 ms for 0.27 GFLOP).
+//
+// The 64-wide layers run on the fp32 matrix cores: v_mfma_f32_16x16x4_f32 is bit-for-bit an fmaf
+// chain in k order (MI355X_MICROARCH.md), so nothing changes numerically against the VALU kernels
+// of mlp_small.hip except the summation order of the weight gradients.  Every layer is padded to
+// 64 x 64 in LDS (row pitch 68 floats: the transposed operand reads of the backward pass are then
+// bank-conflict free); k-steps and column tiles beyond the layer's true width are skipped.
+//   forward   H_out[16 x 64] = act(H_in[16 x 64] W[64 x 64] + b)     wave w: columns 16w .. 16w+15
+//   dW        H_in^T[64 x 16] G[16 x 64]                              wave w: rows 16w .. 16w+15
+//   dX        G[16 x 64] W^T[64 x 64] * act'(H_in)                    wave w: columns 16w .. 16w+15
+// Fragment maps of the 16x16x4 form: A lane l = A[l & 15][l >> 4], B lane l = B[l >> 4][l & 15],
+// D lane l, register r = D[4 (l >> 4) + r][l & 15].
+//
+// Built with -ffp-contract=off: the loss arithmetic is op for op the one of ppo.hip.
+#include "common.h"
+#include "agents_amd.h"
+
+#define PF_TS 16
+#define PF_W 64
+#define PF_PITCH 68
+#define PF_MAXL 3        /* layers per network on this path (LDS: 9 activation tiles + weights < 64 KB) */
+#define PF_HALF_LOG_2PI 0.91893853320467274178f
+
+typedef float pf_f32x4 __attribute__((ext_vector_type(4)));
+
+struct PfArgs {
+  aa_ppo_fused_desc d;
+  float* slabs;        // [n_wg][total]
+  float* partial;      // [n_wg][8]
+};
+
+__device__ static inline float pf_softplus(float x) {
+  return x > 0.f ? x + log1pf(expf(-x)) : log1pf(expf(x));
+}
+__device__ static inline float pf_act(float v, int act) {
+  if (act == AA_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == AA_ACT_TANH) return tanhf(v);
+  return v;
+}
+__device__ static inline float pf_actgrad(float y, int act) {
+  if (act == AA_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (act == AA_ACT_TANH) return 1.f - y * y;
+  return 1.f;
+}
+
+// W [n_in][n_out] (row-major, HBM) -> LDS [64][PF_PITCH], zero padded; bias -> LDS [64].
+__device__ static inline void pf_stage(const float* __restrict__ params, const aa_mlp_layout& net,
+                                       int l, float* Ws, float* bs) {
+  const int n_in = net.dims[l], n_out = net.dims[l + 1];
+  for (int i = threadIdx.x; i < PF_W * PF_W; i += blockDim.x) {
+    const int k = i >> 6, j = i & 63;
+    Ws[k * PF_PITCH + j] =
+        (k < n_in && j < n_out) ? params[net.k_off[l] + (int64_t)k * n_out + j] : 0.f;
+  }
+  if (threadIdx.x < PF_W)
+    bs[threadIdx.x] = threadIdx.x < n_out ? params[net.b_off[l] + threadIdx.x] : 0.f;
+}
+
+// H_out = act(H_in W + b); every one of the 64 columns of H_out is written (zeros beyond n_out).
+__device__ static inline void pf_forward(const float* __restrict__ params, const aa_mlp_layout& net,
+                                         int l, const float (*Hin)[PF_PITCH],
+                                         float (*Hout)[PF_PITCH], float* Ws, float* bs) {
+  const int n_in = net.dims[l], n_out = net.dims[l + 1];
+  __syncthreads();      // H_in complete, previous readers of Ws done
+  pf_stage(params, net, l, Ws, bs);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+  const int col = 16 * wave + lr;
+  pf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (16 * wave < n_out) {          // wave-uniform
+    const int ksteps = (n_in + 3) >> 2;
+    for (int kt = 0; kt < ksteps; ++kt) {
+      const float a = Hin[lr][4 * kt + lg];
+      const float b = Ws[(4 * kt + lg) * PF_PITCH + col];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  const float bias = bs[col];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    Hout[4 * lg + r][col] = col < n_out ? pf_act(acc[r] + bias, net.acts[l]) : 0.f;
+}
+
+// One layer of the backward pass.  G = d loss / d (pre-activation of layer l), all 64 columns
+// defined.  Writes dW / db of the layer into this workgroup's slab and, for l > 0,
+// Gnext = (G W^T) * act'_{l-1}(H_in) = d loss / d (pre-activation of layer l - 1).
+__device__ static inline void pf_backward(const float* __restrict__ params, const aa_mlp_layout& net,
+                                          int l, const float (*Hin)[PF_PITCH],
+                                          const float (*G)[PF_PITCH], float (*Gnext)[PF_PITCH],
+                                          float* Ws, float* bs, float* __restrict__ slab) {
+  const int n_in = net.dims[l], n_out = net.dims[l + 1];
+  __syncthreads();      // G complete, previous readers of Ws / writers of Gnext done
+  pf_stage(params, net, l, Ws, bs);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+  // ---- dW[k][j] = sum_s H_in[s][k] G[s][j]: wave -> rows k = 16 wave ..; column tiles ct ----
+  if (16 * wave < n_in) {
+    for (int ct = 0; 16 * ct < n_out; ++ct) {
+      pf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < PF_TS / 4; ++t) {
+        const float a = Hin[4 * t + lg][16 * wave + lr];     // A[i = k local][kk = sample]
+        const float b = G[4 * t + lg][16 * ct + lr];         // B[kk = sample][j local]
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      }
+      const int j = 16 * ct + lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * wave + 4 * lg + r;
+        if (k < n_in && j < n_out) slab[net.k_off[l] + (int64_t)k * n_out + j] = acc[r];
+      }
+    }
+  }
+  // ---- db[j] = sum_s G[s][j] (sample order) ------------------------------------------------------
+  if ((int)threadIdx.x < n_out) {
+    float sum = 0.f;
+    for (int s = 0; s < PF_TS; ++s) sum += G[s][threadIdx.x];
+    slab[net.b_off[l] + threadIdx.x] = sum;
+  }
+  // ---- Gnext[s][k] = (sum_j G[s][j] W[k][j]) act'(H_in[s][k]) -------------------------------------
+  if (l > 0) {
+    const int k = 16 * wave + lr;
+    pf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (16 * wave < n_in) {
+      const int jsteps = (n_out + 3) >> 2;
+      for (int t = 0; t < jsteps; ++t) {
+        const float a = G[lr][4 * t + lg];                   // A[i = sample][kk = j]
+        const float b = Ws[k * PF_PITCH + 4 * t + lg];       // B[kk = j][n = k] = W[k][j]
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int s = 4 * lg + r;
+      Gnext[s][k] = k < n_in ? acc[r] * pf_actgrad(Hin[s][k], net.acts[l - 1]) : 0.f;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
+  const aa_ppo_fused_desc& d = P.d;
+  __shared__ __attribute__((aligned(16))) float Ws[PF_W * PF_PITCH];
+  __shared__ float bs[PF_W];
+  __shared__ __attribute__((aligned(16))) float X[PF_TS][PF_PITCH];
+  __shared__ __attribute__((aligned(16))) float HA[PF_MAXL][PF_TS][PF_PITCH];
+  __shared__ __attribute__((aligned(16))) float HV[PF_MAXL][PF_TS][PF_PITCH];
+  __shared__ __attribute__((aligned(16))) float G[2][PF_TS][PF_PITCH];
+  __shared__ float red[16];
+  __shared__ float bc[2];
+  __shared__ float s_w[PF_TS], s_advn[PF_TS], s_oldlp[PF_TS], s_dv[PF_TS];
+  __shared__ float s_dbias[PF_TS][AA_PPO_FUSED_MAX_D];
+  __shared__ float s_scale[AA_PPO_FUSED_MAX_D], s_logs[AA_PPO_FUSED_MAX_D],
+      s_dsp[AA_PPO_FUSED_MAX_D];
+  const int tid = threadIdx.x;
+  const int64_t N = d.N, b0 = (int64_t)blockIdx.x * PF_TS;
+  const int D = d.D;
+  float* slab = P.slabs + (int64_t)blockIdx.x * d.total;
+
+  // ---- advantage moments over the WHOLE minibatch (two-pass, fixed order; every workgroup) -----
+  {
+    float s = 0.f;
+    for (int64_t i = tid; i < N; i += blockDim.x) s += d.adv[i];
+    float t = aa_block_sum(s, red);
+    if (tid == 0) bc[0] = t / (float)N;
+    __syncthreads();
+    const float mean = bc[0];
+    float q = 0.f;
+    for (int64_t i = tid; i < N; i += blockDim.x) {
+      const float dl = d.adv[i] - mean;
+      q += dl * dl;
+    }
+    t = aa_block_sum(q, red);
+    if (tid == 0) bc[1] = t / (float)N;
+    __syncthreads();
+  }
+  // ---- per-sample scalars, head constants, the normalised observation tile -----------------------
+  if (tid < PF_TS) {
+    const int64_t b = b0 + tid;
+    float w = 0.f, advn = 0.f, olp = 0.f;
+    if (b < N) {
+      const float inv = 1.0f / sqrtf(bc[1] + d.adv_eps);
+      advn = d.adv[b] * inv + (-bc[0] * inv);     // tf.nn.batch_normalization(adv, mean, var)
+      const bool valid =
+          (d.step_type[b] != 2) && !(d.returns[b] == 0.f && d.adv[b] == 0.f);
+      const float m = valid ? 1.0f : 0.0f;
+      w = d.weights != nullptr ? d.weights[b] * m : m;
+      for (int e = 0; e < D; ++e) {
+        const float sc = d.old_scale[b * D + e];
+        const float diff = d.actions[b * D + e] / sc - d.old_loc[b * D + e] / sc;
+        olp += -0.5f * (diff * diff) - (PF_HALF_LOG_2PI + logf(sc));
+      }
+    }
+    s_w[tid] = w;
+    s_advn[tid] = advn;
+    s_oldlp[tid] = olp;
+  }
+  if (tid >= 64 && tid < 64 + D) {
+    const int e = tid - 64;
+    const float bsd = d.params[d.head_off + e];
+    const float sc = pf_softplus(bsd);
+    s_scale[e] = sc;
+    s_logs[e] = logf(sc);
+    s_dsp[e] = 1.0f / (1.0f + expf(-bsd));       // d softplus / d bias = sigmoid
+  }
+  for (int i = tid; i < PF_TS * PF_W; i += blockDim.x) {
+    const int ss = i >> 6, k = i & 63;
+    const int64_t bb = b0 + ss;
+    float v = 0.f;
+    if (bb < N && k < d.obs_dim) {
+      v = d.obs[bb * d.ld_obs + k];
+      if (d.nrm_avg != nullptr) {
+        const float var = d.nrm_m2[k] / d.nrm_count[k];
+        const float inv = 1.0f / sqrtf(var + d.nrm_eps);
+        v = v * inv + (-d.nrm_avg[k] * inv);
+        if (d.nrm_clip > 0.f) v = fminf(fmaxf(v, -d.nrm_clip), d.nrm_clip);
+      }
+    }
+    X[ss][k] = v;
+  }
+  // ---- forward: actor, value ------------------------------------------------------------------------
+  const int La = d.actor.n_layers, Lv = d.value.n_layers;
+  for (int l = 0; l < La; ++l) pf_forward(d.params, d.actor, l, l == 0 ? X : HA[l - 1], HA[l], Ws, bs);
+  for (int l = 0; l < Lv; ++l) pf_forward(d.params, d.value, l, l == 0 ? X : HV[l - 1], HV[l], Ws, bs);
+  __syncthreads();
+  // ---- loss: one thread per sample (the arithmetic of ppo.hip: aa_ppo_loss_kernel) ----------------
+  for (int i = tid; i < 2 * PF_TS * PF_PITCH; i += blockDim.x) (&G[0][0][0])[i] = 0.f;
+  __syncthreads();
+  float sum_pg = 0.f, sum_v = 0.f, sum_ent = 0.f, sum_clip = 0.f, sum_entw = 0.f;
+  if (tid < PF_TS) {
+    const int64_t b = b0 + tid;
+    float dv = 0.f;
+    for (int e = 0; e < D; ++e) s_dbias[tid][e] = 0.f;
+    if (b < N) {
+      const float w = s_w[tid];
+      const float* z = HA[La - 1][tid];
+      float lp = 0.f, ent = 0.f;
+      for (int e = 0; e < D; ++e) {
+        const float zz = z[e];
+        const float th = d.act_mag != nullptr ? tanhf(zz) : zz;
+        const float loc = d.act_mag != nullptr ? d.act_mean[e] + d.act_mag[e] * th : zz;
+        const float sc = s_scale[e];
+        const float xs = d.actions[b * D + e] / sc, ls = loc / sc;
+        const float diff = xs - ls;
+        lp += -0.5f * (diff * diff) - (PF_HALF_LOG_2PI + s_logs[e]);
+        ent += 0.5f + PF_HALF_LOG_2PI + s_logs[e];
+      }
+      float lp_c = lp;
+      bool lp_live = true;
+      if (d.logp_clip > 0.f) {
+        lp_c = fminf(fmaxf(lp, -d.logp_clip), d.logp_clip);
+        lp_live = (lp >= -d.logp_clip) && (lp <= d.logp_clip);
+      }
+      const float a = s_advn[tid];
+      const float ratio = expf(lp_c - s_oldlp[tid]);
+      const float ratio_c = fminf(fmaxf(ratio, 1.0f - d.clip_eps), 1.0f + d.clip_eps);
+      const float obj = ratio * a, obj_c = ratio_c * a;
+      float pg;
+      bool grad_through_ratio;
+      if (d.clip_eps > 0.f) {
+        pg = -fminf(obj, obj_c);
+        grad_through_ratio = obj <= obj_c;   // tf.minimum routes the gradient to x when x <= y
+        sum_clip = fabsf(ratio - 1.0f) > d.clip_eps ? 1.0f : 0.0f;
+      } else {
+        pg = -obj;
+        grad_through_ratio = true;
+      }
+      sum_pg = (w == 0.f) ? 0.f : pg * w;
+      float dlp = 0.f;
+      if (grad_through_ratio && lp_live) dlp = -(a * ratio) * w / d.denom;
+      const float R = d.returns[b], V = HV[Lv - 1][tid][0];
+      float verr = (R - V) * (R - V);
+      float dverr_dV = -2.0f * (R - V);
+      if (d.value_clip > 0.f && d.old_vpred != nullptr) {
+        const float ov = d.old_vpred[b];
+        const float dlt = V - ov;
+        const float dc = fminf(fmaxf(dlt, -d.value_clip), d.value_clip);
+        const float Vc = ov + dc;
+        const float verr_c = (R - Vc) * (R - Vc);
+        if (verr_c > verr) {     // tf.maximum: gradient to x when x >= y
+          verr = verr_c;
+          const bool live = dlt >= -d.value_clip && dlt <= d.value_clip;
+          dverr_dV = live ? -2.0f * (R - Vc) : 0.f;
+        }
+      }
+      sum_v = (w == 0.f) ? 0.f : verr * w;
+      dv = d.c_v * dverr_dV * w / d.denom;
+      sum_ent = (w == 0.f) ? 0.f : (-ent) * w;
+      sum_entw = ent * w;
+      const float dent = (d.c_e > 0.f) ? (-d.c_e * w / d.denom) : 0.f;
+      for (int e = 0; e < D; ++e) {
+        const float zz = z[e];
+        const float th = d.act_mag != nullptr ? tanhf(zz) : zz;
+        const float loc = d.act_mag != nullptr ? d.act_mean[e] + d.act_mag[e] * th : zz;
+        const float sc = s_scale[e];
+        const float diff = d.actions[b * D + e] - loc;
+        const float dlp_dloc = diff / (sc * sc);
+        const float dlp_dsc = (diff * diff) / (sc * sc * sc) - 1.0f / sc;
+        float dloc_dz = 1.0f;
+        if (d.act_mag != nullptr) dloc_dz = d.act_mag[e] * (1.0f - th * th);
+        G[0][tid][e] = dlp * dlp_dloc * dloc_dz;
+        s_dbias[tid][e] = (dlp * dlp_dsc + dent * (1.0f / sc)) * s_dsp[e];
+      }
+    }
+    s_dv[tid] = dv;
+  }
+  // the tile's five loss sums: 16 lanes of wave 0, xor tree (fixed order)
+  if (tid < 64) {
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+      sum_pg += __shfl_xor(sum_pg, off, 64);
+      sum_v += __shfl_xor(sum_v, off, 64);
+      sum_ent += __shfl_xor(sum_ent, off, 64);
+      sum_clip += __shfl_xor(sum_clip, off, 64);
+      sum_entw += __shfl_xor(sum_entw, off, 64);
+    }
+    if (tid == 0) {
+      float* p = P.partial + (int64_t)blockIdx.x * 8;
+      p[0] = sum_pg; p[1] = sum_v; p[2] = sum_ent; p[3] = sum_clip; p[4] = sum_entw;
+    }
+  }
+  __syncthreads();
+  // std_bias gradient = column sums of the per-sample terms (sample order)
+  if (tid < D) {
+    float sum = 0.f;
+    for (int s = 0; s < PF_TS; ++s) sum += s_dbias[s][tid];
+    slab[d.head_off + tid] = sum;
+  }
+  // ---- backward: actor (G[0] holds dz of the head), then value ----------------------------------------
+  int cur = 0;
+  for (int l = La - 1; l >= 0; --l) {
+    pf_backward(d.params, d.actor, l, l == 0 ? X : HA[l - 1], G[cur], G[cur ^ 1], Ws, bs, slab);
+    cur ^= 1;
+  }
+  __syncthreads();
+  for (int i = tid; i < PF_TS * PF_PITCH; i += blockDim.x) {
+    const int s = i / PF_PITCH, k = i - s * PF_PITCH;
+    G[cur][s][k] = k == 0 ? s_dv[s] : 0.f;
+  }
+  for (int l = Lv - 1; l >= 0; --l) {
+    pf_backward(d.params, d.value, l, l == 0 ? X : HV[l - 1], G[cur], G[cur ^ 1], Ws, bs, slab);
+    cur ^= 1;
+  }
+}
+
+// K2: grads[i] = sum over slabs (16 z-lanes per parameter, four loads in flight, lanes combined in
+// order: the association is fixed for a given slab count), per-workgroup sum of squares for the
+// global norm; workgroup 0 also turns the loss partials into the LossInfo vector and advances the
+// optimizer's step counter.  Alignment padding of the flat layout is never written by K1: the
+// slabs are zero-filled ONCE when the workspace is allocated, so padding gradients read as zero.
+__global__ void __launch_bounds__(256)
+aa_ppo_fused_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int64_t total,
+                           float* __restrict__ grads, float* __restrict__ sumsq_part,
+                           const float* __restrict__ partial, aa_ppo_fused_desc d,
+                           float* __restrict__ stats, int64_t* __restrict__ step_dev) {
+  __shared__ float part[16][16];
+  __shared__ float sq[16];
+  __shared__ float tot5[5];
+  const int it = threadIdx.x & 15, zl = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 16 + it;
+  float v = 0.f;
+  if (i < total) {
+    int z = zl;
+    for (; z + 48 < n_slabs; z += 64) {
+      const float t0 = slabs[(int64_t)z * total + i], t1 = slabs[(int64_t)(z + 16) * total + i];
+      const float t2 = slabs[(int64_t)(z + 32) * total + i];
+      const float t3 = slabs[(int64_t)(z + 48) * total + i];
+      v += t0; v += t1; v += t2; v += t3;
+    }
+    for (; z < n_slabs; z += 16) v += slabs[(int64_t)z * total + i];
+  }
+  part[zl][it] = v;
+  __syncthreads();
+  if (zl == 0) {
+    float r = part[0][it];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) r += part[j][it];
+    if (i < total) grads[i] = r; else r = 0.f;
+    sq[it] = r * r;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int j = 0; j < 16; ++j) s += sq[j];
+    sumsq_part[blockIdx.x] = s;
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 5) {
+      float s = 0.f;
+      for (int p = 0; p < n_slabs; ++p) s += partial[(int64_t)p * 8 + threadIdx.x];
+      tot5[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float n_elems = (float)d.N;
+      const float pg = tot5[0] / d.denom;
+      const float vl = (tot5[1] / d.denom) * d.c_v;
+      const float e = d.c_e > 0.f ? (tot5[2] / d.denom) * d.c_e : 0.f;
+      stats[0] = pg;                      // policy_gradient_loss
+      stats[1] = vl;                      // value_estimation_loss
+      stats[2] = e;                       // entropy_regularization_loss
+      stats[3] = tot5[3] / n_elems;       // clip_fraction
+      stats[4] = tot5[4] / n_elems;       // mean(entropy * weights)
+      stats[5] = 0.f;                     // kl_penalty_loss (no KL terms on this path)
+      stats[6] = pg + vl + e;             // total
+      stats[7] = 0.f;
+      stats[8] = 0.f;                     // l2_regularization_loss
+      if (step_dev != nullptr) *step_dev += 1;
+    }
+  }
+}
+
+// K3: tf.clip_by_global_norm over the whole flat gradient, then Adam (the arithmetic of optim.hip).
+__global__ void __launch_bounds__(256)
+aa_ppo_fused_apply_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                          float* __restrict__ v, int64_t n, float lr, float beta1, float beta2,
+                          float eps, const int64_t* __restrict__ step_dev,
+                          const float* __restrict__ sumsq_part, int n_part, float clip,
+                          float* __restrict__ sumsq_out) {
+  __shared__ float red[16];
+  __shared__ float s_bc[2];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n_part; i += blockDim.x) s += sumsq_part[i];
+  const float tot = aa_block_sum(s, red);
+  if (threadIdx.x == 0) {
+    float scale = 1.0f;
+    if (clip > 0.f) {
+      const float gn = sqrtf(tot);
+      scale = clip * fminf(1.0f / gn, 1.0f / clip);
+    }
+    const float t = (float)(*step_dev);
+    const float b1p = powf(beta1, t), b2p = powf(beta2, t);
+    s_bc[0] = scale;
+    s_bc[1] = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    if (blockIdx.x == 0 && sumsq_out != nullptr) sumsq_out[0] = tot;
+  }
+  __syncthreads();
+  const float scale = s_bc[0], alpha = s_bc[1], omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gi = g[i] * scale;
+    g[i] = gi;
+    float mi = m[i], vi = v[i];
+    mi = mi + (gi - mi) * omb1;
+    vi = vi + (gi * gi - vi) * omb2;
+    p[i] = p[i] - (mi * alpha) / (sqrtf(vi) + eps);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+static int pf_check_net(const aa_mlp_layout& net, int in_dim, int out_dim, int64_t total) {
+  if (net.n_layers < 1 || net.n_layers > PF_MAXL) return AA_ERR_RANGE;
+  if (net.dims[0] != in_dim || net.dims[net.n_layers] != out_dim) return AA_ERR_INVALID;
+  for (int l = 0; l <= net.n_layers; ++l)
+    if (net.dims[l] < 1 || net.dims[l] > PF_W) return AA_ERR_RANGE;
+  for (int l = 0; l < net.n_layers; ++l) {
+    if (net.acts[l] < AA_ACT_NONE || net.acts[l] > AA_ACT_TANH) return AA_ERR_INVALID;
+    if (net.k_off[l] < 0 || net.k_off[l] + (int64_t)net.dims[l] * net.dims[l + 1] > total ||
+        net.b_off[l] < 0 || net.b_off[l] + net.dims[l + 1] > total)
+      return AA_ERR_RANGE;
+  }
+  if (net.acts[net.n_layers - 1] != AA_ACT_NONE) return AA_ERR_INVALID;
+  return AA_OK;
+}
+
+extern "C" {
+
+int64_t aa_ppo_fused_workspace_bytes(int64_t N, int64_t total_params) {
+  if (N <= 0 || total_params <= 0) return -1;
+  const int64_t n_wg = (N + PF_TS - 1) / PF_TS;
+  return (n_wg * total_params + n_wg * 8 + (total_params + 15) / 16 + 16) * (int64_t)sizeof(float);
+}
+
+int aa_ppo_fused_step(const aa_ppo_fused_desc* dsc, float* grads, float* adam_m, float* adam_v,
+                      int64_t* adam_step_dev, float lr, float beta1, float beta2, float adam_eps,
+                      float grad_clip, float* stats9, float* sumsq_out, void* workspace,
+                      int64_t workspace_bytes, void* stream) {
+  if (!dsc || !grads || !adam_m || !adam_v || !adam_step_dev || !stats9 || !workspace)
+    return AA_ERR_INVALID;
+  const aa_ppo_fused_desc& d = *dsc;
+  if (!d.obs || !d.actions || !d.old_loc || !d.old_scale || !d.returns || !d.adv ||
+      !d.step_type || !d.params || d.N <= 0 || d.total <= 0 || !(d.denom > 0.f))
+    return AA_ERR_INVALID;
+  if (d.D < 1 || d.D > AA_PPO_FUSED_MAX_D || d.obs_dim < 1 || d.obs_dim > PF_W ||
+      d.ld_obs < d.obs_dim)
+    return AA_ERR_RANGE;
+  if ((d.nrm_avg != nullptr) != (d.nrm_m2 != nullptr) ||
+      (d.nrm_avg != nullptr) != (d.nrm_count != nullptr))
+    return AA_ERR_INVALID;
+  if ((d.act_mean != nullptr) != (d.act_mag != nullptr)) return AA_ERR_INVALID;
+  int rc = pf_check_net(d.actor, d.obs_dim, d.D, d.total);
+  if (rc != AA_OK) return rc;
+  rc = pf_check_net(d.value, d.obs_dim, 1, d.total);
+  if (rc != AA_OK) return rc;
+  if (d.head_off < 0 || d.head_off + d.D > d.total) return AA_ERR_RANGE;
+  if (workspace_bytes < aa_ppo_fused_workspace_bytes(d.N, d.total)) return AA_ERR_RANGE;
+  const int64_t n_wg = (d.N + PF_TS - 1) / PF_TS;
+  if (n_wg > 0x7fffffffLL) return AA_ERR_RANGE;
+  PfArgs P;
+  P.d = d;
+  P.slabs = reinterpret_cast<float*>(workspace);
+  P.partial = P.slabs + n_wg * d.total;
+  float* sumsq_part = P.partial + n_wg * 8;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(aa_ppo_fused_step_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, P);
+  const unsigned n_red = (unsigned)((d.total + 15) / 16);
+  hipLaunchKernelGGL(aa_ppo_fused_reduce_kernel, dim3(n_red), dim3(256), 0, st,
+                     (const float*)P.slabs, (int)n_wg, d.total, grads, sumsq_part,
+                     (const float*)P.partial, d, stats9, adam_step_dev);
+  int64_t blocks = (d.total + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(aa_ppo_fused_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                     const_cast<float*>(d.params), grads, adam_m, adam_v, d.total, lr, beta1,
+                     beta2, adam_eps, (const int64_t*)adam_step_dev, (const float*)sumsq_part,
+                     (int)n_red, grad_clip, sumsq_out);
+  return aa_launch_status();
+}
+
+}  // extern "C"

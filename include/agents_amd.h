@@ -550,6 +550,48 @@ int aa_ppo_update_kl_beta(const float* mean_kl_dev, float target, float toleranc
 /* g += c * p  (L2 regularisation gradient on a flat parameter range). */
 int aa_add_l2_grad(float* g, const float* p, int64_t n, float c, void* stream);
 
+/* One PPO minibatch train step -- PPOAgent._train's epoch body (ppo_agent.py:895-960) for a
+ * feed-forward tanh-Normal actor (PPOActorNetwork, ppo_actor_network.py:30-113) and a value MLP,
+ * every layer <= 64 wide, without KL / L2 terms -- in THREE launches (csrc/ppo_fused.hip):
+ * [advantage normalisation over the minibatch, trajectory mask, old log-prob, observation
+ * normaliser, both forwards, loss, both backwards -> per-workgroup gradient slabs] ->
+ * [slab sum, sum of squares, LossInfo scalars, step counter] -> [global-norm clip + Adam].
+ * All per-sample inputs are the N rows of the minibatch (N = B * T flattened).
+ * params / grads / adam_m / adam_v: the agent's flat buffers of `total` floats laid out
+ * [actor body | head: std_bias[D] (+ padding) | value body]; the layouts hold ABSOLUTE float
+ * offsets into them.  nrm_*: rows of a StreamingTensorNormalizer state (all NULL: observations
+ * are used as they are); act_mean / act_mag NULL: unbounded action spec (loc = z).
+ * stats9 = {policy_gradient_loss, value_estimation_loss, entropy_regularization_loss,
+ * clip_fraction, mean(entropy * w), kl_penalty_loss = 0, total, 0, l2 = 0}; flat grads hold the
+ * CLIPPED gradient afterwards; sumsq_out (nullable) = squared global norm before clipping.
+ * The workspace must be zero-filled once after allocation (alignment padding of the flat layout
+ * is never written). */
+#define AA_PPO_FUSED_MAX_D 16
+typedef struct {
+  int32_t n_layers;
+  int32_t dims[AA_MLP_MAX_LAYERS + 1];
+  int32_t acts[AA_MLP_MAX_LAYERS];
+  int64_t k_off[AA_MLP_MAX_LAYERS], b_off[AA_MLP_MAX_LAYERS];
+} aa_mlp_layout;
+typedef struct {
+  const float* obs; int64_t ld_obs; int32_t obs_dim; int32_t D;
+  const float* actions; const float* old_loc; const float* old_scale;   /* [N, D] */
+  const float* returns; const float* adv; const float* old_vpred;      /* [N]; old_vpred nullable */
+  const int32_t* step_type; const float* weights;                      /* [N]; weights nullable */
+  int64_t N;
+  const float* nrm_count; const float* nrm_avg; const float* nrm_m2;   /* [obs_dim] or all NULL */
+  float nrm_eps, nrm_clip;
+  const float* params; int64_t total; int64_t head_off;
+  aa_mlp_layout actor, value;
+  const float* act_mean; const float* act_mag;                          /* [D] or both NULL */
+  float clip_eps, value_clip, c_v, c_e, denom, logp_clip, adv_eps;
+} aa_ppo_fused_desc;
+int64_t aa_ppo_fused_workspace_bytes(int64_t N, int64_t total_params);
+int aa_ppo_fused_step(const aa_ppo_fused_desc* d, float* grads, float* adam_m, float* adam_v,
+                      int64_t* adam_step_dev, float lr, float beta1, float beta2, float adam_eps,
+                      float grad_clip /* <= 0: none */, float* stats9, float* sumsq_out,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
 /* =========================================================================================
  * Prioritized (proportional) sampling -- the north star's "segment-tree sampling".  No reference
  * class to mirror (prioritisation exists there only through Reverb); plugs into the reference's

@@ -58,7 +58,12 @@ def test_struct_layouts_match_the_header(tmp_path):
                                             "mask_src", "force_cfg", "colsum_out", "no_dma"]),
               "aa_conv_layer_desc": ("ConvLayerDesc", ["w", "y", "KH", "act"]),
               "aa_conv_dx_desc": ("ConvDxDesc", ["dz", "dx", "n_img", "mask_kind"]),
-              "aa_plane_scatter": ("PlaneScatter", ["n", "stride", "lo", "hi", "pos", "planes"])}
+              "aa_plane_scatter": ("PlaneScatter", ["n", "stride", "lo", "hi", "pos", "planes"]),
+              "aa_mlp_layout": ("MlpLayout", ["n_layers", "dims", "acts", "k_off", "b_off"]),
+              "aa_ppo_fused_desc": ("PpoFusedDesc", [
+                  "obs", "ld_obs", "obs_dim", "D", "actions", "old_vpred", "step_type", "N",
+                  "nrm_count", "nrm_eps", "nrm_clip", "params", "total", "head_off", "actor",
+                  "value", "act_mean", "act_mag", "clip_eps", "denom", "adv_eps"])}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "agents_amd.h"', 'int main(void){']
     for cname, (_, fs) in fields.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
