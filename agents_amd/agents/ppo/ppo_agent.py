@@ -525,6 +525,8 @@ class PPOAgent(tf_agent.TFAgent):
                 FUSED_STEP and isinstance(a, pan.TanhNormalActorNet) and isinstance(v, pan.ValueNet)
                 and a.body._fused_small_ok() and v.body._fused_small_ok()
                 and len(a.body._param_layers) <= 3 and len(v.body._param_layers) <= 3
+                and all(ks[1] % 4 == 0 or ks[0] * ks[1] <= 1024
+                        for ks, _ in a.body._shapes + v.body._shapes)
                 and a.body._param_layers[-1].activation is None
                 and v.body._param_layers[-1].activation is None
                 and self._D <= 16 and self._obs_rank == 1

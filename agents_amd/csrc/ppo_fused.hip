@@ -63,27 +63,101 @@ __device__ static inline float pf_actgrad(float y, int act) {
   return 1.f;
 }
 
-// W [n_in][n_out] (row-major, HBM) -> LDS [64][PF_PITCH], zero padded; bias -> LDS [64].
-__device__ static inline void pf_stage(const float* __restrict__ params, const aa_mlp_layout& net,
-                                       int l, float* Ws, float* bs) {
+// Weights of one layer travel HBM/L2 -> registers -> LDS in two halves, so that the loads of the
+// NEXT layer step are in flight while the current one computes (a workgroup runs 12 dependent
+// layer steps; fetching each layer's 16 KB only when it is needed cost ~5 us of load latency per
+// step: 70 us per launch, measured).  A 64 x 64 matrix is 1024 float4 = 4 per thread; matrices
+// whose rows are not float4-sized (the 6- and 1-wide heads: <= 1024 elements) go element-wise.
+// Only real elements are written to LDS: the tile is zero-filled ONCE at kernel start, afterwards
+// it only ever holds finite values, and every read beyond a layer's true shape is multiplied by an
+// exact zero or discarded by a guard.
+struct PfW {
+  float4 v[4];
+  float bias;
+};
+
+__device__ static inline void pf_prefetch(const float* __restrict__ params,
+                                          const aa_mlp_layout& net, int l, PfW& w) {
   const int n_in = net.dims[l], n_out = net.dims[l + 1];
-  for (int i = threadIdx.x; i < PF_W * PF_W; i += blockDim.x) {
-    const int k = i >> 6, j = i & 63;
-    Ws[k * PF_PITCH + j] =
-        (k < n_in && j < n_out) ? params[net.k_off[l] + (int64_t)k * n_out + j] : 0.f;
+  const float* W = params + net.k_off[l];
+  if ((n_out & 3) == 0 && (net.k_off[l] & 3) == 0) {
+    const int total4 = n_in * (n_out >> 2);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      w.v[u] = i < total4 ? reinterpret_cast<const float4*>(W)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
+    const int total = n_in * n_out;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      w.v[u].x = i < total ? W[i] : 0.f;
+    }
   }
-  if (threadIdx.x < PF_W)
-    bs[threadIdx.x] = threadIdx.x < n_out ? params[net.b_off[l] + threadIdx.x] : 0.f;
+  w.bias = (int)threadIdx.x < n_out ? params[net.b_off[l] + threadIdx.x] : 0.f;
+}
+
+__device__ static inline void pf_commit(const aa_mlp_layout& net, int l, const PfW& w, float* Ws,
+                                        float* bs) {
+  const int n_in = net.dims[l], n_out = net.dims[l + 1];
+  if ((n_out & 3) == 0 && (net.k_off[l] & 3) == 0) {
+    const int q4 = n_out >> 2, total4 = n_in * q4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      if (i < total4) {
+        const int k = i / q4, jq = i - k * q4;
+        *reinterpret_cast<float4*>(Ws + k * PF_PITCH + 4 * jq) = w.v[u];
+      }
+    }
+  } else {
+    const int total = n_in * n_out;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      if (i < total) {
+        const int k = i / n_out, j = i - k * n_out;
+        Ws[k * PF_PITCH + j] = w.v[u].x;
+      }
+    }
+  }
+  if (threadIdx.x < PF_W) bs[threadIdx.x] = w.bias;
+}
+
+// The 2 (La + Lv) layer steps of a launch in execution order: actor forward, value forward, actor
+// backward (top layer first), value backward.
+__device__ static inline void pf_step(const aa_ppo_fused_desc& d, int i, const aa_mlp_layout*& net,
+                                      int& l) {
+  const int La = d.actor.n_layers, Lv = d.value.n_layers;
+  if (i < La) { net = &d.actor; l = i; }
+  else if (i < La + Lv) { net = &d.value; l = i - La; }
+  else if (i < 2 * La + Lv) { net = &d.actor; l = 2 * La + Lv - 1 - i; }
+  else { net = &d.value; l = 2 * (La + Lv) - 1 - i; }
+}
+
+// Start of a layer step: the previous step's readers of Ws are done -> the prefetched weights go
+// to LDS, the next step's loads are issued, and the tile is ready after the second barrier.
+__device__ static inline void pf_begin_step(const aa_ppo_fused_desc& d, int i, PfW& w, float* Ws,
+                                            float* bs) {
+  const aa_mlp_layout* net;
+  int l;
+  pf_step(d, i, net, l);
+  __syncthreads();
+  pf_commit(*net, l, w, Ws, bs);
+  if (i + 1 < 2 * (d.actor.n_layers + d.value.n_layers)) {
+    pf_step(d, i + 1, net, l);
+    pf_prefetch(d.params, *net, l, w);
+  }
+  __syncthreads();
 }
 
 // H_out = act(H_in W + b); every one of the 64 columns of H_out is written (zeros beyond n_out).
-__device__ static inline void pf_forward(const float* __restrict__ params, const aa_mlp_layout& net,
-                                         int l, const float (*Hin)[PF_PITCH],
-                                         float (*Hout)[PF_PITCH], float* Ws, float* bs) {
+// (pf_begin_step has put the layer's weights into Ws / bs and synchronised.)
+__device__ static inline void pf_forward(const aa_mlp_layout& net, int l,
+                                         const float (*Hin)[PF_PITCH], float (*Hout)[PF_PITCH],
+                                         const float* Ws, const float* bs) {
   const int n_in = net.dims[l], n_out = net.dims[l + 1];
-  __syncthreads();      // H_in complete, previous readers of Ws done
-  pf_stage(params, net, l, Ws, bs);
-  __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
   const int col = 16 * wave + lr;
   pf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -104,14 +178,11 @@ __device__ static inline void pf_forward(const float* __restrict__ params, const
 // One layer of the backward pass.  G = d loss / d (pre-activation of layer l), all 64 columns
 // defined.  Writes dW / db of the layer into this workgroup's slab and, for l > 0,
 // Gnext = (G W^T) * act'_{l-1}(H_in) = d loss / d (pre-activation of layer l - 1).
-__device__ static inline void pf_backward(const float* __restrict__ params, const aa_mlp_layout& net,
-                                          int l, const float (*Hin)[PF_PITCH],
-                                          const float (*G)[PF_PITCH], float (*Gnext)[PF_PITCH],
-                                          float* Ws, float* bs, float* __restrict__ slab) {
+__device__ static inline void pf_backward(const aa_mlp_layout& net, int l,
+                                          const float (*Hin)[PF_PITCH], const float (*G)[PF_PITCH],
+                                          float (*Gnext)[PF_PITCH], const float* Ws,
+                                          float* __restrict__ slab) {
   const int n_in = net.dims[l], n_out = net.dims[l + 1];
-  __syncthreads();      // G complete, previous readers of Ws / writers of Gnext done
-  pf_stage(params, net, l, Ws, bs);
-  __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
   // ---- dW[k][j] = sum_s H_in[s][k] G[s][j]: wave -> rows k = 16 wave ..; column tiles ct ----
   if (16 * wave < n_in) {
@@ -175,6 +246,9 @@ __global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
   const int64_t N = d.N, b0 = (int64_t)blockIdx.x * PF_TS;
   const int D = d.D;
   float* slab = P.slabs + (int64_t)blockIdx.x * d.total;
+  PfW wq;
+  pf_prefetch(d.params, d.actor, 0, wq);       // in flight during the prologue below
+  for (int i = tid; i < PF_W * PF_PITCH; i += blockDim.x) Ws[i] = 0.f;
 
   // ---- advantage moments over the WHOLE minibatch (two-pass, fixed order; every workgroup) -----
   {
@@ -239,8 +313,15 @@ __global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
   }
   // ---- forward: actor, value ------------------------------------------------------------------------
   const int La = d.actor.n_layers, Lv = d.value.n_layers;
-  for (int l = 0; l < La; ++l) pf_forward(d.params, d.actor, l, l == 0 ? X : HA[l - 1], HA[l], Ws, bs);
-  for (int l = 0; l < Lv; ++l) pf_forward(d.params, d.value, l, l == 0 ? X : HV[l - 1], HV[l], Ws, bs);
+  int step = 0;
+  for (int l = 0; l < La; ++l) {
+    pf_begin_step(d, step++, wq, Ws, bs);
+    pf_forward(d.actor, l, l == 0 ? X : HA[l - 1], HA[l], Ws, bs);
+  }
+  for (int l = 0; l < Lv; ++l) {
+    pf_begin_step(d, step++, wq, Ws, bs);
+    pf_forward(d.value, l, l == 0 ? X : HV[l - 1], HV[l], Ws, bs);
+  }
   __syncthreads();
   // ---- loss: one thread per sample (the arithmetic of ppo.hip: aa_ppo_loss_kernel) ----------------
   for (int i = tid; i < 2 * PF_TS * PF_PITCH; i += blockDim.x) (&G[0][0][0])[i] = 0.f;
@@ -348,7 +429,8 @@ __global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
   // ---- backward: actor (G[0] holds dz of the head), then value ----------------------------------------
   int cur = 0;
   for (int l = La - 1; l >= 0; --l) {
-    pf_backward(d.params, d.actor, l, l == 0 ? X : HA[l - 1], G[cur], G[cur ^ 1], Ws, bs, slab);
+    pf_begin_step(d, step++, wq, Ws, bs);      // (its first barrier also completes G[cur])
+    pf_backward(d.actor, l, l == 0 ? X : HA[l - 1], G[cur], G[cur ^ 1], Ws, slab);
     cur ^= 1;
   }
   __syncthreads();
@@ -357,7 +439,8 @@ __global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
     G[cur][s][k] = k == 0 ? s_dv[s] : 0.f;
   }
   for (int l = Lv - 1; l >= 0; --l) {
-    pf_backward(d.params, d.value, l, l == 0 ? X : HV[l - 1], G[cur], G[cur ^ 1], Ws, bs, slab);
+    pf_begin_step(d, step++, wq, Ws, bs);
+    pf_backward(d.value, l, l == 0 ? X : HV[l - 1], G[cur], G[cur ^ 1], Ws, slab);
     cur ^= 1;
   }
 }
@@ -372,30 +455,45 @@ aa_ppo_fused_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int64_t
                            float* __restrict__ grads, float* __restrict__ sumsq_part,
                            const float* __restrict__ partial, aa_ppo_fused_desc d,
                            float* __restrict__ stats, int64_t* __restrict__ step_dev) {
-  __shared__ float part[16][16];
+  // workgroup = 64 consecutive parameters (16 float4) x 16 z-lanes: a 16-lane group reads 256
+  // contiguous bytes of one slab (the first version read 4-byte columns 44 KB apart: 30 us for
+  // 11 MB); z-lane zl sums slabs zl, zl + 16, ... in that order, the 16 partials are combined
+  // in lane order -- a fixed association for a given slab count
+  __shared__ float4 part[16][16];
   __shared__ float sq[16];
   __shared__ float tot5[5];
-  const int it = threadIdx.x & 15, zl = threadIdx.x >> 4;
-  const int64_t i = (int64_t)blockIdx.x * 16 + it;
-  float v = 0.f;
+  const int q = threadIdx.x & 15, zl = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 64 + 4 * q;      // total is a multiple of 4
+  const int64_t total4 = total >> 2;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < total) {
+    const float4* s4 = reinterpret_cast<const float4*>(slabs) + (i >> 2);
     int z = zl;
     for (; z + 48 < n_slabs; z += 64) {
-      const float t0 = slabs[(int64_t)z * total + i], t1 = slabs[(int64_t)(z + 16) * total + i];
-      const float t2 = slabs[(int64_t)(z + 32) * total + i];
-      const float t3 = slabs[(int64_t)(z + 48) * total + i];
-      v += t0; v += t1; v += t2; v += t3;
+      const float4 t0 = s4[(int64_t)z * total4], t1 = s4[(int64_t)(z + 16) * total4];
+      const float4 t2 = s4[(int64_t)(z + 32) * total4], t3 = s4[(int64_t)(z + 48) * total4];
+      v.x += t0.x; v.y += t0.y; v.z += t0.z; v.w += t0.w;
+      v.x += t1.x; v.y += t1.y; v.z += t1.z; v.w += t1.w;
+      v.x += t2.x; v.y += t2.y; v.z += t2.z; v.w += t2.w;
+      v.x += t3.x; v.y += t3.y; v.z += t3.z; v.w += t3.w;
     }
-    for (; z < n_slabs; z += 16) v += slabs[(int64_t)z * total + i];
+    for (; z < n_slabs; z += 16) {
+      const float4 t0 = s4[(int64_t)z * total4];
+      v.x += t0.x; v.y += t0.y; v.z += t0.z; v.w += t0.w;
+    }
   }
-  part[zl][it] = v;
+  part[zl][q] = v;
   __syncthreads();
   if (zl == 0) {
-    float r = part[0][it];
+    float4 r = part[0][q];
 #pragma unroll
-    for (int j = 1; j < 16; ++j) r += part[j][it];
-    if (i < total) grads[i] = r; else r = 0.f;
-    sq[it] = r * r;
+    for (int j = 1; j < 16; ++j) {
+      const float4 t = part[j][q];
+      r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+    }
+    if (i < total) reinterpret_cast<float4*>(grads)[i >> 2] = r;
+    else r = make_float4(0.f, 0.f, 0.f, 0.f);
+    sq[q] = ((r.x * r.x + r.y * r.y) + r.z * r.z) + r.w * r.w;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -480,6 +578,12 @@ static int pf_check_net(const aa_mlp_layout& net, int in_dim, int out_dim, int64
       return AA_ERR_RANGE;
   }
   if (net.acts[net.n_layers - 1] != AA_ACT_NONE) return AA_ERR_INVALID;
+  // staging moves 4 float4 (rows of float4-sized width) or 4 elements per thread
+  for (int l = 0; l < net.n_layers; ++l) {
+    const int n_in = net.dims[l], n_out = net.dims[l + 1];
+    const bool vec = (n_out & 3) == 0 && (net.k_off[l] & 3) == 0;
+    if (!vec && n_in * n_out > 1024) return AA_ERR_RANGE;
+  }
   return AA_OK;
 }
 
@@ -512,7 +616,10 @@ int aa_ppo_fused_step(const aa_ppo_fused_desc* dsc, float* grads, float* adam_m,
   if (rc != AA_OK) return rc;
   rc = pf_check_net(d.value, d.obs_dim, 1, d.total);
   if (rc != AA_OK) return rc;
-  if (d.head_off < 0 || d.head_off + d.D > d.total) return AA_ERR_RANGE;
+  if (d.head_off < 0 || d.head_off + d.D > d.total || (d.total & 3) != 0) return AA_ERR_RANGE;
+  if (((uintptr_t)d.params & 15) != 0 || ((uintptr_t)grads & 15) != 0 ||
+      ((uintptr_t)workspace & 15) != 0)
+    return AA_ERR_INVALID;
   if (workspace_bytes < aa_ppo_fused_workspace_bytes(d.N, d.total)) return AA_ERR_RANGE;
   const int64_t n_wg = (d.N + PF_TS - 1) / PF_TS;
   if (n_wg > 0x7fffffffLL) return AA_ERR_RANGE;
@@ -523,7 +630,7 @@ int aa_ppo_fused_step(const aa_ppo_fused_desc* dsc, float* grads, float* adam_m,
   float* sumsq_part = P.partial + n_wg * 8;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(aa_ppo_fused_step_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, P);
-  const unsigned n_red = (unsigned)((d.total + 15) / 16);
+  const unsigned n_red = (unsigned)((d.total + 63) / 64);
   hipLaunchKernelGGL(aa_ppo_fused_reduce_kernel, dim3(n_red), dim3(256), 0, st,
                      (const float*)P.slabs, (int)n_wg, d.total, grads, sumsq_part,
                      (const float*)P.partial, d, stats9, adam_step_dev);

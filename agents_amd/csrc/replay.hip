@@ -322,6 +322,35 @@ static int aa_fill_leaves(AaLeafSet& ls, void* const* tables, void* const* ios,
   return AA_OK;
 }
 
+// Row gather for rows of a few 4-byte words: thread = (row, word); the word's leaf is found by
+// walking the (<= AA_MAX_LEAVES) prefix sums held in LDS.
+__global__ void __launch_bounds__(256)
+aa_rb_gather_small_kernel(AaLeafSet ls, const int64_t* __restrict__ rows, int64_t n_rows,
+                          int words_per_row) {
+  __shared__ int s_start[AA_MAX_LEAVES + 1];
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int l = 0; l < ls.n; ++l) {
+      s_start[l] = acc;
+      acc += (int)(ls.row_bytes[l] >> 2);
+    }
+    s_start[ls.n] = acc;
+  }
+  __syncthreads();
+  const int64_t total = n_rows * words_per_row;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / words_per_row;
+    const int wd = (int)(i - r * words_per_row);
+    int l = 0;
+    while (wd >= s_start[l + 1]) ++l;
+    const int off = wd - s_start[l];
+    const uint32_t* src =
+        reinterpret_cast<const uint32_t*>(ls.table[l] + rows[r] * ls.row_bytes[l]) + off;
+    reinterpret_cast<uint32_t*>(ls.io[l] + r * ls.row_bytes[l])[off] = *src;
+  }
+}
+
 extern "C" {
 
 int aa_rb_scatter_rows(void* const* leaf_tables_h, const void* const* leaf_items_h,
@@ -407,6 +436,24 @@ int aa_rb_gather_rows(const void* const* leaf_tables_h, void* const* leaf_out_h,
                           n_leaves, &max_rb);
   if (rc != AA_OK) return rc;
   if (ids_out != nullptr && id_table == nullptr) return AA_ERR_INVALID;
+  // rows of a few words (a PPO minibatch: 4,096 rows x 11 leaves of 4 .. 68 bytes): one thread
+  // per 4-byte word instead of one workgroup per (row, 32 KiB chunk) -- 24 us -> a few us
+  if (ids_out == nullptr && max_rb <= 512) {
+    int64_t words = 0;
+    bool ok = true;
+    for (int l = 0; l < ls.n; ++l) {
+      ok = ok && (ls.row_bytes[l] & 3) == 0 && ((uintptr_t)ls.table[l] & 3) == 0 &&
+           ((uintptr_t)ls.io[l] & 3) == 0;
+      words += ls.row_bytes[l] >> 2;
+    }
+    if (ok && words > 0 && words <= 0x7fffffffLL) {
+      int64_t blocks = (n_rows * words + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(aa_rb_gather_small_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                         (hipStream_t)stream, ls, rows, n_rows, (int)words);
+      return aa_launch_status();
+    }
+  }
   int n_chunks = (int)((max_rb + AA_RB_CHUNK - 1) / AA_RB_CHUNK);
   if (n_chunks < 1) n_chunks = 1;
   const int64_t grid = n_rows * n_chunks;
