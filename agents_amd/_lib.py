@@ -177,6 +177,7 @@ _SIGNATURES = {
                                           c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32,
                                           c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "aa_ppo_fused_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "aa_ppo_fused_debug_stamps": (c_int, [c_void_p]),
     "aa_ppo_fused_step": (c_int, [POINTER(PpoFusedDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p,
                                   c_void_p, c_int64, c_void_p]),

@@ -47,7 +47,13 @@ struct PfArgs {
   aa_ppo_fused_desc d;
   float* slabs;        // [n_wg][total]
   float* partial;      // [n_wg][8]
+  long long* stamps;   // nullable (aa_ppo_fused_debug_stamps): [n_wg][32] wall_clock64 ticks (10 ns)
 };
+
+static long long* g_pf_stamps = nullptr;
+#define PF_STAMP(i)                                                              \
+  if (P.stamps != nullptr && threadIdx.x == 0)                                   \
+    P.stamps[(size_t)blockIdx.x * 32 + (i)] = wall_clock64();
 
 __device__ static inline float pf_softplus(float x) {
   return x > 0.f ? x + log1pf(expf(-x)) : log1pf(expf(x));
@@ -61,6 +67,16 @@ __device__ static inline float pf_actgrad(float y, int act) {
   if (act == AA_ACT_RELU) return y > 0.f ? 1.f : 0.f;
   if (act == AA_ACT_TANH) return 1.f - y * y;
   return 1.f;
+}
+
+// Workgroup barrier that only waits for this wave's LDS traffic: __syncthreads() carries a release
+// fence that also drains the VM counter, i.e. the gradient-slab stores of the backward steps
+// (never read by this launch) and the weight prefetch of the next step -- measured 3-6 us per
+// layer step with one wave per SIMD and nothing to hide the latency behind.
+__device__ static inline void pf_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 }
 
 // Weights of one layer travel HBM/L2 -> registers -> LDS in two halves, so that the loads of the
@@ -127,52 +143,63 @@ __device__ static inline void pf_commit(const aa_mlp_layout& net, int l, const P
 
 // The 2 (La + Lv) layer steps of a launch in execution order: actor forward, value forward, actor
 // backward (top layer first), value backward.
-__device__ static inline void pf_step(const aa_ppo_fused_desc& d, int i, const aa_mlp_layout*& net,
-                                      int& l) {
-  const int La = d.actor.n_layers, Lv = d.value.n_layers;
-  if (i < La) { net = &d.actor; l = i; }
-  else if (i < La + Lv) { net = &d.value; l = i - La; }
-  else if (i < 2 * La + Lv) { net = &d.actor; l = 2 * La + Lv - 1 - i; }
-  else { net = &d.value; l = 2 * (La + Lv) - 1 - i; }
+// (The two layouts are copied to LDS once -- nets[0] = actor, nets[1] = value -- and addressed by
+// index: a POINTER to a member of the kernel-argument struct made the compiler spill the whole
+// struct to scratch, 440 bytes per lane.)
+__device__ static inline void pf_step(int La, int Lv, int i, int& which, int& l) {
+  if (i < La) { which = 0; l = i; }
+  else if (i < La + Lv) { which = 1; l = i - La; }
+  else if (i < 2 * La + Lv) { which = 0; l = 2 * La + Lv - 1 - i; }
+  else { which = 1; l = 2 * (La + Lv) - 1 - i; }
 }
 
 // Start of a layer step: the previous step's readers of Ws are done -> the prefetched weights go
 // to LDS, the next step's loads are issued, and the tile is ready after the second barrier.
-__device__ static inline void pf_begin_step(const aa_ppo_fused_desc& d, int i, PfW& w, float* Ws,
-                                            float* bs) {
-  const aa_mlp_layout* net;
-  int l;
-  pf_step(d, i, net, l);
-  __syncthreads();
-  pf_commit(*net, l, w, Ws, bs);
-  if (i + 1 < 2 * (d.actor.n_layers + d.value.n_layers)) {
-    pf_step(d, i + 1, net, l);
-    pf_prefetch(d.params, *net, l, w);
+__device__ static inline void pf_begin_step(const float* __restrict__ params,
+                                            const aa_mlp_layout* nets /* LDS */, int i, PfW& w,
+                                            float* Ws, float* bs) {
+  const int La = nets[0].n_layers, Lv = nets[1].n_layers;
+  int which, l;
+  pf_step(La, Lv, i, which, l);
+  pf_barrier();
+  pf_commit(nets[which], l, w, Ws, bs);
+  if (i + 1 < 2 * (La + Lv)) {
+    pf_step(La, Lv, i + 1, which, l);
+    pf_prefetch(params, nets[which], l, w);
   }
-  __syncthreads();
+  pf_barrier();
 }
 
 // H_out = act(H_in W + b); every one of the 64 columns of H_out is written (zeros beyond n_out).
-// (pf_begin_step has put the layer's weights into Ws / bs and synchronised.)
+// (pf_begin_step has put the layer's weights into Ws / bs and synchronised.)  The k loop always
+// runs the padded 16 steps with every LDS read issued up front and two accumulators: with one wave
+// per SIMD a rolled loop exposes an LDS round trip plus the 40-cycle dependent-MFMA latency per
+// step (measured 3.6 us per layer); rows / columns beyond the layer's shape multiply exact zeros.
 __device__ static inline void pf_forward(const aa_mlp_layout& net, int l,
                                          const float (*Hin)[PF_PITCH], float (*Hout)[PF_PITCH],
                                          const float* Ws, const float* bs) {
-  const int n_in = net.dims[l], n_out = net.dims[l + 1];
+  const int n_out = net.dims[l + 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
   const int col = 16 * wave + lr;
-  pf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  pf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   if (16 * wave < n_out) {          // wave-uniform
-    const int ksteps = (n_in + 3) >> 2;
-    for (int kt = 0; kt < ksteps; ++kt) {
-      const float a = Hin[lr][4 * kt + lg];
-      const float b = Ws[(4 * kt + lg) * PF_PITCH + col];
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    float a[16], b[16];
+#pragma unroll
+    for (int kt = 0; kt < 16; ++kt) {
+      a[kt] = Hin[lr][4 * kt + lg];
+      b[kt] = Ws[(4 * kt + lg) * PF_PITCH + col];
+    }
+#pragma unroll
+    for (int kt = 0; kt < 16; kt += 2) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt], b[kt], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt + 1], b[kt + 1], acc1, 0, 0, 0);
     }
   }
   const float bias = bs[col];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
-    Hout[4 * lg + r][col] = col < n_out ? pf_act(acc[r] + bias, net.acts[l]) : 0.f;
+    Hout[4 * lg + r][col] =
+        col < n_out ? pf_act((acc0[r] + acc1[r]) + bias, net.acts[l]) : 0.f;
 }
 
 // One layer of the backward pass.  G = d loss / d (pre-activation of layer l), all 64 columns
@@ -186,44 +213,58 @@ __device__ static inline void pf_backward(const aa_mlp_layout& net, int l,
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
   // ---- dW[k][j] = sum_s H_in[s][k] G[s][j]: wave -> rows k = 16 wave ..; column tiles ct ----
   if (16 * wave < n_in) {
-    for (int ct = 0; 16 * ct < n_out; ++ct) {
-      pf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float a[4];
 #pragma unroll
-      for (int t = 0; t < PF_TS / 4; ++t) {
-        const float a = Hin[4 * t + lg][16 * wave + lr];     // A[i = k local][kk = sample]
-        const float b = G[4 * t + lg][16 * ct + lr];         // B[kk = sample][j local]
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
-      }
-      const int j = 16 * ct + lr;
+    for (int t = 0; t < 4; ++t) a[t] = Hin[4 * t + lg][16 * wave + lr];   // A[i = k local][kk = sample]
+    const int nct = (n_out + 15) >> 4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k = 16 * wave + 4 * lg + r;
-        if (k < n_in && j < n_out) slab[net.k_off[l] + (int64_t)k * n_out + j] = acc[r];
+    for (int ct = 0; ct < 4; ++ct) {
+      if (ct < nct) {               // wave-uniform
+        float b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = G[4 * t + lg][16 * ct + lr];   // B[kk = sample][j local]
+        pf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc, 0, 0, 0);
+        const int j = 16 * ct + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * wave + 4 * lg + r;
+          if (k < n_in && j < n_out) slab[net.k_off[l] + (int64_t)k * n_out + j] = acc[r];
+        }
       }
     }
   }
   // ---- db[j] = sum_s G[s][j] (sample order) ------------------------------------------------------
   if ((int)threadIdx.x < n_out) {
     float sum = 0.f;
+#pragma unroll
     for (int s = 0; s < PF_TS; ++s) sum += G[s][threadIdx.x];
     slab[net.b_off[l] + threadIdx.x] = sum;
   }
   // ---- Gnext[s][k] = (sum_j G[s][j] W[k][j]) act'(H_in[s][k]) -------------------------------------
   if (l > 0) {
     const int k = 16 * wave + lr;
-    pf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    pf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if (16 * wave < n_in) {
-      const int jsteps = (n_out + 3) >> 2;
-      for (int t = 0; t < jsteps; ++t) {
-        const float a = G[lr][4 * t + lg];                   // A[i = sample][kk = j]
-        const float b = Ws[k * PF_PITCH + 4 * t + lg];       // B[kk = j][n = k] = W[k][j]
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      float a[16], b[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        a[t] = G[lr][4 * t + lg];                        // A[i = sample][kk = j]
+        b[t] = Ws[k * PF_PITCH + 4 * t + lg];            // B[kk = j][n = k] = W[k][j]
+      }
+#pragma unroll
+      for (int t = 0; t < 16; t += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t + 1], b[t + 1], acc1, 0, 0, 0);
       }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int s = 4 * lg + r;
-      Gnext[s][k] = k < n_in ? acc[r] * pf_actgrad(Hin[s][k], net.acts[l - 1]) : 0.f;
+      Gnext[s][k] =
+          k < n_in ? (acc0[r] + acc1[r]) * pf_actgrad(Hin[s][k], net.acts[l - 1]) : 0.f;
     }
   }
 }
@@ -238,39 +279,89 @@ __global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
   __shared__ __attribute__((aligned(16))) float G[2][PF_TS][PF_PITCH];
   __shared__ float red[16];
   __shared__ float bc[2];
-  __shared__ float s_w[PF_TS], s_advn[PF_TS], s_oldlp[PF_TS], s_dv[PF_TS];
+  __shared__ float s_w[PF_TS], s_advn[PF_TS], s_oldlp[PF_TS], s_dv[PF_TS], s_dlp[PF_TS],
+      s_dent[PF_TS];
+  // per (sample, action dim): the minibatch rows' actions / old distribution, then loss terms
+  __shared__ float s_act[PF_TS][AA_PPO_FUSED_MAX_D], s_t0[PF_TS][AA_PPO_FUSED_MAX_D],
+      s_t1[PF_TS][AA_PPO_FUSED_MAX_D], s_t2[PF_TS][AA_PPO_FUSED_MAX_D];
   __shared__ float s_dbias[PF_TS][AA_PPO_FUSED_MAX_D];
   __shared__ float s_scale[AA_PPO_FUSED_MAX_D], s_logs[AA_PPO_FUSED_MAX_D],
       s_dsp[AA_PPO_FUSED_MAX_D];
+  __shared__ aa_mlp_layout nets[2];
   const int tid = threadIdx.x;
   const int64_t N = d.N, b0 = (int64_t)blockIdx.x * PF_TS;
   const int D = d.D;
   float* slab = P.slabs + (int64_t)blockIdx.x * d.total;
   PfW wq;
+  PF_STAMP(0)
+  if (tid == 0) nets[0] = d.actor;
+  if (tid == 64) nets[1] = d.value;
   pf_prefetch(d.params, d.actor, 0, wq);       // in flight during the prologue below
   for (int i = tid; i < PF_W * PF_PITCH; i += blockDim.x) Ws[i] = 0.f;
 
   // ---- advantage moments over the WHOLE minibatch (two-pass, fixed order; every workgroup) -----
+  // N <= 4096 with 16-byte rows: the 16 values of a thread stay in registers for both passes
   {
+    const bool vec = (N & 3) == 0 && N <= 4096 && (((uintptr_t)d.adv) & 15) == 0;
+    float4 av[4];
     float s = 0.f;
-    for (int64_t i = tid; i < N; i += blockDim.x) s += d.adv[i];
+    if (vec) {
+      const int64_t n4 = N >> 2;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t i = tid + 256 * u;
+        av[u] = i < n4 ? reinterpret_cast<const float4*>(d.adv)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += ((av[u].x + av[u].y) + av[u].z) + av[u].w;
+    } else {
+      for (int64_t i = tid; i < N; i += blockDim.x) s += d.adv[i];
+    }
     float t = aa_block_sum(s, red);
     if (tid == 0) bc[0] = t / (float)N;
     __syncthreads();
     const float mean = bc[0];
     float q = 0.f;
-    for (int64_t i = tid; i < N; i += blockDim.x) {
-      const float dl = d.adv[i] - mean;
-      q += dl * dl;
+    if (vec) {
+      const int64_t n4 = N >> 2;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (tid + 256 * u < n4) {
+          const float d0 = av[u].x - mean, d1 = av[u].y - mean, d2 = av[u].z - mean,
+                      d3 = av[u].w - mean;
+          q += ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
+        }
+      }
+    } else {
+      for (int64_t i = tid; i < N; i += blockDim.x) {
+        const float dl = d.adv[i] - mean;
+        q += dl * dl;
+      }
     }
     t = aa_block_sum(q, red);
     if (tid == 0) bc[1] = t / (float)N;
     __syncthreads();
   }
-  // ---- per-sample scalars, head constants, the normalised observation tile -----------------------
-  if (tid < PF_TS) {
-    const int64_t b = b0 + tid;
-    float w = 0.f, advn = 0.f, olp = 0.f;
+  PF_STAMP(1)
+  // ---- the tile's rows: actions, old log-prob terms (thread per (sample, dim)), per-sample
+  //      scalars, head constants, the normalised observation tile ----------------------------------
+  if (tid < PF_TS * D) {
+    const int ss = tid / D, e = tid - ss * D;
+    const int64_t b = b0 + ss;
+    float act = 0.f, term = 0.f;
+    if (b < N) {
+      act = d.actions[b * D + e];
+      const float sc = d.old_scale[b * D + e];
+      const float diff = act / sc - d.old_loc[b * D + e] / sc;
+      term = -0.5f * (diff * diff) - (PF_HALF_LOG_2PI + logf(sc));
+    }
+    s_act[ss][e] = act;
+    s_t0[ss][e] = term;
+  }
+  if (tid >= 128 && tid < 128 + PF_TS) {
+    const int ss = tid - 128;
+    const int64_t b = b0 + ss;
+    float w = 0.f, advn = 0.f;
     if (b < N) {
       const float inv = 1.0f / sqrtf(bc[1] + d.adv_eps);
       advn = d.adv[b] * inv + (-bc[0] * inv);     // tf.nn.batch_normalization(adv, mean, var)
@@ -278,25 +369,21 @@ __global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
           (d.step_type[b] != 2) && !(d.returns[b] == 0.f && d.adv[b] == 0.f);
       const float m = valid ? 1.0f : 0.0f;
       w = d.weights != nullptr ? d.weights[b] * m : m;
-      for (int e = 0; e < D; ++e) {
-        const float sc = d.old_scale[b * D + e];
-        const float diff = d.actions[b * D + e] / sc - d.old_loc[b * D + e] / sc;
-        olp += -0.5f * (diff * diff) - (PF_HALF_LOG_2PI + logf(sc));
-      }
     }
-    s_w[tid] = w;
-    s_advn[tid] = advn;
-    s_oldlp[tid] = olp;
+    s_w[ss] = w;
+    s_advn[ss] = advn;
   }
-  if (tid >= 64 && tid < 64 + D) {
-    const int e = tid - 64;
+  if (tid >= 192 && tid < 192 + D) {
+    const int e = tid - 192;
     const float bsd = d.params[d.head_off + e];
     const float sc = pf_softplus(bsd);
     s_scale[e] = sc;
     s_logs[e] = logf(sc);
     s_dsp[e] = 1.0f / (1.0f + expf(-bsd));       // d softplus / d bias = sigmoid
   }
-  for (int i = tid; i < PF_TS * PF_W; i += blockDim.x) {
+#pragma unroll
+  for (int u = 0; u < PF_TS * PF_W / 256; ++u) {
+    const int i = tid + 256 * u;
     const int ss = i >> 6, k = i & 63;
     const int64_t bb = b0 + ss;
     float v = 0.f;
@@ -311,39 +398,56 @@ __global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
     }
     X[ss][k] = v;
   }
+  pf_barrier();
+  if (tid < PF_TS) {          // old log-prob: the per-dim terms added in dim order
+    float olp = 0.f;
+    for (int e = 0; e < D; ++e) olp += s_t0[tid][e];
+    s_oldlp[tid] = olp;
+  }
+  PF_STAMP(2)
   // ---- forward: actor, value ------------------------------------------------------------------------
   const int La = d.actor.n_layers, Lv = d.value.n_layers;
   int step = 0;
   for (int l = 0; l < La; ++l) {
-    pf_begin_step(d, step++, wq, Ws, bs);
-    pf_forward(d.actor, l, l == 0 ? X : HA[l - 1], HA[l], Ws, bs);
+    pf_begin_step(d.params, nets, step++, wq, Ws, bs);
+    pf_forward(nets[0], l, l == 0 ? X : HA[l - 1], HA[l], Ws, bs);
+    PF_STAMP(3 + l)
   }
   for (int l = 0; l < Lv; ++l) {
-    pf_begin_step(d, step++, wq, Ws, bs);
-    pf_forward(d.value, l, l == 0 ? X : HV[l - 1], HV[l], Ws, bs);
+    pf_begin_step(d.params, nets, step++, wq, Ws, bs);
+    pf_forward(nets[1], l, l == 0 ? X : HV[l - 1], HV[l], Ws, bs);
+    PF_STAMP(6 + l)
   }
-  __syncthreads();
-  // ---- loss: one thread per sample (the arithmetic of ppo.hip: aa_ppo_loss_kernel) ----------------
+  pf_barrier();
+  PF_STAMP(9)
+  // ---- loss (the arithmetic of ppo.hip: aa_ppo_loss_kernel), three short phases --------------------
+  // A: thread per (sample, dim): log-prob / entropy terms of the current policy
   for (int i = tid; i < 2 * PF_TS * PF_PITCH; i += blockDim.x) (&G[0][0][0])[i] = 0.f;
-  __syncthreads();
+  float r_th = 0.f, r_diff = 0.f;      // kept for phase C by the (sample, dim) thread
+  if (tid < PF_TS * D) {
+    const int ss = tid / D, e = tid - ss * D;
+    const float zz = HA[La - 1][ss][e];
+    r_th = d.act_mag != nullptr ? tanhf(zz) : zz;
+    const float loc = d.act_mag != nullptr ? d.act_mean[e] + d.act_mag[e] * r_th : zz;
+    const float sc = s_scale[e];
+    const float xs = s_act[ss][e] / sc, ls = loc / sc;
+    const float df = xs - ls;
+    s_t1[ss][e] = -0.5f * (df * df) - (PF_HALF_LOG_2PI + s_logs[e]);
+    s_t2[ss][e] = 0.5f + PF_HALF_LOG_2PI + s_logs[e];
+    r_diff = s_act[ss][e] - loc;
+  }
+  pf_barrier();
+  // B: thread per sample: surrogate, value loss, entropy; d loss / d log-prob, d loss / d entropy
   float sum_pg = 0.f, sum_v = 0.f, sum_ent = 0.f, sum_clip = 0.f, sum_entw = 0.f;
   if (tid < PF_TS) {
     const int64_t b = b0 + tid;
-    float dv = 0.f;
-    for (int e = 0; e < D; ++e) s_dbias[tid][e] = 0.f;
+    float dv = 0.f, dlp = 0.f, dent = 0.f;
     if (b < N) {
       const float w = s_w[tid];
-      const float* z = HA[La - 1][tid];
       float lp = 0.f, ent = 0.f;
       for (int e = 0; e < D; ++e) {
-        const float zz = z[e];
-        const float th = d.act_mag != nullptr ? tanhf(zz) : zz;
-        const float loc = d.act_mag != nullptr ? d.act_mean[e] + d.act_mag[e] * th : zz;
-        const float sc = s_scale[e];
-        const float xs = d.actions[b * D + e] / sc, ls = loc / sc;
-        const float diff = xs - ls;
-        lp += -0.5f * (diff * diff) - (PF_HALF_LOG_2PI + s_logs[e]);
-        ent += 0.5f + PF_HALF_LOG_2PI + s_logs[e];
+        lp += s_t1[tid][e];
+        ent += s_t2[tid][e];
       }
       float lp_c = lp;
       bool lp_live = true;
@@ -366,7 +470,6 @@ __global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
         grad_through_ratio = true;
       }
       sum_pg = (w == 0.f) ? 0.f : pg * w;
-      float dlp = 0.f;
       if (grad_through_ratio && lp_live) dlp = -(a * ratio) * w / d.denom;
       const float R = d.returns[b], V = HV[Lv - 1][tid][0];
       float verr = (R - V) * (R - V);
@@ -387,22 +490,11 @@ __global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
       dv = d.c_v * dverr_dV * w / d.denom;
       sum_ent = (w == 0.f) ? 0.f : (-ent) * w;
       sum_entw = ent * w;
-      const float dent = (d.c_e > 0.f) ? (-d.c_e * w / d.denom) : 0.f;
-      for (int e = 0; e < D; ++e) {
-        const float zz = z[e];
-        const float th = d.act_mag != nullptr ? tanhf(zz) : zz;
-        const float loc = d.act_mag != nullptr ? d.act_mean[e] + d.act_mag[e] * th : zz;
-        const float sc = s_scale[e];
-        const float diff = d.actions[b * D + e] - loc;
-        const float dlp_dloc = diff / (sc * sc);
-        const float dlp_dsc = (diff * diff) / (sc * sc * sc) - 1.0f / sc;
-        float dloc_dz = 1.0f;
-        if (d.act_mag != nullptr) dloc_dz = d.act_mag[e] * (1.0f - th * th);
-        G[0][tid][e] = dlp * dlp_dloc * dloc_dz;
-        s_dbias[tid][e] = (dlp * dlp_dsc + dent * (1.0f / sc)) * s_dsp[e];
-      }
+      dent = (d.c_e > 0.f) ? (-d.c_e * w / d.denom) : 0.f;
     }
     s_dv[tid] = dv;
+    s_dlp[tid] = dlp;
+    s_dent[tid] = dent;
   }
   // the tile's five loss sums: 16 lanes of wave 0, xor tree (fixed order)
   if (tid < 64) {
@@ -419,30 +511,53 @@ __global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
       p[0] = sum_pg; p[1] = sum_v; p[2] = sum_ent; p[3] = sum_clip; p[4] = sum_entw;
     }
   }
-  __syncthreads();
+  pf_barrier();
+  // C: thread per (sample, dim): back through the tanh-Normal head
+  if (tid < PF_TS * D) {
+    const int ss = tid / D, e = tid - ss * D;
+    float gz = 0.f, gb = 0.f;
+    if (b0 + ss < N) {
+      const float sc = s_scale[e];
+      const float dlp = s_dlp[ss], dent = s_dent[ss];
+      const float dlp_dloc = r_diff / (sc * sc);
+      const float dlp_dsc = (r_diff * r_diff) / (sc * sc * sc) - 1.0f / sc;
+      float dloc_dz = 1.0f;
+      if (d.act_mag != nullptr) dloc_dz = d.act_mag[e] * (1.0f - r_th * r_th);
+      gz = dlp * dlp_dloc * dloc_dz;
+      gb = (dlp * dlp_dsc + dent * (1.0f / sc)) * s_dsp[e];
+    }
+    G[0][ss][e] = gz;
+    s_dbias[ss][e] = gb;
+  }
+  pf_barrier();
   // std_bias gradient = column sums of the per-sample terms (sample order)
   if (tid < D) {
     float sum = 0.f;
+#pragma unroll
     for (int s = 0; s < PF_TS; ++s) sum += s_dbias[s][tid];
     slab[d.head_off + tid] = sum;
   }
+  PF_STAMP(10)
   // ---- backward: actor (G[0] holds dz of the head), then value ----------------------------------------
   int cur = 0;
   for (int l = La - 1; l >= 0; --l) {
-    pf_begin_step(d, step++, wq, Ws, bs);      // (its first barrier also completes G[cur])
-    pf_backward(d.actor, l, l == 0 ? X : HA[l - 1], G[cur], G[cur ^ 1], Ws, slab);
+    pf_begin_step(d.params, nets, step++, wq, Ws, bs);      // (its first barrier also completes G[cur])
+    pf_backward(nets[0], l, l == 0 ? X : HA[l - 1], G[cur], G[cur ^ 1], Ws, slab);
     cur ^= 1;
+    PF_STAMP(11 + (La - 1 - l))
   }
-  __syncthreads();
+  pf_barrier();
   for (int i = tid; i < PF_TS * PF_PITCH; i += blockDim.x) {
     const int s = i / PF_PITCH, k = i - s * PF_PITCH;
     G[cur][s][k] = k == 0 ? s_dv[s] : 0.f;
   }
   for (int l = Lv - 1; l >= 0; --l) {
-    pf_begin_step(d, step++, wq, Ws, bs);
-    pf_backward(d.value, l, l == 0 ? X : HV[l - 1], G[cur], G[cur ^ 1], Ws, slab);
+    pf_begin_step(d.params, nets, step++, wq, Ws, bs);
+    pf_backward(nets[1], l, l == 0 ? X : HV[l - 1], G[cur], G[cur ^ 1], Ws, slab);
     cur ^= 1;
+    PF_STAMP(14 + (Lv - 1 - l))
   }
+  PF_STAMP(17)
 }
 
 // K2: grads[i] = sum over slabs (16 z-lanes per parameter, four loads in flight, lanes combined in
@@ -502,10 +617,16 @@ aa_ppo_fused_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int64_t
     sumsq_part[blockIdx.x] = s;
   }
   if (blockIdx.x == 0) {
-    if (threadIdx.x < 5) {
+    // the five loss sums over the n_slabs workgroups of K1: thread t adds workgroups t, t + 256, ...
+    // and the 256 partials are combined by the fixed block tree (a single thread walking 256
+    // dependent loads made this workgroup -- and with it the launch -- take 30 us)
+    __shared__ float red5[16];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
       float s = 0.f;
-      for (int p = 0; p < n_slabs; ++p) s += partial[(int64_t)p * 8 + threadIdx.x];
-      tot5[threadIdx.x] = s;
+      for (int p = threadIdx.x; p < n_slabs; p += blockDim.x) s += partial[(int64_t)p * 8 + k];
+      const float t = aa_block_sum(s, red5);
+      if (threadIdx.x == 0) tot5[k] = t;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -589,6 +710,14 @@ static int pf_check_net(const aa_mlp_layout& net, int in_dim, int out_dim, int64
 
 extern "C" {
 
+// Measurement aid (tools/ppo_fused_probe.py): every workgroup of the next aa_ppo_fused_step
+// launches writes wall_clock64() stamps at its phase boundaries to buf[n_wg][32]; NULL switches
+// it off again.
+int aa_ppo_fused_debug_stamps(int64_t* buf) {
+  g_pf_stamps = reinterpret_cast<long long*>(buf);
+  return AA_OK;
+}
+
 int64_t aa_ppo_fused_workspace_bytes(int64_t N, int64_t total_params) {
   if (N <= 0 || total_params <= 0) return -1;
   const int64_t n_wg = (N + PF_TS - 1) / PF_TS;
@@ -627,6 +756,7 @@ int aa_ppo_fused_step(const aa_ppo_fused_desc* dsc, float* grads, float* adam_m,
   P.d = d;
   P.slabs = reinterpret_cast<float*>(workspace);
   P.partial = P.slabs + n_wg * d.total;
+  P.stamps = g_pf_stamps;
   float* sumsq_part = P.partial + n_wg * 8;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(aa_ppo_fused_step_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, P);

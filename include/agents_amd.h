@@ -587,6 +587,9 @@ typedef struct {
   float clip_eps, value_clip, c_v, c_e, denom, logp_clip, adv_eps;
 } aa_ppo_fused_desc;
 int64_t aa_ppo_fused_workspace_bytes(int64_t N, int64_t total_params);
+/* Measurement aid: the workgroups of the following aa_ppo_fused_step calls write wall_clock64()
+ * stamps (10 ns ticks) at their phase boundaries to buf[ceil(N / 16)][32]; NULL = off. */
+int aa_ppo_fused_debug_stamps(int64_t* buf);
 int aa_ppo_fused_step(const aa_ppo_fused_desc* d, float* grads, float* adam_m, float* adam_v,
                       int64_t* adam_step_dev, float lr, float beta1, float beta2, float adam_eps,
                       float grad_clip /* <= 0: none */, float* stats9, float* sumsq_out,
