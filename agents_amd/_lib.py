@@ -59,6 +59,7 @@ class PpoFusedDesc(Structure):
                 ("actions", c_void_p), ("old_loc", c_void_p), ("old_scale", c_void_p),
                 ("returns", c_void_p), ("adv", c_void_p), ("old_vpred", c_void_p),
                 ("step_type", c_void_p), ("weights", c_void_p), ("N", c_int64),
+                ("rows", c_void_p),
                 ("nrm_count", c_void_p), ("nrm_avg", c_void_p), ("nrm_m2", c_void_p),
                 ("nrm_eps", c_float), ("nrm_clip", c_float),
                 ("params", c_void_p), ("total", c_int64), ("head_off", c_int64),
@@ -181,6 +182,9 @@ _SIGNATURES = {
     "aa_ppo_fused_step": (c_int, [POINTER(PpoFusedDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p,
                                   c_void_p, c_int64, c_void_p]),
+    "aa_ppo_fused_epoch": (c_int, [POINTER(PpoFusedDesc), c_void_p, c_int32, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float,
+                                   c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "aa_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float,
                              c_float, c_float, c_void_p, c_void_p]),
     "aa_rmsprop_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,

@@ -551,19 +551,13 @@ class PPOAgent(tf_agent.TFAgent):
             lay.b_off[i] = base + b_off
         return lay
 
-    def _train_fused(self, processed, returns, advantages, step_type, wts, N):
-        import ctypes
+    def _fused_desc(self, obs, actions, old_loc, old_scale, returns, advantages, old_vpred,
+                    step_type, wts, N):
+        """aa_ppo_fused_desc over the given sample arrays (rows = the minibatch, or all frames when
+        the minibatch is addressed through a row index) + the cached workspace of size N."""
         lib = _lib.load()
         dev = self._device
         D = self._D
-        info = processed.policy_info
-        f2 = lambda t: t.reshape(N, D).to(torch.float32).contiguous()
-        old_loc, old_scale = f2(info["dist_params"]["loc"]), f2(info["dist_params"]["scale"])
-        actions = f2(processed.action)
-        old_vpred = info["value_prediction"].reshape(N).contiguous()
-        obs = self._flat_obs(processed.observation)
-        if obs.stride(-1) != 1:
-            obs = obs.contiguous()
         w = self._w(N)
         fw = w.get("fused")
         total = self.flat_params.numel()
@@ -597,6 +591,32 @@ class PPOAgent(tf_agent.TFAgent):
         d.c_v, d.c_e = self._value_pred_loss_coef, self._entropy_regularization
         d.denom, d.logp_clip, d.adv_eps = float(N * self.num_replicas), \
             self._log_prob_clipping, 1e-8
+        return d, fw
+
+    def _fused_loss_info(self, fw):
+        """LossInfo over the stats vector of the last fused step: VIEWS of a work buffer that the
+        next train step overwrites (consume or clone them before; Learner.run returns copies)."""
+        s = fw["stats"]
+        loss_info = tf_agent.LossInfo(s[6], PPOLossInfo(
+            policy_gradient_loss=s[0], value_estimation_loss=s[1], l2_regularization_loss=s[8],
+            entropy_regularization_loss=s[2], kl_penalty_loss=s[5], clip_fraction=s[3]))
+        self._clip_fraction = loss_info.extra.clip_fraction
+        self._grad_norm = self._norm_sumsq
+        return loss_info
+
+    def _train_fused(self, processed, returns, advantages, step_type, wts, N):
+        import ctypes
+        lib = _lib.load()
+        D = self._D
+        info = processed.policy_info
+        f2 = lambda t: t.reshape(N, D).to(torch.float32).contiguous()
+        obs = self._flat_obs(processed.observation)
+        if obs.stride(-1) != 1:
+            obs = obs.contiguous()
+        d, fw = self._fused_desc(
+            obs, f2(processed.action), f2(info["dist_params"]["loc"]),
+            f2(info["dist_params"]["scale"]), returns, advantages,
+            info["value_prediction"].reshape(N).contiguous(), step_type, wts, N)
         opt = self._optimizer
         slot = opt._slot(self.flat_params, ("m", "v"))
         for _ in range(self._num_epochs):
@@ -608,16 +628,53 @@ class PPOAgent(tf_agent.TFAgent):
                 "aa_ppo_fused_step")
             graph.on_replay(opt._bump_iterations)
             graph.on_replay(self._bump_train_step)
-        self._grad_norm = self._norm_sumsq
-        s = fw["stats"]
-        loss_info = tf_agent.LossInfo(s[6], PPOLossInfo(
-            policy_gradient_loss=s[0], value_estimation_loss=s[1], l2_regularization_loss=s[8],
-            entropy_regularization_loss=s[2], kl_penalty_loss=s[5], clip_fraction=s[3]))
-        self._clip_fraction = loss_info.extra.clip_fraction
+        loss_info = self._fused_loss_info(fw)
         if self.update_normalizers_in_train:      # ppo_agent.py:991-993
             self.update_observation_normalizer(processed.observation)
             self.update_reward_normalizer(processed.reward)
         return loss_info
+
+    # ---- a whole epoch's minibatch steps from one host call ------------------------------------------
+    def fused_minibatches_ok(self, frames):
+        """PPOLearner may hand this agent (frames, permutation) instead of one gathered minibatch
+        per call: the fused step reads its rows through the permutation, so an epoch is ONE host
+        call issuing three launches per minibatch (no gather launch, no per-step Python)."""
+        return (self._fused_step_ok() and self._num_epochs == 1 and
+                not self._compute_value_and_advantage_in_train and
+                not self.update_normalizers_in_train and self._initialized and
+                frames.observation.dtype == torch.float32 and frames.observation.dim() == 2 and
+                frames.step_type.dtype == torch.int32)
+
+    def train_minibatches(self, frames, perm, minibatch_size, n_steps):
+        """`n_steps` train steps, step s on rows perm[s * mb : (s + 1) * mb] of the flattened
+        frames ([F, ...] leaves of a preprocessed trajectory) -- exactly what `train` does when it
+        is called once per gathered minibatch [mb, 1, ...] (tf_agents/train/ppo_learner.py:220-248
+        + ppo_agent.py:834-1076), bit for bit.  Returns the LossInfo of the last step."""
+        import ctypes
+        lib = _lib.load()
+        N, D = int(minibatch_size), self._D
+        if perm.dtype != torch.int64 or perm.numel() < N * n_steps or not perm.is_contiguous():
+            raise ValueError("perm must be a contiguous int64 vector of n_steps * minibatch rows")
+        info = frames.policy_info
+        F = frames.discount.shape[0]
+        c = lambda t, *shape: t.reshape((F,) + shape).contiguous()
+        with torch.cuda.device(self._device):
+            d, fw = self._fused_desc(
+                c(frames.observation, frames.observation.shape[1]), c(frames.action, D),
+                c(info["dist_params"]["loc"], D), c(info["dist_params"]["scale"], D),
+                c(info["return"]), c(info["advantage"]), c(info["value_prediction"]),
+                c(frames.step_type), None, N)
+            opt = self._optimizer
+            slot = opt._slot(self.flat_params, ("m", "v"))
+            _lib.check(lib.aa_ppo_fused_epoch(
+                ctypes.byref(d), perm.data_ptr(), int(n_steps), self.flat_grads.data_ptr(),
+                slot["m"].data_ptr(), slot["v"].data_ptr(), slot["step"].data_ptr(),
+                opt.learning_rate, opt.beta_1, opt.beta_2, opt.epsilon, self._gradient_clipping,
+                fw["stats"].data_ptr(), self._norm_sumsq.data_ptr(), fw["ws"].data_ptr(),
+                fw["ws"].numel(), self._st()), "aa_ppo_fused_epoch")
+        opt.iterations += int(n_steps)
+        self._train_step_counter.assign_add(int(n_steps))
+        return self._fused_loss_info(fw)
 
     def kl_cutoff_loss(self, kl_divergence, debug_summaries=False):
         """Host-side helper on an explicit KL tensor (API parity, ppo_agent.py:1514-1560)."""

@@ -18,18 +18,30 @@
 // against ~28 launches of the layer-by-layer path (mask, log-prob, moments, normaliser, 2 x MLP
 // forward, head forward, loss, head backward, column sums, 2 x MLP backward + slab reduces,
 // segment sum of squares, clip, counter, Adam, pack): at 4,096 samples x (64, 64) the step is pure
-// launch latency (0.21 ms for 0.27 GFLOP).
+// launch latency (0.21 ms for 0.27 GFLOP).  The minibatch rows are read THROUGH the shuffle's
+// row index (`rows`), so no gather launch is needed either (aa_ppo_fused_epoch runs all the
+// minibatches of an epoch from one host call).
 //
 // The 64-wide layers run on the fp32 matrix cores: v_mfma_f32_16x16x4_f32 is bit-for-bit an fmaf
 // chain in k order (MI355X_MICROARCH.md), so nothing changes numerically against the VALU kernels
 // of mlp_small.hip except the summation order of the weight gradients.  Every layer is padded to
 // 64 x 64 in LDS (row pitch 68 floats: the transposed operand reads of the backward pass are then
-// bank-conflict free); k-steps and column tiles beyond the layer's true width are skipped.
+// bank-conflict free).
 //   forward   H_out[16 x 64] = act(H_in[16 x 64] W[64 x 64] + b)     wave w: columns 16w .. 16w+15
 //   dW        H_in^T[64 x 16] G[16 x 64]                              wave w: rows 16w .. 16w+15
 //   dX        G[16 x 64] W^T[64 x 64] * act'(H_in)                    wave w: columns 16w .. 16w+15
 // Fragment maps of the 16x16x4 form: A lane l = A[l & 15][l >> 4], B lane l = B[l >> 4][l & 15],
 // D lane l, register r = D[4 (l >> 4) + r][l & 15].
+//
+// What a 16-sample workgroup is bound by is LATENCY: 12 dependent layer steps with one wave per
+// SIMD and nothing to hide a load, an LDS round trip or a dependent MFMA behind.  Measured with
+// in-kernel wall_clock64 stamps (tools/ppo_fused_probe.py), per launch: first version 70 us
+// (3-6 us per layer step: rolled k loops, __syncthreads draining the slab stores and the weight
+// loads, serial per-sample loops over the action dims, a 440-byte scratch copy of the argument
+// struct) -> 41 us (LDS-only barriers, weights prefetched a step ahead in registers, fully
+// unrolled k loops with two accumulators, (sample, dim)-parallel loss phases) -> this version:
+// the ACTOR and the VALUE network are walked at the same time by two groups of four waves (they
+// are independent between the shared input and the loss), which halves the dependent chain.
 //
 // Built with -ffp-contract=off: the loss arithmetic is op for op the one of ppo.hip.
 #include "common.h"
@@ -38,8 +50,10 @@
 #define PF_TS 16
 #define PF_W 64
 #define PF_PITCH 68
-#define PF_MAXL 3        /* layers per network on this path (LDS: 9 activation tiles + weights < 64 KB) */
+#define PF_MAXL 3        /* layers per network on this path */
+#define PF_THREADS 512   /* 2 groups (actor, value) x 4 waves */
 #define PF_HALF_LOG_2PI 0.91893853320467274178f
+#define PF_MD AA_PPO_FUSED_MAX_D
 
 typedef float pf_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -54,6 +68,22 @@ static long long* g_pf_stamps = nullptr;
 #define PF_STAMP(i)                                                              \
   if (P.stamps != nullptr && threadIdx.x == 0)                                   \
     P.stamps[(size_t)blockIdx.x * 32 + (i)] = wall_clock64();
+
+// Dynamic LDS image of a workgroup (one per CU: 89 KB).
+struct PfLds {
+  float Ws[2][PF_W * PF_PITCH];              // the current layer's weights of each group
+  float bs[2][PF_W];
+  float X[PF_TS][PF_PITCH];                  // normalised observations (input of both networks)
+  float H[2][PF_MAXL][PF_TS][PF_PITCH];      // layer outputs: [0] actor, [1] value
+  float G[2][2][PF_TS][PF_PITCH];            // backward ping-pong per group
+  aa_mlp_layout nets[2];
+  float red[16];
+  float bc[2];
+  float w[PF_TS], advn[PF_TS], oldlp[PF_TS], dlp[PF_TS], dent[PF_TS];
+  float act[PF_TS][PF_MD], t0[PF_TS][PF_MD], t1[PF_TS][PF_MD], t2[PF_TS][PF_MD];
+  float dbias[PF_TS][PF_MD];
+  float scale[PF_MD], logs[PF_MD], dsp[PF_MD];
+};
 
 __device__ static inline float pf_softplus(float x) {
   return x > 0.f ? x + log1pf(expf(-x)) : log1pf(expf(x));
@@ -71,57 +101,54 @@ __device__ static inline float pf_actgrad(float y, int act) {
 
 // Workgroup barrier that only waits for this wave's LDS traffic: __syncthreads() carries a release
 // fence that also drains the VM counter, i.e. the gradient-slab stores of the backward steps
-// (never read by this launch) and the weight prefetch of the next step -- measured 3-6 us per
-// layer step with one wave per SIMD and nothing to hide the latency behind.
+// (never read by this launch) and the weight prefetch of the next step.
 __device__ static inline void pf_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
 
-// Weights of one layer travel HBM/L2 -> registers -> LDS in two halves, so that the loads of the
-// NEXT layer step are in flight while the current one computes (a workgroup runs 12 dependent
-// layer steps; fetching each layer's 16 KB only when it is needed cost ~5 us of load latency per
-// step: 70 us per launch, measured).  A 64 x 64 matrix is 1024 float4 = 4 per thread; matrices
-// whose rows are not float4-sized (the 6- and 1-wide heads: <= 1024 elements) go element-wise.
-// Only real elements are written to LDS: the tile is zero-filled ONCE at kernel start, afterwards
-// it only ever holds finite values, and every read beyond a layer's true shape is multiplied by an
-// exact zero or discarded by a guard.
+// Weights of one layer travel HBM/L2 -> registers -> LDS in two halves, so that the loads of a
+// group's NEXT layer step are in flight while the current one computes.  A 64 x 64 matrix is 1024
+// float4 = 4 per thread of a 256-thread group; matrices whose rows are not float4-sized (the 6-
+// and 1-wide heads: <= 1024 elements) go element-wise.  Only real elements are written to LDS:
+// the tile is zero-filled ONCE at kernel start, afterwards it only ever holds finite values, and
+// every read beyond a layer's true shape is multiplied by an exact zero or discarded by a guard.
 struct PfW {
   float4 v[4];
   float bias;
 };
 
 __device__ static inline void pf_prefetch(const float* __restrict__ params,
-                                          const aa_mlp_layout& net, int l, PfW& w) {
+                                          const aa_mlp_layout& net, int l, int gt, PfW& w) {
   const int n_in = net.dims[l], n_out = net.dims[l + 1];
   const float* W = params + net.k_off[l];
   if ((n_out & 3) == 0 && (net.k_off[l] & 3) == 0) {
     const int total4 = n_in * (n_out >> 2);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = threadIdx.x + 256 * u;
+      const int i = gt + 256 * u;
       w.v[u] = i < total4 ? reinterpret_cast<const float4*>(W)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   } else {
     const int total = n_in * n_out;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = threadIdx.x + 256 * u;
+      const int i = gt + 256 * u;
       w.v[u].x = i < total ? W[i] : 0.f;
     }
   }
-  w.bias = (int)threadIdx.x < n_out ? params[net.b_off[l] + threadIdx.x] : 0.f;
+  w.bias = gt < n_out ? params[net.b_off[l] + gt] : 0.f;
 }
 
-__device__ static inline void pf_commit(const aa_mlp_layout& net, int l, const PfW& w, float* Ws,
-                                        float* bs) {
+__device__ static inline void pf_commit(const aa_mlp_layout& net, int l, int gt, const PfW& w,
+                                        float* Ws, float* bs) {
   const int n_in = net.dims[l], n_out = net.dims[l + 1];
   if ((n_out & 3) == 0 && (net.k_off[l] & 3) == 0) {
     const int q4 = n_out >> 2, total4 = n_in * q4;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = threadIdx.x + 256 * u;
+      const int i = gt + 256 * u;
       if (i < total4) {
         const int k = i / q4, jq = i - k * q4;
         *reinterpret_cast<float4*>(Ws + k * PF_PITCH + 4 * jq) = w.v[u];
@@ -131,55 +158,29 @@ __device__ static inline void pf_commit(const aa_mlp_layout& net, int l, const P
     const int total = n_in * n_out;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = threadIdx.x + 256 * u;
+      const int i = gt + 256 * u;
       if (i < total) {
         const int k = i / n_out, j = i - k * n_out;
         Ws[k * PF_PITCH + j] = w.v[u].x;
       }
     }
   }
-  if (threadIdx.x < PF_W) bs[threadIdx.x] = w.bias;
+  if (gt < PF_W) bs[gt] = w.bias;
 }
 
-// The 2 (La + Lv) layer steps of a launch in execution order: actor forward, value forward, actor
-// backward (top layer first), value backward.
-// (The two layouts are copied to LDS once -- nets[0] = actor, nets[1] = value -- and addressed by
-// index: a POINTER to a member of the kernel-argument struct made the compiler spill the whole
-// struct to scratch, 440 bytes per lane.)
-__device__ static inline void pf_step(int La, int Lv, int i, int& which, int& l) {
-  if (i < La) { which = 0; l = i; }
-  else if (i < La + Lv) { which = 1; l = i - La; }
-  else if (i < 2 * La + Lv) { which = 0; l = 2 * La + Lv - 1 - i; }
-  else { which = 1; l = 2 * (La + Lv) - 1 - i; }
-}
-
-// Start of a layer step: the previous step's readers of Ws are done -> the prefetched weights go
-// to LDS, the next step's loads are issued, and the tile is ready after the second barrier.
-__device__ static inline void pf_begin_step(const float* __restrict__ params,
-                                            const aa_mlp_layout* nets /* LDS */, int i, PfW& w,
-                                            float* Ws, float* bs) {
-  const int La = nets[0].n_layers, Lv = nets[1].n_layers;
-  int which, l;
-  pf_step(La, Lv, i, which, l);
-  pf_barrier();
-  pf_commit(nets[which], l, w, Ws, bs);
-  if (i + 1 < 2 * (La + Lv)) {
-    pf_step(La, Lv, i + 1, which, l);
-    pf_prefetch(params, nets[which], l, w);
-  }
-  pf_barrier();
-}
+// The layer a group works on in step i of its 2 L steps (forward 0 .. L-1, backward L-1 .. 0), or
+// -1 when the group has no layer left in this phase (the other network is deeper).
+__device__ static inline int pf_fwd_layer(int L, int i) { return i < L ? i : -1; }
+__device__ static inline int pf_bwd_layer(int L, int i) { return i < L ? L - 1 - i : -1; }
 
 // H_out = act(H_in W + b); every one of the 64 columns of H_out is written (zeros beyond n_out).
-// (pf_begin_step has put the layer's weights into Ws / bs and synchronised.)  The k loop always
-// runs the padded 16 steps with every LDS read issued up front and two accumulators: with one wave
-// per SIMD a rolled loop exposes an LDS round trip plus the 40-cycle dependent-MFMA latency per
-// step (measured 3.6 us per layer); rows / columns beyond the layer's shape multiply exact zeros.
-__device__ static inline void pf_forward(const aa_mlp_layout& net, int l,
+// The k loop always runs the padded 16 steps with every LDS read issued up front and two
+// accumulators; rows / columns beyond the layer's shape multiply exact zeros.
+__device__ static inline void pf_forward(const aa_mlp_layout& net, int l, int gt,
                                          const float (*Hin)[PF_PITCH], float (*Hout)[PF_PITCH],
                                          const float* Ws, const float* bs) {
   const int n_out = net.dims[l + 1];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+  const int wave = gt >> 6, lane = gt & 63, lr = lane & 15, lg = lane >> 4;
   const int col = 16 * wave + lr;
   pf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   if (16 * wave < n_out) {          // wave-uniform
@@ -205,12 +206,12 @@ __device__ static inline void pf_forward(const aa_mlp_layout& net, int l,
 // One layer of the backward pass.  G = d loss / d (pre-activation of layer l), all 64 columns
 // defined.  Writes dW / db of the layer into this workgroup's slab and, for l > 0,
 // Gnext = (G W^T) * act'_{l-1}(H_in) = d loss / d (pre-activation of layer l - 1).
-__device__ static inline void pf_backward(const aa_mlp_layout& net, int l,
+__device__ static inline void pf_backward(const aa_mlp_layout& net, int l, int gt,
                                           const float (*Hin)[PF_PITCH], const float (*G)[PF_PITCH],
                                           float (*Gnext)[PF_PITCH], const float* Ws,
                                           float* __restrict__ slab) {
   const int n_in = net.dims[l], n_out = net.dims[l + 1];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+  const int wave = gt >> 6, lane = gt & 63, lr = lane & 15, lg = lane >> 4;
   // ---- dW[k][j] = sum_s H_in[s][k] G[s][j]: wave -> rows k = 16 wave ..; column tiles ct ----
   if (16 * wave < n_in) {
     float a[4];
@@ -237,11 +238,11 @@ __device__ static inline void pf_backward(const aa_mlp_layout& net, int l,
     }
   }
   // ---- db[j] = sum_s G[s][j] (sample order) ------------------------------------------------------
-  if ((int)threadIdx.x < n_out) {
+  if (gt < n_out) {
     float sum = 0.f;
 #pragma unroll
-    for (int s = 0; s < PF_TS; ++s) sum += G[s][threadIdx.x];
-    slab[net.b_off[l] + threadIdx.x] = sum;
+    for (int s = 0; s < PF_TS; ++s) sum += G[s][gt];
+    slab[net.b_off[l] + gt] = sum;
   }
   // ---- Gnext[s][k] = (sum_j G[s][j] W[k][j]) act'(H_in[s][k]) -------------------------------------
   if (l > 0) {
@@ -269,77 +270,65 @@ __device__ static inline void pf_backward(const aa_mlp_layout& net, int l,
   }
 }
 
-__global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
+__global__ void __launch_bounds__(PF_THREADS) aa_ppo_fused_step_kernel(PfArgs P) {
   const aa_ppo_fused_desc& d = P.d;
-  __shared__ __attribute__((aligned(16))) float Ws[PF_W * PF_PITCH];
-  __shared__ float bs[PF_W];
-  __shared__ __attribute__((aligned(16))) float X[PF_TS][PF_PITCH];
-  __shared__ __attribute__((aligned(16))) float HA[PF_MAXL][PF_TS][PF_PITCH];
-  __shared__ __attribute__((aligned(16))) float HV[PF_MAXL][PF_TS][PF_PITCH];
-  __shared__ __attribute__((aligned(16))) float G[2][PF_TS][PF_PITCH];
-  __shared__ float red[16];
-  __shared__ float bc[2];
-  __shared__ float s_w[PF_TS], s_advn[PF_TS], s_oldlp[PF_TS], s_dv[PF_TS], s_dlp[PF_TS],
-      s_dent[PF_TS];
-  // per (sample, action dim): the minibatch rows' actions / old distribution, then loss terms
-  __shared__ float s_act[PF_TS][AA_PPO_FUSED_MAX_D], s_t0[PF_TS][AA_PPO_FUSED_MAX_D],
-      s_t1[PF_TS][AA_PPO_FUSED_MAX_D], s_t2[PF_TS][AA_PPO_FUSED_MAX_D];
-  __shared__ float s_dbias[PF_TS][AA_PPO_FUSED_MAX_D];
-  __shared__ float s_scale[AA_PPO_FUSED_MAX_D], s_logs[AA_PPO_FUSED_MAX_D],
-      s_dsp[AA_PPO_FUSED_MAX_D];
-  __shared__ aa_mlp_layout nets[2];
+  extern __shared__ __attribute__((aligned(16))) char pf_lds_raw[];
+  PfLds& S = *reinterpret_cast<PfLds*>(pf_lds_raw);
   const int tid = threadIdx.x;
+  const int grp = tid >> 8, gt = tid & 255;        // group 0: actor, group 1: value
   const int64_t N = d.N, b0 = (int64_t)blockIdx.x * PF_TS;
   const int D = d.D;
   float* slab = P.slabs + (int64_t)blockIdx.x * d.total;
+  // source row of minibatch sample b (the shuffle's permutation slice), or b itself
+  auto row_of = [&](int64_t b) -> int64_t { return d.rows != nullptr ? d.rows[b] : b; };
   PfW wq;
   PF_STAMP(0)
-  if (tid == 0) nets[0] = d.actor;
-  if (tid == 64) nets[1] = d.value;
-  pf_prefetch(d.params, d.actor, 0, wq);       // in flight during the prologue below
-  for (int i = tid; i < PF_W * PF_PITCH; i += blockDim.x) Ws[i] = 0.f;
+  if (tid == 0) S.nets[0] = d.actor;
+  if (tid == 256) S.nets[1] = d.value;
+  // each group's first layer is in flight during the prologue below
+  if (grp == 0) pf_prefetch(d.params, d.actor, 0, gt, wq);
+  else pf_prefetch(d.params, d.value, 0, gt, wq);
+  for (int i = tid; i < 2 * PF_W * PF_PITCH; i += PF_THREADS) (&S.Ws[0][0])[i] = 0.f;
+  for (int i = tid; i < 4 * PF_TS * PF_PITCH; i += PF_THREADS) (&S.G[0][0][0][0])[i] = 0.f;
 
   // ---- advantage moments over the WHOLE minibatch (two-pass, fixed order; every workgroup) -----
-  // N <= 4096 with 16-byte rows: the 16 values of a thread stay in registers for both passes
+  // N <= 8192: the 16 values of a thread stay in registers for both passes
   {
-    const bool vec = (N & 3) == 0 && N <= 4096 && (((uintptr_t)d.adv) & 15) == 0;
-    float4 av[4];
+    const bool keep = N <= 16 * PF_THREADS;
+    float av[16];
     float s = 0.f;
-    if (vec) {
-      const int64_t n4 = N >> 2;
+    if (keep) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t i = tid + 256 * u;
-        av[u] = i < n4 ? reinterpret_cast<const float4*>(d.adv)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int u = 0; u < 16; ++u) {
+        const int64_t i = tid + (int64_t)PF_THREADS * u;
+        av[u] = i < N ? d.adv[row_of(i)] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) s += ((av[u].x + av[u].y) + av[u].z) + av[u].w;
+      for (int u = 0; u < 16; ++u) s += av[u];
     } else {
-      for (int64_t i = tid; i < N; i += blockDim.x) s += d.adv[i];
+      for (int64_t i = tid; i < N; i += PF_THREADS) s += d.adv[row_of(i)];
     }
-    float t = aa_block_sum(s, red);
-    if (tid == 0) bc[0] = t / (float)N;
+    float t = aa_block_sum(s, S.red);
+    if (tid == 0) S.bc[0] = t / (float)N;
     __syncthreads();
-    const float mean = bc[0];
+    const float mean = S.bc[0];
     float q = 0.f;
-    if (vec) {
-      const int64_t n4 = N >> 2;
+    if (keep) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (tid + 256 * u < n4) {
-          const float d0 = av[u].x - mean, d1 = av[u].y - mean, d2 = av[u].z - mean,
-                      d3 = av[u].w - mean;
-          q += ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
+      for (int u = 0; u < 16; ++u) {
+        if (tid + (int64_t)PF_THREADS * u < N) {
+          const float dl = av[u] - mean;
+          q += dl * dl;
         }
       }
     } else {
-      for (int64_t i = tid; i < N; i += blockDim.x) {
-        const float dl = d.adv[i] - mean;
+      for (int64_t i = tid; i < N; i += PF_THREADS) {
+        const float dl = d.adv[row_of(i)] - mean;
         q += dl * dl;
       }
     }
-    t = aa_block_sum(q, red);
-    if (tid == 0) bc[1] = t / (float)N;
+    t = aa_block_sum(q, S.red);
+    if (tid == 0) S.bc[1] = t / (float)N;
     __syncthreads();
   }
   PF_STAMP(1)
@@ -350,45 +339,47 @@ __global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
     const int64_t b = b0 + ss;
     float act = 0.f, term = 0.f;
     if (b < N) {
-      act = d.actions[b * D + e];
-      const float sc = d.old_scale[b * D + e];
-      const float diff = act / sc - d.old_loc[b * D + e] / sc;
+      const int64_t r = row_of(b);
+      act = d.actions[r * D + e];
+      const float sc = d.old_scale[r * D + e];
+      const float diff = act / sc - d.old_loc[r * D + e] / sc;
       term = -0.5f * (diff * diff) - (PF_HALF_LOG_2PI + logf(sc));
     }
-    s_act[ss][e] = act;
-    s_t0[ss][e] = term;
+    S.act[ss][e] = act;
+    S.t0[ss][e] = term;
   }
-  if (tid >= 128 && tid < 128 + PF_TS) {
-    const int ss = tid - 128;
+  if (tid >= 256 && tid < 256 + PF_TS) {
+    const int ss = tid - 256;
     const int64_t b = b0 + ss;
     float w = 0.f, advn = 0.f;
     if (b < N) {
-      const float inv = 1.0f / sqrtf(bc[1] + d.adv_eps);
-      advn = d.adv[b] * inv + (-bc[0] * inv);     // tf.nn.batch_normalization(adv, mean, var)
-      const bool valid =
-          (d.step_type[b] != 2) && !(d.returns[b] == 0.f && d.adv[b] == 0.f);
+      const int64_t r = row_of(b);
+      const float inv = 1.0f / sqrtf(S.bc[1] + d.adv_eps);
+      const float a = d.adv[r];
+      advn = a * inv + (-S.bc[0] * inv);          // tf.nn.batch_normalization(adv, mean, var)
+      const bool valid = (d.step_type[r] != 2) && !(d.returns[r] == 0.f && a == 0.f);
       const float m = valid ? 1.0f : 0.0f;
-      w = d.weights != nullptr ? d.weights[b] * m : m;
+      w = d.weights != nullptr ? d.weights[r] * m : m;
     }
-    s_w[ss] = w;
-    s_advn[ss] = advn;
+    S.w[ss] = w;
+    S.advn[ss] = advn;
   }
-  if (tid >= 192 && tid < 192 + D) {
-    const int e = tid - 192;
+  if (tid >= 320 && tid < 320 + D) {
+    const int e = tid - 320;
     const float bsd = d.params[d.head_off + e];
     const float sc = pf_softplus(bsd);
-    s_scale[e] = sc;
-    s_logs[e] = logf(sc);
-    s_dsp[e] = 1.0f / (1.0f + expf(-bsd));       // d softplus / d bias = sigmoid
+    S.scale[e] = sc;
+    S.logs[e] = logf(sc);
+    S.dsp[e] = 1.0f / (1.0f + expf(-bsd));       // d softplus / d bias = sigmoid
   }
 #pragma unroll
-  for (int u = 0; u < PF_TS * PF_W / 256; ++u) {
-    const int i = tid + 256 * u;
+  for (int u = 0; u < PF_TS * PF_W / PF_THREADS; ++u) {
+    const int i = tid + PF_THREADS * u;
     const int ss = i >> 6, k = i & 63;
     const int64_t bb = b0 + ss;
     float v = 0.f;
     if (bb < N && k < d.obs_dim) {
-      v = d.obs[bb * d.ld_obs + k];
+      v = d.obs[row_of(bb) * d.ld_obs + k];
       if (d.nrm_avg != nullptr) {
         const float var = d.nrm_m2[k] / d.nrm_count[k];
         const float inv = 1.0f / sqrtf(var + d.nrm_eps);
@@ -396,45 +387,54 @@ __global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
         if (d.nrm_clip > 0.f) v = fminf(fmaxf(v, -d.nrm_clip), d.nrm_clip);
       }
     }
-    X[ss][k] = v;
+    S.X[ss][k] = v;
   }
   pf_barrier();
   if (tid < PF_TS) {          // old log-prob: the per-dim terms added in dim order
     float olp = 0.f;
-    for (int e = 0; e < D; ++e) olp += s_t0[tid][e];
-    s_oldlp[tid] = olp;
+    for (int e = 0; e < D; ++e) olp += S.t0[tid][e];
+    S.oldlp[tid] = olp;
   }
   PF_STAMP(2)
-  // ---- forward: actor, value ------------------------------------------------------------------------
-  const int La = d.actor.n_layers, Lv = d.value.n_layers;
-  int step = 0;
-  for (int l = 0; l < La; ++l) {
-    pf_begin_step(d.params, nets, step++, wq, Ws, bs);
-    pf_forward(nets[0], l, l == 0 ? X : HA[l - 1], HA[l], Ws, bs);
-    PF_STAMP(3 + l)
-  }
-  for (int l = 0; l < Lv; ++l) {
-    pf_begin_step(d.params, nets, step++, wq, Ws, bs);
-    pf_forward(nets[1], l, l == 0 ? X : HV[l - 1], HV[l], Ws, bs);
-    PF_STAMP(6 + l)
+  // ---- forward: the actor (group 0) and the value network (group 1) side by side --------------------
+  const aa_mlp_layout& net = S.nets[grp];
+  const int Lg = net.n_layers;
+  const int Lmax = S.nets[0].n_layers > S.nets[1].n_layers ? S.nets[0].n_layers
+                                                           : S.nets[1].n_layers;
+  float* Wg = S.Ws[grp];
+  float* bg = S.bs[grp];
+  // begin of a layer step of this group: the previous step's readers of Ws are done -> the
+  // prefetched weights go to LDS, the next step's loads are issued (`nl` = its layer or -1)
+  auto begin_step = [&](int l, int nl) {
+    pf_barrier();
+    if (l >= 0) pf_commit(net, l, gt, wq, Wg, bg);
+    if (nl >= 0) pf_prefetch(d.params, net, nl, gt, wq);
+    pf_barrier();
+  };
+  for (int i = 0; i < Lmax; ++i) {
+    const int l = pf_fwd_layer(Lg, i);
+    const int nl = i + 1 < Lmax ? pf_fwd_layer(Lg, i + 1) : pf_bwd_layer(Lg, 0);
+    begin_step(l, nl);
+    if (l >= 0) pf_forward(net, l, gt, l == 0 ? S.X : S.H[grp][l - 1], S.H[grp][l], Wg, bg);
+    PF_STAMP(3 + i)
   }
   pf_barrier();
   PF_STAMP(9)
   // ---- loss (the arithmetic of ppo.hip: aa_ppo_loss_kernel), three short phases --------------------
+  const int La = S.nets[0].n_layers, Lv = S.nets[1].n_layers;
   // A: thread per (sample, dim): log-prob / entropy terms of the current policy
-  for (int i = tid; i < 2 * PF_TS * PF_PITCH; i += blockDim.x) (&G[0][0][0])[i] = 0.f;
   float r_th = 0.f, r_diff = 0.f;      // kept for phase C by the (sample, dim) thread
   if (tid < PF_TS * D) {
     const int ss = tid / D, e = tid - ss * D;
-    const float zz = HA[La - 1][ss][e];
+    const float zz = S.H[0][La - 1][ss][e];
     r_th = d.act_mag != nullptr ? tanhf(zz) : zz;
     const float loc = d.act_mag != nullptr ? d.act_mean[e] + d.act_mag[e] * r_th : zz;
-    const float sc = s_scale[e];
-    const float xs = s_act[ss][e] / sc, ls = loc / sc;
+    const float sc = S.scale[e];
+    const float xs = S.act[ss][e] / sc, ls = loc / sc;
     const float df = xs - ls;
-    s_t1[ss][e] = -0.5f * (df * df) - (PF_HALF_LOG_2PI + s_logs[e]);
-    s_t2[ss][e] = 0.5f + PF_HALF_LOG_2PI + s_logs[e];
-    r_diff = s_act[ss][e] - loc;
+    S.t1[ss][e] = -0.5f * (df * df) - (PF_HALF_LOG_2PI + S.logs[e]);
+    S.t2[ss][e] = 0.5f + PF_HALF_LOG_2PI + S.logs[e];
+    r_diff = S.act[ss][e] - loc;
   }
   pf_barrier();
   // B: thread per sample: surrogate, value loss, entropy; d loss / d log-prob, d loss / d entropy
@@ -443,11 +443,12 @@ __global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
     const int64_t b = b0 + tid;
     float dv = 0.f, dlp = 0.f, dent = 0.f;
     if (b < N) {
-      const float w = s_w[tid];
+      const int64_t r = row_of(b);
+      const float w = S.w[tid];
       float lp = 0.f, ent = 0.f;
       for (int e = 0; e < D; ++e) {
-        lp += s_t1[tid][e];
-        ent += s_t2[tid][e];
+        lp += S.t1[tid][e];
+        ent += S.t2[tid][e];
       }
       float lp_c = lp;
       bool lp_live = true;
@@ -455,8 +456,8 @@ __global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
         lp_c = fminf(fmaxf(lp, -d.logp_clip), d.logp_clip);
         lp_live = (lp >= -d.logp_clip) && (lp <= d.logp_clip);
       }
-      const float a = s_advn[tid];
-      const float ratio = expf(lp_c - s_oldlp[tid]);
+      const float a = S.advn[tid];
+      const float ratio = expf(lp_c - S.oldlp[tid]);
       const float ratio_c = fminf(fmaxf(ratio, 1.0f - d.clip_eps), 1.0f + d.clip_eps);
       const float obj = ratio * a, obj_c = ratio_c * a;
       float pg;
@@ -471,11 +472,11 @@ __global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
       }
       sum_pg = (w == 0.f) ? 0.f : pg * w;
       if (grad_through_ratio && lp_live) dlp = -(a * ratio) * w / d.denom;
-      const float R = d.returns[b], V = HV[Lv - 1][tid][0];
+      const float R = d.returns[r], V = S.H[1][Lv - 1][tid][0];
       float verr = (R - V) * (R - V);
       float dverr_dV = -2.0f * (R - V);
       if (d.value_clip > 0.f && d.old_vpred != nullptr) {
-        const float ov = d.old_vpred[b];
+        const float ov = d.old_vpred[r];
         const float dlt = V - ov;
         const float dc = fminf(fmaxf(dlt, -d.value_clip), d.value_clip);
         const float Vc = ov + dc;
@@ -492,9 +493,9 @@ __global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
       sum_entw = ent * w;
       dent = (d.c_e > 0.f) ? (-d.c_e * w / d.denom) : 0.f;
     }
-    s_dv[tid] = dv;
-    s_dlp[tid] = dlp;
-    s_dent[tid] = dent;
+    S.G[1][0][tid][0] = dv;        // d loss / d value: column 0 of the value group's gradient tile
+    S.dlp[tid] = dlp;
+    S.dent[tid] = dent;
   }
   // the tile's five loss sums: 16 lanes of wave 0, xor tree (fixed order)
   if (tid < 64) {
@@ -517,45 +518,39 @@ __global__ void __launch_bounds__(256) aa_ppo_fused_step_kernel(PfArgs P) {
     const int ss = tid / D, e = tid - ss * D;
     float gz = 0.f, gb = 0.f;
     if (b0 + ss < N) {
-      const float sc = s_scale[e];
-      const float dlp = s_dlp[ss], dent = s_dent[ss];
+      const float sc = S.scale[e];
+      const float dlp = S.dlp[ss], dent = S.dent[ss];
       const float dlp_dloc = r_diff / (sc * sc);
       const float dlp_dsc = (r_diff * r_diff) / (sc * sc * sc) - 1.0f / sc;
       float dloc_dz = 1.0f;
       if (d.act_mag != nullptr) dloc_dz = d.act_mag[e] * (1.0f - r_th * r_th);
       gz = dlp * dlp_dloc * dloc_dz;
-      gb = (dlp * dlp_dsc + dent * (1.0f / sc)) * s_dsp[e];
+      gb = (dlp * dlp_dsc + dent * (1.0f / sc)) * S.dsp[e];
     }
-    G[0][ss][e] = gz;
-    s_dbias[ss][e] = gb;
+    S.G[0][0][ss][e] = gz;
+    S.dbias[ss][e] = gb;
   }
   pf_barrier();
   // std_bias gradient = column sums of the per-sample terms (sample order)
   if (tid < D) {
     float sum = 0.f;
 #pragma unroll
-    for (int s = 0; s < PF_TS; ++s) sum += s_dbias[s][tid];
+    for (int s = 0; s < PF_TS; ++s) sum += S.dbias[s][tid];
     slab[d.head_off + tid] = sum;
   }
   PF_STAMP(10)
-  // ---- backward: actor (G[0] holds dz of the head), then value ----------------------------------------
+  // ---- backward: both groups, top layer first ------------------------------------------------------------
   int cur = 0;
-  for (int l = La - 1; l >= 0; --l) {
-    pf_begin_step(d.params, nets, step++, wq, Ws, bs);      // (its first barrier also completes G[cur])
-    pf_backward(nets[0], l, l == 0 ? X : HA[l - 1], G[cur], G[cur ^ 1], Ws, slab);
-    cur ^= 1;
-    PF_STAMP(11 + (La - 1 - l))
-  }
-  pf_barrier();
-  for (int i = tid; i < PF_TS * PF_PITCH; i += blockDim.x) {
-    const int s = i / PF_PITCH, k = i - s * PF_PITCH;
-    G[cur][s][k] = k == 0 ? s_dv[s] : 0.f;
-  }
-  for (int l = Lv - 1; l >= 0; --l) {
-    pf_begin_step(d.params, nets, step++, wq, Ws, bs);
-    pf_backward(nets[1], l, l == 0 ? X : HV[l - 1], G[cur], G[cur ^ 1], Ws, slab);
-    cur ^= 1;
-    PF_STAMP(14 + (Lv - 1 - l))
+  for (int i = 0; i < Lmax; ++i) {
+    const int l = pf_bwd_layer(Lg, i);
+    const int nl = i + 1 < Lmax ? pf_bwd_layer(Lg, i + 1) : -1;
+    begin_step(l, nl);             // (its first barrier also completes G[grp][cur])
+    if (l >= 0) {
+      pf_backward(net, l, gt, l == 0 ? S.X : S.H[grp][l - 1], S.G[grp][cur], S.G[grp][cur ^ 1], Wg,
+                  slab);
+      cur ^= 1;
+    }
+    PF_STAMP(11 + i)
   }
   PF_STAMP(17)
 }
@@ -724,12 +719,17 @@ int64_t aa_ppo_fused_workspace_bytes(int64_t N, int64_t total_params) {
   return (n_wg * total_params + n_wg * 8 + (total_params + 15) / 16 + 16) * (int64_t)sizeof(float);
 }
 
-int aa_ppo_fused_step(const aa_ppo_fused_desc* dsc, float* grads, float* adam_m, float* adam_v,
-                      int64_t* adam_step_dev, float lr, float beta1, float beta2, float adam_eps,
-                      float grad_clip, float* stats9, float* sumsq_out, void* workspace,
-                      int64_t workspace_bytes, void* stream) {
-  if (!dsc || !grads || !adam_m || !adam_v || !adam_step_dev || !stats9 || !workspace)
+// n_steps consecutive minibatch steps from ONE host call: step s trains on rows
+// rows_dev[s * N .. (s + 1) * N) of the sample arrays the descriptor points at (d.rows is ignored;
+// rows_dev NULL with n_steps == 1: the N rows of the arrays themselves, or d.rows if set).
+int aa_ppo_fused_epoch(const aa_ppo_fused_desc* dsc, const int64_t* rows_dev, int32_t n_steps,
+                       float* grads, float* adam_m, float* adam_v, int64_t* adam_step_dev, float lr,
+                       float beta1, float beta2, float adam_eps, float grad_clip, float* stats9,
+                       float* sumsq_out, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!dsc || !grads || !adam_m || !adam_v || !adam_step_dev || !stats9 || !workspace ||
+      n_steps < 1)
     return AA_ERR_INVALID;
+  if (rows_dev == nullptr && n_steps != 1) return AA_ERR_INVALID;
   const aa_ppo_fused_desc& d = *dsc;
   if (!d.obs || !d.actions || !d.old_loc || !d.old_scale || !d.returns || !d.adv ||
       !d.step_type || !d.params || d.N <= 0 || d.total <= 0 || !(d.denom > 0.f))
@@ -752,6 +752,14 @@ int aa_ppo_fused_step(const aa_ppo_fused_desc* dsc, float* grads, float* adam_m,
   if (workspace_bytes < aa_ppo_fused_workspace_bytes(d.N, d.total)) return AA_ERR_RANGE;
   const int64_t n_wg = (d.N + PF_TS - 1) / PF_TS;
   if (n_wg > 0x7fffffffLL) return AA_ERR_RANGE;
+  static bool lds_granted = false;       // 89 KB of dynamic LDS: granted once per process
+  if (!lds_granted) {
+    if (hipFuncSetAttribute((const void*)aa_ppo_fused_step_kernel,
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(PfLds)) != hipSuccess)
+      return AA_ERR_LAUNCH;
+    lds_granted = true;
+  }
   PfArgs P;
   P.d = d;
   P.slabs = reinterpret_cast<float*>(workspace);
@@ -759,18 +767,31 @@ int aa_ppo_fused_step(const aa_ppo_fused_desc* dsc, float* grads, float* adam_m,
   P.stamps = g_pf_stamps;
   float* sumsq_part = P.partial + n_wg * 8;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(aa_ppo_fused_step_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, P);
   const unsigned n_red = (unsigned)((d.total + 63) / 64);
-  hipLaunchKernelGGL(aa_ppo_fused_reduce_kernel, dim3(n_red), dim3(256), 0, st,
-                     (const float*)P.slabs, (int)n_wg, d.total, grads, sumsq_part,
-                     (const float*)P.partial, d, stats9, adam_step_dev);
   int64_t blocks = (d.total + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(aa_ppo_fused_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
-                     const_cast<float*>(d.params), grads, adam_m, adam_v, d.total, lr, beta1,
-                     beta2, adam_eps, (const int64_t*)adam_step_dev, (const float*)sumsq_part,
-                     (int)n_red, grad_clip, sumsq_out);
+  for (int s = 0; s < n_steps; ++s) {
+    if (rows_dev != nullptr) P.d.rows = rows_dev + (int64_t)s * d.N;
+    hipLaunchKernelGGL(aa_ppo_fused_step_kernel, dim3((unsigned)n_wg), dim3(PF_THREADS),
+                       sizeof(PfLds), st, P);
+    hipLaunchKernelGGL(aa_ppo_fused_reduce_kernel, dim3(n_red), dim3(256), 0, st,
+                       (const float*)P.slabs, (int)n_wg, d.total, grads, sumsq_part,
+                       (const float*)P.partial, d, stats9, adam_step_dev);
+    hipLaunchKernelGGL(aa_ppo_fused_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                       const_cast<float*>(d.params), grads, adam_m, adam_v, d.total, lr, beta1,
+                       beta2, adam_eps, (const int64_t*)adam_step_dev, (const float*)sumsq_part,
+                       (int)n_red, grad_clip, sumsq_out);
+  }
   return aa_launch_status();
+}
+
+int aa_ppo_fused_step(const aa_ppo_fused_desc* dsc, float* grads, float* adam_m, float* adam_v,
+                      int64_t* adam_step_dev, float lr, float beta1, float beta2, float adam_eps,
+                      float grad_clip, float* stats9, float* sumsq_out, void* workspace,
+                      int64_t workspace_bytes, void* stream) {
+  return aa_ppo_fused_epoch(dsc, nullptr, 1, grads, adam_m, adam_v, adam_step_dev, lr, beta1, beta2,
+                            adam_eps, grad_clip, stats9, sumsq_out, workspace, workspace_bytes,
+                            stream);
 }
 
 }  // extern "C"

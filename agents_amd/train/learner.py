@@ -180,6 +180,12 @@ class Learner:
         loss_info = None
         for _ in range(iterations):
             loss_info = self.single_train_step(iterator)
+        return self.finish_run(loss_info)
+
+    def finish_run(self, loss_info):
+        """The end of `run` (learner.py:293-305): train_step follows the agent's counter, the last
+        LossInfo is reduced over replicas and axes, triggers fire.  Also called by PPOLearner when
+        the agent ran a whole epoch's minibatch steps from one host call."""
         if self.train_step is not None and self.train_step is not self._agent.train_step_counter:
             self.train_step.assign(int(self._agent.train_step_counter))
         reduced = self._reduce_loss(loss_info)

@@ -20,12 +20,17 @@ network keyed by Philox4x32-10(seed, epoch counter), restated in oracle/perm.py)
 its own replay shard) instead of dividing one dataset's batches by the replica count.
 """
 import ctypes
+import os
 
 import torch
 
 from agents_amd import _lib
 from agents_amd.train import learner
 from agents_amd.utils import nest_utils
+
+
+# AA_PPO_FUSED_EPOCHS=0: always one `agent.train` call per gathered minibatch (A/B, tests)
+FUSED_EPOCHS = os.environ.get("AA_PPO_FUSED_EPOCHS", "1") != "0"
 
 
 class PPOLearner:
@@ -93,10 +98,9 @@ class PPOLearner:
             frames += n
         return frames
 
-    def _minibatches(self, samples):
-        mb = self._minibatch_size
+    def _frames(self, samples):
+        """The `num_samples` elements flattened to [F, ...] leaves + the permutation buffer."""
         trajs = [s[0] for s in samples]
-        spec_rank = {}
         flat = []
         for tr in trajs:
             flat.append(nest_utils.map_structure(
@@ -109,6 +113,41 @@ class PPOLearner:
         dev = frames.discount.device
         if self._perm is None or self._perm.numel() != F:
             self._perm = torch.empty((F,), dtype=torch.int64, device=dev)
+        return frames, F, dev
+
+    def _shuffle(self, F, dev):
+        """One pseudo-random permutation of the F frames, computed index by index on the device
+        (csrc/replay.hip: Feistel network keyed by Philox; oracle/perm.py)."""
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().aa_random_permutation(
+                F, self._seed & 0xFFFFFFFFFFFFFFFF, self._perm_calls, self._perm.data_ptr(),
+                _lib.stream_ptr()), "aa_random_permutation")
+        self._perm_calls += 1
+        return self._perm
+
+    def _run_fused(self, samples, num_total_batches):
+        """Every minibatch step of every epoch through PPOAgent.train_minibatches (one host call
+        per epoch), or None when the agent / configuration does not take that path."""
+        agent = self._agent
+        gl = self._generic_learner
+        if not (FUSED_EPOCHS and hasattr(agent, "train_minibatches") and
+                gl._after_train_strategy_step_fn is None and self.num_replicas == 1 and
+                not gl.use_kwargs_in_agent_train):
+            return None
+        frames, F, dev = self._frames(samples)
+        mb = self._minibatch_size
+        if not agent.fused_minibatches_ok(frames) or \
+                (F // mb) * self._num_epochs != num_total_batches:
+            return None
+        loss_info = None
+        for _ in range(self._num_epochs):
+            perm = self._shuffle(F, dev)
+            loss_info = agent.train_minibatches(frames, perm, mb, F // mb)
+        return loss_info
+
+    def _minibatches(self, samples):
+        mb = self._minibatch_size
+        frames, F, dev = self._frames(samples)
         # minibatches are gathered into ONE persistent buffer set: the train step's HIP graph is
         # bound to these addresses and replays without input copies (utils/graph.py)
         key = (mb, tuple((tuple(t.shape[1:]), t.dtype) for t in nest_utils.flatten(frames)))
@@ -129,14 +168,9 @@ class PPOLearner:
         lib = _lib.load()
         perm = self._perm
         for _ in range(self._num_epochs):
-            # one pseudo-random permutation of the F frames per epoch, computed index by index on
-            # the device (csrc/replay.hip: Feistel network keyed by Philox; oracle/perm.py) -- no
-            # sort, no torch arithmetic
-            with torch.cuda.device(dev):
-                _lib.check(lib.aa_random_permutation(F, self._seed & 0xFFFFFFFFFFFFFFFF,
-                                                     self._perm_calls, perm.data_ptr(),
-                                                     _lib.stream_ptr()), "aa_random_permutation")
-            self._perm_calls += 1
+            # one pseudo-random permutation of the F frames per epoch -- no sort, no torch
+            # arithmetic
+            perm = self._shuffle(F, dev)
             for i in range(F // mb):
                 idx = perm[i * mb:(i + 1) * mb]
                 with torch.cuda.device(dev):
@@ -180,6 +214,10 @@ class PPOLearner:
                     "dataset {}; the run is sized from the former (ppo_learner.py:281-291)".format(
                         num_frames, train_frames))
             num_total_batches = int(num_frames / self._minibatch_size) * self._num_epochs
+            if num_total_batches > 0:
+                loss_info = self._run_fused(samples, num_total_batches)
+                if loss_info is not None:
+                    return self._generic_learner.finish_run(loss_info)
             it = self._minibatches(samples)
         else:
             num_total_batches = self._num_samples * self._num_epochs

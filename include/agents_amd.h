@@ -579,6 +579,8 @@ typedef struct {
   const float* returns; const float* adv; const float* old_vpred;      /* [N]; old_vpred nullable */
   const int32_t* step_type; const float* weights;                      /* [N]; weights nullable */
   int64_t N;
+  const int64_t* rows;   /* nullable [N]: minibatch sample b is row rows[b] of the arrays above
+                          * (the shuffle's permutation slice, train/ppo_learner.py:228-247) */
   const float* nrm_count; const float* nrm_avg; const float* nrm_m2;   /* [obs_dim] or all NULL */
   float nrm_eps, nrm_clip;
   const float* params; int64_t total; int64_t head_off;
@@ -594,6 +596,13 @@ int aa_ppo_fused_step(const aa_ppo_fused_desc* d, float* grads, float* adam_m, f
                       int64_t* adam_step_dev, float lr, float beta1, float beta2, float adam_eps,
                       float grad_clip /* <= 0: none */, float* stats9, float* sumsq_out,
                       void* workspace, int64_t workspace_bytes, void* stream);
+/* n_steps consecutive minibatch steps from one host call -- the minibatch loop of
+ * train/ppo_learner.py:220-248 over one epoch's shuffle: step s trains on rows
+ * rows_dev[s * N .. (s + 1) * N) of the sample arrays (all frames of the collected batch). */
+int aa_ppo_fused_epoch(const aa_ppo_fused_desc* d, const int64_t* rows_dev, int32_t n_steps,
+                       float* grads, float* adam_m, float* adam_v, int64_t* adam_step_dev, float lr,
+                       float beta1, float beta2, float adam_eps, float grad_clip, float* stats9,
+                       float* sumsq_out, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* =========================================================================================
  * Prioritized (proportional) sampling -- the north star's "segment-tree sampling".  No reference

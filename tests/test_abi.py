@@ -61,7 +61,7 @@ def test_struct_layouts_match_the_header(tmp_path):
               "aa_plane_scatter": ("PlaneScatter", ["n", "stride", "lo", "hi", "pos", "planes"]),
               "aa_mlp_layout": ("MlpLayout", ["n_layers", "dims", "acts", "k_off", "b_off"]),
               "aa_ppo_fused_desc": ("PpoFusedDesc", [
-                  "obs", "ld_obs", "obs_dim", "D", "actions", "old_vpred", "step_type", "N",
+                  "obs", "ld_obs", "obs_dim", "D", "actions", "old_vpred", "step_type", "N", "rows",
                   "nrm_count", "nrm_eps", "nrm_clip", "params", "total", "head_off", "actor",
                   "value", "act_mean", "act_mag", "clip_eps", "denom", "adv_eps"])}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "agents_amd.h"', 'int main(void){']

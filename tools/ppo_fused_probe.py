@@ -35,15 +35,14 @@ def main():
     torch.cuda.synchronize()
     lib.aa_ppo_fused_debug_stamps(None)
     t = buf.cpu().double() * 0.01          # us
-    names = ["start", "adv moments", "scalars + obs tile", "actor fwd0", "actor fwd1",
-             "actor fwd2", "value fwd0", "value fwd1", "value fwd2", "fwd done", "loss",
-             "actor bwd2", "actor bwd1", "actor bwd0", "value bwd2", "value bwd1", "value bwd0",
-             "end"]
+    names = {0: "start", 1: "adv moments", 2: "scalars + obs tile", 3: "fwd layer 0 (both nets)",
+             4: "fwd layer 1", 5: "fwd layer 2", 9: "fwd done", 10: "loss", 11: "bwd top layer",
+             12: "bwd middle layer", 13: "bwd first layer", 17: "end"}
     t0 = t[:, 0:1]
     rel = (t - t0)
     print("phase                 mean us since start   delta")
     prev = 0.0
-    for i, n in enumerate(names):
+    for i, n in sorted(names.items()):
         m = float(rel[:, i].mean())
         print(f"{n:22s} {m:10.2f} {m - prev:10.2f}")
         prev = m
