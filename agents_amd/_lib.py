@@ -192,6 +192,9 @@ _SIGNATURES = {
     "aa_adam_step_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
                                     c_float, c_float, c_float, c_void_p, POINTER(PlaneScatter),
                                     c_void_p]),
+    "aa_adam_step_counted": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
+                                     c_float, c_float, c_float, c_void_p, c_void_p,
+                                     POINTER(PlaneScatter), c_void_p]),
     "aa_rmsprop_step_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                        c_float, c_float, c_float, c_float, POINTER(PlaneScatter),
                                        c_void_p]),
@@ -243,7 +246,7 @@ _SIGNATURES = {
                             c_void_p, c_void_p]),
     "aa_prio_on_add": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "aa_sac_sample": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
-                              c_uint64] + [c_void_p] * 7),
+                              c_uint64] + [c_void_p] * 8),
     "aa_sac_head_backward": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32] +
                              [c_void_p] * 7),
     "aa_sac_critic_loss": (c_int, [c_void_p] * 9 + [c_float, c_float, c_int32, c_float, c_int64,
@@ -281,7 +284,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 8:
+    if lib.aa_abi_version() != 9:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -68,6 +68,7 @@ class SacPolicy(tf_policy.TFPolicy):
             self._dev_consts = (torch.from_numpy(self._mean_h.copy()).to(dev),
                                 torch.from_numpy(self._mag_h.copy()).to(dev))
             self._call_counter = torch.zeros((1,), dtype=torch.int64, device=dev)
+            self._arrival = torch.zeros((16,), dtype=torch.int64, device=dev)
         return self._dev_consts
 
     def sample(self, observation, slot, need_grad=False, eps=None, save=None):
@@ -90,11 +91,11 @@ class SacPolicy(tf_policy.TFPolicy):
         _lib.check(lib.aa_sac_sample(
             z.data_ptr(), B, self._A, mean.data_ptr(), mag.data_ptr(),
             self._actor_network.projection.std_kind, _lib.ptr(eps), self._seed,
-            self._call_counter.data_ptr(), b["action"].data_ptr(), b["logp"].data_ptr(),
+            self._call_counter.data_ptr(), self._arrival.data_ptr(), b["action"].data_ptr(),
+            b["logp"].data_ptr(),
             _lib.ptr(save["tanh"]) if save else None, _lib.ptr(save["sigma"]) if save else None,
             _lib.ptr(save["eps"]) if save else None, st), "aa_sac_sample")
-        if eps is None:
-            _lib.check(lib.aa_counter_add(self._call_counter.data_ptr(), 1, st), "aa_counter_add")
+        # (the launch itself advances the call counter when it drew the noise)
         return b["action"], b["logp"], z
 
     def state_dict(self):

@@ -62,14 +62,18 @@ __device__ static inline float adam_elem(float& p, float g, float& m, float& v, 
   return p;
 }
 
+// `arrival` != nullptr: *step_dev holds the number of steps taken so far; every workgroup reads it
+// at its start (t = that + 1) and the LAST one to finish advances it -- instead of a one-thread
+// aa_counter_add launch in front of every optimizer step (three per SAC iteration).
 template <bool PLANES>
 __global__ void __launch_bounds__(AA_EW_THREADS)
 aa_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps,
-               const int64_t* __restrict__ step_dev, aa_plane_scatter S) {
+               int64_t* __restrict__ step_dev, int64_t* __restrict__ arrival,
+               aa_plane_scatter S) {
   __shared__ float s_alpha;
   if (threadIdx.x == 0) {
-    const float t = (float)(*step_dev);
+    const float t = (float)(*step_dev + (arrival != nullptr ? 1 : 0));
     const float b1p = powf(beta1, t), b2p = powf(beta2, t);
     s_alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
   }
@@ -98,6 +102,7 @@ aa_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __rest
     const float pn = adam_elem(p[i], g[i], m[i], v[i], alpha, omb1, omb2, eps);
     if (PLANES) aa_planes_put(S, i, pn);
   }
+  if (arrival != nullptr) aa_advance_when_all_done(step_dev, arrival, 1, gridDim.x);
 }
 
 template <bool CENTERED, bool MOMENTUM>
@@ -229,9 +234,9 @@ static int aa_planes_check(const aa_plane_scatter* S, int64_t n) {
   return AA_OK;
 }
 
-int aa_adam_step_planes(float* p, const float* g, float* m, float* v, int64_t n, float lr,
-                        float beta1, float beta2, float eps, const int64_t* step_dev,
-                        const aa_plane_scatter* planes, void* stream) {
+static int aa_adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                          float beta1, float beta2, float eps, int64_t* step_dev, int64_t* arrival,
+                          const aa_plane_scatter* planes, void* stream) {
   if (!p || !g || !m || !v || !step_dev || n <= 0) return AA_ERR_INVALID;
   if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0)
     return AA_ERR_INVALID;
@@ -239,11 +244,26 @@ int aa_adam_step_planes(float* p, const float* g, float* m, float* v, int64_t n,
   const dim3 grid(aa_ew_blocks(n / 4)), block(AA_EW_THREADS);
   if (planes != nullptr && planes->n > 0)
     hipLaunchKernelGGL(aa_adam_kernel<true>, grid, block, 0, (hipStream_t)stream, p, g, m, v, n,
-                       lr, beta1, beta2, eps, step_dev, *planes);
+                       lr, beta1, beta2, eps, step_dev, arrival, *planes);
   else
     hipLaunchKernelGGL(aa_adam_kernel<false>, grid, block, 0, (hipStream_t)stream, p, g, m, v, n,
-                       lr, beta1, beta2, eps, step_dev, aa_plane_scatter{});
+                       lr, beta1, beta2, eps, step_dev, arrival, aa_plane_scatter{});
   return aa_launch_status();
+}
+
+int aa_adam_step_planes(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                        float beta1, float beta2, float eps, const int64_t* step_dev,
+                        const aa_plane_scatter* planes, void* stream) {
+  return aa_adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, const_cast<int64_t*>(step_dev),
+                        nullptr, planes, stream);
+}
+
+int aa_adam_step_counted(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                         float beta1, float beta2, float eps, int64_t* steps_taken_dev,
+                         int64_t* arrival_dev, const aa_plane_scatter* planes, void* stream) {
+  if (arrival_dev == nullptr) return AA_ERR_INVALID;
+  return aa_adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, steps_taken_dev, arrival_dev, planes,
+                        stream);
 }
 
 int aa_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,

@@ -54,6 +54,7 @@
 #define PF_THREADS 512   /* 2 groups (actor, value) x 4 waves */
 #define PF_HALF_LOG_2PI 0.91893853320467274178f
 #define PF_MD AA_PPO_FUSED_MAX_D
+#define PF_MAX_EPOCH_STEPS 4096   /* minibatches per host call whose moments are computed ahead */
 
 typedef float pf_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -61,6 +62,7 @@ struct PfArgs {
   aa_ppo_fused_desc d;
   float* slabs;        // [n_wg][total]
   float* partial;      // [n_wg][8]
+  const float* moments;  // nullable: {mean, var} of this step's advantages, computed per epoch
   long long* stamps;   // nullable (aa_ppo_fused_debug_stamps): [n_wg][32] wall_clock64 ticks (10 ns)
 };
 
@@ -270,6 +272,66 @@ __device__ static inline void pf_backward(const aa_mlp_layout& net, int l, int g
   }
 }
 
+// mean / variance of the N advantages of one minibatch (tf.nn.moments, two-pass, a fixed order for
+// PF_THREADS threads): every workgroup of a step computes them itself, or -- when a whole epoch is
+// issued from one host call -- one launch computes them for ALL of the epoch's minibatches ahead
+// of time (they depend on the shuffle, not on the weights); the same code, the same bits.
+// bc[0] = mean, bc[1] = variance; ends with a barrier.
+__device__ static inline void pf_moments(const float* __restrict__ adv,
+                                         const int64_t* __restrict__ rows, int64_t N, float* red,
+                                         float* bc) {
+  const int tid = threadIdx.x;
+  const bool keep = N <= 16 * PF_THREADS;      // the 16 values of a thread stay in registers
+  float av[16];
+  float s = 0.f;
+  if (keep) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int64_t i = tid + (int64_t)PF_THREADS * u;
+      av[u] = i < N ? adv[rows != nullptr ? rows[i] : i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += av[u];
+  } else {
+    for (int64_t i = tid; i < N; i += PF_THREADS) s += adv[rows != nullptr ? rows[i] : i];
+  }
+  float t = aa_block_sum(s, red);
+  if (tid == 0) bc[0] = t / (float)N;
+  __syncthreads();
+  const float mean = bc[0];
+  float q = 0.f;
+  if (keep) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (tid + (int64_t)PF_THREADS * u < N) {
+        const float dl = av[u] - mean;
+        q += dl * dl;
+      }
+    }
+  } else {
+    for (int64_t i = tid; i < N; i += PF_THREADS) {
+      const float dl = adv[rows != nullptr ? rows[i] : i] - mean;
+      q += dl * dl;
+    }
+  }
+  t = aa_block_sum(q, red);
+  if (tid == 0) bc[1] = t / (float)N;
+  __syncthreads();
+}
+
+// workgroup s: the moments of minibatch s of an epoch -> out[2 s], out[2 s + 1]
+__global__ void __launch_bounds__(PF_THREADS)
+aa_ppo_fused_moments_kernel(const float* __restrict__ adv, const int64_t* __restrict__ rows,
+                            int64_t N, float* __restrict__ out) {
+  __shared__ float red[16];
+  __shared__ float bc[2];
+  pf_moments(adv, rows + (int64_t)blockIdx.x * N, N, red, bc);
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = bc[0];
+    out[2 * blockIdx.x + 1] = bc[1];
+  }
+}
+
 __global__ void __launch_bounds__(PF_THREADS) aa_ppo_fused_step_kernel(PfArgs P) {
   const aa_ppo_fused_desc& d = P.d;
   extern __shared__ __attribute__((aligned(16))) char pf_lds_raw[];
@@ -291,45 +353,12 @@ __global__ void __launch_bounds__(PF_THREADS) aa_ppo_fused_step_kernel(PfArgs P)
   for (int i = tid; i < 2 * PF_W * PF_PITCH; i += PF_THREADS) (&S.Ws[0][0])[i] = 0.f;
   for (int i = tid; i < 4 * PF_TS * PF_PITCH; i += PF_THREADS) (&S.G[0][0][0][0])[i] = 0.f;
 
-  // ---- advantage moments over the WHOLE minibatch (two-pass, fixed order; every workgroup) -----
-  // N <= 8192: the 16 values of a thread stay in registers for both passes
-  {
-    const bool keep = N <= 16 * PF_THREADS;
-    float av[16];
-    float s = 0.f;
-    if (keep) {
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int64_t i = tid + (int64_t)PF_THREADS * u;
-        av[u] = i < N ? d.adv[row_of(i)] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) s += av[u];
-    } else {
-      for (int64_t i = tid; i < N; i += PF_THREADS) s += d.adv[row_of(i)];
-    }
-    float t = aa_block_sum(s, S.red);
-    if (tid == 0) S.bc[0] = t / (float)N;
+  // ---- advantage moments over the WHOLE minibatch ----------------------------------------------------
+  if (P.moments != nullptr) {
+    if (tid == 0) { S.bc[0] = P.moments[0]; S.bc[1] = P.moments[1]; }
     __syncthreads();
-    const float mean = S.bc[0];
-    float q = 0.f;
-    if (keep) {
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        if (tid + (int64_t)PF_THREADS * u < N) {
-          const float dl = av[u] - mean;
-          q += dl * dl;
-        }
-      }
-    } else {
-      for (int64_t i = tid; i < N; i += PF_THREADS) {
-        const float dl = d.adv[row_of(i)] - mean;
-        q += dl * dl;
-      }
-    }
-    t = aa_block_sum(q, S.red);
-    if (tid == 0) S.bc[1] = t / (float)N;
-    __syncthreads();
+  } else {
+    pf_moments(d.adv, d.rows, N, S.red, S.bc);
   }
   PF_STAMP(1)
   // ---- the tile's rows: actions, old log-prob terms (thread per (sample, dim)), per-sample
@@ -716,7 +745,8 @@ int aa_ppo_fused_debug_stamps(int64_t* buf) {
 int64_t aa_ppo_fused_workspace_bytes(int64_t N, int64_t total_params) {
   if (N <= 0 || total_params <= 0) return -1;
   const int64_t n_wg = (N + PF_TS - 1) / PF_TS;
-  return (n_wg * total_params + n_wg * 8 + (total_params + 15) / 16 + 16) * (int64_t)sizeof(float);
+  return (n_wg * total_params + n_wg * 8 + (total_params + 15) / 16 + 16 + 2 * PF_MAX_EPOCH_STEPS) *
+         (int64_t)sizeof(float);
 }
 
 // n_steps consecutive minibatch steps from ONE host call: step s trains on rows
@@ -766,12 +796,19 @@ int aa_ppo_fused_epoch(const aa_ppo_fused_desc* dsc, const int64_t* rows_dev, in
   P.partial = P.slabs + n_wg * d.total;
   P.stamps = g_pf_stamps;
   float* sumsq_part = P.partial + n_wg * 8;
+  float* moments = sumsq_part + (d.total + 15) / 16 + 16;
   hipStream_t st = (hipStream_t)stream;
   const unsigned n_red = (unsigned)((d.total + 63) / 64);
   int64_t blocks = (d.total + 255) / 256;
   if (blocks > 1024) blocks = 1024;
+  P.moments = nullptr;
+  const bool ahead = rows_dev != nullptr && n_steps > 1 && n_steps <= PF_MAX_EPOCH_STEPS;
+  if (ahead)     // the advantage moments of every minibatch of this call, one launch
+    hipLaunchKernelGGL(aa_ppo_fused_moments_kernel, dim3((unsigned)n_steps), dim3(PF_THREADS), 0,
+                       st, d.adv, rows_dev, d.N, moments);
   for (int s = 0; s < n_steps; ++s) {
     if (rows_dev != nullptr) P.d.rows = rows_dev + (int64_t)s * d.N;
+    if (ahead) P.moments = moments + 2 * s;
     hipLaunchKernelGGL(aa_ppo_fused_step_kernel, dim3((unsigned)n_wg), dim3(PF_THREADS),
                        sizeof(PfLds), st, P);
     hipLaunchKernelGGL(aa_ppo_fused_reduce_kernel, dim3(n_red), dim3(256), 0, st,

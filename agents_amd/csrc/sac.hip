@@ -33,10 +33,10 @@ __global__ void __launch_bounds__(256)
 aa_sac_sample_kernel(const float* __restrict__ z, int64_t B, int A, int per_block,
                      const float* __restrict__ act_mean, const float* __restrict__ act_mag,
                      int std_kind, const float* __restrict__ eps_in, uint32_t seed_lo,
-                     uint32_t seed_hi, const int64_t* __restrict__ call_counter,
-                     float* __restrict__ action, float* __restrict__ logp,
-                     float* __restrict__ save_tanh, float* __restrict__ save_sigma,
-                     float* __restrict__ save_eps) {
+                     uint32_t seed_hi, int64_t* __restrict__ call_counter,
+                     int64_t* __restrict__ arrival, float* __restrict__ action,
+                     float* __restrict__ logp, float* __restrict__ save_tanh,
+                     float* __restrict__ save_sigma, float* __restrict__ save_eps) {
   __shared__ float terms[256];
   const uint64_t call = call_counter != nullptr ? (uint64_t)call_counter[0] : 0ull;
   const int local = threadIdx.x / A, d = threadIdx.x - local * A;
@@ -79,6 +79,10 @@ aa_sac_sample_kernel(const float* __restrict__ z, int64_t B, int A, int per_bloc
     for (int k = 0; k < A; ++k) lp += terms[local * A + k];   // dimension order, as before
     logp[b] = lp;
   }
+  // the Philox call counter moves on inside the launch (every workgroup has read it by the time
+  // the last one finishes), not in a one-thread launch of its own
+  if (arrival != nullptr && eps_in == nullptr && call_counter != nullptr)
+    aa_advance_when_all_done(call_counter, arrival, 1, gridDim.x);
 }
 
 // dz[B,2A] from dL/daction [B,A] and dL/dlog_pi [B] (reparameterised sample x = mu + sigma eps):
@@ -223,8 +227,8 @@ extern "C" {
 
 int aa_sac_sample(const float* z, int64_t B, int32_t A, const float* act_mean,
                   const float* act_mag, int32_t std_kind, const float* eps_in, uint64_t seed,
-                  const int64_t* call_counter_dev, float* action, float* logp, float* save_tanh,
-                  float* save_sigma, float* save_eps, void* stream) {
+                  int64_t* call_counter_dev, int64_t* arrival_dev, float* action, float* logp,
+                  float* save_tanh, float* save_sigma, float* save_eps, void* stream) {
   if (!z || !act_mean || !act_mag || !action || !logp || B <= 0 || A <= 0) return AA_ERR_INVALID;
   if (std_kind != AA_SAC_STD_EXP && std_kind != AA_SAC_STD_CLIP_EXP) return AA_ERR_INVALID;
   if ((save_tanh == nullptr) != (save_sigma == nullptr) ||
@@ -236,7 +240,8 @@ int aa_sac_sample(const float* z, int64_t B, int32_t A, const float* act_mean,
   if (blocks > 0x7fffffffLL) return AA_ERR_RANGE;
   hipLaunchKernelGGL(aa_sac_sample_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      (hipStream_t)stream, z, B, A, per_block, act_mean, act_mag, std_kind, eps_in,
-                     (uint32_t)seed, (uint32_t)(seed >> 32), call_counter_dev, action, logp,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), call_counter_dev, arrival_dev, action,
+                     logp,
                      save_tanh, save_sigma, save_eps);
   return aa_launch_status();
 }

@@ -85,6 +85,7 @@ class Adam(Optimizer):
         super().__init__(name)
         self.learning_rate, self.beta_1, self.beta_2, self.epsilon = \
             float(learning_rate), float(beta_1), float(beta_2), float(epsilon)
+        self._arrive = {}
 
     supports_planes = True
 
@@ -93,13 +94,18 @@ class Adam(Optimizer):
         lib = _lib.load()
         _lib.require_cuda(params, grads)
         s = self._slot(params, ("m", "v"))
-        st = _lib.stream_ptr()
-        _lib.check(lib.aa_counter_add(s["step"].data_ptr(), 1, st), "aa_counter_add")
-        _lib.check(lib.aa_adam_step_planes(
+        key = params.data_ptr()
+        arrive = self._arrive.get(key)
+        if arrive is None:      # scratch of the in-launch step counter (not optimizer state)
+            arrive = self._arrive[key] = torch.zeros((16,), dtype=torch.int64,
+                                                     device=params.device)
+        # s["step"] = steps applied so far; the launch uses t = step + 1 and stores it back itself
+        _lib.check(lib.aa_adam_step_counted(
             params.data_ptr(), grads.data_ptr(), s["m"].data_ptr(), s["v"].data_ptr(),
             params.numel(), self.learning_rate, self.beta_1, self.beta_2, self.epsilon,
-            s["step"].data_ptr(), None if planes is None else ctypes.byref(planes), st),
-            "aa_adam_step_planes")
+            s["step"].data_ptr(), arrive.data_ptr(),
+            None if planes is None else ctypes.byref(planes), _lib.stream_ptr()),
+            "aa_adam_step_counted")
         graph.on_replay(self._bump_iterations)
 
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 8
+#define AA_ABI_VERSION 9
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -416,6 +416,13 @@ typedef struct {
 int aa_adam_step_planes(float* p, const float* g, float* m, float* v, int64_t n, float lr,
                         float beta1, float beta2, float eps, const int64_t* step_dev,
                         const aa_plane_scatter* planes /* nullable */, void* stream);
+/* Adam with the step count kept by the launch itself: *steps_taken_dev = steps applied so far (the
+ * launch uses t = that + 1 and its last workgroup to finish stores t back; arrival_dev = one int64
+ * of scratch, zero before the first call) -- no counter launch in front of the optimizer step. */
+int aa_adam_step_counted(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                         float beta1, float beta2, float eps, int64_t* steps_taken_dev,
+                         int64_t* arrival_dev, const aa_plane_scatter* planes /* nullable */,
+                         void* stream);
 int aa_rmsprop_step_planes(float* p, const float* g, float* ms, float* mg, float* mom, int64_t n,
                            float lr, float rho, float momentum, float eps,
                            const aa_plane_scatter* planes /* nullable */, void* stream);
@@ -638,11 +645,14 @@ int aa_prio_on_add(const int64_t* last_id_dev, int64_t batch, int64_t max_len,
  * tanh-squashed sample action = act_mean + act_mag * tanh(mean + sigma*eps) and its log-probability
  * (Normal log-density at the pre-tanh sample minus log|mag| and the stable tanh log-det-Jacobian).
  * eps_in nullable: N(0,1) noise supplied by the caller; else drawn from Philox(seed, *counter).
+ * arrival_dev nullable: one int64 of scratch (zero before the first call); when given (and the
+ * noise is drawn here) the launch advances *call_counter_dev by one itself once every workgroup
+ * has used it -- no counter launch after the sample.
  * save_* (all or none, [B,A]) keep tanh(x), sigma, eps for aa_sac_head_backward. */
 int aa_sac_sample(const float* z, int64_t B, int32_t A, const float* act_mean,
                   const float* act_mag, int32_t std_kind, const float* eps_in, uint64_t seed,
-                  const int64_t* call_counter_dev, float* action, float* logp, float* save_tanh,
-                  float* save_sigma, float* save_eps, void* stream);
+                  int64_t* call_counter_dev, int64_t* arrival_dev, float* action, float* logp,
+                  float* save_tanh, float* save_sigma, float* save_eps, void* stream);
 /* dz[B,2A] = d loss / d head output from d loss / d action (nullable) and d loss / d log_pi. */
 int aa_sac_head_backward(const float* z, int64_t B, int32_t A, const float* act_mag,
                          int32_t std_kind, const float* save_tanh, const float* save_sigma,

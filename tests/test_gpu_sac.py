@@ -103,7 +103,7 @@ def test_sample_and_head_backward_vs_autograd(dev, kind, B, A):
     sv = [torch.empty(B, A, device=dev) for _ in range(3)]
     k = _lib.AA_SAC_STD_EXP if kind == "exp" else _lib.AA_SAC_STD_CLIP_EXP
     _lib.check(lib.aa_sac_sample(zd.data_ptr(), B, A, meand.data_ptr(),
-                                 magd.data_ptr(), k, epsd.data_ptr(), 0, None,
+                                 magd.data_ptr(), k, epsd.data_ptr(), 0, None, None,
                                  action.data_ptr(), logp.data_ptr(), sv[0].data_ptr(),
                                  sv[1].data_ptr(), sv[2].data_ptr(), _lib.stream_ptr()), "sample")
     close(action, act_o, rtol=2e-6)
@@ -128,7 +128,7 @@ def test_sample_internal_noise_is_standard_normal_and_advances(dev):
         lp = torch.empty(B, device=dev)
         sv = [torch.empty(B, A, device=dev) for _ in range(3)]
         _lib.check(lib.aa_sac_sample(z.data_ptr(), B, A, mean.data_ptr(), mag.data_ptr(), 0, None,
-                                     1234, ctr.data_ptr(), a.data_ptr(), lp.data_ptr(),
+                                     1234, ctr.data_ptr(), None, a.data_ptr(), lp.data_ptr(),
                                      sv[0].data_ptr(), sv[1].data_ptr(), sv[2].data_ptr(),
                                      _lib.stream_ptr()), "sample")
         ctr += 1
