@@ -764,15 +764,16 @@ static int aa_gemm_plan(const aa_gemm_desc* d, AaGemmPlan* pl) {
     const int max_by_k = (int)(K / (4 * AA_BK));  // at least four K-steps per split
     if (splits > max_by_k) splits = max_by_k;
     if (splits < 1) splits = 1;
-    // Small contractions (the 256-wide SAC layers at batch 256: 40-50 MFLOP) are bound by launch
-    // latency, not by occupancy: splitting K buys a 2 us shorter main loop and costs a whole
-    // extra launch (the slab reduce, 4.6 us + its dispatch gap) -- 30 of the ~120 launches of a
-    // SAC iteration.  Below AA_GEMM_NOSPLIT_MFLOP (default 128; 0 = always fill the chip) the
-    // contraction runs unsplit on however many tiles it has, provided that is >= 16 workgroups.
+    // A/B knob AA_GEMM_NOSPLIT_MFLOP (default 0 = off): contractions below that size run unsplit
+    // on however many tiles they have (>= 16 workgroups), which saves the slab-reduce launch --
+    // 30 of the ~120 launches of a SAC iteration (256-wide layers at batch 256: 40-50 MFLOP each).
+    // Measured on MI355X, alternating runs on one box: SAC iteration 0.554 ms split vs 0.584 ms
+    // unsplit at 128 -- 32 workgroups walking K = 393 take longer than 256 walking K = 49 plus the
+    // reduce; not adopted.
     static double nosplit = -1.0;
     if (nosplit < 0.0) {
       const char* e = getenv("AA_GEMM_NOSPLIT_MFLOP");
-      nosplit = e != nullptr ? atof(e) : 128.0;
+      nosplit = e != nullptr ? atof(e) : 0.0;
     }
     if (2.0 * (double)M * (double)N * (double)K <= nosplit * 1e6 && tiles >= 16) splits = 1;
   }

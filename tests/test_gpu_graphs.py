@@ -328,9 +328,12 @@ def test_ppo_train_graph_matches_eager(dev):
         fn = lambda: rb.as_dataset(sample_batch_size=B, num_steps=T + 1,
                                    single_deterministic_pass=True).map(
             lambda traj, info: (agent.preprocess_sequence(traj), info))
+        # a per-step hook keeps the learner on one `agent.train` call per minibatch -- the path
+        # that is graphed (without it an epoch runs from one host call: train_minibatches)
         lrn = ppo_learner.PPOLearner(None, common.Variable(0), agent, fn, fn, num_samples=1,
                                      num_epochs=6, minibatch_size=32,
-                                     shuffle_buffer_size=B * (T + 1), seed=3)
+                                     shuffle_buffer_size=B * (T + 1), seed=3,
+                                     after_train_strategy_step_fn=lambda *a: None)
         if not use_graph:
             lrn._generic_learner._train_fn = agent.train
         li = lrn.run()
