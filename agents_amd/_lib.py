@@ -97,6 +97,10 @@ _SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                     c_int64, c_int64, c_uint64, c_uint64, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
+    "aa_rb_sample_gather_stamped": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64),
+                                            c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                            c_int64, c_int64, c_int64, c_uint64, c_uint64,
+                                            c_void_p, c_void_p, c_void_p]),
     "aa_rb_gather_rows": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int,
                                   c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "aa_rb_write_rows": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int,

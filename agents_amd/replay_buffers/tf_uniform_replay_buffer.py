@@ -19,6 +19,8 @@ names a torch/HIP device).
 import collections
 
 import numpy as np
+import os
+
 import torch
 
 from agents_amd import _lib
@@ -33,6 +35,10 @@ _EMPTY_SAMPLE = ("TFUniformReplayBuffer is empty. Make sure to add items before 
                  "buffer.")
 _EMPTY_DATASET = ("TFUniformReplayBuffer is empty. Make sure to add items before asking the "
                   "buffer for data.")
+
+
+# AA_RB_STAMPED=0: graphed datasets replay the device-counter launch instead of stamping (A/B)
+STAMPED_DRAWS = os.environ.get("AA_RB_STAMPED", "1") != "0"
 
 
 def _valid_range_ids(last_id, max_length, num_steps=None):
@@ -143,6 +149,39 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
         lo, hi = _valid_range_ids(self._last_id_host, self._max_length, num_steps)
         if hi <= lo:
             raise RuntimeError(_EMPTY_SAMPLE)
+
+    # ---- stamped draws: the host mirrors of last_id / the call counter ride in the launch ------
+    def supports_stamped_draws(self):
+        """True when `draw_into` reproduces `get_next` (no subclass sampler in the way)."""
+        return STAMPED_DRAWS and \
+            type(self)._sample_rows is TFUniformReplayBuffer._sample_rows and \
+            type(self)._get_next is TFUniformReplayBuffer._get_next
+
+    def stamped_slot(self, element):
+        """The launch arguments of `draw_into` for one static output element
+        (data [S, T, ...], BufferInfo(ids [S, T], probabilities [S])), packed once."""
+        data, info = element
+        outs = nest_utils.flatten(data)
+        S, T = (int(d) for d in info.ids.shape)
+        for t in outs + [info.ids, info.probabilities]:
+            if not t.is_contiguous() or int(t.shape[0]) != S:
+                raise ValueError("stamped_slot: not a [S, T, ...] element of this buffer")
+        return (self._data_table.pack(outs), info.ids.data_ptr(), info.probabilities.data_ptr(),
+                S, T)
+
+    def draw_into(self, slot):
+        """`get_next(S, T)` into the buffers of `slot` with ONE eager launch that carries last_id
+        and the Philox call number by value (aa_rb_sample_gather_stamped): same samples, bit for
+        bit, as the device-counter launch a HIP graph replays, without its dependent counter
+        read.  Not capturable (the values would freeze); the caller holds the device context."""
+        p, ids_ptr, probs_ptr, S, T = slot
+        self._check_not_empty(T)
+        _lib.check(_lib.load().aa_rb_sample_gather_stamped(
+            p.tables, p.ios, p.row_bytes, p.n, self._id_table.variables()[0].data_ptr(), ids_ptr,
+            probs_ptr, self._last_id_host, self._batch_size, self._max_length, S, T, self._seed,
+            self._sample_calls, self._sample_calls_dev.data_ptr(), self._err_flag.data_ptr(),
+            _lib.stream_ptr()), "aa_rb_sample_gather_stamped")
+        self._sample_calls += 1
 
     def _sample_rows(self, S, T):
         lib = _lib.load()

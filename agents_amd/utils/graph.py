@@ -550,6 +550,7 @@ class GraphedSampler:
         self._i = 0
         self._warm = 0
         self._ref = None
+        self._stamped = None      # per ring slot: packed arguments of rb.draw_into
         self.enabled = True
         self.replays = 0
 
@@ -599,17 +600,32 @@ class GraphedSampler:
             if self._ring[slot] is None:
                 self._prime()
                 self._ptr0 = [nest_utils.flatten(c.out[0])[0].data_ptr() for c in self._ring]
+                if self._S is not None and self._T is not None and \
+                        getattr(rb, "supports_stamped_draws", lambda: False)():
+                    self._stamped = [rb.stamped_slot(c.out) for c in self._ring]
             c = self._ring[slot]
+            # a buffer that mirrors its counters on the host draws with one eager launch that
+            # carries them by value (no dependent counter read on the device); otherwise the
+            # captured device-counter launch is replayed
+            stamped = self._stamped[slot] if self._stamped is not None else None
             lanes = _LANES.get((dev.type, dev.index)) if _LANES else None
             if lanes is None:
-                out = c.replay()
+                if stamped is not None:
+                    rb.draw_into(stamped)
+                    out = c.out
+                else:
+                    out = c.replay()
             else:
                 if lanes.collect_done is not None:
                     lanes.S.wait_event(lanes.collect_done)
                 lanes.S.wait_event(lanes.main_frontier())
                 with torch.cuda.stream(lanes.S):
                     _mark("sample.begin", lanes.S)
-                    out = c.replay()
+                    if stamped is not None:
+                        rb.draw_into(stamped)
+                        out = c.out
+                    else:
+                        out = c.replay()
                     lanes.sample_done = lanes.event_on(lanes.S)
                     _mark("sample.done", lanes.S)
                 lanes.ready[self._ptr0[slot]] = lanes.sample_done

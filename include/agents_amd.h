@@ -79,6 +79,20 @@ int aa_rb_sample_gather(const void* const* leaf_tables_h, void* const* leaf_out_
                         uint64_t call_counter, int64_t* call_counter_dev, int64_t* arrival_dev,
                         int* err_flag_dev, void* stream);
 
+/* The same draw + gather launched EAGERLY once per draw by a host that mirrors both counters (the
+ * replay buffer's last_id and the Philox call counter): they arrive by value, so no workgroup
+ * waits for a device read before it can compute its rows and no arrival protocol runs -- the
+ * dependent round trip of aa_rb_sample_gather's counter read is ~3 us of a launch whose copy takes
+ * 5.  *call_counter_out_dev (nullable) receives call_counter + 1, which keeps the device-resident
+ * counter in step for graph-captured draws.  Same stream of samples, bit for bit
+ * (tf_uniform_replay_buffer.py:211-310). */
+int aa_rb_sample_gather_stamped(const void* const* leaf_tables_h, void* const* leaf_out_h,
+                                const int64_t* leaf_row_bytes_h, int n_leaves,
+                                const int64_t* id_table, int64_t* ids_out, float* prob_out,
+                                int64_t last_id, int64_t batch, int64_t max_len, int64_t S,
+                                int64_t T, uint64_t seed, uint64_t call_counter,
+                                int64_t* call_counter_out_dev, int* err_flag_dev, void* stream);
+
 /* Row gather of every leaf + the id table: out[r] = table[rows[r]].
  * Replaces Table.read / ResourceVariable.sparse_read per leaf (table.py:86-110). */
 int aa_rb_gather_rows(const void* const* leaf_tables_h, void* const* leaf_out_h,

@@ -280,3 +280,77 @@ def test_fused_get_next_equals_the_two_launch_path(dev):
         for a, b in zip(nest_utils.flatten(data), nest_utils.flatten(ref)):
             assert torch.equal(a, b)
         assert torch.equal(info.ids, ids) and torch.equal(info.probabilities, probs)
+
+
+@pytest.mark.parametrize("B,L,last_id,T", [
+    (256, 3906, 5000, 2),                       # BASELINE configs[1]: both moduli far below 2^32
+    (1, (1 << 32) - 1, (1 << 33) + 12345, 2),   # num_ids = 2^32 - 2: the largest 32-bit modulus
+    ((1 << 32) - 5, 7, 100, 3),                 # batch just below 2^32, ids above 2^32 in rows
+    ((1 << 32) + 7, 5, 1000, 4),                # batch >= 2^32: the generic 64-bit path
+    (3, 1 << 33, (1 << 35) + 17, 4),            # num_ids >= 2^32: the generic 64-bit path
+    (3, 1 << 31, (1 << 40) + 5, 1),             # id + t above 2^32 with a 32-bit ring length
+    (65537, 65521, 70000, 5),
+])
+def test_draw_arithmetic_is_exact_at_the_modulus_boundaries(dev, B, L, last_id, T):
+    """The draw reduces 64-bit Philox words with a float64 quotient + one correction step when the
+    modulus fits 32 bits, and maps ids to ring slots with 32-bit arithmetic when both operands fit
+    (csrc/replay.hip: aa_umod64 / aa_mod_nonneg).  No table is needed to check the rows: against
+    numpy's uint64 arithmetic (oracle/replay.py) bit for bit, 8,192 draws per case."""
+    from agents_amd import _lib
+    lib = _lib.load()
+    n, seed = 8192, 0x9E3779B97F4A7C15
+    lid = torch.tensor([last_id], dtype=torch.int64, device=dev)
+    rows = torch.empty((n, T), dtype=torch.int64, device=dev)
+    probs = torch.empty((n,), dtype=torch.float32, device=dev)
+    for call in (0, 1, (1 << 40) + 3):
+        _lib.check(lib.aa_rb_sample_rows(lid.data_ptr(), B, L, n, T, seed, call, None,
+                                         rows.data_ptr(), probs.data_ptr(), None,
+                                         _lib.stream_ptr()), "aa_rb_sample_rows")
+        a, c = oracle_replay.raw_draws(seed, call, n)
+        orows, oprobs = oracle_replay.rows_from_draws(a, c, last_id, B, L, T)
+        assert np.array_equal(rows.cpu().numpy(), orows)
+        assert np.array_equal(probs.cpu().numpy(), oprobs)
+
+
+@pytest.mark.parametrize("obs_shape,dtype,B,L,S,T", [
+    ((84, 84, 4), torch.uint8, 8, 6, 64, 2),     # two rows of a sample per workgroup
+    ((84, 84, 4), torch.uint8, 4, 9, 33, 4),     # 4 x 28 KB > 64 KB: two rows per workgroup
+    ((20000,), torch.float32, 3, 9, 50, 3),      # three chunks per row, odd T: one row per group
+    ((5,), torch.float32, 16, 8, 1000, 4),       # narrow leaves only: no wide-leaf workgroup
+    ((1031,), torch.uint8, 5, 7, 200, 2),        # 1,031-byte rows: the byte-wise copy
+])
+def test_stamped_draws_equal_device_counter_draws(dev, obs_shape, dtype, B, L, S, T):
+    """rb.draw_into (aa_rb_sample_gather_stamped: last_id and the call number by value, one eager
+    launch) == rb.get_next (device-resident counters, the launch HIP graphs replay) on the same
+    buffer state, leaf by leaf, ids and probabilities included; the two paths can be interleaved
+    because each leaves both counters where the other expects them."""
+    from agents_amd.utils import nest_utils
+    spec = _traj_spec(obs_shape, dtype)
+    rbs = [rb_lib.TFUniformReplayBuffer(spec, batch_size=B, max_length=L, device=dev, seed=11)
+           for _ in range(2)]
+    rng = np.random.RandomState(4)
+    element, slot = None, None
+    for i in range(L + 3):
+        items = nest_utils.map_structure(lambda a: torch.as_tensor(a, device=dev),
+                                         _rand_items(rng, spec, B))
+        for rb in rbs:
+            rb.add_batch(items)
+        if i + 1 < T:
+            continue
+        ref, iref = rbs[1].get_next(S, T)
+        if slot is None:
+            element = rbs[0].get_next(S, T)            # allocates the static element
+            slot = rbs[0].stamped_slot(element)
+            got, igot = element
+        elif i % 3 == 0:                               # interleave the device-counter path
+            got, igot = rbs[0].get_next(S, T)
+        else:
+            with torch.cuda.device(dev):
+                rbs[0].draw_into(slot)
+            got, igot = element
+        for a, b in zip(nest_utils.flatten(got), nest_utils.flatten(ref)):
+            assert torch.equal(a, b)
+        assert torch.equal(igot.ids, iref.ids)
+        assert torch.equal(igot.probabilities, iref.probabilities)
+        assert int(rbs[0]._sample_calls_dev.item()) == rbs[0]._sample_calls == rbs[1]._sample_calls
+        assert not bool(rbs[0]._sample_arrival.any())
