@@ -511,15 +511,21 @@ def main_other_config(args):
                           f"{n_mb} minibatch train steps", "parallelism": "single"},
                "collect_env_steps_per_sec": r["collect_env_steps_per_sec"],
                "train_minibatch_steps_per_sec": r["train_minibatch_steps_per_sec"],
-               "roofline": {"kernel": "PPOClipAgent.train minibatch step (gather + ~28 launches: "
-                                      "mlp_small fwd/bwd x2, loss, clip, Adam)", "bound": "mfma",
+               "roofline": {"kernel": "PPOClipAgent.train minibatch step: 3 launches "
+                                      "(aa_ppo_fused_step / _reduce / _apply: row gather, both MLPs "
+                                      "forward + backward, loss, clip, Adam; csrc/ppo_fused.hip), "
+                                      "a whole epoch of them per host call", "bound": "mfma",
                             "achieved": flop / mb_ms / 1e9, "peak": MFMA_F32_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": flop / mb_ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
                             "traffic": None, "algorithmic_flop_per_launch": flop,
                             "avg_launch_ms": mb_ms,
-                            "note": "a 64-wide MLP on 4,096 frames is 0.27 GFLOP per step: the "
-                                    "step is bound by launch latency (one HIP graph of ~28 small "
-                                    "kernels), not by the VALU or MFMA rate"}}
+                            "note": "a 64-wide MLP on 4,096 frames is 0.27 GFLOP per step; the "
+                                    "fused step runs fp32 FMAs on the VALU out of LDS (no MFMA "
+                                    "tile fits 17-wide inputs and 6-/1-wide heads), so frac "
+                                    "against the fp32 MFMA peak is what the shape allows, not a "
+                                    "kernel-quality figure: the step's ~42 us are K1 ~35 us "
+                                    "(forward ~7, loss 2, backward ~9, staging / barriers the "
+                                    "rest), K2 + K3 ~7 us"}}
         if not args.no_cpu_baseline:
             th, ncpu, cands = _best_threads(lambda n, t: bench_ppo.cpu_baseline(4096, n, t))
             sps = bench_ppo.cpu_baseline(4096, 200, th)
@@ -836,7 +842,7 @@ def main():
                 log(f"    {name:40s} {ms * 1e3:8.1f} | "
                     f"{(f'{il:8.1f}' if il else '     n/a')} us x{n}  {extra}")
             # HBM bytes and matrix-pipe busy per launch come from COMMITTED rocprofv3 --pmc passes
-            # (isolated launches, one counter set per pass: tools/pmc_r03.sh); they are not
+            # (isolated launches, one counter set per pass: tools/pmc_r02.sh, run by tools/profile_r03.sh); they are not
             # re-measured by this run and are labelled so
             pmc_case = {"conv2+conv3.fwd(fused)": "conv23.fwd", "fc1.fwd": "fc1.fwd",
                         "fc1+fc2.fwd(head sums fc1's slabs)": "fc1.fwd",
