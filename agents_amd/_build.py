@@ -32,6 +32,7 @@ SOURCES = [
     ("nn.hip", ["-ffp-contract=off"]),
     ("dense_small.hip", []),
     ("mlp_small.hip", []),
+    ("mlp_wide.hip", ["-ffp-contract=off"]),
     ("dqn.hip", ["-ffp-contract=off"]),
     ("optim.hip", ["-ffp-contract=off"]),
     ("rollout.hip", ["-ffp-contract=off"]),

@@ -53,6 +53,23 @@ class MlpLayout(Structure):
                 ("k_off", c_int64 * 4), ("b_off", c_int64 * 4)]
 
 
+class MlpWideFwd(Structure):
+    """aa_mlp_wide_fwd (include/agents_amd.h)."""
+    _fields_ = [("layout", MlpLayout), ("n_nets", c_int32), ("x_split", c_int32), ("B", c_int64),
+                ("params", c_void_p * 4), ("x", c_void_p * 4), ("ldx", c_int64 * 4),
+                ("x2", c_void_p * 4), ("ldx2", c_int64 * 4), ("y", (c_void_p * 4) * 4)]
+
+
+class MlpWideBwd(Structure):
+    """aa_mlp_wide_bwd (include/agents_amd.h)."""
+    _fields_ = [("layout", MlpLayout), ("n_nets", c_int32), ("x_split", c_int32), ("B", c_int64),
+                ("params", c_void_p * 4), ("x", c_void_p * 4), ("ldx", c_int64 * 4),
+                ("x2", c_void_p * 4), ("ldx2", c_int64 * 4), ("y", (c_void_p * 4) * 4),
+                ("dout", c_void_p * 4), ("ld_dout", c_int64 * 4), ("dz", (c_void_p * 4) * 4),
+                ("dx", c_void_p * 4), ("ld_dx", c_int64 * 4), ("dx_lo", c_int32),
+                ("dx_hi", c_int32), ("grads", c_void_p * 4)]
+
+
 class PpoFusedDesc(Structure):
     """aa_ppo_fused_desc (include/agents_amd.h)."""
     _fields_ = [("obs", c_void_p), ("ld_obs", c_int64), ("obs_dim", c_int32), ("D", c_int32),
@@ -155,6 +172,10 @@ _SIGNATURES = {
                                      POINTER(c_int32), POINTER(c_int64), POINTER(c_int64), c_int64,
                                      POINTER(c_void_p), c_void_p]),
     "aa_mlp_small_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "aa_mlp_wide_supported": (c_int, [POINTER(MlpLayout), c_int64]),
+    "aa_mlp_wide_forward": (c_int, [POINTER(MlpWideFwd), c_void_p]),
+    "aa_mlp_wide_backward": (c_int, [POINTER(MlpWideBwd), c_void_p]),
+    "aa_mlp_wide_debug_stamps": (c_int, [c_void_p]),
     "aa_mlp_small_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int32, POINTER(c_int32),
                                       POINTER(c_int32), POINTER(c_int64), POINTER(c_int64), c_int64,
                                       POINTER(c_void_p), c_void_p, c_void_p, c_int64, c_void_p,

@@ -27,6 +27,7 @@ import torch
 from agents_amd import _lib, ops
 from agents_amd.agents import tf_agent
 from agents_amd.networks import actor_distribution_network as adn
+from agents_amd.networks import critic_network
 from agents_amd.policies import tf_policy
 from agents_amd.trajectories import policy_step
 from agents_amd.utils import common, graph, nest_utils
@@ -325,7 +326,11 @@ class SacAgent(tf_agent.TFAgent):
         xc = self._xcat
         fast = xc is not None and xc["obs1"].data_ptr() == next_obs.data_ptr() and \
             xc["obs0"].data_ptr() == obs.data_ptr()
-        branches = SAC_BRANCHES and fast
+        # twin critics per launch, [observation | action] read in place (csrc/mlp_wide.hip)
+        pair = critic_network.pair_ok(self._critic_network_1, self._critic_network_2, obs, actions) \
+            and critic_network.pair_ok(self._target_critic_network_1,
+                                       self._target_critic_network_2, next_obs, actions)
+        branches = SAC_BRANCHES and fast and not pair
         main = torch.cuda.current_stream(dev)
         if branches:
             # the online critics only need the batch: they start while the actor still samples
@@ -341,11 +346,18 @@ class SacAgent(tf_agent.TFAgent):
         na, nlogp, _ = self._policy.sample(next_obs, slot="next", eps=eps_next,
                                            save=w.get("save_next"))
         x_next = x_sa = None
-        if fast:
+        if fast and not pair:
             # [observation | action] once for both twin critics; the observation halves are there
             x_next, x_sa = xc["x_next"], xc["x_sa"]
             ops.copy_segments([(na.reshape(B, -1), x_next[:, self._O:])])
-        if branches:
+        if pair:
+            tq1, tq2 = critic_network.forward_pair(
+                self._target_critic_network_1, self._target_critic_network_2, next_obs, na,
+                slot="target")
+            q1, q2 = critic_network.forward_pair(
+                self._critic_network_1, self._critic_network_2, obs, actions, slot="critic",
+                need_grad=need_grad)
+        elif branches:
             sides[2].wait_stream(main)
             with ops.side_line(sides[2]):
                 tq2 = self._target_critic_network_2.forward(next_obs, na, slot="target",
@@ -369,7 +381,10 @@ class SacAgent(tf_agent.TFAgent):
             w["dq1"].data_ptr() if need_grad else None, w["dq2"].data_ptr() if need_grad else None,
             _lib.stream_ptr()), "aa_sac_critic_loss")
         if need_grad:
-            if branches:
+            if pair:
+                critic_network.backward_pair(self._critic_network_1, self._critic_network_2,
+                                             w["dq1"], w["dq2"], slot="critic")
+            elif branches:
                 sides[0].wait_stream(main)
                 with ops.side_line(sides[0]):
                     self._critic_network_2.backward(w["dq2"], slot="critic")
@@ -389,11 +404,18 @@ class SacAgent(tf_agent.TFAgent):
                                 save=w["save"] if need_grad else None)
         x_pi = None
         xc = self._xcat
-        if xc is not None and xc["obs0"].data_ptr() == obs.data_ptr():
-            x_pi = xc["x_pi"]
-            ops.copy_segments([(a.reshape(B, -1), x_pi[:, self._O:])])
-        q1 = self._critic_network_1.forward(obs, a, slot="actor_q", need_grad=need_grad, x_cat=x_pi)
-        q2 = self._critic_network_2.forward(obs, a, slot="actor_q", need_grad=need_grad, x_cat=x_pi)
+        pair = critic_network.pair_ok(self._critic_network_1, self._critic_network_2, obs, a)
+        if pair:
+            q1, q2 = critic_network.forward_pair(self._critic_network_1, self._critic_network_2,
+                                                 obs, a, slot="actor_q", need_grad=need_grad)
+        else:
+            if xc is not None and xc["obs0"].data_ptr() == obs.data_ptr():
+                x_pi = xc["x_pi"]
+                ops.copy_segments([(a.reshape(B, -1), x_pi[:, self._O:])])
+            q1 = self._critic_network_1.forward(obs, a, slot="actor_q", need_grad=need_grad,
+                                                x_cat=x_pi)
+            q2 = self._critic_network_2.forward(obs, a, slot="actor_q", need_grad=need_grad,
+                                                x_cat=x_pi)
         _lib.check(lib.aa_sac_actor_loss(
             q1.data_ptr(), q2.data_ptr(), logp.data_ptr(), _lib.ptr(weights),
             self._log_alpha_buf.data_ptr(), self._actor_loss_weight, B,
@@ -403,10 +425,15 @@ class SacAgent(tf_agent.TFAgent):
             "aa_sac_actor_loss")
         if need_grad:
             # d loss / d action through BOTH critics (their weights are not touched here)
-            da1 = self._critic_network_1.backward(w["dq1"], slot="actor_q", param_grads=False,
-                                                  want_action_grad=True)
-            da2 = self._critic_network_2.backward(w["dq2"], slot="actor_q", param_grads=False,
-                                                  want_action_grad=True)
+            if pair:
+                da1, da2 = critic_network.backward_pair(
+                    self._critic_network_1, self._critic_network_2, w["dq1"], w["dq2"],
+                    slot="actor_q", param_grads=False, want_action_grad=True)
+            else:
+                da1 = self._critic_network_1.backward(w["dq1"], slot="actor_q",
+                                                      param_grads=False, want_action_grad=True)
+                da2 = self._critic_network_2.backward(w["dq2"], slot="actor_q",
+                                                      param_grads=False, want_action_grad=True)
             # da = da1 + da2: both are column slices of the critics' input-gradient buffers
             _lib.check(lib.aa_add_strided_f32(da1.data_ptr(), da1.stride(0), da2.data_ptr(),
                                               da2.stride(0), B, self._A, w["da"].data_ptr(),

@@ -1,0 +1,695 @@
+// Whole MLPs of "wide" Dense layers (every hidden / output width <= 256, input <= 1024) at small
+// batch, forward in ONE launch and backward in TWO, for up to four networks of the same layout per
+// launch -- the actor and the twin (target) critics of SAC at batch 256
+// (tf_agents/agents/sac/sac_agent.py:286-330 train; networks/critic_network.py:150-170 and
+// actor_distribution_network.py: (256, 256) hidden layers in examples/sac/haarnoja18).
+//
+// Why: one SAC train step is ~40 Dense contractions of 25-50 MFLOP.  As one MFMA GEMM launch each
+// (plus a split-K reduce, plus copies that build [observation | action]) the step was ~105
+// launches of 4.5-8 us, i.e. bound by launch latency and by the dependent round trips of every
+// launch (profiles/r03_a_sac_kernel_stats.csv), not by arithmetic or bytes.  Here:
+//   forward  : a workgroup owns FOUR samples and walks all layers.  Activations live in LDS,
+//              transposed ([feature][4 samples] -> one broadcast 16-byte read per feature); the
+//              weights are streamed once per workgroup straight from L2: wave q takes an eighth
+//              of the layer's input features, lane c four output columns, so a wave reads whole
+//              rows of W (1 KiB, coalesced) with sixteen rows in flight per lane and does 16 FMAs
+//              per 16-byte load.  Partial sums meet in LDS in wave order (deterministic).  The
+//              first layer can read its input from two tensors ([observation | action]).
+//   backward : (1) the gradient chain g_l -> dz_l = g_l * act'(y_l) -> g_{l-1} = dz_l W_l^T, again
+//              four samples per workgroup; W_l^T is never formed: 32-row tiles of W go to LDS
+//              with coalesced loads and are read back row-per-lane.  dz_l is written for (2);
+//              the input gradient is optional and can be limited to a column range (the action
+//              columns of a critic's input in SAC's actor loss).
+//              (2) every weight gradient dW_l = H_{l-1}^T dz_l (+ bias column sums) of every layer
+//              and network in one grid of 32 x 32 tiles on the fp32 matrix cores, full batch per
+//              tile (no split-K slabs); written, not accumulated.
+// At four samples per workgroup a batch of 256 is 64 workgroups per network, each streaming the
+// network's weights (0.66 MB for a SAC critic) at the ~64 B/clk a CU draws from L2: ~4 us, against
+// which the 16 FMAs per loaded float4 are balanced (2.6 us of VALU for the widest layer).  For
+// batches in the thousands the GEMM path (gemm.hip) is the better plan: callers use this one up
+// to AA_MLPW_MAX_BATCH samples.
+#include "common.h"
+#include "agents_amd.h"
+
+#define MW_THREADS 512
+#define MW_WAVES 8
+#define MW_TS 4
+#define MW_MAXW 256
+#define MW_MAXIN 1024
+#define MW_U 8           // weight rows per batch, two batches in flight per lane (forward)
+#define MW_WT_LD (MW_MAXW + 4)
+
+typedef float mw_f4 __attribute__((ext_vector_type(4)));
+
+__device__ static inline float mw_act(float v, int act) {
+  if (act == AA_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == AA_ACT_TANH) return tanhf(v);
+  return v;
+}
+__device__ static inline float mw_actgrad(float y, int act) {
+  if (act == AA_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (act == AA_ACT_TANH) return 1.f - y * y;
+  return 1.f;
+}
+
+struct MwNetF {
+  const float* params;
+  const float* x;
+  const float* x2;
+  int64_t ldx, ldx2;
+  float* y[AA_MLP_MAX_LAYERS];
+};
+struct MwFwdP {
+  aa_mlp_layout lay;
+  MwNetF net[AA_MLPW_MAX_NETS];
+  int64_t B;
+  int x_split;
+};
+
+__global__ void __launch_bounds__(MW_THREADS) aa_mlp_wide_fwd_kernel(MwFwdP p) {
+  __shared__ mw_f4 hin[MW_MAXIN];               // input features of the 4 samples
+  __shared__ mw_f4 hid[2][MW_MAXW];             // hidden activations, ping-pong
+  __shared__ __attribute__((aligned(16))) float red[MW_WAVES][MW_TS][MW_MAXW];
+  const int g = blockIdx.y;
+  const int64_t s0 = (int64_t)blockIdx.x * MW_TS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* __restrict__ params = p.net[g].params;
+  {
+    const float* __restrict__ x = p.net[g].x;
+    const float* __restrict__ x2 = p.net[g].x2;
+    const int64_t ldx = p.net[g].ldx, ldx2 = p.net[g].ldx2;
+    const int n0 = p.lay.dims[0], split = p.x_split;
+    float* hf = reinterpret_cast<float*>(hin);
+    for (int i = tid; i < n0 * MW_TS; i += MW_THREADS) {
+      const int s = i / n0, k = i - s * n0;
+      float v = 0.f;
+      if (s0 + s < p.B)
+        v = k < split ? x[(s0 + s) * ldx + k] : x2[(s0 + s) * ldx2 + (k - split)];
+      hf[k * MW_TS + s] = v;
+    }
+  }
+  __syncthreads();
+  const mw_f4* hcur = hin;
+  const int L = p.lay.n_layers;
+  for (int l = 0; l < L; ++l) {
+    const int n_in = p.lay.dims[l], n_out = p.lay.dims[l + 1];
+    const float* __restrict__ W = params + p.lay.k_off[l];
+    const float* __restrict__ bias = params + p.lay.b_off[l];
+    // the (<= 2) outputs this thread finishes after the reduction, and their biases: requested
+    // now, needed after the weight stream
+    const int i_a = tid, i_b = tid + MW_THREADS;
+    const int s_a = i_a / n_out, c_a = i_a - s_a * n_out;
+    const int s_b = i_b / n_out, c_b = i_b - s_b * n_out;
+    const float bias_a = i_a < MW_TS * n_out ? bias[c_a] : 0.f;
+    const float bias_b = i_b < MW_TS * n_out ? bias[c_b] : 0.f;
+    float acc[MW_TS][4];
+#pragma unroll
+    for (int s = 0; s < MW_TS; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[s][j] = 0.f;
+    const bool vec = (n_out & 3) == 0 && (((uintptr_t)W) & 15) == 0 && n_out > 64;
+    if (vec) {
+      // wave q: rows [kb, ke) (a multiple of MW_U except for the last wave); lane c: four columns
+      int kq = (n_in + MW_WAVES - 1) / MW_WAVES;
+      kq = ((kq + MW_U - 1) / MW_U) * MW_U;
+      const int kb = wave * kq < n_in ? wave * kq : n_in;
+      const int ke = kb + kq < n_in ? kb + kq : n_in;
+      const int c4 = lane * 4;
+      if (c4 < n_out) {
+        // two batches of MW_U rows: the next batch's loads are in flight while this one is
+        // multiplied.  The steady-state loop is straight-line code (no per-row guards: the
+        // compiler then counts the outstanding loads exactly and waits for ONE batch).
+        mw_f4 wa[MW_U], wb[MW_U];
+        const float* __restrict__ Wc = W + c4;
+#define MW_LOAD(w, kk)                                   \
+  _Pragma("unroll") for (int u = 0; u < MW_U; ++u)       \
+      (w)[u] = *reinterpret_cast<const mw_f4*>(Wc + (int64_t)((kk) + u) * n_out);
+#define MW_FMA(w, kk)                                                                    \
+  _Pragma("unroll") for (int u = 0; u < MW_U; ++u) {                                     \
+    const mw_f4 h = hcur[(kk) + u];                                                      \
+    _Pragma("unroll") for (int s = 0; s < MW_TS; ++s)                                    \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[s][j] =                        \
+            fmaf(h[s], (w)[u][j], acc[s][j]);                                            \
+  }
+        const int kfull = kb + ((ke - kb) / MW_U) * MW_U;
+        int k = kb;
+        if (k < kfull) {
+          MW_LOAD(wa, k)
+          while (true) {
+            if (k + MW_U < kfull) { MW_LOAD(wb, k + MW_U) }
+            MW_FMA(wa, k)
+            k += MW_U;
+            if (k >= kfull) break;
+            if (k + MW_U < kfull) { MW_LOAD(wa, k + MW_U) }
+            MW_FMA(wb, k)
+            k += MW_U;
+            if (k >= kfull) break;
+          }
+        }
+#undef MW_LOAD
+#undef MW_FMA
+        for (; k < ke; ++k) {   // the last wave's remainder
+          const mw_f4 w = *reinterpret_cast<const mw_f4*>(Wc + (int64_t)k * n_out);
+          const mw_f4 h = hcur[k];
+#pragma unroll
+          for (int s = 0; s < MW_TS; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[s][j] = fmaf(h[s], w[j], acc[s][j]);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < MW_TS; ++s)
+        *reinterpret_cast<mw_f4*>(&red[wave][s][c4]) =
+            mw_f4{acc[s][0], acc[s][1], acc[s][2], acc[s][3]};
+    } else {
+      // narrow layer (a head: 1, 6, 34 ... columns) or an odd width: a lane owns ONE column and a
+      // share of the rows -- cg column slots (the power of two >= n_out, <= 64... 256), 512 / cg row
+      // groups -- so that all lanes load at once even for a single output column
+      int cg = 1;
+      while (cg < n_out) cg <<= 1;
+      const int col = tid & (cg - 1);
+      const int kg = tid / cg, nkg = MW_THREADS / cg;
+      float a1[MW_TS] = {0.f, 0.f, 0.f, 0.f};
+      if (col < n_out) {
+        int k = kg;
+        for (; k + 3 * nkg < n_in; k += 4 * nkg) {
+          float w[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) w[u] = W[(int64_t)(k + u * nkg) * n_out + col];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const mw_f4 h = hcur[k + u * nkg];
+#pragma unroll
+            for (int s = 0; s < MW_TS; ++s) a1[s] = fmaf(h[s], w[u], a1[s]);
+          }
+        }
+        for (; k < n_in; k += nkg) {
+          const float w = W[(int64_t)k * n_out + col];
+          const mw_f4 h = hcur[k];
+#pragma unroll
+          for (int s = 0; s < MW_TS; ++s) a1[s] = fmaf(h[s], w, a1[s]);
+        }
+      }
+      // lanes of a wave that share a column: lane, lane + cg, lane + 2 cg ... (cg < 64)
+      for (int off = 32; off >= cg; off >>= 1)
+#pragma unroll
+        for (int s = 0; s < MW_TS; ++s) a1[s] += __shfl_down(a1[s], off, 64);
+      // red[wave][s][col]: for cg >= 64 a wave holds 64 / ... one row group per (wave, col / 64)
+      if (cg <= 64) {
+        if (lane < cg) {
+#pragma unroll
+          for (int s = 0; s < MW_TS; ++s) red[wave][s][lane] = col < n_out ? a1[s] : 0.f;
+        }
+      } else {
+        // cg = 128 / 256: nkg = 4 / 2 row groups; this thread's sum goes to slot kg
+#pragma unroll
+        for (int s = 0; s < MW_TS; ++s) red[kg][s][col] = col < n_out ? a1[s] : 0.f;
+        // the other slots of the fixed eight-term sum below hold zeros
+        for (int q = nkg + (tid / cg); q < MW_WAVES; q += nkg)
+#pragma unroll
+          for (int s = 0; s < MW_TS; ++s) red[q][s][col] = 0.f;
+      }
+    }
+    __syncthreads();
+    float* __restrict__ y = p.net[g].y[l];
+    float* hn = reinterpret_cast<float*>(hid[l & 1]);
+    const int act = p.lay.acts[l];
+    if (i_a < MW_TS * n_out) {
+      float v = bias_a;
+#pragma unroll
+      for (int q = 0; q < MW_WAVES; ++q) v += red[q][s_a][c_a];
+      v = mw_act(v, act);
+      if (s0 + s_a < p.B) y[(s0 + s_a) * n_out + c_a] = v;
+      hn[c_a * MW_TS + s_a] = v;
+    }
+    if (i_b < MW_TS * n_out) {
+      float v = bias_b;
+#pragma unroll
+      for (int q = 0; q < MW_WAVES; ++q) v += red[q][s_b][c_b];
+      v = mw_act(v, act);
+      if (s0 + s_b < p.B) y[(s0 + s_b) * n_out + c_b] = v;
+      hn[c_b * MW_TS + s_b] = v;
+    }
+    __syncthreads();
+    hcur = hid[l & 1];
+  }
+}
+
+// ---- backward (1): the gradient chain ---------------------------------------------------------------
+struct MwNetB {
+  const float* params;
+  const float* y[AA_MLP_MAX_LAYERS];
+  const float* dout;
+  int64_t ld_dout;
+  float* dz[AA_MLP_MAX_LAYERS];
+  float* dx;
+  int64_t ld_dx;
+};
+struct MwBwdP {
+  aa_mlp_layout lay;
+  MwNetB net[AA_MLPW_MAX_NETS];
+  int64_t B;
+  int dx_lo, dx_hi;
+  long long* stamps;   // nullable (aa_mlp_wide_debug_stamps): [workgroup][16] wall_clock64 ticks
+};
+static long long* g_mw_stamps = nullptr;
+#define MW_STAMP(i)                                  \
+  if (p.stamps != nullptr && threadIdx.x == 0)       \
+    p.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64();
+
+// Sixteen samples per workgroup, the products on the fp32 matrix cores: g_{l-1}[s][i] =
+// sum_o dz[s][o] W[i][o] is a [16 samples] x [16 rows of W] block per MFMA chain, A = dz from LDS,
+// B = W straight from L2 -- the contraction index o is dealt to the four k-slots of the
+// instruction as o = 16 b + 4 slot + step, so a lane's four steps read four CONSECUTIVE floats of
+// its row of W (one 16-byte load) and of its sample's dz (one 16-byte LDS read).  The matrix core
+// does the cross-lane sum that a VALU formulation pays for with an LDS transpose of W and two
+// barriers per 32 rows (18 us per launch against ~10).
+#define MW_CS 16   // samples per workgroup of the chain kernel
+#define MW_CTHREADS 1024
+#define MW_CWAVES 16
+#define MW_CE (MW_CS * MW_MAXW / MW_CTHREADS)   // (sample, column) elements per thread and layer
+
+// Workgroup barrier that only waits for this wave's LDS traffic: __syncthreads() carries a release
+// fence that also drains the vector-memory counter, i.e. the dz stores (read by the NEXT launch)
+// and the prefetched rows of W (waited for where they are used) -- 2 us per layer on the in-kernel
+// timeline.
+__device__ static inline void mw_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+typedef float mw_acc4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(MW_CTHREADS) aa_mlp_wide_chain_kernel(MwBwdP p) {
+  __shared__ __attribute__((aligned(16))) float dzs[MW_CS][MW_MAXW + 4];
+  __shared__ __attribute__((aligned(16))) float gs[MW_CS][MW_MAXW + 4];
+  const int g = blockIdx.y;
+  const int64_t s0 = (int64_t)blockIdx.x * MW_CS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* __restrict__ params = p.net[g].params;
+  const int L = p.lay.n_layers;
+  MW_STAMP(0)
+  // the saved activations (act' factors) of a layer are requested one layer AHEAD of their use:
+  // behind the weight rows of sixteen waves in the CU's memory pipeline they arrive 4 us late
+  float yv[MW_CE];
+#define MW_YLOAD(LL)                                                          \
+  {                                                                           \
+    const int n_ = p.lay.dims[(LL) + 1];                                      \
+    const float* __restrict__ y_ = p.net[g].y[LL];                            \
+    _Pragma("unroll") for (int h = 0; h < MW_CE; ++h) {                       \
+      const int s = (tid >> 8) + (MW_CTHREADS / 256) * h, c = tid & 255;      \
+      const bool live = c < n_ && s0 + s < p.B;                               \
+      yv[h] = y_[live ? (s0 + s) * n_ + c : 0];                               \
+    }                                                                         \
+  }
+  MW_YLOAD(L - 1)
+  {
+    const float* __restrict__ dout = p.net[g].dout;
+    const int64_t ld = p.net[g].ld_dout;
+    const int n = p.lay.dims[L];
+#pragma unroll
+    for (int h = 0; h < MW_CE; ++h) {
+      const int s = (tid >> 8) + (MW_CTHREADS / 256) * h, c = tid & 255;
+      if (c < n) gs[s][c] = s0 + s < p.B ? dout[(s0 + s) * ld + c] : 0.f;
+    }
+  }
+  mw_lds_barrier();
+  MW_STAMP(1)
+  const int lr = lane & 15, lk = lane >> 4;
+  // (a run-time loop over the layers: unrolled, the kernel was 100 KB of code that every launch
+  // had to pull through the instruction cache first)
+  for (int l = L - 1; l >= 0; --l) {
+    const int n_in = p.lay.dims[l], n_out = p.lay.dims[l + 1];
+    const float* __restrict__ W = params + p.lay.k_off[l];
+    float* __restrict__ dz = p.net[g].dz[l];
+    const int act = p.lay.acts[l];
+    const int n16 = (n_out + 15) & ~15;
+    int lo = 0, hi = n_in;
+    float* __restrict__ dx = nullptr;
+    if (l == 0) {
+      dx = p.net[g].dx;
+      lo = dx != nullptr ? p.dx_lo : 0;
+      hi = dx != nullptr ? p.dx_hi : 0;
+    }
+    // layers whose width is a multiple of 16 go to the matrix cores; the others (heads: 1, 34
+    // columns) take a plain FMA loop, one lane per row
+    const bool mfma = hi > lo && (n_out & 15) == 0 && (((uintptr_t)W) & 15) == 0;
+    const int nblk = hi > lo ? (hi - lo + 15) >> 4 : 0;
+    const bool full = n_out == MW_MAXW;
+    const int64_t ld_dx = p.net[g].ld_dx;
+    // The rows of W this wave multiplies do not depend on the chain: its first 16-row block
+    // (sixteen waves: all of a 256-row layer) is requested BEFORE the dz phase and its barrier, so one round
+    // trip per layer is shared by the weights and the phase that produces their other operand.
+    // The loads are UNCONDITIONAL, from clamped addresses: a load under a per-lane condition is
+    // merged with its zero alternative at the join and waited for right there.  Rows beyond the
+    // range are never stored.
+    mw_f4 wv[1][MW_MAXW / 16];
+#define MW_ROWS(slot, blk_)                                                 \
+  {                                                                         \
+    int i_ = lo + (blk_) * 16 + lr;                                         \
+    i_ = i_ < hi ? i_ : hi - 1;                                             \
+    i_ = i_ > lo ? i_ : lo;                                                 \
+    const float* __restrict__ wr_ = W + (int64_t)i_ * n_out + 4 * lk;       \
+    if (full) { /* 256 columns: straight-line loads, which the compiler can COUNT (it then  \
+                   waits for exactly the loads an instruction needs; behind a branch it     \
+                   waits for all of them) */                                                \
+      _Pragma("unroll") for (int q = 0; q < MW_MAXW / 16; ++q)              \
+        wv[slot][q] = *reinterpret_cast<const mw_f4*>(wr_ + q * 16);        \
+    } else {                                                                \
+      _Pragma("unroll") for (int q = 0; q < MW_MAXW / 16; ++q)              \
+        if (q * 16 < n_out) /* (uniform) */                                 \
+          wv[slot][q] = *reinterpret_cast<const mw_f4*>(wr_ + q * 16);      \
+    }                                                                       \
+  }
+#define MW_BLOCK(slot, blk_)                                                                 \
+  if ((blk_) < nblk) {                                                                       \
+    mw_acc4 acc_ = {0.f, 0.f, 0.f, 0.f};                                                     \
+    _Pragma("unroll") for (int q = 0; q < MW_MAXW / 16; ++q) {                               \
+      if (q * 16 < n16) {                                                                    \
+        const mw_f4 av_ = *reinterpret_cast<const mw_f4*>(&dzs[lr][q * 16 + 4 * lk]);        \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) acc_ =                                 \
+            __builtin_amdgcn_mfma_f32_16x16x4f32(av_[t], wv[slot][q][t], acc_, 0, 0, 0);    \
+      }                                                                                      \
+    }                                                                                        \
+    /* acc_[r] = g_prev[sample 4 lk + r][row lo + blk * 16 + lr] */                          \
+    const int i_ = lo + (blk_) * 16 + lr;                                                    \
+    if (i_ < hi) {                                                                           \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                        \
+        const int s_ = 4 * lk + r;                                                           \
+        if (l > 0) gs[s_][i_] = acc_[r];                                                     \
+        else if (s0 + s_ < p.B) dx[(s0 + s_) * ld_dx + i_] = acc_[r];                        \
+      }                                                                                      \
+    }                                                                                        \
+  }
+    // the act' factors (requested a layer ago) are pinned in registers BEFORE the rows are
+    // requested: a wait for them placed after the row loads would have to be a wait for
+    // everything (the number of row loads differs between the branches above)
+#pragma unroll
+    for (int h = 0; h < MW_CE; ++h) asm volatile("" ::"v"(yv[h]));
+    if (mfma) {
+      MW_ROWS(0, wave)
+    }
+    if (l == L - 2) { MW_STAMP(10) }
+    // dz = g * act'(y); columns up to the next multiple of 16 are zero for the MFMA loop
+#pragma unroll
+    for (int h = 0; h < MW_CE; ++h) {
+      const int s = (tid >> 8) + (MW_CTHREADS / 256) * h, c = tid & 255;
+      if (c < n_out) {
+        const float d = s0 + s < p.B ? gs[s][c] * mw_actgrad(yv[h], act) : 0.f;
+        dzs[s][c] = d;
+        if (s0 + s < p.B) dz[(s0 + s) * n_out + c] = d;
+      }
+    }
+    if (l == L - 2) { MW_STAMP(11) }
+    if (n16 != n_out && tid < MW_CS * 16) {      // (sample, one of <= 15 padding columns)
+      const int s = tid >> 4, c = n_out + (tid & 15);
+      if (c < n16) dzs[s][c] = 0.f;
+    }
+    mw_lds_barrier();
+    MW_STAMP(2 + 2 * (L - 1 - l))
+    if (l > 0) { MW_YLOAD(l - 1) }   // (yv was consumed by the dz phase above)
+    if (mfma) {
+      MW_BLOCK(0, wave)
+      for (int blk = wave + MW_CWAVES; blk < nblk; blk += MW_CWAVES) {   // > 256 rows
+        MW_ROWS(0, blk)
+        MW_BLOCK(0, blk)
+      }
+    } else if (hi > lo) {
+      for (int i = lo + tid; i < hi; i += MW_CTHREADS) {
+        const float* __restrict__ wr = W + (int64_t)i * n_out;
+#pragma unroll 1
+        for (int sb = 0; sb < MW_CS; sb += 8) {       // eight samples at a time (registers)
+          float acc[8];
+#pragma unroll
+          for (int s = 0; s < 8; ++s) acc[s] = 0.f;
+          for (int o = 0; o < n_out; ++o) {
+            const float w = wr[o];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc[s] = fmaf(dzs[sb + s][o], w, acc[s]);
+          }
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            if (l > 0) gs[sb + s][i] = acc[s];
+            else if (s0 + sb + s < p.B) dx[(s0 + sb + s) * ld_dx + i] = acc[s];
+          }
+        }
+      }
+    }
+#undef MW_ROWS
+#undef MW_BLOCK
+    mw_lds_barrier();
+    MW_STAMP(3 + 2 * (L - 1 - l))
+  }
+#undef MW_YLOAD
+}
+
+// ---- backward (2): every dW / db of every layer and network ------------------------------------------
+struct MwNetW {
+  const float* x;
+  const float* x2;
+  int64_t ldx, ldx2;
+  const float* y[AA_MLP_MAX_LAYERS];
+  const float* dz[AA_MLP_MAX_LAYERS];
+  float* grads;
+};
+struct MwDwP {
+  aa_mlp_layout lay;
+  MwNetW net[AA_MLPW_MAX_NETS];
+  int64_t B;
+  int x_split;
+  int tile_start[AA_MLP_MAX_LAYERS + 1];
+};
+
+__global__ void __launch_bounds__(256) aa_mlp_wide_dw_kernel(MwDwP p) {
+  __shared__ float part[4][32][33];
+  __shared__ float bsum[8][32];
+  const int g = blockIdx.y;
+  const int t = blockIdx.x;
+  int l = 0;
+  while (l + 1 < p.lay.n_layers && t >= p.tile_start[l + 1]) ++l;
+  const int n_in = p.lay.dims[l], n_out = p.lay.dims[l + 1];
+  const int tn_count = (n_out + 31) / 32;
+  const int local = t - p.tile_start[l];
+  const int tm = local / tn_count, tn = local - tm * tn_count;
+  const int i0 = tm * 32, o0 = tn * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // layer input H [B][n_in]: the network input (two tensors) or the previous layer's output
+  const float* __restrict__ H = l == 0 ? p.net[g].x : p.net[g].y[l - 1];
+  const float* __restrict__ H2 = p.net[g].x2;
+  const int64_t ldh = l == 0 ? p.net[g].ldx : (int64_t)n_in;
+  const int64_t ldh2 = p.net[g].ldx2;
+  const int split = l == 0 ? p.x_split : n_in;
+  const float* __restrict__ dz = p.net[g].dz[l];
+  const int B = (int)p.B;
+  int kq = (B + 3) / 4;
+  kq = (kq + 3) & ~3;
+  const int kb = wave * kq;
+  const int ke = kb + kq < B ? kb + kq : B;
+  mw_acc4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = mw_acc4{0.f, 0.f, 0.f, 0.f};
+  const int lr = lane & 15, lk = lane >> 4;
+  // chunks of 64 samples: every operand of the chunk is requested before the first MFMA (one
+  // round trip per chunk -- a batch of 256 is one chunk per wave)
+  for (int k0 = kb; k0 < ke; k0 += 64) {
+    float av[16][2], bv[16][2];
+    // loads from clamped (always valid) addresses first, masks afterwards: a load under a
+    // condition is waited for at the join with its zero alternative, one round trip each
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      int k = k0 + u * 4 + lk;
+      k = k < ke ? k : ke - 1;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        int i = i0 + m * 16 + lr;
+        i = i < n_in ? i : n_in - 1;
+        const float* src = i < split ? H + (int64_t)k * ldh + i : H2 + (int64_t)k * ldh2 + (i - split);
+        av[u][m] = *src;
+        int o = o0 + m * 16 + lr;
+        o = o < n_out ? o : n_out - 1;
+        bv[u][m] = dz[(int64_t)k * n_out + o];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const bool kin = k0 + u * 4 + lk < ke;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        if (!(kin && i0 + m * 16 + lr < n_in)) av[u][m] = 0.f;
+        if (!(kin && o0 + m * 16 + lr < n_out)) bv[u][m] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[wave][a * 16 + 4 * lk + r][b * 16 + lr] = acc[a][b][r];
+  // bias gradient: column sums of dz over the batch, by the tiles of the first row band
+  const bool do_bias = tm == 0;
+  if (do_bias) {
+    const int c = tid & 31, kg = tid >> 5;
+    float sacc = 0.f;
+    if (o0 + c < n_out)
+      for (int k = kg; k < B; k += 8) sacc += dz[(int64_t)k * n_out + o0 + c];
+    bsum[kg][c] = sacc;
+  }
+  __syncthreads();
+  float* __restrict__ grads = p.net[g].grads;
+  for (int e = tid; e < 32 * 32; e += 256) {
+    const int r = e >> 5, c = e & 31;
+    const float v = ((part[0][r][c] + part[1][r][c]) + part[2][r][c]) + part[3][r][c];
+    if (i0 + r < n_in && o0 + c < n_out)
+      grads[p.lay.k_off[l] + (int64_t)(i0 + r) * n_out + o0 + c] = v;
+  }
+  if (do_bias && tid < 32 && o0 + tid < n_out) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v += bsum[q][tid];
+    grads[p.lay.b_off[l] + o0 + tid] = v;
+  }
+}
+
+static int mw_check_layout(const aa_mlp_layout* lay) {
+  if (lay->n_layers < 1 || lay->n_layers > AA_MLP_MAX_LAYERS) return AA_ERR_RANGE;
+  if (lay->dims[0] < 1 || lay->dims[0] > MW_MAXIN) return AA_ERR_RANGE;
+  for (int l = 0; l < lay->n_layers; ++l) {
+    if (lay->dims[l + 1] < 1 || lay->dims[l + 1] > MW_MAXW) return AA_ERR_RANGE;
+    if (lay->k_off[l] < 0 || lay->b_off[l] < 0) return AA_ERR_INVALID;
+    if (lay->acts[l] != AA_ACT_NONE && lay->acts[l] != AA_ACT_RELU && lay->acts[l] != AA_ACT_TANH)
+      return AA_ERR_INVALID;
+  }
+  return AA_OK;
+}
+
+extern "C" {
+
+// Measurement aid (tools/mlp_wide_probe.py): every workgroup of the following
+// aa_mlp_wide_backward launches writes wall_clock64() stamps (10 ns ticks) at the phase boundaries
+// of its gradient chain to buf[workgroup][16]; NULL switches it off again.
+int aa_mlp_wide_debug_stamps(int64_t* buf) {
+  g_mw_stamps = reinterpret_cast<long long*>(buf);
+  return AA_OK;
+}
+
+int aa_mlp_wide_supported(const aa_mlp_layout* layout, int64_t B) {
+  if (layout == nullptr || B < 1 || B > AA_MLPW_MAX_BATCH) return 0;
+  return mw_check_layout(layout) == AA_OK ? 1 : 0;
+}
+
+int aa_mlp_wide_forward(const aa_mlp_wide_fwd* d, void* stream) {
+  if (d == nullptr || d->B < 1 || d->n_nets < 1 || d->n_nets > AA_MLPW_MAX_NETS) return AA_ERR_INVALID;
+  int rc = mw_check_layout(&d->layout);
+  if (rc != AA_OK) return rc;
+  if (d->x_split < 0 || d->x_split > d->layout.dims[0]) return AA_ERR_INVALID;
+  MwFwdP p;
+  p.lay = d->layout;
+  p.B = d->B;
+  p.x_split = d->x_split;
+  for (int g = 0; g < AA_MLPW_MAX_NETS; ++g) {
+    const int s = g < d->n_nets ? g : 0;
+    if (d->params[s] == nullptr) return AA_ERR_INVALID;
+    if (d->x_split > 0 && (d->x[s] == nullptr || d->ldx[s] < d->x_split)) return AA_ERR_INVALID;
+    if (d->x_split < d->layout.dims[0] &&
+        (d->x2[s] == nullptr || d->ldx2[s] < d->layout.dims[0] - d->x_split))
+      return AA_ERR_INVALID;
+    p.net[g].params = d->params[s];
+    p.net[g].x = d->x[s];
+    p.net[g].x2 = d->x2[s];
+    p.net[g].ldx = d->ldx[s];
+    p.net[g].ldx2 = d->ldx2[s];
+    for (int l = 0; l < AA_MLP_MAX_LAYERS; ++l) {
+      if (l < d->layout.n_layers && d->y[s][l] == nullptr) return AA_ERR_INVALID;
+      p.net[g].y[l] = d->y[s][l];
+    }
+  }
+  const int64_t gx = (d->B + MW_TS - 1) / MW_TS;
+  if (gx > 0x7fffffffLL) return AA_ERR_RANGE;
+  hipLaunchKernelGGL(aa_mlp_wide_fwd_kernel, dim3((unsigned)gx, (unsigned)d->n_nets),
+                     dim3(MW_THREADS), 0, (hipStream_t)stream, p);
+  return aa_launch_status();
+}
+
+int aa_mlp_wide_backward(const aa_mlp_wide_bwd* d, void* stream) {
+  if (d == nullptr || d->B < 1 || d->n_nets < 1 || d->n_nets > AA_MLPW_MAX_NETS) return AA_ERR_INVALID;
+  int rc = mw_check_layout(&d->layout);
+  if (rc != AA_OK) return rc;
+  const aa_mlp_layout& lay = d->layout;
+  const int L = lay.n_layers;
+  if (d->x_split < 0 || d->x_split > lay.dims[0]) return AA_ERR_INVALID;
+  const bool want_dx = d->dx[0] != nullptr;
+  const bool want_dw = d->grads[0] != nullptr;
+  if (want_dx && (d->dx_lo < 0 || d->dx_hi > lay.dims[0] || d->dx_lo >= d->dx_hi))
+    return AA_ERR_INVALID;
+  MwBwdP p;
+  p.lay = lay;
+  p.B = d->B;
+  p.dx_lo = d->dx_lo;
+  p.dx_hi = d->dx_hi;
+  p.stamps = g_mw_stamps;
+  MwDwP q;
+  q.lay = lay;
+  q.B = d->B;
+  q.x_split = d->x_split;
+  for (int g = 0; g < AA_MLPW_MAX_NETS; ++g) {
+    const int s = g < d->n_nets ? g : 0;
+    if (d->params[s] == nullptr || d->dout[s] == nullptr || d->ld_dout[s] < lay.dims[L])
+      return AA_ERR_INVALID;
+    if ((d->dx[s] != nullptr) != want_dx || (d->grads[s] != nullptr) != want_dw)
+      return AA_ERR_INVALID;
+    if (want_dx && d->ld_dx[s] < d->dx_hi) return AA_ERR_INVALID;
+    p.net[g].params = d->params[s];
+    p.net[g].dout = d->dout[s];
+    p.net[g].ld_dout = d->ld_dout[s];
+    p.net[g].dx = d->dx[s];
+    p.net[g].ld_dx = d->ld_dx[s];
+    q.net[g].x = d->x[s];
+    q.net[g].x2 = d->x2[s];
+    q.net[g].ldx = d->ldx[s];
+    q.net[g].ldx2 = d->ldx2[s];
+    q.net[g].grads = d->grads[s];
+    for (int l = 0; l < AA_MLP_MAX_LAYERS; ++l) {
+      if (l < L && (d->y[s][l] == nullptr || d->dz[s][l] == nullptr)) return AA_ERR_INVALID;
+      p.net[g].y[l] = d->y[s][l];
+      p.net[g].dz[l] = d->dz[s][l];
+      q.net[g].y[l] = d->y[s][l];
+      q.net[g].dz[l] = d->dz[s][l];
+    }
+    if (want_dw) {
+      if (d->x_split > 0 && (d->x[s] == nullptr || d->ldx[s] < d->x_split)) return AA_ERR_INVALID;
+      if (d->x_split < lay.dims[0] && (d->x2[s] == nullptr || d->ldx2[s] < lay.dims[0] - d->x_split))
+        return AA_ERR_INVALID;
+    }
+  }
+  if (d->B > 0x7fffffffLL) return AA_ERR_RANGE;
+  const int64_t gx = (d->B + MW_TS - 1) / MW_TS;
+  if (gx > 0x7fffffffLL) return AA_ERR_RANGE;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(aa_mlp_wide_chain_kernel,
+                     dim3((unsigned)((d->B + MW_CS - 1) / MW_CS), (unsigned)d->n_nets),
+                     dim3(MW_CTHREADS), 0, st, p);
+  if (want_dw) {
+    int tiles = 0;
+    for (int l = 0; l < L; ++l) {
+      q.tile_start[l] = tiles;
+      tiles += ((lay.dims[l] + 31) / 32) * ((lay.dims[l + 1] + 31) / 32);
+    }
+    for (int l = L; l <= AA_MLP_MAX_LAYERS; ++l) q.tile_start[l] = tiles;
+    hipLaunchKernelGGL(aa_mlp_wide_dw_kernel, dim3((unsigned)tiles, (unsigned)d->n_nets), dim3(256),
+                       0, st, q);
+  }
+  return aa_launch_status();
+}
+
+}  // extern "C"

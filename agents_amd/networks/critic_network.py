@@ -146,9 +146,51 @@ class CriticNetwork(network.Network):
         buf = self._inputs[(slot, B)]
         self._body.backward(dq.view(B, 1), slot=slot, side_stream=side_stream,
                             param_grads=param_grads,
-                            input_grad=buf["dx"] if want_action_grad else None)
+                            input_grad=buf["dx"] if want_action_grad else None,
+                            input_grad_cols=(self._obs_dim, self._obs_dim + self._act_dim))
         return buf["dx"][:, self._obs_dim:] if want_action_grad else None
 
     def call(self, inputs, step_type=None, network_state=(), training=False, **kwargs):
         obs, act = inputs
         return self.forward(obs, act, slot="call").clone(), network_state
+
+
+# ---- twin critics in one launch (csrc/mlp_wide.hip through networks/sequential.py) -------------------
+def pair_ok(c1, c2, observation, action):
+    """True when `forward_pair` / `backward_pair` run BOTH critics per launch: their bodies share a
+    layout the wide-MLP kernels take at this batch size, and (observation, action) are float32
+    device tensors with unit column stride (they are read in place: no [obs | act] copy)."""
+    B = int(observation.shape[0])
+    o2, a2 = observation.reshape(B, -1), action.reshape(B, -1)
+    return (isinstance(c1, CriticNetwork) and isinstance(c2, CriticNetwork) and
+            c1.body.wide_ok(B) and c1.body.wide_key() is not None and
+            c1.body.wide_key() == c2.body.wide_key() and
+            o2.dtype == torch.float32 and a2.dtype == torch.float32 and o2.is_cuda and
+            o2.stride(1) == 1 and a2.stride(1) == 1 and
+            o2.shape[1] == c1._obs_dim and a2.shape[1] == c1._act_dim)
+
+
+def forward_pair(c1, c2, observation, action, slot=0, need_grad=False):
+    """(q1 [B], q2 [B]) of twin critics on the same (observation, action): one launch
+    (sac_agent.py:286-330 evaluates both critics of a pair on the same inputs every time)."""
+    B = int(observation.shape[0])
+    o2, a2 = observation.reshape(B, -1), action.reshape(B, -1)
+    q1, q2 = sequential.forward_wide([c1.body, c2.body], [o2, o2], slot=slot,
+                                     need_grad=need_grad, x2s=[a2, a2])
+    return q1.view(B), q2.view(B)
+
+
+def backward_pair(c1, c2, dq1, dq2, slot=0, param_grads=True, want_action_grad=False):
+    """`backward` of both critics of a `forward_pair`: the gradient chains in one launch, all
+    weight gradients in a second one; returns (da1, da2) [B, act] views if asked."""
+    B = int(dq1.shape[0])
+    bufs = [c._input(slot, B, dq1.device) for c in (c1, c2)]
+    lo, hi = c1._obs_dim, c1._obs_dim + c1._act_dim
+    sequential.backward_wide([c1.body, c2.body], [dq1.view(B, 1), dq2.view(B, 1)], slot=slot,
+                             param_grads=param_grads,
+                             input_grads=[b["dx"] for b in bufs] if want_action_grad else None,
+                             input_grad_cols=(lo, hi))
+    if want_action_grad:
+        return bufs[0]["dx"][:, lo:], bufs[1]["dx"][:, lo:]
+    return None, None
+

@@ -27,6 +27,10 @@ from agents_amd.utils import nest_utils
 SMALL_HEAD_ON_MAIN = True
 FUSE_HEAD_BACKWARD = os.environ.get("AA_FUSE_HEAD_BACKWARD", "1") != "0"   # dX + dW of a small head: one launch
 FUSED_SMALL_MLP = True   # whole <=64-wide MLPs in one forward / one backward launch
+# whole <=256-wide MLPs (SAC's actor / critics) at batch <= 1024: one forward launch, two backward
+# launches, several networks of one layout per launch (csrc/mlp_wide.hip).  AA_FUSED_WIDE_MLP=0:
+# one GEMM launch per layer and direction instead (A/B measurements)
+FUSED_WIDE_MLP = os.environ.get("AA_FUSED_WIDE_MLP", "1") != "0"
 DX_FIRST = True   # record a layer's input-gradient launch before its weight-gradient launch
 # the first layer's weight gradient on the main stream (AA_LAST_DW_ON_MAIN=0: on the side stream)
 LAST_DW_ON_MAIN = os.environ.get("AA_LAST_DW_ON_MAIN", "1") != "0"
@@ -108,6 +112,8 @@ class _Slot:
         self.pair_prep = None   # {param index of a fused pair's first conv: filter-plane scratch}
         self.prep_issued = None  # pairs whose pre-pass prepare_forward already put on the prep stream
         self.dx_prep = None     # {param index of a conv: input-gradient filter scratch}
+        self.dzs = None         # wide-MLP path: d loss / d pre-activation of each layer
+        self.wide_in = None     # wide-MLP path: (x, x2) the last forward read its input from
 
 
 class Sequential(network.Network):
@@ -362,6 +368,9 @@ class Sequential(network.Network):
         s = self._slot(slot, B, need_grad)
         if self._fused_small_ok() and x.dtype == torch.float32:
             return self._forward_fused(x, s, B)
+        if self.wide_ok(B) and x.dtype == torch.float32:
+            return forward_wide([self], [x], slot=slot, need_grad=need_grad)[0]
+        s.wide_in = None
         cur = x
         div = None
         pi = 0
@@ -675,6 +684,44 @@ class Sequential(network.Network):
             self._fused_ok = ok
         return ok and FUSED_SMALL_MLP
 
+    def wide_layout(self):
+        """The aa_mlp_layout of this stack when csrc/mlp_wide.hip can run it (every parametrised
+        layer Dense, at most 4, every width <= 256, input <= 1024, activations None / relu / tanh,
+        and not already a <=64-wide stack), else None."""
+        lay = getattr(self, "_wide_layout", False)
+        if lay is False:
+            lay = None
+            if self._built and 1 <= len(self._param_layers) <= 4 and \
+                    all(isinstance(l, (L.Dense, L.Flatten)) for l in self._layers) and \
+                    not self._fused_small_ok():
+                n0 = int(np.prod(self._input_tensor_spec.shape))
+                widths = [n0] + [ks[1] for ks, _ in self._shapes]
+                if 1 <= n0 <= 1024 and all(1 <= w_ <= 256 for w_ in widths[1:]) and \
+                        all(l.activation in (None, "relu", "tanh") for l in self._param_layers):
+                    n = len(self._param_layers)
+                    lay = _lib.MlpLayout()
+                    lay.n_layers = n
+                    for i, w_ in enumerate(widths):
+                        lay.dims[i] = w_
+                    for i, l in enumerate(self._param_layers):
+                        lay.acts[i] = ops.ACT[l.activation]
+                        lay.k_off[i] = self._offsets[i][0]
+                        lay.b_off[i] = self._offsets[i][1]
+            self._wide_layout = lay
+        return lay
+
+    def wide_ok(self, B):
+        return FUSED_WIDE_MLP and 1 <= B <= 1024 and self.wide_layout() is not None
+
+    def wide_key(self):
+        """Two networks can share a wide-MLP launch when this is equal."""
+        lay = self.wide_layout()
+        if lay is None:
+            return None
+        n = lay.n_layers
+        return (n, tuple(lay.dims[:n + 1]), tuple(lay.acts[:n]), tuple(lay.k_off[:n]),
+                tuple(lay.b_off[:n]))
+
     def _fused_ptrs(self, s):
         n = len(self._param_layers)
         return (ctypes.c_void_p * n)(*[y.data_ptr() for y in s.ys])
@@ -733,13 +780,14 @@ class Sequential(network.Network):
                     bias_grad=self._gbviews[n - 1])
 
     def backward(self, dout, slot=0, side_stream=None, param_grads=True, input_grad=None,
-                 stop_layer=0, head_done=False):
+                 stop_layer=0, head_done=False, input_grad_cols=None):
         """Given d loss / d output [B, out], fills flat_grads (overwrites).
 
         `param_grads=False` skips every weight/bias gradient (only the input-gradient chain runs:
         SAC's actor loss differentiates THROUGH the critics without updating them);
         `input_grad` ([B, in] float32 buffer, Dense first layer only) also receives
-        d loss / d network input.  `head_done=True`: the last layer's backward (its dX into this
+        d loss / d network input (`input_grad_cols=(lo, hi)`: only those columns are needed -- a
+        critic's action gradient -- the others may be left unwritten).  `head_done=True`: the last layer's backward (its dX into this
         slot's buffer, dW, db) has already been produced by the caller's loss launch
         (`fusable_head`); the walk starts at the layer below.
         `stop_layer=k > 0` stops after parametrised layer k (its input gradient is computed); `backward_resume` continues with layers k-1 .. 0 -- the Learner
@@ -756,6 +804,10 @@ class Sequential(network.Network):
         if self._fused_small_ok() and param_grads and stop_layer == 0 and \
                 s.xs[0].dtype == torch.float32 and s.xs[0].dim() == 2:
             return self._backward_fused(dout, s, B, input_grad)
+        if s.wide_in is not None and stop_layer == 0 and not head_done:
+            return backward_wide([self], [dout], slot=slot, param_grads=param_grads,
+                                 input_grads=None if input_grad is None else [input_grad],
+                                 input_grad_cols=input_grad_cols)
         lib = _lib.load()
         n = len(self._param_layers)
         top = self._param_layers[-1]
@@ -901,3 +953,114 @@ class Sequential(network.Network):
     def call(self, inputs, step_type=None, network_state=(), training=False, **kwargs):
         out = self.forward(inputs, slot="call")
         return out.clone(), network_state
+
+
+
+# ---- wide MLPs: several networks of one layout per launch (csrc/mlp_wide.hip) ---------------------
+def _wide_group(nets, B):
+    if not 1 <= len(nets) <= 4:
+        raise ValueError("a wide-MLP launch takes 1..4 networks")
+    key = nets[0].wide_key()
+    if key is None or any(n.wide_key() != key for n in nets[1:]) or not nets[0].wide_ok(B):
+        raise ValueError("forward_wide / backward_wide: the networks do not share a layout "
+                         "csrc/mlp_wide.hip supports at this batch size")
+    return nets[0].wide_layout()
+
+
+def forward_wide(nets, xs, slot=0, need_grad=False, x2s=None):
+    """`net.forward(x, slot, need_grad)` of up to four Sequential networks of the same layout in
+    ONE launch.  xs[g]: float32 [B, d] with unit column stride (any row stride); with x2s the
+    network input is [xs[g] | x2s[g]] -- a critic's (observation, action) -- read from the two
+    tensors in place.  Returns the networks' output buffers (owned by their slots)."""
+    B = int(xs[0].shape[0])
+    lay = _wide_group(nets, B)
+    d = _lib.MlpWideFwd()
+    d.layout = lay
+    d.n_nets = len(nets)
+    d.B = B
+    n = lay.n_layers
+    outs = []
+    for g, net in enumerate(nets):
+        x = xs[g] if xs[g].dim() == 2 else xs[g].reshape(B, -1)
+        x2 = None
+        if x2s is not None:
+            x2 = x2s[g] if x2s[g].dim() == 2 else x2s[g].reshape(B, -1)
+        for t in (x, x2):
+            if t is not None and (t.dtype != torch.float32 or t.stride(1) != 1 or
+                                  int(t.shape[0]) != B or not t.is_cuda):
+                raise ValueError("wide-MLP inputs are float32 [B, d] device tensors with unit "
+                                 "column stride")
+        width = int(x.shape[1]) + (int(x2.shape[1]) if x2 is not None else 0)
+        if width != lay.dims[0]:
+            raise ValueError(f"network input has {width} columns, expected {lay.dims[0]}")
+        if g == 0:
+            d.x_split = int(x.shape[1])
+        elif d.x_split != int(x.shape[1]):
+            raise ValueError("every network of a launch splits its input at the same column")
+        s = net._slot(slot, B, need_grad)
+        s.wide_in = (x, x2)
+        s.xs[0] = x
+        for i in range(1, n):
+            s.xs[i] = s.ys[i - 1]
+        d.params[g] = net.flat_params.data_ptr()
+        d.x[g] = x.data_ptr()
+        d.ldx[g] = x.stride(0)
+        if x2 is not None:
+            d.x2[g] = x2.data_ptr()
+            d.ldx2[g] = x2.stride(0)
+        for i in range(n):
+            d.y[g][i] = s.ys[i].data_ptr()
+        outs.append(s.ys[-1])
+    with torch.cuda.device(xs[0].device):
+        _lib.check(_lib.load().aa_mlp_wide_forward(ctypes.byref(d), _lib.stream_ptr()),
+                   "aa_mlp_wide_forward")
+    return outs
+
+
+def backward_wide(nets, douts, slot=0, param_grads=True, input_grads=None, input_grad_cols=None):
+    """`net.backward(dout, slot, param_grads, input_grad)` of the networks of a `forward_wide`
+    group: the gradient chain in one launch, every weight / bias gradient of every layer and
+    network in a second one (skipped with param_grads=False).  input_grads[g]: [B, d] float32
+    buffers receiving d loss / d input columns `input_grad_cols` (default: all)."""
+    B = int(douts[0].shape[0])
+    lay = _wide_group(nets, B)
+    d = _lib.MlpWideBwd()
+    d.layout = lay
+    d.n_nets = len(nets)
+    d.B = B
+    n = lay.n_layers
+    d.dx_lo, d.dx_hi = input_grad_cols if input_grad_cols is not None else (0, lay.dims[0])
+    for g, net in enumerate(nets):
+        s = net._slots.get((slot, B))
+        if s is None or s.wide_in is None:
+            raise RuntimeError("backward_wide() needs a preceding forward_wide on this slot")
+        if s.dzs is None:
+            s.dzs = [torch.empty_like(y) for y in s.ys]
+        x, x2 = s.wide_in
+        if g == 0:
+            d.x_split = int(x.shape[1])
+        dout = douts[g] if douts[g].dim() == 2 else douts[g].reshape(B, -1)
+        if dout.dtype != torch.float32 or dout.stride(1) != 1 or int(dout.shape[1]) != lay.dims[n]:
+            raise ValueError("d loss / d output must be float32 [B, out] with unit column stride")
+        d.params[g] = net.flat_params.data_ptr()
+        d.x[g] = x.data_ptr()
+        d.ldx[g] = x.stride(0)
+        if x2 is not None:
+            d.x2[g] = x2.data_ptr()
+            d.ldx2[g] = x2.stride(0)
+        d.dout[g] = dout.data_ptr()
+        d.ld_dout[g] = dout.stride(0)
+        for i in range(n):
+            d.y[g][i] = s.ys[i].data_ptr()
+            d.dz[g][i] = s.dzs[i].data_ptr()
+        if input_grads is not None:
+            ig = input_grads[g]
+            if ig.dtype != torch.float32 or ig.stride(1) != 1 or int(ig.shape[1]) < d.dx_hi:
+                raise ValueError("input_grad must be a float32 [B, in] buffer")
+            d.dx[g] = ig.data_ptr()
+            d.ld_dx[g] = ig.stride(0)
+        if param_grads:
+            d.grads[g] = net.flat_grads.data_ptr()
+    with torch.cuda.device(douts[0].device):
+        _lib.check(_lib.load().aa_mlp_wide_backward(ctypes.byref(d), _lib.stream_ptr()),
+                   "aa_mlp_wide_backward")

@@ -594,6 +594,63 @@ typedef struct {
   int32_t acts[AA_MLP_MAX_LAYERS];
   int64_t k_off[AA_MLP_MAX_LAYERS], b_off[AA_MLP_MAX_LAYERS];
 } aa_mlp_layout;
+/* Whole MLPs of wide Dense layers (every hidden / output width <= 256, input width <= 1024,
+ * <= 4 layers) at small batch -- SAC's actor and twin (target) critics, (256, 256) hidden layers at
+ * batch 256 (agents/sac/sac_agent.py:286-330, networks/critic_network.py:150-170,
+ * networks/actor_distribution_network.py) -- forward in ONE launch, backward in TWO, for up to
+ * AA_MLPW_MAX_NETS networks of the same layout per launch (csrc/mlp_wide.hip).  Replaces one GEMM
+ * launch (+ split-K reduce) per Dense layer and direction, and the copies that built the
+ * [observation | action] input: the first layer reads columns [0, x_split) of its input from x
+ * and the rest from x2 (x_split = layout.dims[0]: x only, x2 unused).
+ *   params[g] / grads[g]: flat fp32 buffers of network g (layer l's kernel [dims[l]][dims[l+1]] at
+ *     k_off[l], bias at b_off[l]);  y[g][l]: layer l's output [B, dims[l+1]] (all written by
+ *     forward, read by backward);  dout[g]: d loss / d y[g][last], row stride ld_dout.
+ *   backward: dz[g][l] [B, dims[l+1]] receives d loss / d (pre-activation of layer l) (workspace
+ *     the weight-gradient launch reads);  dx[g] (all NULL or none): d loss / d input columns
+ *     [dx_lo, dx_hi) written to dx[g][b * ld_dx + column] (a critic's action gradient: only those
+ *     rows of the first kernel are read);  grads[g] (all NULL or none): every kernel and bias
+ *     gradient, written (not accumulated), full batch per 32 x 32 tile, fixed summation order. */
+#define AA_MLPW_MAX_NETS 4
+#define AA_MLPW_MAX_BATCH 1024
+typedef struct {
+  aa_mlp_layout layout;
+  int32_t n_nets, x_split;
+  int64_t B;
+  const float* params[AA_MLPW_MAX_NETS];
+  const float* x[AA_MLPW_MAX_NETS];
+  int64_t ldx[AA_MLPW_MAX_NETS];
+  const float* x2[AA_MLPW_MAX_NETS];
+  int64_t ldx2[AA_MLPW_MAX_NETS];
+  float* y[AA_MLPW_MAX_NETS][AA_MLP_MAX_LAYERS];
+} aa_mlp_wide_fwd;
+typedef struct {
+  aa_mlp_layout layout;
+  int32_t n_nets, x_split;
+  int64_t B;
+  const float* params[AA_MLPW_MAX_NETS];
+  const float* x[AA_MLPW_MAX_NETS];
+  int64_t ldx[AA_MLPW_MAX_NETS];
+  const float* x2[AA_MLPW_MAX_NETS];
+  int64_t ldx2[AA_MLPW_MAX_NETS];
+  const float* y[AA_MLPW_MAX_NETS][AA_MLP_MAX_LAYERS];
+  const float* dout[AA_MLPW_MAX_NETS];
+  int64_t ld_dout[AA_MLPW_MAX_NETS];
+  float* dz[AA_MLPW_MAX_NETS][AA_MLP_MAX_LAYERS];
+  float* dx[AA_MLPW_MAX_NETS];
+  int64_t ld_dx[AA_MLPW_MAX_NETS];
+  int32_t dx_lo, dx_hi;
+  float* grads[AA_MLPW_MAX_NETS];
+} aa_mlp_wide_bwd;
+/* 1 when (layout, B) is within the limits above, else 0 (callers then take the per-layer path) */
+int aa_mlp_wide_supported(const aa_mlp_layout* layout, int64_t B);
+int aa_mlp_wide_forward(const aa_mlp_wide_fwd* d, void* stream);
+int aa_mlp_wide_backward(const aa_mlp_wide_bwd* d, void* stream);
+/* Measurement aid: the workgroups of the following aa_mlp_wide_backward launches write
+ * wall_clock64() stamps (10 ns ticks) at the phase boundaries of the gradient chain to
+ * buf[workgroup][16] (0 start, 1 operands staged, then per layer from the top: dz ready, product
+ * done); NULL = off. */
+int aa_mlp_wide_debug_stamps(int64_t* buf);
+
 typedef struct {
   const float* obs; int64_t ld_obs; int32_t obs_dim; int32_t D;
   const float* actions; const float* old_loc; const float* old_scale;   /* [N, D] */
