@@ -198,6 +198,13 @@ class SacAgent(tf_agent.TFAgent):
         policy = SacPolicy(time_step_spec, action_spec, actor_network, training=False, seed=seed)
         self._train_policy = SacPolicy(time_step_spec, action_spec, actor_network, training=True,
                                        seed=seed + 1)
+        # The losses sample the actor on noise streams of their OWN (next-state actions of the
+        # critic loss, the alpha loss): with the collect policy's stream they would interleave with
+        # the collect step's draws in launch order -- which a graphed loop changes when it runs the
+        # critic update beside the collect step -- and two concurrent launches would share one
+        # device-resident call counter.
+        self._loss_policy = SacPolicy(time_step_spec, action_spec, actor_network, training=False,
+                                      seed=seed + 2)
         self._update_target = common.Periodically(self._soft_update_targets,
                                                   self._target_update_period, "update_targets")
         super().__init__(time_step_spec, action_spec, policy=policy, collect_policy=policy,
@@ -343,7 +350,7 @@ class SacAgent(tf_agent.TFAgent):
             with ops.side_line(sides[1]):
                 q2 = self._critic_network_2.forward(obs, actions, slot="critic",
                                                     need_grad=need_grad, x_cat=xc["x_sa"])
-        na, nlogp, _ = self._policy.sample(next_obs, slot="next", eps=eps_next,
+        na, nlogp, _ = self._loss_policy.sample(next_obs, slot="next", eps=eps_next,
                                            save=w.get("save_next"))
         x_next = x_sa = None
         if fast and not pair:
@@ -399,7 +406,7 @@ class SacAgent(tf_agent.TFAgent):
         lib = _lib.load()
         B = obs.shape[0]
         w = self._w(B, obs.device)
-        pol = self._train_policy if need_grad else self._policy
+        pol = self._train_policy if need_grad else self._loss_policy
         a, logp, z = pol.sample(obs, slot="actor", need_grad=need_grad, eps=eps,
                                 save=w["save"] if need_grad else None)
         x_pi = None
@@ -452,7 +459,8 @@ class SacAgent(tf_agent.TFAgent):
         lib = _lib.load()
         B = obs.shape[0]
         w = self._w(B, obs.device)
-        _, logp, _ = self._policy.sample(obs, slot="alpha", eps=eps, save=w.get("save_alpha"))
+        _, logp, _ = self._loss_policy.sample(obs, slot="alpha", eps=eps,
+                                              save=w.get("save_alpha"))
         _lib.check(lib.aa_sac_alpha_loss(
             logp.data_ptr(), _lib.ptr(weights), self._log_alpha_buf.data_ptr(),
             self._target_entropy, 1 if self._use_log_alpha_in_alpha_loss else 0,
@@ -545,6 +553,13 @@ class SacAgent(tf_agent.TFAgent):
 
     def _train(self, experience, weights, eps=None):
         """`eps` (tests): dict of externally supplied N(0,1) noise {"next", "actor", "alpha"}."""
+        self._train_part_a(experience, weights, eps)
+        return self._train_part_b()
+
+    def _train_part_a(self, experience, weights, eps=None):
+        """The critic update (sac_agent.py:286-330, first third): reads the actor, writes the
+        critics -- nothing the collect policy uses is modified, so a graphed loop runs it beside
+        the collect step (utils/graph.py: GraphedTrain, whole mode in two parts)."""
         eps = eps or {}
         obs, actions, next_obs, reward, discount = self._as_transition(experience)
         B = obs.shape[0]
@@ -556,6 +571,13 @@ class SacAgent(tf_agent.TFAgent):
                                        eps_next=eps.get("next"))
             self._apply(self._critic_optimizer, self._critic_params, self._critic_grads,
                         [self._critic_network_1.body, self._critic_network_2.body])
+        self._part_a = (obs, wts, closs, eps)
+
+    def _train_part_b(self):
+        """Actor and alpha updates, LossInfo, counters and the soft target update."""
+        obs, wts, closs, eps = self._part_a
+        dev = obs.device
+        with torch.cuda.device(dev):
             aloss = self._actor_phase(obs, wts, True, eps=eps.get("actor"))
             self._apply(self._actor_optimizer, self._actor_network.flat_params,
                         self._actor_network.flat_grads, [self._actor_network.body])
@@ -588,6 +610,12 @@ class SacAgent(tf_agent.TFAgent):
         one HIP graph per input signature (utils/graph.py: GraphedTrain, whole mode)."""
         return self._train(experience, weights)
 
+    def _graph_train_whole_a(self, experience, weights):
+        self._train_part_a(experience, weights)
+
+    def _graph_train_whole_b(self):
+        return self._train_part_b()
+
     # ---- checkpointing ---------------------------------------------------------------------------
     def replicated_state(self):
         """Tensors every data-parallel replica must hold identically (train.Learner broadcasts
@@ -608,7 +636,8 @@ class SacAgent(tf_agent.TFAgent):
                 "optimizers": [o.state_dict() for o in (self._actor_optimizer,
                                                         self._critic_optimizer,
                                                         self._alpha_optimizer)],
-                "policies": [self._policy.state_dict(), self._train_policy.state_dict()]}
+                "policies": [self._policy.state_dict(), self._train_policy.state_dict(),
+                             self._loss_policy.state_dict()]}
 
     def load_state_dict(self, sd):
         self._actor_network.flat_params.copy_(sd["actor"])
@@ -622,6 +651,8 @@ class SacAgent(tf_agent.TFAgent):
             o.load_state_dict(osd)
         self._policy.load_state_dict(sd["policies"][0])
         self._train_policy.load_state_dict(sd["policies"][1])
+        if len(sd["policies"]) > 2:
+            self._loss_policy.load_state_dict(sd["policies"][2])
         self._initialized = True
 
     def _loss(self, experience, weights=None, training=False):

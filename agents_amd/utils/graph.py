@@ -296,7 +296,8 @@ class _Entry:
         self.g_grads = None       # _Captured: forwards + loss + backward (bucket mode: first half)
         self.g_apply = None       # _Captured: optimizer (shared by every entry of a signature)
         self.g_grads_b = None     # _Captured, bucket mode: second half of the backward
-        self.captured = None      # _Captured, whole mode
+        self.captured = None      # _Captured, whole mode (part (a) when the agent splits it)
+        self.captured_b = None    # _Captured, whole mode, part (b)
         self.out = None
 
 
@@ -446,7 +447,17 @@ class GraphedTrain:
                         dst.copy_(src, non_blocking=True)
             if e.static_w is not None and e.static_w.data_ptr() != weights.data_ptr():
                 e.static_w.copy_(weights, non_blocking=True)
-            if self._whole:
+            if self._whole and e.captured_b is not None:
+                # part (a) only reads what the collect step reads (the policy's weights) and the
+                # batch (waited for above); part (b) overwrites the policy: after the collect
+                # step that is using it, and after every draw (it also ends the iteration)
+                _mark("train.begin")
+                e.captured.replay()
+                if lanes is not None:
+                    lanes.join()
+                e.captured_b.replay()
+                _mark("train.apply_done")
+            elif self._whole:
                 if lanes is not None:
                     lanes.join()
                 e.captured.replay()
@@ -496,6 +507,14 @@ class GraphedTrain:
         w_arg = e.static_w if e.static_w is not None else weights
         with capture_batch():
             if self._whole:
+                if hasattr(agent, "_graph_train_whole_a"):
+                    # two graphs: (a) everything that leaves the collect policy's weights alone,
+                    # (b) the rest -- with overlap on, (a) runs beside the collect step
+                    e.captured = _Captured("train.whole_a")
+                    e.captured.capture(lambda: agent._graph_train_whole_a(e.static_in, w_arg))
+                    e.captured_b = _Captured("train.whole_b")
+                    e.out = e.captured_b.capture(agent._graph_train_whole_b)
+                    return
                 e.captured = _Captured("train.whole")
                 e.out = e.captured.capture(lambda: agent._graph_train_whole(e.static_in, w_arg))
                 return

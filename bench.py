@@ -663,8 +663,17 @@ def main():
         graph.enable_overlap(dev)
     time_step = None
 
+    # A/B aid: AA_BENCH_HOST_DELAY_US=n burns n us of host time per iteration.  If the throughput
+    # does not move, the host has that much slack (the loop is GPU-bound); if it drops by n us per
+    # iteration, the loop is bound by the host's enqueue work.
+    host_delay = float(os.environ.get("AA_BENCH_HOST_DELAY_US", "0")) * 1e-6
+
     def step():
         nonlocal time_step
+        if host_delay:
+            t_ = time.perf_counter() + host_delay
+            while time.perf_counter() < t_:
+                pass
         time_step, _ = collect_run(time_step)
         return lrn.run(iterations=1, iterator=it)
 

@@ -2,10 +2,11 @@
 f32[17], actor and twin critics (256,256), batch 256, tau 0.005, three Adam(3e-4), 4,096 envs), on
 the stack `bench.py --config sac` times (tools/bench_sac.py: build) with the replay ring shortened
 to 8 frames per env -- i.e. through the GRAPHED path: the collect / sample / train HIP graphs,
-train graphs bound to the sampler's ring slots.  At these widths every Dense layer takes the
-fp32-MFMA GEMM route (`aa_gemm_f32`, split-K slabs) and the twin critics' [observation | action]
-inputs are assembled by `aa_copy_segments`; the (32,32) networks of tests/test_gpu_sac.py take the
-small-MLP kernels instead, so this is the agent-level check of that route
+train graphs bound to the sampler's ring slots.  At these widths the actor and the twin critics
+take the wide-MLP kernels (csrc/mlp_wide.hip: one forward launch, two backward launches, both
+critics of a pair per launch with [observation | action] read in place); the (32,32) networks of
+tests/test_gpu_sac.py take the small-MLP kernels instead, so this is the agent-level check of that
+route
 (tf_agents/agents/sac/sac_agent.py:314-410,559-740; examples/sac/haarnoja18/sac_train_eval.py:182-199).
 
 Oracle: oracle/sac.py (torch-CPU autograd), fed the batch the train graph consumed and the very
@@ -161,3 +162,38 @@ def test_sac_bench_configuration_matches_oracle_through_the_graphs(dev):
         print(f"SAC configs[4] parity through the graphs over {STEPS} steps: worst loss rel err "
               f"{worst['loss']:.2e}, gradient relative L2 {worst['grad']:.2e}, parameter error "
               f"after one optimizer step {worst['param']:.2e} of max|p|; {flips} boundary flips")
+
+
+def test_sac_stream_overlap_matches_single_stream(dev):
+    """With overlap on, the train step replays as two graphs -- the critic update beside the
+    collect step (both only read the actor), the actor / alpha / target updates after it -- and
+    the sampler draws on its own lane.  Bit-identical to the same loop on one stream: parameters,
+    targets, log_alpha, optimizer state and losses after every iteration block."""
+    import bench_sac
+    runs = []
+    for overlap in (False, True):
+        w = bench_sac.build(dev, envs=256, max_length=8, batch=64)
+        agent, collect, lrn = w["agent"], w["collect"], w["learner"]
+        it = iter(w["dataset"])
+        if overlap:
+            graph.enable_overlap(dev)
+        try:
+            tsx, snaps = None, []
+            for i in range(30):
+                tsx, _ = collect(tsx)
+                li = lrn.run(iterations=1, iterator=it)
+                if i % 6 == 5:
+                    graph.join_lanes(dev)
+                    torch.cuda.synchronize()
+                    snaps.append([t.clone() for t in agent.replicated_state()] +
+                                 [li.loss.clone(), tsx.observation.clone()])
+            gt = graph.graphed_train(agent)
+            assert gt.replays > 20
+            runs.append(snaps)
+        finally:
+            graph.disable_overlap()
+    for a, b in zip(*runs):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+

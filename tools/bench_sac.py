@@ -104,11 +104,21 @@ def run(args):
     torch.cuda.set_device(dev)
     w = build(dev, args.envs, args.max_length, args.batch)
     agent, collect, lrn = w["agent"], w["collect"], w["learner"]
+    if not getattr(args, "no_overlap", False):
+        # collect / sample / train graphs on three HIP streams, ordered along the true data
+        # dependencies (utils/graph.py: Lanes): the critic update runs beside the collect step
+        graph.enable_overlap(dev)
     it = iter(w["dataset"])
     tsx = None
 
+    host_delay = float(os.environ.get("AA_BENCH_HOST_DELAY_US", "0")) * 1e-6   # see bench.py
+
     def step():
         nonlocal tsx
+        if host_delay:
+            t_ = time.perf_counter() + host_delay
+            while time.perf_counter() < t_:
+                pass
         tsx, _ = collect(tsx)
         return lrn.run(iterations=1, iterator=it)
 
@@ -118,13 +128,15 @@ def run(args):
     t0 = time.perf_counter()
     for _ in range(args.iters):
         li = step()
+    t_host = (time.perf_counter() - t0) / args.iters    # the host is done enqueueing here
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.iters
     row = 4 + 376 * 4 + 17 * 4 + 4 + 4 + 4
     return ({
         "workload": "configs[4] at 1 GPU: SAC Humanoid-shaped, %d envs, batch %d, actor/critics "
                     "(256,256)" % (args.envs, args.batch),
-        "ms_per_iteration": dt * 1e3, "learner_steps_per_sec": 1.0 / dt,
+        "ms_per_iteration": dt * 1e3, "host_enqueue_ms_per_iteration": t_host * 1e3,
+        "learner_steps_per_sec": 1.0 / dt,
         "env_steps_per_sec": args.envs / dt, "trained_transitions_per_sec": args.batch / dt,
         "replay_row_bytes": row, "final_loss": float(li.loss), "n_gpus": 1,
         "train_graph_replays": graph.graphed_train(agent).replays})
@@ -136,6 +148,7 @@ def main():
     ap.add_argument("--max-length", type=int, default=64)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--no-overlap", action="store_true")
     print(json.dumps(run(ap.parse_args())))
 
 
