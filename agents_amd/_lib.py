@@ -309,7 +309,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 9:
+    if lib.aa_abi_version() != 10:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -64,7 +64,12 @@ struct MwFwdP {
   MwNetF net[AA_MLPW_MAX_NETS];
   int64_t B;
   int x_split;
+  long long* stamps;   // nullable (aa_mlp_wide_debug_stamps): [workgroup][16] wall_clock64 ticks
 };
+static long long* g_mw_stamps = nullptr;
+#define MW_STAMP(i)                                  \
+  if (p.stamps != nullptr && threadIdx.x == 0)       \
+    p.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64();
 
 __global__ void __launch_bounds__(MW_THREADS) aa_mlp_wide_fwd_kernel(MwFwdP p) {
   __shared__ mw_f4 hin[MW_MAXIN];               // input features of the 4 samples
@@ -74,6 +79,7 @@ __global__ void __launch_bounds__(MW_THREADS) aa_mlp_wide_fwd_kernel(MwFwdP p) {
   const int64_t s0 = (int64_t)blockIdx.x * MW_TS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* __restrict__ params = p.net[g].params;
+  MW_STAMP(0)
   {
     const float* __restrict__ x = p.net[g].x;
     const float* __restrict__ x2 = p.net[g].x2;
@@ -89,6 +95,7 @@ __global__ void __launch_bounds__(MW_THREADS) aa_mlp_wide_fwd_kernel(MwFwdP p) {
     }
   }
   __syncthreads();
+  MW_STAMP(1)
   const mw_f4* hcur = hin;
   const int L = p.lay.n_layers;
   for (int l = 0; l < L; ++l) {
@@ -135,15 +142,23 @@ __global__ void __launch_bounds__(MW_THREADS) aa_mlp_wide_fwd_kernel(MwFwdP p) {
         int k = kb;
         if (k < kfull) {
           MW_LOAD(wa, k)
-          while (true) {
-            if (k + MW_U < kfull) { MW_LOAD(wb, k + MW_U) }
+          // steady state: no condition between a load and the multiply that waits for it, so the
+          // compiler knows exactly one batch is outstanding behind the one it needs
+          while (k + 2 * MW_U < kfull) {
+            MW_LOAD(wb, k + MW_U)
+            MW_FMA(wa, k)
+            MW_LOAD(wa, k + 2 * MW_U)
+            MW_FMA(wb, k + MW_U)
+            k += 2 * MW_U;
+          }
+          if (k + MW_U < kfull) {       // two batches left: wa (loaded) and one more
+            MW_LOAD(wb, k + MW_U)
+            MW_FMA(wa, k)
+            MW_FMA(wb, k + MW_U)
+            k += 2 * MW_U;
+          } else {
             MW_FMA(wa, k)
             k += MW_U;
-            if (k >= kfull) break;
-            if (k + MW_U < kfull) { MW_LOAD(wa, k + MW_U) }
-            MW_FMA(wb, k)
-            k += MW_U;
-            if (k >= kfull) break;
           }
         }
 #undef MW_LOAD
@@ -210,7 +225,9 @@ __global__ void __launch_bounds__(MW_THREADS) aa_mlp_wide_fwd_kernel(MwFwdP p) {
           for (int s = 0; s < MW_TS; ++s) red[q][s][col] = 0.f;
       }
     }
+    MW_STAMP(2 + 3 * l)
     __syncthreads();
+    MW_STAMP(3 + 3 * l)
     float* __restrict__ y = p.net[g].y[l];
     float* hn = reinterpret_cast<float*>(hid[l & 1]);
     const int act = p.lay.acts[l];
@@ -231,6 +248,7 @@ __global__ void __launch_bounds__(MW_THREADS) aa_mlp_wide_fwd_kernel(MwFwdP p) {
       hn[c_b * MW_TS + s_b] = v;
     }
     __syncthreads();
+    MW_STAMP(4 + 3 * l)
     hcur = hid[l & 1];
   }
 }
@@ -252,10 +270,7 @@ struct MwBwdP {
   int dx_lo, dx_hi;
   long long* stamps;   // nullable (aa_mlp_wide_debug_stamps): [workgroup][16] wall_clock64 ticks
 };
-static long long* g_mw_stamps = nullptr;
-#define MW_STAMP(i)                                  \
-  if (p.stamps != nullptr && threadIdx.x == 0)       \
-    p.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64();
+
 
 // Sixteen samples per workgroup, the products on the fp32 matrix cores: g_{l-1}[s][i] =
 // sum_o dz[s][o] W[i][o] is a [16 samples] x [16 rows of W] block per MFMA chain, A = dz from LDS,
@@ -597,6 +612,7 @@ int aa_mlp_wide_forward(const aa_mlp_wide_fwd* d, void* stream) {
   p.lay = d->layout;
   p.B = d->B;
   p.x_split = d->x_split;
+  p.stamps = g_mw_stamps;
   for (int g = 0; g < AA_MLPW_MAX_NETS; ++g) {
     const int s = g < d->n_nets ? g : 0;
     if (d->params[s] == nullptr) return AA_ERR_INVALID;

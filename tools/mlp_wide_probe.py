@@ -71,6 +71,8 @@ def main():
     from agents_amd import _lib
     lib = _lib.load()
     for name, fn, n_wg in (
+            ("critic pair forward (0 start, 1 input staged, per layer: streamed / summed / out)",
+             f2, 2 * ((B + 3) // 4)),
             ("critic pair chain, d/d action", lambda: sequential.backward_wide(
                 crit, dq, slot="p", param_grads=False, input_grads=dxs,
                 input_grad_cols=(376, 393)), 2 * ((B + 15) // 16)),
@@ -84,9 +86,9 @@ def main():
         lib.aa_mlp_wide_debug_stamps(None)
         t = buf.cpu().numpy().astype("float64")
         rel = (t - t[:, :1]) * 0.01           # us since the workgroup's first stamp
-        span = (t[:, :9].max() - t[:, 0].min()) * 0.01
+        span = (t[:, :11].max() - t[:, 0].min()) * 0.01
         print(f"{name}: stamps (us, median over workgroups) "
-              + " ".join(f"{v:5.1f}" for v in __import__("numpy").median(rel[:, :9], axis=0))
+              + " ".join(f"{v:5.1f}" for v in __import__("numpy").median(rel[:, :11], axis=0))
               + f" | first start -> last end {span:5.1f} us | second layer from the top: rows "
               f"requested {__import__('numpy').median(rel[:, 10]):5.1f}, dz computed "
               f"{__import__('numpy').median(rel[:, 11]):5.1f}")
