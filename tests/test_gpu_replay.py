@@ -112,6 +112,9 @@ def _rand_items(rng, spec, B):
     ((84, 84, 4), torch.uint8, 4, 6, 9),     # Atari rows (28,224 B), wrapped
     ((17,), torch.float32, 5, 3, 3),         # row_bytes not a multiple of 16
     ((3, 5), torch.uint8, 2, 4, 6),          # 15-byte rows: byte path
+    ((300,), torch.float32, 5, 4, 7),        # 1,200-byte rows: sixteen rows per workgroup, ragged
+    ((376,), torch.float32, 37, 3, 5),       # SAC-sized rows, three workgroups of 16 / 16 / 5 rows
+    ((1028,), torch.float32, 18, 3, 4),      # 4,112 bytes: just above the medium-row limit
 ])
 def test_fuzz_vs_oracle_bit_exact(dev, obs_shape, obs_dtype, B, L, adds):
     from agents_amd.utils import nest_utils
