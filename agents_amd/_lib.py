@@ -273,7 +273,7 @@ _SIGNATURES = {
     "aa_sac_sample": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
                               c_uint64] + [c_void_p] * 8),
     "aa_sac_head_backward": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32] +
-                             [c_void_p] * 7),
+                             [c_void_p] * 4 + [c_int64, c_void_p, c_int64] + [c_void_p] * 3),
     "aa_sac_critic_loss": (c_int, [c_void_p] * 9 + [c_float, c_float, c_int32, c_float, c_int64,
                                                     c_float] + [c_void_p] * 5),
     "aa_sac_actor_loss": (c_int, [c_void_p] * 5 + [c_float, c_int64, c_float] + [c_void_p] * 5),

@@ -441,15 +441,14 @@ class SacAgent(tf_agent.TFAgent):
                                                       param_grads=False, want_action_grad=True)
                 da2 = self._critic_network_2.backward(w["dq2"], slot="actor_q",
                                                       param_grads=False, want_action_grad=True)
-            # da = da1 + da2: both are column slices of the critics' input-gradient buffers
-            _lib.check(lib.aa_add_strided_f32(da1.data_ptr(), da1.stride(0), da2.data_ptr(),
-                                              da2.stride(0), B, self._A, w["da"].data_ptr(),
-                                              _lib.stream_ptr()), "aa_add_strided_f32")
+            # d loss / d action = da1 + da2, both column slices of the critics' input-gradient
+            # buffers: added inside the head's backward launch
             mag = self._train_policy._consts(obs.device)[1]
             _lib.check(lib.aa_sac_head_backward(
                 z.data_ptr(), B, self._A, mag.data_ptr(),
                 self._actor_network.projection.std_kind, w["save"]["tanh"].data_ptr(),
-                w["save"]["sigma"].data_ptr(), w["save"]["eps"].data_ptr(), w["da"].data_ptr(),
+                w["save"]["sigma"].data_ptr(), w["save"]["eps"].data_ptr(), da1.data_ptr(),
+                da1.stride(0), da2.data_ptr(), da2.stride(0),
                 w["dlogp"].data_ptr(), w["dz"].data_ptr(), _lib.stream_ptr()),
                 "aa_sac_head_backward")
             self._actor_network.backward(w["dz"], slot="actor")

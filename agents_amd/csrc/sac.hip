@@ -93,6 +93,7 @@ aa_sac_head_bwd_kernel(const float* __restrict__ z, int64_t B, int A,
                        const float* __restrict__ act_mag, int std_kind,
                        const float* __restrict__ save_tanh, const float* __restrict__ save_sigma,
                        const float* __restrict__ save_eps, const float* __restrict__ daction,
+                       int64_t ld_da, const float* __restrict__ daction2, int64_t ld_da2,
                        const float* __restrict__ dlogp, float* __restrict__ dz) {
   const int64_t total = B * A, stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -100,7 +101,9 @@ aa_sac_head_bwd_kernel(const float* __restrict__ z, int64_t B, int A,
     const int d = (int)(i - b * A);
     const float t = save_tanh[i], sigma = save_sigma[i], eps = save_eps[i];
     const float dl = dlogp[b];
-    const float da = daction != nullptr ? daction[i] : 0.f;
+    // d loss / d action: one tensor, or the sum of two (the twin critics' input gradients)
+    float da = daction != nullptr ? daction[b * ld_da + d] : 0.f;
+    if (daction2 != nullptr) da = da + daction2[b * ld_da2 + d];
     const float gx = da * (act_mag[d] * (1.0f - t * t)) + dl * (2.0f * t);
     const float dsigma = gx * eps - dl / sigma;
     const float raw = z[b * 2 * A + A + d];
@@ -248,16 +251,20 @@ int aa_sac_sample(const float* z, int64_t B, int32_t A, const float* act_mean,
 
 int aa_sac_head_backward(const float* z, int64_t B, int32_t A, const float* act_mag,
                          int32_t std_kind, const float* save_tanh, const float* save_sigma,
-                         const float* save_eps, const float* daction, const float* dlogp,
+                         const float* save_eps, const float* daction, int64_t ld_daction,
+                         const float* daction2, int64_t ld_daction2, const float* dlogp,
                          float* dz, void* stream) {
   if (!z || !act_mag || !save_tanh || !save_sigma || !save_eps || !dlogp || !dz || B <= 0 ||
       A <= 0)
+    return AA_ERR_INVALID;
+  if ((daction != nullptr && ld_daction < A) || (daction2 != nullptr && ld_daction2 < A) ||
+      (daction2 != nullptr && daction == nullptr))
     return AA_ERR_INVALID;
   int64_t blocks = (B * A + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(aa_sac_head_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      (hipStream_t)stream, z, B, A, act_mag, std_kind, save_tanh, save_sigma,
-                     save_eps, daction, dlogp, dz);
+                     save_eps, daction, ld_daction, daction2, ld_daction2, dlogp, dz);
   return aa_launch_status();
 }
 

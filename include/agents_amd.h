@@ -724,10 +724,14 @@ int aa_sac_sample(const float* z, int64_t B, int32_t A, const float* act_mean,
                   const float* act_mag, int32_t std_kind, const float* eps_in, uint64_t seed,
                   int64_t* call_counter_dev, int64_t* arrival_dev, float* action, float* logp,
                   float* save_tanh, float* save_sigma, float* save_eps, void* stream);
-/* dz[B,2A] = d loss / d head output from d loss / d action (nullable) and d loss / d log_pi. */
+/* dz[B,2A] = d loss / d head output from d loss / d action (nullable; [B,A] with row stride
+ * ld_daction; daction2 nullable: the gradient is daction + daction2 -- the action columns of the
+ * twin critics' input gradients, sac_agent.py:646-694, without a launch that adds them first) and
+ * d loss / d log_pi. */
 int aa_sac_head_backward(const float* z, int64_t B, int32_t A, const float* act_mag,
                          int32_t std_kind, const float* save_tanh, const float* save_sigma,
-                         const float* save_eps, const float* daction, const float* dlogp,
+                         const float* save_eps, const float* daction, int64_t ld_daction,
+                         const float* daction2, int64_t ld_daction2, const float* dlogp,
                          float* dz, void* stream);
 /* critic_loss: td = scale*r + gamma*d*(min(tq1,tq2) - exp(log_alpha)*next_logp);
  * loss = weight * sum_b w_b (f(td,q1)+f(td,q2)) / global_batch; dq1/dq2 nullable (both or none). */

@@ -111,9 +111,23 @@ def test_sample_and_head_backward_vs_autograd(dev, kind, B, A):
     dz = torch.empty(B, 2 * A, device=dev)
     _lib.check(lib.aa_sac_head_backward(zd.data_ptr(), B, A, magd.data_ptr(), k,
                                         sv[0].data_ptr(), sv[1].data_ptr(), sv[2].data_ptr(),
-                                        dad.data_ptr(), dld.data_ptr(),
+                                        dad.data_ptr(), A, None, 0, dld.data_ptr(),
                                         dz.data_ptr(), _lib.stream_ptr()), "head bwd")
     close(dz, zr.grad, rtol=2e-5, atol=1e-5)
+    # d loss / d action as the sum of two strided tensors (the twin critics' input gradients):
+    # the same bits as adding them first
+    g = torch.Generator().manual_seed(9)
+    part = torch.randn(B, A + 3, generator=g).to(dev)
+    rest = torch.zeros(B, A + 5, device=dev)
+    rest[:, :A] = dad - part[:, :A]
+    summed = (part[:, :A] + rest[:, :A]).contiguous()
+    dz_a, dz_b = torch.empty(B, 2 * A, device=dev), torch.empty(B, 2 * A, device=dev)
+    for da1, ld1, da2, ld2, out in ((summed, A, None, 0, dz_a), (part, A + 3, rest, A + 5, dz_b)):
+        _lib.check(lib.aa_sac_head_backward(
+            zd.data_ptr(), B, A, magd.data_ptr(), k, sv[0].data_ptr(), sv[1].data_ptr(),
+            sv[2].data_ptr(), da1.data_ptr(), ld1, None if da2 is None else da2.data_ptr(), ld2,
+            dld.data_ptr(), out.data_ptr(), _lib.stream_ptr()), "head bwd")
+    assert torch.equal(dz_a, dz_b)
 
 
 def test_sample_internal_noise_is_standard_normal_and_advances(dev):
