@@ -34,12 +34,9 @@ from agents_amd.utils import common, graph, nest_utils
 
 SacLossInfo = collections.namedtuple("SacLossInfo", ("critic_loss", "actor_loss", "alpha_loss"))
 
-# AA_SAC_BRANCHES=1: the critic phase runs its four independent forwards (two targets, two online
-# critics) and the two critic backward passes as parallel branches of the train graph (fork / join
-# on side streams, each branch with its own GEMM scratch: ops.side_line) instead of one serial
-# chain of ~40 five-microsecond launches.  A/B knob; see DESIGN.md for the measurement.
-import os as _os
-SAC_BRANCHES = _os.environ.get("AA_SAC_BRANCHES", "0") == "1"
+# (Tried in round 3: the critic phase's four independent forwards and the twin critics' backward on
+# parallel graph branches -- 0.768 vs 0.556 ms per iteration: branch edges of a HIP graph cost more
+# than the overlap of latency-bound kernels gains.  Removed; the twin critics now share launches.)
 
 std_clip_transform = adn.std_clip_transform
 
@@ -269,12 +266,6 @@ class SacAgent(tf_agent.TFAgent):
             self._work[B] = w
         return w
 
-    def _branch_streams(self, dev):
-        st = getattr(self, "_sides", None)
-        if st is None:
-            st = self._sides = [ops.new_side_stream(dev) for _ in range(3)]
-        return st
-
     def _weights(self, weights, B, dev):
         if weights is None:
             return None
@@ -337,26 +328,8 @@ class SacAgent(tf_agent.TFAgent):
         pair = critic_network.pair_ok(self._critic_network_1, self._critic_network_2, obs, actions) \
             and critic_network.pair_ok(self._target_critic_network_1,
                                        self._target_critic_network_2, next_obs, actions)
-        branches = SAC_BRANCHES and fast and not pair
-        main = torch.cuda.current_stream(dev)
-        if branches:
-            # the online critics only need the batch: they start while the actor still samples
-            sides = self._branch_streams(dev)
-            for st in sides[:2]:
-                st.wait_stream(main)
-            with ops.side_line(sides[0]):
-                q1 = self._critic_network_1.forward(obs, actions, slot="critic",
-                                                    need_grad=need_grad, x_cat=xc["x_sa"])
-            with ops.side_line(sides[1]):
-                q2 = self._critic_network_2.forward(obs, actions, slot="critic",
-                                                    need_grad=need_grad, x_cat=xc["x_sa"])
         na, nlogp, _ = self._loss_policy.sample(next_obs, slot="next", eps=eps_next,
-                                           save=w.get("save_next"))
-        x_next = x_sa = None
-        if fast and not pair:
-            # [observation | action] once for both twin critics; the observation halves are there
-            x_next, x_sa = xc["x_next"], xc["x_sa"]
-            ops.copy_segments([(na.reshape(B, -1), x_next[:, self._O:])])
+                                                save=w.get("save_next"))
         if pair:
             tq1, tq2 = critic_network.forward_pair(
                 self._target_critic_network_1, self._target_critic_network_2, next_obs, na,
@@ -364,15 +337,13 @@ class SacAgent(tf_agent.TFAgent):
             q1, q2 = critic_network.forward_pair(
                 self._critic_network_1, self._critic_network_2, obs, actions, slot="critic",
                 need_grad=need_grad)
-        elif branches:
-            sides[2].wait_stream(main)
-            with ops.side_line(sides[2]):
-                tq2 = self._target_critic_network_2.forward(next_obs, na, slot="target",
-                                                            x_cat=x_next)
-            tq1 = self._target_critic_network_1.forward(next_obs, na, slot="target", x_cat=x_next)
-            for st in sides:
-                main.wait_stream(st)
         else:
+            x_next = x_sa = None
+            if fast:
+                # [observation | action] once for both twin critics; the observation halves are
+                # there already (_as_transition)
+                x_next, x_sa = xc["x_next"], xc["x_sa"]
+                ops.copy_segments([(na.reshape(B, -1), x_next[:, self._O:])])
             tq1 = self._target_critic_network_1.forward(next_obs, na, slot="target", x_cat=x_next)
             tq2 = self._target_critic_network_2.forward(next_obs, na, slot="target", x_cat=x_next)
             q1 = self._critic_network_1.forward(obs, actions, slot="critic", need_grad=need_grad,
@@ -391,12 +362,6 @@ class SacAgent(tf_agent.TFAgent):
             if pair:
                 critic_network.backward_pair(self._critic_network_1, self._critic_network_2,
                                              w["dq1"], w["dq2"], slot="critic")
-            elif branches:
-                sides[0].wait_stream(main)
-                with ops.side_line(sides[0]):
-                    self._critic_network_2.backward(w["dq2"], slot="critic")
-                self._critic_network_1.backward(w["dq1"], slot="critic")
-                main.wait_stream(sides[0])
             else:
                 self._critic_network_1.backward(w["dq1"], slot="critic")
                 self._critic_network_2.backward(w["dq2"], slot="critic")

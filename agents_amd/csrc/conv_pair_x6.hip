@@ -2,7 +2,7 @@
 // the Mnih-15 Q-network, examples/dqn/mnih15/dqn_train_eval_atari.py:80-112) on the bf16 matrix
 // cores at fp32 accuracy: one workgroup per frame, both activations written.
 //
-// Arithmetic (the identity proven for the conv1 kernels, conv_u8_bf16.h / gemm_bf16x6.h, and
+// Arithmetic (the identity proven for the conv1 kernels, conv_u8_bf16.h, and
 // restated on the CPU in oracle/numerics.py): an fp32 value is EXACTLY hi + mid + lo, three
 // round-to-nearest bf16 pieces; a product of two bf16 numbers is exact in fp32; of the nine piece
 // products of x * w the three smallest (< 2^-27 |x w|) are below fp32 rounding and dropped; the
@@ -10,8 +10,9 @@
 // accumulator and hi * hi in another, added at the end.  Six bf16 MFMAs cost 6/16 of the fp32 MFMA
 // of the same shape.
 //
-// What makes it pay here and not in the generic GEMM (gemm_bf16x6.h: "the in-register split of the
-// activations costs what the MFMAs save"): in this kernel every operand element is split ONCE.
+// What makes it pay here and not in a generic GEMM (a round-1 forward plan that split both fp32
+// operands in registers tied the fp32 MFMA kernels -- "the in-register split of the activations
+// costs what the MFMAs save" -- and was removed in round 3): in this kernel every operand element is split ONCE.
 //   * the input frame is split while it is staged into LDS (three bf16 planes, one ds_write_b128
 //     per 8 channels and plane) -- each element is then READ as a ready fragment by every patch
 //     that covers it (conv2: x4, conv3: x9) and every filter tile;

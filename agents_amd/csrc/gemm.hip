@@ -636,7 +636,6 @@ static const AaTileCfg kCfgs[] = {
 // (4 VALU per element) ~11 -- which is the floor to attack next, not the tile shape.
 
 #include "conv_u8_bf16.h"
-#include "gemm_bf16x6.h"
 #include "gemm_x6d.h"
 #define AA_CFG_X6D 10      // force_cfg value of the dense bf16x6 plan (gemm_x6d.h)
 
@@ -684,17 +683,6 @@ static int aa_gemm_plan(const aa_gemm_desc* d, AaGemmPlan* pl) {
     pl->cfg = AA_CFG_U8_BF16 - 1;
     pl->bm = 256; pl->bn = 32;
     pl->splits = 1; pl->k_per_split = (int)K; pl->ws_bytes = 0;
-    return AA_OK;
-  }
-  if ((d->a_mode == AA_A_ROW || d->a_mode == AA_A_PATCH) &&
-      d->force_cfg == AA_CFG_U8_BF16) {   // opt-in only: ties the fp32 plans (gemm_bf16x6.h)
-    if (!aa_fwd_x6_ok(d)) return AA_ERR_INVALID;
-    AaX6Plan x;
-    aa_fwd_x6_plan(d, &x);
-    pl->cfg = AA_CFG_U8_BF16 - 1;
-    pl->bm = 32 * x.nw; pl->bn = 32 * x.tn;
-    pl->splits = x.splits; pl->k_per_split = x.k_per_split;
-    pl->ws_bytes = x.splits > 1 ? (size_t)x.splits * (size_t)(M * N) * sizeof(float) : 0;
     return AA_OK;
   }
   if (d->a_mode == AA_A_PATCH_T_U8 &&
@@ -764,18 +752,9 @@ static int aa_gemm_plan(const aa_gemm_desc* d, AaGemmPlan* pl) {
     const int max_by_k = (int)(K / (4 * AA_BK));  // at least four K-steps per split
     if (splits > max_by_k) splits = max_by_k;
     if (splits < 1) splits = 1;
-    // A/B knob AA_GEMM_NOSPLIT_MFLOP (default 0 = off): contractions below that size run unsplit
-    // on however many tiles they have (>= 16 workgroups), which saves the slab-reduce launch --
-    // 30 of the ~120 launches of a SAC iteration (256-wide layers at batch 256: 40-50 MFLOP each).
-    // Measured on MI355X, alternating runs on one box: SAC iteration 0.554 ms split vs 0.584 ms
-    // unsplit at 128 -- 32 workgroups walking K = 393 take longer than 256 walking K = 49 plus the
-    // reduce; not adopted.
-    static double nosplit = -1.0;
-    if (nosplit < 0.0) {
-      const char* e = getenv("AA_GEMM_NOSPLIT_MFLOP");
-      nosplit = e != nullptr ? atof(e) : 0.0;
-    }
-    if (2.0 * (double)M * (double)N * (double)K <= nosplit * 1e6 && tiles >= 16) splits = 1;
+    // (tried: contractions below ~128 MFLOP unsplit on however many tiles they have, which saves
+    // the slab-reduce launch -- SAC iteration 0.584 vs 0.554 ms: 32 workgroups walking K = 393
+    // take longer than 256 walking K = 49 plus the reduce; removed)
   }
   int kps = (int)((K + splits - 1) / splits);
   kps = ((kps + AA_BK - 1) / AA_BK) * AA_BK;
@@ -1003,12 +982,6 @@ static int aa_gemm_f32_impl(const aa_gemm_desc* d, void* workspace, int64_t work
   if (d->b_mode == AA_B_COL && d->a_mode != AA_A_ROW) return AA_ERR_INVALID;
   switch (d->a_mode) {
     case AA_A_ROW:
-      if (pl.cfg == AA_CFG_U8_BF16 - 1) {
-        AaX6Plan x;
-        aa_fwd_x6_plan(d, &x);
-        rc = aa_fwd_x6_launch(p, x, false, st);
-        break;
-      }
       if (pl.cfg == AA_CFG_X6D - 1) {
         rc = aa_x6d_launch(p, true, d->b_mode == AA_B_COL, st);
         break;
@@ -1024,12 +997,6 @@ static int aa_gemm_f32_impl(const aa_gemm_desc* d, void* workspace, int64_t work
       rc = aa_gemm_launch_cfg<AA_A_COL, AA_B_ROW>(p, pl, st);
       break;
     case AA_A_PATCH:
-      if (pl.cfg == AA_CFG_U8_BF16 - 1) {
-        AaX6Plan x;
-        aa_fwd_x6_plan(d, &x);
-        rc = aa_fwd_x6_launch(p, x, true, st);
-        break;
-      }
       rc = aa_gemm_launch_cfg<AA_A_PATCH, AA_B_ROW>(p, pl, st);
       break;
     case AA_A_PATCH_U8:

@@ -173,8 +173,8 @@ typedef struct aa_gemm_desc {
   int32_t force_cfg;      /* 0 = auto; 1..8 = fp32 MFMA tiles 128x64, 128x32, 64x64, 128x128, 64x32,
                            * 32x64, 32x32, 256x32 (LDS-DMA operands only); 9 = the bf16 matrix-core
                            * plans with exact 3-piece splits: uint8 conv forward / weight gradient
-                           * with 32 filters (the automatic choice there, csrc/conv_u8_bf16.h) and
-                           * fp32 forward contractions (opt-in, csrc/gemm_bf16x6.h); 10 = the dense
+                           * with 32 filters (the automatic choice there, csrc/conv_u8_bf16.h);
+                           * 10 = the dense
                            * bf16x6 plan (csrc/gemm_x6d.h: both operands split on their way into
                            * LDS, 64x64 tiles; K % 32 == 0; opt-in: it wins in isolation, not inside
                            * the DQN iteration); AA_ERR_INVALID when the shape is not

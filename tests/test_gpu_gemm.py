@@ -626,83 +626,6 @@ def test_conv_u8_bf16x3_dw_exact_and_deterministic(dev):
     assert torch.equal(outs[0][1].double(), dz.double().sum(0))
 
 
-# ---- fp32 forward contractions on the bf16 matrix cores, 3 x 3 piece products (gemm_bf16x6.h) ---
-X6_DENSE = [  # (M, K, N)
-    (256, 3136, 512),    # Atari fc1: K split over workgroups + slab reduce
-    (1000, 128, 40),     # ragged rows and columns, one K range
-    (128, 768, 32),      # exactly one LDS slice of K
-    (333, 1600, 96),     # three column slices, K split 3 ways (not a divisor-friendly count)
-    (4096, 256, 64),
-]
-
-
-@pytest.mark.parametrize("shape", X6_DENSE)
-@pytest.mark.parametrize("act", [None, "relu", "tanh"])
-def test_dense_forward_bf16x6(dev, shape, act):
-    M, K, N = shape
-    rng = np.random.default_rng(M + K + N)
-    x, w, b = rnd(rng, M, K), rnd(rng, K, N) * 0.1, rnd(rng, N)
-    ref = act_ref(x.double() @ w.double() + b.double(), act)
-    outs = {}
-    for name, force in (("x6", 9), ("auto", 0), ("fp32", 3)):
-        out = torch.full((M, N), float("nan"), device=dev)
-        ops.dense_forward(x.to(dev), w.to(dev), b.to(dev), act, out, force_cfg=force)
-        close(out, ref)
-        outs[name] = out.cpu()
-    err = lambda o: (o.double() - ref).abs().max().item()
-    assert err(outs["x6"]) <= 2.0 * err(outs["fp32"]) + 1e-7
-
-
-def test_dense_forward_bf16x6_wide_dynamic_range(dev):
-    """Rows scaled over 12 decades and a strided (row-pitch) input: the three-piece split is exact
-    per element, so the relative error per output row stays at fp32 level."""
-    rng = np.random.default_rng(3)
-    M, K, N = 512, 512, 64
-    big = rnd(rng, M, K + 16)
-    x = big[:, :K] * torch.logspace(-6, 6, M).unsqueeze(1)
-    w = rnd(rng, K, N)
-    out = torch.empty(M, N, device=dev)
-    xd = (big.to(dev) * torch.logspace(-6, 6, M, device=dev).unsqueeze(1))[:, :K]
-    assert not xd.is_contiguous()
-    ops.dense_forward(xd, w.to(dev), None, None, out, force_cfg=9)
-    ref = xd.cpu().double() @ w.double()
-    rel = ((out.cpu().double() - ref).abs().max(1).values / ref.abs().max(1).values).max().item()
-    assert rel < 2e-6, rel
-
-
-X6_CONVS = [  # (B, H, W, C, KH, KW, stride, F)
-    (8, 20, 20, 32, 4, 4, 2, 64),    # Atari conv2
-    (8, 9, 9, 64, 3, 3, 1, 64),      # Atari conv3
-    (3, 12, 10, 16, 4, 2, 1, 40),    # 32-float patch rows, ragged filters
-    (2, 17, 17, 8, 5, 4, 3, 32),     # 32-float patch rows, stride 3
-]
-
-
-@pytest.mark.parametrize("cfg", X6_CONVS)
-def test_conv_forward_bf16x6(dev, cfg):
-    B, H, W, C, KH, KW, s, Fo = cfg
-    rng = np.random.default_rng(sum(cfg) + 17)
-    x, w, b = rnd(rng, B, H, W, C), rnd(rng, KH, KW, C, Fo) * 0.1, rnd(rng, Fo)
-    OH, OW = ops.conv_out_hw(H, W, KH, KW, s)
-    ref = torch.relu(conv_ref(x, w, b, s, 1.0))
-    outs = {}
-    for name, force in (("x6", 9), ("auto", 0), ("fp32", 3)):
-        out = torch.full((B, OH, OW, Fo), float("nan"), device=dev)
-        ops.conv_forward(x.to(dev), w.to(dev), b.to(dev), s, "relu", out, force_cfg=force)
-        close(out, ref)
-        outs[name] = out.cpu()
-    err = lambda o: (o.double() - ref).abs().max().item()
-    assert err(outs["x6"]) <= 2.0 * err(outs["fp32"]) + 1e-7
-
-
-def test_bf16x6_refuses_ineligible(dev):
-    rng = np.random.default_rng(1)
-    x, w = rnd(rng, 64, 50), rnd(rng, 50, 32)      # K not a multiple of 16
-    with pytest.raises(Exception):
-        ops.dense_forward(x.to(dev), w.to(dev), None, None, torch.empty(64, 32, device=dev),
-                          force_cfg=9)
-
-
 def test_sequential_dense_tail_equals_layer_by_layer(dev):
     """The Atari Q-network with the head summing fc1's split-K slabs: outputs, stored activations and
     gradients are bit-identical to the layer-by-layer forward (ops.FUSE_DENSE_TAIL off)."""
