@@ -554,14 +554,22 @@ def main_other_config(args):
                "config": {"workload": r["workload"] + "; step = 1 collect step (4096 envs) + "
                           "sample 256x2 + 1 SacAgent.train", "parallelism": "single"},
                "env_steps_per_sec": r["env_steps_per_sec"],
-               "roofline": {"kernel": "one SAC iteration (3 HIP graphs, ~70 launches)",
+               "roofline": {"kernel": "one SAC iteration: 36 launches (train step 25: whole "
+                                      "(256,256) MLPs forward in one launch and backward in two, "
+                                      "twin critics per launch, csrc/mlp_wide.hip; collect 10; "
+                                      "draw 1), train step replayed as two HIP graphs beside the "
+                                      "collect graph",
                             "bound": "mfma", "achieved": flop / dt / 1e9,
                             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": flop / dt / 1e9 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                             "algorithmic_flop_per_launch": flop, "avg_launch_ms": dt,
-                            "note": "256-wide MLPs at batch 256: latency-bound chains of small "
-                                    "GEMMs; the collect forward on 4,096 envs is the only launch "
-                                    "that fills the chip"}}
+                            "note": "256-wide MLPs at batch 256: every launch is bound by what "
+                                    "ONE CU can stream from L2 and multiply (forward 13 us, "
+                                    "gradient chain 21 us, weight gradients 7-10 us per launch; "
+                                    "in-kernel timelines in DESIGN.md); frac against the fp32 MFMA "
+                                    "peak is what the shape allows, not a kernel-quality figure; "
+                                    "the collect forward on 4,096 envs is the only launch that "
+                                    "fills the chip"}}
         if not args.no_cpu_baseline:
             th, ncpu, cands = _best_threads(lambda n, t: bench_sac.cpu_baseline(256, n, t))
             sps = bench_sac.cpu_baseline(256, 300, th)
