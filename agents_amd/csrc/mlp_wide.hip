@@ -15,19 +15,26 @@
 //              rows of W (1 KiB, coalesced) with sixteen rows in flight per lane and does 16 FMAs
 //              per 16-byte load.  Partial sums meet in LDS in wave order (deterministic).  The
 //              first layer can read its input from two tensors ([observation | action]).
-//   backward : (1) the gradient chain g_l -> dz_l = g_l * act'(y_l) -> g_{l-1} = dz_l W_l^T, again
-//              four samples per workgroup; W_l^T is never formed: 32-row tiles of W go to LDS
-//              with coalesced loads and are read back row-per-lane.  dz_l is written for (2);
-//              the input gradient is optional and can be limited to a column range (the action
-//              columns of a critic's input in SAC's actor loss).
+//   backward : (1) the gradient chain g_l -> dz_l = g_l * act'(y_l) -> g_{l-1} = dz_l W_l^T, four
+//              samples per workgroup again; W_l^T is never formed: 32-row tiles of W travel
+//              L2 -> registers -> LDS with coalesced whole-row loads, two tiles ahead, and are read
+//              back one row per 16-lane group (see aa_mlp_wide_chain_kernel); narrow / odd-width
+//              layers (heads) take a plain FMA loop.  dz_l is written for (2); the input gradient
+//              is optional and can be limited to a column range (the action columns of a
+//              critic's input in SAC's actor loss: only those rows of the first kernel are read).
 //              (2) every weight gradient dW_l = H_{l-1}^T dz_l (+ bias column sums) of every layer
 //              and network in one grid of 32 x 32 tiles on the fp32 matrix cores, full batch per
-//              tile (no split-K slabs); written, not accumulated.
-// At four samples per workgroup a batch of 256 is 64 workgroups per network, each streaming the
-// network's weights (0.66 MB for a SAC critic) at the ~64 B/clk a CU draws from L2: ~4 us, against
-// which the 16 FMAs per loaded float4 are balanced (2.6 us of VALU for the widest layer).  For
-// batches in the thousands the GEMM path (gemm.hip) is the better plan: callers use this one up
-// to AA_MLPW_MAX_BATCH samples.
+//              tile (no split-K slabs), every operand of a 64-sample chunk requested before the
+//              first MFMA; written, not accumulated.
+// Forward: at four samples per workgroup a batch of 256 is 64 workgroups per network, each streaming
+// the network's weights (0.66 MB for a SAC critic) at the ~64 B/clk a CU draws from L2: ~4 us,
+// against which the 16 FMAs per loaded float4 are balanced (2.6 us of VALU for the widest layer);
+// measured 13 us per launch for one network or two.  For batches in the thousands the GEMM path
+// (gemm.hip) is the better plan: callers use this one up to AA_MLPW_MAX_BATCH samples.
+// Rules these kernels were rebuilt around ("Round 3"): no load under a per-lane or
+// per-group condition in a steady state (the compiler then waits for ALL outstanding loads),
+// older values pinned before a prefetch is issued, no scratch spills behind a prefetch, a
+// run-time loop over the layers (unrolled, a chain kernel was 100 KB of code per launch).
 #include "common.h"
 #include "agents_amd.h"
 
@@ -272,22 +279,9 @@ struct MwBwdP {
 };
 
 
-// Sixteen samples per workgroup, the products on the fp32 matrix cores: g_{l-1}[s][i] =
-// sum_o dz[s][o] W[i][o] is a [16 samples] x [16 rows of W] block per MFMA chain, A = dz from LDS,
-// B = W straight from L2 -- the contraction index o is dealt to the four k-slots of the
-// instruction as o = 16 b + 4 slot + step, so a lane's four steps read four CONSECUTIVE floats of
-// its row of W (one 16-byte load) and of its sample's dz (one 16-byte LDS read).  The matrix core
-// does the cross-lane sum that a VALU formulation pays for with an LDS transpose of W and two
-// barriers per 32 rows (18 us per launch against ~10).
-#define MW_CS 16   // samples per workgroup of the chain kernel
-#define MW_CTHREADS 1024
-#define MW_CWAVES 16
-#define MW_CE (MW_CS * MW_MAXW / MW_CTHREADS)   // (sample, column) elements per thread and layer
-
 // Workgroup barrier that only waits for this wave's LDS traffic: __syncthreads() carries a release
 // fence that also drains the vector-memory counter, i.e. the dz stores (read by the NEXT launch)
-// and the prefetched rows of W (waited for where they are used) -- 2 us per layer on the in-kernel
-// timeline.
+// and the prefetched rows of W (waited for where they are used).
 __device__ static inline void mw_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -296,50 +290,77 @@ __device__ static inline void mw_lds_barrier() {
 
 typedef float mw_acc4 __attribute__((ext_vector_type(4)));
 
-__global__ void __launch_bounds__(MW_CTHREADS) aa_mlp_wide_chain_kernel(MwBwdP p) {
-  __shared__ __attribute__((aligned(16))) float dzs[MW_CS][MW_MAXW + 4];
-  __shared__ __attribute__((aligned(16))) float gs[MW_CS][MW_MAXW + 4];
+// ---- backward (1): four samples per workgroup, W through LDS in 32-row tiles ----------------------
+// g_{l-1}[s][i] = sum_o dz[s][o] W[i][o]: a tile of 32 rows of W travels L2 -> registers -> LDS with
+// coalesced whole-row loads (two tiles ahead of the one being multiplied); lane (row, column group
+// og) multiplies its 16 columns for the 4 samples (dz in registers) and the 16 partial sums of a
+// (row, sample) meet inside a 16-lane DPP row.  64 workgroups per network, each streams the layer's
+// weights once.  17.3 us per launch for a critic pair with the action gradient.
+// Tried and removed: sixteen samples per workgroup on v_mfma_f32_16x16x4_f32 with the rows of W
+// read straight from L2 in MFMA layout (64-byte runs): 21.5 us -- 4.5 us of row loads behind
+// sixteen waves and 4.9 us of MFMA per 256 x 256 layer on the in-kernel timeline (3.4 us is ONE CU's
+// fp32 MFMA rate for 16 x 256 x 256); partial sums through __shfl_xor (ds_bpermute): 19.4 us;
+// through LDS with a two-wave reduce phase: 17.9 us.
+#define MW_VT 512
+
+// v of the lane N places to the left inside its 16-lane row (cyclic): a DPP modifier on a VALU
+// move, no LDS crossbar.  Four of them (8, 4, 2, 1) leave the row's sum in every lane.
+template <int N>
+__device__ static inline float mw_row_ror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+
+__global__ void __launch_bounds__(MW_VT) aa_mlp_wide_chain_kernel(MwBwdP p) {
+  __shared__ float dzs[MW_TS][MW_MAXW];
+  __shared__ float gs[MW_TS][MW_MAXW];
+  __shared__ __attribute__((aligned(16))) float Wt[32][MW_WT_LD];
   const int g = blockIdx.y;
-  const int64_t s0 = (int64_t)blockIdx.x * MW_CS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t s0 = (int64_t)blockIdx.x * MW_TS;
+  const int tid = threadIdx.x;
   const float* __restrict__ params = p.net[g].params;
   const int L = p.lay.n_layers;
   MW_STAMP(0)
-  // the saved activations (act' factors) of a layer are requested one layer AHEAD of their use:
-  // behind the weight rows of sixteen waves in the CU's memory pipeline they arrive 4 us late
-  float yv[MW_CE];
-#define MW_YLOAD(LL)                                                          \
-  {                                                                           \
-    const int n_ = p.lay.dims[(LL) + 1];                                      \
-    const float* __restrict__ y_ = p.net[g].y[LL];                            \
-    _Pragma("unroll") for (int h = 0; h < MW_CE; ++h) {                       \
-      const int s = (tid >> 8) + (MW_CTHREADS / 256) * h, c = tid & 255;      \
-      const bool live = c < n_ && s0 + s < p.B;                               \
-      yv[h] = y_[live ? (s0 + s) * n_ + c : 0];                               \
-    }                                                                         \
+  // element (sample, column) = (tid >> 8) + 2 h, tid & 255 for h < 2: every saved activation this
+  // thread needs, of every layer, is requested now (unconditionally, from clamped addresses)
+  const int ec = tid & 255, es = tid >> 8;
+  float yv[AA_MLP_MAX_LAYERS][2];
+#pragma unroll
+  for (int l = 0; l < AA_MLP_MAX_LAYERS; ++l) {
+    const int ll = l < L ? l : L - 1;
+    const int n_out = p.lay.dims[ll + 1];
+    const float* __restrict__ y = p.net[g].y[ll];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int s = es + 2 * h;
+      const bool live = ec < n_out && s0 + s < p.B;
+      yv[l][h] = y[live ? (s0 + s) * n_out + ec : 0];
+    }
   }
-  MW_YLOAD(L - 1)
   {
     const float* __restrict__ dout = p.net[g].dout;
     const int64_t ld = p.net[g].ld_dout;
     const int n = p.lay.dims[L];
 #pragma unroll
-    for (int h = 0; h < MW_CE; ++h) {
-      const int s = (tid >> 8) + (MW_CTHREADS / 256) * h, c = tid & 255;
-      if (c < n) gs[s][c] = s0 + s < p.B ? dout[(s0 + s) * ld + c] : 0.f;
+    for (int h = 0; h < 2; ++h) {
+      const int s = es + 2 * h;
+      const bool live = ec < n && s0 + s < p.B;
+      const float v = dout[live ? (s0 + s) * ld + ec : 0];
+      if (ec < n) gs[s][ec] = live ? v : 0.f;
     }
   }
   mw_lds_barrier();
+  // every act' factor is pinned in its register here, once: a wait for one of them placed behind
+  // a layer's (conditional) tile prefetch would have to be a wait for the prefetch as well
+#pragma unroll
+  for (int l = 0; l < AA_MLP_MAX_LAYERS; ++l)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) asm volatile("" ::"v"(yv[l][h]));
   MW_STAMP(1)
-  const int lr = lane & 15, lk = lane >> 4;
-  // (a run-time loop over the layers: unrolled, the kernel was 100 KB of code that every launch
-  // had to pull through the instruction cache first)
   for (int l = L - 1; l >= 0; --l) {
     const int n_in = p.lay.dims[l], n_out = p.lay.dims[l + 1];
     const float* __restrict__ W = params + p.lay.k_off[l];
     float* __restrict__ dz = p.net[g].dz[l];
     const int act = p.lay.acts[l];
-    const int n16 = (n_out + 15) & ~15;
     int lo = 0, hi = n_in;
     float* __restrict__ dx = nullptr;
     if (l == 0) {
@@ -347,116 +368,125 @@ __global__ void __launch_bounds__(MW_CTHREADS) aa_mlp_wide_chain_kernel(MwBwdP p
       lo = dx != nullptr ? p.dx_lo : 0;
       hi = dx != nullptr ? p.dx_hi : 0;
     }
-    // layers whose width is a multiple of 16 go to the matrix cores; the others (heads: 1, 34
-    // columns) take a plain FMA loop, one lane per row
-    const bool mfma = hi > lo && (n_out & 15) == 0 && (((uintptr_t)W) & 15) == 0;
-    const int nblk = hi > lo ? (hi - lo + 15) >> 4 : 0;
-    const bool full = n_out == MW_MAXW;
     const int64_t ld_dx = p.net[g].ld_dx;
-    // The rows of W this wave multiplies do not depend on the chain: its first 16-row block
-    // (sixteen waves: all of a 256-row layer) is requested BEFORE the dz phase and its barrier, so one round
-    // trip per layer is shared by the weights and the phase that produces their other operand.
-    // The loads are UNCONDITIONAL, from clamped addresses: a load under a per-lane condition is
-    // merged with its zero alternative at the join and waited for right there.  Rows beyond the
-    // range are never stored.
-    mw_f4 wv[1][MW_MAXW / 16];
-#define MW_ROWS(slot, blk_)                                                 \
-  {                                                                         \
-    int i_ = lo + (blk_) * 16 + lr;                                         \
-    i_ = i_ < hi ? i_ : hi - 1;                                             \
-    i_ = i_ > lo ? i_ : lo;                                                 \
-    const float* __restrict__ wr_ = W + (int64_t)i_ * n_out + 4 * lk;       \
-    if (full) { /* 256 columns: straight-line loads, which the compiler can COUNT (it then  \
-                   waits for exactly the loads an instruction needs; behind a branch it     \
-                   waits for all of them) */                                                \
-      _Pragma("unroll") for (int q = 0; q < MW_MAXW / 16; ++q)              \
-        wv[slot][q] = *reinterpret_cast<const mw_f4*>(wr_ + q * 16);        \
-    } else {                                                                \
-      _Pragma("unroll") for (int q = 0; q < MW_MAXW / 16; ++q)              \
-        if (q * 16 < n_out) /* (uniform) */                                 \
-          wv[slot][q] = *reinterpret_cast<const mw_f4*>(wr_ + q * 16);      \
-    }                                                                       \
-  }
-#define MW_BLOCK(slot, blk_)                                                                 \
-  if ((blk_) < nblk) {                                                                       \
-    mw_acc4 acc_ = {0.f, 0.f, 0.f, 0.f};                                                     \
-    _Pragma("unroll") for (int q = 0; q < MW_MAXW / 16; ++q) {                               \
-      if (q * 16 < n16) {                                                                    \
-        const mw_f4 av_ = *reinterpret_cast<const mw_f4*>(&dzs[lr][q * 16 + 4 * lk]);        \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) acc_ =                                 \
-            __builtin_amdgcn_mfma_f32_16x16x4f32(av_[t], wv[slot][q][t], acc_, 0, 0, 0);    \
-      }                                                                                      \
-    }                                                                                        \
-    /* acc_[r] = g_prev[sample 4 lk + r][row lo + blk * 16 + lr] */                          \
-    const int i_ = lo + (blk_) * 16 + lr;                                                    \
-    if (i_ < hi) {                                                                           \
-      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                        \
-        const int s_ = 4 * lk + r;                                                           \
-        if (l > 0) gs[s_][i_] = acc_[r];                                                     \
-        else if (s0 + s_ < p.B) dx[(s0 + s_) * ld_dx + i_] = acc_[r];                        \
-      }                                                                                      \
-    }                                                                                        \
-  }
-    // the act' factors (requested a layer ago) are pinned in registers BEFORE the rows are
-    // requested: a wait for them placed after the row loads would have to be a wait for
-    // everything (the number of row loads differs between the branches above)
+    // (widths that are a multiple of 64: 128, 192, 256; the others take the plain loop below)
+    const bool wide = hi > lo && n_out > 64 && (n_out & 63) == 0 && (((uintptr_t)W) & 15) == 0;
+    // the first two tiles of a wide layer are requested BEFORE the dz phase (they do not depend on
+    // it); rows are clamped into [lo, hi): loads are unconditional
+    const int n4 = n_out >> 2;
+    int pr[4], pc[4];
+    mw_f4 pre[2][4];
 #pragma unroll
-    for (int h = 0; h < MW_CE; ++h) asm volatile("" ::"v"(yv[h]));
-    if (mfma) {
-      MW_ROWS(0, wave)
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + q * MW_VT;
+      pr[q] = wide && e < 32 * n4 ? e / n4 : -1;
+      pc[q] = pr[q] >= 0 ? (e - pr[q] * n4) * 4 : 0;
     }
-    if (l == L - 2) { MW_STAMP(10) }
-    // dz = g * act'(y); columns up to the next multiple of 16 are zero for the MFMA loop
+#define MW_ISSUE(slot, row0)                                                         \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                    \
+    int r_ = (row0) + (pr[q] >= 0 ? pr[q] : 0);                                      \
+    r_ = r_ < hi ? r_ : hi - 1;                                                      \
+    pre[slot][q] = *reinterpret_cast<const mw_f4*>(W + (int64_t)r_ * n_out + pc[q]); \
+  }
+#define MW_COMMIT(slot)                                                              \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) if (pr[q] >= 0)                      \
+      *reinterpret_cast<mw_f4*>(&Wt[pr[q]][pc[q]]) = pre[slot][q];
+    if (wide) {
+      MW_ISSUE(0, lo)
+      MW_ISSUE(1, lo + 32)
+    }
+    // dz = g * act'(y)
 #pragma unroll
-    for (int h = 0; h < MW_CE; ++h) {
-      const int s = (tid >> 8) + (MW_CTHREADS / 256) * h, c = tid & 255;
-      if (c < n_out) {
-        const float d = s0 + s < p.B ? gs[s][c] * mw_actgrad(yv[h], act) : 0.f;
-        dzs[s][c] = d;
-        if (s0 + s < p.B) dz[(s0 + s) * n_out + c] = d;
+    for (int h = 0; h < 2; ++h) {
+      const int s = es + 2 * h;
+      if (ec < n_out) {
+        float yy = yv[0][h];
+        if (l == 1) yy = yv[1][h];
+        if (l == 2) yy = yv[2][h];
+        if (l == 3) yy = yv[3][h];
+        const float d = s0 + s < p.B ? gs[s][ec] * mw_actgrad(yy, act) : 0.f;
+        dzs[s][ec] = d;
+        if (s0 + s < p.B) dz[(s0 + s) * n_out + ec] = d;
       }
-    }
-    if (l == L - 2) { MW_STAMP(11) }
-    if (n16 != n_out && tid < MW_CS * 16) {      // (sample, one of <= 15 padding columns)
-      const int s = tid >> 4, c = n_out + (tid & 15);
-      if (c < n16) dzs[s][c] = 0.f;
     }
     mw_lds_barrier();
     MW_STAMP(2 + 2 * (L - 1 - l))
-    if (l > 0) { MW_YLOAD(l - 1) }   // (yv was consumed by the dz phase above)
-    if (mfma) {
-      MW_BLOCK(0, wave)
-      for (int blk = wave + MW_CWAVES; blk < nblk; blk += MW_CWAVES) {   // > 256 rows
-        MW_ROWS(0, blk)
-        MW_BLOCK(0, blk)
+    if (wide) {
+      // lane = (row r of the wave's four, column group og): group og owns columns
+      // 64 j + 4 og .. + 3 (j < 4) -- a 16-lane row of the wave reads 256 consecutive bytes of
+      // LDS per instruction (conflict-free) and the 16 partial sums of a (row, sample) meet
+      // inside that 16-lane row by DPP row rotations: no partial sums through LDS, no reduce phase that
+      // two waves execute while six wait (0.4 us per tile on the in-kernel timeline)
+      const int lane = tid & 63, og = lane & 15, il = (tid >> 6) * 4 + (lane >> 4);
+      float dzr[MW_TS][16];
+#pragma unroll
+      for (int s = 0; s < MW_TS; ++s)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int c = (j >> 2) * 64 + og * 4 + (j & 3);
+          dzr[s][j] = c < n_out ? dzs[s][c] : 0.f;
+        }
+      // Tiles in PAIRS, both always executed, every load unconditional (rows clamped into the
+      // range; rows beyond it are multiplied and dropped): between a tile's loads and the store
+      // to LDS that waits for them lies a fixed number of younger loads, so the compiler waits
+      // for exactly that tile (with a conditional issue it waited for everything: 1.1 us per tile
+      // on the in-kernel timeline).
+#define MW_TILE(slot, row0)                                                                    \
+  {                                                                                            \
+    MW_COMMIT(slot)                                                                            \
+    mw_lds_barrier();                                                                          \
+    MW_ISSUE(slot, (row0) + 64)                                                                \
+    mw_f4 w_[4];                                                                               \
+    _Pragma("unroll") for (int j4 = 0; j4 < 4; ++j4)                                           \
+        w_[j4] = j4 * 64 < n_out ? *reinterpret_cast<const mw_f4*>(&Wt[il][j4 * 64 + og * 4])  \
+                                 : mw_f4{0.f, 0.f, 0.f, 0.f};                                  \
+    float acc[MW_TS] = {0.f, 0.f, 0.f, 0.f};                                                   \
+    _Pragma("unroll") for (int j4 = 0; j4 < 4; ++j4)                                           \
+        _Pragma("unroll") for (int s = 0; s < MW_TS; ++s)                                      \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[s] =                             \
+                fmaf(dzr[s][j4 * 4 + j], w_[j4][j], acc[s]);                                   \
+    _Pragma("unroll") for (int s = 0; s < MW_TS; ++s) {                                        \
+      acc[s] += mw_row_ror<8>(acc[s]);                                                         \
+      acc[s] += mw_row_ror<4>(acc[s]);                                                         \
+      acc[s] += mw_row_ror<2>(acc[s]);                                                         \
+      acc[s] += mw_row_ror<1>(acc[s]);                                                         \
+    }                                                                                          \
+    const int i = (row0) + il;                                                                 \
+    if (og == 0 && i < hi) {                                                                   \
+      _Pragma("unroll") for (int s = 0; s < MW_TS; ++s) {                                      \
+        if (l > 0) gs[s][i] = acc[s];                                                          \
+        else if (s0 + s < p.B) dx[(s0 + s) * ld_dx + i] = acc[s];                              \
+      }                                                                                        \
+    }                                                                                          \
+    mw_lds_barrier(); /* every lane is done with this tile before the next one lands in Wt */  \
+  }
+      for (int i0 = lo; i0 < hi; i0 += 64) {
+        MW_TILE(0, i0)
+        MW_TILE(1, i0 + 32)
       }
+#undef MW_TILE
     } else if (hi > lo) {
-      for (int i = lo + tid; i < hi; i += MW_CTHREADS) {
+      // narrow or odd-width layer: one lane per row of W, plain FMA loop
+      for (int i = lo + tid; i < hi; i += MW_VT) {
         const float* __restrict__ wr = W + (int64_t)i * n_out;
-#pragma unroll 1
-        for (int sb = 0; sb < MW_CS; sb += 8) {       // eight samples at a time (registers)
-          float acc[8];
+        float acc[MW_TS] = {0.f, 0.f, 0.f, 0.f};
+        for (int o = 0; o < n_out; ++o) {
+          const float w = wr[o];
 #pragma unroll
-          for (int s = 0; s < 8; ++s) acc[s] = 0.f;
-          for (int o = 0; o < n_out; ++o) {
-            const float w = wr[o];
+          for (int s = 0; s < MW_TS; ++s) acc[s] = fmaf(dzs[s][o], w, acc[s]);
+        }
 #pragma unroll
-            for (int s = 0; s < 8; ++s) acc[s] = fmaf(dzs[sb + s][o], w, acc[s]);
-          }
-#pragma unroll
-          for (int s = 0; s < 8; ++s) {
-            if (l > 0) gs[sb + s][i] = acc[s];
-            else if (s0 + sb + s < p.B) dx[(s0 + sb + s) * ld_dx + i] = acc[s];
-          }
+        for (int s = 0; s < MW_TS; ++s) {
+          if (l > 0) gs[s][i] = acc[s];
+          else if (s0 + s < p.B) dx[(s0 + s) * ld_dx + i] = acc[s];
         }
       }
     }
-#undef MW_ROWS
-#undef MW_BLOCK
+#undef MW_ISSUE
+#undef MW_COMMIT
     mw_lds_barrier();
     MW_STAMP(3 + 2 * (L - 1 - l))
   }
-#undef MW_YLOAD
 }
 
 // ---- backward (2): every dW / db of every layer and network ------------------------------------------
@@ -692,9 +722,8 @@ int aa_mlp_wide_backward(const aa_mlp_wide_bwd* d, void* stream) {
   const int64_t gx = (d->B + MW_TS - 1) / MW_TS;
   if (gx > 0x7fffffffLL) return AA_ERR_RANGE;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(aa_mlp_wide_chain_kernel,
-                     dim3((unsigned)((d->B + MW_CS - 1) / MW_CS), (unsigned)d->n_nets),
-                     dim3(MW_CTHREADS), 0, st, p);
+  hipLaunchKernelGGL(aa_mlp_wide_chain_kernel, dim3((unsigned)gx, (unsigned)d->n_nets),
+                     dim3(MW_VT), 0, st, p);
   if (want_dw) {
     int tiles = 0;
     for (int l = 0; l < L; ++l) {

@@ -565,7 +565,7 @@ def main_other_config(args):
                             "algorithmic_flop_per_launch": flop, "avg_launch_ms": dt,
                             "note": "256-wide MLPs at batch 256: every launch is bound by what "
                                     "ONE CU can stream from L2 and multiply (forward 13 us, "
-                                    "gradient chain 21 us, weight gradients 7-10 us per launch; "
+                                    "gradient chain 17 us, weight gradients 7-10 us per launch; "
                                     "in-kernel timelines in DESIGN.md); frac against the fp32 MFMA "
                                     "peak is what the shape allows, not a kernel-quality figure; "
                                     "the collect forward on 4,096 envs is the only launch that "
