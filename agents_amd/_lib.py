@@ -285,6 +285,8 @@ _SIGNATURES = {
                               c_float, c_void_p, c_void_p]),
     "aa_sac_alpha_loss": (c_int, [c_void_p] * 3 + [c_float, c_int32, c_float, c_int64, c_float] +
                           [c_void_p] * 3),
+    "aa_sac_alpha_step": (c_int, [c_void_p] * 3 + [c_float, c_int32, c_float, c_int64, c_float] +
+                          [c_void_p] * 5 + [c_float] * 4 + [c_void_p] * 4),
 }
 
 _lib = None

@@ -419,12 +419,27 @@ class SacAgent(tf_agent.TFAgent):
             self._actor_network.backward(w["dz"], slot="actor")
         return w["aloss"]
 
-    def _alpha_phase(self, obs, weights, need_grad, eps=None):
+    def _alpha_phase(self, obs, weights, need_grad, eps=None, tail=None):
+        """`tail` = (critic_loss, actor_loss, packed4): loss, the Adam step on log_alpha and the
+        LossInfo pack run as ONE launch (aa_sac_alpha_step; bit-identical to the three)."""
         lib = _lib.load()
         B = obs.shape[0]
         w = self._w(B, obs.device)
         _, logp, _ = self._loss_policy.sample(obs, slot="alpha", eps=eps,
                                               save=w.get("save_alpha"))
+        if tail is not None:
+            opt = self._alpha_optimizer
+            slot = opt._slot(self._log_alpha_buf, ("m", "v"))
+            _lib.check(lib.aa_sac_alpha_step(
+                logp.data_ptr(), _lib.ptr(weights), self._log_alpha_buf.data_ptr(),
+                self._target_entropy, 1 if self._use_log_alpha_in_alpha_loss else 0,
+                self._alpha_loss_weight, B, float(B * self.num_replicas), w["lloss"].data_ptr(),
+                self._log_alpha_grad.data_ptr(), slot["m"].data_ptr(), slot["v"].data_ptr(),
+                slot["step"].data_ptr(), opt.learning_rate, opt.beta_1, opt.beta_2, opt.epsilon,
+                tail[0].data_ptr(), tail[1].data_ptr(), tail[2].data_ptr(), _lib.stream_ptr()),
+                "aa_sac_alpha_step")
+            graph.on_replay(opt._bump_iterations)
+            return w["lloss"]
         _lib.check(lib.aa_sac_alpha_loss(
             logp.data_ptr(), _lib.ptr(weights), self._log_alpha_buf.data_ptr(),
             self._target_entropy, 1 if self._use_log_alpha_in_alpha_loss else 0,
@@ -545,13 +560,21 @@ class SacAgent(tf_agent.TFAgent):
             aloss = self._actor_phase(obs, wts, True, eps=eps.get("actor"))
             self._apply(self._actor_optimizer, self._actor_network.flat_params,
                         self._actor_network.flat_grads, [self._actor_network.body])
-            lloss = self._alpha_phase(obs, wts, True, eps=eps.get("alpha"))
-            self._apply(self._alpha_optimizer, self._log_alpha_buf, self._log_alpha_grad, None)
-            # total + storage of its own for the three terms: one launch
+            # total + storage of its own for the three terms
             packed = torch.empty((4,), dtype=torch.float32, device=dev)
-            _lib.check(_lib.load().aa_pack_sum3_f32(closs.data_ptr(), aloss.data_ptr(),
-                                                    lloss.data_ptr(), packed.data_ptr(),
-                                                    _lib.stream_ptr()), "aa_pack_sum3_f32")
+            from agents_amd import optimizers as _opt
+            if type(self._alpha_optimizer) in (_opt.Adam, _opt.AdamOptimizer) and \
+                    self._gradient_clipping is None and self.gradient_hook is None:
+                # alpha loss + its Adam step + the pack: one launch
+                self._alpha_phase(obs, wts, True, eps=eps.get("alpha"),
+                                  tail=(closs, aloss, packed))
+            else:
+                lloss = self._alpha_phase(obs, wts, True, eps=eps.get("alpha"))
+                self._apply(self._alpha_optimizer, self._log_alpha_buf, self._log_alpha_grad,
+                            None)
+                _lib.check(_lib.load().aa_pack_sum3_f32(closs.data_ptr(), aloss.data_ptr(),
+                                                        lloss.data_ptr(), packed.data_ptr(),
+                                                        _lib.stream_ptr()), "aa_pack_sum3_f32")
             info = tf_agent.LossInfo(packed[0], SacLossInfo(critic_loss=packed[1],
                                                             actor_loss=packed[2],
                                                             alpha_loss=packed[3]))

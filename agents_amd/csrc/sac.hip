@@ -226,6 +226,62 @@ aa_sac_alpha_loss_kernel(const float* __restrict__ logp, const float* __restrict
   }
 }
 
+// The tail of a SAC train step in ONE launch: alpha loss + gradient (as above), one Adam step on
+// log_alpha with that gradient (the arithmetic of aa_adam_kernel, optim.hip: t = steps + 1,
+// alpha_t = lr sqrt(1 - b2^t) / (1 - b1^t), m += (g - m)(1 - b1), v += (g g - v)(1 - b2),
+// p -= m alpha_t / (sqrt(v) + eps)) and the LossInfo pack of aa_pack_sum3_kernel -- three
+// single-workgroup launches of ~5 us each otherwise.
+__global__ void __launch_bounds__(256)
+aa_sac_alpha_step_kernel(const float* __restrict__ logp, const float* __restrict__ weights,
+                         float* __restrict__ log_alpha, float target_entropy, int use_log_alpha,
+                         float loss_weight, int64_t B, float global_batch,
+                         float* __restrict__ loss_out, float* __restrict__ grad_out,
+                         float* __restrict__ adam_m, float* __restrict__ adam_v,
+                         int64_t* __restrict__ adam_steps, float lr, float beta1, float beta2,
+                         float eps, const float* __restrict__ critic_loss,
+                         const float* __restrict__ actor_loss, float* __restrict__ packed4) {
+  __shared__ float red[16];
+  const float la = log_alpha[0];
+  const float coef = use_log_alpha ? la : expf(la);
+  float local = 0.f, gsum = 0.f;
+  for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+    const float diff = -logp[b] - target_entropy;
+    const float l = coef * diff;
+    float w = 1.f, wl = l, wd = diff;
+    if (weights != nullptr) {
+      w = weights[b];
+      wl = (w == 0.f) ? 0.f : l * w;
+      wd = (w == 0.f) ? 0.f : diff * w;
+    }
+    local += wl;
+    gsum += wd;
+  }
+  const float total = aa_block_sum(local, red);
+  __syncthreads();
+  const float gtot = aa_block_sum(gsum, red);
+  if (threadIdx.x == 0) {
+    const float loss = loss_weight * (total / global_batch);
+    const float grad = loss_weight * ((use_log_alpha ? 1.0f : expf(la)) * gtot / global_batch);
+    loss_out[0] = loss;
+    grad_out[0] = grad;
+    const float t = (float)(adam_steps[0] + 1);
+    const float b1p = powf(beta1, t), b2p = powf(beta2, t);
+    const float alpha_t = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    float m = adam_m[0], v = adam_v[0];
+    m = m + (grad - m) * (1.0f - beta1);
+    v = v + (grad * grad - v) * (1.0f - beta2);
+    log_alpha[0] = la - (m * alpha_t) / (sqrtf(v) + eps);
+    adam_m[0] = m;
+    adam_v[0] = v;
+    adam_steps[0] += 1;
+    const float x = critic_loss[0], y = actor_loss[0];
+    packed4[0] = (x + y) + loss;
+    packed4[1] = x;
+    packed4[2] = y;
+    packed4[3] = loss;
+  }
+}
+
 extern "C" {
 
 int aa_sac_sample(const float* z, int64_t B, int32_t A, const float* act_mean,
@@ -308,6 +364,22 @@ int aa_sac_alpha_loss(const float* logp, const float* weights, const float* log_
   hipLaunchKernelGGL(aa_sac_alpha_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logp,
                      weights, log_alpha_dev, target_entropy, use_log_alpha, loss_weight, B,
                      global_batch, loss_out, grad_out);
+  return aa_launch_status();
+}
+
+int aa_sac_alpha_step(const float* logp, const float* weights, float* log_alpha_dev,
+                      float target_entropy, int32_t use_log_alpha, float loss_weight, int64_t B,
+                      float global_batch, float* loss_out, float* grad_out, float* adam_m,
+                      float* adam_v, int64_t* adam_steps_dev, float lr, float beta1, float beta2,
+                      float eps, const float* critic_loss, const float* actor_loss,
+                      float* packed4, void* stream) {
+  if (!logp || !log_alpha_dev || !loss_out || !grad_out || !adam_m || !adam_v || !adam_steps_dev ||
+      !critic_loss || !actor_loss || !packed4 || B <= 0 || !(global_batch > 0.f))
+    return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_sac_alpha_step_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logp,
+                     weights, log_alpha_dev, target_entropy, use_log_alpha, loss_weight, B,
+                     global_batch, loss_out, grad_out, adam_m, adam_v, adam_steps_dev, lr, beta1,
+                     beta2, eps, critic_loss, actor_loss, packed4);
   return aa_launch_status();
 }
 

@@ -751,6 +751,17 @@ int aa_sac_actor_loss(const float* q1, const float* q2, const float* logp, const
 int aa_sac_alpha_loss(const float* logp, const float* weights, const float* log_alpha_dev,
                       float target_entropy, int32_t use_log_alpha, float loss_weight, int64_t B,
                       float global_batch, float* loss_out, float* grad_out, void* stream);
+/* The tail of SacAgent.train in one launch (sac_agent.py:296-330, 696-740): aa_sac_alpha_loss, one
+ * Adam step on log_alpha with its gradient (aa_adam_step_counted's arithmetic; *adam_steps_dev =
+ * steps taken so far, read and advanced here) and the LossInfo pack of aa_pack_sum3_f32:
+ * packed4 = [critic + actor + alpha loss, critic, actor, alpha].  Bit-identical to the three
+ * launches it replaces. */
+int aa_sac_alpha_step(const float* logp, const float* weights, float* log_alpha_dev,
+                      float target_entropy, int32_t use_log_alpha, float loss_weight, int64_t B,
+                      float global_batch, float* loss_out, float* grad_out, float* adam_m,
+                      float* adam_v, int64_t* adam_steps_dev, float lr, float beta1, float beta2,
+                      float eps, const float* critic_loss, const float* actor_loss,
+                      float* packed4, void* stream);
 
 /* LossInfo packing (one launch instead of clone + add + clone on the agents' train paths):
  * aa_pack_small_f32: out[0..n) = src[0..n), out[n] = addend ? *addend : 0, out[add_at] += out[n]

@@ -326,3 +326,23 @@ def test_sac_train_graph_matches_eager(dev):
     assert torch.equal(ag_e._log_alpha_buf, ag_g._log_alpha_buf)
     assert int(ag_e.train_step_counter.numpy()) == int(ag_g.train_step_counter.numpy()) == 30
     assert ag_e._actor_optimizer.iterations == ag_g._actor_optimizer.iterations == 30
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(initial_log_alpha=0.7, target_entropy=-1.0,
+                                              use_log_alpha_in_alpha_loss=False)])
+def test_fused_alpha_tail_is_bit_identical(dev, cfg):
+    """aa_sac_alpha_step (alpha loss + Adam step on log_alpha + LossInfo pack in one launch) against
+    the three launches it replaces (an identity gradient hook sends the agent down that path):
+    every parameter, optimizer slot, log_alpha and loss after five train steps, bit for bit."""
+    a_fused, _ = make_pair(dev, **cfg)
+    a_three, _ = make_pair(dev, **cfg)
+    a_three.gradient_hook = lambda g: g
+    for step in range(5):
+        exp_d, _, eps_d, _ = batch(dev, 64, 300 + step)
+        li_f = a_fused.train(exp_d, eps=eps_d)
+        li_t = a_three.train(exp_d, eps=eps_d)
+        for x, y in zip([li_f.loss] + list(li_f.extra), [li_t.loss] + list(li_t.extra)):
+            assert torch.equal(x, y)
+    for x, y in zip(a_fused.replicated_state(), a_three.replicated_state()):
+        assert torch.equal(x, y)
+    assert a_fused._alpha_optimizer.iterations == a_three._alpha_optimizer.iterations == 5
