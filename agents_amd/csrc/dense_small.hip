@@ -84,32 +84,38 @@ aa_dense_small_fwd_slabs_kernel(const float* __restrict__ slab, int splits, int6
   for (int n = 0; n < N; ++n) acc[n] = 0.f;
   for (int k = 4 * lane; k < K; k += 256) {
     const float* src = slab + (size_t)m * K + k;
+    // Everything this pass needs is requested before anything is used -- up to eight slabs, the
+    // hidden layer's bias, the four rows of the head's kernel: ONE round trip per pass.  (Slabs
+    // four at a time, then the bias, then the head's rows was four dependent round trips per
+    // pass, ~1 us each in a launch whose arithmetic is nothing.)  Unconditional loads from clamped
+    // addresses; the adds below keep the z order of aa_splitk_reduce_kernel<*,1>.
+    float4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      t[u] = *reinterpret_cast<const float4*>(src + (size_t)(u < splits ? u : splits - 1) * MK);
+    const float4 b1 = *reinterpret_cast<const float4*>(bias1 != nullptr ? bias1 + k : src);
+    const float* wk = w + (size_t)k * N;
+    float wr[4 * N];
+#pragma unroll
+    for (int j = 0; j < 4 * N; ++j) wr[j] = wk[j];
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    int z = 0;
-    for (; z + 3 < splits; z += 4) {   // four slab loads in flight, added in z order
-      float4 t[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const float4*>(src + (size_t)(z + u) * MK);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
+    for (int u = 0; u < 8; ++u)
+      if (u < splits) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
+    for (int z = 8; z < splits; ++z) {
+      const float4 tz = *reinterpret_cast<const float4*>(src + (size_t)z * MK);
+      v.x += tz.x; v.y += tz.y; v.z += tz.z; v.w += tz.w;
     }
-    for (; z < splits; ++z) {
-      const float4 t = *reinterpret_cast<const float4*>(src + (size_t)z * MK);
-      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-    }
-    if (bias1 != nullptr) {
-      v.x += bias1[k]; v.y += bias1[k + 1]; v.z += bias1[k + 2]; v.w += bias1[k + 3];
-    }
+    if (bias1 != nullptr) { v.x += b1.x; v.y += b1.y; v.z += b1.z; v.w += b1.w; }
     v.x = aa_sm_act(v.x, act1); v.y = aa_sm_act(v.y, act1);
     v.z = aa_sm_act(v.z, act1); v.w = aa_sm_act(v.w, act1);
     *reinterpret_cast<float4*>(h + m * ldh + k) = v;
-    const float* wk = w + (size_t)k * N;
 #pragma unroll
     for (int n = 0; n < N; ++n) {
-      acc[n] = fmaf(v.x, wk[n], acc[n]);
-      acc[n] = fmaf(v.y, wk[N + n], acc[n]);
-      acc[n] = fmaf(v.z, wk[2 * N + n], acc[n]);
-      acc[n] = fmaf(v.w, wk[3 * N + n], acc[n]);
+      acc[n] = fmaf(v.x, wr[n], acc[n]);
+      acc[n] = fmaf(v.y, wr[N + n], acc[n]);
+      acc[n] = fmaf(v.z, wr[2 * N + n], acc[n]);
+      acc[n] = fmaf(v.w, wr[3 * N + n], acc[n]);
     }
   }
 #pragma unroll
