@@ -247,6 +247,10 @@ __device__ static inline void aa_arrivals_finish(int64_t* counter, int64_t* arri
   unsigned long long* a = reinterpret_cast<unsigned long long*>(arrival);
   const unsigned lane = threadIdx.x;
   unsigned long long total;
+  // (bounded: arrival words that were not zero at launch -- two launches sharing them on
+  // different streams -- must not hang the device; ~4 M polls is seconds, a healthy launch needs
+  // one or two)
+  int polls = 0;
   do {
     unsigned long long mine = 0;
     if (lane < 8)
@@ -255,7 +259,7 @@ __device__ static inline void aa_arrivals_finish(int64_t* counter, int64_t* arri
     total = mine;
     for (int o = 4; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
     total = __shfl(total, 0, 64);
-  } while (total != (unsigned long long)n_groups);
+  } while (total != (unsigned long long)n_groups && ++polls < (1 << 22));
   if (lane < 8)
     __hip_atomic_store(a + lane * AA_RB_ARRIVAL_STRIDE, 0ull, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
