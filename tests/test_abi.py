@@ -97,6 +97,50 @@ def test_argument_validation_without_gpu(lib):
     assert lib.aa_colsum_workspace_bytes(1000, 32) > 0
 
 
+def test_round3_entries_validate_on_the_host(lib):
+    """The entry points added in round 3 reject what they cannot run before any launch: the
+    wide-MLP limits (widths <= 256 behind a <= 1,024-wide input, <= 4 layers, batch <= 1,024),
+    stamped replay draws, the fused SAC tail."""
+    def layout(dims, acts=None):
+        lay = _lib.MlpLayout()
+        lay.n_layers = len(dims) - 1
+        for i, d in enumerate(dims):
+            lay.dims[i] = d
+        for i in range(len(dims) - 1):
+            lay.acts[i] = (acts or [1] * (len(dims) - 1))[i]
+            lay.k_off[i] = 0
+            lay.b_off[i] = 0
+        return lay
+    ok = layout([393, 256, 256, 1], [1, 1, 0])
+    assert lib.aa_mlp_wide_supported(ctypes.byref(ok), 256) == 1
+    assert lib.aa_mlp_wide_supported(ctypes.byref(ok), 1024) == 1
+    assert lib.aa_mlp_wide_supported(ctypes.byref(ok), 1025) == 0          # GEMM path beyond that
+    assert lib.aa_mlp_wide_supported(ctypes.byref(layout([1025, 64, 1])), 8) == 0
+    assert lib.aa_mlp_wide_supported(ctypes.byref(layout([64, 257, 1])), 8) == 0
+    assert lib.aa_mlp_wide_supported(ctypes.byref(layout([64, 64, 1], [1, 7])), 8) == 0
+    assert lib.aa_mlp_wide_supported(None, 8) == 0
+    f = _lib.MlpWideFwd()
+    f.layout = ok
+    f.n_nets, f.x_split, f.B = 1, 393, 256
+    assert lib.aa_mlp_wide_forward(ctypes.byref(f), None) == -22            # no parameter pointer
+    f.n_nets = 5
+    assert lib.aa_mlp_wide_forward(ctypes.byref(f), None) == -22
+    b = _lib.MlpWideBwd()
+    b.layout = ok
+    b.n_nets, b.x_split, b.B = 1, 376, 256
+    assert lib.aa_mlp_wide_backward(ctypes.byref(b), None) == -22
+    assert lib.aa_mlp_wide_backward(None, None) == -22
+    # stamped draws: S, T, batch, max_len must be positive; ids need an id table
+    assert lib.aa_rb_sample_gather_stamped(None, None, None, 0, None, None, None, 5, 4, 8, 0, 2, 0,
+                                           0, None, None, None) == -22
+    assert lib.aa_rb_sample_gather_stamped(None, None, None, 0, None, 1 << 20, None, 5, 4, 8, 2, 2,
+                                           0, 0, None, None, None) == -22
+    assert lib.aa_sac_alpha_step(None, None, None, 0.0, 1, 1.0, 8, 8.0, None, None, None, None,
+                                 None, 1e-3, 0.9, 0.999, 1e-7, None, None, None, None) == -22
+    assert lib.aa_sac_head_backward(1 << 20, 4, 2, 1 << 20, 0, 1 << 20, 1 << 20, 1 << 20, 1 << 20, 1,
+                                    None, 0, 1 << 20, 1 << 20, None) == -22   # row stride < A
+
+
 def test_shape_qualification_is_host_side(lib):
     """The per-frame conv kernels decide on the host which shapes they take (no device access):
     the Atari conv2 -> conv3 pair and both input gradients qualify, the 84x84 first layer does not;
