@@ -89,10 +89,11 @@ def main():
         rel = (t - t[:, :1]) * 0.01           # us since the workgroup's first stamp
         span = (t[:, :11].max() - t[:, 0].min()) * 0.01
         print(f"{name}: stamps (us, median over workgroups) "
-              + " ".join(f"{v:5.1f}" for v in __import__("numpy").median(rel[:, :11], axis=0))
+              + " ".join(f"{v:5.1f}" for v in __import__("numpy").median(rel[:, :11], axis=0)
+                         if v >= 0)
               + f" | first start -> last end {span:5.1f} us | second layer from the top: rows "
               f"requested {__import__('numpy').median(rel[:, 10]):5.1f}, dz computed "
-              f"{__import__('numpy').median(rel[:, 11]):5.1f}")
+              f"{__import__('numpy').median(rel[:, 11]):5.1f} (negative: not stamped by this kernel)")
 
 
 if __name__ == "__main__":
