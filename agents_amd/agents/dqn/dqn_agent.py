@@ -331,8 +331,10 @@ class DqnAgent(tf_agent.TFAgent):
         net = self._q_network
         w = self._forward_and_loss(experience, self._td_errors_loss_fn, self._gamma,
                                    self._reward_scale_factor, weights, need_grad=True)
-        net.backward(w.dq, slot="train", side_stream=self._side_stream(w.dq.device),
-                     head_done=w.head_done)
+        # head_done only exists in networks that exposed `fusable_head` (Sequential): a q_network
+        # with the plain backward(dout, slot, side_stream, stop_layer) contract never sees it
+        extra = {"head_done": True} if w.head_done else {}
+        net.backward(w.dq, slot="train", side_stream=self._side_stream(w.dq.device), **extra)
         total = w.loss
         if net.has_regularization:
             net.add_regularization_grads(1.0 / self.num_replicas)
@@ -359,8 +361,9 @@ class DqnAgent(tf_agent.TFAgent):
         w = self._forward_and_loss(experience, self._td_errors_loss_fn, self._gamma,
                                    self._reward_scale_factor, weights, need_grad=True)
         self._bucket_B = w.dq.shape[0]
+        extra = {"head_done": True} if w.head_done else {}
         net.backward(w.dq, slot="train", side_stream=self._side_stream(w.dq.device),
-                     stop_layer=self._bucket_split(), head_done=w.head_done)
+                     stop_layer=self._bucket_split(), **extra)
         return tf_agent.LossInfo(w.loss.reshape(()),
                                  DqnLossInfo(td_loss=w.td_loss, td_error=w.td_error))
 

@@ -643,7 +643,20 @@ class PPOAgent(tf_agent.TFAgent):
                 not self._compute_value_and_advantage_in_train and
                 not self.update_normalizers_in_train and self._initialized and
                 frames.observation.dtype == torch.float32 and frames.observation.dim() == 2 and
-                frames.step_type.dtype == torch.int32)
+                frames.step_type.dtype == torch.int32 and self._fused_leaves_are_f32(frames))
+
+    @staticmethod
+    def _fused_leaves_are_f32(frames):
+        """aa_ppo_fused_epoch reads these leaves as raw float32 pointers (no cast on the way, unlike
+        `_train` / `_train_fused`): anything else -- a float64 action spec, a float64 policy_info
+        leaf -- must take the per-minibatch path, which casts."""
+        info = frames.policy_info
+        try:
+            leaves = (frames.action, info["dist_params"]["loc"], info["dist_params"]["scale"],
+                      info["return"], info["advantage"], info["value_prediction"])
+        except (KeyError, TypeError, IndexError):
+            return False
+        return all(torch.is_tensor(t) and t.dtype == torch.float32 for t in leaves)
 
     def train_minibatches(self, frames, perm, minibatch_size, n_steps):
         """`n_steps` train steps, step s on rows perm[s * mb : (s + 1) * mb] of the flattened

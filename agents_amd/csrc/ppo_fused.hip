@@ -782,13 +782,17 @@ int aa_ppo_fused_epoch(const aa_ppo_fused_desc* dsc, const int64_t* rows_dev, in
   if (workspace_bytes < aa_ppo_fused_workspace_bytes(d.N, d.total)) return AA_ERR_RANGE;
   const int64_t n_wg = (d.N + PF_TS - 1) / PF_TS;
   if (n_wg > 0x7fffffffLL) return AA_ERR_RANGE;
-  static bool lds_granted = false;       // 89 KB of dynamic LDS: granted once per process
-  if (!lds_granted) {
+  // 89 KB of dynamic LDS: the attribute belongs to the CURRENT device's function object, so it
+  // is granted once per device ordinal (a process that steps agents on two GPUs needs it on both)
+  static bool lds_granted[64] = {};
+  int dev_ord = 0;
+  if (hipGetDevice(&dev_ord) != hipSuccess) return AA_ERR_LAUNCH;
+  if (dev_ord < 0 || dev_ord >= 64 || !lds_granted[dev_ord]) {
     if (hipFuncSetAttribute((const void*)aa_ppo_fused_step_kernel,
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sizeof(PfLds)) != hipSuccess)
       return AA_ERR_LAUNCH;
-    lds_granted = true;
+    if (dev_ord >= 0 && dev_ord < 64) lds_granted[dev_ord] = true;
   }
   PfArgs P;
   P.d = d;

@@ -238,18 +238,26 @@ __device__ static inline void aa_counter_finish(int64_t* counter, int64_t* arriv
 // the counter and never looks at the result (a returning atomic in wave 0 sits in front of the
 // draw; nothing waits for this one).  The LAST workgroup of the grid -- dispatched last, and done
 // with its copy microseconds after every other workgroup has started -- sums the eight shards
-// when it is finished; once they add up to the grid every workgroup has read the counter, and it
-// zeroes the shards and advances the counter.  If some workgroup has not arrived yet it polls:
-// that workgroup needs nothing from this one and has been dispatched, or will be as slots free up.
+// when it is finished.  The shards are MONOTONIC (never zeroed); word 8 holds the arrivals already
+// accounted for by earlier launches, so "every workgroup of THIS launch has read the counter" is
+// sum(shards) - consumed == n_groups; then consumed moves up and the counter advances.  If some
+// workgroup has not arrived yet the last one polls: that workgroup needs nothing from this one and
+// has been dispatched, or will be as slots free up.
+// The poll is bounded (two launches sharing the words on different streams must not hang the
+// device; ~4 M polls is seconds, a healthy launch needs one or two).  On a timeout the launch is
+// reported through *err and the counter is NOT advanced; `consumed` still moves by n_groups, so
+// arrivals that trickle in late are absorbed and the following launches see a consistent count
+// again (zeroing the shards, as the first version did, left a residue that made every later
+// launch time out as well).
 __device__ static inline void aa_arrivals_finish(int64_t* counter, int64_t* arrival, int64_t inc,
-                                                 unsigned n_groups) {
+                                                 unsigned n_groups, int* err) {
   if (blockIdx.x != n_groups - 1u || threadIdx.x >= 64) return;
   unsigned long long* a = reinterpret_cast<unsigned long long*>(arrival);
   const unsigned lane = threadIdx.x;
+  unsigned long long consumed = 0;
+  if (lane == 0) consumed = a[8 * AA_RB_ARRIVAL_STRIDE];
+  consumed = __shfl(consumed, 0, 64);
   unsigned long long total;
-  // (bounded: arrival words that were not zero at launch -- two launches sharing them on
-  // different streams -- must not hang the device; ~4 M polls is seconds, a healthy launch needs
-  // one or two)
   int polls = 0;
   do {
     unsigned long long mine = 0;
@@ -259,11 +267,14 @@ __device__ static inline void aa_arrivals_finish(int64_t* counter, int64_t* arri
     total = mine;
     for (int o = 4; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
     total = __shfl(total, 0, 64);
-  } while (total != (unsigned long long)n_groups && ++polls < (1 << 22));
-  if (lane < 8)
-    __hip_atomic_store(a + lane * AA_RB_ARRIVAL_STRIDE, 0ull, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  if (lane == 0) *counter += inc;
+  } while (total - consumed != (unsigned long long)n_groups && ++polls < (1 << 22));
+  if (lane == 0) {
+    a[8 * AA_RB_ARRIVAL_STRIDE] = consumed + (unsigned long long)n_groups;
+    if (total - consumed == (unsigned long long)n_groups)
+      *counter += inc;
+    else if (err != nullptr)
+      *err = 2;   // arrival timeout: the draw of this call is not trustworthy, counter untouched
+  }
 }
 
 // ---- add_batch: rows[b] = b*L + (last_id+1) mod L ------------------------------------------
@@ -715,7 +726,7 @@ aa_rb_sample_gather_kernel(AaLeafSet leaves, AaRowGrid g, const int64_t* __restr
         counter_out != nullptr)
       *counter_out = (int64_t)(call + 1);
   }
-  if (call_dev != nullptr) aa_arrivals_finish(call_dev, arrival, 1, gridDim.x);
+  if (call_dev != nullptr) aa_arrivals_finish(call_dev, arrival, 1, gridDim.x, err);
 }
 
 // ---- pseudo-random permutation of [0, n) without a sort -------------------------------------------

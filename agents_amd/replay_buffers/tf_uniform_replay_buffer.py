@@ -97,6 +97,20 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
         # the counter the kernels read: device resident so that captured graphs advance it
         self._sample_calls_dev = torch.zeros((1,), dtype=torch.int64, device=self._device)
 
+    def device_error(self):
+        """The kernels' error word (synchronises): 0 = fine, 1 = a draw found no valid range (the
+        buffer was emptier than the host mirror believed), 2 = the arrival protocol of a
+        sample-and-gather launch timed out (two launches shared the arrival words concurrently);
+        the call counter was not advanced for that launch and its rows must not be trusted."""
+        return int(self._err_flag.item())
+
+    def check_device_error(self):
+        code = self.device_error()
+        if code:
+            self._err_flag.zero_()
+            raise RuntimeError(f"TFUniformReplayBuffer: device-side error {code} in a sample / "
+                               "gather launch (see device_error())")
+
     # ---- properties ------------------------------------------------------------------------
     @property
     def device(self):

@@ -10,6 +10,7 @@
 import functools
 import os
 import pickle
+import zipfile
 
 import torch
 
@@ -183,7 +184,8 @@ class Checkpointer:
         for fname in reversed(files):
             try:
                 blob = torch.load(os.path.join(self._dir, fname), weights_only=True)
-            except (OSError, EOFError, RuntimeError, ValueError, pickle.UnpicklingError) as e:
+            except (OSError, EOFError, RuntimeError, ValueError, KeyError, zipfile.BadZipFile,
+                    pickle.UnpicklingError) as e:
                 # the FILE is bad (truncated / foreign): the previous one may still be whole
                 import warnings
                 warnings.warn(f"Checkpointer: could not read {fname} ({type(e).__name__}: {e}); "

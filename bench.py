@@ -59,6 +59,116 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+LINE_LIMIT = 4096   # the driver keeps a 10 KB tail of stdout: the JSON line must fit with room
+
+
+def _r(x, nd=4):
+    """Round floats for the compact line (6 significant digits for large values)."""
+    if isinstance(x, float):
+        return float(f"{x:.6g}")
+    return x
+
+
+def _compact_roofline(r):
+    """ONE roofline entry for the final line: the contract's keys + the in-loop duration and the
+    few qualifiers a reader needs; the long notes stay in the detail file."""
+    if not r:
+        return None
+    keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms",
+            "isolated_ms", "launches_per_step", "frac_isolated", "pipe_frac", "frac_ceiling",
+            "mfma_busy", "algorithmic_flop_per_launch", "algorithmic_bytes_per_launch")
+    o = {k: _r(r[k]) for k in keep if k in r and r[k] is not None or k == "traffic"}
+    o["kernel"] = str(r.get("kernel", ""))[:120]
+    src = r.get("duration_source", "")
+    o["duration_source"] = "in-loop rocprofv3" if src.startswith("in-loop") else (
+        "isolated HIP events" if src else "wall clock")
+    if r.get("traffic") is not None:
+        o["traffic_source"] = "committed --pmc pass (" + str(r.get("traffic_source", "")
+                                                              ).split(" ")[0] + ")"
+    return o
+
+
+def _compact_other(o):
+    if not o or "error" in o:
+        return {"error": str((o or {}).get("error", "missing"))[:160]}
+    c = {"value": _r(o.get("value")), "unit": o.get("unit"), "ms_per_step": _r(o.get("ms_per_step")),
+         "steps": o.get("steps")}
+    for k in ("train_minibatch_steps_per_sec", "collect_env_steps_per_sec", "env_steps_per_sec"):
+        if k in o:
+            c[k] = _r(o[k])
+    rf = o.get("roofline") or {}
+    c["roofline"] = {k: _r(rf.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac",
+                                                "traffic", "avg_launch_ms")}
+    cb = o.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {k: _r(cb.get(k)) for k in ("value", "unit", "cores", "kind")}
+    return c
+
+
+def compact_line(out):
+    """The ONE stdout line the driver parses: contract keys, one roofline entry (dominant kernel by
+    time per step) plus the two replay kernels in brief, cpu_baseline, compact other_configs.
+    Everything else (`roofline_all`, `inloop`, notes) goes to --detail-out and stderr.  Guaranteed
+    shorter than LINE_LIMIT bytes: optional blocks are dropped, least important first."""
+    line = {k: _r(out[k]) for k in (
+        "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+        "scaling", "vs_baseline", "dtype", "data") if k in out}
+    cfg = dict(out.get("config", {}))
+    cfg["workload"] = str(cfg.get("workload", ""))[:300]
+    line["config"] = cfg
+    for k in ("learner_steps_per_sec", "env_steps_per_sec", "host_enqueue_ms_per_step",
+              "prime_steps", "captures_in_timed_region", "final_loss", "step_algorithmic_gflop",
+              "step_mfma_frac", "kernel_time_sum_ms", "steady_ms_per_step", "steady_steps",
+              "rccl_ranks"):
+        if k in out:
+            line[k] = _r(out[k])
+    if "roofline" in out:
+        line["roofline"] = _compact_roofline(out["roofline"])
+    for k in ("roofline_replay_gather", "roofline_replay_add"):
+        if k in out:
+            r = out[k]
+            line[k] = {kk: _r(r.get(kk)) for kk in ("achieved", "unit", "frac", "frac_isolated",
+                                                    "avg_launch_ms", "isolated_ms", "traffic")}
+    il = out.get("inloop")
+    if il and "error" not in il:
+        line["inloop"] = {k: _r(il[k]) for k in ("steps", "ms_per_step_under_profiler",
+                                                  "kernel_time_sum_us_per_step",
+                                                  "launches_per_step", "gpu_wall_us_per_step")
+                          if k in il}
+    if "cpu_baseline" in out:
+        cb = dict(out["cpu_baseline"])
+        cb["sample"] = str(cb.get("sample", ""))[:240]
+        line["cpu_baseline"] = {k: _r(v) for k, v in cb.items()}
+    if "other_configs" in out:
+        line["other_configs"] = {k: _compact_other(v) for k, v in out["other_configs"].items()}
+    if "detail" in out:
+        line["detail"] = out["detail"]
+    s = json.dumps(line, separators=(",", ":"))
+    for drop in ("inloop", "roofline_replay_add", "roofline_replay_gather", "other_configs",
+                 "detail"):
+        if len(s) < LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        s = json.dumps(line, separators=(",", ":"))
+    assert len(s) < LINE_LIMIT, len(s)
+    return s
+
+
+def emit(out, detail_path):
+    """Full record -> detail file (+ stderr pointer); compact line -> stdout (the LAST line)."""
+    if detail_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
+            with open(detail_path, "w") as fh:
+                json.dump(out, fh, indent=1)
+            out = dict(out, detail=os.path.relpath(os.path.abspath(detail_path), ROOT)
+                       if os.path.abspath(detail_path).startswith(ROOT) else detail_path)
+            log(f"[bench] full record (roofline_all, inloop kernel table, notes): {detail_path}")
+        except OSError as e:
+            log(f"[bench] could not write {detail_path}: {e}")
+    print(compact_line(out), flush=True)
+
+
 def atari_layers(L, num_actions):
     vs = lambda: L.VarianceScaling(2.0)
     return [L.Rescale(255.0), L.Conv2D(32, (8, 8), 4, "relu", kernel_initializer=vs()),
@@ -519,13 +629,12 @@ def main_other_config(args):
                             "unit": "TFLOP/s", "frac": flop / mb_ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
                             "traffic": None, "algorithmic_flop_per_launch": flop,
                             "avg_launch_ms": mb_ms,
-                            "note": "a 64-wide MLP on 4,096 frames is 0.27 GFLOP per step; the "
-                                    "fused step runs fp32 FMAs on the VALU out of LDS (no MFMA "
-                                    "tile fits 17-wide inputs and 6-/1-wide heads), so frac "
-                                    "against the fp32 MFMA peak is what the shape allows, not a "
-                                    "kernel-quality figure: the step's ~42 us are K1 ~35 us "
-                                    "(forward ~7, loss 2, backward ~9, staging / barriers the "
-                                    "rest), K2 + K3 ~7 us"}}
+                            "note": "a 64-wide MLP on 4,096 frames is 0.27 GFLOP per step; K1 "
+                                    "runs every layer padded to 64x64 on v_mfma_f32_16x16x4_f32 "
+                                    "out of LDS (17-wide inputs and 6-/1-wide heads multiply "
+                                    "zeros), so frac counts algorithmic flop only; the step is "
+                                    "bound by staging, barriers and launch latency, not the "
+                                    "matrix pipe (in-kernel timeline: DESIGN.md)"}}
         if not args.no_cpu_baseline:
             th, ncpu, cands = _best_threads(lambda n, t: bench_ppo.cpu_baseline(4096, n, t))
             sps = bench_ppo.cpu_baseline(4096, 200, th)
@@ -610,6 +719,12 @@ def main():
                     help="write the in-loop per-kernel table (CSV) here")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short --config ppo / --config sac runs appended to the line")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="full record (roofline_all, in-loop kernel table, notes); the stdout "
+                         "line is the compact one (< 4 KB)")
+    ap.add_argument("--steady-steps", type=int, default=300,
+                    help="when --steps < 200, time this many further steps after the timed "
+                         "region and report them as steady_ms_per_step (0 = off)")
     args = ap.parse_args()
     args.steps_given = any(a == "--steps" or a.startswith("--steps=") for a in sys.argv[1:])
     if args.config != "dqn":
@@ -621,9 +736,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under
+        # torch.distributed.run on this node (rendezvous on 127.0.0.1), same arguments
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log(f"[bench] --gpus {args.gpus} without WORLD_SIZE: re-launching under "
+            f"torch.distributed.run ({args.gpus} ranks, 127.0.0.1:{port})")
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with that many ranks "
-                         f"(WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     # AA_BENCH_BACKEND=gloo AA_BENCH_SHARE_GPU=1: development aid -- runs the N-rank control flow
     # (hooks, buckets, barriers, rank-0 breakdown) with every rank on GPU 0 when only one GPU exists
@@ -724,6 +854,18 @@ def main():
     dt = time.perf_counter() - t0
     mark("loop.end")
     captures_in_timed_region = graph.capture_count() - captures_before
+    # `--steps 20` times ~8 ms of wall clock: a second, longer region of the same loop right after
+    # it says whether the short one was representative (reported beside it, never instead of it)
+    steady = None
+    if (not TRACE_CHILD and args.steady_steps > 0 and args.steps < 200
+            and not args.host_profile):
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(args.steady_steps):
+            step()
+        graph.join_lanes(dev)
+        sync_all()
+        steady = (time.perf_counter() - t1) / args.steady_steps * 1e3
     if TRACE_CHILD:
         # child of inloop_profile(): the isolated cases once more, bracketed by markers, so that
         # the parent learns which device kernels each case launches; then one JSON line
@@ -821,7 +963,7 @@ def main():
         "learner_steps_per_sec": steps_per_sec,
         "env_steps_per_sec": steps_per_sec * args.envs * world,
         "replay_rows_gathered_per_sec": steps_per_sec * S * 2 * world,
-        "final_loss": loss_val,
+        "final_loss": loss_val, "rccl_ranks": world,
         "config": {"workload": "configs[1]: DQN Atari Pong-shaped (84x84x4 uint8 stack), replay "
                                f"{args.envs}x{args.max_length} rows/GPU, batch={S}, num_steps=2, "
                                "Mnih-15 Q-net, Huber, centred RMSProp, 1 collect step (256 envs) "
@@ -830,6 +972,14 @@ def main():
                    "replay_rows_per_gpu": args.envs * args.max_length,
                    "parallelism": f"dp{world}" if world > 1 else "single"},
     }
+    if steady is not None:
+        if world > 1:
+            import torch.distributed as dist
+            tm = torch.tensor([steady], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            steady = float(tm.item())
+        out["steady_ms_per_step"] = steady
+        out["steady_steps"] = args.steady_steps
     if rank == 0:
         flops_step = train_flops_per_sample() * S + 2.0 * sum(fwd_macs_per_sample()) * args.envs
         out["step_algorithmic_gflop"] = flops_step / 1e9
@@ -963,7 +1113,7 @@ def main():
                           f"batch 256) of the numpy/torch-CPU oracle on {threads} of {ncpu} host "
                           f"threads (fastest of {cands}), {spstep:.3f} s/iteration, replay ring "
                           "shortened to 8 frames/env"}
-        print(json.dumps(out), flush=True)
+        emit(out, args.detail_out)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -13,6 +13,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a HIP device (run with -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The canary (tests/test_gpu_00_canary.py) runs before every other test, whatever the file
+    order: with `-x` a box that cannot do a torch H2D copy then fails there, not in a parity test."""
+    first = [it for it in items if "test_gpu_00_canary" in it.nodeid]
+    if first:
+        rest = [it for it in items if "test_gpu_00_canary" not in it.nodeid]
+        items[:] = first + rest
+
+
 @pytest.fixture(scope="session")
 def lib():
     """The built C-ABI library (built in-tree if missing; hipcc cross-compiles without a GPU)."""
