@@ -259,6 +259,8 @@ _SIGNATURES = {
     "aa_normal_log_prob": (c_int, [c_void_p] * 3 + [c_int64, c_int32, c_void_p, c_void_p]),
     "aa_normal_sample": (c_int, [c_void_p, c_void_p, c_int64, c_uint64, c_void_p, c_void_p,
                                  c_void_p]),
+    "aa_uniform_sample": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_uint64, c_void_p,
+                                  c_void_p, c_void_p]),
     "aa_ppo_discounts": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int64, c_void_p,
                                  c_void_p]),
     "aa_ppo_trajectory_mask": (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p]),
@@ -311,7 +313,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 10:
+    if lib.aa_abi_version() != 11:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -426,6 +426,24 @@ aa_normal_sample_kernel(const float* __restrict__ loc, const float* __restrict__
   }
 }
 
+// RandomTFPolicy on a bounded continuous spec: out[i, d] = lo[d] + (hi[d] - lo[d]) * u, u in [0, 1)
+// from Philox(counter = (element index, call counter), key = seed), word 0.
+__global__ void __launch_bounds__(256)
+aa_uniform_sample_kernel(const float* __restrict__ lo, const float* __restrict__ hi, int64_t N,
+                         int D, uint32_t seed_lo, uint32_t seed_hi,
+                         const int64_t* __restrict__ call_counter, float* __restrict__ out) {
+  const uint64_t call = (uint64_t)call_counter[0];
+  const int64_t total = N * D, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int d = (int)(i % D);
+    const Philox4 r = philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)call,
+                                    (uint32_t)(call >> 32), seed_lo, seed_hi);
+    const float l = lo[d], h = hi[d];
+    float v = l + (h - l) * aa_u01(r.x);
+    out[i] = v < h ? v : l;       // rounding must not reach the open end of [lo, hi)
+  }
+}
+
 // discounts for the return / GAE scans: discount * gamma * (next_step_type != LAST)
 // (ppo_agent.py:630-676, utils/common.py:883-895), over the first T of T+1 columns.
 __global__ void __launch_bounds__(256)
@@ -657,6 +675,15 @@ int aa_normal_sample(const float* loc, const float* scale, int64_t n, uint64_t s
   if (!loc || !scale || !out || !call_counter_dev || n <= 0) return AA_ERR_INVALID;
   hipLaunchKernelGGL(aa_normal_sample_kernel, dim3(aa_ew_blocks(n)), dim3(256), 0,
                      (hipStream_t)stream, loc, scale, n, (uint32_t)(seed & 0xffffffffu),
+                     (uint32_t)(seed >> 32), call_counter_dev, out);
+  return aa_launch_status();
+}
+
+int aa_uniform_sample(const float* lo, const float* hi, int64_t N, int32_t D, uint64_t seed,
+                      const int64_t* call_counter_dev, float* out, void* stream) {
+  if (!lo || !hi || !out || !call_counter_dev || N <= 0 || D <= 0) return AA_ERR_INVALID;
+  hipLaunchKernelGGL(aa_uniform_sample_kernel, dim3(aa_ew_blocks(N * D)), dim3(256), 0,
+                     (hipStream_t)stream, lo, hi, N, (int)D, (uint32_t)(seed & 0xffffffffu),
                      (uint32_t)(seed >> 32), call_counter_dev, out);
   return aa_launch_status();
 }

@@ -1,0 +1,60 @@
+"""GreedyPolicy (tf_agents/policies/greedy_policy.py:48-130): wraps a policy and takes the mode of
+its action distribution.
+
+  discrete Q policies      -> argmax (q_policy.GreedyPolicy)
+  SAC's tanh-Normal actor  -> the squashed mean: the sampling kernel run with eps = 0
+                              (mean + magnitude * tanh(loc)), what `SquashToSpecNormal.mode()` returns
+  PPO's Normal actor       -> loc (PPOPolicy(greedy=True))
+"""
+import torch
+
+from agents_amd.policies import q_policy, tf_policy
+from agents_amd.trajectories import policy_step
+from agents_amd.utils import graph
+
+
+class _GreedySacPolicy(tf_policy.TFPolicy):
+    def __init__(self, policy, name=None):
+        super().__init__(policy.time_step_spec, policy.action_spec, name=name or "GreedyPolicy")
+        self._wrapped_policy = policy
+        self._zeros = {}
+
+    @property
+    def wrapped_policy(self):
+        return self._wrapped_policy
+
+    def _variables(self):
+        return self._wrapped_policy.variables()
+
+    def _action(self, time_step, policy_state, seed):
+        p = self._wrapped_policy
+        obs = time_step.observation
+        batched = time_step.step_type.dim() > 0
+        if not batched:
+            obs = obs.unsqueeze(0)
+        graph.join_lanes(obs.device)
+        B = obs.shape[0]
+        eps = self._zeros.get(B)
+        if eps is None:
+            eps = self._zeros[B] = torch.zeros((B, p._A), dtype=torch.float32, device=obs.device)
+        with torch.cuda.device(obs.device):
+            action, _, _ = p.sample(obs, slot="greedy", eps=eps)
+            action = action.reshape((B,) + tuple(p._spec.shape)).clone()
+        if not batched:
+            action = action.squeeze(0)
+        return policy_step.PolicyStep(action, policy_state, ())
+
+
+def GreedyPolicy(policy, name=None):      # noqa: N802
+    from agents_amd.agents.ppo import ppo_policy
+    from agents_amd.agents.sac import sac_agent
+    if isinstance(policy, q_policy._DiscretePolicy):
+        return q_policy.GreedyPolicy(policy, name=name)
+    if isinstance(policy, sac_agent.SacPolicy):
+        return _GreedySacPolicy(policy, name=name)
+    if isinstance(policy, ppo_policy.PPOPolicy):
+        return ppo_policy.PPOPolicy(policy.time_step_spec, policy.action_spec,
+                                    policy._actor_network, policy._value_network,
+                                    observation_normalizer=policy._observation_normalizer,
+                                    clip=policy._clip, collect=False, greedy=True, name=name)
+    raise NotImplementedError(f"GreedyPolicy over {type(policy).__name__}")

@@ -34,7 +34,9 @@ def function(*args, **kwargs):
             return graph.graphed_driver_run(owner)
         return fn
 
-    if len(args) == 1 and callable(args[0]) and not kwargs:
+    # `common.function(fn)` and `common.function(fn, autograph=False)` (the PPO script) wrap fn;
+    # `@common.function(autograph=False)` returns the decorator
+    if len(args) >= 1 and callable(args[0]):
         return wrap(args[0])
     return wrap
 

@@ -110,13 +110,16 @@ def compact_line(out):
     time per step) plus the two replay kernels in brief, cpu_baseline, compact other_configs.
     Everything else (`roofline_all`, `inloop`, notes) goes to --detail-out and stderr.  Guaranteed
     shorter than LINE_LIMIT bytes: optional blocks are dropped, least important first."""
-    line = {k: _r(out[k]) for k in (
+    # (the contract's numbers keep full precision; derived figures are rounded to 6 digits)
+    line = {k: out[k] for k in (
         "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
         "scaling", "vs_baseline", "dtype", "data") if k in out}
     cfg = dict(out.get("config", {}))
     cfg["workload"] = str(cfg.get("workload", ""))[:300]
     line["config"] = cfg
-    for k in ("learner_steps_per_sec", "env_steps_per_sec", "host_enqueue_ms_per_step",
+    if "learner_steps_per_sec" in out:
+        line["learner_steps_per_sec"] = out["learner_steps_per_sec"]
+    for k in ("env_steps_per_sec", "host_enqueue_ms_per_step",
               "prime_steps", "captures_in_timed_region", "final_loss", "step_algorithmic_gflop",
               "step_mfma_frac", "kernel_time_sum_ms", "steady_ms_per_step", "steady_steps",
               "rccl_ranks"):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 10
+#define AA_ABI_VERSION 11
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -557,6 +557,12 @@ int aa_normal_log_prob(const float* loc, const float* scale, const float* x, int
  * seed)); replaces tfd.Normal.sample in PPOPolicy._action (policies/actor_policy.py). */
 int aa_normal_sample(const float* loc, const float* scale, int64_t n, uint64_t seed,
                      const int64_t* call_counter_dev, float* out, void* stream);
+/* out[i,d] = lo[d] + (hi[d] - lo[d]) * u, u ~ U[0,1) (Philox(counter = (element, *call_counter),
+ * key = seed)): RandomTFPolicy on a bounded continuous action spec -- replaces tf.random.uniform in
+ * tensor_spec.sample_bounded_spec (specs/tensor_spec.py:327-420) under
+ * policies/random_tf_policy.py:60-150 (the SAC script's initial collect policy). */
+int aa_uniform_sample(const float* lo, const float* hi, int64_t N, int32_t D, uint64_t seed,
+                      const int64_t* call_counter_dev, float* out, void* stream);
 /* out[b,t] = discount[b,t] * gamma * (next_step_type[b,t] != LAST), t < T1-1
  * (ppo_agent.py:630-676, utils/common.py:883-895); inputs are [B,T1]. */
 int aa_ppo_discounts(const float* discount, const int32_t* next_step_type, float gamma, int64_t B,

@@ -102,7 +102,14 @@ class OracleSacAgent:
                  target_update_period=1, initial_log_alpha=0.0, target_entropy=None,
                  std_kind="exp", critic_loss_weight=0.5, actor_loss_weight=1.0,
                  alpha_loss_weight=1.0, td_errors_loss_fn=squared_difference,
-                 use_log_alpha_in_alpha_loss=True):
+                 use_log_alpha_in_alpha_loss=True, dtype=torch.float32):
+        # dtype=torch.float64: the same training in double precision (parameters, forwards, losses,
+        # Adam arithmetic with the same fp32-rounded hyper-parameters) -- the yardstick of the
+        # free-running envelope test (tests/test_gpu_free_running.py)
+        self.dtype = dtype
+        cast = lambda ps: [p.to(dtype) for p in ps]
+        actor_params, critic1_params, critic2_params = cast(actor_params), cast(critic1_params), \
+            cast(critic2_params)
         self.A = act_dim
         self.actor_layers = nets.mlp_q_layers(actor_fc, 2 * act_dim, "relu")
         self.critic_layers = nets.mlp_q_layers(critic_fc, 1, "relu")
@@ -111,9 +118,9 @@ class OracleSacAgent:
         self.c2 = [p.clone().requires_grad_(True) for p in critic2_params]
         self.t1 = [p.detach().clone() for p in critic1_params]
         self.t2 = [p.detach().clone() for p in critic2_params]
-        self.log_alpha = torch.tensor(float(initial_log_alpha), requires_grad=True)
-        self.act_mean = torch.as_tensor(act_mean, dtype=torch.float32)
-        self.act_mag = torch.as_tensor(act_mag, dtype=torch.float32)
+        self.log_alpha = torch.tensor(float(initial_log_alpha), dtype=dtype, requires_grad=True)
+        self.act_mean = torch.as_tensor(act_mean, dtype=torch.float32).to(dtype)
+        self.act_mag = torch.as_tensor(act_mag, dtype=torch.float32).to(dtype)
         self.opt_actor = optim.Adam(actor_lr, eps=adam_eps)
         self.opt_critic = optim.Adam(critic_lr, eps=adam_eps)
         self.opt_alpha = optim.Adam(alpha_lr, eps=adam_eps)
@@ -133,8 +140,8 @@ class OracleSacAgent:
         logged in self.flips as (tag, count, largest |z| / max|z|): legitimate only if the
         pre-activation is numerically zero (oracle/arbiter.py explains why this matters)."""
         if masks is None:
-            return nets.forward(layers, params, x)
-        out, pre = nets.forward_branch(layers, params, x, masks=masks, dtype=torch.float32)
+            return nets.forward(layers, params, x, dtype=self.dtype)
+        out, pre = nets.forward_branch(layers, params, x, masks=masks, dtype=self.dtype)
         for z, m in zip(pre, masks):
             if m is None:
                 continue
@@ -146,12 +153,13 @@ class OracleSacAgent:
         return out
 
     def q(self, params, obs, act, masks=None, tag=""):
-        return self._mlp(self.critic_layers, params, torch.cat([obs, act], -1), masks,
+        return self._mlp(self.critic_layers, params,
+                         torch.cat([obs.to(self.dtype), act.to(self.dtype)], -1), masks,
                          tag).reshape(-1)
 
     def pi(self, obs, eps, masks=None, tag=""):
-        z = self._mlp(self.actor_layers, self.actor, obs, masks, tag)
-        return tanh_normal(z, eps, self.act_mean, self.act_mag, self.kind)
+        z = self._mlp(self.actor_layers, self.actor, obs.to(self.dtype), masks, tag)
+        return tanh_normal(z, eps.to(self.dtype), self.act_mean, self.act_mag, self.kind)
 
     def train(self, obs, actions, next_obs, reward, discount, eps_next, eps_actor, eps_alpha,
               weights=None, grads_override=None, masks=None):
@@ -192,7 +200,8 @@ class OracleSacAgent:
         lloss = self.wl * alpha_loss(logp, self.log_alpha, self.target_entropy,
                                      self.use_log_alpha, weights)
         lgrad = torch.autograd.grad(lloss, [self.log_alpha])
-        self.opt_alpha.step([self.log_alpha], [torch.tensor(float(grads_override["alpha"]))]
+        self.opt_alpha.step([self.log_alpha],
+                            [torch.tensor(float(grads_override["alpha"]), dtype=self.dtype)]
                             if grads_override else lgrad)
 
         self.steps += 1

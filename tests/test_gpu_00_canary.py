@@ -45,7 +45,7 @@ def test_01_library_loads_and_trivial_kernels_launch(dev, lib):
     import torch
 
     from agents_amd import _lib
-    assert lib.aa_abi_version() >= 10
+    assert lib.aa_abi_version() >= 11
     torch.cuda.synchronize()
     stream = _lib.stream_ptr()
     _lib.check(lib.aa_marker(0, stream), "aa_marker")

@@ -51,3 +51,23 @@ def test_bench_two_ranks_prints_a_well_formed_line(dev):
     assert abs(out["value"] - steps_per_sec * 256 * 2) <= 1e-6 * out["value"]
     assert "cpu_baseline" not in out and "other_configs" not in out      # N = 1 only
     assert "process group up: backend gloo, 2 ranks" in r.stderr
+
+
+@pytest.mark.timeout(400)
+def test_plain_python_bench_gpus_2_launches_its_own_ranks(dev):
+    """The driver's command line is `python bench.py --gpus N ...` with no WORLD_SIZE: bench.py must
+    become the launcher (torch.distributed.run, one rank per GPU) instead of exiting."""
+    env = dict(os.environ, AA_BENCH_BACKEND="gloo", AA_BENCH_SHARE_GPU="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8",
+           "--warmup", "2", "--max-length", "16", "--no-breakdown", "--steady-steps", "0"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=380)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["steps"] == 8
+    assert "re-launching under torch.distributed.run (2 ranks" in r.stderr
+    assert len(lines[0]) < 4096
