@@ -87,13 +87,15 @@ def train_eval(
     root_dir = os.path.expanduser(root_dir)
     train_dir = os.path.join(root_dir, "train")
 
-    eval_metrics = [
-        tf_metrics.AverageReturnMetric(buffer_size=num_eval_episodes),
-        tf_metrics.AverageEpisodeLengthMetric(buffer_size=num_eval_episodes),
-    ]
     global_step = common.Variable(0, name="global_step")
     seed_kw = {} if random_seed is None else {"seed": int(random_seed)}
     eval_tf_env = env_load_fn(env_name, batch_size=1, **seed_kw)
+    eval_metrics = [
+        tf_metrics.AverageReturnMetric(buffer_size=num_eval_episodes,
+                                       batch_size=eval_tf_env.batch_size),
+        tf_metrics.AverageEpisodeLengthMetric(buffer_size=num_eval_episodes,
+                                              batch_size=eval_tf_env.batch_size),
+    ]
     tf_env = env_load_fn(env_name, batch_size=num_parallel_environments, **seed_kw)
     optimizer = optimizers.AdamOptimizer(learning_rate=learning_rate)
 

@@ -134,7 +134,11 @@ class PPOAgent(tf_agent.TFAgent):
         self._D = int(np.prod(spec.shape)) if len(spec.shape) else 1
         self._obs_rank = len(time_step_spec.observation.shape)
         self._work = {}
-        self._norm_seg = None
+        # [0, total] segment table of the global-norm clip + its accumulator: created here, not
+        # lazily inside `_train` -- an H2D copy is not allowed while a HIP graph is being captured
+        self._norm_seg = torch.tensor([0, self.flat_grads.numel()], dtype=torch.int64,
+                                      device=self.flat_grads.device)
+        self._norm_sumsq = torch.zeros((1,), dtype=torch.float32, device=self.flat_grads.device)
         self.num_replicas = 1       # installed by train.Learner
         self.gradient_hook = None
         self._clip_fraction = 0.0
@@ -433,6 +437,16 @@ class PPOAgent(tf_agent.TFAgent):
 
     def _bump_train_step(self):
         self._train_step_counter.assign_add(1)
+
+    @property
+    def graph_train_whole_ok(self):
+        """`common.function(agent.train)` replays the train step as ONE HIP graph only for the
+        static configuration (minibatches of a fixed shape prepared by PPOLearner: no in-train
+        preprocessing, no in-train normaliser update, one epoch per call).  The reference
+        script's `tf_agent.train(gather_all())` -- a different [B, T] every iteration, GAE and
+        `num_epochs` epochs inside the call -- stays on eager launches."""
+        return (not self._compute_value_and_advantage_in_train and
+                not self.update_normalizers_in_train and self._num_epochs == 1)
 
     def _graph_train_whole(self, experience, weights):
         """The whole train step is device work plus host counters registered with

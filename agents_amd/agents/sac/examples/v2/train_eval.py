@@ -110,17 +110,23 @@ def train_eval(
     root_dir = os.path.expanduser(root_dir)
     train_dir = os.path.join(root_dir, "train")
 
-    eval_metrics = [
-        tf_metrics.AverageReturnMetric(buffer_size=num_eval_episodes),
-        tf_metrics.AverageEpisodeLengthMetric(buffer_size=num_eval_episodes),
-    ]
     global_step = common.Variable(0, name="global_step")
 
+    train_env_load_fn = env_load_fn
     if env_load_fn is suite_synthetic.load:
-        env_load_fn = functools.partial(suite_synthetic.load, batch_size=num_parallel_environments)
-    tf_env = env_load_fn(env_name)
+        train_env_load_fn = functools.partial(suite_synthetic.load,
+                                              batch_size=num_parallel_environments)
+    tf_env = train_env_load_fn(env_name)
     eval_env_name = eval_env_name or env_name
     eval_tf_env = env_load_fn(eval_env_name)
+    # (the reference's eval environment has batch size 1, the metrics' default; an env_load_fn
+    # that returns a batched environment is followed)
+    eval_metrics = [
+        tf_metrics.AverageReturnMetric(buffer_size=num_eval_episodes,
+                                       batch_size=eval_tf_env.batch_size),
+        tf_metrics.AverageEpisodeLengthMetric(buffer_size=num_eval_episodes,
+                                              batch_size=eval_tf_env.batch_size),
+    ]
 
     time_step_spec = tf_env.time_step_spec()
     observation_spec = time_step_spec.observation

@@ -180,6 +180,15 @@ __device__ static inline void aa_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+#ifdef AA_GD_STAMPS       /* tools/fc1_probe.hip: per-workgroup wall_clock64 stamps (10 ns ticks) */
+__device__ long long* d_gd_stamps = nullptr;
+#define GD_STAMP(i)                                                              \
+  if (d_gd_stamps != nullptr && threadIdx.x == 0)                                \
+    d_gd_stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64();
+#else
+#define GD_STAMP(i)
+#endif
+
 template <int AK, int BKIND, int BM, int BN, int WGM, int WGN, int WGK, int NS>
 __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
   static_assert(WGM * WGN * WGK == 4, "4 waves per workgroup");
@@ -195,6 +204,7 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
 
   AaBlk blk;
   if (!aa_block_of(p, &blk)) return;
+  GD_STAMP(0)
   const int m0 = blk.x * BM;
   const int n0 = blk.y * BN;
   const int k_begin = blk.z * p.k_per_split;
@@ -227,9 +237,28 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
   const bool do_colsum = (BKIND == AA_KIND_D_DENSE) && p.colsum_out != nullptr && blk.x == 0;
   float csum = 0.f;
 
+  // K rotation.  The workgroups that share an operand slice (same M tile -> same A rows, same N
+  // tile -> same B columns; with the XCD-aware order they also share an L2) used to walk K in
+  // lock-step, so EVERY tile was a first touch for all of them at once: each wave waited a full
+  // memory round trip per tile (in-kernel timeline: 0.83 us per tile against 0.43 us of MFMA,
+  // tools/fc1_probe.hip) although seven of eight requests could have been L2 hits.  Starting each
+  // workgroup's walk at tile ((M tile + N tile) mod R) * nk / R spreads the first touches: one
+  // sharer pays the round trip, the others find the line in L2.  Only the fp32 summation order
+  // changes (still fixed per workgroup: deterministic).  MEASURED (round 4): -0.4 us of 15.2 on
+  // fc1.fwd with the in-order loop, nothing with the pipelined loop -- the lock-step hypothesis
+  // was wrong (the operand stream alone runs at 17 TB/s: tools/fc1_mem_probe.hip); an explicit
+  // L2 warm-up pass in front of the loop was slower (+1.5 us) and is gone.  Off by default.
+  int rot = 0;
+  if (p.k_rot != 0 && nk > 1) {
+    const int R = nk < 8 ? nk : 8;
+    rot = (((blk.x + blk.y) % R) * nk) / R;
+  }
+
   auto issue_tile = [&](int t) {  // K-tile t -> ring slot t % NS (tiles past nk are all-zero)
     const unsigned st = lds0 + (unsigned)(t % NS) * STAGE;
-    const int k0 = k_begin + t * AA_BK;
+    int tt = t + rot;
+    if (tt >= nk) tt -= nk;
+    const int k0 = t < nk ? k_begin + tt * AA_BK : k_end;
     la.issue(p, rA, p.lda, st, k0, k_end, wave);
     lb.issue(p, rB, p.ldb, st + OA::kPadded, k0, k_end, wave);
   };
@@ -238,16 +267,8 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
 #pragma unroll
   for (int t = 0; t < NS - 1; ++t) issue_tile(t);
 
-  for (int t = 0; t < nk; ++t) {
-    // tile t has landed once this wave's DMAs older than the (NS-2) newest groups are done ...
-    aa_wait_vmcnt<(NS - 2) * NIW>();
-    // ... for every wave of the workgroup; the barrier also says everybody finished reading
-    // slot (t-1) % NS, which the next DMA group overwrites.
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    issue_tile(t + NS - 1);
-    const char* sa = lds + (t % NS) * STAGE;
-    const char* sb = sa + OA::kPadded;
+  constexpr int NCH = 4 / WGK;   // 8-k chunks of a K-tile this wave multiplies
+  auto colsum_tile = [&](const char* sb) {
     if constexpr (BKIND == AA_KIND_D_DENSE) {
       if (do_colsum && threadIdx.x < BN) {  // fixed k order -> deterministic bias gradient
         const float* col = reinterpret_cast<const float*>(sb) + threadIdx.x;
@@ -255,6 +276,73 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
         for (int k = 0; k < AA_BK; ++k) csum += col[k * BN];
       }
     }
+  };
+  if (p.pipe != 0) {
+    // Software-pipelined form: the operands of tile t+1 travel LDS -> registers while the MFMAs of
+    // tile t run.  The in-order form below (wait, barrier, ds_read, MFMA) exposes barrier skew +
+    // LDS latency once per tile with one wave per SIMD: in-kernel timeline 0.83 us per tile
+    // against 0.43 us of MFMA issue (tools/fc1_probe.hip); the same DMA ring with the MFMAs fed
+    // from registers runs at the MFMA rate (tools/fc1_mem_probe.hip: 9.8 us vs 14.5).
+    float ra[2][NCH][TM][4], rb[2][NCH][TN][4];
+    auto stage = [&](int t, int buf) {   // tile t has landed -> registers of `buf`
+      aa_wait_vmcnt<(NS - 2) * NIW>();
+      // every wave is done READING the slot the DMA below overwrites (tile t-1's, fetched one
+      // step ago) -- its ds_reads have retired -- and tile t has landed for every wave
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue_tile(t + NS - 1);
+      const char* sa = lds + (t % NS) * STAGE;
+      const char* sb = sa + OA::kPadded;
+      if (t < nk) colsum_tile(sb);
+#pragma unroll
+      for (int cq = 0; cq < NCH; ++cq) {
+        const int c = cq * WGK + wk;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          OA::fetch(p, sa, wm * (TM * 32) + 32 * i + l31, c, lh, ra[buf][cq][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          OB::fetch(p, sb, wn * (TN * 32) + 32 * j + l31, c, lh, rb[buf][cq][j]);
+      }
+    };
+    auto multiply = [&](int buf) {
+#pragma unroll
+      for (int cq = 0; cq < NCH; ++cq)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[buf][cq][i][jj], rb[buf][cq][j][jj],
+                                                               acc[i][j], 0, 0, 0);
+    };
+    stage(0, 0);
+    GD_STAMP(1)
+    int t = 0;
+    for (; t + 2 <= nk; t += 2) {
+      stage(t + 1, 1);
+      multiply(0);
+      stage(t + 2, 0);      // (tile nk is the all-zero tail tile: staged, never multiplied)
+      multiply(1);
+    }
+    if (t < nk) multiply(0);
+  } else {
+  for (int t = 0; t < nk; ++t) {
+    // tile t has landed once this wave's DMAs older than the (NS-2) newest groups are done ...
+    aa_wait_vmcnt<(NS - 2) * NIW>();
+    // ... for every wave of the workgroup; the barrier also says everybody finished reading
+    // slot (t-1) % NS, which the next DMA group overwrites.
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#ifdef AA_GD_STAMPS
+    if (t == 0) { GD_STAMP(1) }
+#endif
+    issue_tile(t + NS - 1);
+    const char* sa = lds + (t % NS) * STAGE;
+    const char* sb = sa + OA::kPadded;
+    colsum_tile(sb);
 #pragma unroll
     for (int cq = 0; cq < 4 / WGK; ++cq) {
       const int c = cq * WGK + wk;
@@ -272,6 +360,8 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][jj], b[j][jj], acc[i][j], 0, 0, 0);
     }
   }
+  }
+  GD_STAMP(2)
   aa_wait_vmcnt<0>();  // drain the (all-zero) tail DMAs before the LDS is reused
   __syncthreads();
 
@@ -340,6 +430,7 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
     }
   }
   }
+  GD_STAMP(3)
 }
 
 template <int AK, int BKIND, int BM, int BN, int WGM, int WGN, int WGK, int NS>

@@ -26,6 +26,13 @@ class _GreedySacPolicy(tf_policy.TFPolicy):
     def _variables(self):
         return self._wrapped_policy.variables()
 
+    def state_dict(self):
+        """Checkpoint = the wrapped policy's (the mode needs no state of its own)."""
+        return self._wrapped_policy.state_dict()
+
+    def load_state_dict(self, sd):
+        self._wrapped_policy.load_state_dict(sd)
+
     def _action(self, time_step, policy_state, seed):
         p = self._wrapped_policy
         obs = time_step.observation

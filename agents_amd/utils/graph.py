@@ -335,6 +335,9 @@ class GraphedTrain:
 
     def __init__(self, agent):
         self._agent = agent
+        # the class's own method: `tf_agent.train = common.function(tf_agent.train)` (the PPO and
+        # SAC scripts) rebinds the INSTANCE attribute to this object
+        self._eager_train = type(agent).train.__get__(agent)
         self._cache = {}       # signature -> {input address tuple | None: _Entry}
         self._warm = {}
         self._seen = {}
@@ -398,10 +401,10 @@ class GraphedTrain:
     def __call__(self, experience, weights=None, **kwargs):
         agent = self._agent
         if not self.enabled or kwargs or getattr(agent, "check_numerics", False) or capturing():
-            return agent.train(experience, weights=weights, **kwargs)
+            return self._eager_train(experience, weights=weights, **kwargs)
         if self._whole and (getattr(agent, "gradient_hook", None) is not None or
                             not getattr(agent, "graph_train_whole_ok", True)):
-            return agent.train(experience, weights=weights)
+            return self._eager_train(experience, weights=weights)
         _ensure_prepared()
         # Steady state: the very same experience object (a sampler ring slot) as on an earlier
         # call whose graph reads it in place -- signature, trajectory checks and address tuple
@@ -413,7 +416,7 @@ class GraphedTrain:
             sig = _sig(experience, weights)
             if self._warm.get(sig, 0) < _WARMUP_CALLS:
                 self._warm[sig] = self._warm.get(sig, 0) + 1
-                return agent.train(experience, weights=weights)
+                return self._eager_train(experience, weights=weights)
             if not agent._initialized:
                 agent.initialize()
             if hasattr(agent, "_check_trajectory"):

@@ -70,7 +70,10 @@ int aa_rb_sample_rows(const int64_t* last_id_dev, int64_t batch, int64_t max_len
  * bit) is recomputed by every workgroup of sample s, which then copies row (id+t) mod L + block*L
  * of every leaf into out[s*T + t]; ids_out[s*T+t] = id_table[row] (nullable), prob_out[s]
  * (nullable); the last workgroup advances *call_counter_dev (nullable: then `call_counter` alone
- * numbers the call).  Replaces aa_rb_sample_rows + aa_rb_gather_rows (+ the counter bump) on the
+ * numbers the call).  `arrival_dev`: 144 int64 words, zero before the FIRST call, owned by the
+ * kernel afterwards (eight monotonic arrival shards on their own cache lines + the count already
+ * accounted for; they are not zero between calls).  *err_flag_dev: 1 = a draw found no valid range,
+ * 2 = the arrival poll timed out (the call counter is then left untouched).  Replaces aa_rb_sample_rows + aa_rb_gather_rows (+ the counter bump) on the
  * get_next path (tf_uniform_replay_buffer.py:211-310, table.py:86-110). */
 int aa_rb_sample_gather(const void* const* leaf_tables_h, void* const* leaf_out_h,
                         const int64_t* leaf_row_bytes_h, int n_leaves, const int64_t* id_table,
