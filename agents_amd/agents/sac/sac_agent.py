@@ -20,6 +20,7 @@ and `networks.critic_network.CriticNetwork`.  The reference lets callers pass `a
 here the policy is always `SacPolicy` (an ActorPolicy over the same kernels).
 """
 import collections
+import os
 
 import numpy as np
 import torch
@@ -39,6 +40,10 @@ SacLossInfo = collections.namedtuple("SacLossInfo", ("critic_loss", "actor_loss"
 # than the overlap of latency-bound kernels gains.  Removed; the twin critics now share launches.)
 
 std_clip_transform = adn.std_clip_transform
+
+
+# A/B knob: AA_SAC_QUAD_FORWARD=0 evaluates the target pair and the critic pair in two launches
+_QUAD_FORWARD = os.environ.get("AA_SAC_QUAD_FORWARD", "1") != "0"
 
 
 def _spec_means_and_magnitudes(spec):
@@ -330,7 +335,14 @@ class SacAgent(tf_agent.TFAgent):
                                        self._target_critic_network_2, next_obs, actions)
         na, nlogp, _ = self._loss_policy.sample(next_obs, slot="next", eps=eps_next,
                                                 save=w.get("save_next"))
-        if pair:
+        targets = (self._target_critic_network_1, self._target_critic_network_2)
+        critics = (self._critic_network_1, self._critic_network_2)
+        if pair and _QUAD_FORWARD and critic_network.two_pairs_ok(targets, critics):
+            # target pair + critic pair: one launch of four networks (256 workgroups)
+            (tq1, tq2), (q1, q2) = critic_network.forward_two_pairs(
+                targets, next_obs, na, "target", critics, obs, actions, "critic",
+                need_grad_b=need_grad)
+        elif pair:
             tq1, tq2 = critic_network.forward_pair(
                 self._target_critic_network_1, self._target_critic_network_2, next_obs, na,
                 slot="target")

@@ -71,10 +71,6 @@ struct GemmP {
   // XCD-aware block order (aa_block_of): 0 = the launch's own (x, y, z); 1 / 2 / 3 = a 1-D launch
   // whose blocks are dealt to the 8 XCDs in contiguous runs of the K-split / N-tile / M-tile index
   int xcd_mode, gx, gy, gz;
-  // LDS-DMA main loop only (gemm_dma.h): k_rot != 0 -> each workgroup starts its K walk at a tile
-  // offset that depends on (M tile + N tile), see aa_gemm_dma_kernel
-  int k_rot;
-  int pipe;          // 1 = software-pipelined k loop (operands one tile ahead in registers)
 };
 
 // Which (M tile, N tile, K split) a workgroup computes.  Hardware deals consecutive workgroups to
@@ -85,11 +81,6 @@ struct GemmP {
 // [c * per, (c + 1) * per), and the index is decomposed with the dimension that partitions the
 // most operand bytes slowest, so an XCD's L2 sees one slice of it.  Pure relabelling: every
 // (x, y, z) is computed exactly once by the same code, results are bit-identical.
-#define AA_GEMM_KROT_DEFAULT 0
-#define AA_GEMM_PIPE_DEFAULT 1
-static int g_aa_gemm_krot = -1;   // -1: read the environment on first use
-static int g_aa_gemm_pipe = -1;
-
 struct AaBlk { int x, y, z; };
 __device__ static inline bool aa_block_of(const GemmP& p, AaBlk* b) {
   if (p.xcd_mode == 0) {
@@ -981,18 +972,6 @@ static int aa_gemm_f32_impl(const aa_gemm_desc* d, void* workspace, int64_t work
       else if (p.gx % 8 != 0) p.xcd_mode = 3;      // launch order already partitions M when 8 | gx
     }
   }
-  // K rotation / software pipelining of the LDS-DMA loop (gemm_dma.h).  AA_GEMM_KROT / AA_GEMM_PIPE
-  // = 0 / 1 override the defaults (A/B measurements; the probes set the statics directly).
-  if (g_aa_gemm_krot < 0) {
-    const char* e = getenv("AA_GEMM_KROT");
-    g_aa_gemm_krot = e != nullptr ? (e[0] != '0') : AA_GEMM_KROT_DEFAULT;
-  }
-  if (g_aa_gemm_pipe < 0) {
-    const char* e = getenv("AA_GEMM_PIPE");
-    g_aa_gemm_pipe = e != nullptr ? (e[0] != '0') : AA_GEMM_PIPE_DEFAULT;
-  }
-  p.pipe = g_aa_gemm_pipe;
-  p.k_rot = g_aa_gemm_krot;
   p.bias = d->bias;
   p.act = d->act;
   p.mask_src = d->mask_src;

@@ -237,28 +237,30 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
   const bool do_colsum = (BKIND == AA_KIND_D_DENSE) && p.colsum_out != nullptr && blk.x == 0;
   float csum = 0.f;
 
-  // K rotation.  The workgroups that share an operand slice (same M tile -> same A rows, same N
-  // tile -> same B columns; with the XCD-aware order they also share an L2) used to walk K in
-  // lock-step, so EVERY tile was a first touch for all of them at once: each wave waited a full
-  // memory round trip per tile (in-kernel timeline: 0.83 us per tile against 0.43 us of MFMA,
-  // tools/fc1_probe.hip) although seven of eight requests could have been L2 hits.  Starting each
-  // workgroup's walk at tile ((M tile + N tile) mod R) * nk / R spreads the first touches: one
-  // sharer pays the round trip, the others find the line in L2.  Only the fp32 summation order
-  // changes (still fixed per workgroup: deterministic).  MEASURED (round 4): -0.4 us of 15.2 on
-  // fc1.fwd with the in-order loop, nothing with the pipelined loop -- the lock-step hypothesis
-  // was wrong (the operand stream alone runs at 17 TB/s: tools/fc1_mem_probe.hip); an explicit
-  // L2 warm-up pass in front of the loop was slower (+1.5 us) and is gone.  Off by default.
-  int rot = 0;
-  if (p.k_rot != 0 && nk > 1) {
-    const int R = nk < 8 ? nk : 8;
-    rot = (((blk.x + blk.y) % R) * nk) / R;
+  // Activation-derivative mask of the epilogue (dX GEMMs): its 16 values per lane are requested
+  // HERE, before the first DMA, so the round trip (it was the first dependent access of the
+  // epilogue: 4.1 us of epilogue on fc1.dX in the in-kernel timeline) rides under the k loop.
+  // Branch-free on purpose -- a load under a condition is waited for at the join: clamped
+  // in-range indices, or element 0 of the B operand when the launch has no mask.  One-tile waves
+  // only (16 registers held across the loop).
+  constexpr bool kPreMask = TM == 1 && TN == 1;
+  float mk[16];
+  if constexpr (kPreMask) {
+    const bool use = p.splits <= 1 && p.mask_kind != 0;
+    const float* msrc = use ? p.mask_src : p.B;
+    const int nq = n0 + wn * 32 + l31;
+    const int nc = nq < p.N ? nq : p.N - 1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int mq = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      const int mc = mq < p.M ? mq : p.M - 1;
+      mk[e] = msrc[use ? (size_t)mc * p.ldm + nc : (size_t)0];
+    }
   }
 
   auto issue_tile = [&](int t) {  // K-tile t -> ring slot t % NS (tiles past nk are all-zero)
     const unsigned st = lds0 + (unsigned)(t % NS) * STAGE;
-    int tt = t + rot;
-    if (tt >= nk) tt -= nk;
-    const int k0 = t < nk ? k_begin + tt * AA_BK : k_end;
+    const int k0 = k_begin + t * AA_BK;
     la.issue(p, rA, p.lda, st, k0, k_end, wave);
     lb.issue(p, rB, p.ldb, st + OA::kPadded, k0, k_end, wave);
   };
@@ -277,12 +279,15 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
       }
     }
   };
-  if (p.pipe != 0) {
-    // Software-pipelined form: the operands of tile t+1 travel LDS -> registers while the MFMAs of
-    // tile t run.  The in-order form below (wait, barrier, ds_read, MFMA) exposes barrier skew +
-    // LDS latency once per tile with one wave per SIMD: in-kernel timeline 0.83 us per tile
-    // against 0.43 us of MFMA issue (tools/fc1_probe.hip); the same DMA ring with the MFMAs fed
-    // from registers runs at the MFMA rate (tools/fc1_mem_probe.hip: 9.8 us vs 14.5).
+  {
+    // Software-pipelined k loop: the operands of tile t+1 travel LDS -> registers while the MFMAs
+    // of tile t run.  The in-order form it replaced (wait, barrier, ds_read, MFMA) exposed barrier
+    // skew + LDS latency once per tile with one wave per SIMD: in-kernel timeline 0.83 us per tile
+    // against 0.43 us of MFMA issue on fc1.fwd (tools/fc1_probe.hip: k loop 9.6 -> 7.6 us, launch
+    // 15.2 -> 13.9 us; fc1.dX 18.1 -> 17.2, fc1.dW 17.1 -> 16.5); the same DMA ring with the MFMAs
+    // fed from registers alone runs at the MFMA rate (tools/fc1_mem_probe.hip: 9.8 us, of which
+    // 6.1 us are the 196 fp32 MFMAs per SIMD at the ~2.05 GHz the matrix pipe sustains).  In the
+    // training loop the change is neutral (0.3535 vs 0.3546 ms, three alternating pairs).
     float ra[2][NCH][TM][4], rb[2][NCH][TN][4];
     auto stage = [&](int t, int buf) {   // tile t has landed -> registers of `buf`
       aa_wait_vmcnt<(NS - 2) * NIW>();
@@ -328,38 +333,6 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
       multiply(1);
     }
     if (t < nk) multiply(0);
-  } else {
-  for (int t = 0; t < nk; ++t) {
-    // tile t has landed once this wave's DMAs older than the (NS-2) newest groups are done ...
-    aa_wait_vmcnt<(NS - 2) * NIW>();
-    // ... for every wave of the workgroup; the barrier also says everybody finished reading
-    // slot (t-1) % NS, which the next DMA group overwrites.
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#ifdef AA_GD_STAMPS
-    if (t == 0) { GD_STAMP(1) }
-#endif
-    issue_tile(t + NS - 1);
-    const char* sa = lds + (t % NS) * STAGE;
-    const char* sb = sa + OA::kPadded;
-    colsum_tile(sb);
-#pragma unroll
-    for (int cq = 0; cq < 4 / WGK; ++cq) {
-      const int c = cq * WGK + wk;
-      float a[TM][4], b[TN][4];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) OA::fetch(p, sa, wm * (TM * 32) + 32 * i + l31, c, lh, a[i]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) OB::fetch(p, sb, wn * (TN * 32) + 32 * j + l31, c, lh, b[j]);
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][jj], b[j][jj], acc[i][j], 0, 0, 0);
-    }
-  }
   }
   GD_STAMP(2)
   aa_wait_vmcnt<0>();  // drain the (all-zero) tail DMAs before the LDS is reused
@@ -423,7 +396,12 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
         float v = acc[i][j][e];
         if (!raw) {
           v = aa_act(v + bv, p.act);
-          if (p.mask_kind != 0) v *= aa_actgrad(p.mask_src[(size_t)m * p.ldm + n], p.mask_kind);
+          if (p.mask_kind != 0) {
+            if constexpr (kPreMask)
+              v *= aa_actgrad(mk[e], p.mask_kind);
+            else
+              v *= aa_actgrad(p.mask_src[(size_t)m * p.ldm + n], p.mask_kind);
+          }
         }
         C[(size_t)m * ldc + n] = v;
       }

@@ -489,6 +489,46 @@ __device__ static inline int64_t aa_mod_nonneg(int64_t a, int64_t n) {
   return a % n;
 }
 
+// The same draw on the HOST (stamped launches with S <= AA_RB_DRAWN_MAX: the host mirrors last_id
+// and the call number, so it can compute the S start rows itself -- a few microseconds of Philox
+// -- and hand them to the kernel BY VALUE in the kernel arguments; the device then starts its
+// row loads with no draw and no dependent read in front of them).  Same Philox stream, same
+// reductions (a % n in 64-bit integers is what aa_umod64 computes), same ring arithmetic:
+// bit-identical rows, ids and probabilities (tests/test_gpu_replay.py).
+#define AA_RB_DRAWN_MAX 256
+struct AaDrawnRows {
+  uint32_t idm[AA_RB_DRAWN_MAX];   // first row of the sample inside its env block: id mod max_len
+  uint32_t seg[AA_RB_DRAWN_MAX];   // env block
+};
+static bool aa_rb_draw_host(int64_t last_id, int64_t batch, int64_t max_len, int64_t S, int64_t T,
+                            uint64_t call, uint32_t k0, uint32_t k1, AaDrawnRows* out,
+                            float* prob) {
+  int64_t min_id, max_id;
+  if (last_id < max_len) {
+    min_id = 0;
+    max_id = last_id + 1 - T + 1;
+    if (max_id < 0) max_id = 0;
+  } else {
+    min_id = last_id + 1 - max_len;
+    max_id = last_id + 1 - T + 1;
+  }
+  const int64_t num_ids = max_id - min_id;
+  if (num_ids <= 0) return false;
+  for (int64_t s = 0; s < S; ++s) {
+    const Philox4 r = philox4x32_10((uint32_t)s, (uint32_t)((uint64_t)s >> 32), (uint32_t)call,
+                                    (uint32_t)(call >> 32), k0, k1);
+    const uint64_t a = ((uint64_t)r.y << 32) | r.x;
+    const uint64_t c = ((uint64_t)r.w << 32) | r.z;
+    const int64_t id = min_id + (int64_t)(a % (uint64_t)num_ids);
+    int64_t m = id % max_len;
+    if (m < 0) m += max_len;
+    out->idm[s] = (uint32_t)m;
+    out->seg[s] = (uint32_t)(c % (uint64_t)batch);
+  }
+  *prob = 1.0f / (float)(num_ids * batch);
+  return true;
+}
+
 // One sample's draw: start id, env block and probability; false when the buffer has no valid id.
 __device__ static inline bool aa_rb_draw(int64_t last_id, int64_t batch, int64_t max_len, int64_t T,
                                          int64_t s, uint64_t call, uint32_t k0, uint32_t k1,
@@ -729,6 +769,110 @@ aa_rb_sample_gather_kernel(AaLeafSet leaves, AaRowGrid g, const int64_t* __restr
   if (call_dev != nullptr) aa_arrivals_finish(call_dev, arrival, 1, gridDim.x, err);
 }
 
+// The gather of a draw the HOST made (aa_rb_draw_host): rows arrive in the kernel arguments, so a
+// workgroup's first instructions are its row loads -- no Philox, no device word to read, no LDS
+// hand-over, no arrival protocol.  Same grid and the same movers as aa_rb_sample_gather_kernel.
+template <int K>
+__global__ void __launch_bounds__(AA_RB_SG_THREADS)
+aa_rb_gather_drawn_kernel(AaLeafSet leaves, AaRowGrid g, const int64_t* __restrict__ id_table,
+                          int64_t* __restrict__ ids_out, float* __restrict__ probs,
+                          AaDrawnRows dv, float prob, int64_t max_len, int64_t S, int64_t T,
+                          int64_t* counter_out, int64_t next_call) {
+  const bool small = (int)blockIdx.x < g.small_blocks;
+  if (small) {
+    const int64_t i = (int64_t)blockIdx.x * AA_RB_SG_SMALL + threadIdx.x;
+    const int64_t n_rows = S * T;
+    if (threadIdx.x < AA_RB_SG_SMALL) {
+      const bool live = i < n_rows * g.per_row;
+      const int64_t r = !live ? 0 : (int64_t)((uint32_t)i / (uint32_t)g.per_row);
+      const int j = (int)(i - r * g.per_row);
+      const int64_t s = (int64_t)((uint32_t)r / (uint32_t)T);
+      const int64_t t = r - s * T;
+      int64_t m = (int64_t)dv.idm[s] + t;
+      if (m >= max_len) m -= max_len;
+      const int64_t row = m + (int64_t)dv.seg[s] * max_len;
+      const bool book = live && j == leaves.n - leaves.n_big;  // the bookkeeping slot
+      const char* src = nullptr;
+      char* dst = nullptr;
+      int64_t rb = 0;
+      if (book) {
+        if (ids_out != nullptr) {
+          rb = 8;
+          src = reinterpret_cast<const char*>(id_table + row);
+          dst = reinterpret_cast<char*>(ids_out + r);
+        }
+      } else if (live) {
+        const int l = leaves.n_big + j;
+        rb = leaves.row_bytes[l];
+        src = leaves.table[l] + row * rb;
+        dst = leaves.io[l] + r * rb;
+      }
+      aa_copy_items(src, dst, (int)rb);
+      if (book && t == 0 && probs != nullptr) probs[s] = prob;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && counter_out != nullptr) *counter_out = next_call;
+    return;
+  }
+  const uint32_t bid = blockIdx.x - (uint32_t)g.small_blocks;
+  const uint32_t groups = (uint32_t)T / K;
+  const uint32_t rg = bid / (uint32_t)g.n_chunks;
+  const int chunk = (int)(bid - rg * (uint32_t)g.n_chunks);
+  const uint32_t s_big = rg / groups;
+  const int64_t t0 = (int64_t)(rg - s_big * groups) * K;
+  int64_t row[K];
+  {
+    const int64_t m0 = (int64_t)dv.idm[s_big] + t0, base = (int64_t)dv.seg[s_big] * max_len;
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      int64_t m = m0 + t;
+      if (m >= max_len) m -= max_len;
+      row[t] = m + base;
+    }
+  }
+  const int64_t r0 = (int64_t)s_big * T + t0;
+  const int64_t off = (int64_t)chunk * g.chunk_bytes;
+  for (int l = 0; l < leaves.n_big; ++l) {
+    const int64_t rb = leaves.row_bytes[l];
+    if (off >= rb) continue;
+    int64_t len = rb - off;
+    if (len > g.chunk_bytes) len = g.chunk_bytes;
+    const char* tab = leaves.table[l] + off;
+    char* io = leaves.io[l] + off;
+    if ((((uintptr_t)tab | (uintptr_t)io | (uintptr_t)rb | (uintptr_t)len) & 15) == 0) {
+      // every 16-byte load of the K rows' chunks is issued before the first store
+      const int n = (int)(len >> 4);
+      for (int base = threadIdx.x; base < n; base += 2 * AA_RB_SG_THREADS) {
+        aa_u32x4 v[K][2];
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+          const aa_u32x4* src = reinterpret_cast<const aa_u32x4*>(tab + row[t] * rb);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int i = base + u * AA_RB_SG_THREADS;
+            if (i < n) v[t][u] = __builtin_nontemporal_load(src + i);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+          aa_u32x4* dst = reinterpret_cast<aa_u32x4*>(io + (r0 + t) * rb);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int i = base + u * AA_RB_SG_THREADS;
+            if (i < n) dst[i] = v[t][u];
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < K; ++t)
+        aa_copy_row_chunk<true, false>(leaves.table[l] + row[t] * rb, leaves.io[l] + (r0 + t) * rb,
+                                       rb, chunk, g.chunk_bytes);
+    }
+  }
+  if (g.small_blocks == 0 && blockIdx.x == 0 && threadIdx.x == 0 && counter_out != nullptr)
+    *counter_out = next_call;
+}
+
 // ---- pseudo-random permutation of [0, n) without a sort -------------------------------------------
 // perm[i] = the image of i under a 4-round balanced Feistel network on 2h bits (2^(2h) >= n, h >= 1)
 // whose round function is Philox4x32-10(counter = (half, round, call_lo, call_hi), key = seed),
@@ -953,6 +1097,31 @@ static int aa_rb_sample_gather_launch(const void* const* leaf_tables_h, void* co
   int64_t grid = 0;
   rc = aa_plan_rows(ls, S * T, true, &g, &grid, AA_RB_SG_SMALL, K);
   if (rc != AA_OK) return rc;
+  // stamped launch of a small batch: draw on the host, rows by value (see aa_rb_draw_host)
+  static int host_draw = -1;
+  if (host_draw < 0) {
+    const char* e = getenv("AA_RB_HOST_DRAW");
+    host_draw = (e != nullptr && e[0] == '0') ? 0 : 1;
+  }
+  if (host_draw && last_id_dev == nullptr && call_counter_dev == nullptr &&
+      S <= AA_RB_DRAWN_MAX && T <= max_len && (S * T * (int64_t)g.per_row >> 31) == 0 &&
+      batch * max_len < (1LL << 40)) {
+    AaDrawnRows dv;
+    float prob = 0.f;
+    if (aa_rb_draw_host(last_id_value, batch, max_len, S, T, call_counter, (uint32_t)seed,
+                        (uint32_t)(seed >> 32), &dv, &prob)) {
+#define AA_GD_LAUNCH(KK)                                                                         \
+  hipLaunchKernelGGL(aa_rb_gather_drawn_kernel<KK>, dim3((unsigned)grid),                       \
+                     dim3(AA_RB_SG_THREADS), 0, (hipStream_t)stream, ls, g, id_table, ids_out,  \
+                     prob_out, dv, prob, max_len, S, T, counter_out, (int64_t)(call_counter + 1))
+      if (K == 4) AA_GD_LAUNCH(4);
+      else if (K == 2) AA_GD_LAUNCH(2);
+      else AA_GD_LAUNCH(1);
+#undef AA_GD_LAUNCH
+      return aa_launch_status();
+    }
+    // (no valid id: the device kernel below reports it through *err_flag_dev as before)
+  }
 #define AA_SG_LAUNCH(KK)                                                                          \
   hipLaunchKernelGGL(aa_rb_sample_gather_kernel<KK>, dim3((unsigned)grid),                       \
                      dim3(AA_RB_SG_THREADS), 0, (hipStream_t)stream, ls, g, id_table, ids_out,   \

@@ -141,10 +141,27 @@ aa_count_steps_kernel(const int32_t* __restrict__ step_type, int64_t B,
                       int64_t* mailbox) {
   __shared__ float red[16];
   float s = 0.f;
-  for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
-    const int inc = step_type[b] != 2 ? 1 : 0;
-    if (counter != nullptr) counter[b] += inc;
-    s += (float)inc;
+  // eight elements per thread and pass, every load of a pass requested before the first use: the
+  // one-element loop took a memory round trip per element (13 us for 4,096 environments on the
+  // rocprofv3 timeline of the SAC loop; 2.4 us for 256)
+  for (int64_t b0 = threadIdx.x; b0 < B; b0 += 8 * (int64_t)blockDim.x) {
+    int st[8], cv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t b = b0 + u * (int64_t)blockDim.x;
+      const int64_t bc = b < B ? b : B - 1;         // clamped: unconditional loads
+      st[u] = step_type[bc];
+      cv[u] = counter != nullptr ? counter[bc] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t b = b0 + u * (int64_t)blockDim.x;
+      if (b < B) {
+        const int inc = st[u] != 2 ? 1 : 0;
+        if (counter != nullptr) counter[b] = cv[u] + inc;
+        s += (float)inc;
+      }
+    }
   }
   const float t = aa_block_sum(s, red);
   if (threadIdx.x == 0) {

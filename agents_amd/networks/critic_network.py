@@ -180,6 +180,27 @@ def forward_pair(c1, c2, observation, action, slot=0, need_grad=False):
     return q1.view(B), q2.view(B)
 
 
+def forward_two_pairs(pair_a, obs_a, act_a, slot_a, pair_b, obs_b, act_b, slot_b,
+                      need_grad_b=False):
+    """Both critic pairs of SAC's critic loss in ONE launch of four networks
+    (sac_agent.py:559-640: target critics on (next observation, next action), critics on
+    (observation, action)): the two forwards are independent, and four networks of 64 workgroups
+    fill the 256 CUs where a pair leaves half of them idle.  Returns ((qa1, qa2), (qb1, qb2));
+    bit-identical to two `forward_pair` calls (every network is computed by its own workgroups)."""
+    B = int(obs_a.shape[0])
+    oa, aa = obs_a.reshape(B, -1), act_a.reshape(B, -1)
+    ob, ab = obs_b.reshape(B, -1), act_b.reshape(B, -1)
+    outs = sequential.forward_wide(
+        [pair_a[0].body, pair_a[1].body, pair_b[0].body, pair_b[1].body], [oa, oa, ob, ob],
+        x2s=[aa, aa, ab, ab], slots=[slot_a, slot_a, slot_b, slot_b],
+        need_grads=[False, False, need_grad_b, need_grad_b])
+    return (outs[0].view(B), outs[1].view(B)), (outs[2].view(B), outs[3].view(B))
+
+
+def two_pairs_ok(pair_a, pair_b):
+    return pair_a[0].body.wide_key() == pair_b[0].body.wide_key()
+
+
 def backward_pair(c1, c2, dq1, dq2, slot=0, param_grads=True, want_action_grad=False):
     """`backward` of both critics of a `forward_pair`: the gradient chains in one launch, all
     weight gradients in a second one; returns (da1, da2) [B, act] views if asked."""

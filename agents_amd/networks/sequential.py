@@ -967,11 +967,14 @@ def _wide_group(nets, B):
     return nets[0].wide_layout()
 
 
-def forward_wide(nets, xs, slot=0, need_grad=False, x2s=None):
+def forward_wide(nets, xs, slot=0, need_grad=False, x2s=None, slots=None, need_grads=None):
     """`net.forward(x, slot, need_grad)` of up to four Sequential networks of the same layout in
     ONE launch.  xs[g]: float32 [B, d] with unit column stride (any row stride); with x2s the
     network input is [xs[g] | x2s[g]] -- a critic's (observation, action) -- read from the two
-    tensors in place.  Returns the networks' output buffers (owned by their slots)."""
+    tensors in place.  `slots` / `need_grads` (optional lists) give every network its own slot and
+    flag -- SAC's critic update evaluates the twin TARGET critics on (next observation, next
+    action) and the twin critics on (observation, action) in one launch of four networks.
+    Returns the networks' output buffers (owned by their slots)."""
     B = int(xs[0].shape[0])
     lay = _wide_group(nets, B)
     d = _lib.MlpWideFwd()
@@ -997,7 +1000,8 @@ def forward_wide(nets, xs, slot=0, need_grad=False, x2s=None):
             d.x_split = int(x.shape[1])
         elif d.x_split != int(x.shape[1]):
             raise ValueError("every network of a launch splits its input at the same column")
-        s = net._slot(slot, B, need_grad)
+        s = net._slot(slot if slots is None else slots[g], B,
+                      need_grad if need_grads is None else need_grads[g])
         s.wide_in = (x, x2)
         s.xs[0] = x
         for i in range(1, n):

@@ -453,11 +453,17 @@ class GraphedTrain:
             if self._whole and e.captured_b is not None:
                 # part (a) only reads what the collect step reads (the policy's weights) and the
                 # batch (waited for above); part (b) overwrites the policy: after the collect
-                # step that is using it, and after every draw (it also ends the iteration)
+                # step that is using it.  NOT after the draw issued in this iteration: that batch is
+                # consumed `prefetch` iterations from now behind its own `ready` event, and the
+                # draw reads nothing part (b) writes.  (Round 3 joined both lanes here: the GPU
+                # timeline of the SAC loop -- tools/bench_sac.py --timeline -- showed part (b)
+                # starting 28 us after part (a) had finished, waiting for a 9 us gather.)
                 _mark("train.begin")
                 e.captured.replay()
-                if lanes is not None:
-                    lanes.join()
+                _mark("train.part_a_done")
+                if lanes is not None and lanes.collect_done is not None:
+                    torch.cuda.current_stream(dev).wait_event(lanes.collect_done)
+                _mark("train.part_b_begin")
                 e.captured_b.replay()
                 _mark("train.apply_done")
             elif self._whole:

@@ -294,8 +294,17 @@ def kernel_breakdown(w, S, reps=20):
     from agents_amd.trajectories import policy_step
     act = torch.zeros((S,), dtype=torch.int64, device=obs_t.device)
     traj = trajectory.from_transition(items, policy_step.PolicyStep(act, (), ()), items)
-    out.append(("replay.get_next(sample+gather 512 rows)", timeit(lambda: rb.get_next(S, 2)), 1,
-                0.0, 512 * (2.0 * ROW_BYTES + 24)))
+    # what the loop's dataset runs: the stamped launch (last_id and the call number by value, the
+    # draw made by the host library: csrc/replay.hip aa_rb_gather_drawn_kernel).  Captured for the
+    # timing only -- the rows freeze, the bytes moved are the same.
+    if rb.supports_stamped_draws() and getattr(rb, "_dataset_ring", 1):
+        elem = rb.get_next(S, 2)
+        stamped = rb.stamped_slot(elem)
+        out.append(("replay.get_next(sample+gather 512 rows)",
+                    timeit(lambda: rb.draw_into(stamped)), 1, 0.0, 512 * (2.0 * ROW_BYTES + 24)))
+    else:
+        out.append(("replay.get_next(sample+gather 512 rows)", timeit(lambda: rb.get_next(S, 2)),
+                    1, 0.0, 512 * (2.0 * ROW_BYTES + 24)))
     out.append(("replay.add_batch(scatter 256 rows)", timeit(lambda: rb.add_batch(traj)), 1, 0.0,
                 256 * (2.0 * ROW_BYTES + 8)))
     out.append(("conv1.fwd(u8)", timeit(lambda: ops.conv_forward(

@@ -21,7 +21,7 @@ def run(var, val, steps):
     env = dict(os.environ)
     env[var] = val
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps),
-                          "--no-cpu-baseline", "--no-breakdown"], env=env, capture_output=True,
+                          "--no-cpu-baseline", "--no-breakdown", "--no-other-configs"], env=env, capture_output=True,
                          text=True)
     for line in reversed(out.stdout.strip().splitlines()):
         if line.startswith("{"):

@@ -131,6 +131,31 @@ def run(args):
     t_host = (time.perf_counter() - t0) / args.iters    # the host is done enqueueing here
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.iters
+    if getattr(args, "timeline", 0):
+        # GPU-side event timeline of the loop (timing events around the graph launches), us after
+        # the end of the previous iteration's train step: who waits for whom
+        graph.TIMELINE = []
+        for _ in range(args.timeline + 10):
+            step()
+        graph.join_lanes(dev)
+        torch.cuda.synchronize()
+        marks, graph.TIMELINE = graph.TIMELINE, None
+        iters, cur = [], None
+        for tag, ev in marks:
+            if tag == "collect.begin":
+                cur = {}
+                iters.append(cur)
+            if cur is not None:
+                cur[tag] = ev
+        rows = []
+        for a, b in zip(iters[8:-1], iters[9:]):
+            if "train.apply_done" in a and "train.apply_done" in b:
+                rows.append({k: a["train.apply_done"].elapsed_time(v) * 1e3 for k, v in b.items()})
+        keys = ["collect.begin", "collect.done", "sample.begin", "sample.done", "train.begin",
+                "train.part_a_done", "train.part_b_begin", "train.apply_done"]
+        print("[bench_sac] GPU timeline, us after the previous train step's end (mean of %d): " %
+              len(rows) + ", ".join(f"{k} {sum(r[k] for r in rows if k in r) / max(len(rows), 1):.0f}"
+                                    for k in keys), file=sys.stderr, flush=True)
     row = 4 + 376 * 4 + 17 * 4 + 4 + 4 + 4
     return ({
         "workload": "configs[4] at 1 GPU: SAC Humanoid-shaped, %d envs, batch %d, actor/critics "
@@ -149,6 +174,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--timeline", type=int, default=0,
+                    help="print a GPU-side event timeline averaged over this many iterations")
     print(json.dumps(run(ap.parse_args())))
 
 

@@ -86,10 +86,7 @@ int main() {
   hipMalloc(&st_, N_ST * 8);
   hipMemcpyToSymbol(HIP_SYMBOL(d_gd_stamps), &st_, sizeof(st_));
   // cfg numbering = force_cfg: 1 128x64, 2 128x32, 3 64x64, 4 128x128, 5 64x32, 6 32x64
-  for (int mode = 0; mode < 4; ++mode) {
-    g_aa_gemm_krot = mode & 1;
-    g_aa_gemm_pipe = (mode >> 1) & 1;
-    printf("==== k_rot %d  pipe %d\n", g_aa_gemm_krot, g_aa_gemm_pipe);
+  {
     run("fc1.fwd", 256, 512, 3136, AA_A_ROW, AA_B_ROW, false, 0, 0, true);
     run("fc1.fwd", 256, 512, 3136, AA_A_ROW, AA_B_ROW, false, 3, 8, true);
     run("fc1.fwd", 256, 512, 3136, AA_A_ROW, AA_B_ROW, false, 6, 4, true);
