@@ -82,40 +82,58 @@ aa_dense_small_fwd_slabs_kernel(const float* __restrict__ slab, int splits, int6
   float acc[N];
 #pragma unroll
   for (int n = 0; n < N; ++n) acc[n] = 0.f;
-  for (int k = 4 * lane; k < K; k += 256) {
-    const float* src = slab + (size_t)m * K + k;
-    // Everything this pass needs is requested before anything is used -- up to eight slabs, the
-    // hidden layer's bias, the four rows of the head's kernel: ONE round trip per pass.  (Slabs
-    // four at a time, then the bias, then the head's rows was four dependent round trips per
-    // pass, ~1 us each in a launch whose arithmetic is nothing.)  Unconditional loads from clamped
-    // addresses; the adds below keep the z order of aa_splitk_reduce_kernel<*,1>.
-    float4 t[8];
+  // Two 256-column passes per trip (K = 512: the whole row in ONE trip): everything both passes
+  // need -- up to eight slabs each, the hidden layer's bias, the four rows of the head's kernel --
+  // is requested before anything is used, so a row costs one memory round trip, not one per pass
+  // (round 3 had already merged the four dependent round trips INSIDE a pass).  Unconditional
+  // loads from clamped addresses; the adds keep the z order of aa_splitk_reduce_kernel<*,1> and
+  // the pass order of the one-pass loop: bit-identical results.
+  for (int k0 = 4 * lane; k0 < K; k0 += 512) {
+    float4 t[2][8], b1[2];
+    float wr[2][4 * N];
+    int kk[2];
+    bool on[2];
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      t[u] = *reinterpret_cast<const float4*>(src + (size_t)(u < splits ? u : splits - 1) * MK);
-    const float4 b1 = *reinterpret_cast<const float4*>(bias1 != nullptr ? bias1 + k : src);
-    const float* wk = w + (size_t)k * N;
-    float wr[4 * N];
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int k = k0 + 256 * h2;
+      on[h2] = k < K;
+      kk[h2] = on[h2] ? k : k0;
+      const float* src = slab + (size_t)m * K + kk[h2];
 #pragma unroll
-    for (int j = 0; j < 4 * N; ++j) wr[j] = wk[j];
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int u = 0; u < 8; ++u)
+        t[h2][u] =
+            *reinterpret_cast<const float4*>(src + (size_t)(u < splits ? u : splits - 1) * MK);
+      b1[h2] = *reinterpret_cast<const float4*>(bias1 != nullptr ? bias1 + kk[h2] : src);
+      const float* wk = w + (size_t)kk[h2] * N;
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (u < splits) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
-    for (int z = 8; z < splits; ++z) {
-      const float4 tz = *reinterpret_cast<const float4*>(src + (size_t)z * MK);
-      v.x += tz.x; v.y += tz.y; v.z += tz.z; v.w += tz.w;
+      for (int j = 0; j < 4 * N; ++j) wr[h2][j] = wk[j];
     }
-    if (bias1 != nullptr) { v.x += b1.x; v.y += b1.y; v.z += b1.z; v.w += b1.w; }
-    v.x = aa_sm_act(v.x, act1); v.y = aa_sm_act(v.y, act1);
-    v.z = aa_sm_act(v.z, act1); v.w = aa_sm_act(v.w, act1);
-    *reinterpret_cast<float4*>(h + m * ldh + k) = v;
 #pragma unroll
-    for (int n = 0; n < N; ++n) {
-      acc[n] = fmaf(v.x, wr[n], acc[n]);
-      acc[n] = fmaf(v.y, wr[N + n], acc[n]);
-      acc[n] = fmaf(v.z, wr[2 * N + n], acc[n]);
-      acc[n] = fmaf(v.w, wr[3 * N + n], acc[n]);
+    for (int h2 = 0; h2 < 2; ++h2) {
+      if (!on[h2]) continue;
+      const int k = kk[h2];
+      const float* src = slab + (size_t)m * K + k;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (u < splits) {
+          v.x += t[h2][u].x; v.y += t[h2][u].y; v.z += t[h2][u].z; v.w += t[h2][u].w;
+        }
+      for (int z = 8; z < splits; ++z) {
+        const float4 tz = *reinterpret_cast<const float4*>(src + (size_t)z * MK);
+        v.x += tz.x; v.y += tz.y; v.z += tz.z; v.w += tz.w;
+      }
+      if (bias1 != nullptr) { v.x += b1[h2].x; v.y += b1[h2].y; v.z += b1[h2].z; v.w += b1[h2].w; }
+      v.x = aa_sm_act(v.x, act1); v.y = aa_sm_act(v.y, act1);
+      v.z = aa_sm_act(v.z, act1); v.w = aa_sm_act(v.w, act1);
+      *reinterpret_cast<float4*>(h + m * ldh + k) = v;
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        acc[n] = fmaf(v.x, wr[h2][n], acc[n]);
+        acc[n] = fmaf(v.y, wr[h2][N + n], acc[n]);
+        acc[n] = fmaf(v.z, wr[h2][2 * N + n], acc[n]);
+        acc[n] = fmaf(v.w, wr[h2][3 * N + n], acc[n]);
+      }
     }
   }
 #pragma unroll

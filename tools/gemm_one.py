@@ -97,7 +97,12 @@ def main():
                 v.random_(0, 256)
         rb._last_id.fill_(255)
         rb._last_id_host = 255
-        fn = lambda: rb.get_next(S, 2)
+        if rb.supports_stamped_draws() and os.environ.get("AA_PMC_DEVICE_DRAW") != "1":
+            # what a graphed dataset runs: the stamped launch, rows drawn by the host library
+            stamped = rb.stamped_slot(rb.get_next(S, 2))
+            fn = lambda: rb.draw_into(stamped)
+        else:
+            fn = lambda: rb.get_next(S, 2)
     elif args.name == "replay.gather":
         # 512 random rows of the Atari trajectory table (28,248 B per row), 4096-row table
         from agents_amd.replay_buffers import table
