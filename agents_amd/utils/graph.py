@@ -122,6 +122,11 @@ class Lanes:
 
 
 _LANES = {}
+# Lanes objects of devices whose overlap was switched off: switched on again, a device gets ITS
+# streams back.  New streams land on other hardware queues (HIP deals streams to its 4 queues
+# round robin), and a sample lane that shares a queue with the training stream serialises the loop
+# (measured: 0.407 ms per iteration before an off / on cycle that created new streams, 0.492 after).
+_LANES_PARKED = {}
 
 
 def enable_overlap(device=None):
@@ -130,17 +135,27 @@ def enable_overlap(device=None):
         else torch.device(device)
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     if key not in _LANES:
-        _LANES[key] = Lanes(torch.device("cuda", key[1]))
+        lanes = _LANES_PARKED.pop(key, None)
+        if lanes is None:
+            lanes = Lanes(torch.device("cuda", key[1]))
+        else:
+            lanes.collect_done = lanes.sample_done = None
+            lanes.ready = {}
+        _LANES[key] = lanes
     return _LANES[key]
 
 
 def disable_overlap(device=None):
     join_lanes(device)
     if device is None:
+        _LANES_PARKED.update(_LANES)
         _LANES.clear()
     else:
         device = torch.device(device)
-        _LANES.pop((device.type, device.index), None)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        lanes = _LANES.pop((device.type, idx), None)
+        if lanes is not None:
+            _LANES_PARKED[(device.type, idx)] = lanes
 
 
 def lanes_for(device):

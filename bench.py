@@ -122,7 +122,7 @@ def compact_line(out):
     for k in ("env_steps_per_sec", "host_enqueue_ms_per_step",
               "prime_steps", "captures_in_timed_region", "final_loss", "step_algorithmic_gflop",
               "step_mfma_frac", "kernel_time_sum_ms", "steady_ms_per_step", "steady_steps",
-              "rccl_ranks", "dominant_device_kernel"):
+              "rccl_ranks", "dominant_device_kernel", "lanes", "lane_probe"):
         if k in out:
             line[k] = _r(out[k])
     if "roofline" in out:
@@ -468,7 +468,7 @@ def inloop_profile(args, trace_out=None, timeout=420):
            os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(steps), "--warmup", "10",
            "--max-length", str(args.max_length), "--batch", str(args.batch), "--envs",
            str(args.envs), "--prefill", str(args.prefill), "--no-cpu-baseline", "--no-inloop",
-           "--no-other-configs"] + (["--no-overlap"] if args.no_overlap else [])
+           "--no-other-configs", "--lanes", getattr(args, "lanes_decided", "on")]
     env = dict(os.environ, AA_BENCH_TRACE_CHILD="1", TMPDIR="/tmp")
     try:
         r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True,
@@ -720,8 +720,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="replay the collect / sample / train graphs on ONE stream (default: three "
-                         "streams ordered by events)")
+                    help="replay the collect / sample / train graphs on ONE stream (= --lanes off)")
+    ap.add_argument("--lanes", choices=["auto", "on", "off"], default="on",
+                    help="on (default) = collect / sample / train graphs on three HIP streams "
+                         "ordered by events; off = one stream; auto = time both for --lane-probe "
+                         "untimed iterations after priming and keep the faster one (measured on "
+                         "the pool's slow and fast boxes alike: three lanes win, 0.408 vs 0.447 "
+                         "and 0.352 vs 0.401 ms)")
+    ap.add_argument("--lane-probe", type=int, default=60)
     ap.add_argument("--prefill", type=int, default=-1, help="frames per env to prefill (-1 = all)")
     ap.add_argument("--host-profile", type=int, default=0,
                     help="cProfile this many extra steps after the timed region (stderr)")
@@ -808,10 +814,10 @@ def main():
     # train_eval.py:234-237: `collect_driver.run = common.function(collect_driver.run)`
     from agents_amd.utils import common, graph
     collect_run = common.function(drv.run)
-    if not args.no_overlap:
+    lanes_mode = "off" if args.no_overlap else args.lanes
+    if lanes_mode != "off":
         # collect / sample / train graphs on three HIP streams, ordered by events along the true
-        # data dependencies (agents_amd/utils/graph.py: Lanes).  Bit-identical results; 0.569 vs
-        # 0.584 ms per iteration on MI355X.
+        # data dependencies (agents_amd/utils/graph.py: Lanes).  Bit-identical results either way.
         graph.enable_overlap(dev)
     time_step = None
 
@@ -854,6 +860,41 @@ def main():
     if rank == 0:
         log(f"[bench] primed in {prime_steps} iterations / {t_prime:.2f}s "
             f"({seen} HIP-graph captures)")
+    # ---- lane mode (untimed): the same loop, bit-identical results, on three streams or on one.
+    # On most boxes of the pool three lanes win by ~10 %; on some the kernels of concurrent streams
+    # stretch each other so much (in-loop kernel time 667 us against 505 on the same tree) that
+    # one stream is as fast.  `--lanes auto` measures, like a library's autotuning warm-up.
+    lane_probe = None
+    if lanes_mode == "auto" and not TRACE_CHILD:
+        def timed(n):
+            for _ in range(10):
+                step()
+            graph.join_lanes(dev)
+            sync_all()
+            t_ = time.perf_counter()
+            for _ in range(n):
+                step()
+            graph.join_lanes(dev)
+            sync_all()
+            return (time.perf_counter() - t_) / n * 1e3
+        t_on = timed(args.lane_probe)
+        graph.disable_overlap(dev)
+        t_off = timed(args.lane_probe)
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([t_on, t_off], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)      # every rank takes the same decision
+            t_on, t_off = float(tt[0]), float(tt[1])
+        lanes_mode = "on" if t_on <= t_off else "off"
+        if lanes_mode == "on":
+            graph.enable_overlap(dev)
+        lane_probe = {"three_lanes_ms": t_on, "one_stream_ms": t_off, "steps_each": args.lane_probe}
+        if rank == 0:
+            log(f"[bench] lane probe: three lanes {t_on:.4f} ms, one stream {t_off:.4f} ms per "
+                f"iteration -> lanes {lanes_mode}")
+    elif lanes_mode == "auto":
+        lanes_mode = "on"
+    args.lanes_decided = lanes_mode
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -977,7 +1018,7 @@ def main():
         "learner_steps_per_sec": steps_per_sec,
         "env_steps_per_sec": steps_per_sec * args.envs * world,
         "replay_rows_gathered_per_sec": steps_per_sec * S * 2 * world,
-        "final_loss": loss_val, "rccl_ranks": world,
+        "final_loss": loss_val, "rccl_ranks": world, "lanes": lanes_mode,
         "config": {"workload": "configs[1]: DQN Atari Pong-shaped (84x84x4 uint8 stack), replay "
                                f"{args.envs}x{args.max_length} rows/GPU, batch={S}, num_steps=2, "
                                "Mnih-15 Q-net, Huber, centred RMSProp, 1 collect step (256 envs) "
@@ -986,6 +1027,8 @@ def main():
                    "replay_rows_per_gpu": args.envs * args.max_length,
                    "parallelism": f"dp{world}" if world > 1 else "single"},
     }
+    if lane_probe is not None:
+        out["lane_probe"] = lane_probe
     if steady is not None:
         if world > 1:
             import torch.distributed as dist
