@@ -156,6 +156,10 @@ _SIGNATURES = {
     "aa_conv_dw_frame_x6_workspace_bytes": (c_int64, [POINTER(ConvDxDesc)]),
     "aa_conv_dw_frame_x6": (c_int, [POINTER(ConvDxDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int64, c_void_p]),
+    "aa_conv_dw_frame_x6_slabs": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int64,
+                                          c_void_p]),
+    "aa_conv_dw_frame_x6_reduce": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p]),
     "aa_dense_small_forward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64,
                                        c_int32, c_int32, c_void_p, c_void_p]),
     "aa_dense_small_forward_slabs": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int32,
@@ -313,7 +317,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 11:
+    if lib.aa_abi_version() != 12:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

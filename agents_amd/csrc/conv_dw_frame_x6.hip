@@ -384,18 +384,18 @@ int64_t aa_conv_dw_frame_x6_workspace_bytes(const aa_conv_dx_desc* d) {
   return dw6_plan(d, &pl) == AA_OK ? (int64_t)pl.ws : 0;
 }
 
-int aa_conv_dw_frame_x6(const aa_conv_dx_desc* d, const float* x, float* dw, float* db,
-                        void* workspace, int64_t workspace_bytes, void* stream) {
+// Main launch only: the per-group slabs (+ the bias-gradient rows when want_db) are left in
+// `workspace` for aa_conv_dw_frame_x6_reduce.
+static int dw6_main(const aa_conv_dx_desc* d, const float* x, int want_db, void* workspace,
+                    int64_t workspace_bytes, void* stream, Dw6Plan* pl_out) {
   Dw6Plan pl;
   const int rc = dw6_plan(d, &pl);
   if (rc != AA_OK) return rc;
-  if (x == nullptr || d->dz == nullptr || dw == nullptr || workspace == nullptr)
-    return AA_ERR_INVALID;
-  if ((((uintptr_t)x | (uintptr_t)d->dz | (uintptr_t)workspace | (uintptr_t)dw) & 15) != 0)
-    return AA_ERR_INVALID;
+  if (x == nullptr || d->dz == nullptr || workspace == nullptr) return AA_ERR_INVALID;
+  if ((((uintptr_t)x | (uintptr_t)d->dz | (uintptr_t)workspace) & 15) != 0) return AA_ERR_INVALID;
   if ((int64_t)pl.ws > workspace_bytes) return AA_ERR_RANGE;
   Dw6P& P = pl.P;
-  P.x = x; P.dz = d->dz; P.slab = (float*)workspace; P.want_db = db != nullptr;
+  P.x = x; P.dz = d->dz; P.slab = (float*)workspace; P.want_db = want_db;
 #ifdef AA_DW6_DEBUG
   P.dbg = g_dw6_dbg;
 #endif
@@ -422,22 +422,73 @@ int aa_conv_dw_frame_x6(const aa_conv_dx_desc* d, const float* x, float* dw, flo
 #undef AA_DW6_CASE
   if (!done) return AA_ERR_RANGE;
   if (aa_launch_status() != AA_OK) return AA_ERR_LAUNCH;
-  // deterministic sum of the per-group slabs (+ the bias-gradient rows that follow them)
-  const int M = d->KH * d->KW * d->Cin, N = d->Cout;
-  const size_t work = ((size_t)M * N + (db != nullptr ? N : 0)) / 4;
-  const bool deep = P.groups >= 32 && work <= 65536;
-  const int ipb = deep ? 16 : 256;
-  int blocks = (int)((work + ipb - 1) / ipb);
-  if (blocks > 2048) blocks = 2048;
-  if (deep)
-    hipLaunchKernelGGL((aa_splitk_reduce_kernel<4, 16>), dim3(blocks), dim3(256), 0, st,
-                       (const float*)P.slab, P.groups, M, N, dw, N, (const float*)nullptr, 0,
-                       (const float*)nullptr, 0, 0, db);
+  if (pl_out != nullptr) *pl_out = pl;
+  return AA_OK;
+}
+
+int aa_conv_dw_frame_x6_slabs(const aa_conv_dx_desc* d, const float* x, int32_t want_db,
+                              void* workspace, int64_t workspace_bytes, void* stream) {
+  return dw6_main(d, x, want_db, workspace, workspace_bytes, stream, nullptr);
+}
+
+// Deterministic sum of the per-group slabs (+ the bias-gradient rows that follow them) of up to
+// four layers in ONE launch; layer l: slabs in workspaces[l] (as left by aa_conv_dw_frame_x6_slabs
+// for descs[l]), result in dws[l] / dbs[l] (nullable).  Bit-identical to one reduce launch each.
+int aa_conv_dw_frame_x6_reduce(int32_t n_layers, const aa_conv_dx_desc* const* descs,
+                               const void* const* workspaces, float* const* dws,
+                               float* const* dbs, void* stream) {
+  if (n_layers < 1 || n_layers > AA_REDUCE_MAX_SEGS || !descs || !workspaces || !dws || !dbs)
+    return AA_ERR_INVALID;
+  AaReduceSegs g;
+  g.n = n_layers;
+  int blocks_total = 0;
+  bool deep_all = true;
+  for (int l = 0; l < n_layers; ++l) {
+    Dw6Plan pl;
+    const int rc = dw6_plan(descs[l], &pl);
+    if (rc != AA_OK) return rc;
+    if (workspaces[l] == nullptr || dws[l] == nullptr) return AA_ERR_INVALID;
+    if ((((uintptr_t)workspaces[l] | (uintptr_t)dws[l]) & 15) != 0) return AA_ERR_INVALID;
+    const int M = descs[l]->KH * descs[l]->KW * descs[l]->Cin, N = descs[l]->Cout;
+    const size_t work = ((size_t)M * N + (dbs[l] != nullptr ? N : 0)) / 4;
+    const bool deep = pl.P.groups >= 32 && work <= 65536;
+    deep_all = deep_all && deep;
+    g.slab[l] = (const float*)workspaces[l];
+    g.splits[l] = pl.P.groups; g.M[l] = M; g.N[l] = N;
+    g.C[l] = dws[l]; g.colsum[l] = dbs[l];
+    g.first[l] = blocks_total;
+    // (block counts of aa_conv_dw_frame_x6's own reduce launch: same grid-stride walk per segment)
+    int blocks = (int)((work + (deep ? 16 : 256) - 1) / (deep ? 16 : 256));
+    if (blocks > 2048) blocks = 2048;
+    blocks_total += blocks;
+    g.first[l + 1] = blocks_total;
+  }
+  // the z-lane count is a template parameter: mixed "deep" / flat layers take one launch each
+  if (n_layers > 1 && !deep_all) {
+    for (int l = 0; l < n_layers; ++l) {
+      const int rc = aa_conv_dw_frame_x6_reduce(1, descs + l, workspaces + l, dws + l, dbs + l,
+                                                stream);
+      if (rc != AA_OK) return rc;
+    }
+    return AA_OK;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (deep_all)
+    hipLaunchKernelGGL((aa_splitk_reduce_multi_kernel<4, 16>), dim3(blocks_total), dim3(256), 0,
+                       st, g);
   else
-    hipLaunchKernelGGL((aa_splitk_reduce_kernel<4, 1>), dim3(blocks), dim3(256), 0, st,
-                       (const float*)P.slab, P.groups, M, N, dw, N, (const float*)nullptr, 0,
-                       (const float*)nullptr, 0, 0, db);
+    hipLaunchKernelGGL((aa_splitk_reduce_multi_kernel<4, 1>), dim3(blocks_total), dim3(256), 0,
+                       st, g);
   return aa_launch_status();
+}
+
+int aa_conv_dw_frame_x6(const aa_conv_dx_desc* d, const float* x, float* dw, float* db,
+                        void* workspace, int64_t workspace_bytes, void* stream) {
+  if (dw == nullptr || (((uintptr_t)dw) & 15) != 0) return AA_ERR_INVALID;
+  int rc = dw6_main(d, x, db != nullptr, workspace, workspace_bytes, stream, nullptr);
+  if (rc != AA_OK) return rc;
+  const void* ws = workspace;
+  return aa_conv_dw_frame_x6_reduce(1, &d, &ws, &dw, &db, stream);
 }
 
 }  // extern "C"

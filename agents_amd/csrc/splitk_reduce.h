@@ -27,18 +27,18 @@ __device__ static inline float aa_actgrad(float y, int kind) {
 // Elements [M*N, M*N + N) of the index space are the fused bias-gradient rows that follow the
 // slabs: colsum_out[n] = sum_z slab_end[z][n].
 template <int VEC, int ZL>
-__global__ void __launch_bounds__(256)
-aa_splitk_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N,
-                        float* __restrict__ C, int ldc, const float* __restrict__ bias, int act,
-                        const float* __restrict__ mask_src, int ldm, int mask_kind,
-                        float* __restrict__ colsum_out) {
+__device__ static inline void
+aa_splitk_reduce_body(const float* __restrict__ slab, int splits, int M, int N,
+                      float* __restrict__ C, int ldc, const float* __restrict__ bias, int act,
+                      const float* __restrict__ mask_src, int ldm, int mask_kind,
+                      float* __restrict__ colsum_out, unsigned block, unsigned n_blocks) {
   constexpr int IPB = 256 / ZL;
   __shared__ float part[ZL][IPB][VEC];
   const size_t MN = (size_t)M * N;
   const size_t total = (MN + (colsum_out != nullptr ? (size_t)N : 0)) / VEC;
   const float* cs_rows = slab + (size_t)splits * MN;
   const int it = threadIdx.x % IPB, zl = threadIdx.x / IPB;
-  for (size_t q0 = (size_t)blockIdx.x * IPB; q0 < total; q0 += (size_t)gridDim.x * IPB) {
+  for (size_t q0 = (size_t)block * IPB; q0 < total; q0 += (size_t)n_blocks * IPB) {
     const size_t q = q0 + it;
     const bool live = q < total;
     const size_t i = q * VEC;
@@ -111,3 +111,45 @@ aa_splitk_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N
   }
 }
 
+
+template <int VEC, int ZL>
+__global__ void __launch_bounds__(256)
+aa_splitk_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N,
+                        float* __restrict__ C, int ldc, const float* __restrict__ bias, int act,
+                        const float* __restrict__ mask_src, int ldm, int mask_kind,
+                        float* __restrict__ colsum_out) {
+  aa_splitk_reduce_body<VEC, ZL>(slab, splits, M, N, C, ldc, bias, act, mask_src, ldm, mask_kind,
+                                 colsum_out, blockIdx.x, gridDim.x);
+}
+
+// Several independent slab sets in ONE launch (the conv weight gradients of consecutive layers:
+// their reduces used to be a launch each on the backward pass's side stream).  Segment s owns the
+// blocks [first[s], first[s + 1]); inside a segment the arithmetic is aa_splitk_reduce_body's:
+// bit-identical to one launch per segment.
+#define AA_REDUCE_MAX_SEGS 4
+struct AaReduceSegs {
+  int n;
+  int first[AA_REDUCE_MAX_SEGS + 1];
+  const float* slab[AA_REDUCE_MAX_SEGS];
+  int splits[AA_REDUCE_MAX_SEGS], M[AA_REDUCE_MAX_SEGS], N[AA_REDUCE_MAX_SEGS];
+  float* C[AA_REDUCE_MAX_SEGS];
+  float* colsum[AA_REDUCE_MAX_SEGS];
+};
+template <int VEC, int ZL>
+__global__ void __launch_bounds__(256) aa_splitk_reduce_multi_kernel(AaReduceSegs g) {
+  int s = 0;
+#pragma unroll
+  for (int k = 1; k < AA_REDUCE_MAX_SEGS; ++k)
+    if (k < g.n && (int)blockIdx.x >= g.first[k]) s = k;
+  // (uniform per workgroup: scalar selects of the segment's descriptor)
+  const float* slab = g.slab[0]; int splits = g.splits[0], M = g.M[0], N = g.N[0];
+  float* C = g.C[0]; float* cs = g.colsum[0]; int b0 = g.first[0], b1 = g.first[1];
+#pragma unroll
+  for (int k = 1; k < AA_REDUCE_MAX_SEGS; ++k)
+    if (s == k) {
+      slab = g.slab[k]; splits = g.splits[k]; M = g.M[k]; N = g.N[k];
+      C = g.C[k]; cs = g.colsum[k]; b0 = g.first[k]; b1 = g.first[k + 1];
+    }
+  aa_splitk_reduce_body<VEC, ZL>(slab, splits, M, N, C, N, nullptr, 0, nullptr, 0, 0, cs,
+                                 blockIdx.x - (unsigned)b0, (unsigned)(b1 - b0));
+}

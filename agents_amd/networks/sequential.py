@@ -862,6 +862,10 @@ class Sequential(network.Network):
             with ops.side_line(side_stream):
                 return fn()
 
+        # conv weight gradients on the side stream leave their slabs unsummed; ONE launch sums them
+        # for all layers after the last of them has been enqueued (ops.PendingDwReduce)
+        pending_dw = ops.PendingDwReduce() if side_stream is not main else None
+
         for i in range(hi, lo - 1, -1):
             l = self._param_layers[i]
             ks = self._shapes[i][0]
@@ -925,9 +929,11 @@ class Sequential(network.Network):
                                 prepared=prepared)
                     dz_next = s.dxs[i]
                 if param_grads:
+                    on_main = i == 0 and LAST_DW_ON_MAIN
                     dw = lambda: ops.conv_dw(x, dz2, ks, l.stride, self._gkviews[i],
                                              a_div=self._first_div() if i == 0 else 1.0,
-                                             bias_grad=self._gbviews[i])
+                                             bias_grad=self._gbviews[i],
+                                             defer=None if on_main else pending_dw)
                     if i == 0 and LAST_DW_ON_MAIN:
                         # layer 0 has no input gradient: main has nothing left to do, while the
                         # side stream is still finishing layer 1's weight gradient (timeline:
@@ -939,6 +945,8 @@ class Sequential(network.Network):
                     dz = dz_next
         if dx_prep_pending:
             main.wait_stream(self._prep_stream)
+        if pending_dw is not None and pending_dw.items:
+            on_side(lambda: ops.conv_dw_flush(pending_dw), fork=False)
         if side_stream is not main:
             main.wait_stream(side_stream)
 

@@ -462,12 +462,43 @@ def conv_pair_forward(x, w1, b1, s1, act1, y1, w2, b2, s2, act2, y2, prepared=No
 # AA_CONV_DW_X6=0: keep the conv weight gradients of fp32 layers on the fp32 MFMA GEMM (A/B)
 CONV_DW_X6 = _os.environ.get("AA_CONV_DW_X6", "1") != "0"
 _DW_X6_WS = {}
+# slabs of weight gradients whose reduce is deferred (one buffer per pending layer and line)
+_WS_DW_DEFER = [_Workspace() for _ in range(4)]
+# AA_CONV_DW_MERGE_REDUCE=0: every conv weight gradient sums its own slabs (A/B measurements)
+CONV_DW_MERGE_REDUCE = _os.environ.get("AA_CONV_DW_MERGE_REDUCE", "1") != "0"
+
+
+class PendingDwReduce:
+    """Conv weight gradients whose per-frame-group slabs are written but not summed yet
+    (`conv_dw(..., defer=pending)`); `conv_dw_flush(pending)` sums them all in ONE launch
+    (csrc/splitk_reduce.h: aa_splitk_reduce_multi_kernel) -- the backward pass of a conv stack
+    used to pay one reduce launch per layer on its side stream."""
+
+    def __init__(self):
+        self.items = []      # (desc, slabs, out, bias_grad)
+
+
+def conv_dw_flush(pending):
+    items, pending.items = pending.items, []
+    if not items:
+        return
+    n = len(items)
+    descs = (ctypes.c_void_p * n)(*[ctypes.addressof(it[0]) for it in items])
+    wss = (ctypes.c_void_p * n)(*[ptr(it[1]) for it in items])
+    dws = (ctypes.c_void_p * n)(*[ptr(it[2]) for it in items])
+    dbs = (ctypes.c_void_p * n)(*[_bias_grad_ptr(it[3], it[0].Cout) for it in items])
+    with torch.cuda.device(items[0][2].device):
+        check(_lib.load().aa_conv_dw_frame_x6_reduce(
+            n, ctypes.cast(descs, ctypes.c_void_p), ctypes.cast(wss, ctypes.c_void_p),
+            ctypes.cast(dws, ctypes.c_void_p), ctypes.cast(dbs, ctypes.c_void_p), stream_ptr()),
+            "aa_conv_dw_frame_x6_reduce")
 
 
 def conv_dw(x, dz, w_shape, stride, out, a_div=255.0, force_cfg=0, force_splits=0,
-            bias_grad=None):
+            bias_grad=None, defer=None):
     """out[KH,KW,Cin,Cout] = patches(x)^T @ dz[B*OH*OW, Cout]; bias_grad[Cout] = column sums of
-    dz (fused, optional)."""
+    dz (fused, optional).  defer: a PendingDwReduce -- when the per-frame kernel takes the layer,
+    only its slabs are written and `conv_dw_flush(defer)` finishes `out` / `bias_grad` later."""
     require_cuda(x, dz, out)
     KH, KW, Cin, Cout = w_shape
     Bn, H, W, C = x.shape
@@ -490,6 +521,14 @@ def conv_dw(x, dz, w_shape, stride, out, a_div=255.0, force_cfg=0, force_splits=
         if ws_bytes > 0:
             # per-frame kernel on the bf16 matrix cores at fp32 accuracy (csrc/conv_dw_frame_x6.hip);
             # its slabs live in the calling line's scratch like the GEMM's
+            if defer is not None and CONV_DW_MERGE_REDUCE and len(defer.items) < 4:
+                ws = _WS_DW_DEFER[len(defer.items)].get(ws_bytes, x.device)
+                with torch.cuda.device(x.device):
+                    check(_lib.load().aa_conv_dw_frame_x6_slabs(
+                        ctypes.byref(dd), ptr(x), 1 if bias_grad is not None else 0, ptr(ws),
+                        ws.numel(), stream_ptr()), "aa_conv_dw_frame_x6_slabs")
+                defer.items.append((dd, ws, out, bias_grad))
+                return out
             ws = _WS.get(ws_bytes, x.device)
             with torch.cuda.device(x.device):
                 check(_lib.load().aa_conv_dw_frame_x6(

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 11
+#define AA_ABI_VERSION 12
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -333,6 +333,16 @@ int aa_conv_dx_frame_x6_phase(const aa_conv_dx_desc* d, void* workspace, int64_t
 int64_t aa_conv_dw_frame_x6_workspace_bytes(const aa_conv_dx_desc* d);
 int aa_conv_dw_frame_x6(const aa_conv_dx_desc* d, const float* x, float* dw, float* db,
                         void* workspace, int64_t workspace_bytes, void* stream);
+/* The same in two calls, so that the slab sums of consecutive layers share ONE launch: `_slabs`
+ * runs the per-frame kernel and leaves the per-group slabs (+ bias-gradient rows when want_db) in
+ * `workspace`; `_reduce` sums the slabs of up to four layers (descs[l], workspaces[l]) into
+ * dws[l] / dbs[l] (dbs[l] nullable) in fixed order.  Bit-identical to aa_conv_dw_frame_x6 per
+ * layer.  (tf.GradientTape through keras Conv2D, agents/dqn/dqn_agent.py:412-426.) */
+int aa_conv_dw_frame_x6_slabs(const aa_conv_dx_desc* d, const float* x, int32_t want_db,
+                              void* workspace, int64_t workspace_bytes, void* stream);
+int aa_conv_dw_frame_x6_reduce(int32_t n_layers, const aa_conv_dx_desc* const* descs,
+                               const void* const* workspaces, float* const* dws,
+                               float* const* dbs, void* stream);
 
 /* out[n] = sum_m x[m*ld + n]  (bias gradients).  workspace >= aa_colsum_workspace_bytes. */
 int64_t aa_colsum_workspace_bytes(int64_t M, int64_t N);

@@ -84,7 +84,7 @@ def test_struct_layouts_match_the_header(tmp_path):
 
 
 def test_abi_version(lib):
-    assert lib.aa_abi_version() == 11
+    assert lib.aa_abi_version() == 12
 
 
 def test_argument_validation_without_gpu(lib):
