@@ -224,6 +224,8 @@ _SIGNATURES = {
     "aa_adam_step_counted": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
                                      c_float, c_float, c_float, c_void_p, c_void_p,
                                      POINTER(PlaneScatter), c_void_p]),
+    "aa_adam_step_counted_target": (c_int, [c_void_p] * 4 + [c_int64] + [c_float] * 4 +
+                                    [c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "aa_rmsprop_step_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                        c_float, c_float, c_float, c_float, POINTER(PlaneScatter),
                                        c_void_p]),

@@ -44,6 +44,8 @@ std_clip_transform = adn.std_clip_transform
 
 # A/B knob: AA_SAC_QUAD_FORWARD=0 evaluates the target pair and the critic pair in two launches
 _QUAD_FORWARD = os.environ.get("AA_SAC_QUAD_FORWARD", "1") != "0"
+# A/B knob: AA_SAC_FUSE_TARGET_UPDATE=0 keeps the soft target update a launch of its own
+_FUSE_TARGET_UPDATE = os.environ.get("AA_SAC_FUSE_TARGET_UPDATE", "1") != "0"
 
 
 def _spec_means_and_magnitudes(spec):
@@ -511,12 +513,23 @@ class SacAgent(tf_agent.TFAgent):
             self._alpha_loss_weight = weight
 
     # ---- train ----------------------------------------------------------------------------------
-    def _apply(self, optimizer, params, grads, net_for_clip=None):
+    def _apply(self, optimizer, params, grads, net_for_clip=None, soft_target=None):
         if self._gradient_clipping is not None:
             self._clip(params, grads, net_for_clip)
         if self.gradient_hook is not None:
             self.gradient_hook(grads)
-        optimizer.apply_flat(params, grads)
+        if soft_target is not None:
+            optimizer.apply_flat(params, grads, soft_target=soft_target)
+        else:
+            optimizer.apply_flat(params, grads)
+
+    def _fuse_target_update(self):
+        """The soft update of the target critics rides in the critic optimizer's launch when it
+        happens every step (sac_agent.py:385-410 with target_update_period == 1): the critics do not
+        change between their Adam step and the end of the train step, so updating the targets right
+        behind it is the same computation, one launch earlier and one launch less."""
+        return (_FUSE_TARGET_UPDATE and self._target_update_period == 1 and
+                getattr(self._critic_optimizer, "supports_soft_target", False))
 
     def _clip(self, params, grads, nets):
         """Per-variable tf.clip_by_norm (eager_utils.clip_gradient_norms, eager_utils.py:227-246)."""
@@ -561,7 +574,9 @@ class SacAgent(tf_agent.TFAgent):
             closs = self._critic_phase(obs, actions, next_obs, reward, discount, wts, True,
                                        eps_next=eps.get("next"))
             self._apply(self._critic_optimizer, self._critic_params, self._critic_grads,
-                        [self._critic_network_1.body, self._critic_network_2.body])
+                        [self._critic_network_1.body, self._critic_network_2.body],
+                        soft_target=(self._target_params, self._target_update_tau)
+                        if self._fuse_target_update() else None)
         self._part_a = (obs, wts, closs, eps)
 
     def _train_part_b(self):
@@ -592,7 +607,8 @@ class SacAgent(tf_agent.TFAgent):
                                                             alpha_loss=packed[3]))
             # counter + (periodic) soft target update: device work of the update is enqueued here
             graph.on_replay(self._bump_counter)
-            self._update_target()
+            if not self._fuse_target_update():
+                self._update_target()
         return info
 
     def _bump_counter(self):

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(AA_EW_THREADS)
 aa_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps,
                int64_t* __restrict__ step_dev, int64_t* __restrict__ arrival,
-               aa_plane_scatter S) {
+               aa_plane_scatter S, float* __restrict__ target, float tau) {
   __shared__ float s_alpha;
   if (threadIdx.x == 0) {
     const float t = (float)(*step_dev + (arrival != nullptr ? 1 : 0));
@@ -93,6 +93,17 @@ aa_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __rest
     reinterpret_cast<float4*>(p)[i] = pp;
     reinterpret_cast<float4*>(m)[i] = mm;
     reinterpret_cast<float4*>(v)[i] = vv;
+    if (target != nullptr) {
+      // soft_variables_update of the target copy from the parameters just written
+      // (aa_soft_update_kernel's expression), in the same pass
+      const float omt = 1.0f - tau;
+      float4 a = reinterpret_cast<float4*>(target)[i];
+      a.x = omt * a.x + tau * pp.x;
+      a.y = omt * a.y + tau * pp.y;
+      a.z = omt * a.z + tau * pp.z;
+      a.w = omt * a.w + tau * pp.w;
+      reinterpret_cast<float4*>(target)[i] = a;
+    }
     if (PLANES && aa_planes_touch(S, 4 * i, 4 * i + 4)) {
       aa_planes_put(S, 4 * i, pp.x); aa_planes_put(S, 4 * i + 1, pp.y);
       aa_planes_put(S, 4 * i + 2, pp.z); aa_planes_put(S, 4 * i + 3, pp.w);
@@ -101,6 +112,7 @@ aa_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __rest
   for (int64_t i = nv * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float pn = adam_elem(p[i], g[i], m[i], v[i], alpha, omb1, omb2, eps);
     if (PLANES) aa_planes_put(S, i, pn);
+    if (target != nullptr) target[i] = (1.0f - tau) * target[i] + tau * pn;
   }
   if (arrival != nullptr) aa_advance_when_all_done(step_dev, arrival, 1, gridDim.x);
 }
@@ -236,18 +248,19 @@ static int aa_planes_check(const aa_plane_scatter* S, int64_t n) {
 
 static int aa_adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr,
                           float beta1, float beta2, float eps, int64_t* step_dev, int64_t* arrival,
-                          const aa_plane_scatter* planes, void* stream) {
+                          const aa_plane_scatter* planes, void* stream, float* target = nullptr,
+                          float tau = 0.f) {
   if (!p || !g || !m || !v || !step_dev || n <= 0) return AA_ERR_INVALID;
-  if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0)
+  if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)target) & 15) != 0)
     return AA_ERR_INVALID;
   if (aa_planes_check(planes, n) != AA_OK) return AA_ERR_INVALID;
   const dim3 grid(aa_ew_blocks(n / 4)), block(AA_EW_THREADS);
   if (planes != nullptr && planes->n > 0)
     hipLaunchKernelGGL(aa_adam_kernel<true>, grid, block, 0, (hipStream_t)stream, p, g, m, v, n,
-                       lr, beta1, beta2, eps, step_dev, arrival, *planes);
+                       lr, beta1, beta2, eps, step_dev, arrival, *planes, target, tau);
   else
     hipLaunchKernelGGL(aa_adam_kernel<false>, grid, block, 0, (hipStream_t)stream, p, g, m, v, n,
-                       lr, beta1, beta2, eps, step_dev, arrival, aa_plane_scatter{});
+                       lr, beta1, beta2, eps, step_dev, arrival, aa_plane_scatter{}, target, tau);
   return aa_launch_status();
 }
 
@@ -264,6 +277,14 @@ int aa_adam_step_counted(float* p, const float* g, float* m, float* v, int64_t n
   if (arrival_dev == nullptr) return AA_ERR_INVALID;
   return aa_adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, steps_taken_dev, arrival_dev, planes,
                         stream);
+}
+
+int aa_adam_step_counted_target(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                                float beta1, float beta2, float eps, int64_t* steps_taken_dev,
+                                int64_t* arrival_dev, float* target, float tau, void* stream) {
+  if (arrival_dev == nullptr || target == nullptr) return AA_ERR_INVALID;
+  return aa_adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, steps_taken_dev, arrival_dev,
+                        nullptr, stream, target, tau);
 }
 
 int aa_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,

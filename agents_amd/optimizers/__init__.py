@@ -89,7 +89,11 @@ class Adam(Optimizer):
 
     supports_planes = True
 
-    def apply_flat(self, params, grads, planes=None):
+    supports_soft_target = True
+
+    def apply_flat(self, params, grads, planes=None, soft_target=None):
+        """soft_target = (target_flat, tau): the same launch also moves `target_flat` towards the
+        updated parameters (soft_variables_update; SAC's target critics)."""
         import ctypes
         lib = _lib.load()
         _lib.require_cuda(params, grads)
@@ -99,6 +103,20 @@ class Adam(Optimizer):
         if arrive is None:      # scratch of the in-launch step counter (not optimizer state)
             arrive = self._arrive[key] = torch.zeros((16,), dtype=torch.int64,
                                                      device=params.device)
+        if soft_target is not None:
+            if planes is not None:
+                raise ValueError("soft_target and planes are not combined")
+            target, tau = soft_target
+            _lib.require_cuda(target)
+            if target.numel() != params.numel() or target.dtype != torch.float32:
+                raise ValueError("soft_target must mirror the parameter buffer")
+            _lib.check(lib.aa_adam_step_counted_target(
+                params.data_ptr(), grads.data_ptr(), s["m"].data_ptr(), s["v"].data_ptr(),
+                params.numel(), self.learning_rate, self.beta_1, self.beta_2, self.epsilon,
+                s["step"].data_ptr(), arrive.data_ptr(), target.data_ptr(), float(tau),
+                _lib.stream_ptr()), "aa_adam_step_counted_target")
+            graph.on_replay(self._bump_iterations)
+            return
         # s["step"] = steps applied so far; the launch uses t = step + 1 and stores it back itself
         _lib.check(lib.aa_adam_step_counted(
             params.data_ptr(), grads.data_ptr(), s["m"].data_ptr(), s["v"].data_ptr(),

@@ -450,6 +450,13 @@ int aa_adam_step_counted(float* p, const float* g, float* m, float* v, int64_t n
                          float beta1, float beta2, float eps, int64_t* steps_taken_dev,
                          int64_t* arrival_dev, const aa_plane_scatter* planes /* nullable */,
                          void* stream);
+/* aa_adam_step_counted followed, in the same pass, by target = (1 - tau) * target + tau * p_new
+ * (soft_variables_update, utils/common.py:250-346): SAC's critic update and the soft update of
+ * its target critics when target_update_period == 1 (agents/sac/sac_agent.py:286-330, 385-410);
+ * same arithmetic as aa_adam_step_counted + aa_soft_update. */
+int aa_adam_step_counted_target(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                                float beta1, float beta2, float eps, int64_t* steps_taken_dev,
+                                int64_t* arrival_dev, float* target, float tau, void* stream);
 int aa_rmsprop_step_planes(float* p, const float* g, float* ms, float* mg, float* mom, int64_t n,
                            float lr, float rho, float momentum, float eps,
                            const aa_plane_scatter* planes /* nullable */, void* stream);
