@@ -38,3 +38,22 @@ def u01(bits):
     """Top 24 bits * 2^-24, as float32 (agents_amd/csrc/common.h::aa_u01)."""
     return ((np.asarray(bits, dtype=np.uint32) >> np.uint32(8)).astype(np.float32) *
             np.float32(1.0 / 16777216.0))
+
+
+def uniform_bounded(lo, hi, n_rows, seed, call):
+    """RandomTFPolicy on a bounded continuous spec as csrc/ppo.hip::aa_uniform_sample_kernel draws
+    it: out[i, d] = lo[d] + (hi[d] - lo[d]) * u01(word 0 of Philox(counter = (element index,
+    call), key = seed)) in float32, folded back to lo when rounding reaches hi.  (The reference
+    samples with an unseeded tf.random.uniform -- specs/tensor_spec.py:235-312 -- the stream is
+    ours, the range is the spec's.)"""
+    lo = np.asarray(lo, np.float32).reshape(-1)
+    hi = np.asarray(hi, np.float32).reshape(-1)
+    D = lo.size
+    i = np.arange(n_rows * D, dtype=np.uint64)
+    r0, _, _, _ = philox4x32_10(i & MASK, i >> np.uint64(32), int(call) & 0xFFFFFFFF,
+                                (int(call) >> 32) & 0xFFFFFFFF, int(seed) & 0xFFFFFFFF,
+                                (int(seed) >> 32) & 0xFFFFFFFF)
+    d = (np.arange(n_rows * D) % D)
+    l, h = lo[d], hi[d]
+    v = (l + ((h - l).astype(np.float32) * u01(r0)).astype(np.float32)).astype(np.float32)
+    return np.where(v < h, v, l).reshape(n_rows, D)
