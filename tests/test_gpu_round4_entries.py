@@ -10,7 +10,6 @@
   critic_network.forward_two_pairs     == two forward_pair launches, bit for bit
                                        (sac_agent.py:559-640)
 """
-import ctypes
 
 import numpy as np
 import pytest
