@@ -169,6 +169,27 @@ __global__ void __launch_bounds__(AA_DX6_THREADS) aa_conv_dx_frame_x6_kernel(Dx6
         big[rt] = cx_f32x4{0.f, 0.f, 0.f, 0.f};
         small[rt] = cx_f32x4{0.f, 0.f, 0.f, 0.f};
       }
+      // The activation-derivative mask of this task's outputs (the layer's forward input at the
+      // same positions) is requested HERE, in front of the k loop: it used to be the first
+      // dependent access of the task's epilogue -- one exposed memory round trip per task, two
+      // tasks per wave and frame on conv2.  Unconditional loads from clamped in-range positions
+      // (of the dZ tensor when the launch has no mask): no branch between the loads and the wait.
+      const int ci = ct * 16 + lr;
+      const int img_off = P.H * P.W * P.Cin;
+      const float* mimg = P.mask != nullptr ? P.mask + (size_t)img * img_off + ci : P.dz;
+      const int m_lim = P.mask != nullptr ? img_off - ci - 1 : 0;
+      float mv[RT][4];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int q = (rt0 + rt) * 16 + 4 * lg + e;
+          if (q >= nq) q = nq - 1;
+          const int yq = cx_div(q, m_nx), xq = q - yq * nx;
+          int o = ((s * yq + py) * P.W + s * xq + px) * P.Cin;
+          o = o < m_lim ? o : m_lim;
+          mv[rt][e] = mimg[o];
+        }
       const int2* tab = s_tab + cls * AA_DX6_MAX_KS;
       const uint4* wp = P.wf + (size_t)ct * 3 * 64 + lane;
       auto entry = [&](int ks) {
@@ -218,9 +239,6 @@ __global__ void __launch_bounds__(AA_DX6_THREADS) aa_conv_dx_frame_x6_kernel(Dx6
       if (ks + 2 < S) step(std::integral_constant<int, 2>{}, ks);
       }
 
-      const int ci = ct * 16 + lr;
-      const int img_off = P.H * P.W * P.Cin;
-      const float* mimg = P.mask != nullptr ? P.mask + (size_t)img * img_off + ci : nullptr;
       float* ximg = P.dx + (size_t)img * img_off + ci;
       auto emit = [&](auto maskc) {
         constexpr int MK = decltype(maskc)::value;
@@ -233,7 +251,7 @@ __global__ void __launch_bounds__(AA_DX6_THREADS) aa_conv_dx_frame_x6_kernel(Dx6
             const int yq = cx_div(q, m_nx), xq = q - yq * nx;
             const int o = ((s * yq + py) * P.W + s * xq + px) * P.Cin;
             float v = big[rt][e] + small[rt][e];
-            if (MK != 0) v *= dx6_actgrad(mimg[o], MK);
+            if (MK != 0) v *= dx6_actgrad(mv[rt][e], MK);
             ximg[o] = v;
           }
         }
