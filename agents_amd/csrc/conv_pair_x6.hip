@@ -152,6 +152,11 @@ __device__ static inline void cx_layer(const CxLayer& L, const char* __restrict_
       small[rt] = cx_f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const uint4* wp = L.wf + (size_t)ct * 3 * 64 + lane;
+    // the bias of this lane's output channel is requested in FRONT of the k loop (it was the first
+    // dependent access of the epilogue: an exposed L2 round trip per layer); unconditional load
+    // from a valid address, selected afterwards
+    const int co = ct * 16 + lr;
+    const float bias_raw = (L.bias != nullptr ? L.bias : L.w)[co];
     auto load_b = [&](CxFrag (&b)[3], int ks) {
 #pragma unroll
       for (int s = 0; s < 3; ++s) b[s].q = wp[(size_t)ks * wstep + s * 64];
@@ -218,8 +223,7 @@ __device__ static inline void cx_layer(const CxLayer& L, const char* __restrict_
     if (ks + 1 < S) step(std::integral_constant<int, 1>{}, ks);
     if (ks + 2 < S) step(std::integral_constant<int, 2>{}, ks);
     if (dst != nullptr) { CX_STAMP_L(7) }
-    const int co = ct * 16 + lr;
-    const float bv = L.bias != nullptr ? L.bias[co] : 0.f;
+    const float bv = L.bias != nullptr ? bias_raw : 0.f;
     float* yimg = L.y + (size_t)img * OHW * L.Cout + co;
     // the activation kind and "feeds a next layer" are resolved ONCE, outside the element loop
     auto emit = [&](auto actc, auto splitc) {
