@@ -280,17 +280,19 @@ __global__ void __launch_bounds__(NW * 64) aa_conv_pair_x6_kernel(CxParams P) {
     __syncthreads();   // the previous frame's readers are done
     CX_STAMP(0)
     const float4* xs = reinterpret_cast<const float4*>(P.x + (size_t)img * P.img_pitch);
-    for (int it0 = tid; it0 < n_item; it0 += 2 * NT) {   // 4 x 16-byte loads in flight
-      float4 v[2][2];
+    // 8 x 16-byte loads in flight: a 20 x 20 x 32 frame (1,600 items) is ONE trip of the loop,
+    // i.e. one memory round trip per frame instead of two
+    for (int it0 = tid; it0 < n_item; it0 += 4 * NT) {
+      float4 v[4][2];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < 4; ++u) {
         int it = it0 + u * NT;
         if (it >= n_item) it = n_item - 1;
         v[u][0] = xs[2 * it];
         v[u][1] = xs[2 * it + 1];
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < 4; ++u) {
         const int it = it0 + u * NT;
         if (it >= n_item) continue;
         const int q = it >> oct_sh, j = it & (octs - 1);

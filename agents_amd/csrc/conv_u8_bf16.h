@@ -303,14 +303,22 @@ aa_conv_u8_dw_bf16x3_kernel(GemmP p, int n_img, int frame_bytes, int want_colsum
     const uint4* fsrc = reinterpret_cast<const uint4*>(A + (size_t)img * p.imgpitch);
     uint4* fdst = reinterpret_cast<uint4*>(frame);
     const int n16 = frame_bytes >> 4;
-    int i0 = tid;
-    for (; i0 + 3 * NT < n16; i0 += 4 * NT) {   // 4 loads in flight
-      const uint4 t0 = fsrc[i0], t1 = fsrc[i0 + NT];
-      const uint4 t2 = fsrc[i0 + 2 * NT], t3 = fsrc[i0 + 3 * NT];
-      fdst[i0] = t0; fdst[i0 + NT] = t1;
-      fdst[i0 + 2 * NT] = t2; fdst[i0 + 3 * NT] = t3;
+    // four loads per thread in flight per trip, every thread (clamped indices: the threads whose
+    // fourth item fell off the end used to take the remainder loop -- one dependent round trip
+    // per item, three for more than half of the workgroup at the Atari frame size)
+    for (int i0 = tid; i0 < n16; i0 += 4 * NT) {
+      uint4 tv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * NT;
+        tv[u] = fsrc[i < n16 ? i : n16 - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * NT;
+        if (i < n16) fdst[i] = tv[u];
+      }
     }
-    for (; i0 < n16; i0 += NT) fdst[i0] = fsrc[i0];
     // (b) dZ rows of the frame -> three bf16 planes in fragment order (4 items = 32 loads in flight)
     const float* dz = p.B + (size_t)img * OHW * p.ldb;
     const int n_item = n_oct * 32;
