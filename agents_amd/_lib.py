@@ -10,7 +10,9 @@ from ctypes import (POINTER, Structure, c_double, c_float, c_int, c_int32, c_int
 import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libagents_amd.so")
+# AA_LIB_PATH: a developer override used by tools/ab_lib.sh to time two builds of the library on
+# one box (boxes of the pool differ by several percent); the product loads the in-tree library.
+LIB_PATH = os.environ.get("AA_LIB_PATH") or os.path.join(_PKG_DIR, "libagents_amd.so")
 
 AA_ACT_NONE, AA_ACT_RELU, AA_ACT_TANH = 0, 1, 2
 AA_A_ROW, AA_A_COL, AA_A_PATCH, AA_A_PATCH_U8, AA_A_PATCH_T, AA_A_PATCH_T_U8 = 0, 1, 2, 3, 4, 5
