@@ -110,36 +110,12 @@ __global__ void __launch_bounds__(256) aa_conv_pair_x6_split_kernel(CxLayer L0, 
   }
 }
 
-// The first four k-steps of the filter-fragment ring of this wave's FIRST task of layer L
-// (ct = wave & 3): requested before the frame is staged (layer 0) / before the previous layer's
-// epilogue (layer 1), so that the task's first MFMA does not wait for an L2 round trip behind a
-// barrier (in-kernel timeline, tools/cx_probe.hip: 1.0 us of prologue per layer and frame).
-__device__ static inline void cx_preload_b(const CxLayer& L, int ct, CxFrag (&b)[4][3]) {
-  const int lane = threadIdx.x & 63;
-  const int nct = L.Cout >> 4;
-  if (ct >= nct) ct = nct - 1;               // a wave without a task: a valid, unused address
-  const uint4* wp = L.wf + (size_t)ct * 3 * 64 + lane;
-  const size_t wstep = (size_t)nct * 3 * 64;
-  const int last = L.ksteps - 1;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int ks = j < last ? j : last;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) b[j][s].q = wp[(size_t)ks * wstep + s * 64];
-  }
-}
-
 // ---- one layer of one frame -------------------------------------------------------------------
 // src: this layer's three LDS planes; results to global y, and (dst != nullptr) split into the
 // next layer's planes.  RT row tiles per wave (compile time).
-// b: the filter-fragment ring.  On entry it holds the first four k-steps of the wave's first task
-// (cx_preload_b); every task requests the ring of the task that follows it - the wave's next
-// column tile, or (dst != nullptr) its first tile of the next layer - between its k loop and its
-// epilogue.
 template <int RT>
 __device__ static inline void cx_layer(const CxLayer& L, const char* __restrict__ src, int img,
-                                       char* __restrict__ dst, const CxLayer& Ln,
-                                       CxFrag (&b)[4][3]) {
+                                       char* __restrict__ dst, const CxLayer& Ln) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, lr = lane & 15, lg = lane >> 4;
@@ -219,7 +195,9 @@ __device__ static inline void cx_layer(const CxLayer& L, const char* __restrict_
     // refills are unconditional, with the index clamped to the last k-step: no branches in the
     // body.  Ring slot = k-step & 3; the 0-3 leftover steps reuse the slots in order.
     const int S = L.ksteps, last = S - 1;
-    CxFrag a0[RT][3], a1[RT][3];
+    CxFrag a0[RT][3], a1[RT][3], b[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) load_b(b[j], j < last ? j : last);
     load_a(a0, L.tap[0]);
     auto step = [&](auto jc, int ks) {
       constexpr int J = decltype(jc)::value;
@@ -245,9 +223,6 @@ __device__ static inline void cx_layer(const CxLayer& L, const char* __restrict_
     if (ks + 1 < S) step(std::integral_constant<int, 1>{}, ks);
     if (ks + 2 < S) step(std::integral_constant<int, 2>{}, ks);
     if (dst != nullptr) { CX_STAMP_L(7) }
-    // the following task's ring is on its way while this task's epilogue runs
-    if (ct + 4 < nct) cx_preload_b(L, ct + 4, b);
-    else if (dst != nullptr) cx_preload_b(Ln, wave & 3, b);
     const float bv = L.bias != nullptr ? bias_raw : 0.f;
     float* yimg = L.y + (size_t)img * OHW * L.Cout + co;
     // the activation kind and "feeds a next layer" are resolved ONCE, outside the element loop
@@ -287,7 +262,6 @@ __device__ static inline void cx_layer(const CxLayer& L, const char* __restrict_
     if (dst != nullptr) emit_act(std::true_type{});
     else emit_act(std::false_type{});
   }
-  if ((wave & 3) >= nct && dst != nullptr) cx_preload_b(Ln, wave & 3, b);   // a wave without a task
 }
 
 template <int RT0, int RT1, int NW>
@@ -305,8 +279,6 @@ __global__ void __launch_bounds__(NW * 64) aa_conv_pair_x6_kernel(CxParams P) {
   for (int img = blockIdx.x; img < P.n_img; img += gridDim.x) {
     __syncthreads();   // the previous frame's readers are done
     CX_STAMP(0)
-    CxFrag b[4][3];
-    cx_preload_b(L0, (threadIdx.x >> 6) & 3, b);   // layer 0's filter fragments: in flight under the staging
     const float4* xs = reinterpret_cast<const float4*>(P.x + (size_t)img * P.img_pitch);
     // 8 x 16-byte loads in flight: a 20 x 20 x 32 frame (1,600 items) is ONE trip of the loop,
     // i.e. one memory round trip per frame instead of two
@@ -337,11 +309,11 @@ __global__ void __launch_bounds__(NW * 64) aa_conv_pair_x6_kernel(CxParams P) {
     CX_STAMP(1)
     __syncthreads();
     CX_STAMP(2)
-    cx_layer<RT0 * 4 / NW>(L0, s_in, img, s_mid, L1, b);
+    cx_layer<RT0 * 4 / NW>(L0, s_in, img, s_mid, L1);
     CX_STAMP(3)
     __syncthreads();
     CX_STAMP(4)
-    cx_layer<RT1 * 4 / NW>(L1, s_mid, img, nullptr, L1, b);
+    cx_layer<RT1 * 4 / NW>(L1, s_mid, img, nullptr, L1);
     CX_STAMP(5)
   }
 }
