@@ -49,6 +49,12 @@ class PlaneScatter(Structure):
                 ("pos", c_void_p * 4), ("planes", c_void_p * 4)]
 
 
+class GradSlabs(Structure):
+    """aa_grad_slabs (include/agents_amd.h)."""
+    _fields_ = [("n", c_int32), ("splits", c_int32 * 4), ("mn", c_int32 * 4),
+                ("n_tail", c_int32 * 4), ("offset", c_int64 * 4), ("slab", c_void_p * 4)]
+
+
 class MlpLayout(Structure):
     """aa_mlp_layout."""
     _fields_ = [("n_layers", c_int32), ("dims", c_int32 * 5), ("acts", c_int32 * 4),
@@ -231,6 +237,9 @@ _SIGNATURES = {
     "aa_rmsprop_step_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                        c_float, c_float, c_float, c_float, POINTER(PlaneScatter),
                                        c_void_p]),
+    "aa_rmsprop_step_slabs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                      c_float, c_float, c_float, c_float, POINTER(PlaneScatter),
+                                      POINTER(GradSlabs), c_void_p]),
     "aa_sgd_step": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "aa_soft_update": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "aa_segment_sumsq": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
@@ -321,7 +330,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 12:
+    if lib.aa_abi_version() != 13:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -37,6 +37,9 @@ from agents_amd.utils import common, graph, nest_utils
 # A/B knob: AA_TRAIN_SINGLE_STREAM=1 keeps the whole train step on the caller's stream (no target /
 # weight-gradient side stream): fewer branches for the HIP-graph launch, no kernel overlap
 _SINGLE_STREAM = os.environ.get("AA_TRAIN_SINGLE_STREAM", "0") == "1"
+# AA_OPT_SUMS_SLABS=0: the conv weight gradients' slabs are summed by reduce launches into
+# flat_grads even when nothing but the optimizer reads them (A/B measurements; bit-identical)
+OPT_SUMS_SLABS = os.environ.get("AA_OPT_SUMS_SLABS", "1") != "0"
 
 
 class DqnLossInfo(collections.namedtuple("DqnLossInfo", ("td_loss", "td_error"))):
@@ -334,6 +337,8 @@ class DqnAgent(tf_agent.TFAgent):
         # head_done only exists in networks that exposed `fusable_head` (Sequential): a q_network
         # with the plain backward(dout, slot, side_stream, stop_layer) contract never sees it
         extra = {"head_done": True} if w.head_done else {}
+        if self._optimizer_sums_slabs(net):
+            extra["keep_dw_slabs"] = True
         net.backward(w.dq, slot="train", side_stream=self._side_stream(w.dq.device), **extra)
         total = w.loss
         if net.has_regularization:
@@ -373,10 +378,34 @@ class DqnAgent(tf_agent.TFAgent):
                             side_stream=self._side_stream(net.flat_grads.device),
                             from_layer=self._bucket_split())
 
+    def _optimizer_sums_slabs(self, net):
+        """Nothing reads flat_grads between backward and the optimizer step (no clipping, no
+        regulariser, no gradient hook = no all-reduce) and the optimizer can take the conv weight
+        gradients as unsummed slabs: the reduce launches of the backward pass are dropped."""
+        return OPT_SUMS_SLABS and self.gradient_hook is None and \
+            self._gradient_clipping is None and not net.has_regularization and \
+            getattr(self._optimizer, "supports_grad_slabs", False) and \
+            hasattr(net, "take_grad_slabs")
+
+    # GraphedTrain: the optimizer phase of an entry replays behind ITS gradient graph
+    def _apply_state(self):
+        net = self._q_network
+        return net.take_grad_slabs() if hasattr(net, "take_grad_slabs") else None
+
+    def _set_apply_state(self, state):
+        if hasattr(self._q_network, "set_grad_slabs"):
+            self._q_network.set_grad_slabs(state)
+
     def _train_phase_apply(self):
         net = self._q_network
         planes = net.plane_scatter() if hasattr(net, "plane_scatter") else None
-        if planes is not None and getattr(self._optimizer, "supports_planes", False):
+        slabs = net.take_grad_slabs() if hasattr(net, "take_grad_slabs") else None
+        if slabs is not None:
+            self._optimizer.apply_flat(net.flat_params, net.flat_grads, planes=planes,
+                                       grad_slabs=slabs)
+            if planes is None:
+                self._refresh_prepared(net)
+        elif planes is not None and getattr(self._optimizer, "supports_planes", False):
             # the optimizer kernel writes the new filters' bf16 pieces into the prepared planes
             self._optimizer.apply_flat(net.flat_params, net.flat_grads, planes=planes)
         else:

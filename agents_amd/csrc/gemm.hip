@@ -1056,9 +1056,11 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
 int aa_gemm_f32_slabs(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
                       int32_t* splits_out, void* stream) {
   if (d == nullptr || splits_out == nullptr) return AA_ERR_INVALID;
-  // the consumer applies bias / activation itself; fused column sums and masks belong to the
-  // backward contractions, which keep the reduce launch
-  if (d->colsum_out != nullptr || d->mask_src != nullptr) return AA_ERR_INVALID;
+  // the consumer applies bias / activation itself; masks belong to the input-gradient
+  // contractions, which keep the reduce launch.  colsum_out != nullptr (a weight gradient with
+  // its fused bias gradient): the column-sum rows follow the slabs, for a consumer that sums both
+  // (aa_rmsprop_step_slabs); with *splits_out == 1 C and colsum_out hold the final values.
+  if (d->mask_src != nullptr) return AA_ERR_INVALID;
   int splits = 0;
   const int rc = aa_gemm_f32_impl(d, workspace, workspace_bytes, stream, &splits);
   *splits_out = splits;

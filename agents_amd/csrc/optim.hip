@@ -9,6 +9,7 @@
 #include "common.h"
 #include "agents_amd.h"
 #include "x6_common.h"
+#include "splitk_reduce.h"
 
 #define AA_EW_THREADS 256
 
@@ -175,6 +176,89 @@ aa_rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __r
   }
 }
 
+// RMSprop reading some gradients straight from split-K slabs.  The conv weight gradients of the
+// DQN step leave per-frame-group slabs (conv_dw_frame_x6.hip, conv_u8_bf16.h) that a reduce launch
+// used to sum into the flat gradient buffer right before this kernel read it back: when nothing
+// sits between backward and the optimizer (no clipping, no all-reduce) the leading workgroups of
+// the optimizer launch do that sum themselves -- aa_splitk_reduce_walk, i.e. the association of the
+// reduce launch, bit for bit -- and update the segment's parameters with it; the other workgroups
+// walk the rest of the flat buffer as aa_rmsprop_kernel does.  The sums are also stored to g (0.3 MB
+// for the Atari net), so that the flat gradient buffer is complete once the step has run.
+struct AaSlabSrc {
+  int n;
+  int first[AA_MAX_GRAD_SLABS + 1];          // workgroups [first[s], first[s + 1]) sum segment s
+  const float* slab[AA_MAX_GRAD_SLABS];
+  int splits[AA_MAX_GRAD_SLABS], mn[AA_MAX_GRAD_SLABS], n_tail[AA_MAX_GRAD_SLABS];
+  long long off[AA_MAX_GRAD_SLABS];
+};
+
+template <bool CENTERED, bool MOMENTUM, bool PLANES>
+__global__ void __launch_bounds__(AA_EW_THREADS)
+aa_rmsprop_slabs_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ ms,
+                        float* __restrict__ mg, float* __restrict__ mom, int64_t n, float lr,
+                        float rho, float momentum, float eps, aa_plane_scatter S, AaSlabSrc G) {
+  const float omr = 1.0f - rho;
+  auto update4 = [&](int64_t i, const float4 gg) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    float4 s = reinterpret_cast<float4*>(ms)[i];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), mo = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (CENTERED) a = reinterpret_cast<float4*>(mg)[i];
+    if (MOMENTUM) mo = reinterpret_cast<float4*>(mom)[i];
+    rms_elem<CENTERED, MOMENTUM>(pp.x, gg.x, s.x, &a.x, &mo.x, lr, rho, omr, momentum, eps);
+    rms_elem<CENTERED, MOMENTUM>(pp.y, gg.y, s.y, &a.y, &mo.y, lr, rho, omr, momentum, eps);
+    rms_elem<CENTERED, MOMENTUM>(pp.z, gg.z, s.z, &a.z, &mo.z, lr, rho, omr, momentum, eps);
+    rms_elem<CENTERED, MOMENTUM>(pp.w, gg.w, s.w, &a.w, &mo.w, lr, rho, omr, momentum, eps);
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(ms)[i] = s;
+    if (CENTERED) reinterpret_cast<float4*>(mg)[i] = a;
+    if (MOMENTUM) reinterpret_cast<float4*>(mom)[i] = mo;
+    if (PLANES && aa_planes_touch(S, 4 * i, 4 * i + 4)) {
+      aa_planes_put(S, 4 * i, pp.x); aa_planes_put(S, 4 * i + 1, pp.y);
+      aa_planes_put(S, 4 * i + 2, pp.z); aa_planes_put(S, 4 * i + 3, pp.w);
+    }
+  };
+  const int slab_blocks = G.first[G.n];
+  if ((int)blockIdx.x < slab_blocks) {
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k < AA_MAX_GRAD_SLABS; ++k)
+      if (k < G.n && (int)blockIdx.x >= G.first[k]) s = k;
+    const float* slab = G.slab[0]; int splits = G.splits[0], mn = G.mn[0], nt = G.n_tail[0];
+    long long off = G.off[0]; int b0 = G.first[0], b1 = G.first[1];
+#pragma unroll
+    for (int k = 1; k < AA_MAX_GRAD_SLABS; ++k)
+      if (s == k) {
+        slab = G.slab[k]; splits = G.splits[k]; mn = G.mn[k]; nt = G.n_tail[k];
+        off = G.off[k]; b0 = G.first[k]; b1 = G.first[k + 1];
+      }
+    aa_splitk_reduce_walk<4, 16>(slab, splits, (size_t)mn, nt, blockIdx.x - (unsigned)b0,
+                                 (unsigned)(b1 - b0), [&](size_t i, bool, float (&v)[4]) {
+                                   const float4 gg = make_float4(v[0], v[1], v[2], v[3]);
+                                   reinterpret_cast<float4*>(g)[(off + (long long)i) >> 2] = gg;
+                                   update4((off + (long long)i) >> 2, gg);
+                                 });
+    return;
+  }
+  const int64_t nv = n / 4;
+  const int64_t fb = (int64_t)blockIdx.x - slab_blocks;
+  const int64_t stride = ((int64_t)gridDim.x - slab_blocks) * blockDim.x;
+  for (int64_t i = fb * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    bool covered = false;
+#pragma unroll
+    for (int k = 0; k < AA_MAX_GRAD_SLABS; ++k)
+      covered = covered || (k < G.n && 4 * i >= G.off[k] && 4 * i < G.off[k] + G.mn[k] + G.n_tail[k]);
+    if (covered) continue;
+    update4(i, reinterpret_cast<const float4*>(g)[i]);
+  }
+  for (int64_t i = nv * 4 + fb * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float a = CENTERED ? mg[i] : 0.f, mo = MOMENTUM ? mom[i] : 0.f;
+    rms_elem<CENTERED, MOMENTUM>(p[i], g[i], ms[i], &a, &mo, lr, rho, omr, momentum, eps);
+    if (CENTERED) mg[i] = a;
+    if (MOMENTUM) mom[i] = mo;
+    if (PLANES) aa_planes_put(S, i, p[i]);
+  }
+}
+
 __global__ void __launch_bounds__(AA_EW_THREADS)
 aa_sgd_kernel(float* __restrict__ p, const float* __restrict__ g, int64_t n, float lr) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -311,6 +395,65 @@ int aa_rmsprop_step_planes(float* p, const float* g, float* ms, float* mg, float
     else                                                                                        \
       hipLaunchKernelGGL((aa_rmsprop_kernel<C_, M_, false>), grid, block, 0, st, p, g, ms, mg,  \
                          mom, n, lr, rho, momentum, eps, S);                                    \
+  } while (0)
+  if (mg && mom) AA_RMS(true, true);
+  else if (mg) AA_RMS(true, false);
+  else if (mom) AA_RMS(false, true);
+  else AA_RMS(false, false);
+#undef AA_RMS
+  return aa_launch_status();
+}
+
+int aa_rmsprop_step_slabs(float* p, float* g, float* ms, float* mg, float* mom, int64_t n,
+                          float lr, float rho, float momentum, float eps,
+                          const aa_plane_scatter* planes, const aa_grad_slabs* slabs,
+                          void* stream) {
+  if (slabs == nullptr || slabs->n <= 0)
+    return aa_rmsprop_step_planes(p, g, ms, mg, mom, n, lr, rho, momentum, eps, planes, stream);
+  if (!p || !g || !ms || n <= 0 || slabs->n > AA_MAX_GRAD_SLABS) return AA_ERR_INVALID;
+  if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)ms | (uintptr_t)mg | (uintptr_t)mom) & 15) != 0)
+    return AA_ERR_INVALID;
+  if (aa_planes_check(planes, n) != AA_OK) return AA_ERR_INVALID;
+  AaSlabSrc G;
+  G.n = slabs->n;
+  int blocks = 0;
+  int64_t covered = 0, prev_end = 0;
+  for (int s = 0; s < slabs->n; ++s) {
+    const int64_t off = slabs->offset[s];
+    const int mn = slabs->mn[s], nt = slabs->n_tail[s], z = slabs->splits[s];
+    if (slabs->slab[s] == nullptr || (((uintptr_t)slabs->slab[s]) & 15) != 0 || mn <= 0 ||
+        nt < 0 || (mn & 3) != 0 || (nt & 3) != 0 || (off & 3) != 0 || off < prev_end ||
+        off + mn + nt > n)
+      return AA_ERR_INVALID;
+    // the 16 z-lane association of the reduce launches (gemm.hip / conv_dw_frame_x6.hip: "deep")
+    const int64_t work = ((int64_t)mn + nt) / 4;
+    if (z < 32 || work > 65536) return AA_ERR_RANGE;
+    prev_end = off + mn + nt;
+    covered += mn + nt;
+    G.slab[s] = slabs->slab[s]; G.splits[s] = z; G.mn[s] = mn; G.n_tail[s] = nt; G.off[s] = off;
+    G.first[s] = blocks;
+    int b = (int)((work + 15) / 16);
+    if (b > 2048) b = 2048;      // (the reduce launch's block count: same grid-stride walk)
+    blocks += b;
+    G.first[s + 1] = blocks;
+  }
+  for (int s = slabs->n; s < AA_MAX_GRAD_SLABS; ++s) {
+    G.slab[s] = nullptr; G.splits[s] = 0; G.mn[s] = 0; G.n_tail[s] = 0; G.off[s] = 0;
+    G.first[s + 1] = blocks;
+  }
+  const unsigned flat = aa_ew_blocks((n - covered) / 4);
+  const dim3 grid((unsigned)blocks + flat), block(AA_EW_THREADS);
+  hipStream_t st = (hipStream_t)stream;
+  const bool pl = planes != nullptr && planes->n > 0;
+  const aa_plane_scatter S = pl ? *planes : aa_plane_scatter{};
+#define AA_RMS(C_, M_)                                                                          \
+  do {                                                                                          \
+    if (pl)                                                                                     \
+      hipLaunchKernelGGL((aa_rmsprop_slabs_kernel<C_, M_, true>), grid, block, 0, st, p, g, ms, \
+                         mg, mom, n, lr, rho, momentum, eps, S, G);                             \
+    else                                                                                        \
+      hipLaunchKernelGGL((aa_rmsprop_slabs_kernel<C_, M_, false>), grid, block, 0, st, p, g,    \
+                         ms, mg, mom, n, lr, rho, momentum, eps, S, G);                         \
   } while (0)
   if (mg && mom) AA_RMS(true, true);
   else if (mg) AA_RMS(true, false);

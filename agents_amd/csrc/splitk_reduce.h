@@ -26,16 +26,17 @@ __device__ static inline float aa_actgrad(float y, int kind) {
 // gradient serially took 60 us for 8 MB; 16 z-lanes bring it to the memory system's pace.)
 // Elements [M*N, M*N + N) of the index space are the fused bias-gradient rows that follow the
 // slabs: colsum_out[n] = sum_z slab_end[z][n].
-template <int VEC, int ZL>
+// The sum itself, shared by every consumer of slabs (the reduce launches below and the optimizer
+// that reads gradients straight from slabs, optim.hip): `emit(i, tail, v)` is called by the thread
+// that holds the finished sum of item i (tail: a bias-gradient item, i >= MN).  n_tail = number of
+// bias-gradient elements that follow the slabs (0: none).
+template <int VEC, int ZL, class Emit>
 __device__ static inline void
-aa_splitk_reduce_body(const float* __restrict__ slab, int splits, int M, int N,
-                      float* __restrict__ C, int ldc, const float* __restrict__ bias, int act,
-                      const float* __restrict__ mask_src, int ldm, int mask_kind,
-                      float* __restrict__ colsum_out, unsigned block, unsigned n_blocks) {
+aa_splitk_reduce_walk(const float* __restrict__ slab, int splits, size_t MN, int n_tail,
+                      unsigned block, unsigned n_blocks, Emit emit) {
   constexpr int IPB = 256 / ZL;
   __shared__ float part[ZL][IPB][VEC];
-  const size_t MN = (size_t)M * N;
-  const size_t total = (MN + (colsum_out != nullptr ? (size_t)N : 0)) / VEC;
+  const size_t total = (MN + (size_t)n_tail) / VEC;
   const float* cs_rows = slab + (size_t)splits * MN;
   const int it = threadIdx.x % IPB, zl = threadIdx.x / IPB;
   for (size_t q0 = (size_t)block * IPB; q0 < total; q0 += (size_t)n_blocks * IPB) {
@@ -44,7 +45,7 @@ aa_splitk_reduce_body(const float* __restrict__ slab, int splits, int M, int N,
     const size_t i = q * VEC;
     const bool tail = live && i >= MN;   // bias-gradient element(s)
     const float* src = tail ? cs_rows + (i - MN) : slab + i;
-    const size_t zstride = tail ? (size_t)N : MN;
+    const size_t zstride = tail ? (size_t)n_tail : MN;
     float v[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) v[e] = 0.f;
@@ -89,26 +90,40 @@ aa_splitk_reduce_body(const float* __restrict__ slab, int splits, int M, int N,
         for (int e = 0; e < VEC; ++e) v[e] += part[j][it][e];
     }
     if (!live) continue;
-    if (tail) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) colsum_out[i - MN + e] = v[e];
-      continue;
-    }
-    const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      float x = v[e];
-      if (bias != nullptr) x += bias[n + e];
-      x = aa_act(x, act);
-      if (mask_kind != 0) x *= aa_actgrad(mask_src[(size_t)m * ldm + n + e], mask_kind);
-      v[e] = x;
-    }
-    if constexpr (VEC == 4) {
-      *reinterpret_cast<float4*>(C + (size_t)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-      C[(size_t)m * ldc + n] = v[0];
-    }
+    emit(i, tail, v);
   }
+}
+
+template <int VEC, int ZL>
+__device__ static inline void
+aa_splitk_reduce_body(const float* __restrict__ slab, int splits, int M, int N,
+                      float* __restrict__ C, int ldc, const float* __restrict__ bias, int act,
+                      const float* __restrict__ mask_src, int ldm, int mask_kind,
+                      float* __restrict__ colsum_out, unsigned block, unsigned n_blocks) {
+  const size_t MN = (size_t)M * N;
+  aa_splitk_reduce_walk<VEC, ZL>(
+      slab, splits, MN, colsum_out != nullptr ? N : 0, block, n_blocks,
+      [&](size_t i, bool tail, float (&v)[VEC]) {
+        if (tail) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) colsum_out[i - MN + e] = v[e];
+          return;
+        }
+        const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float x = v[e];
+          if (bias != nullptr) x += bias[n + e];
+          x = aa_act(x, act);
+          if (mask_kind != 0) x *= aa_actgrad(mask_src[(size_t)m * ldm + n + e], mask_kind);
+          v[e] = x;
+        }
+        if constexpr (VEC == 4) {
+          *reinterpret_cast<float4*>(C + (size_t)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          C[(size_t)m * ldc + n] = v[0];
+        }
+      });
 }
 
 

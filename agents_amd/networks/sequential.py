@@ -780,7 +780,7 @@ class Sequential(network.Network):
                     bias_grad=self._gbviews[n - 1])
 
     def backward(self, dout, slot=0, side_stream=None, param_grads=True, input_grad=None,
-                 stop_layer=0, head_done=False, input_grad_cols=None):
+                 stop_layer=0, head_done=False, input_grad_cols=None, keep_dw_slabs=False):
         """Given d loss / d output [B, out], fills flat_grads (overwrites).
 
         `param_grads=False` skips every weight/bias gradient (only the input-gradient chain runs:
@@ -790,6 +790,10 @@ class Sequential(network.Network):
         critic's action gradient -- the others may be left unwritten).  `head_done=True`: the last layer's backward (its dX into this
         slot's buffer, dW, db) has already been produced by the caller's loss launch
         (`fusable_head`); the walk starts at the layer below.
+        `keep_dw_slabs=True`: conv weight gradients that leave split-K slabs are NOT summed into
+        flat_grads; `take_grad_slabs()` hands the slabs to an optimizer that sums them itself
+        (`optimizers.RMSprop.apply_flat(grad_slabs=...)`) -- for a caller with nothing between
+        backward and the optimizer step (no clipping, no all-reduce).
         `stop_layer=k > 0` stops after parametrised layer k (its input gradient is computed); `backward_resume` continues with layers k-1 .. 0 -- the Learner
         starts the all-reduce of the tail's gradients in between (`grad_buckets`).
 
@@ -811,6 +815,8 @@ class Sequential(network.Network):
         lib = _lib.load()
         n = len(self._param_layers)
         top = self._param_layers[-1]
+        self._grad_slabs = None
+        self._keep_dw_slabs = bool(keep_dw_slabs) and stop_layer == 0 and param_grads
         if top.activation is not None:
             _lib.check(lib.aa_act_backward(dout.data_ptr(), s.ys[-1].data_ptr(),
                                            ops.ACT[top.activation], dout.numel(),
@@ -827,6 +833,17 @@ class Sequential(network.Network):
                                      param_grads, input_grad)
             return
         self._backward_range(s, B, dz, n - 1, stop_layer, side_stream, param_grads, input_grad)
+
+    def take_grad_slabs(self):
+        """The unsummed weight-gradient slabs of the last `backward` as an aa_grad_slabs (None
+        unless it ran with keep_dw_slabs=True and layers left slabs): the caller's optimizer step
+        must consume them.  Valid until the next backward; a HIP-graph replay of a backward pass
+        does not run this Python, so a replayer restores what `backward` left at capture time
+        (`set_grad_slabs`; utils/graph.py: GraphedTrain)."""
+        return getattr(self, "_grad_slabs", None)
+
+    def set_grad_slabs(self, g):
+        self._grad_slabs = g
 
     def backward_resume(self, B, slot=0, side_stream=None, from_layer=1):
         """Continues a `backward(..., stop_layer=from_layer)`: layers from_layer-1 .. 0."""
@@ -864,7 +881,9 @@ class Sequential(network.Network):
 
         # conv weight gradients on the side stream leave their slabs unsummed; ONE launch sums them
         # for all layers after the last of them has been enqueued (ops.PendingDwReduce)
-        pending_dw = ops.PendingDwReduce() if side_stream is not main else None
+        keep = getattr(self, "_keep_dw_slabs", False)
+        self._keep_dw_slabs = False
+        pending_dw = ops.PendingDwReduce(keep=keep) if (keep or side_stream is not main) else None
 
         for i in range(hi, lo - 1, -1):
             l = self._param_layers[i]
@@ -933,7 +952,7 @@ class Sequential(network.Network):
                     dw = lambda: ops.conv_dw(x, dz2, ks, l.stride, self._gkviews[i],
                                              a_div=self._first_div() if i == 0 else 1.0,
                                              bias_grad=self._gbviews[i],
-                                             defer=None if on_main else pending_dw)
+                                             defer=pending_dw if (keep or not on_main) else None)
                     if i == 0 and LAST_DW_ON_MAIN:
                         # layer 0 has no input gradient: main has nothing left to do, while the
                         # side stream is still finishing layer 1's weight gradient (timeline:
@@ -947,6 +966,8 @@ class Sequential(network.Network):
             main.wait_stream(self._prep_stream)
         if pending_dw is not None and pending_dw.items:
             on_side(lambda: ops.conv_dw_flush(pending_dw), fork=False)
+        if keep:
+            self._grad_slabs = ops.grad_slabs(pending_dw, self.flat_grads)
         if side_stream is not main:
             main.wait_stream(side_stream)
 

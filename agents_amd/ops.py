@@ -474,11 +474,45 @@ class PendingDwReduce:
     (csrc/splitk_reduce.h: aa_splitk_reduce_multi_kernel) -- the backward pass of a conv stack
     used to pay one reduce launch per layer on its side stream."""
 
-    def __init__(self):
+    def __init__(self, keep=False):
         self.items = []      # (desc, slabs, out, bias_grad)
+        # keep=True: nobody sums the slabs -- the optimizer launch reads its gradients from them
+        # (`grad_slabs`, csrc/optim.hip: aa_rmsprop_step_slabs); `kept` then also lists the slabs
+        # of GEMM-path weight gradients: (slabs, splits, M * N, N, out, bias_grad)
+        self.keep = keep
+        self.kept = []
+
+
+def _slabs_deep(splits, mn, n_tail):
+    """The slab shapes the 16-z-lane reduce (and aa_rmsprop_step_slabs) takes."""
+    return splits >= 32 and (mn + n_tail) // 4 <= 65536 and mn % 4 == 0 and n_tail % 4 == 0
+
+
+def _follows(out, bias_grad, mn):
+    """bias_grad is the tensor right behind `out` in one flat buffer (kernel, bias order)."""
+    return bias_grad is not None and bias_grad.dtype == torch.float32 and \
+        bias_grad.data_ptr() == out.data_ptr() + 4 * mn
+
+
+def grad_slabs(pending, flat_grads):
+    """aa_grad_slabs of a keep=True PendingDwReduce relative to `flat_grads` (None: nothing kept)."""
+    if pending is None or not pending.kept:
+        return None
+    kept = sorted(pending.kept, key=lambda k: k[4].data_ptr())
+    g = _lib.GradSlabs()
+    g.n = len(kept)
+    for i, (ws, splits, mn, n_tail, out, _bg) in enumerate(kept):
+        off = (out.data_ptr() - flat_grads.data_ptr()) // 4
+        if off < 0 or off + mn + n_tail > flat_grads.numel():
+            raise ValueError("grad_slabs: a weight gradient is not a view of flat_grads")
+        g.splits[i], g.mn[i], g.n_tail[i], g.offset[i], g.slab[i] = splits, mn, n_tail, off, ptr(ws)
+    g._keepalive = [k[0] for k in kept]
+    return g
 
 
 def conv_dw_flush(pending):
+    if pending.keep:
+        return
     items, pending.items = pending.items, []
     if not items:
         return
@@ -521,13 +555,21 @@ def conv_dw(x, dz, w_shape, stride, out, a_div=255.0, force_cfg=0, force_splits=
         if ws_bytes > 0:
             # per-frame kernel on the bf16 matrix cores at fp32 accuracy (csrc/conv_dw_frame_x6.hip);
             # its slabs live in the calling line's scratch like the GEMM's
-            if defer is not None and CONV_DW_MERGE_REDUCE and len(defer.items) < 4:
-                ws = _WS_DW_DEFER[len(defer.items)].get(ws_bytes, x.device)
+            groups = ws_bytes // (4 * (Kp * Cout + Cout))
+            keep = defer is not None and defer.keep and len(defer.kept) < 4 and \
+                _follows(out, bias_grad, Kp * Cout) and _slabs_deep(groups, Kp * Cout, Cout)
+            if keep or (defer is not None and not defer.keep and CONV_DW_MERGE_REDUCE and
+                        len(defer.items) < 4):
+                n_pending = len(defer.kept) if keep else len(defer.items)
+                ws = _WS_DW_DEFER[n_pending].get(ws_bytes, x.device)
                 with torch.cuda.device(x.device):
                     check(_lib.load().aa_conv_dw_frame_x6_slabs(
                         ctypes.byref(dd), ptr(x), 1 if bias_grad is not None else 0, ptr(ws),
                         ws.numel(), stream_ptr()), "aa_conv_dw_frame_x6_slabs")
-                defer.items.append((dd, ws, out, bias_grad))
+                if keep:
+                    defer.kept.append((ws, groups, Kp * Cout, Cout, out, bias_grad))
+                else:
+                    defer.items.append((dd, ws, out, bias_grad))
                 return out
             ws = _WS.get(ws_bytes, x.device)
             with torch.cuda.device(x.device):
@@ -540,6 +582,23 @@ def conv_dw(x, dz, w_shape, stride, out, a_div=255.0, force_cfg=0, force_splits=
                   stride=stride, img_pitch=_img_pitch(x), a_div=float(a_div),
                   force_cfg=force_cfg, force_splits=force_splits,
                   colsum_out=_bias_grad_ptr(bias_grad, Cout))
+    if defer is not None and defer.keep and len(defer.kept) < 4 and \
+            _follows(out, bias_grad, Kp * Cout):
+        # GEMM-path weight gradient (the uint8 first layer): slabs + column-sum rows only when the
+        # plan is split the way the optimizer's slab walk takes; splits = bytes / slab bytes
+        lib = _lib.load()
+        need = int(lib.aa_gemm_f32_workspace_bytes(ctypes.byref(d)))
+        splits = need // (4 * (Kp * Cout + Cout)) if need > 0 else 1
+        if _slabs_deep(splits, Kp * Cout, Cout):
+            ws = _WS_DW_DEFER[len(defer.kept)].get(need, x.device)
+            got = ctypes.c_int32(0)
+            with torch.cuda.device(x.device):
+                check(lib.aa_gemm_f32_slabs(ctypes.byref(d), ptr(ws), ws.numel(), ctypes.byref(got),
+                                            stream_ptr()), "aa_gemm_f32_slabs")
+            if got.value != splits:
+                raise RuntimeError(f"conv_dw: plan has {got.value} slabs, workspace says {splits}")
+            defer.kept.append((ws, splits, Kp * Cout, Cout, out, bias_grad))
+            return out
     gemm(d, x.device)
     return out
 

@@ -143,20 +143,24 @@ class RMSprop(Optimizer):
             float(learning_rate), float(rho), float(momentum), float(epsilon), bool(centered)
 
     supports_planes = True
+    supports_grad_slabs = True
 
-    def apply_flat(self, params, grads, planes=None):
+    def apply_flat(self, params, grads, planes=None, grad_slabs=None):
+        """grad_slabs: an aa_grad_slabs (`Sequential.take_grad_slabs()`): those parameter ranges
+        take their gradient from unsummed split-K slabs instead of `grads`."""
         import ctypes
         lib = _lib.load()
         _lib.require_cuda(params, grads)
         names = ["ms"] + (["mg"] if self.centered else []) + (["mom"] if self.momentum > 0 else [])
         s = self._slot(params, names)
-        _lib.check(lib.aa_rmsprop_step_planes(
+        _lib.check(lib.aa_rmsprop_step_slabs(
             params.data_ptr(), grads.data_ptr(), s["ms"].data_ptr(),
             s["mg"].data_ptr() if self.centered else None,
             s["mom"].data_ptr() if self.momentum > 0 else None, params.numel(),
             self.learning_rate, self.rho, self.momentum, self.epsilon,
-            None if planes is None else ctypes.byref(planes), _lib.stream_ptr()),
-            "aa_rmsprop_step_planes")
+            None if planes is None else ctypes.byref(planes),
+            None if grad_slabs is None else ctypes.byref(grad_slabs), _lib.stream_ptr()),
+            "aa_rmsprop_step_slabs")
         graph.on_replay(self._bump_iterations)
 
 

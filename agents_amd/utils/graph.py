@@ -310,6 +310,7 @@ class _Entry:
         self.static_w = None
         self.g_grads = None       # _Captured: forwards + loss + backward (bucket mode: first half)
         self.g_apply = None       # _Captured: optimizer (shared by every entry of a signature)
+        self.apply_state = None   # agent._apply_state() after this entry's gradient phase
         self.g_grads_b = None     # _Captured, bucket mode: second half of the backward
         self.captured = None      # _Captured, whole mode (part (a) when the agent splits it)
         self.captured_b = None    # _Captured, whole mode, part (b)
@@ -498,6 +499,8 @@ class GraphedTrain:
                 w2.wait()
                 if lanes is not None and lanes.collect_done is not None:
                     torch.cuda.current_stream(dev).wait_event(lanes.collect_done)
+                if hasattr(agent, "_set_apply_state"):
+                    agent._set_apply_state(e.apply_state)
                 e.g_apply.replay()
                 agent._train_phase_host()
             else:
@@ -509,6 +512,8 @@ class GraphedTrain:
                 if lanes is not None and lanes.collect_done is not None:
                     # the optimizer overwrites theta_k: the collect policy's forward must be done
                     torch.cuda.current_stream(dev).wait_event(lanes.collect_done)
+                if hasattr(agent, "_set_apply_state"):
+                    agent._set_apply_state(e.apply_state)
                 if APPLY_EAGER:
                     # the optimizer phase is one or two launches: issued directly they follow the
                     # gradient graph without a second graph-launch boundary on the critical stream
@@ -552,10 +557,16 @@ class GraphedTrain:
             if bucketed:
                 e.g_grads_b = _Captured("train.grads_b")
                 e.g_grads_b.capture(agent._train_phase_grads_b)
-            if g_apply is not None:
+            # what the optimizer phase takes over from THIS entry's gradient phase besides
+            # flat_grads (DqnAgent: the unsummed conv weight-gradient slabs of its batch size);
+            # replays put it back before the phase runs, eagerly or from its own graph
+            e.apply_state = agent._apply_state() if hasattr(agent, "_apply_state") else None
+            if g_apply is not None and e.apply_state is None and \
+                    not getattr(g_apply, "has_state", False):
                 e.g_apply = g_apply          # the optimizer phase does not depend on the inputs
             else:
                 e.g_apply = _Captured("train.apply")
+                e.g_apply.has_state = e.apply_state is not None
                 e.g_apply.capture(agent._train_phase_apply)
 
     def static_inputs(self, experience_like=None):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 12
+#define AA_ABI_VERSION 13
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -196,7 +196,9 @@ int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
 /* aa_gemm_f32 without the split-K reduce launch, for a consumer that sums the partial products in
  * its own prologue (aa_dense_small_forward_slabs): *splits_out = s > 1 -> `workspace` starts with
  * the raw fp32 slabs [s][M][N] (no bias, no activation) and C is untouched; *splits_out = 1 -> the
- * plan was not split and C holds the finished result.  colsum_out / mask_src must be NULL. */
+ * plan was not split and C holds the finished result.  mask_src must be NULL.  colsum_out != NULL
+ * (a weight gradient with its bias gradient fused): the [s][N] column-sum rows follow the slabs
+ * (aa_rmsprop_step_slabs sums both); with *splits_out == 1 colsum_out holds the final sums. */
 int aa_gemm_f32_slabs(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
                       int32_t* splits_out, void* stream);
 
@@ -460,6 +462,27 @@ int aa_adam_step_counted_target(float* p, const float* g, float* m, float* v, in
 int aa_rmsprop_step_planes(float* p, const float* g, float* ms, float* mg, float* mom, int64_t n,
                            float lr, float rho, float momentum, float eps,
                            const aa_plane_scatter* planes /* nullable */, void* stream);
+/* RMSprop whose gradient comes partly from split-K slabs that have NOT been summed: segment s
+ * covers parameters [offset[s], offset[s] + mn[s] + n_tail[s]) (a conv kernel followed by its
+ * bias); its gradient is sum_z slab[s][z * mn + i] for i < mn and sum_z slab[s][splits * mn +
+ * z * n_tail + (i - mn)] for the bias -- the layout aa_conv_dw_frame_x6_slabs and aa_gemm_f32_slabs
+ * leave -- summed with the association of the reduce launch those entry points pair with (16
+ * z-lanes; needs splits >= 32 and (mn + n_tail) / 4 <= 65536, AA_ERR_RANGE otherwise), so the
+ * parameters come out bit-identical to reduce + aa_rmsprop_step_planes; the sums are also stored
+ * to g, which is complete when the launch has run.  Everything else is read from g.  Applies when nothing sits between backward and the optimizer (no clipping, no
+ * all-reduce): keras RMSprop.apply_gradients of agents/dqn/dqn_agent.py:412-449 with
+ * gradient_clipping=None.  slabs == NULL or n == 0: aa_rmsprop_step_planes. */
+#define AA_MAX_GRAD_SLABS 4
+typedef struct aa_grad_slabs {
+  int32_t n;
+  int32_t splits[AA_MAX_GRAD_SLABS], mn[AA_MAX_GRAD_SLABS], n_tail[AA_MAX_GRAD_SLABS];
+  int64_t offset[AA_MAX_GRAD_SLABS];
+  const float* slab[AA_MAX_GRAD_SLABS];
+} aa_grad_slabs;
+int aa_rmsprop_step_slabs(float* p, float* g, float* ms, float* mg, float* mom, int64_t n,
+                          float lr, float rho, float momentum, float eps,
+                          const aa_plane_scatter* planes /* nullable */,
+                          const aa_grad_slabs* slabs /* nullable */, void* stream);
 int aa_sgd_step(float* p, const float* g, int64_t n, float lr, void* stream);
 /* t = (1-tau)*t + tau*s  (soft_variables_update, utils/common.py:314-346) */
 int aa_soft_update(float* target, const float* source, int64_t n, float tau, void* stream);

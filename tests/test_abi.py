@@ -59,6 +59,7 @@ def test_struct_layouts_match_the_header(tmp_path):
               "aa_conv_layer_desc": ("ConvLayerDesc", ["w", "y", "KH", "act"]),
               "aa_conv_dx_desc": ("ConvDxDesc", ["dz", "dx", "n_img", "mask_kind"]),
               "aa_plane_scatter": ("PlaneScatter", ["n", "stride", "lo", "hi", "pos", "planes"]),
+              "aa_grad_slabs": ("GradSlabs", ["n", "splits", "mn", "n_tail", "offset", "slab"]),
               "aa_mlp_layout": ("MlpLayout", ["n_layers", "dims", "acts", "k_off", "b_off"]),
               "aa_ppo_fused_desc": ("PpoFusedDesc", [
                   "obs", "ld_obs", "obs_dim", "D", "actions", "old_vpred", "step_type", "N", "rows",
@@ -84,7 +85,7 @@ def test_struct_layouts_match_the_header(tmp_path):
 
 
 def test_abi_version(lib):
-    assert lib.aa_abi_version() == 12
+    assert lib.aa_abi_version() == 13
 
 
 def test_argument_validation_without_gpu(lib):
@@ -139,6 +140,31 @@ def test_round3_entries_validate_on_the_host(lib):
                                  None, 1e-3, 0.9, 0.999, 1e-7, None, None, None, None) == -22
     assert lib.aa_sac_head_backward(1 << 20, 4, 2, 1 << 20, 0, 1 << 20, 1 << 20, 1 << 20, 1 << 20, 1,
                                     None, 0, 1 << 20, 1 << 20, None) == -22   # row stride < A
+
+
+def test_slab_optimizer_validates_on_the_host(lib):
+    """aa_rmsprop_step_slabs rejects segment tables it cannot walk before any launch."""
+    P = 1 << 20
+
+    def call(g, n=4096):
+        return lib.aa_rmsprop_step_slabs(P, P, P, None, None, n, 1e-3, 0.9, 0.0, 1e-7, None,
+                                         ctypes.byref(g), None)
+
+    def seg(splits=64, mn=256, n_tail=16, offset=0, slab=P, n=1):
+        g = _lib.GradSlabs()
+        g.n = n
+        g.splits[0], g.mn[0], g.n_tail[0], g.offset[0], g.slab[0] = splits, mn, n_tail, offset, slab
+        return g
+    assert call(seg(n=5)) == -22                 # more than AA_MAX_GRAD_SLABS segments
+    assert call(seg(slab=None)) == -22
+    assert call(seg(mn=254)) == -22              # 16-byte items
+    assert call(seg(offset=2)) == -22
+    assert call(seg(offset=4000)) == -22         # runs past the parameter vector
+    assert call(seg(splits=8)) == -34            # not the 16-z-lane shape of the reduce launch
+    assert call(seg(mn=4 * 65536 + 4), n=1 << 20) == -34
+    two = seg(n=2)
+    two.splits[1], two.mn[1], two.n_tail[1], two.offset[1], two.slab[1] = 64, 64, 0, 128, P
+    assert call(two) == -22                      # overlapping segments
 
 
 def test_shape_qualification_is_host_side(lib):
