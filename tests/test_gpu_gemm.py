@@ -472,10 +472,14 @@ def test_dense_tail_refuses_bad_arguments(dev):
                                             w.data_ptr(), None, 0, 2, y.data_ptr(), st) != 0
     assert lib.aa_dense_small_forward_slabs(z.data_ptr(), 1, 4, 8, None, 0, z.data_ptr(), 8,
                                             w.data_ptr(), None, 0, 17, y.data_ptr(), st) != 0
+    # masks belong to the input-gradient contractions, which keep their reduce launch (a fused
+    # column sum is accepted since ABI 13: its rows follow the slabs, tests/test_gpu_opt_slabs.py)
     d = ops.gemm_desc(A=z.data_ptr(), B=w.data_ptr(), C=y.data_ptr(), M=4, N=2, K=8, lda=8, ldb=2,
-                      ldc=2, a_mode=_lib.AA_A_ROW, b_mode=_lib.AA_B_ROW, colsum_out=y.data_ptr())
+                      ldc=2, a_mode=_lib.AA_A_ROW, b_mode=_lib.AA_B_ROW, mask_src=y.data_ptr(),
+                      ldm=2, mask_kind=_lib.AA_ACT_RELU)
     sp = ctypes.c_int32(0)
     assert lib.aa_gemm_f32_slabs(ctypes.byref(d), None, 0, ctypes.byref(sp), st) != 0
+    assert lib.aa_gemm_f32_slabs(None, None, 0, ctypes.byref(sp), st) != 0
     torch.cuda.synchronize()
 
 
