@@ -107,6 +107,11 @@ class DqnAgent(tf_agent.TFAgent):
         self._reward_scale_factor = reward_scale_factor
         self._gradient_clipping = gradient_clipping
         self._target_update_tau = target_update_tau
+        # Early target forward (utils/graph.py: GraphedTrain): what a target forward computed ahead
+        # of its train step depends on besides the batch -- writes of theta_target by this agent,
+        # and launches outside the graphs that overwrite the target network's activation slot
+        self._target_writes = 0
+        self._target_fwd_epoch = 0
         self._update_target = self._get_target_updater(target_update_tau, target_update_period)
         self._seed = seed
         policy, collect_policy = self._setup_policy(time_step_spec, action_spec,
@@ -165,6 +170,7 @@ class DqnAgent(tf_agent.TFAgent):
 
     def _get_target_updater(self, tau=1.0, period=1):
         def update():
+            self._target_writes += 1
             out = common.soft_variables_update(self._q_network.flat_params,
                                                self._target_q_network.flat_params, tau)
             self._refresh_prepared(self._target_q_network)
@@ -189,6 +195,7 @@ class DqnAgent(tf_agent.TFAgent):
 
     def post_replicated_state_update(self):
         """Learner.sync_replicas calls this after broadcasting rank 0's parameters."""
+        self._target_writes += 1
         self._refresh_prepared(self._q_network)
         self._refresh_prepared(self._target_q_network)
 
@@ -223,8 +230,24 @@ class DqnAgent(tf_agent.TFAgent):
                 "common.element_wise_squared_loss (the fused loss kernel implements those two)")
         return kind
 
+    def _early_target_key(self):
+        """Changes whenever a target forward computed earlier (GraphedTrain's early target
+        forward) may have gone stale: theta_target written by this agent or by a torch op, or the
+        target network's `train` activation slot overwritten by an un-captured launch."""
+        return (self._target_writes, self._target_fwd_epoch,
+                self._target_q_network.flat_params._version)
+
+    def _train_phase_target(self, experience):
+        """The target network's forward on the batch's LAST observation, alone: depends on the
+        batch and on theta_target only, not on the optimizer step in front of the train step that
+        consumes it (`_train_phase_grads(..., q_next_target=...)`)."""
+        obs = experience.observation
+        if self._observation_and_action_constraint_splitter is not None:
+            obs, _ = self._observation_and_action_constraint_splitter(obs)
+        return self._target_q_network.forward(obs[:, -1], slot="train")
+
     def _forward_and_loss(self, experience, td_errors_loss_fn, gamma, reward_scale_factor, weights,
-                          need_grad):
+                          need_grad, q_next_target=None):
         obs = experience.observation
         mask = None
         if self._observation_and_action_constraint_splitter is not None:
@@ -239,9 +262,17 @@ class DqnAgent(tf_agent.TFAgent):
         # target one on a side stream so the two overlap (fork / join, also under graph capture).
         main = torch.cuda.current_stream(dev)
         side = self._side_stream(dev)
-        if side is None:
+        forked = False
+        if q_next_target is not None:
+            pass    # computed ahead of this step (GraphedTrain's early target forward)
+        elif side is None:
+            if not graph.capturing():
+                self._target_fwd_epoch += 1
             q_next_target = self._target_q_network.forward(obs_next, slot="train")
         else:
+            if not graph.capturing():
+                self._target_fwd_epoch += 1
+            forked = True
             if hasattr(self._target_q_network, "prepare_forward"):
                 self._target_q_network.prepare_forward(obs_next.shape[0], slot="train")
             side.wait_stream(main)
@@ -251,7 +282,7 @@ class DqnAgent(tf_agent.TFAgent):
         q_next_select = None
         if self._double_q:
             q_next_select = self._q_network.forward(obs_next, slot="next")
-        if side is not None:
+        if forked:
             main.wait_stream(side)
         next_mask = None
         if mask is not None:
@@ -329,11 +360,13 @@ class DqnAgent(tf_agent.TFAgent):
     # The train step is split in three so that it can be replayed from HIP graphs
     # (agents_amd/utils/graph.py): two capturable device phases around the gradient hook (the
     # Learner's RCCL all-reduce) and a host phase (counters, periodic target update).
-    def _train_phase_grads(self, experience, weights):
-        """forward(s) + loss + backward (+ regulariser, clipping): fills flat_grads."""
+    def _train_phase_grads(self, experience, weights, q_next_target=None):
+        """forward(s) + loss + backward (+ regulariser, clipping): fills flat_grads.
+        `q_next_target`: the output of `_train_phase_target` on this batch, already computed."""
         net = self._q_network
         w = self._forward_and_loss(experience, self._td_errors_loss_fn, self._gamma,
-                                   self._reward_scale_factor, weights, need_grad=True)
+                                   self._reward_scale_factor, weights, need_grad=True,
+                                   q_next_target=q_next_target)
         # head_done only exists in networks that exposed `fusable_head` (Sequential): a q_network
         # with the plain backward(dout, slot, side_stream, stop_layer) contract never sees it
         extra = {"head_done": True} if w.head_done else {}
@@ -361,10 +394,11 @@ class DqnAgent(tf_agent.TFAgent):
         k = net.dense_tail_start()
         return k if 0 < k < len(net._param_layers) else None
 
-    def _train_phase_grads_a(self, experience, weights):
+    def _train_phase_grads_a(self, experience, weights, q_next_target=None):
         net = self._q_network
         w = self._forward_and_loss(experience, self._td_errors_loss_fn, self._gamma,
-                                   self._reward_scale_factor, weights, need_grad=True)
+                                   self._reward_scale_factor, weights, need_grad=True,
+                                   q_next_target=q_next_target)
         self._bucket_B = w.dq.shape[0]
         extra = {"head_done": True} if w.head_done else {}
         net.backward(w.dq, slot="train", side_stream=self._side_stream(w.dq.device),
@@ -449,6 +483,7 @@ class DqnAgent(tf_agent.TFAgent):
         graph.join_lanes(self._q_network.flat_params.device)
         self._q_network.flat_params.copy_(sd["q"])
         self._target_q_network.flat_params.copy_(sd["target"])
+        self._target_writes += 1
         self._train_step_counter.assign(sd["train_step"])
         self._update_target._counter = int(sd.get("target_update_calls", 0))
         if sd.get("optimizer") is not None and self._optimizer is not None:

@@ -52,6 +52,12 @@ _HOIST = os.environ.get("AA_HOIST_PREP", "3")
 HOIST_PREP = _HOIST != "0"
 _HOIST_FWD = _HOIST in ("1", "2")
 _HOIST_BWD = _HOIST in ("1", "3")
+# AA_DX_PREP_LATE=1 (default): the backward pre-passes fork from the start of the backward pass but
+# are RECORDED behind the first input-gradient launch, so that under graph capture the chain's
+# first kernel -- not a pre-pass -- is the first child of the loss node and stays on its queue
+# (rocprofv3 timeline: fc1's dX ran on another hardware queue than the loss before it and conv3's
+# dX after it, ~10 us of cross-queue hand-over each way)
+DX_PREP_LATE = os.environ.get("AA_DX_PREP_LATE", "1") != "0"
 # (The pre-passes on the weight-gradient side stream instead of a stream of their own: 0.427 vs
 # 0.360 ms -- the join in front of the first conv dX then also waits for fc1's weight gradient.)
 
@@ -631,9 +637,11 @@ class Sequential(network.Network):
                                       self._kviews[pi + 1], nxt.stride, ws)
         return list(s.pair_prep)
 
-    def _hoist_dx_prep(self, s, B, hi, lo):
+    def _hoist_dx_prep(self, s, B, hi, lo, fork_event=None):
         """Same for the conv input gradients of layers lo..hi of this backward pass: True when
-        something was issued (the caller joins the prep stream before the first of them)."""
+        something was issued (the caller joins the prep stream before the first of them).
+        `fork_event`: the prep stream forks from that (earlier) point of the caller's stream
+        instead of from its current one."""
         if not (HOIST_PREP and _HOIST_BWD):
             return False
         dev = self.flat_params.device
@@ -653,7 +661,10 @@ class Sequential(network.Network):
         if not todo:
             return False
         prep = self._prep(dev)
-        prep.wait_stream(torch.cuda.current_stream(dev))
+        if fork_event is not None:
+            prep.wait_event(fork_event)
+        else:
+            prep.wait_stream(torch.cuda.current_stream(dev))
         with ops.side_line(prep):
             for i in todo:
                 ops.conv_dx_prepare((B,) + tuple(self._info[i][2]), self._kviews[i],
@@ -869,7 +880,23 @@ class Sequential(network.Network):
             side_stream = main
 
         pw_dx = self._pw["dx"] if (self._prepared_ok() and self._pw["dx"]) else None
-        dx_prep_pending = False if pw_dx is not None else self._hoist_dx_prep(s, B, hi, lo)
+        # the pre-passes of the conv input gradients below: issued now, or (DX_PREP_LATE) forked
+        # from here but recorded behind the first input-gradient launch of the chain
+        prep_fork = None
+        late_prep = (pw_dx is None and DX_PREP_LATE and HOIST_PREP and _HOIST_BWD and hi > lo and
+                     isinstance(self._param_layers[hi], L.Dense) and hi > 0)
+        if late_prep:
+            prep_fork = torch.cuda.Event()
+            prep_fork.record(main)
+            dx_prep_pending = False
+        else:
+            dx_prep_pending = False if pw_dx is not None else self._hoist_dx_prep(s, B, hi, lo)
+
+        def issue_late_prep():
+            nonlocal prep_fork, dx_prep_pending
+            if prep_fork is not None:
+                dx_prep_pending = self._hoist_dx_prep(s, B, hi, lo, fork_event=prep_fork)
+                prep_fork = None
 
         def on_side(fn, fork=True):
             if side_stream is main:
@@ -909,6 +936,7 @@ class Sequential(network.Network):
                     ops.dense_small_backward(x, dz2, self._kviews[i], s.dxs[i].view(B, -1),
                                              self._gkviews[i], mask_src=x if prev_act else None,
                                              mask_act=prev_act, bias_grad=self._gbviews[i])
+                    issue_late_prep()
                     dz = s.dxs[i]
                     continue
                 if i > 0:
@@ -917,6 +945,7 @@ class Sequential(network.Network):
                         side_stream.wait_stream(main) if side_stream is not main else None
                     ops.dense_dx(dz2, self._kviews[i], dx, mask_src=x if prev_act else None,
                                  mask_act=prev_act)
+                    issue_late_prep()
                     dz_next = s.dxs[i]
                 if param_grads:
                     if dz2.shape[1] <= ops.SMALL_N and SMALL_HEAD_ON_MAIN:
@@ -935,6 +964,7 @@ class Sequential(network.Network):
                     raise NotImplementedError("input_grad is implemented for a Dense first layer")
                 dz_next = None
                 if i > 0:
+                    issue_late_prep()
                     if DX_FIRST:
                         side_stream.wait_stream(main) if side_stream is not main else None
                     prepared = s.dx_prep.get(i) if (s.dx_prep and HOIST_PREP) else None
@@ -962,6 +992,7 @@ class Sequential(network.Network):
                         on_side(dw, fork=not (DX_FIRST and i > 0))
                 if dz_next is not None:
                     dz = dz_next
+        issue_late_prep()
         if dx_prep_pending:
             main.wait_stream(self._prep_stream)
         if pending_dw is not None and pending_dw.items:

@@ -57,6 +57,18 @@ def on_replay(fn):
 APPLY_EAGER = os.environ.get("AA_APPLY_EAGER", "1") != "0"
 
 
+# A/B knob AA_EARLY_TARGET: with overlap on, GraphedTrain runs the target network's forward of the
+# NEXT train step right behind the gradient graph of this one, next to the optimizer launch (see
+# GraphedTrain._issue_early_target).  0 = off; "side" (default) = on the agent's side stream,
+# "new" = on a stream of its own, "S" = on the sample lane's stream.  Same box, 400 iterations,
+# two alternating rounds (DQN configs[1]): off 0.3458 ms, side 0.3319, new 0.3318, S 0.3771 (the
+# sample lane shares a hardware queue with the collect lane: the next collect step queues up
+# behind the early forward).
+EARLY_TARGET = os.environ.get("AA_EARLY_TARGET", "side")
+if EARLY_TARGET in ("1", "on", "true"):
+    EARLY_TARGET = "side"
+
+
 class Lanes:
     """Opt-in overlap of the three graphs on separate HIP streams (`enable_overlap(device)`).
 
@@ -90,16 +102,19 @@ class Lanes:
         self.collect_done = None
         self.sample_done = None
         self.ready = {}          # first-leaf data_ptr of a sampler ring slot -> ready Event
+        self.ready_seq = {}      # ... -> number of the draw that last filled the slot
+        self.n_draws = 0
+        self.aux_done = None     # last work issued on a lane besides collect / sample (early target)
         # Events are recycled round robin (creating and destroying four per iteration showed in
         # the host profile of the loop).  A holder of a recycled event waits for its NEWER record,
         # i.e. for more than it asked for -- never for less, and never for work enqueued after
-        # the waiter -- 64 records (16 iterations) after it was handed out.
-        self._pool = [torch.cuda.Event() for _ in range(64)]
+        # the waiter -- 128 records (about 20 iterations) after it was handed out.
+        self._pool = [torch.cuda.Event() for _ in range(128)]
         self._pool_i = 0
 
     def event_on(self, stream):
         ev = self._pool[self._pool_i]
-        self._pool_i = (self._pool_i + 1) & 63
+        self._pool_i = (self._pool_i + 1) & 127
         ev.record(stream)
         return ev
 
@@ -119,6 +134,8 @@ class Lanes:
             cur.wait_event(self.collect_done)
         if self.sample_done is not None:
             cur.wait_event(self.sample_done)
+        if self.aux_done is not None:
+            cur.wait_event(self.aux_done)
 
 
 _LANES = {}
@@ -139,8 +156,9 @@ def enable_overlap(device=None):
         if lanes is None:
             lanes = Lanes(torch.device("cuda", key[1]))
         else:
-            lanes.collect_done = lanes.sample_done = None
+            lanes.collect_done = lanes.sample_done = lanes.aux_done = None
             lanes.ready = {}
+            lanes.ready_seq = {}
         _LANES[key] = lanes
     return _LANES[key]
 
@@ -315,6 +333,11 @@ class _Entry:
         self.captured = None      # _Captured, whole mode (part (a) when the agent splits it)
         self.captured_b = None    # _Captured, whole mode, part (b)
         self.out = None
+        # early target forward (ring-slot entries of agents with `_train_phase_target`)
+        self.ptr0 = None          # first-leaf address of the batch this entry reads in place
+        self.g_target = None      # _Captured: the target network's forward on this entry's batch
+        self.g_grads_nt = None    # _Captured: g_grads without the target forward (reads g_target's)
+        self.apply_state_nt = None
 
 
 def _sig(experience, weights):
@@ -366,6 +389,14 @@ class GraphedTrain:
         self._whole = not self._phases and hasattr(agent, "_graph_train_whole")
         self.enabled = self._phases or self._whole
         self.replays = 0
+        # early target forward (phase mode, overlap on, batches in sampler ring slots)
+        self._succ = {}          # entry -> entry of the call that followed it (the ring is cyclic)
+        self._prev_entry = None
+        self._early = None       # (entry, done event, agent._early_target_key(), draw number)
+        self._early_stream = None
+        self._early_sized = False
+        self.early_hits = 0
+        self.early_issued = 0
 
     @property
     def agent(self):
@@ -381,16 +412,27 @@ class GraphedTrain:
         if sampler is not None and len(bound) < _MAX_BINDINGS:
             # a sampler ring slot: one graph per slot of that ring, all captured now
             join_lanes(dev)
+            in_order = []
             with capture_batch():
                 for exp_k in sampler.ring_experiences():
                     pk = tuple(t.data_ptr() for t in nest_utils.flatten(exp_k))
+                    if pk in bound:
+                        in_order.append(bound[pk])
                     if pk in bound or _sig(exp_k, weights) != sig or \
                             len(bound) >= _MAX_BINDINGS:
                         continue
                     ek = _Entry()
-                    self._capture(ek, exp_k, weights, clone=False, g_apply=shared_apply)
+                    ek.ptr0 = pk[0]
+                    self._capture(ek, exp_k, weights, clone=False, g_apply=shared_apply,
+                                  ring=True)
                     shared_apply = ek.g_apply
                     bound[pk] = ek
+                    in_order.append(ek)
+            if len(in_order) == len(sampler.ring_experiences()):
+                # the dataset hands the slots out in ring order: each entry's successor is known
+                # from the start (a call that breaks the order re-learns it, _issue_early_target)
+                for a, b in zip(in_order, in_order[1:] + in_order[:1]):
+                    self._succ.setdefault(a, b)
             e = bound.get(ptrs)
             if e is not None:
                 return e
@@ -452,6 +494,18 @@ class GraphedTrain:
                 self._fast[id(experience)] = (experience, e, dev, ptr0, True)   # keeps it alive
         with _device_ctx(dev):
             lanes = _LANES.get((dev.type, dev.index)) if _LANES else None
+            use_early = False
+            early, self._early = self._early, None
+            if early is not None:
+                # whatever this call launches comes after the early forward's writes (the target
+                # network's activation slot, its output); its result is used only if it was made
+                # for THIS entry, from the draw the slot still holds, and nothing it depends on
+                # has been written since
+                torch.cuda.current_stream(dev).wait_event(early[1])
+                use_early = (early[0] is e and lanes is not None and e.g_grads_nt is not None
+                             and early[2] == agent._early_target_key()
+                             and early[3] == lanes.ready_seq.get(ptr0))
+                self.early_hits += int(use_early)
             if lanes is not None:
                 ev = lanes.ready.get(ptr0)
                 if ev is not None:       # the draw that filled this ring slot (on lane S)
@@ -491,29 +545,34 @@ class GraphedTrain:
                 # all-reduce of the tail's gradients -> [conv backward] overlaps it -> all-reduce
                 # of the (small) head -> wait for both -> optimizer
                 tail, head = agent._q_network.grad_buckets(agent._bucket_split())
-                e.g_grads.replay()
+                (e.g_grads_nt if use_early else e.g_grads).replay()
                 w1 = agent.gradient_hook_async(tail)
                 e.g_grads_b.replay()
+                grads_done = self._early_mark(lanes, dev)
                 w2 = agent.gradient_hook_async(head)
                 w1.wait()
                 w2.wait()
                 if lanes is not None and lanes.collect_done is not None:
                     torch.cuda.current_stream(dev).wait_event(lanes.collect_done)
                 if hasattr(agent, "_set_apply_state"):
-                    agent._set_apply_state(e.apply_state)
+                    agent._set_apply_state(e.apply_state_nt if use_early else e.apply_state)
                 e.g_apply.replay()
+                tw = getattr(agent, "_target_writes", None)
                 agent._train_phase_host()
+                self._issue_early_target(e, lanes, dev, grads_done,
+                                         getattr(agent, "_target_writes", None) != tw)
             else:
                 _mark("train.begin")
-                e.g_grads.replay()
+                (e.g_grads_nt if use_early else e.g_grads).replay()
                 _mark("train.grads_done")
+                grads_done = self._early_mark(lanes, dev)
                 if agent.gradient_hook is not None:
                     agent.gradient_hook(agent._q_network.flat_grads)
                 if lanes is not None and lanes.collect_done is not None:
                     # the optimizer overwrites theta_k: the collect policy's forward must be done
                     torch.cuda.current_stream(dev).wait_event(lanes.collect_done)
                 if hasattr(agent, "_set_apply_state"):
-                    agent._set_apply_state(e.apply_state)
+                    agent._set_apply_state(e.apply_state_nt if use_early else e.apply_state)
                 if APPLY_EAGER:
                     # the optimizer phase is one or two launches: issued directly they follow the
                     # gradient graph without a second graph-launch boundary on the critical stream
@@ -521,11 +580,88 @@ class GraphedTrain:
                 else:
                     e.g_apply.replay()
                 _mark("train.apply_done")
+                tw = getattr(agent, "_target_writes", None)
                 agent._train_phase_host()
+                self._issue_early_target(e, lanes, dev, grads_done,
+                                         getattr(agent, "_target_writes", None) != tw)
         self.replays += 1
         return e.out
 
-    def _capture(self, e, experience, weights, clone=True, g_apply=None):
+    # ---- early target forward ---------------------------------------------------------------
+    # The target network's forward of train(k+1) reads the batch of step k+1 (drawn `prefetch`
+    # iterations ago) and theta_target -- nothing the optimizer step of train(k) writes.  Its own
+    # graph per ring slot, it is launched on a lane right behind the gradient graph of train(k):
+    # it runs next to the optimizer launch and through the boundary between the iterations, where
+    # the device otherwise executes one memory-bound kernel, and train(k+1) replays its gradient
+    # graph WITHOUT the target forward.  Which batch train(k+1) will get is predicted from the
+    # order the entries came in last time (a sampler ring is cyclic); a wrong guess, a target
+    # update or an eager launch in between only cost the early forward (the full graph replays).
+    def _early_mark(self, lanes, dev):
+        """Event on the caller's stream behind the gradient graph (its loss launch has consumed
+        the target output of THIS step), or None when early target forwards are off."""
+        if lanes is None or EARLY_TARGET == "0" or \
+                not hasattr(self._agent, "_train_phase_target"):
+            return None
+        return lanes.main_frontier()
+
+    def _early_target_stream(self, lanes, dev):
+        if EARLY_TARGET == "side" and getattr(self._agent, "_side_stream", None) is not None:
+            st = self._agent._side_stream(dev)
+            if st is not None:
+                return st
+        if EARLY_TARGET == "new":
+            if self._early_stream is None:
+                self._early_stream = torch.cuda.Stream(dev)
+            return self._early_stream
+        return lanes.S
+
+    def _issue_early_target(self, e, lanes, dev, grads_done, target_written):
+        prev, self._prev_entry = self._prev_entry, e
+        if prev is not None:
+            self._succ[prev] = e
+        if lanes is None or grads_done is None or EARLY_TARGET == "0":
+            return
+        nxt = self._succ.get(e)
+        if nxt is None or nxt.g_target is None or nxt.ptr0 is None:
+            return
+        seq = lanes.ready_seq.get(nxt.ptr0)
+        rdy = lanes.ready.get(nxt.ptr0)
+        if seq is None or rdy is None:
+            return
+        st = self._early_target_stream(lanes, dev)
+        st.wait_event(grads_done)
+        if target_written:       # theta_target was updated behind the optimizer step, on this stream
+            st.wait_event(lanes.main_frontier())
+        st.wait_event(rdy)
+        with torch.cuda.stream(st):
+            _mark("early_target.begin", st)
+            nxt.g_target.replay()
+            done = lanes.event_on(st)
+            _mark("early_target.done", st)
+        lanes.aux_done = done
+        self._early = (nxt, done, self._agent._early_target_key(), seq)
+        self.early_issued += 1
+
+    def _capture_early(self, e, bucketed):
+        """Per ring slot: the target forward alone, and the gradient phase that reads its output."""
+        from agents_amd import ops
+        agent = self._agent
+        dev = e.static_in.discount.device
+        with ops.workspace_scope(("early_target", id(self)), dev):
+            if not self._early_sized:
+                # one un-captured pass sizes this scope's scratch (it must not grow in a capture)
+                agent._train_phase_target(e.static_in)
+                agent._target_fwd_epoch += 1
+                self._early_sized = True
+            gt = _Captured("train.target")
+            q_t = gt.capture(lambda: agent._train_phase_target(e.static_in))
+        phase = agent._train_phase_grads_a if bucketed else agent._train_phase_grads
+        gn = _Captured("train.grads")
+        gn.capture(lambda: phase(e.static_in, None, q_next_target=q_t))
+        e.apply_state_nt = agent._apply_state() if hasattr(agent, "_apply_state") else None
+        e.g_target, e.g_grads_nt = gt, gn
+
+    def _capture(self, e, experience, weights, clone=True, g_apply=None, ring=False):
         """Records the entry's graphs.  Host bookkeeping the phases do through `on_replay` (the
         optimizer's `iterations` mirror) is collected as replay hooks, and `capturing()` is true
         throughout, so nothing in the phases waits on un-captured events (join_lanes is a no-op)."""
@@ -568,6 +704,10 @@ class GraphedTrain:
                 e.g_apply = _Captured("train.apply")
                 e.g_apply.has_state = e.apply_state is not None
                 e.g_apply.capture(agent._train_phase_apply)
+            if ring and not clone and weights is None and EARLY_TARGET != "0" and \
+                    hasattr(agent, "_train_phase_target") and \
+                    hasattr(agent, "_early_target_key"):
+                self._capture_early(e, bucketed)
 
     def static_inputs(self, experience_like=None):
         """Static input nest of the (single) captured signature, or None before capture."""
@@ -673,6 +813,9 @@ class GraphedSampler:
                 if lanes.collect_done is not None:
                     lanes.S.wait_event(lanes.collect_done)
                 lanes.S.wait_event(lanes.main_frontier())
+                if lanes.aux_done is not None:
+                    # an early target forward may still be reading the slot this draw overwrites
+                    lanes.S.wait_event(lanes.aux_done)
                 with torch.cuda.stream(lanes.S):
                     _mark("sample.begin", lanes.S)
                     if stamped is not None:
@@ -683,6 +826,8 @@ class GraphedSampler:
                     lanes.sample_done = lanes.event_on(lanes.S)
                     _mark("sample.done", lanes.S)
                 lanes.ready[self._ptr0[slot]] = lanes.sample_done
+                lanes.n_draws += 1
+                lanes.ready_seq[self._ptr0[slot]] = lanes.n_draws
         self.replays += 1
         return out
 

@@ -34,19 +34,23 @@ def main():
     ap.add_argument("var")
     ap.add_argument("a")
     ap.add_argument("b")
+    ap.add_argument("more", nargs="*", help="further values of the toggle (round robin with a, b)")
     ap.add_argument("--pairs", type=int, default=3)
     ap.add_argument("--steps", type=int, default=400)
     args = ap.parse_args()
-    res = {args.a: [], args.b: []}
+    vals = [args.a, args.b] + list(args.more)
+    res = {v: [] for v in vals}
     for _ in range(args.pairs):
-        for v in (args.a, args.b):
+        for v in vals:
             ms = run(args.var, v, args.steps)
             res[v].append(ms)
             print(f"{args.var}={v}: {ms:.4f} ms", flush=True)
     ma, mb = (sum(res[v]) / len(res[v]) for v in (args.a, args.b))
-    print(json.dumps({"var": args.var, args.a: res[args.a], args.b: res[args.b],
-                      "mean_" + args.a: ma, "mean_" + args.b: mb,
-                      "b_over_a": mb / ma}))
+    out = {"var": args.var, "mean_" + args.a: ma, "mean_" + args.b: mb, "b_over_a": mb / ma}
+    for v in vals:
+        out[v] = res[v]
+        out["mean_" + v] = sum(res[v]) / len(res[v])
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":
