@@ -63,7 +63,10 @@ APPLY_EAGER = os.environ.get("AA_APPLY_EAGER", "1") != "0"
 # "new" = on a stream of its own, "S" = on the sample lane's stream.  Same box, 400 iterations,
 # two alternating rounds (DQN configs[1]): off 0.3458 ms, side 0.3319, new 0.3318, S 0.3771 (the
 # sample lane shares a hardware queue with the collect lane: the next collect step queues up
-# behind the early forward).
+# behind the early forward).  Tried and removed: the early forward in stream order on the caller's
+# stream behind the gradient graph with the OPTIMIZER launch moved to the side stream instead
+# (no event hand-over in front of the forward): 0.4351 vs 0.3639 ms, three alternating pairs --
+# the forward then took 107 us and the optimizer step ended 59 us after the gradients.
 EARLY_TARGET = os.environ.get("AA_EARLY_TARGET", "side")
 if EARLY_TARGET in ("1", "on", "true"):
     EARLY_TARGET = "side"
@@ -494,6 +497,7 @@ class GraphedTrain:
                 self._fast[id(experience)] = (experience, e, dev, ptr0, True)   # keeps it alive
         with _device_ctx(dev):
             lanes = _LANES.get((dev.type, dev.index)) if _LANES else None
+            cur = torch.cuda.current_stream(dev)     # (looked up once: ~2 us of host time each)
             use_early = False
             early, self._early = self._early, None
             if early is not None:
@@ -501,7 +505,7 @@ class GraphedTrain:
                 # network's activation slot, its output); its result is used only if it was made
                 # for THIS entry, from the draw the slot still holds, and nothing it depends on
                 # has been written since
-                torch.cuda.current_stream(dev).wait_event(early[1])
+                cur.wait_event(early[1])
                 use_early = (early[0] is e and lanes is not None and e.g_grads_nt is not None
                              and early[2] == agent._early_target_key()
                              and early[3] == lanes.ready_seq.get(ptr0))
@@ -509,7 +513,7 @@ class GraphedTrain:
             if lanes is not None:
                 ev = lanes.ready.get(ptr0)
                 if ev is not None:       # the draw that filled this ring slot (on lane S)
-                    torch.cuda.current_stream(dev).wait_event(ev)
+                    cur.wait_event(ev)
                 else:
                     lanes.join()
             if not in_place:
@@ -532,7 +536,7 @@ class GraphedTrain:
                 e.captured.replay()
                 _mark("train.part_a_done")
                 if lanes is not None and lanes.collect_done is not None:
-                    torch.cuda.current_stream(dev).wait_event(lanes.collect_done)
+                    cur.wait_event(lanes.collect_done)
                 _mark("train.part_b_begin")
                 e.captured_b.replay()
                 _mark("train.apply_done")
@@ -548,12 +552,12 @@ class GraphedTrain:
                 (e.g_grads_nt if use_early else e.g_grads).replay()
                 w1 = agent.gradient_hook_async(tail)
                 e.g_grads_b.replay()
-                grads_done = self._early_mark(lanes, dev)
+                grads_done = self._early_mark(lanes, cur)
                 w2 = agent.gradient_hook_async(head)
                 w1.wait()
                 w2.wait()
                 if lanes is not None and lanes.collect_done is not None:
-                    torch.cuda.current_stream(dev).wait_event(lanes.collect_done)
+                    cur.wait_event(lanes.collect_done)
                 if hasattr(agent, "_set_apply_state"):
                     agent._set_apply_state(e.apply_state_nt if use_early else e.apply_state)
                 e.g_apply.replay()
@@ -565,12 +569,12 @@ class GraphedTrain:
                 _mark("train.begin")
                 (e.g_grads_nt if use_early else e.g_grads).replay()
                 _mark("train.grads_done")
-                grads_done = self._early_mark(lanes, dev)
+                grads_done = self._early_mark(lanes, cur)
                 if agent.gradient_hook is not None:
                     agent.gradient_hook(agent._q_network.flat_grads)
                 if lanes is not None and lanes.collect_done is not None:
                     # the optimizer overwrites theta_k: the collect policy's forward must be done
-                    torch.cuda.current_stream(dev).wait_event(lanes.collect_done)
+                    cur.wait_event(lanes.collect_done)
                 if hasattr(agent, "_set_apply_state"):
                     agent._set_apply_state(e.apply_state_nt if use_early else e.apply_state)
                 if APPLY_EAGER:
@@ -596,13 +600,13 @@ class GraphedTrain:
     # graph WITHOUT the target forward.  Which batch train(k+1) will get is predicted from the
     # order the entries came in last time (a sampler ring is cyclic); a wrong guess, a target
     # update or an eager launch in between only cost the early forward (the full graph replays).
-    def _early_mark(self, lanes, dev):
+    def _early_mark(self, lanes, cur):
         """Event on the caller's stream behind the gradient graph (its loss launch has consumed
         the target output of THIS step), or None when early target forwards are off."""
         if lanes is None or EARLY_TARGET == "0" or \
                 not hasattr(self._agent, "_train_phase_target"):
             return None
-        return lanes.main_frontier()
+        return lanes.event_on(cur)
 
     def _early_target_stream(self, lanes, dev):
         if EARLY_TARGET == "side" and getattr(self._agent, "_side_stream", None) is not None:

@@ -974,7 +974,8 @@ def main():
             rows.append({k: t0.elapsed_time(v) * 1e3 for k, v in b.items()})
         if rows:
             keys = ["collect.begin", "collect.done", "sample.begin", "sample.done", "train.begin",
-                    "train.grads_done", "train.apply_done"]
+                    "train.grads_done", "train.apply_done", "early_target.begin",
+                    "early_target.done"]
             log("[bench] GPU timeline of an iteration, us after the previous optimizer step "
                 "(mean over %d): " % len(rows) +
                 ", ".join(f"{k} {sum(r[k] for r in rows if k in r) / len(rows):.0f}"
