@@ -66,7 +66,11 @@ APPLY_EAGER = os.environ.get("AA_APPLY_EAGER", "1") != "0"
 # behind the early forward).  Tried and removed: the early forward in stream order on the caller's
 # stream behind the gradient graph with the OPTIMIZER launch moved to the side stream instead
 # (no event hand-over in front of the forward): 0.4351 vs 0.3639 ms, three alternating pairs --
-# the forward then took 107 us and the optimizer step ended 59 us after the gradients.
+# the forward then took 107 us and the optimizer step ended 59 us after the gradients; the early
+# forward on a HIGH-priority stream of its own (0.973 vs 0.318 ms); a step on an early forward
+# replaying its gradient phase as two graphs, online forward | loss + backward behind the early
+# forward's event, so that the online forward need not wait for it (0.3277 vs 0.3232 ms, three
+# pairs: the second graph launch costs the host and the stream more than the wait).
 EARLY_TARGET = os.environ.get("AA_EARLY_TARGET", "side")
 if EARLY_TARGET in ("1", "on", "true"):
     EARLY_TARGET = "side"
@@ -139,6 +143,24 @@ class Lanes:
             cur.wait_event(self.sample_done)
         if self.aux_done is not None:
             cur.wait_event(self.aux_done)
+
+
+class _on_stream:
+    """`with torch.cuda.stream(s):` for a caller that knows the stream it is on and stays on one
+    device: two set_stream calls instead of the context manager's device and current-stream
+    queries (the loop enters a lane three times per iteration; ~6 us of host time each)."""
+    __slots__ = ("s", "prev")
+
+    def __init__(self, s, prev):
+        self.s, self.prev = s, prev
+
+    def __enter__(self):
+        torch.cuda.set_stream(self.s)
+        return self.s
+
+    def __exit__(self, *exc):
+        torch.cuda.set_stream(self.prev)
+        return False
 
 
 _LANES = {}
@@ -563,7 +585,7 @@ class GraphedTrain:
                 e.g_apply.replay()
                 tw = getattr(agent, "_target_writes", None)
                 agent._train_phase_host()
-                self._issue_early_target(e, lanes, dev, grads_done,
+                self._issue_early_target(e, lanes, dev, cur, grads_done,
                                          getattr(agent, "_target_writes", None) != tw)
             else:
                 _mark("train.begin")
@@ -586,7 +608,7 @@ class GraphedTrain:
                 _mark("train.apply_done")
                 tw = getattr(agent, "_target_writes", None)
                 agent._train_phase_host()
-                self._issue_early_target(e, lanes, dev, grads_done,
+                self._issue_early_target(e, lanes, dev, cur, grads_done,
                                          getattr(agent, "_target_writes", None) != tw)
         self.replays += 1
         return e.out
@@ -619,7 +641,7 @@ class GraphedTrain:
             return self._early_stream
         return lanes.S
 
-    def _issue_early_target(self, e, lanes, dev, grads_done, target_written):
+    def _issue_early_target(self, e, lanes, dev, cur, grads_done, target_written):
         prev, self._prev_entry = self._prev_entry, e
         if prev is not None:
             self._succ[prev] = e
@@ -635,9 +657,9 @@ class GraphedTrain:
         st = self._early_target_stream(lanes, dev)
         st.wait_event(grads_done)
         if target_written:       # theta_target was updated behind the optimizer step, on this stream
-            st.wait_event(lanes.main_frontier())
+            st.wait_event(lanes.event_on(cur))
         st.wait_event(rdy)
-        with torch.cuda.stream(st):
+        with _on_stream(st, cur):
             _mark("early_target.begin", st)
             nxt.g_target.replay()
             done = lanes.event_on(st)
@@ -816,11 +838,12 @@ class GraphedSampler:
             else:
                 if lanes.collect_done is not None:
                     lanes.S.wait_event(lanes.collect_done)
-                lanes.S.wait_event(lanes.main_frontier())
+                cur = torch.cuda.current_stream(dev)
+                lanes.S.wait_event(lanes.event_on(cur))      # = the main frontier
                 if lanes.aux_done is not None:
                     # an early target forward may still be reading the slot this draw overwrites
                     lanes.S.wait_event(lanes.aux_done)
-                with torch.cuda.stream(lanes.S):
+                with _on_stream(lanes.S, cur):
                     _mark("sample.begin", lanes.S)
                     if stamped is not None:
                         rb.draw_into(stamped)
@@ -1002,7 +1025,8 @@ class GraphedDriverRun:
                         raise
                     c = self._graphs[slot]
                 if lanes is not None and it == 0:
-                    lanes.C.wait_event(lanes.main_frontier())
+                    cur = torch.cuda.current_stream(st.device)
+                    lanes.C.wait_event(lanes.event_on(cur))      # = the main frontier
                     if lanes.sample_done is not None:
                         lanes.C.wait_event(lanes.sample_done)
                 if self._pub != (self._epoch(), slot) or self._epoch() is None:
@@ -1010,8 +1034,8 @@ class GraphedDriverRun:
                     # step in between, an environment without `host_epoch`): post it now.  What
                     # the abandoned post had added to the device total counts as consumed.
                     self._t_counted = self._read_post()
-                    with torch.cuda.stream(lanes.C) if lanes is not None \
-                            else contextlib.nullcontext():
+                    with _on_stream(lanes.C, torch.cuda.current_stream(st.device)) \
+                            if lanes is not None else contextlib.nullcontext():
                         self._count(time_step.step_type)
                     self._seq += 1
                 if base is None:
@@ -1021,7 +1045,9 @@ class GraphedDriverRun:
                 if lanes is None:
                     time_step = c.replay()
                 else:
-                    with torch.cuda.stream(lanes.C):
+                    if it > 0:
+                        cur = torch.cuda.current_stream(st.device)
+                    with _on_stream(lanes.C, cur):
                         _mark("collect.begin", lanes.C)
                         time_step = c.replay()
                         lanes.collect_done = lanes.event_on(lanes.C)
