@@ -135,3 +135,12 @@ __device__ static inline void aa_advance_sharded(int64_t* counter, int64_t* arri
   }
 }
 
+
+// hipFuncSetAttribute (the grant of more than 64 KiB of dynamic LDS) applies to the function object
+// of the CURRENT device: the launchers' "largest size granted so far" tables are kept per device
+// ordinal, so that a process that drives a second GPU grants there too.
+#define AA_MAX_DEVICES 16
+static inline int aa_device_ordinal() {
+  int d = 0;
+  return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < AA_MAX_DEVICES) ? d : -1;
+}

@@ -401,16 +401,18 @@ static int dw6_main(const aa_conv_dx_desc* d, const float* x, int want_db, void*
 #endif
   hipStream_t st = (hipStream_t)stream;
   const int grid = P.per_xcd * 8;
-  static size_t lds_limit[5][5] = {{0}};   // > 64 KiB of dynamic LDS: granted once per kernel
+  static size_t lds_limit[AA_MAX_DEVICES][5][5] = {{{0}}};   // > 64 KiB of dynamic LDS: granted
+  const int dv = aa_device_ordinal();                          // once per kernel and device
+  if (dv < 0) return AA_ERR_LAUNCH;
   int done = 0;
 #define AA_DW6_CASE(R_, K_)                                                                     \
   if (pl.rtw == R_ && pl.ks == K_) {                                                            \
-    if (pl.lds > 65536 && pl.lds > lds_limit[R_][K_]) {                                         \
+    if (pl.lds > 65536 && pl.lds > lds_limit[dv][R_][K_]) {                                         \
       if (hipFuncSetAttribute((const void*)aa_conv_dw_frame_x6_kernel<R_, K_>,                  \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) !=       \
           hipSuccess)                                                                           \
         return AA_ERR_LAUNCH;                                                                   \
-      lds_limit[R_][K_] = pl.lds;                                                               \
+      lds_limit[dv][R_][K_] = pl.lds;                                                             \
     }                                                                                           \
     hipLaunchKernelGGL((aa_conv_dw_frame_x6_kernel<R_, K_>), dim3(grid), dim3(AA_DW6_THREADS),  \
                        pl.lds, st, P);                                                          \

@@ -220,15 +220,17 @@ int aa_conv_dx_frame(const aa_conv_dx_desc* d, void* stream) {
   P.mask = d->mask_src;
   P.mask_kind = d->mask_src != nullptr ? d->mask_kind : 0;
   int grid = d->n_img > 512 ? 512 : d->n_img;
-  static size_t lds_limit[AA_DXF_MAX_RT + 1] = {0};   // > 64 KiB of dynamic LDS: granted per kernel
+  static size_t lds_limit[AA_MAX_DEVICES][AA_DXF_MAX_RT + 1] = {{0}};   // > 64 KiB of dynamic
+  const int dv = aa_device_ordinal();                   // LDS: granted per kernel and device
+  if (dv < 0) return AA_ERR_LAUNCH;
   int done = 0;
 #define AA_DXF_CASE(R_)                                                                         \
   if (rt == R_) {                                                                               \
-    if (lds > 65536 && lds > lds_limit[R_]) {                                                   \
+    if (lds > 65536 && lds > lds_limit[dv][R_]) {                                                   \
       if (hipFuncSetAttribute((const void*)aa_conv_dx_frame_kernel<R_>,                         \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
         return AA_ERR_LAUNCH;                                                                   \
-      lds_limit[R_] = lds;                                                                      \
+      lds_limit[dv][R_] = lds;                                                                    \
     }                                                                                           \
     hipLaunchKernelGGL((aa_conv_dx_frame_kernel<R_>), dim3(grid), dim3(AA_DXF_THREADS), lds,     \
                        (hipStream_t)stream, P);                                                 \

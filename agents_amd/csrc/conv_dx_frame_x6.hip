@@ -349,15 +349,17 @@ int aa_conv_dx_frame_x6_phase(const aa_conv_dx_desc* d, void* workspace, int64_t
   }
   if (!(phases & 2)) return aa_launch_status();
   int grid = d->n_img > 512 ? 512 : d->n_img;
-  static size_t lds_limit[AA_DX6_MAX_RT + 1] = {0};   // > 64 KiB of dynamic LDS: granted per kernel
+  static size_t lds_limit[AA_MAX_DEVICES][AA_DX6_MAX_RT + 1] = {{0}};   // > 64 KiB of dynamic
+  const int dv = aa_device_ordinal();                   // LDS: granted per kernel and device
+  if (dv < 0) return AA_ERR_LAUNCH;
   int done = 0;
 #define AA_DX6_CASE(R_)                                                                         \
   if (rt == R_) {                                                                               \
-    if (lds > 65536 && lds > lds_limit[R_]) {                                                   \
+    if (lds > 65536 && lds > lds_limit[dv][R_]) {                                                   \
       if (hipFuncSetAttribute((const void*)aa_conv_dx_frame_x6_kernel<R_>,                      \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
         return AA_ERR_LAUNCH;                                                                   \
-      lds_limit[R_] = lds;                                                                      \
+      lds_limit[dv][R_] = lds;                                                                    \
     }                                                                                           \
     hipLaunchKernelGGL((aa_conv_dx_frame_x6_kernel<R_>), dim3(grid), dim3(AA_DX6_THREADS), lds,  \
                        st, P);                                                                  \

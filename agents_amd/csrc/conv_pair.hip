@@ -238,11 +238,13 @@ int aa_conv_pair_forward(const float* x, int64_t img_pitch, int32_t n_img, int32
   // row tiles per layer, rounded up to the instantiated counts {2, 4, 6, 8}
   auto up = [](int ohw) { const int t = (ohw + 15) / 16; return t <= 2 ? 2 : t <= 4 ? 4 : t <= 6 ? 6 : 8; };
   const int r0 = up(P.l[0].OH * P.l[0].OW), r1 = up(P.l[1].OH * P.l[1].OW);
-  static size_t lds_limit[16] = {0};   // dynamic LDS above 64 KiB is granted once per kernel
+  static size_t lds_limit[AA_MAX_DEVICES][16] = {{0}};   // dynamic LDS above 64 KiB is granted
+  const int dv = aa_device_ordinal();                    // once per kernel and device
+  if (dv < 0) return AA_ERR_LAUNCH;
   int rc2 = AA_ERR_INVALID;
 #define AA_CP_CASE(A_, B_)                                                                      \
   if (r0 == A_ && r1 == B_) {                                                                   \
-    size_t& lim = lds_limit[(A_ / 2 - 1) * 4 + (B_ / 2 - 1)];                                   \
+    size_t& lim = lds_limit[dv][(A_ / 2 - 1) * 4 + (B_ / 2 - 1)];                               \
     if (lds > 65536 && lds > lim) {                                                             \
       if (hipFuncSetAttribute((const void*)aa_conv_pair_kernel<A_, B_>,                         \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \

@@ -428,11 +428,13 @@ int aa_conv_pair_x6_phase(const float* x, int64_t img_pitch, int32_t n_img, int3
     const char* e = getenv("AA_CX_WAVES");      // tuning knob: 4 or 8 waves per workgroup
     nw = (e != nullptr && atoi(e) == 4) ? 4 : 8;
   }
-  static size_t lds_limit[32] = {0};   // dynamic LDS above 64 KiB is granted once per kernel
+  static size_t lds_limit[AA_MAX_DEVICES][32] = {{0}};   // dynamic LDS above 64 KiB is granted
+  const int dv = aa_device_ordinal();                    // once per kernel and device
+  if (dv < 0) return AA_ERR_LAUNCH;
   int rc2 = AA_ERR_INVALID;
 #define AA_CX_CASE(A_, B_, W_)                                                                  \
   if (r0 == A_ && r1 == B_ && nw == W_) {                                                       \
-    size_t& lim = lds_limit[((A_ / 2 - 1) * 4 + (B_ / 2 - 1)) * 2 + (W_ == 8)];                 \
+    size_t& lim = lds_limit[dv][((A_ / 2 - 1) * 4 + (B_ / 2 - 1)) * 2 + (W_ == 8)];             \
     if (lds > 65536 && lds > lim) {                                                             \
       if (hipFuncSetAttribute((const void*)aa_conv_pair_x6_kernel<A_, B_, W_>,                  \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \

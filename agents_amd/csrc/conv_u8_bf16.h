@@ -449,12 +449,14 @@ static int aa_conv_u8_dw_bf16_launch(const GemmP& p, int n_img, int frame_bytes,
                                      hipStream_t st) {
   const size_t smem = aa_conv_u8_dw_lds(p, frame_bytes);
   constexpr int NW = AA_CU8_DW_WAVES;
-  static size_t lds_limit = 0;   // dynamic LDS above 64 KiB has to be granted once per process
-  if (smem > lds_limit) {
+  static size_t lds_limit[AA_MAX_DEVICES] = {0};   // dynamic LDS above 64 KiB: granted per device
+  const int dv = aa_device_ordinal();
+  if (dv < 0) return AA_ERR_LAUNCH;
+  if (smem > lds_limit[dv]) {
     if (hipFuncSetAttribute((const void*)aa_conv_u8_dw_bf16x3_kernel<NW>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return AA_ERR_LAUNCH;
-    lds_limit = smem;
+    lds_limit[dv] = smem;
   }
   hipLaunchKernelGGL(aa_conv_u8_dw_bf16x3_kernel<NW>, dim3(groups), dim3(NW * 64), smem, st, p,
                      n_img, frame_bytes, p.colsum_out != nullptr ? 1 : 0);

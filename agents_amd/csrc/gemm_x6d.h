@@ -304,10 +304,12 @@ static int aa_x6d_launch(const GemmP& p, bool a_kc, bool b_kc, hipStream_t st) {
   const dim3 grid = p.xcd_mode != 0 ? dim3(((n + 7) / 8) * 8, 1, 1) : dim3(p.gx, p.gy, p.gz);
   const size_t smem = 2 * (size_t)AA_X6D_STAGE;      // 72 KiB
   const bool cs = p.colsum_out != nullptr;
-  static bool granted[8] = {false, false, false, false, false, false, false, false};
+  static bool granted[AA_MAX_DEVICES][8] = {{false}};   // per kernel and device
+  const int dv = aa_device_ordinal();
+  if (dv < 0) return AA_ERR_LAUNCH;
 #define AA_X6D_CASE(AKC_, BKC_, CS_)                                                              \
   if (a_kc == AKC_ && b_kc == BKC_ && cs == CS_) {                                                \
-    bool& g = granted[(AKC_ ? 4 : 0) + (BKC_ ? 2 : 0) + (CS_ ? 1 : 0)];                           \
+    bool& g = granted[dv][(AKC_ ? 4 : 0) + (BKC_ ? 2 : 0) + (CS_ ? 1 : 0)];                       \
     if (!g) {                                                                                     \
       if (hipFuncSetAttribute((const void*)aa_gemm_x6d_kernel<AKC_, BKC_, CS_>,                   \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) \
