@@ -53,14 +53,16 @@ def _needs_early():
         pytest.skip("AA_EARLY_TARGET=0")
 
 
-@pytest.mark.parametrize("cls,tau,period", [(dqn_agent.DqnAgent, 1.0, 3),
-                                            (dqn_agent.DqnAgent, 0.25, 1),
-                                            (dqn_agent.DdqnAgent, 1.0, 2)])
-def test_early_target_forward_is_bit_identical(dev, cls, tau, period):
+@pytest.mark.parametrize("cls,tau,period,ring", [(dqn_agent.DqnAgent, 1.0, 3, 8),
+                                                 (dqn_agent.DqnAgent, 0.25, 1, 8),
+                                                 (dqn_agent.DdqnAgent, 1.0, 2, 8),
+                                                 (dqn_agent.DqnAgent, 1.0, 7, 5)])
+def test_early_target_forward_is_bit_identical(dev, cls, tau, period, ring):
+    """(ring 5: another ring length than the default, shorter than two prefetch queues.)"""
     _needs_early()
     S = 16
     ag_e, rb_e, drv_e, net_e = _stack(dev, cls, 8, tau, period, dataset_ring=0)
-    ag_g, rb_g, drv_g, net_g = _stack(dev, cls, 8, tau, period)
+    ag_g, rb_g, drv_g, net_g = _stack(dev, cls, 8, tau, period, dataset_ring=ring)
     run_g = common.function(drv_g.run)
     lrn = learner.Learner(None, common.Variable(0), ag_g)
     for _ in range(4):
