@@ -59,13 +59,46 @@ union AaFrag {
 };
 
 template <int TPW, int NCH>
-__global__ void __launch_bounds__(AA_CU8_THREADS)
+__global__ void __launch_bounds__(AA_CU8_THREADS, 2)   // two workgroups per CU (400 on 256 CUs)
 aa_conv_u8_bf16x3_kernel(GemmP p, int n_super, int nch_rt) {
   extern __shared__ __attribute__((aligned(16))) uint4 wfrag[];   // [3][J][2][32]
   const int nch = NCH > 0 ? NCH : nch_rt;     // 32-byte chunks per patch = KH * seg / 32
   const int J = nch * 2;
   const int R = p.seg >> 5;
   const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const unsigned char* A = reinterpret_cast<const unsigned char*>(p.A);
+  const int per_xcd = (n_super + 7) >> 3;
+  auto chunk_off = [&](int ch) {   // R == 1 (32-byte patch rows) needs no division
+    if (R == 1) return ch * p.rowpitch;
+    const int ky = ch / R;
+    return ky * p.rowpitch + ((ch - ky * R) << 5);
+  };
+  // pixel origin of wave-tile t of super-tile slot sb (-1: nothing to do there)
+  auto tile_pix0 = [&](int sb) {
+    const int st = (sb & 7) * per_xcd + (sb >> 3);
+    if ((sb >> 3) >= per_xcd || st >= n_super) return -1;
+    const int pix0 = (st * 4 + wave) * (32 * TPW);
+    return pix0 < p.M ? pix0 : -1;
+  };
+  // The whole patch of the FIRST super-tile is requested before the filter split below: its
+  // round trip to memory runs under the split (each workgroup used to start its loads behind it).
+  uint4 a16[NCH > 0 ? NCH : 1][TPW];   // the whole patch of a tile in flight at once
+  auto request = [&](int pix0) {
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      int pix = pix0 + t * 32 + r;
+      if (pix >= p.M) pix = p.M - 1;
+      const unsigned char* sp = A + aa_pix_base(p, pix) + h * 16;
+#pragma unroll
+      for (int ch = 0; ch < (NCH > 0 ? NCH : 1); ++ch)
+        a16[ch][t] = *reinterpret_cast<const uint4*>(sp + chunk_off(ch));
+    }
+  };
+  if constexpr (NCH > 0) {
+    const int pix0 = tile_pix0(blockIdx.x);
+    if (pix0 >= 0) request(pix0);
+  }
 
   // ---- filter bank: fp32 [K][32] -> three bf16 pieces in fragment order --------------------
   for (int item = tid; item < (p.K >> 3) * 32; item += AA_CU8_THREADS) {
@@ -96,17 +129,12 @@ aa_conv_u8_bf16x3_kernel(GemmP p, int n_super, int nch_rt) {
   }
   __syncthreads();
 
-  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-  const unsigned char* A = reinterpret_cast<const unsigned char*>(p.A);
   const float bv = p.bias != nullptr ? p.bias[r] : 0.f;
   // XCD-aware: the 8 XCDs take workgroups round-robin; give each a contiguous range of pixels so
   // the 4x patch overlap of a frame is served by ONE L2.
-  const int per_xcd = (n_super + 7) >> 3;
   for (int sb = blockIdx.x; sb < per_xcd * 8; sb += gridDim.x) {
-    const int st = (sb & 7) * per_xcd + (sb >> 3);
-    if ((sb >> 3) >= per_xcd || st >= n_super) continue;
-    const int pix0 = (st * 4 + wave) * (32 * TPW);
-    if (pix0 >= p.M) continue;
+    const int pix0 = tile_pix0(sb);
+    if (pix0 < 0) continue;
     const unsigned char* src[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -122,11 +150,6 @@ aa_conv_u8_bf16x3_kernel(GemmP p, int n_super, int nch_rt) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[s][t][e] = 0.f;
 
-    auto chunk_off = [&](int ch) {   // R == 1 (32-byte patch rows) needs no division
-      if (R == 1) return ch * p.rowpitch;
-      const int ky = ch / R;
-      return ky * p.rowpitch + ((ch - ky * R) << 5);
-    };
     auto mma = [&](int ch, const uint4 (&a16)[TPW]) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -151,12 +174,7 @@ aa_conv_u8_bf16x3_kernel(GemmP p, int n_super, int nch_rt) {
     };
 
     if constexpr (NCH > 0) {
-      uint4 a16[NCH][TPW];   // the whole patch of each tile in flight at once
-#pragma unroll
-      for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-        for (int t = 0; t < TPW; ++t)
-          a16[ch][t] = *reinterpret_cast<const uint4*>(src[t] + chunk_off(ch));
+      if (sb != (int)blockIdx.x) request(pix0);   // (the first tile's: in front of the split)
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) mma(ch, a16[ch]);
     } else {
