@@ -271,7 +271,20 @@ static void aa_conv_u8_bf16_launch(const GemmP& p, hipStream_t st) {
 #define AA_CU8_DW_MAX_FRAME 32768   /* frame bytes staged in LDS */
 #define AA_CU8_DW_MAX_OHW 512       /* output pixels per frame (3 * 64 B of LDS each) */
 
-template <int NW>   // waves per workgroup; wave w owns the patch-row chunks {w, w + NW, ...}
+// gfx950's 8-bit LDS transpose read (semantics established by tools/tr8_probe.hip): the 16 lanes
+// of a group each supply the address of an 8-byte chunk; lane j receives, as element e = 0..7, byte
+// (j & 7) of the chunk supplied by lane 2e + (j >> 3).  With lane i supplying the 8 patch bytes
+// [8 (i & 1), 8 (i & 1) + 8) of pixel (i >> 1), lane j gets the byte of patch element j at the 8
+// pixels: the MFMA operand of the weight gradient (reduction index = pixel) in ONE LDS
+// instruction instead of eight ds_read_u8.  (The compiler builtin, not inline assembly: the
+// compiler then counts the read among its outstanding LDS operations and places the waits.)
+typedef int aa_i32x2_t __attribute__((ext_vector_type(2)));
+__device__ static inline aa_i32x2_t aa_ds_read_tr8(const unsigned char* lds_ptr) {
+  return __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+      (__attribute__((address_space(3))) aa_i32x2_t*)lds_ptr);
+}
+
+template <int NW, bool TR8>   // waves per workgroup; wave w owns the patch-row chunks {w, w + NW, ...}
 __global__ void __launch_bounds__(NW * 64)
 aa_conv_u8_dw_bf16x3_kernel(GemmP p, int n_img, int frame_bytes, int want_colsum) {
   constexpr int NT = NW * 64;
@@ -379,6 +392,53 @@ aa_conv_u8_dw_bf16x3_kernel(GemmP p, int n_img, int frame_bytes, int want_colsum
     }
     __syncthreads();
 
+    if constexpr (TR8) {
+      // one transpose read per fragment: this lane supplies 8 patch bytes of pixel (lane & 15) >> 1
+      // of its octet, at elements [16 ((lane >> 4) & 1) + 8 (lane & 1), + 8) of the wave's chunk
+      const int sub = (lane & 15) >> 1;
+      const int eoff = (((lane >> 4) & 1) << 4) + ((lane & 1) << 3) - r;   // toff holds + r
+      // software pipeline: the fragment of step s + 1 is requested -- its pixel origin was loaded
+      // a step earlier -- before the MFMAs of step s, the origin of step s + 2 behind it
+      const int last_o = n_oct - 2 + h;
+      auto org_of = [&](int o) { return origin[(o <= last_o ? o : last_o) * 8 + sub]; };
+      aa_i32x2_t fa[MT], fb[MT];   // two register sets: a step never copies a fragment
+      int org_nxt = org_of(h + 2);
+      {
+        const int org = org_of(h);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) fa[t] = aa_ds_read_tr8(frame + org + toff[t] + eoff);
+      }
+      auto step = [&](int o0, const aa_i32x2_t (&c)[MT], aa_i32x2_t (&n)[MT]) {
+        const int o = o0 + h;
+        AaFrag bf[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) bf[s].q = zfrag[(s * n_oct + o) * 32 + r];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) n[t] = aa_ds_read_tr8(frame + org_nxt + toff[t] + eoff);
+        org_nxt = org_of(o + 4);
+        // (the scheduler otherwise sinks the requests above behind the MFMAs below, and the
+        // next step then starts by waiting for its fragment)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          // (a wave without a live chunk computes on chunk 0 and stores nothing: no branch in
+          // the loop)
+          AaFrag af;
+          aa_u8x4_to_bf16((unsigned)c[t].x, af.q.x, af.q.y);
+          aa_u8x4_to_bf16((unsigned)c[t].y, af.q.z, af.q.w);
+#pragma unroll
+          for (int s = 0; s < 3; ++s)
+            acc[t][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, bf[s].v, acc[t][s], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (nor the next step's address arithmetic above them)
+      };
+      int o0 = 0;
+      for (; o0 + 2 < n_oct; o0 += 4) {
+        step(o0, fa, fb);
+        step(o0 + 2, fb, fa);
+      }
+      if (o0 < n_oct) step(o0, fa, fb);
+    } else
     for (int o0 = 0; o0 < n_oct; o0 += 2) {
       const int o = o0 + h;
       int base[8];   // this lane's 8 pixels
@@ -467,16 +527,28 @@ static int aa_conv_u8_dw_bf16_launch(const GemmP& p, int n_img, int frame_bytes,
                                      hipStream_t st) {
   const size_t smem = aa_conv_u8_dw_lds(p, frame_bytes);
   constexpr int NW = AA_CU8_DW_WAVES;
-  static size_t lds_limit[AA_MAX_DEVICES] = {0};   // dynamic LDS above 64 KiB: granted per device
-  const int dv = aa_device_ordinal();
+  // the transpose-read loop needs 8-byte aligned chunk addresses: pixel origins and patch rows
+  static const bool tr8_on = []() {
+    const char* e = getenv("AA_CONV1_DW_TR8");
+    return e == nullptr || atoi(e) != 0;
+  }();
+  const bool tr8 = tr8_on && (p.stride * p.Cin) % 8 == 0 && p.rowpitch % 8 == 0;
+  static size_t lds_limit[AA_MAX_DEVICES][2] = {{0}};   // dynamic LDS above 64 KiB: granted per
+  const int dv = aa_device_ordinal();                   // kernel and device
   if (dv < 0) return AA_ERR_LAUNCH;
-  if (smem > lds_limit[dv]) {
-    if (hipFuncSetAttribute((const void*)aa_conv_u8_dw_bf16x3_kernel<NW>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+  if (smem > lds_limit[dv][tr8]) {
+    const void* fn = tr8 ? (const void*)aa_conv_u8_dw_bf16x3_kernel<NW, true>
+                         : (const void*)aa_conv_u8_dw_bf16x3_kernel<NW, false>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
+        hipSuccess)
       return AA_ERR_LAUNCH;
-    lds_limit[dv] = smem;
+    lds_limit[dv][tr8] = smem;
   }
-  hipLaunchKernelGGL(aa_conv_u8_dw_bf16x3_kernel<NW>, dim3(groups), dim3(NW * 64), smem, st, p,
-                     n_img, frame_bytes, p.colsum_out != nullptr ? 1 : 0);
+  if (tr8)
+    hipLaunchKernelGGL((aa_conv_u8_dw_bf16x3_kernel<NW, true>), dim3(groups), dim3(NW * 64), smem,
+                       st, p, n_img, frame_bytes, p.colsum_out != nullptr ? 1 : 0);
+  else
+    hipLaunchKernelGGL((aa_conv_u8_dw_bf16x3_kernel<NW, false>), dim3(groups), dim3(NW * 64), smem,
+                       st, p, n_img, frame_bytes, p.colsum_out != nullptr ? 1 : 0);
   return aa_launch_status();
 }
