@@ -58,6 +58,9 @@ _HOIST_BWD = _HOIST in ("1", "3")
 # (rocprofv3 timeline: fc1's dX ran on another hardware queue than the loss before it and conv3's
 # dX after it, ~10 us of cross-queue hand-over each way)
 DX_PREP_LATE = os.environ.get("AA_DX_PREP_LATE", "1") != "0"
+# (Tried on top of it and not kept: conv3's weight gradient waiting for the fork of conv2's -- one
+# fork of the weight-gradient branch from the input-gradient chain for the pair instead of one per
+# layer, a superset of its dependencies: 0.3158 vs 0.3128 ms, three alternating pairs.)
 # (The pre-passes on the weight-gradient side stream instead of a stream of their own: 0.427 vs
 # 0.360 ms -- the join in front of the first conv dX then also waits for fc1's weight gradient.)
 
