@@ -338,17 +338,21 @@ aa_conv_u8_dw_bf16x3_kernel(GemmP p, int n_img, int frame_bytes, int want_colsum
     // fourth item fell off the end used to take the remainder loop -- one dependent round trip
     // per item, three for more than half of the workgroup at the Atari frame size)
     for (int i0 = tid; i0 < n16; i0 += 4 * NT) {
-      uint4 tv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * NT;
-        tv[u] = fsrc[i < n16 ? i : n16 - 1];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * NT;
-        if (i < n16) fdst[i] = tv[u];
-      }
+      // four requests per thread in flight, pinned in front of the stores (native vectors through
+      // an empty asm): in the transpose-read variant the compiler otherwise sinks two of them
+      // into the conditions below -- one dependent round trip each -- and parks the array on the
+      // stack (80 bytes of scratch per lane, tools/kernel_resources.py)
+      typedef unsigned aa_u32x4_t __attribute__((ext_vector_type(4)));
+      const aa_u32x4_t* vsrc = reinterpret_cast<const aa_u32x4_t*>(fsrc);
+      aa_u32x4_t* vdst = reinterpret_cast<aa_u32x4_t*>(fdst);
+      const int i1 = i0 + NT, i2 = i0 + 2 * NT, i3 = i0 + 3 * NT;
+      aa_u32x4_t t0 = vsrc[i0 < n16 ? i0 : n16 - 1], t1 = vsrc[i1 < n16 ? i1 : n16 - 1];
+      aa_u32x4_t t2 = vsrc[i2 < n16 ? i2 : n16 - 1], t3 = vsrc[i3 < n16 ? i3 : n16 - 1];
+      asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+      if (i0 < n16) vdst[i0] = t0;
+      if (i1 < n16) vdst[i1] = t1;
+      if (i2 < n16) vdst[i2] = t2;
+      if (i3 < n16) vdst[i3] = t3;
     }
     // (b) dZ rows of the frame -> three bf16 planes in fragment order (4 items = 32 loads in flight)
     const float* dz = p.B + (size_t)img * OHW * p.ldb;
