@@ -421,6 +421,12 @@ class DqnAgent(tf_agent.TFAgent):
             getattr(self._optimizer, "supports_grad_slabs", False) and \
             hasattr(net, "take_grad_slabs")
 
+    def _graph_capture_key(self):
+        """What `_train_phase_grads` decides on the host while it is recorded (GraphedTrain replays
+        an entry only under the state it was captured in): with a gradient hook installed the
+        backward pass must sum its weight gradients into flat_grads for the all-reduce."""
+        return (self.gradient_hook is None, self.gradient_hook_async is None)
+
     # GraphedTrain: the optimizer phase of an entry replays behind ITS gradient graph
     def _apply_state(self):
         net = self._q_network

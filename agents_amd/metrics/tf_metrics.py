@@ -18,6 +18,7 @@ class _Counter:
     def __init__(self, name, prefix="Metrics", dtype=torch.int64):
         self.name, self.prefix = name, prefix
         self._count = None
+        self._restore = None      # a count restored before the first call (applied on allocation)
 
     def _hit(self, traj):
         raise NotImplementedError
@@ -25,16 +26,24 @@ class _Counter:
     def __call__(self, traj):
         hit = self._hit(traj)
         if self._count is None:
-            self._count = torch.zeros((), dtype=torch.int64, device=hit.device)
+            # lazily allocated on the first trajectory's device; a checkpoint restored before that
+            # (train_eval scripts: `train_checkpointer.initialize_or_restore()` precedes the first
+            # driver run) left its count in `_restore`
+            self._count = torch.full((), int(self._restore or 0), dtype=torch.int64,
+                                     device=hit.device)
+            self._restore = None
         self._count += hit.sum()
         return traj
 
     call = __call__
 
     def result(self):
-        return 0 if self._count is None else int(self._count.item())
+        if self._count is None:
+            return int(self._restore or 0)
+        return int(self._count.item())
 
     def reset(self):
+        self._restore = None
         if self._count is not None:
             self._count.zero_()
 
@@ -42,9 +51,11 @@ class _Counter:
         return {"count": self.result()}
 
     def load_state_dict(self, sd):
-        self._restore = int(sd.get("count", 0))
+        n = int(sd.get("count", 0))
         if self._count is not None:
-            self._count.fill_(self._restore)
+            self._count.fill_(n)
+        else:
+            self._restore = n
 
     def tf_summaries(self, train_step=None, step_metrics=()):
         """Summary writers are outside the hot-path scope."""
@@ -74,12 +85,21 @@ class _EpisodeAverage:
         self.name, self.prefix = name, prefix
         self._batch_size, self._buffer_size = int(batch_size), int(buffer_size)
         self._acc = self._ring = self._pushed = None
+        self._restore = None      # a state restored before the first call (applied on allocation)
 
     def _alloc(self, dev):
         self._acc = torch.zeros((self._batch_size,), dtype=torch.float32, device=dev)
         # one spare slot at the end swallows the writes of environments that did not finish
         self._ring = torch.zeros((self._buffer_size + 1,), dtype=torch.float32, device=dev)
         self._pushed = torch.zeros((), dtype=torch.int64, device=dev)
+        if self._restore is not None:
+            sd, self._restore = self._restore, None
+            self._apply(sd)
+
+    def _apply(self, sd):
+        self._acc.copy_(torch.as_tensor(sd["acc"]).to(self._acc.device))
+        self._ring.copy_(torch.as_tensor(sd["ring"]).to(self._ring.device))
+        self._pushed.fill_(int(sd["pushed"]))
 
     def _increment(self, traj):
         raise NotImplementedError
@@ -88,25 +108,36 @@ class _EpisodeAverage:
         first, last = traj.is_first().reshape(-1), traj.is_last().reshape(-1)
         if self._acc is None:
             self._alloc(first.device)
-        self._acc.mul_((~first).to(torch.float32))
+        # reset on is_first by selection, not by a multiplication (0 * inf = nan would stick; the
+        # reference resets with tf.where, tf_metrics.py:236-240)
+        self._acc.copy_(torch.where(first, torch.zeros_like(self._acc), self._acc))
         self._acc += self._increment(traj)
-        # finished environments take consecutive ring positions in environment order
+        # finished environments take consecutive ring positions in environment order; when more
+        # finish in one step than the ring holds only the LAST `buffer_size` of them are kept (the
+        # reference's TFDeque adds them one after the other), so no two writes share a position
         rank = torch.cumsum(last.to(torch.int64), 0) - 1
-        pos = torch.where(last, (self._pushed + rank) % self._buffer_size,
+        n_last = last.sum()
+        keep = last & (rank >= n_last - self._buffer_size)
+        pos = torch.where(keep, (self._pushed + rank) % self._buffer_size,
                           torch.full_like(rank, self._buffer_size))
         self._ring.scatter_(0, pos, self._acc)
-        self._pushed += last.sum()
+        self._pushed += n_last
         return traj
 
     call = __call__
 
     def result(self):
         if self._acc is None:
-            return 0.0
+            if self._restore is None:
+                return 0.0
+            n = min(int(self._restore["pushed"]), self._buffer_size)
+            ring = torch.as_tensor(self._restore["ring"])
+            return float(ring[:n].mean().item()) if n else 0.0
         n = min(int(self._pushed.item()), self._buffer_size)
         return float(self._ring[:n].mean().item()) if n else 0.0
 
     def reset(self):
+        self._restore = None
         if self._acc is not None:
             self._acc.zero_()
             self._ring.zero_()
@@ -114,14 +145,18 @@ class _EpisodeAverage:
 
     def state_dict(self):
         if self._acc is None:
-            return {}
-        return {"acc": self._acc.cpu(), "ring": self._ring.cpu(), "pushed": int(self._pushed)}
+            return dict(self._restore) if self._restore is not None else {}
+        # copies (Tensor.cpu() of a host tensor is the tensor itself)
+        return {"acc": self._acc.detach().cpu().clone(), "ring": self._ring.detach().cpu().clone(),
+                "pushed": int(self._pushed)}
 
     def load_state_dict(self, sd):
-        if sd and self._acc is not None:
-            self._acc.copy_(sd["acc"])
-            self._ring.copy_(sd["ring"])
-            self._pushed.fill_(int(sd["pushed"]))
+        if not sd:
+            return
+        if self._acc is not None:
+            self._apply(sd)
+        else:
+            self._restore = dict(sd)      # applied when the first trajectory allocates the state
 
     def tf_summaries(self, train_step=None, step_metrics=()):
         """Summary writers are outside the hot-path scope."""

@@ -145,6 +145,7 @@ class Sequential(network.Network):
         self._kviews = self._bviews = self._gkviews = self._gbviews = None
         self._reg_scratch = None
         self._pw = None         # prepared weights (enable_prepared_weights)
+        self._kept_ws = None    # scratch of kept weight-gradient slabs (backward(keep_dw_slabs=True))
 
     # ---- construction -------------------------------------------------------------------------
     @property
@@ -913,7 +914,10 @@ class Sequential(network.Network):
         # for all layers after the last of them has been enqueued (ops.PendingDwReduce)
         keep = getattr(self, "_keep_dw_slabs", False)
         self._keep_dw_slabs = False
-        pending_dw = ops.PendingDwReduce(keep=keep) if (keep or side_stream is not main) else None
+        if keep and getattr(self, "_kept_ws", None) is None:
+            self._kept_ws = ops.new_kept_workspaces()     # this network's own (advisor, round 4)
+        pending_dw = ops.PendingDwReduce(keep=keep, kept_ws=self._kept_ws if keep else None) \
+            if (keep or side_stream is not main) else None
 
         for i in range(hi, lo - 1, -1):
             l = self._param_layers[i]

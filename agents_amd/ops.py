@@ -474,13 +474,22 @@ class PendingDwReduce:
     (csrc/splitk_reduce.h: aa_splitk_reduce_multi_kernel) -- the backward pass of a conv stack
     used to pay one reduce launch per layer on its side stream."""
 
-    def __init__(self, keep=False):
+    def __init__(self, keep=False, kept_ws=None):
         self.items = []      # (desc, slabs, out, bias_grad)
+        # kept slabs outlive the backward pass (until the optimizer launch): they live in buffers
+        # of their OWNER (`kept_ws`: four _Workspace objects held by the network), not in the
+        # module-wide per-line scratch another network's backward on the same line would overwrite
+        self.kept_ws = kept_ws
         # keep=True: nobody sums the slabs -- the optimizer launch reads its gradients from them
         # (`grad_slabs`, csrc/optim.hip: aa_rmsprop_step_slabs); `kept` then also lists the slabs
         # of GEMM-path weight gradients: (slabs, splits, M * N, N, out, bias_grad)
         self.keep = keep
         self.kept = []
+
+
+def new_kept_workspaces():
+    """Four scratch buffers (one per kept layer) for an owner of keep=True weight-gradient slabs."""
+    return [_Workspace() for _ in range(4)]
 
 
 def _slabs_deep(splits, mn, n_tail):
@@ -561,7 +570,8 @@ def conv_dw(x, dz, w_shape, stride, out, a_div=255.0, force_cfg=0, force_splits=
             if keep or (defer is not None and not defer.keep and CONV_DW_MERGE_REDUCE and
                         len(defer.items) < 4):
                 n_pending = len(defer.kept) if keep else len(defer.items)
-                ws = _WS_DW_DEFER[n_pending].get(ws_bytes, x.device)
+                pool = defer.kept_ws if (keep and defer.kept_ws is not None) else _WS_DW_DEFER
+                ws = pool[n_pending].get(ws_bytes, x.device)
                 with torch.cuda.device(x.device):
                     check(_lib.load().aa_conv_dw_frame_x6_slabs(
                         ctypes.byref(dd), ptr(x), 1 if bias_grad is not None else 0, ptr(ws),
@@ -590,7 +600,8 @@ def conv_dw(x, dz, w_shape, stride, out, a_div=255.0, force_cfg=0, force_splits=
         need = int(lib.aa_gemm_f32_workspace_bytes(ctypes.byref(d)))
         splits = need // (4 * (Kp * Cout + Cout)) if need > 0 else 1
         if _slabs_deep(splits, Kp * Cout, Cout):
-            ws = _WS_DW_DEFER[len(defer.kept)].get(need, x.device)
+            pool = defer.kept_ws if defer.kept_ws is not None else _WS_DW_DEFER
+            ws = pool[len(defer.kept)].get(need, x.device)
             got = ctypes.c_int32(0)
             with torch.cuda.device(x.device):
                 check(lib.aa_gemm_f32_slabs(ctypes.byref(d), ptr(ws), ws.numel(), ctypes.byref(got),

@@ -368,6 +368,11 @@ class _Entry:
         self.g_target = None      # _Captured: the target network's forward on this entry's batch
         self.g_grads_nt = None    # _Captured: g_grads without the target forward (reads g_target's)
         self.apply_state_nt = None
+        # what the agent's phases looked at while they were recorded and a replay cannot re-evaluate
+        # (DqnAgent: whether a gradient hook is installed decides if the backward pass leaves its
+        # conv weight gradients as slabs for the optimizer); a replay under another state would
+        # all-reduce stale gradients -- such a call takes the eager path instead
+        self.cap_key = None
 
 
 def _sig(experience, weights):
@@ -486,12 +491,28 @@ class GraphedTrain:
             bound[None] = e
         return e
 
+    def _capture_key(self):
+        fn = getattr(self._agent, "_graph_capture_key", None)
+        return fn() if fn is not None else None
+
+    def _consume_early(self):
+        """Orders the caller's stream behind a pending early target forward and forgets it: every
+        path out of __call__ that does not use the result (eager fall-backs included) goes through
+        here, so that no launch of this call can overlap the forward's writes of the target
+        network's activation slot -- whatever the agent's eager path joins or does not join."""
+        early, self._early = self._early, None
+        if early is not None and not capturing():
+            torch.cuda.current_stream().wait_event(early[1])
+        return early
+
     def __call__(self, experience, weights=None, **kwargs):
         agent = self._agent
         if not self.enabled or kwargs or getattr(agent, "check_numerics", False) or capturing():
+            self._consume_early()
             return self._eager_train(experience, weights=weights, **kwargs)
         if self._whole and (getattr(agent, "gradient_hook", None) is not None or
                             not getattr(agent, "graph_train_whole_ok", True)):
+            self._consume_early()
             return self._eager_train(experience, weights=weights)
         _ensure_prepared()
         # Steady state: the very same experience object (a sampler ring slot) as on an earlier
@@ -504,6 +525,7 @@ class GraphedTrain:
             sig = _sig(experience, weights)
             if self._warm.get(sig, 0) < _WARMUP_CALLS:
                 self._warm[sig] = self._warm.get(sig, 0) + 1
+                self._consume_early()
                 return self._eager_train(experience, weights=weights)
             if not agent._initialized:
                 agent.initialize()
@@ -522,6 +544,12 @@ class GraphedTrain:
                 if len(self._fast) > 256:
                     self._fast.clear()
                 self._fast[id(experience)] = (experience, e, dev, ptr0, True)   # keeps it alive
+        if e.cap_key is not None and e.cap_key != self._capture_key():
+            # recorded under another hook / clipping state (a gradient hook installed after
+            # `common.function(agent.train)` had captured): the graphs' backward and optimizer
+            # phases no longer describe the step
+            self._consume_early()
+            return self._eager_train(experience, weights=weights)
         with _device_ctx(dev):
             lanes = _LANES.get((dev.type, dev.index)) if _LANES else None
             cur = torch.cuda.current_stream(dev)     # (looked up once: ~2 us of host time each)
@@ -701,6 +729,7 @@ class GraphedTrain:
             else experience
         e.static_w = weights.clone() if isinstance(weights, torch.Tensor) else None
         w_arg = e.static_w if e.static_w is not None else weights
+        e.cap_key = self._capture_key()
         with capture_batch():
             if self._whole:
                 if hasattr(agent, "_graph_train_whole_a"):

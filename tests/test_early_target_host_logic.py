@@ -150,3 +150,37 @@ def test_early_mark_only_for_agents_with_a_target_phase(gt):
     other = graph.GraphedTrain.__new__(graph.GraphedTrain)
     other._agent = plain
     assert other._early_mark(lanes, cur) is None
+
+
+def test_eager_fallbacks_wait_for_a_pending_early_forward(gt, monkeypatch):
+    """Advisor finding (round 4): the early returns to the eager train path left a pending early
+    target forward neither waited for nor dropped; every one of them now orders the caller's stream
+    behind it first, independent of what the agent's eager path joins."""
+    cur = _Stream("main")
+    monkeypatch.setattr(graph.torch.cuda, "current_stream", lambda *a: cur)
+    calls = []
+    gt._eager_train = lambda experience, weights=None, **kw: calls.append(kw) or "eager"
+    done = _Ev("early done")
+    gt._early = (_entry(1), done, gt.agent.key, 1)
+    assert gt("exp", some_kwarg=1) == "eager"            # kwargs -> eager path
+    assert gt._early is None and cur.waits == [done]
+    gt._early = (_entry(1), done, gt.agent.key, 1)
+    gt.agent.check_numerics = True
+    assert gt("exp") == "eager" and cur.waits == [done, done] and gt._early is None
+
+
+def test_entry_captured_under_another_hook_state_is_not_replayed(gt, monkeypatch):
+    """Advisor finding (round 4): `_optimizer_sums_slabs()` is evaluated while the gradient phase
+    is recorded; a gradient hook installed afterwards must not meet that graph."""
+    cur = _Stream("main")
+    monkeypatch.setattr(graph.torch.cuda, "current_stream", lambda *a: cur)
+    state = {"hook": None}
+    gt.agent._graph_capture_key = lambda: (state["hook"] is None,)
+    e = _entry(5)
+    e.cap_key = gt._capture_key()
+    e.g_grads = _Graph()
+    exp = object()
+    gt._fast[id(exp)] = (exp, e, None, 5, True)
+    gt._eager_train = lambda experience, weights=None, **kw: "eager"
+    state["hook"] = lambda g: g                           # installed after capture
+    assert gt(exp) == "eager" and e.g_grads.replays == 0

@@ -319,3 +319,66 @@ def test_checkpointer_does_not_hide_load_state_dict_errors(tmp_path):
         warnings.simplefilter("ignore")
         with pytest.raises(RuntimeError, match="none could be read"):
             common.Checkpointer(d, obj=_Obj(), step=common.Variable(0))
+
+
+def _metric_traj(step_type, reward):
+    st = torch.tensor(step_type, dtype=torch.int32)
+    n = st.numel()
+    return trajectory.Trajectory(step_type=st, observation=torch.zeros((n, 1)),
+                                 action=torch.zeros((n,), dtype=torch.int64), policy_info=(),
+                                 next_step_type=st, reward=torch.tensor(reward, dtype=torch.float32),
+                                 discount=torch.ones((n,)))
+
+
+def test_metrics_restored_before_first_call_keep_their_state():
+    """Advisor finding (round 4): a metric restored before its first call lost its state -- the
+    scripts restore the checkpoint before any driver run, so a resumed run restarted
+    `while environment_steps_metric.result() < num_environment_steps` from 0
+    (tf_agents/agents/ppo/examples/v2/train_eval_clip_agent.py:228-246 restores metrics with the
+    checkpoint)."""
+    from agents_amd.eval import metric_utils
+    from agents_amd.metrics import tf_metrics
+
+    def group():
+        return metric_utils.MetricsGroup([
+            tf_metrics.NumberOfEpisodes(), tf_metrics.EnvironmentSteps(),
+            tf_metrics.AverageReturnMetric(batch_size=2, buffer_size=3),
+            tf_metrics.AverageEpisodeLengthMetric(batch_size=2, buffer_size=3)])
+
+    a = group()
+    steps = [([0, 0], [0., 0.]), ([1, 1], [1., 2.]), ([1, 2], [1., 2.]), ([2, 0], [3., 0.]),
+             ([0, 1], [0., 5.])]
+    for st, r in steps:
+        for m in a.metrics:
+            m(_metric_traj(st, r))
+    want = a.results()
+    assert want["EnvironmentSteps"] > 0 and want["NumberOfEpisodes"] == 2
+    sd = a.state_dict()
+    b = group()
+    b.load_state_dict(sd)                      # before any call: state is not allocated yet
+    assert b.results() == want
+    assert b.state_dict().keys() == sd.keys()  # a save before the first call keeps it, too
+    c = group()
+    c.load_state_dict(b.state_dict())
+    more = ([1, 2], [1., 1.])
+    for g in (a, b, c):
+        for m in g.metrics:
+            m(_metric_traj(*more))
+    assert b.results() == a.results() == c.results()
+    assert a.results()["EnvironmentSteps"] == want["EnvironmentSteps"] + 1
+
+
+def test_episode_average_keeps_the_last_finishers_and_resets_non_finite_accumulators():
+    """More environments finishing in one step than the ring holds: the LAST `buffer_size` in
+    environment order stay (TFDeque adds them sequentially, tf_metrics.py:41-95); an accumulator
+    that went non-finite is cleared by the is_first reset (tf.where, not a multiplication)."""
+    from agents_amd.metrics import tf_metrics
+    m = tf_metrics.AverageReturnMetric(batch_size=5, buffer_size=2)
+    m(_metric_traj([0] * 5, [0.] * 5))
+    m(_metric_traj([2] * 5, [1., 2., 3., 4., 5.]))
+    assert m.result() == pytest.approx(4.5)
+    m2 = tf_metrics.AverageReturnMetric(batch_size=1, buffer_size=2)
+    m2(_metric_traj([1], [float("inf")]))
+    m2(_metric_traj([0], [1.0]))
+    m2(_metric_traj([2], [2.0]))
+    assert m2.result() == pytest.approx(3.0)
