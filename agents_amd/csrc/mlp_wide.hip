@@ -400,10 +400,14 @@ __global__ void __launch_bounds__(MW_VT) aa_mlp_wide_chain_kernel(MwBwdP p) {
     for (int h = 0; h < 2; ++h) {
       const int s = es + 2 * h;
       if (ec < n_out) {
-        float yy = yv[0][h];
-        if (l == 1) yy = yv[1][h];
-        if (l == 2) yy = yv[2][h];
-        if (l == 3) yy = yv[3][h];
+        // the layer's saved activation, selected by OR-ing masked bit patterns: a chain of
+        // `if (l == k) yy = yv[k][h]` is turned into an indexed load by the compiler, which sends
+        // yv[][] to the stack (48 bytes of scratch per lane, two scratch loads per layer --
+        // tools/kernel_resources.py); this form keeps all eight values in registers
+        unsigned yb = 0u;
+#pragma unroll
+        for (int k = 0; k < AA_MLP_MAX_LAYERS; ++k) yb |= l == k ? __float_as_uint(yv[k][h]) : 0u;
+        const float yy = __uint_as_float(yb);
         const float d = s0 + s < p.B ? gs[s][ec] * mw_actgrad(yy, act) : 0.f;
         dzs[s][ec] = d;
         if (s0 + s < p.B) dz[(s0 + s) * n_out + ec] = d;

@@ -87,6 +87,113 @@ aa_scan_kernel(const float* __restrict__ values, const float* __restrict__ final
   }
 }
 
+// ---- batch-major inputs (unit time stride): the layout both PPO call sites use ------------------
+// Round 5.  The kernel above gives a 64-lane workgroup 64 trajectories: [2048 x 128] is 32 waves on a
+// 1,024-SIMD chip, each filling and draining its tiles with a serial 64-iteration loop -- 49 us for
+// 4.2 MB (rocprofv3, PPO configs[2]).  The recurrence itself is cheap (two dependent fp32 ops per
+// step once delta is taken out of the chain: ~0.6 us for 128 steps); what has to be spread over
+// lanes is the memory phase.  Here a 256-lane workgroup owns SC_TB = 16 trajectories: all of its
+// lanes fetch a [16 x 128] chunk of every operand with coalesced loads that are ALL requested
+// before the first is used (unconditional, from clamped addresses), transpose it through LDS
+// (pitch 17: conflict-free both ways), sixteen lanes of wave 0 run the recurrence in the reference's
+// op order (bit-exact with the kernel above and oracle/value_ops.py), and all lanes store the
+// result coalesced.  For T > 128 the next chunk's loads are in flight during the scan.
+// 128 workgroups for B = 2,048.
+#define SC_TB 16
+#define SC_TT 128
+#define SC_PER ((SC_TB * SC_TT) / 256)
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+aa_scan_bm_kernel(const float* __restrict__ values, const float* __restrict__ final_value,
+                  const float* __restrict__ discounts, const float* __restrict__ rewards,
+                  float td_lambda, int64_t B, int64_t T, int64_t sb, float* __restrict__ out) {
+  __shared__ float t_r[SC_TT][SC_TB + 1];
+  __shared__ float t_d[SC_TT][SC_TB + 1];
+  __shared__ float t_v[MODE == 1 ? SC_TT : 1][SC_TB + 1];
+  const int tid = threadIdx.x;
+  const int64_t b0 = (int64_t)blockIdx.x * SC_TB;
+  float acc = 0.f, v_next = 0.f;
+  if (tid < SC_TB) {
+    const int64_t bc = b0 + tid < B ? b0 + tid : B - 1;
+    if (MODE == 0) acc = final_value != nullptr ? final_value[bc] : 0.f;
+    if (MODE == 1) v_next = final_value[bc];
+  }
+  float rr[SC_PER], dd[SC_PER], vv[SC_PER];
+  // element e = tid + 256 k of a chunk: trajectory e / SC_TT, step e % SC_TT (consecutive lanes
+  // read consecutive steps of one trajectory: 512-byte runs)
+  auto request = [&](int64_t t_lo, int nt) {
+#pragma unroll
+    for (int k = 0; k < SC_PER; ++k) {
+      const int e = tid + 256 * k;
+      const int row = e / SC_TT, tt = e - row * SC_TT;
+      const int64_t bc = b0 + row < B ? b0 + row : B - 1;
+      const int64_t o = bc * sb + t_lo + (tt < nt ? tt : nt - 1);
+      rr[k] = rewards[o];
+      dd[k] = discounts[o];
+      if (MODE == 1) vv[k] = values[o];
+    }
+  };
+  int64_t t_hi = T;
+  int64_t t_lo = t_hi > SC_TT ? t_hi - SC_TT : 0;
+  request(t_lo, (int)(t_hi - t_lo));
+  while (t_hi > 0) {
+    const int nt = (int)(t_hi - t_lo);
+#pragma unroll
+    for (int k = 0; k < SC_PER; ++k) {
+      const int e = tid + 256 * k;
+      const int row = e / SC_TT, tt = e - row * SC_TT;
+      t_r[tt][row] = rr[k];
+      t_d[tt][row] = dd[k];
+      if (MODE == 1) t_v[tt][row] = vv[k];
+    }
+    __syncthreads();
+    const int64_t n_hi = t_lo;
+    const int64_t n_lo = n_hi > SC_TT ? n_hi - SC_TT : 0;
+    if (n_hi > 0) request(n_lo, (int)(n_hi - n_lo));     // in flight during the scan
+    if (tid < SC_TB) {
+#pragma unroll 8
+      for (int tt = nt - 1; tt >= 0; --tt) {
+        const float r = t_r[tt][tid], d = t_d[tt][tid];
+        if (MODE == 0) {
+          acc = acc * d + r;
+        } else {
+          const float v = t_v[tt][tid];
+          const float delta = r + d * v_next - v;
+          acc = delta + (d * td_lambda) * acc;
+          v_next = v;
+        }
+        t_r[tt][tid] = acc;  // the reward tile becomes the output tile
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SC_PER; ++k) {
+      const int e = tid + 256 * k;
+      const int row = e / SC_TT, tt = e - row * SC_TT;
+      if (b0 + row < B && tt < nt) out[(b0 + row) * sb + t_lo + tt] = t_r[tt][row];
+    }
+    __syncthreads();
+    t_hi = n_hi;
+    t_lo = n_lo;
+  }
+}
+
+template <int MODE>
+static void aa_scan_launch(const float* values, const float* final_value, const float* discounts,
+                           const float* rewards, float td_lambda, int64_t B, int64_t T,
+                           int64_t sb, int64_t st, float* out, hipStream_t stream) {
+  if (st == 1) {
+    const dim3 grid((unsigned)((B + SC_TB - 1) / SC_TB));
+    hipLaunchKernelGGL(aa_scan_bm_kernel<MODE>, grid, dim3(256), 0, stream, values, final_value,
+                       discounts, rewards, td_lambda, B, T, sb, out);
+  } else {
+    const dim3 grid((unsigned)((B + AA_SCAN_TILE - 1) / AA_SCAN_TILE));
+    hipLaunchKernelGGL(aa_scan_kernel<MODE>, grid, dim3(64), 0, stream, values, final_value,
+                       discounts, rewards, td_lambda, B, T, sb, st, out);
+  }
+}
+
 // Two-pass moments over n elements in ONE workgroup launch pair (n is B*T <= a few million):
 // pass 1: per-block partial sums -> mean ; pass 2: partial sum of squared deviations -> var
 // (tf.nn.moments computes mean, then mean(squared_difference(x, stop_gradient(mean)))).
@@ -168,10 +275,8 @@ int aa_discounted_return(const float* rewards, const float* discounts, const flo
                          int64_t B, int64_t T, int64_t stride_b, int64_t stride_t, float* out,
                          void* stream) {
   if (!rewards || !discounts || !out || B <= 0 || T <= 0) return AA_ERR_INVALID;
-  const dim3 grid((unsigned)((B + AA_SCAN_TILE - 1) / AA_SCAN_TILE));
-  hipLaunchKernelGGL(aa_scan_kernel<0>, grid, dim3(64), 0, (hipStream_t)stream,
-                     (const float*)nullptr, final_value, discounts, rewards, 0.f, B, T, stride_b,
-                     stride_t, out);
+  aa_scan_launch<0>(nullptr, final_value, discounts, rewards, 0.f, B, T, stride_b, stride_t, out,
+                    (hipStream_t)stream);
   return aa_launch_status();
 }
 
@@ -180,9 +285,8 @@ int aa_gae(const float* values, const float* final_value, const float* discounts
            int64_t stride_t, float* out, void* stream) {
   if (!values || !final_value || !rewards || !discounts || !out || B <= 0 || T <= 0)
     return AA_ERR_INVALID;
-  const dim3 grid((unsigned)((B + AA_SCAN_TILE - 1) / AA_SCAN_TILE));
-  hipLaunchKernelGGL(aa_scan_kernel<1>, grid, dim3(64), 0, (hipStream_t)stream, values,
-                     final_value, discounts, rewards, td_lambda, B, T, stride_b, stride_t, out);
+  aa_scan_launch<1>(values, final_value, discounts, rewards, td_lambda, B, T, stride_b, stride_t,
+                    out, (hipStream_t)stream);
   return aa_launch_status();
 }
 

@@ -53,6 +53,30 @@ class DataParallelStrategy(Strategy):
                 f"DataParallelStrategy: the process group has {self.num_replicas_in_sync} ranks "
                 f"but the launcher started WORLD_SIZE={ws}")
         self.backend = dist.get_backend(process_group)
+        # what the data path exchanged so far (bench.py reports it per step, so that the first
+        # multi-GPU scaling run can be read: bytes and calls per step, and -- with `profile` on --
+        # how long the calling stream sat in / waited for the collectives)
+        self.stats = {"calls": 0, "bytes": 0}
+        self.profile = False
+        self._timed = []          # (begin event, end event) pairs while `profile` is on
+
+    def reset_stats(self):
+        self.stats = {"calls": 0, "bytes": 0}
+        self._timed = []
+
+    def _count(self, tensor):
+        self.stats["calls"] += 1
+        self.stats["bytes"] += tensor.numel() * tensor.element_size()
+
+    def _stamp(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def exposed_ms(self):
+        """Stream time between the stamps taken around the synchronous collectives and around the
+        waits for the asynchronous ones (call after a device synchronisation)."""
+        return sum(a.elapsed_time(b) for a, b in self._timed)
 
     def describe(self):
         return (f"{self.num_replicas_in_sync} replicas over {self.backend} "
@@ -60,6 +84,12 @@ class DataParallelStrategy(Strategy):
 
     def all_reduce_sum_(self, tensor):
         """In-place SUM all-reduce (ncclAllReduce over xGMI on GPUs)."""
+        self._count(tensor)
+        if self.profile and tensor.is_cuda:
+            a = self._stamp()
+            dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self._pg)
+            self._timed.append((a, self._stamp()))
+            return tensor
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self._pg)
         return tensor
 
@@ -67,7 +97,11 @@ class DataParallelStrategy(Strategy):
         """Starts an in-place SUM all-reduce and returns its Work handle; `handle.wait()` makes the
         CURRENT stream wait for it (no host block).  RCCL runs it on its own stream after the work
         already enqueued on the current stream, so kernels enqueued afterwards overlap with it."""
-        return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self._pg, async_op=True)
+        self._count(tensor)
+        work = dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self._pg, async_op=True)
+        if self.profile and tensor.is_cuda:
+            return _TimedWork(work, self)
+        return work
 
     def reduce_sum(self, tensor):
         out = tensor.clone()
@@ -101,6 +135,24 @@ class DataParallelStrategy(Strategy):
 
     def barrier(self):
         dist.barrier(group=self._pg)
+
+
+class _TimedWork:
+    """A collective's Work handle whose wait() is bracketed by timing events on the waiting stream
+    (DataParallelStrategy.profile): the stream time between them is the EXPOSED part of the
+    collective, the rest ran under the kernels enqueued in between."""
+
+    def __init__(self, work, strategy):
+        self._work, self._strategy = work, strategy
+
+    def wait(self):
+        a = self._strategy._stamp()
+        out = self._work.wait()
+        self._strategy._timed.append((a, self._strategy._stamp()))
+        return out
+
+    def __getattr__(self, name):
+        return getattr(self._work, name)
 
 
 def get_strategy(tpu=None, use_gpu=True):

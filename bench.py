@@ -125,6 +125,8 @@ def compact_line(out):
               "rccl_ranks", "dominant_device_kernel", "lanes", "lane_probe"):
         if k in out:
             line[k] = _r(out[k])
+    if out.get("collectives"):
+        line["collectives"] = {k: _r(v) for k, v in out["collectives"].items()}
     if "roofline" in out:
         line["roofline"] = _compact_roofline(out["roofline"])
     for k in ("roofline_replay_gather", "roofline_replay_add"):
@@ -604,19 +606,73 @@ def _best_threads(fn):
     return max(probe, key=probe.get), ncpu, cands
 
 
+def setup_ranks(args):
+    """One process per GPU.  `python bench.py --gpus N` without a launcher re-launches itself under
+    torch.distributed.run (one rank per GPU of this node, rendezvous on 127.0.0.1); under a
+    launcher the process joins the RCCL process group.  Returns (world, rank, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under
+        # torch.distributed.run on this node (rendezvous on 127.0.0.1), same arguments
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log(f"[bench] --gpus {args.gpus} without WORLD_SIZE: re-launching under "
+            f"torch.distributed.run ({args.gpus} ranks, 127.0.0.1:{port})")
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    # AA_BENCH_BACKEND=gloo AA_BENCH_SHARE_GPU=1: development aid -- runs the N-rank control flow
+    # (hooks, buckets, barriers, rank-0 breakdown) with every rank on GPU 0 when only one GPU exists
+    backend = os.environ.get("AA_BENCH_BACKEND", "nccl")
+    if os.environ.get("AA_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus says "
+                             f"{args.gpus}")
+        if rank == 0:
+            log(f"[bench] process group up: backend {dist.get_backend()}, "
+                f"{dist.get_world_size()} ranks, one rank per GPU (this rank: {dev})")
+
+    return world, rank, dev
+
+
 def main_other_config(args):
     """`--config ppo` / `--config sac`: BASELINE.json configs[2] and configs[4] at one GPU -- parity
     configurations, measured for the record with the same JSON contract (the graded metric is the
     DQN line).  A "step" is one iteration of the config's train_eval loop."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
-    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    # `--gpus N`: one process per GPU, weak scaling like the DQN line (per-rank environments and
+    # replay shard, gradients SUM all-reduced per train step through the Learner's strategy);
+    # BASELINE.json configs[4] is an 8-GPU configuration
+    world, rank, dev = setup_ranks(args)
     from agents_amd import _lib
     _lib.load()
+    par = "single" if world == 1 else f"dp{world}"
     if args.config == "ppo":
         import bench_ppo
         a = argparse.Namespace(envs=2048, steps=128, minibatch=4096, epochs=10,
                                iters=max(args.steps, 1) if args.steps_given else 3)
-        r = bench_ppo.run(a)
+        r = bench_ppo.run(a, dev=dev, rank=rank, world=world)
         r.pop("agent")
         it_s = r["iteration_s"]
         n_mb = r["minibatch_steps_per_iteration"]
@@ -627,12 +683,13 @@ def main_other_config(args):
         mb_ms = r["train_s_per_iteration"] / n_mb * 1e3
         out = {"metric": "PPO frames trained per second (minibatch steps/s x 4096), configs[2] "
                          "HalfCheetah-shaped", "value": r["train_frames_per_sec"],
-               "unit": "frames/s", "n_gpus": 1, "steps": a.iters, "warmup": 1,
+               "unit": "frames/s", "n_gpus": world, "steps": a.iters, "warmup": 1,
                "ms_per_step": it_s * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": r["workload"] + "; reward + observation normalisers on "
                           "(the reference's defaults); step = collect 2048 x 129 env steps + "
-                          f"{n_mb} minibatch train steps", "parallelism": "single"},
+                          f"{n_mb} minibatch train steps, per GPU", "parallelism": par},
+               "rccl_ranks": world, "collectives": r.get("collectives"),
                "collect_env_steps_per_sec": r["collect_env_steps_per_sec"],
                "train_minibatch_steps_per_sec": r["train_minibatch_steps_per_sec"],
                "roofline": {"kernel": "PPOClipAgent.train minibatch step: 3 launches "
@@ -649,7 +706,7 @@ def main_other_config(args):
                                     "zeros), so frac counts algorithmic flop only; the step is "
                                     "bound by staging, barriers and launch latency, not the "
                                     "matrix pipe (in-kernel timeline: DESIGN.md)"}}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and rank == 0 and world == 1:
             th, ncpu, cands = _best_threads(lambda n, t: bench_ppo.cpu_baseline(4096, n, t))
             sps = bench_ppo.cpu_baseline(4096, 200, th)
             out["cpu_baseline"] = {"value": sps * 4096, "unit": "frames/s", "cores": th,
@@ -662,7 +719,7 @@ def main_other_config(args):
         import bench_sac
         a = argparse.Namespace(envs=4096, max_length=64, batch=256,
                                iters=args.steps if args.steps_given else 200)
-        r = bench_sac.run(a)
+        r = bench_sac.run(a, dev=dev, rank=rank, world=world)
         dt = r["ms_per_iteration"]
         O, A, H = 376, 17, 256
         actor = O * H + H * H + H * 2 * A
@@ -671,12 +728,15 @@ def main_other_config(args):
         # fwd + bwd, 2 critics fwd + input-grad; alpha phase: actor fwd; collect: actor fwd on 4,096
         flop = 2.0 * 256 * (critic * (2 + 2 + 4 + 2 + 4) + actor * (1 + 3 + 1)) + 2.0 * 4096 * actor
         out = {"metric": "SAC learner steps/sec (batch 256) + 4,096-env collect, configs[4] at 1 GPU",
-               "value": r["learner_steps_per_sec"], "unit": "steps/s", "n_gpus": 1,
+               "value": r["learner_steps_per_sec"], "unit": "steps/s", "n_gpus": world,
                "steps": a.iters, "warmup": 40, "ms_per_step": dt, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": r["workload"] + "; step = 1 collect step (4096 envs) + "
-                          "sample 256x2 + 1 SacAgent.train", "parallelism": "single"},
+                          "sample 256x2 + 1 SacAgent.train, per GPU (global batch "
+                          f"{256 * world})", "parallelism": par},
                "env_steps_per_sec": r["env_steps_per_sec"],
+               "trained_transitions_per_sec": r["trained_transitions_per_sec"],
+               "rccl_ranks": world, "collectives": r.get("collectives"),
                "roofline": {"kernel": "one SAC iteration: 36 launches (train step 25: whole "
                                       "(256,256) MLPs forward in one launch and backward in two, "
                                       "twin critics per launch, csrc/mlp_wide.hip; collect 10; "
@@ -693,7 +753,7 @@ def main_other_config(args):
                                     "peak is what the shape allows, not a kernel-quality figure; "
                                     "the collect forward on 4,096 envs is the only launch that "
                                     "fills the chip"}}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and rank == 0 and world == 1:
             th, ncpu, cands = _best_threads(lambda n, t: bench_sac.cpu_baseline(256, n, t))
             sps = bench_sac.cpu_baseline(256, 300, th)
             out["cpu_baseline"] = {"value": sps, "unit": "steps/s", "cores": th, "kind": "port",
@@ -701,6 +761,13 @@ def main_other_config(args):
                                              f"twin critics (256,256), three Adam) on {th} of "
                                              f"{ncpu} host threads (fastest of {cands}); no "
                                              "collect step on the CPU side"}
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        dist.destroy_process_group()
+        return
     print(json.dumps(out), flush=True)
 
 
@@ -748,54 +815,11 @@ def main():
     args = ap.parse_args()
     args.steps_given = any(a == "--steps" or a.startswith("--steps=") for a in sys.argv[1:])
     if args.config != "dqn":
-        if args.gpus != 1:
-            raise SystemExit("--config ppo / sac are single-GPU lines")
-        torch.cuda.set_device(0)
         return main_other_config(args)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under
-        # torch.distributed.run on this node (rendezvous on 127.0.0.1), same arguments
-        import socket
-        import subprocess
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        log(f"[bench] --gpus {args.gpus} without WORLD_SIZE: re-launching under "
-            f"torch.distributed.run ({args.gpus} ranks, 127.0.0.1:{port})")
-        env = dict(os.environ)
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        raise SystemExit(subprocess.call(cmd, env=env))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    # AA_BENCH_BACKEND=gloo AA_BENCH_SHARE_GPU=1: development aid -- runs the N-rank control flow
-    # (hooks, buckets, barriers, rank-0 breakdown) with every rank on GPU 0 when only one GPU exists
+    world, rank, dev = setup_ranks(args)
+    local_rank = dev.index
     backend = os.environ.get("AA_BENCH_BACKEND", "nccl")
-    if os.environ.get("AA_BENCH_SHARE_GPU") == "1":
-        local_rank = 0
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-        if dist.get_world_size() != args.gpus:
-            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus says "
-                             f"{args.gpus}")
-        if rank == 0:
-            log(f"[bench] process group up: backend {dist.get_backend()}, "
-                f"{dist.get_world_size()} ranks, one rank per GPU (this rank: {dev})")
-
     from agents_amd import _lib
     _lib.load()  # fail loudly if the HIP library is missing
     S = args.batch
@@ -899,6 +923,8 @@ def main():
         step()
     sync_all()
     captures_before = graph.capture_count()
+    if hasattr(lrn.strategy, "reset_stats"):
+        lrn.strategy.reset_stats()
     mark("loop.begin")
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -909,6 +935,25 @@ def main():
     dt = time.perf_counter() - t0
     mark("loop.end")
     captures_in_timed_region = graph.capture_count() - captures_before
+    collectives = None
+    if world > 1 and hasattr(lrn.strategy, "stats"):
+        # what the data path exchanged per step in the timed region, then an untimed pass with
+        # timing events around the collectives / the waits for them: their EXPOSED stream time
+        st_ = dict(lrn.strategy.stats)
+        lrn.strategy.reset_stats()
+        lrn.strategy.profile = True
+        n_prof = min(max(args.steps, 10), 50)
+        for _ in range(n_prof):
+            step()
+        graph.join_lanes(dev)
+        sync_all()
+        collectives = {"allreduce_calls_per_step": st_["calls"] / args.steps,
+                       "allreduce_bytes_per_step": st_["bytes"] / args.steps,
+                       "allreduce_exposed_ms_per_step": lrn.strategy.exposed_ms() / n_prof,
+                       "backend": lrn.strategy.backend,
+                       "ranks": lrn.strategy.num_replicas_in_sync}
+        lrn.strategy.profile = False
+        lrn.strategy.reset_stats()
     # `--steps 20` times ~8 ms of wall clock: a second, longer region of the same loop right after
     # it says whether the short one was representative (reported beside it, never instead of it)
     steady = None
@@ -1019,7 +1064,8 @@ def main():
         "learner_steps_per_sec": steps_per_sec,
         "env_steps_per_sec": steps_per_sec * args.envs * world,
         "replay_rows_gathered_per_sec": steps_per_sec * S * 2 * world,
-        "final_loss": loss_val, "rccl_ranks": world, "lanes": lanes_mode,
+        "final_loss": loss_val, "rccl_ranks": world, "collectives": collectives,
+        "lanes": lanes_mode,
         "config": {"workload": "configs[1]: DQN Atari Pong-shaped (84x84x4 uint8 stack), replay "
                                f"{args.envs}x{args.max_length} rows/GPU, batch={S}, num_steps=2, "
                                "Mnih-15 Q-net, Huber, centred RMSProp, 1 collect step (256 envs) "

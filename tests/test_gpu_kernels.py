@@ -76,7 +76,8 @@ def test_dqn_td_loss_int32_actions_and_known_answer(dev):
 
 
 # ---- scans ---------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,T", [(1, 1), (7, 9), (2048, 128), (70, 130), (3, 200)])
+@pytest.mark.parametrize("B,T", [(1, 1), (7, 9), (2048, 128), (70, 130), (3, 200), (17, 128),
+                                 (33, 257), (16, 513), (2051, 127)])
 @pytest.mark.parametrize("batch_major", [True, False])
 def test_discounted_return_and_gae_bit_exact(dev, B, T, batch_major):
     lib = _lib.load()

@@ -366,3 +366,83 @@ def test_stamped_draws_equal_device_counter_draws(dev, obs_shape, dtype, B, L, S
         assert torch.equal(igot.probabilities, iref.probabilities)
         assert int(rbs[0]._sample_calls_dev.item()) == rbs[0]._sample_calls == rbs[1]._sample_calls
         _arrivals_consistent(rbs[0])
+
+
+def test_far_rows(dev):
+    """Byte copies at table offsets beyond 2^32 (the benchmarked Atari table is 28.2 GB; the
+    oracle-checked cases above all live in the first megabytes).  One uint8 leaf of 16 env blocks x
+    15,000 rows x 28,224 B = 6.77 GB: blocks 11..15 start past 4 GiB and the last row of block 15
+    sits at byte 6.77e9.  `add_batch` writes patterns that name (id, env); `gather_all` and
+    `get_next` must return exactly those bytes -- first at the START of every block (buffer not
+    full), then, after the ring position has been moved next to the END of the blocks the way a
+    restore does, across the wrap.  The patterns are recomputed, so no oracle holds the table.
+    Reference behaviour: replay_buffers/table.py:86-137 on a [B * L, 84, 84, 4] variable,
+    tf_uniform_replay_buffer.py:182-310."""
+    free, _total = torch.cuda.mem_get_info(dev)
+    if free < 24 * (1 << 30):
+        pytest.skip("needs 24 GiB of free device memory")
+    f = tensor_spec.TensorSpec
+    spec = collections.OrderedDict(obs=f((84, 84, 4), torch.uint8), tag=f((), torch.int64))
+    B, L, T = 16, 15000, 2
+    rb = rb_lib.TFUniformReplayBuffer(spec, batch_size=B, max_length=L, device=dev, seed=21)
+    assert rb._data_table.variables()[0].numel() > 6 * (1 << 30)
+    assert 11 * L * 28224 > (1 << 32)
+    env = torch.arange(B, device=dev, dtype=torch.int64)
+    pos = torch.arange(84 * 84 * 4, device=dev, dtype=torch.int64)
+
+    def pattern(ids, envs):
+        """uint8 [n, 84, 84, 4] for int64 vectors ids, envs: every byte depends on (id, env, position)."""
+        v = (pos[None, :] * (7 + ids[:, None] % 97) + 31 * envs[:, None] + ids[:, None]) % 251
+        return v.to(torch.uint8).view(-1, 84, 84, 4)
+
+    def add(i):
+        ids = torch.full((B,), i, dtype=torch.int64, device=dev)
+        rb.add_batch(collections.OrderedDict(obs=pattern(ids, env), tag=ids * 1000 + env + 1))
+
+    def check_samples(S):
+        data, info = rb.get_next(S, T)
+        tag = data["tag"].reshape(-1)
+        obs = data["obs"].reshape(-1, 84, 84, 4)
+        written = tag > 0
+        ids_from_tag = torch.div(tag - 1, 1000, rounding_mode="floor")
+        env_from_tag = (tag - 1) % 1000
+        assert torch.equal(info.ids.reshape(-1)[written], ids_from_tag[written])
+        want = pattern(ids_from_tag.clamp(min=0), env_from_tag.clamp(min=0))
+        want[~written] = 0                       # rows nobody wrote: the table's zero fill
+        assert torch.equal(obs, want)
+        return int(written.sum()), int((env_from_tag[written] >= 11).sum())
+
+    # ---- block starts (not full) ------------------------------------------------------------------
+    for i in range(6):
+        add(i)
+    got = rb.gather_all()
+    assert tuple(got["obs"].shape) == (B, 6, 84, 84, 4)
+    ids6 = torch.arange(6, device=dev, dtype=torch.int64)
+    for b in range(B):
+        assert torch.equal(got["obs"][b], pattern(ids6, torch.full_like(ids6, b))), b
+        assert torch.equal(got["tag"][b], ids6 * 1000 + b + 1)
+    n_written, n_far = check_samples(512)
+    assert n_written == 512 * T and n_far > 0        # every sampled row exists; 5 of 16 blocks are far
+
+    # ---- block ends and the wrap: ring position moved to L - 4 as a restore would ------------------
+    rb._last_id.fill_(L - 4)
+    rb._last_id_host = L - 4
+    for i in range(L - 3, L + 5):                    # ring positions L-3, L-2, L-1, 0, 1, 2, 3, 4
+        add(i)
+    assert rb.num_frames() == rb.capacity
+    got = rb.gather_all()                            # ids [5, L + 5): all 6.77 GB
+    assert tuple(got["obs"].shape) == (B, L, 84, 84, 4)
+    tail = torch.arange(L - 3, L + 5, device=dev, dtype=torch.int64)
+    for b in (0, 10, 11, 15):
+        assert torch.equal(got["obs"][b, L - 8:], pattern(tail, torch.full_like(tail, b))), b
+        assert torch.equal(got["tag"][b, L - 8:], tail * 1000 + b + 1)
+        five = torch.tensor([5], device=dev)
+        assert torch.equal(got["obs"][b, :1], pattern(five, torch.full_like(five, b)))   # phase 1's id 5
+        assert not bool(got["obs"][b, 1:L - 8].any())                                   # never written
+    del got
+    hits = far = 0
+    for _ in range(4):
+        h, fr = check_samples(4096)
+        hits, far = hits + h, far + fr
+    assert hits > 0                                  # ~9 of 15,000 ids are written: a few dozen rows
+    _arrivals_consistent(rb)

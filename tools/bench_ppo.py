@@ -72,7 +72,7 @@ def cpu_baseline(minibatch, steps, threads):
 
 
 def build(dev, envs=2048, steps=128, minibatch=4096, epochs=10, after_train_step_fn=None,
-          episode_end_probability=1e-3):
+          episode_end_probability=1e-3, rank=0):
     """configs[2] as this benchmark runs it (also what tests/test_gpu_bench_config_ppo.py checks
     against oracle/ppo.py + oracle/tensor_normalizer.py)."""
     from agents_amd import optimizers
@@ -101,7 +101,7 @@ def build(dev, envs=2048, steps=128, minibatch=4096, epochs=10, after_train_step
     agent.initialize()
     env = random_tf_environment.RandomTFEnvironment(tss, act, batch_size=B,
                                                     episode_end_probability=episode_end_probability,
-                                                    seed=3, device=dev)
+                                                    seed=3 + 1000 * rank, device=dev)
     rb = rb_lib.TFUniformReplayBuffer(agent.collect_data_spec, batch_size=B, max_length=T + 1,
                                       device=dev)
     drv = dynamic_step_driver.DynamicStepDriver(env, agent.collect_policy,
@@ -122,27 +122,41 @@ def build(dev, envs=2048, steps=128, minibatch=4096, epochs=10, after_train_step
                 learner=lrn, raw_dataset_fn=raw_dataset_fn, obs_spec=obs, action_spec=act)
 
 
-def run(args):
-    dev = torch.device("cuda", 0)
+def run(args, dev=None, rank=0, world=1):
+    """`world` > 1: one process per GPU (bench.py --config ppo --gpus N): every rank collects with
+    its own environments and trains on its own frames; the gradient buffer is SUM all-reduced per
+    minibatch step and the normalisers see the gathered batch (Learner's strategy)."""
+    if dev is None:
+        dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     B, T = args.envs, args.steps
-    w = build(dev, B, T, args.minibatch, args.epochs)
+    w = build(dev, B, T, args.minibatch, args.epochs, rank=rank)
     agent, rb, drv, lrn = w["agent"], w["rb"], w["collect_driver"], w["learner"]
 
+    def sync_all():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
     def one_iteration():
+        sync_all()
         t0 = time.perf_counter()
         rb.clear()
         drv.run()
-        torch.cuda.synchronize()
+        sync_all()
         t1 = time.perf_counter()
         lrn._train_iter = lrn._norm_iter = None   # a fresh deterministic pass over the new data
         li = lrn.run()
-        torch.cuda.synchronize()
+        sync_all()
         t2 = time.perf_counter()
         n_steps = (lrn.num_frames_for_training // args.minibatch) * args.epochs
         return t1 - t0, t2 - t1, n_steps, float(li.loss)
 
     one_iteration()   # warm-up (buffers, workspaces)
+    strategy = lrn.strategy
+    if hasattr(strategy, "reset_stats"):
+        strategy.reset_stats()
     tc = tt = 0.0
     steps = 0
     for _ in range(args.iters):
@@ -150,16 +164,32 @@ def run(args):
         tc += c
         tt += t
         steps += n
+    coll = None
+    if world > 1:
+        import torch.distributed as dist
+        v = torch.tensor([tc, tt], dtype=torch.float64, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)      # the slowest rank's time counts
+        tc, tt = float(v[0]), float(v[1])
+        st = dict(strategy.stats)
+        strategy.reset_stats()
+        strategy.profile = True
+        _c, _t, n_prof, _l = one_iteration()
+        coll = {"allreduce_calls_per_step": st["calls"] / max(steps, 1),
+                "allreduce_bytes_per_step": st["bytes"] / max(steps, 1),
+                "allreduce_exposed_ms_per_step": strategy.exposed_ms() / max(n_prof, 1),
+                "backend": strategy.backend, "ranks": strategy.num_replicas_in_sync}
+        strategy.profile = False
     frames = B * (T + 1)
     out = {"workload": "configs[2]: PPO HalfCheetah-shaped, %d envs x %d steps, minibatch %d, "
                        "%d epochs, MLP (64,64)" % (B, T, args.minibatch, args.epochs),
-           "collect_env_steps_per_sec": frames * args.iters / tc,
+           "collect_env_steps_per_sec": world * frames * args.iters / tc,
            "collect_s_per_iteration": tc / args.iters,
            "train_minibatch_steps_per_sec": steps / tt,
-           "train_frames_per_sec": steps * args.minibatch / tt,
+           "train_frames_per_sec": world * steps * args.minibatch / tt,
            "train_s_per_iteration": tt / args.iters,
            "minibatch_steps_per_iteration": steps // args.iters,
-           "iteration_s": (tc + tt) / args.iters, "final_loss": loss, "n_gpus": 1}
+           "iteration_s": (tc + tt) / args.iters, "final_loss": loss, "n_gpus": world,
+           "collectives": coll}
     out["frames_per_iteration"] = frames
     out["agent"] = agent
     return out

@@ -45,9 +45,11 @@ def cpu_baseline(batch, steps, threads):
     return steps / (time.perf_counter() - t0)
 
 
-def build(dev, envs=4096, max_length=64, batch=256, record_noise=False, prefill=True):
+def build(dev, envs=4096, max_length=64, batch=256, record_noise=False, prefill=True, rank=0):
     """configs[4] at one GPU as this benchmark runs it (also what
-    tests/test_gpu_bench_config_sac.py checks against oracle/sac.py)."""
+    tests/test_gpu_bench_config_sac.py checks against oracle/sac.py).  `rank`: data-parallel
+    replica index -- its own environment and replay streams; the networks are seeded alike (and the
+    Learner broadcasts rank 0's state anyway)."""
     from agents_amd import optimizers
     from agents_amd.agents.sac import sac_agent
     from agents_amd.drivers import dynamic_step_driver
@@ -79,9 +81,10 @@ def build(dev, envs=4096, max_length=64, batch=256, record_noise=False, prefill=
     agent.record_noise = record_noise
     agent.initialize()
     env = random_tf_environment.RandomTFEnvironment(tss, act, batch_size=envs,
-                                                    episode_end_probability=1e-3, seed=3, device=dev)
+                                                    episode_end_probability=1e-3,
+                                                    seed=3 + 1000 * rank, device=dev)
     rb = rb_lib.TFUniformReplayBuffer(agent.collect_data_spec, batch_size=envs,
-                                      max_length=max_length, device=dev)
+                                      max_length=max_length, device=dev, seed=13 * rank)
     init = dynamic_step_driver.DynamicStepDriver(env, agent.collect_policy,
                                                  observers=[rb.add_batch],
                                                  num_steps=envs * max_length)
@@ -97,12 +100,16 @@ def build(dev, envs=4096, max_length=64, batch=256, record_noise=False, prefill=
                 obs_spec=obs, action_spec=act)
 
 
-def run(args):
+def run(args, dev=None, rank=0, world=1):
+    """`world` > 1: one process per GPU (bench.py --config sac --gpus N): per-rank envs and replay
+    shard, the three gradient buffers SUM all-reduced per train step (Learner's strategy); timed
+    between barriers, the slowest rank's time counts."""
     from agents_amd.utils import graph
 
-    dev = torch.device("cuda", 0)
+    if dev is None:
+        dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    w = build(dev, args.envs, args.max_length, args.batch)
+    w = build(dev, args.envs, args.max_length, args.batch, rank=rank)
     agent, collect, lrn = w["agent"], w["collect"], w["learner"]
     if not getattr(args, "no_overlap", False):
         # collect / sample / train graphs on three HIP streams, ordered along the true data
@@ -122,15 +129,44 @@ def run(args):
         tsx, _ = collect(tsx)
         return lrn.run(iterations=1, iterator=it)
 
+    def sync_all():
+        graph.join_lanes(dev)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    strategy = lrn.strategy
     for _ in range(40):
         step()
-    torch.cuda.synchronize()
+    sync_all()
+    if hasattr(strategy, "reset_stats"):
+        strategy.reset_stats()
     t0 = time.perf_counter()
     for _ in range(args.iters):
         li = step()
     t_host = (time.perf_counter() - t0) / args.iters    # the host is done enqueueing here
-    torch.cuda.synchronize()
+    sync_all()
     dt = (time.perf_counter() - t0) / args.iters
+    coll = None
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+        st = dict(strategy.stats)
+        # a second, untimed pass with timing events around the collectives: exposed stream time
+        strategy.reset_stats()
+        strategy.profile = True
+        n_prof = min(args.iters, 50)
+        for _ in range(n_prof):
+            step()
+        sync_all()
+        coll = {"allreduce_calls_per_step": st["calls"] / args.iters,
+                "allreduce_bytes_per_step": st["bytes"] / args.iters,
+                "allreduce_exposed_ms_per_step": strategy.exposed_ms() / n_prof,
+                "backend": strategy.backend, "ranks": strategy.num_replicas_in_sync}
+        strategy.profile = False
     if getattr(args, "timeline", 0):
         # GPU-side event timeline of the loop (timing events around the graph launches), us after
         # the end of the previous iteration's train step: who waits for whom
@@ -162,8 +198,10 @@ def run(args):
                     "(256,256)" % (args.envs, args.batch),
         "ms_per_iteration": dt * 1e3, "host_enqueue_ms_per_iteration": t_host * 1e3,
         "learner_steps_per_sec": 1.0 / dt,
-        "env_steps_per_sec": args.envs / dt, "trained_transitions_per_sec": args.batch / dt,
-        "replay_row_bytes": row, "final_loss": float(li.loss), "n_gpus": 1,
+        "env_steps_per_sec": world * args.envs / dt,
+        "trained_transitions_per_sec": world * args.batch / dt,
+        "replay_row_bytes": row, "final_loss": float(li.loss), "n_gpus": world,
+        "collectives": coll,
         "train_graph_replays": graph.graphed_train(agent).replays})
 
 
