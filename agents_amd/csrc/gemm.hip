@@ -636,8 +636,6 @@ static const AaTileCfg kCfgs[] = {
 // (4 VALU per element) ~11 -- which is the floor to attack next, not the tile shape.
 
 #include "conv_u8_bf16.h"
-#include "gemm_x6d.h"
-#define AA_CFG_X6D 10      // force_cfg value of the dense bf16x6 plan (gemm_x6d.h)
 
 struct AaGemmPlan {
   int cfg;
@@ -696,32 +694,11 @@ static int aa_gemm_plan(const aa_gemm_desc* d, AaGemmPlan* pl) {
     pl->ws_bytes = (size_t)pl->splits * (size_t)(M * N + (d->colsum_out ? N : 0)) * sizeof(float);
     return AA_OK;
   }
-  {
-    // dense layers of fc1's size and up on the bf16 matrix cores at fp32 accuracy (gemm_x6d.h):
-    // OPT-IN (force_cfg = 10 or AA_GEMM_X6D=1).  Measured on MI355X: in isolation it beats the
-    // fp32-MFMA plans (fc1 forward 18.8 vs 19.3 us, input gradient 17.0 vs 18.5, weight gradient
-    // 15.1 vs 20.5), inside the DQN iteration it does not (0.4009 vs 0.3970 ms, two alternating
-    // pairs on one box): with ~200 workgroups of one wave per SIMD its k loop is instruction-issue
-    // bound (~220 instructions per 24 MFMAs), and its 72 KiB of LDS keep the other streams'
-    // workgroups off the CU.
-    static int x6d_enabled = -1;
-    if (x6d_enabled < 0) {
-      const char* e = getenv("AA_GEMM_X6D");
-      x6d_enabled = (e != nullptr && e[0] == '1') ? 1 : 0;
-    }
-    const bool big = M >= 64 && N >= 64 && M * N * K >= 100000000LL;
-    if (d->force_cfg == AA_CFG_X6D ||
-        (d->force_cfg == 0 && x6d_enabled && big && aa_x6d_ok(d))) {
-      if (!aa_x6d_ok(d)) return AA_ERR_INVALID;
-      pl->cfg = AA_CFG_X6D - 1;
-      pl->bm = AA_X6D_BM; pl->bn = AA_X6D_BN;
-      aa_x6d_plan(d, &pl->splits, &pl->k_per_split);
-      pl->ws_bytes = pl->splits > 1 ? (size_t)pl->splits *
-                                          (size_t)(M * N + (d->colsum_out ? N : 0)) * sizeof(float)
-                                    : 0;
-      return AA_OK;
-    }
-  }
+  // (Round 5: the dense bf16x6 plan -- gemm_x6d.h, force_cfg = 10 / AA_GEMM_X6D=1 -- is gone.  It won
+  // in isolation (fc1 forward 18.8 vs 19.3 us, dX 17.0 vs 18.5, dW 15.1 vs 20.5) and lost inside the
+  // DQN iteration in two rounds (0.4009 vs 0.3970 ms, 0.434 vs 0.423 ms): its k loop is
+  // instruction-issue bound (~220 instructions per 24 MFMAs with the operand split inside it) and
+  // its 72 KiB of LDS keep the other streams' workgroups off the CU.  git history has it.)
   if (d->force_cfg > 0) {
     cfg = d->force_cfg - 1;
     if (cfg >= AA_NCFG) return AA_ERR_INVALID;
@@ -985,18 +962,10 @@ static int aa_gemm_f32_impl(const aa_gemm_desc* d, void* workspace, int64_t work
   if (d->b_mode == AA_B_COL && d->a_mode != AA_A_ROW) return AA_ERR_INVALID;
   switch (d->a_mode) {
     case AA_A_ROW:
-      if (pl.cfg == AA_CFG_X6D - 1) {
-        rc = aa_x6d_launch(p, true, d->b_mode == AA_B_COL, st);
-        break;
-      }
       rc = d->b_mode == AA_B_ROW ? aa_gemm_launch_cfg<AA_A_ROW, AA_B_ROW>(p, pl, st)
                                  : aa_gemm_launch_cfg<AA_A_ROW, AA_B_COL>(p, pl, st);
       break;
     case AA_A_COL:
-      if (pl.cfg == AA_CFG_X6D - 1) {
-        rc = aa_x6d_launch(p, false, false, st);
-        break;
-      }
       rc = aa_gemm_launch_cfg<AA_A_COL, AA_B_ROW>(p, pl, st);
       break;
     case AA_A_PATCH:

@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+CPU_RING_FRAMES = 256          # replay frames per env of the cpu_baseline leg (see cpu_baseline)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 PMC_FILE = os.path.join("profiles", "r04_pmc.json")   # committed rocprofv3 --pmc passes (isolated)
 # Set in the child of the in-loop profiling pass (see inloop_profile): the run brackets its timed
@@ -197,7 +198,7 @@ def train_flops_per_sample():
     return 2.0 * (2 * fwd + bwd)
 
 
-def build_workload(dev, rank, world, B_env, max_length, S, seed):
+def build_workload(dev, rank, world, B_env, max_length, S, seed, replay="uniform"):
     from agents_amd import optimizers
     from agents_amd.agents.dqn import dqn_agent
     from agents_amd.drivers import dynamic_step_driver
@@ -225,16 +226,31 @@ def build_workload(dev, rank, world, B_env, max_length, S, seed):
         td_errors_loss_fn=common.element_wise_huber_loss, gamma=0.99, epsilon_greedy=0.1,
         target_update_tau=1.0, target_update_period=2500, train_step_counter=train_step,
         seed=seed * 77 + rank)
-    rb = rb_lib.TFUniformReplayBuffer(agent.collect_data_spec, batch_size=B_env,
-                                      max_length=max_length, device=dev, seed=seed * 13 + rank)
+    hook = None
+    if replay == "prioritized":
+        # proportional prioritized sampling (csrc/prio.hip) closed into a loop through the hooks
+        # the reference provides: DqnLossInfo.td_error -> Learner(after_train_strategy_step_fn)
+        # (tf_agents/train/learner.py:362-376, agents/dqn/dqn_agent.py:50-72)
+        from agents_amd.replay_buffers import tf_prioritized_replay_buffer as prb
+        rb = prb.TFPrioritizedReplayBuffer(agent.collect_data_spec, batch_size=B_env,
+                                           max_length=max_length, device=dev,
+                                           seed=seed * 13 + rank)
+        hook = rb.update_priorities_from_loss
+    else:
+        rb = rb_lib.TFUniformReplayBuffer(agent.collect_data_spec, batch_size=B_env,
+                                          max_length=max_length, device=dev,
+                                          seed=seed * 13 + rank)
     random_policy = q_policy.RandomTFPolicy(tss, aspec, seed=seed * 5 + rank)
     init_driver = dynamic_step_driver.DynamicStepDriver(env, random_policy,
                                                         observers=[rb.add_batch],
                                                         num_steps=B_env * max_length)
     collect_driver = dynamic_step_driver.DynamicStepDriver(env, agent.collect_policy,
                                                            observers=[rb.add_batch], num_steps=1)
-    dataset = rb.as_dataset(num_parallel_calls=3, sample_batch_size=S, num_steps=2).prefetch(3)
-    lrn = learner.Learner(None, train_step, agent, experience_dataset_fn=None)
+    dataset = rb.as_dataset(num_parallel_calls=3, sample_batch_size=S, num_steps=2)
+    if replay != "prioritized":     # priorities change between draws: no sampling ahead
+        dataset = dataset.prefetch(3)
+    lrn = learner.Learner(None, train_step, agent, experience_dataset_fn=None,
+                          after_train_strategy_step_fn=hook)
     return dict(env=env, agent=agent, rb=rb, init_driver=init_driver,
                 collect_driver=collect_driver, dataset=dataset, learner=lrn, net=net)
 
@@ -554,13 +570,15 @@ def run_other_config(name, steps, timeout=300):
 
 def cpu_baseline(S, steps, threads):
     """The oracle (numpy replay + torch-CPU DQN step) timed on this host: a bounded sample of the
-    same workload (same shapes, batch 256, replay ring shortened to 64 frames per env)."""
+    same workload (same shapes, batch 256, replay ring shortened to CPU_RING_FRAMES = 256 frames per
+    env: 65,536 rows = 1.85 GB of host memory -- a working set beyond the host's last-level cache,
+    where round 4's 8-frame ring (58 MB) sat inside it; the GPU side runs 3,906 frames per env)."""
     from oracle import dqn as odqn
     from oracle import nets as onets
     from oracle import optim as ooptim
     from oracle import replay as oreplay
     torch.set_num_threads(threads)
-    B_env, L_ = 256, 8
+    B_env, L_ = 256, CPU_RING_FRAMES
     layers = onets.atari_q_layers(NUM_ACTIONS)
     params = onets.init_params(layers, OBS_SHAPE, seed=0)
     agent = odqn.OracleDqnAgent(layers, OBS_SHAPE, NUM_ACTIONS, params,
@@ -570,9 +588,10 @@ def cpu_baseline(S, steps, threads):
     dtypes = [np.int32, np.uint8, np.int64, np.int32, np.float32, np.float32]
     rb = oreplay.OracleReplayBuffer(shapes, dtypes, B_env, L_, seed=1)
     rng = np.random.default_rng(0)
-    for _ in range(L_):
+    frames = [rng.integers(0, 256, (B_env,) + OBS_SHAPE, dtype=np.uint8) for _ in range(4)]
+    for i in range(L_):     # (untimed prefill: four distinct frame batches, cycled)
         rb.add_batch([rng.integers(0, 3, B_env).astype(np.int32),
-                      rng.integers(0, 256, (B_env,) + OBS_SHAPE, dtype=np.uint8),
+                      frames[i & 3],
                       rng.integers(0, NUM_ACTIONS, B_env).astype(np.int64),
                       rng.integers(0, 3, B_env).astype(np.int32),
                       rng.choice([-1.0, 0.0, 1.0], B_env).astype(np.float32),
@@ -654,6 +673,89 @@ def setup_ranks(args):
                 f"{dist.get_world_size()} ranks, one rank per GPU (this rank: {dev})")
 
     return world, rank, dev
+
+
+def main_prioritized(args):
+    """`--replay prioritized`: configs[1]'s loop (256 envs, 1 M-row uint8 Atari replay, batch 256,
+    Mnih-15 Q-net) with proportional prioritized sampling instead of uniform: every iteration is
+    collect (add_batch gives the new rows the running maximum priority) -> get_next (two-level
+    exact scan over the 1 M priorities, csrc/prio.hip) -> DqnAgent.train -> update_priorities from
+    DqnLossInfo.td_error via Learner(after_train_strategy_step_fn=...).  One GPU, for the record;
+    the graded line is the uniform one.  `roofline` = the sampler's scan launches."""
+    if args.gpus != 1:
+        raise SystemExit("--replay prioritized is a single-GPU line")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from agents_amd import _lib
+    from agents_amd.utils import common
+    _lib.load()
+    S = args.batch
+    w = build_workload(dev, 0, 1, args.envs, args.max_length, S, seed=1, replay="prioritized")
+    prefill = args.max_length if args.prefill < 0 else min(args.prefill, args.max_length)
+    w["init_driver"]._num_steps = args.envs * max(prefill, 2)
+    w["init_driver"].run()
+    torch.cuda.synchronize()
+    rb, lrn = w["rb"], w["learner"]
+    log(f"[bench] prioritized replay: prefilled {rb.num_frames()} frames")
+    it = iter(w["dataset"])
+    collect_run = common.function(w["collect_driver"].run)
+    time_step = None
+
+    def step():
+        nonlocal time_step
+        time_step, _ = collect_run(time_step)
+        return lrn.run(iterations=1, iterator=it)
+
+    for _ in range(max(args.warmup, 8)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        li = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    # the sampler alone: HIP events around back-to-back draws (index sampling only, no row gather)
+    reps = 50
+    rb._sample_rows(S, 2)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        rb._sample_rows(S, 2)
+    e1.record()
+    torch.cuda.synchronize()
+    scan_ms = e0.elapsed_time(e1) / reps
+    cap = rb.capacity
+    n_blocks = (cap + 1023) // 1024
+    # level 1 reads every priority (4 B) and stored id (8 B); level 2, per sample, the block sums
+    # (8 B each) and one block's 1,024 priorities + ids
+    scan_bytes = cap * 12 + S * (n_blocks * 8 + 1024 * 12)
+    pri = rb.priorities()
+    out = {"metric": "replay_samples_per_sec trained, DQN Atari b=256, PRIORITIZED replay "
+                     "(proportional, priorities from td_error each step)",
+           "value": S / dt, "unit": "samples/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": max(args.warmup, 8), "ms_per_step": dt * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "learner_steps_per_sec": 1.0 / dt, "final_loss": float(li.loss),
+           "config": {"workload": "configs[1] with TFPrioritizedReplayBuffer: DQN Atari "
+                                  f"Pong-shaped, replay {args.envs}x{args.max_length} rows, "
+                                  f"batch={S}, num_steps=2, Mnih-15 Q-net; collect -> prioritized "
+                                  "get_next -> train -> update_priorities(td_error) per iteration "
+                                  "(no sampling ahead, one stream)",
+                      "global_batch": S, "envs_per_gpu": args.envs,
+                      "replay_rows_per_gpu": cap, "parallelism": "single",
+                      "replay": "prioritized"},
+           "roofline": {"kernel": "aa_prio_block_sums_kernel + aa_prio_sample_kernel "
+                                  "(csrc/prio.hip): exact uint64 two-level scan over all "
+                                  "priorities, one draw of 256 window starts",
+                        "bound": "hbm", "achieved": scan_bytes / scan_ms / 1e6,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": scan_bytes / scan_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_ms": scan_ms, "algorithmic_bytes_per_launch": scan_bytes,
+                        "duration_source": "HIP events around 50 back-to-back draws"},
+           "priorities": {"max": float(pri.max()), "mean_nonzero":
+                          float(pri[pri > 0].mean()), "rows_with_priority": int((pri > 0).sum())}}
+    print(json.dumps(out), flush=True)
 
 
 def main_other_config(args):
@@ -776,6 +878,10 @@ def main():
     ap.add_argument("--config", choices=["dqn", "ppo", "sac"], default="dqn",
                     help="dqn = BASELINE.json's metric (configs[1] / [3]); ppo / sac = configs[2] / "
                          "configs[4] at one GPU, for the record")
+    ap.add_argument("--replay", choices=["uniform", "prioritized"], default="uniform",
+                    help="prioritized = the DQN loop on TFPrioritizedReplayBuffer (proportional "
+                         "sampling, csrc/prio.hip) with priorities fed back from td_error through "
+                         "the Learner's after_train_strategy_step_fn; one GPU, for the record")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=40)
@@ -816,6 +922,8 @@ def main():
     args.steps_given = any(a == "--steps" or a.startswith("--steps=") for a in sys.argv[1:])
     if args.config != "dqn":
         return main_other_config(args)
+    if args.replay == "prioritized":
+        return main_prioritized(args)
 
     world, rank, dev = setup_ranks(args)
     local_rank = dev.index
@@ -1237,7 +1345,7 @@ def main():
                 "sample": f"{args.cpu_steps} iterations (collect 256 envs + sample 256x2 + train "
                           f"batch 256) of the numpy/torch-CPU oracle on {threads} of {ncpu} host "
                           f"threads (fastest of {cands}), {spstep:.3f} s/iteration, replay ring "
-                          "shortened to 8 frames/env"}
+                          f"shortened to {CPU_RING_FRAMES} frames/env (1.85 GB)"}
         emit(out, args.detail_out)
     if world > 1:
         import torch.distributed as dist

@@ -52,14 +52,21 @@ def _judge(name, hip, fp32, f64):
             assert e_h <= 3e-5 * abs(d) + 1e-9, f"{name} step {k}: {e_h:.2e} of {d:.6g}"
 
 
-def test_dqn_configs1_free_running_envelope(dev):
+@pytest.mark.parametrize("period", [2500, 3])
+def test_dqn_configs1_free_running_envelope(dev, period):
     """configs[1] shapes as bench.py builds them (batch 256, Mnih-15 net on uint8 84x84x4, Huber,
-    centred RMSProp), replay ring shortened to 8 frames per env; eager `agent.train`."""
+    centred RMSProp), replay ring shortened to 8 frames per env; eager `agent.train`.
+    period = 3: the hard target update (dqn_agent.py:385-409) fires after steps 3 and 6, so the
+    free-running trajectory crosses two target updates inside the K = 8 steps (the benchmark's
+    2,500-step period never fires in a test-sized run); the graphed loop is held bit-identical
+    to these eager steps across such updates by tests/test_gpu_early_target.py."""
     S = 256
     with torch.cuda.device(dev):
         w = bench.build_workload(dev, 0, 1, 256, 8, S, seed=1)
         w["rb"]._dataset_ring = 0
         agent, net, rb = w["agent"], w["net"], w["rb"]
+        if period != 2500:
+            agent._update_target = agent._get_target_updater(1.0, period)
         w["init_driver"]._num_steps = 256 * 8
         w["init_driver"].run()
         batches = [rb.get_next(S, 2)[0] for _ in range(K)]
@@ -68,9 +75,9 @@ def test_dqn_configs1_free_running_envelope(dev):
         p0 = [torch.tensor(a) for a in net.get_weights()]
         rms = lambda: ooptim.RMSprop(2.5e-4, 0.95, 0.95, 0.01, True)
         o32 = odqn.OracleDqnAgent(layers, bench.OBS_SHAPE, bench.NUM_ACTIONS, p0, optimizer=rms(),
-                                  gamma=0.99, loss="huber", target_update_period=2500)
+                                  gamma=0.99, loss="huber", target_update_period=period)
         o64 = freerun.F64DqnAgent(layers, p0, rms(), gamma=0.99, loss="huber",
-                                  target_update_period=2500)
+                                  target_update_period=period)
         hip, fp32, f64 = [], [], []
         for exp in batches:
             hip.append(float(agent.train(exp).loss))
@@ -78,7 +85,9 @@ def test_dqn_configs1_free_running_envelope(dev):
             total, _, _ = o32.train(torch.from_numpy(obs), act, rew, disc, st)
             fp32.append(float(total))
             f64.append(o64.train(torch.from_numpy(obs), act, rew, disc, st))
-        _judge("DQN configs[1]", hip, fp32, f64)
+        _judge(f"DQN configs[1] (target update every {period})", hip, fp32, f64)
+        if period != 2500:
+            assert agent._target_writes >= 1 + K // period   # initialize() + the periodic updates
         # the parameters after K free steps, against float64: same yardstick
         d = lambda ps: float(torch.sqrt(sum(((p.detach().double() - q.detach()) ** 2).sum()
                                             for p, q in zip(ps, o64.params))))

@@ -63,72 +63,6 @@ def test_dense_forward_forced_configs(dev, cfg, splits):
     close(out, torch.relu(x.double() @ w.double() + b.double()))
 
 
-X6D = 10     # force_cfg of the dense bf16x6 plan (csrc/gemm_x6d.h); opt-in
-
-
-@pytest.mark.parametrize("splits", [0, 1, 3, 5])
-@pytest.mark.parametrize("act", [None, "relu"])
-def test_dense_x6d_forward(dev, splits, act):
-    """Ragged M / N (edge tiles, clamped rows), K a multiple of 32, with and without split-K."""
-    rng = np.random.default_rng(40 + splits)
-    M, N, K = 200, 70, 320
-    x, w, b = rnd(rng, M, K), rnd(rng, K, N) * 0.1, rnd(rng, N)
-    out = torch.full((M, N), float("nan"), device=dev)
-    ops.dense_forward(x.to(dev), w.to(dev), b.to(dev), act, out, force_cfg=X6D,
-                      force_splits=splits)
-    close(out, act_ref(x.double() @ w.double() + b.double(), act))
-
-
-@pytest.mark.parametrize("splits", [0, 1, 2, 5])
-def test_dense_x6d_dw_fused_bias_grad(dev, splits):
-    rng = np.random.default_rng(50 + splits)
-    M, N, K = 320, 70, 150       # x[M,K], dz[M,N]: the contraction runs over M
-    x, dz = rnd(rng, M, K), rnd(rng, M, N)
-    out = torch.full((K, N), float("nan"), device=dev)
-    bg = torch.full((N,), float("nan"), device=dev)
-    ops.dense_dw(x.to(dev), dz.to(dev), out, force_cfg=X6D, force_splits=splits, bias_grad=bg)
-    close(out, x.double().T @ dz.double())
-    close(bg, dz.double().sum(0), tol=5e-6)
-
-
-@pytest.mark.parametrize("splits", [0, 3])
-@pytest.mark.parametrize("mask_act", [None, "tanh"])
-def test_dense_x6d_dx(dev, splits, mask_act):
-    rng = np.random.default_rng(60 + splits)
-    M, N, K = 130, 96, 210       # dz[M,N], w[K,N]: the contraction runs over N
-    dz, w = rnd(rng, M, N), rnd(rng, K, N) * 0.1
-    y = torch.tanh(rnd(rng, M, K))
-    out = torch.full((M, K), float("nan"), device=dev)
-    ops.dense_dx(dz.to(dev), w.to(dev), out, mask_src=y.to(dev) if mask_act else None,
-                 mask_act=mask_act, force_cfg=X6D, force_splits=splits)
-    close(out, (dz.double() @ w.double().T) * actgrad_ref(y.double(), mask_act))
-
-
-def test_dense_x6d_exact_on_small_integers_and_ineligible_shapes(dev):
-    """Small-integer operands are single bf16 pieces with exact fp32 partial sums: all three
-    contractions reproduce float64 bit for bit (any operand-role / K-order mix-up shows); K not a
-    multiple of 32 is refused when the plan is forced (AA_ERR_INVALID) and falls back when not."""
-    rng = np.random.default_rng(7)
-    M, N, K = 256, 512, 3136
-    x = torch.from_numpy(rng.integers(-4, 5, (M, K)).astype(np.float32))
-    w = torch.from_numpy(rng.integers(-3, 4, (K, N)).astype(np.float32))
-    dz = torch.from_numpy(rng.integers(-4, 5, (M, N)).astype(np.float32))
-    y = torch.empty(M, N, device=dev)
-    ops.dense_forward(x.to(dev), w.to(dev), None, None, y, force_cfg=X6D)
-    assert torch.equal(y.cpu().double(), x.double() @ w.double())
-    dx = torch.empty(M, K, device=dev)
-    ops.dense_dx(dz.to(dev), w.to(dev), dx, force_cfg=X6D)
-    assert torch.equal(dx.cpu().double(), dz.double() @ w.double().T)
-    dw = torch.empty(K, N, device=dev)
-    bg = torch.empty(N, device=dev)
-    ops.dense_dw(x.to(dev), dz.to(dev), dw, bias_grad=bg, force_cfg=X6D)
-    assert torch.equal(dw.cpu().double(), x.double().T @ dz.double())
-    assert torch.equal(bg.cpu().double(), dz.double().sum(0))
-    with pytest.raises(Exception):
-        ops.dense_forward(torch.zeros(64, 100, device=dev), torch.zeros(100, 64, device=dev), None,
-                          None, torch.empty(64, 64, device=dev), force_cfg=X6D)
-
-
 def test_dense_forward_strided_rows(dev):
     """A operand = experience.observation[:, 0] of a [B, T, K] tensor (row pitch T*K)."""
     rng = np.random.default_rng(5)
