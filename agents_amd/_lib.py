@@ -155,6 +155,13 @@ _SIGNATURES = {
     "aa_conv_pair_x6_phase": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                       POINTER(ConvLayerDesc), POINTER(ConvLayerDesc), c_void_p,
                                       c_int64, c_int32, c_void_p]),
+    "aa_conv_triple_x6_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32,
+                                                    POINTER(ConvLayerDesc), POINTER(ConvLayerDesc),
+                                                    POINTER(ConvLayerDesc)]),
+    "aa_conv_triple_x6_phase": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                        c_float, POINTER(ConvLayerDesc), POINTER(ConvLayerDesc),
+                                        POINTER(ConvLayerDesc), c_void_p, c_int64, c_int32,
+                                        c_void_p]),
     "aa_conv_dx_frame_supported": (c_int, [POINTER(ConvDxDesc)]),
     "aa_conv_dx_frame": (c_int, [POINTER(ConvDxDesc), c_void_p]),
     "aa_conv_dx_frame_x6_workspace_bytes": (c_int64, [POINTER(ConvDxDesc)]),
@@ -330,7 +337,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 13:
+    if lib.aa_abi_version() != 14:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -224,7 +224,9 @@ __device__ static inline void cx_layer(const CxLayer& L, const char* __restrict_
     if (ks + 2 < S) step(std::integral_constant<int, 2>{}, ks);
     if (dst != nullptr) { CX_STAMP_L(7) }
     const float bv = L.bias != nullptr ? bias_raw : 0.f;
-    float* yimg = L.y + (size_t)img * OHW * L.Cout + co;
+    // (L.y == nullptr: an output only a backward pass would read, and no backward pass follows --
+    // conv_triple_x6.h's callers; the pair's own entry points always pass both)
+    float* yimg = L.y != nullptr ? L.y + (size_t)img * OHW * L.Cout + co : nullptr;
     // the activation kind and "feeds a next layer" are resolved ONCE, outside the element loop
     auto emit = [&](auto actc, auto splitc) {
       constexpr int ACT = decltype(actc)::value;
@@ -238,7 +240,7 @@ __device__ static inline void cx_layer(const CxLayer& L, const char* __restrict_
           float v = (big[rt][e] + small[rt][e]) + bv;
           if (ACT == AA_ACT_RELU) v = v > 0.f ? v : 0.f;
           if (ACT == AA_ACT_TANH) v = tanhf(v);
-          yimg[p * L.Cout] = v;
+          if (yimg != nullptr) yimg[p * L.Cout] = v;
           if (SPLIT) {
             // v = hi + mid + lo exactly; one 2-byte store per plane at [pixel][channel]
             const unsigned h = cx_pk_bf16(v, 0.f) & 0xffffu;
@@ -461,3 +463,5 @@ int aa_conv_pair_x6_forward(const float* x, int64_t img_pitch, int32_t n_img, in
 }
 
 }  // extern "C"
+
+#include "conv_triple_x6.h"

@@ -384,14 +384,15 @@ class Sequential(network.Network):
         cur = x
         div = None
         pi = 0
-        skip = False
+        skip = 0
         pw_pair = self._pw["pair"] if (self._prepared_ok() and self._pw["pair"]) else None
+        pw_triple = self._pw.get("triple") if self._prepared_ok() else None
         prep_pending, s.prep_issued = s.prep_issued, None
         if prep_pending is None and pw_pair is None:
             prep_pending = self._hoist_pair_prep(s, B)
         for li, l in enumerate(self._layers):
-            if skip:        # second conv of a fused pair: already computed
-                skip = False
+            if skip:        # later conv(s) of a fused pair / triple: already computed
+                skip -= 1
                 cur = s.ys[pi]
                 pi += 1
                 continue
@@ -409,6 +410,30 @@ class Sequential(network.Network):
                 div = None
                 s.xs[pi] = cur
                 nxt = self._layers[li + 1] if li + 1 < len(self._layers) else None
+                nx2 = self._layers[li + 2] if li + 2 < len(self._layers) else None
+                if (FUSE_CONV_PAIRS and cur.dtype == torch.uint8 and isinstance(nxt, L.Conv2D)
+                        and isinstance(nx2, L.Conv2D) and cur.data_ptr() % 16 == 0
+                        and (B == 1 or cur.stride(0) % 16 == 0)
+                        and ops.conv_triple_prepare_bytes(
+                            tuple(cur.shape), self._kviews[pi:pi + 3],
+                            (l.stride, nxt.stride, nx2.stride)) > 0):
+                    # uint8 frames through all three convs in one launch, one workgroup per frame
+                    # (csrc/conv_triple_x6.h); the two intermediate activations are stored only on
+                    # slots a backward pass reads (the online network's train slot)
+                    keep = need_grad or s.dz_top is not None
+                    s.xs[pi + 1] = s.ys[pi]
+                    s.xs[pi + 2] = s.ys[pi + 1]
+                    prepared = pw_triple.get(pi) if pw_triple else None
+                    ops.conv_triple_forward(
+                        cur, self._kviews[pi:pi + 3], self._bviews[pi:pi + 3],
+                        (l.stride, nxt.stride, nx2.stride),
+                        (l.activation, nxt.activation, nx2.activation),
+                        (s.ys[pi] if keep else None, s.ys[pi + 1] if keep else None,
+                         s.ys[pi + 2]), a_div=a_div, prepared=prepared)
+                    skip = 2
+                    cur = s.ys[pi]
+                    pi += 1
+                    continue
                 if (FUSE_CONV_PAIRS and cur.dtype == torch.float32 and isinstance(nxt, L.Conv2D)
                         and cur.data_ptr() % 16 == 0 and cur.stride(0) % 4 == 0
                         and ops.conv_pair_supported(cur.shape, self._kviews[pi], l.stride,
@@ -425,7 +450,7 @@ class Sequential(network.Network):
                                           l.activation, s.ys[pi], self._kviews[pi + 1],
                                           self._bviews[pi + 1], nxt.stride, nxt.activation,
                                           s.ys[pi + 1], prepared=prepared)
-                    skip = True
+                    skip = 1
                 else:
                     ops.conv_forward(cur, self._kviews[pi], self._bviews[pi], l.stride,
                                      l.activation, s.ys[pi], a_div=a_div)
@@ -446,7 +471,7 @@ class Sequential(network.Network):
                     ops.dense_tail_forward(cur2, self._kviews[pi], self._bviews[pi], l.activation,
                                            s.ys[pi], self._kviews[pi + 1], self._bviews[pi + 1],
                                            nxt.activation, s.ys[pi + 1])
-                    skip = True
+                    skip = 1
                 else:
                     ops.dense_forward(cur2, self._kviews[pi], self._bviews[pi], l.activation,
                                       s.ys[pi])
@@ -476,6 +501,26 @@ class Sequential(network.Network):
             pi += 1
         return out
 
+    def _triple_head(self):
+        """((1, H, W, C), strides) when the stack opens with [Rescale,] three Conv2D layers on a
+        uint8 observation (the Atari Q-network: csrc/conv_triple_x6.h), else None."""
+        spec = self._input_tensor_spec
+        if spec is None or spec.dtype != torch.uint8 or len(spec.shape) != 3:
+            return None
+        convs = []
+        for l in self._layers:
+            if isinstance(l, L.Rescale):
+                continue
+            if isinstance(l, L.Conv2D):
+                convs.append(l)
+                if len(convs) == 3:
+                    break
+            else:
+                break
+        if len(convs) != 3 or len(self._param_layers) < 3:
+            return None
+        return (1,) + tuple(spec.shape), tuple(c.stride for c in convs)
+
     def enable_prepared_weights(self):
         """Opts this network into prepared weights (see PREPARED_WEIGHTS above).  The caller takes
         over the duty of calling `refresh_prepared()` after every write to the parameters that does
@@ -485,10 +530,17 @@ class Sequential(network.Network):
         if self._pw is not None or self._fused_small_ok():
             return self._pw is not None
         dev = self.flat_params.device
-        pair, dx = {}, {}
+        pair, dx, triple = {}, {}, {}
+        t3 = self._triple_head()
+        if t3 is not None and FUSE_CONV_PAIRS and "pair" in _PW_KINDS:
+            # uint8 frames -> three convs in one launch: one scratch holds the three split banks
+            shape, strides = t3
+            n = ops.conv_triple_prepare_bytes(shape, self._kviews[0:3], strides)
+            if n > 0:
+                triple[0] = torch.empty((n,), dtype=torch.uint8, device=dev)
         if FUSE_CONV_PAIRS and "pair" in _PW_KINDS:
             for pi in self._conv_param_pairs():
-                if pi in pair or (pi - 1) in pair:
+                if pi in pair or (pi - 1) in pair or (triple and pi in (0, 1)):
                     continue
                 l, nxt = self._param_layers[pi], self._param_layers[pi + 1]
                 shape = (1,) + tuple(self._info[pi][2])
@@ -504,9 +556,10 @@ class Sequential(network.Network):
             n = ops.conv_dx_prepare_bytes((1,) + tuple(self._info[i][2]), self._kviews[i], l.stride)
             if n > 0:
                 dx[i] = torch.empty((n,), dtype=torch.uint8, device=dev)
-        if not pair and not dx:
+        if not pair and not dx and not triple:
             return False
-        self._pw = {"pair": pair, "dx": dx, "torch_version": -1, "scatter": None}
+        self._pw = {"pair": pair, "dx": dx, "triple": triple, "torch_version": -1,
+                    "scatter": None}
         _PREPARED_NETS.append(weakref.ref(self))
         self.refresh_prepared()
         self._pw["scatter"] = self._build_plane_scatter()
@@ -523,11 +576,13 @@ class Sequential(network.Network):
         pw = self._pw
         n = self.flat_params.numel()
         targets = []
-        for kind in ("pair", "dx"):
-            for pi, ws in pw[kind].items():
+        for kind in ("triple", "pair", "dx"):
+            for pi, ws in pw.get(kind, {}).items():
                 nw = int(np.prod(self._shapes[pi][0]))
-                if kind == "pair":
+                if kind in ("pair", "triple"):
                     nw += int(np.prod(self._shapes[pi + 1][0]))
+                if kind == "triple":
+                    nw += int(np.prod(self._shapes[pi + 2][0]))
                 targets.append((ws, nw))
         if not targets or len(targets) > 4 or n >= (1 << 24):
             return None
@@ -580,6 +635,9 @@ class Sequential(network.Network):
         pw = self._pw
         if pw is None:
             return
+        for pi, ws in pw.get("triple", {}).items():
+            shape, strides = self._triple_head()
+            ops.conv_triple_prepare(shape, self._kviews[pi:pi + 3], strides, ws)
         for pi, ws in pw["pair"].items():
             l, nxt = self._param_layers[pi], self._param_layers[pi + 1]
             ops.conv_pair_prepare((1,) + tuple(self._info[pi][2]), self._kviews[pi], l.stride,

@@ -459,6 +459,91 @@ def conv_pair_forward(x, w1, b1, s1, act1, y1, w2, b2, s2, act2, y2, prepared=No
     return y2
 
 
+# ---- conv1 -> conv2 -> conv3 on uint8 frames in one launch (csrc/conv_triple_x6.h) ----------------
+# AA_FUSE_CONV_TRIPLE=0: conv1 stays its own launch in front of the fused pair (A/B measurements)
+CONV_TRIPLE = _os.environ.get("AA_FUSE_CONV_TRIPLE", "1") != "0"
+_TRIPLE_WS = {}
+
+
+def _triple_descs(ws_, bs_, strides, acts, ys):
+    d = []
+    for w, b, st, act, y in zip(ws_, bs_, strides, acts, ys):
+        KH, KW, _, Cout = w.shape
+        d.append(_lib.ConvLayerDesc(w=ptr(w), bias=ptr(b), y=ptr(y), KH=KH, KW=KW, stride=st,
+                                    Cout=Cout, act=ACT[act] if act in ACT else 0))
+    return d
+
+
+def conv_triple_prepare_bytes(x_shape, ws_, strides):
+    """Bytes of split-filter scratch of the three-layer kernel for uint8 frames of x_shape and the
+    three HWIO kernels `ws_`; 0 when the shapes do not qualify (the caller keeps conv1 + the pair)."""
+    if not (CONV_TRIPLE and CONV_PAIR_X6):
+        return 0
+    Bn, H, W, C = x_shape
+    key = (Bn, H, W, C) + tuple(tuple(w.shape) for w in ws_) + tuple(strides)
+    n = _TRIPLE_WS.get(key)
+    if n is None:
+        n = 0
+        if all(len(w.shape) == 4 for w in ws_) and ws_[0].shape[2] == C and \
+                ws_[1].shape[2] == ws_[0].shape[3] and ws_[2].shape[2] == ws_[1].shape[3]:
+            d = [_lib.ConvLayerDesc(w=None, bias=None, y=None, KH=w.shape[0], KW=w.shape[1],
+                                    stride=st, Cout=w.shape[3], act=0)
+                 for w, st in zip(ws_, strides)]
+            n = int(_lib.load().aa_conv_triple_x6_workspace_bytes(
+                Bn, H, W, C, ctypes.byref(d[0]), ctypes.byref(d[1]), ctypes.byref(d[2])))
+        _TRIPLE_WS[key] = n
+    return n
+
+
+def conv_triple_prepare(x_shape, ws_, strides, ws):
+    """The weights-only half of conv_triple_forward: the three filter banks split into `ws`."""
+    require_cuda(ws_[0], ws_[1], ws_[2], ws)
+    Bn, H, W, C = x_shape
+    d = _triple_descs(ws_, (None,) * 3, strides, (None,) * 3, (None,) * 3)
+    with torch.cuda.device(ws.device):
+        check(_lib.load().aa_conv_triple_x6_phase(
+            None, 0, Bn, H, W, C, 255.0, ctypes.byref(d[0]), ctypes.byref(d[1]),
+            ctypes.byref(d[2]), ptr(ws), ws.numel(), 1, _lib.stream_ptr()),
+            "aa_conv_triple_x6_phase(1)")
+
+
+def conv_triple_forward(x, ws_, bs_, strides, acts, ys, a_div=255.0, prepared=None):
+    """ys[2] = act3(conv(act2(conv(act1(conv(x / a_div, w1) + b1), w2) + b2), w3) + b3) on uint8
+    NHWC frames x [B, H, W, C] (only the batch dimension may be strided) in ONE launch.  ys[0] /
+    ys[1] may be None: intermediate activations only a backward pass would read are then not
+    stored.  prepared: scratch that conv_triple_prepare filled for these weights."""
+    require_cuda(x, ws_[0], ws_[1], ws_[2], ys[2])
+    if x.dtype != torch.uint8 or x.dim() != 4:
+        raise ValueError("conv_triple_forward needs a uint8 NHWC input")
+    Bn, H, W, C = x.shape
+    for w in ws_:
+        _f32c(w, "w")
+    oh, ow, cin = H, W, C
+    for w, st, y in zip(ws_, strides, ys):
+        KH, KW, Ci, Co = w.shape
+        if Ci != cin:
+            raise ValueError("conv_triple_forward: channel mismatch between the layers")
+        oh, ow = conv_out_hw(oh, ow, KH, KW, st)
+        cin = Co
+        if y is not None:
+            _f32c(y, "y")
+            if y.numel() != Bn * oh * ow * Co:
+                raise ValueError("conv_triple_forward: bad output size")
+    if ys[2] is None:
+        raise ValueError("conv_triple_forward: the last output is required")
+    n = conv_triple_prepare_bytes((Bn, H, W, C), ws_, strides)
+    if n <= 0:
+        raise ValueError("conv_triple_forward: shapes not supported (conv_triple_prepare_bytes)")
+    d = _triple_descs(ws_, bs_, strides, acts, ys)
+    with torch.cuda.device(x.device):
+        ws = prepared if prepared is not None else _WS3.get(n, x.device)
+        check(_lib.load().aa_conv_triple_x6_phase(
+            ptr(x), _img_pitch(x), Bn, H, W, C, float(a_div), ctypes.byref(d[0]),
+            ctypes.byref(d[1]), ctypes.byref(d[2]), ptr(ws), ws.numel(),
+            2 if prepared is not None else 3, _lib.stream_ptr()), "aa_conv_triple_x6_phase")
+    return ys[2]
+
+
 # AA_CONV_DW_X6=0: keep the conv weight gradients of fp32 layers on the fp32 MFMA GEMM (A/B)
 CONV_DW_X6 = _os.environ.get("AA_CONV_DW_X6", "1") != "0"
 _DW_X6_WS = {}

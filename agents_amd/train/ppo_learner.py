@@ -62,7 +62,8 @@ class PPOLearner:
             after_train_strategy_step_fn=after_train_strategy_step_fn, triggers=triggers,
             checkpoint_interval=checkpoint_interval, summary_interval=summary_interval,
             use_kwargs_in_agent_train=use_kwargs_in_agent_train, strategy=strategy)
-        self.num_replicas = self._generic_learner.strategy.num_replicas_in_sync
+        self.strategy = self._generic_learner.strategy
+        self.num_replicas = self.strategy.num_replicas_in_sync
         self.num_frames_for_training = 0
         self._perm = None
         self._perm_calls = 0      # Philox call counter of the shuffle: one permutation per epoch

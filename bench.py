@@ -707,14 +707,26 @@ def main_prioritized(args):
         time_step, _ = collect_run(time_step)
         return lrn.run(iterations=1, iterator=it)
 
-    for _ in range(max(args.warmup, 8)):
+    from agents_amd.utils import graph
+    # untimed until no HIP graph has been captured for a while: the sampled batches are fresh
+    # tensors, and GraphedTrain gives an address set that comes back its own graph
+    quiet, seen, primed = 0, graph.capture_count(), 0
+    while primed < 400 and quiet < 20:
+        step()
+        primed += 1
+        now = graph.capture_count()
+        quiet = quiet + 1 if now == seen else 0
+        seen = now
+    for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    captures_before = graph.capture_count()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         li = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    captures_in_timed_region = graph.capture_count() - captures_before
     # the sampler alone: HIP events around back-to-back draws (index sampling only, no row gather)
     reps = 50
     rb._sample_rows(S, 2)
@@ -734,9 +746,10 @@ def main_prioritized(args):
     out = {"metric": "replay_samples_per_sec trained, DQN Atari b=256, PRIORITIZED replay "
                      "(proportional, priorities from td_error each step)",
            "value": S / dt, "unit": "samples/s", "n_gpus": 1, "steps": args.steps,
-           "warmup": max(args.warmup, 8), "ms_per_step": dt * 1e3, "higher_is_better": True,
+           "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "learner_steps_per_sec": 1.0 / dt, "final_loss": float(li.loss),
+           "prime_steps": primed, "captures_in_timed_region": captures_in_timed_region,
            "config": {"workload": "configs[1] with TFPrioritizedReplayBuffer: DQN Atari "
                                   f"Pong-shaped, replay {args.envs}x{args.max_length} rows, "
                                   f"batch={S}, num_steps=2, Mnih-15 Q-net; collect -> prioritized "

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 13
+#define AA_ABI_VERSION 14
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -177,11 +177,7 @@ typedef struct aa_gemm_desc {
                            * 32x64, 32x32, 256x32 (LDS-DMA operands only); 9 = the bf16 matrix-core
                            * plans with exact 3-piece splits: uint8 conv forward / weight gradient
                            * with 32 filters (the automatic choice there, csrc/conv_u8_bf16.h);
-                           * 10 = the dense
-                           * bf16x6 plan (csrc/gemm_x6d.h: both operands split on their way into
-                           * LDS, 64x64 tiles; K % 32 == 0; opt-in: it wins in isolation, not inside
-                           * the DQN iteration); AA_ERR_INVALID when the shape is not
-                           * eligible */
+                           * AA_ERR_INVALID when the shape is not eligible */
   int32_t force_splits;   /* 0 = auto split-K */
   /* nullable, AA_B_ROW only: colsum_out[n] = sum_k B(k,n).  With B = dZ this is the bias
    * gradient (tf.GradientTape of keras BiasAdd), produced by the weight-gradient GEMM that
@@ -289,6 +285,28 @@ int aa_conv_pair_x6_phase(const float* x, int64_t img_pitch, int32_t n_img, int3
                           int32_t Cin, const aa_conv_layer_desc* first,
                           const aa_conv_layer_desc* second, void* workspace,
                           int64_t workspace_bytes, int32_t phases, void* stream);
+
+/* The whole convolutional stack of the Mnih-15 Q-network in ONE launch (csrc/conv_triple_x6.h):
+ * y1 = act1(conv(x / a_div, w1) + b1) on uint8 frames (the Lambda(x / 255) + first Conv2D of
+ * examples/dqn/mnih15/dqn_train_eval_atari.py:80-112; QNetwork / EncodingNetwork forward,
+ * networks/encoding_network.py:222-359), then the pair above on y1 -- one workgroup per frame, y1
+ * handed from the first layer's epilogue to the second layer's LDS planes without a trip through
+ * memory.  first->y and second->y may be NULL (activations only a backward pass would read are
+ * then not stored); third->y is always written.  x: uint8 NHWC, `img_pitch` BYTES between frames
+ * (0 = dense), 16-byte aligned.  Limits: KW * Cin % 32 == 0 with at most 8 such 32-byte steps per
+ * patch, first Cout in {16, 32, 64, 128}, the pair's limits for layers two and three, the frame's
+ * bytes <= the third layer's LDS planes (aa_conv_triple_x6_workspace_bytes returns 0 when a shape
+ * does not qualify; the call then returns AA_ERR_RANGE and aa_gemm_f32 + aa_conv_pair_x6_* remain
+ * the path).  phases as for aa_conv_pair_x6_phase; workspace = the three split filter banks. */
+int64_t aa_conv_triple_x6_workspace_bytes(int32_t n_img, int32_t H, int32_t W, int32_t Cin,
+                                          const aa_conv_layer_desc* first,
+                                          const aa_conv_layer_desc* second,
+                                          const aa_conv_layer_desc* third);
+int aa_conv_triple_x6_phase(const uint8_t* x, int64_t img_pitch, int32_t n_img, int32_t H,
+                            int32_t W, int32_t Cin, float a_div,
+                            const aa_conv_layer_desc* first, const aa_conv_layer_desc* second,
+                            const aa_conv_layer_desc* third, void* workspace,
+                            int64_t workspace_bytes, int32_t phases, void* stream);
 
 /* Input gradient of a VALID Conv2D in gather form, one workgroup per frame (no column-gradient
  * slab, no col2im): dx[b,iy,ix,ci] = act'(mask_src[b,iy,ix,ci]) * sum over the patches containing
