@@ -398,7 +398,9 @@ int aa_conv_pair_x6_phase(const float* x, int64_t img_pitch, int32_t n_img, int3
   const int rc = cx_check(n_img, H, W, Cin, first, second, &P, &lds, &ws);
   if (rc != AA_OK) return rc;
   if (first->w == nullptr || second->w == nullptr) return AA_ERR_INVALID;
-  if ((phases & 2) && (first->y == nullptr || second->y == nullptr)) return AA_ERR_INVALID;
+  // first->y may be NULL: the middle activation is only read by a backward pass (the policy's and
+  // the target network's forwards have none), the second layer takes it from LDS
+  if ((phases & 2) && second->y == nullptr) return AA_ERR_INVALID;
   if ((int64_t)ws > workspace_bytes || ((uintptr_t)workspace & 15) != 0) return AA_ERR_RANGE;
   const int64_t dense = (int64_t)H * W * Cin;
   P.x = x;

@@ -21,11 +21,12 @@
 // (16x16x32 here, 32x32x16 there), i.e. only the order of the fp32 accumulations.
 //
 // Mapping: k-step = 32 consecutive bytes of one patch row (KW * Cin = 32 for the Atari layer: one
-// kernel row); lane (pixel l & 15, octet l >> 4) reads its 8 bytes with one ds_read_b64 and converts
-// them with v_cvt_f32_ubyteN + v_perm (exact).  Wave w owns column tile w % nct and every
+// kernel row); the frame is converted to bf16 (exact) while it is staged, so lane (pixel l & 15,
+// octet l >> 4) reads its fragment with one ds_read_b128.  Wave w owns column tile w % nct and every
 // (NW / nct)-th 16-pixel row tile; the wave's filter fragments (3 pieces x 8 k-steps) are loaded
-// once into registers and reused by all of its row tiles.  The frame is staged in the region of
-// conv3's input planes, which are not written before conv2's epilogue.
+// once into registers and reused by all of its row tiles.  The frame is staged from the start of
+// conv3's input planes on (56 KB as bf16: past their end, inside the 160 KB), which are not written
+// before conv2's epilogue.
 #pragma once
 
 #define AA_CT_MAX_KS 8        /* k-steps of the first layer (their filter fragments live in registers) */
@@ -115,12 +116,12 @@ __device__ static inline void ct_first(const CtFirst& F, const char* __restrict_
       const int oy = cx_div(p, F.m_ow), ox = p - oy * F.OW;
       pb[u] = oy * F.stride * F.rowb + ox * F.stride * F.Cin + lg * 8;
     }
-    uint2 raw[AA_CT_MAX_KS][2];
+    CxFrag raw[AA_CT_MAX_KS][2];
 #pragma unroll
     for (int ks = 0; ks < AA_CT_MAX_KS; ++ks)
 #pragma unroll
       for (int u = 0; u < 2; ++u)
-        raw[ks][u] = *reinterpret_cast<const uint2*>(frame + pb[u] + F.tap[ks]);
+        raw[ks][u].q = *reinterpret_cast<const uint4*>(frame + 2 * (pb[u] + F.tap[ks]));
     cx_f32x4 acc[2][3];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -130,14 +131,11 @@ __device__ static inline void ct_first(const CtFirst& F, const char* __restrict_
     for (int ks = 0; ks < AA_CT_MAX_KS; ++ks) {
       if (ks < F.ksteps) {                     // uniform
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          CxFrag a;
-          ct_u8x4_to_bf16(raw[ks][u].x, a.q.x, a.q.y);
-          ct_u8x4_to_bf16(raw[ks][u].y, a.q.z, a.q.w);
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
           for (int s = 0; s < 3; ++s)
-            acc[u][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b[ks][s].v, acc[u][s], 0, 0, 0);
-        }
+            acc[u][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(raw[ks][u].v, b[ks][s].v,
+                                                                acc[u][s], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -179,7 +177,7 @@ __global__ void __launch_bounds__(NW * 64) aa_conv_triple_x6_kernel(CtParams P) 
   const CxLayer& L0 = P.l[0];
   const CxLayer& L1 = P.l[1];
   char* s_in = cx_lds;                             // conv2's input planes (conv1's split output)
-  char* s_mid = cx_lds + 3 * (size_t)L0.plane;     // the uint8 frame, then conv3's input planes
+  char* s_mid = cx_lds + 3 * (size_t)L0.plane;     // the frame as bf16, then conv3's input planes
   const int tid = threadIdx.x;
   const int n16 = F.frame_bytes >> 4;
   for (int img = blockIdx.x; img < P.n_img; img += gridDim.x) {
@@ -190,7 +188,10 @@ __global__ void __launch_bounds__(NW * 64) aa_conv_triple_x6_kernel(CtParams P) 
     float bias1;
     ct_load_b<NW>(F, b1, bias1);
     const uint4* xs = reinterpret_cast<const uint4*>(F.x + (size_t)img * F.img_pitch);
-    // the whole frame in flight at once: four 16-byte loads per lane and trip (28,224 B = one trip)
+    // the whole frame in flight at once: four 16-byte loads per lane and trip (28,224 B = one
+    // trip).  Every byte is converted to bf16 (exact) HERE, once: the first version converted in
+    // the k loop, once per use and column tile -- 12 VALU per fragment, as much issue time as the
+    // MFMAs they fed (conv1 phase 8 us of 30; tools/gemm_one.py conv123.fwd).
     for (int it0 = tid; it0 < n16; it0 += 4 * NT) {
       uint4 v[4];
 #pragma unroll
@@ -201,7 +202,15 @@ __global__ void __launch_bounds__(NW * 64) aa_conv_triple_x6_kernel(CtParams P) 
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int it = it0 + u * NT;
-        if (it < n16) reinterpret_cast<uint4*>(s_mid)[it] = v[u];
+        if (it < n16) {
+          uint4 lo, hi;
+          ct_u8x4_to_bf16(v[u].x, lo.x, lo.y);
+          ct_u8x4_to_bf16(v[u].y, lo.z, lo.w);
+          ct_u8x4_to_bf16(v[u].z, hi.x, hi.y);
+          ct_u8x4_to_bf16(v[u].w, hi.z, hi.w);
+          reinterpret_cast<uint4*>(s_mid)[2 * it] = lo;
+          reinterpret_cast<uint4*>(s_mid)[2 * it + 1] = hi;
+        }
       }
     }
     __syncthreads();
@@ -253,8 +262,11 @@ static int ct_check(int n_img, int H, int W, int Cin, float a_div, const aa_conv
   P->l[0] = pair.l[0];
   P->l[1] = pair.l[1];
   P->n_img = n_img;
-  // the frame is staged where conv3's input planes will be written
-  if ((size_t)F.frame_bytes > 3 * (size_t)P->l[1].plane) return AA_ERR_RANGE;
+  // the frame (as bf16: 2 bytes per byte) is staged from where conv3's input planes will be
+  // written on: dead by the time conv2's epilogue writes them
+  const size_t with_frame = 3 * (size_t)P->l[0].plane + 2 * (size_t)F.frame_bytes;
+  if (with_frame > lds) lds = with_frame;
+  if (lds > 160 * 1024) return AA_ERR_RANGE;
   *lds_bytes = lds;
   *ws1_bytes = (size_t)ksteps * (a->Cout / 16) * 3 * 64 * sizeof(uint4);
   *ws_pair_bytes = wsp;
@@ -340,7 +352,7 @@ int aa_conv_triple_x6_phase(const uint8_t* x, int64_t img_pitch, int32_t n_img, 
     rc2 = AA_OK;                                                                                \
   }
   // (the shapes of the Atari stack and its near relatives; others keep the two-launch path)
-  AA_CT_CASE(6, 4) AA_CT_CASE(6, 2) AA_CT_CASE(4, 2) AA_CT_CASE(4, 4) AA_CT_CASE(8, 4)
+  AA_CT_CASE(6, 4) AA_CT_CASE(6, 2) AA_CT_CASE(4, 2) AA_CT_CASE(4, 4) AA_CT_CASE(8, 4) AA_CT_CASE(2, 2)
   AA_CT_CASE(8, 6) AA_CT_CASE(6, 6) AA_CT_CASE(8, 8)
 #undef AA_CT_CASE
   if (rc2 != AA_OK) return AA_ERR_RANGE;

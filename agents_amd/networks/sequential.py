@@ -446,8 +446,13 @@ class Sequential(network.Network):
                     elif prepared is not None and prep_pending:
                         torch.cuda.current_stream(cur.device).wait_stream(self._prep_stream)
                         prep_pending.clear()
+                    # (the middle activation is stored only on slots a backward pass reads)
+                    keep = need_grad or s.dz_top is not None or \
+                        ops.conv_pair_prepare_bytes(tuple(cur.shape), self._kviews[pi], l.stride,
+                                                    self._kviews[pi + 1], nxt.stride) <= 0
                     ops.conv_pair_forward(cur, self._kviews[pi], self._bviews[pi], l.stride,
-                                          l.activation, s.ys[pi], self._kviews[pi + 1],
+                                          l.activation, s.ys[pi] if keep else None,
+                                          self._kviews[pi + 1],
                                           self._bviews[pi + 1], nxt.stride, nxt.activation,
                                           s.ys[pi + 1], prepared=prepared)
                     skip = 1

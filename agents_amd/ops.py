@@ -426,9 +426,10 @@ def conv_pair_prepare(x_shape, w1, s1, w2, s2, ws):
 
 
 def conv_pair_forward(x, w1, b1, s1, act1, y1, w2, b2, s2, act2, y2, prepared=None):
-    """y1 = act1(conv(x, w1) + b1), y2 = act2(conv(y1, w2) + b2) in one launch; both are written.
-    prepared: scratch that conv_pair_prepare filled for these weights."""
-    require_cuda(x, w1, w2, y1, y2)
+    """y1 = act1(conv(x, w1) + b1), y2 = act2(conv(y1, w2) + b2) in one launch; both are written
+    (y1 = None on the bf16x6 kernel: the middle activation stays in LDS -- a forward no backward
+    pass follows).  prepared: scratch that conv_pair_prepare filled for these weights."""
+    require_cuda(x, w1, w2, y2)
     if x.dtype != torch.float32:
         raise ValueError("conv_pair_forward needs a float32 NHWC input")
     Bn, H, W, C, KH1, KW1, C1, OH1, OW1 = _conv_common(x, w1, s1)
@@ -436,8 +437,13 @@ def conv_pair_forward(x, w1, b1, s1, act1, y1, w2, b2, s2, act2, y2, prepared=No
     OH2, OW2 = conv_out_hw(OH1, OW1, KH2, KW2, s2)
     if Cin2 != C1 or not w2.is_contiguous():
         raise ValueError("conv_pair_forward: second kernel does not match the first layer")
-    _f32c(w1, "w1"); _f32c(w2, "w2"); _f32c(y1, "y1"); _f32c(y2, "y2")
-    if y1.numel() != Bn * OH1 * OW1 * C1 or y2.numel() != Bn * OH2 * OW2 * C2:
+    _f32c(w1, "w1"); _f32c(w2, "w2"); _f32c(y2, "y2")
+    if y1 is not None:
+        _f32c(y1, "y1")
+    elif conv_pair_prepare_bytes((Bn, H, W, C), w1, s1, w2, s2) <= 0:
+        raise ValueError("conv_pair_forward: y1=None needs the bf16x6 kernel")
+    if (y1 is not None and y1.numel() != Bn * OH1 * OW1 * C1) or \
+            y2.numel() != Bn * OH2 * OW2 * C2:
         raise ValueError("conv_pair_forward: bad output sizes")
     d = _pair_descs(w1, b1, s1, act1, y1, w2, b2, s2, act2, y2)
     lib = _lib.load()

@@ -307,3 +307,18 @@ def test_prepared_weights_follow_every_kind_of_write(dev):
         assert torch.equal(la.loss, lb.loss), f"step {step}"
         assert torch.equal(a_on._q_network.flat_params, a_off._q_network.flat_params)
         assert torch.equal(a_on._target_q_network.flat_params, a_off._target_q_network.flat_params)
+
+
+def test_pair_without_the_middle_output(dev):
+    """y1 = None on the bf16x6 kernel (a forward no backward pass follows: the policy's, the target
+    network's): the second output is bit-identical and nothing is written for the first."""
+    rng = np.random.default_rng(21)
+    B = 40
+    x = rnd(rng, B, 20, 20, 32).to(dev)
+    w1, b1 = (rnd(rng, 4, 4, 32, 64) * 0.05).to(dev), rnd(rng, 64).to(dev)
+    w2, b2 = (rnd(rng, 3, 3, 64, 64) * 0.05).to(dev), rnd(rng, 64).to(dev)
+    y1, y2 = torch.empty(B, 9, 9, 64, device=dev), torch.empty(B, 7, 7, 64, device=dev)
+    ops.conv_pair_forward(x, w1, b1, 2, "relu", y1, w2, b2, 1, "relu", y2)
+    y2b = torch.full_like(y2, float("nan"))
+    ops.conv_pair_forward(x, w1, b1, 2, "relu", None, w2, b2, 1, "relu", y2b)
+    assert torch.equal(y2, y2b)

@@ -79,7 +79,7 @@ CASES = [   # (B, H, W, C, layers)
     (300, 84, 84, 4, ATARI),                                 # more frames than CUs
     (1100, 84, 84, 4, ATARI),                                # frames looped per workgroup
     (5, 44, 44, 4, ((8, 8, 4, 32, "tanh"), (4, 4, 2, 32, None), (2, 2, 1, 16, "relu"))),
-    (3, 36, 52, 8, ((4, 4, 4, 16, "relu"), (3, 3, 1, 32, "relu"), (3, 3, 2, 16, None))),
+    (3, 36, 52, 8, ((4, 4, 4, 32, "relu"), (3, 3, 1, 32, "relu"), (3, 3, 2, 16, None))),
 ]
 
 
