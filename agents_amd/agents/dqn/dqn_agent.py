@@ -40,6 +40,7 @@ _SINGLE_STREAM = os.environ.get("AA_TRAIN_SINGLE_STREAM", "0") == "1"
 # AA_OPT_SUMS_SLABS=0: the conv weight gradients' slabs are summed by reduce launches into
 # flat_grads even when nothing but the optimizer reads them (A/B measurements; bit-identical)
 OPT_SUMS_SLABS = os.environ.get("AA_OPT_SUMS_SLABS", "1") != "0"
+_TRIPLE_FOR_DEFAULT = "all"
 
 
 class DqnLossInfo(collections.namedtuple("DqnLossInfo", ("td_loss", "td_error"))):
@@ -126,6 +127,18 @@ class DqnAgent(tf_agent.TFAgent):
                          summarize_grads_and_vars=summarize_grads_and_vars,
                          train_step_counter=train_step_counter,
                          training_data_spec=training_data_spec)
+        # AA_TRIPLE_FOR: which of the three forwards of an iteration take the one-launch conv stack
+        # (csrc/conv_triple_x6.h) -- a comma list of policy / online / target; default: see DESIGN.md
+        which = os.environ.get("AA_TRIPLE_FOR", _TRIPLE_FOR_DEFAULT)
+        if which != "all" and hasattr(q_network, "triple_slots"):
+            names = {w for w in which.split(",") if w}
+            q_slots = set()
+            if "policy" in names:
+                q_slots |= {"collect", "policy", "greedy", "call"}
+            if "online" in names:
+                q_slots |= {"train", "next"}
+            q_network.triple_slots = q_slots
+            self._target_q_network.triple_slots = None if "target" in names else set()
         self._work = {}
         self._side_streams = {}
         self._seg_offsets = None

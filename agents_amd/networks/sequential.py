@@ -146,6 +146,10 @@ class Sequential(network.Network):
         self._reg_scratch = None
         self._pw = None         # prepared weights (enable_prepared_weights)
         self._kept_ws = None    # scratch of kept weight-gradient slabs (backward(keep_dw_slabs=True))
+        # forward slots that take the three-conv launch (None = every slot; an empty set = none):
+        # the launch owns a CU for its whole duration (153 KB of LDS), which costs a forward that
+        # runs beside other lanes' kernels more than one that runs alone -- DqnAgent decides
+        self.triple_slots = None
 
     # ---- construction -------------------------------------------------------------------------
     @property
@@ -413,6 +417,7 @@ class Sequential(network.Network):
                 nx2 = self._layers[li + 2] if li + 2 < len(self._layers) else None
                 if (FUSE_CONV_PAIRS and cur.dtype == torch.uint8 and isinstance(nxt, L.Conv2D)
                         and isinstance(nx2, L.Conv2D) and cur.data_ptr() % 16 == 0
+                        and (self.triple_slots is None or slot in self.triple_slots)
                         and (B == 1 or cur.stride(0) % 16 == 0)
                         and ops.conv_triple_prepare_bytes(
                             tuple(cur.shape), self._kviews[pi:pi + 3],
@@ -443,6 +448,15 @@ class Sequential(network.Network):
                     prepared = s.pair_prep.get(pi) if prep_pending is not None else None
                     if pw_pair is not None and pi in pw_pair:
                         prepared = pw_pair[pi]      # split by whoever wrote the weights
+                    elif pw_triple and (pi - 1) in pw_triple:
+                        # a slot that keeps conv1 as its own launch: the pair's two banks are the
+                        # tail of the three-conv scratch (same fragment layout)
+                        nb = ops.conv_pair_prepare_bytes(tuple(cur.shape), self._kviews[pi],
+                                                         l.stride, self._kviews[pi + 1],
+                                                         nxt.stride)
+                        t3 = pw_triple[pi - 1]
+                        if 0 < nb <= t3.numel():
+                            prepared = t3[t3.numel() - nb:]
                     elif prepared is not None and prep_pending:
                         torch.cuda.current_stream(cur.device).wait_stream(self._prep_stream)
                         prep_pending.clear()
