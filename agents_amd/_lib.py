@@ -247,6 +247,10 @@ _SIGNATURES = {
     "aa_rmsprop_step_slabs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_float, c_float, c_float, c_float, POINTER(PlaneScatter),
                                       POINTER(GradSlabs), c_void_p]),
+    "aa_rmsprop_step_slabs_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int64, c_float, c_float, c_float, c_float,
+                                           POINTER(PlaneScatter), POINTER(GradSlabs), c_void_p,
+                                           c_int32, c_void_p, c_void_p]),
     "aa_sgd_step": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "aa_soft_update": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "aa_segment_sumsq": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),

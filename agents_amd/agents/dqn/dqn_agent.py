@@ -41,6 +41,9 @@ _SINGLE_STREAM = os.environ.get("AA_TRAIN_SINGLE_STREAM", "0") == "1"
 # flat_grads even when nothing but the optimizer reads them (A/B measurements; bit-identical)
 OPT_SUMS_SLABS = os.environ.get("AA_OPT_SUMS_SLABS", "1") != "0"
 _TRIPLE_FOR_DEFAULT = "all"
+# AA_PACK_IN_OPTIMIZER=0: Learner.run's LossInfo scalars are packed by a launch of their own behind
+# the optimizer step (A/B measurements; same values either way)
+PACK_IN_OPTIMIZER = os.environ.get("AA_PACK_IN_OPTIMIZER", "1") != "0"
 
 
 class DqnLossInfo(collections.namedtuple("DqnLossInfo", ("td_loss", "td_error"))):
@@ -331,6 +334,15 @@ class DqnAgent(tf_agent.TFAgent):
         LossInfo of scalars (views of the work buffer), or None for any other LossInfo."""
         extra = getattr(loss_info, "extra", None)
         td = getattr(extra, "td_loss", None)
+        self.reduced_owns_storage = False
+        packed = getattr(self, "_packed", None)
+        if packed is not None and td is packed[0].td_loss and extra.td_error is packed[0].td_error \
+                and not self._q_network.has_regularization:
+            # the optimizer launch of this step already copied the three sums into storage of
+            # their own (`_train_phase_apply`): nothing left to launch
+            v = packed[1].unbind(0)
+            self.reduced_owns_storage = True
+            return tf_agent.LossInfo(v[0], DqnLossInfo(td_loss=v[1], td_error=v[2]))
         for w in self._work.values():
             if td is w.td_loss and extra.td_error is w.td_error:
                 return tf_agent.LossInfo(loss_info.loss, DqnLossInfo(
@@ -380,6 +392,7 @@ class DqnAgent(tf_agent.TFAgent):
         w = self._forward_and_loss(experience, self._td_errors_loss_fn, self._gamma,
                                    self._reward_scale_factor, weights, need_grad=True,
                                    q_next_target=q_next_target)
+        self._last_work = w
         # head_done only exists in networks that exposed `fusable_head` (Sequential): a q_network
         # with the plain backward(dout, slot, side_stream, stop_layer) contract never sees it
         extra = {"head_done": True} if w.head_done else {}
@@ -440,22 +453,42 @@ class DqnAgent(tf_agent.TFAgent):
         backward pass must sum its weight gradients into flat_grads for the all-reduce."""
         return (self.gradient_hook is None, self.gradient_hook_async is None)
 
-    # GraphedTrain: the optimizer phase of an entry replays behind ITS gradient graph
+    # GraphedTrain: the optimizer phase of an entry replays behind ITS gradient graph.  State =
+    # (the unsummed weight-gradient slabs the backward pass left, the work buffers its loss wrote)
     def _apply_state(self):
         net = self._q_network
-        return net.take_grad_slabs() if hasattr(net, "take_grad_slabs") else None
+        slabs = net.take_grad_slabs() if hasattr(net, "take_grad_slabs") else None
+        return None if slabs is None else (slabs, getattr(self, "_last_work", None))
 
     def _set_apply_state(self, state):
+        slabs, work = state if state is not None else (None, None)
         if hasattr(self._q_network, "set_grad_slabs"):
-            self._q_network.set_grad_slabs(state)
+            self._q_network.set_grad_slabs(slabs)
+        if work is not None:
+            self._last_work = work
 
     def _train_phase_apply(self):
         net = self._q_network
         planes = net.plane_scatter() if hasattr(net, "plane_scatter") else None
         slabs = net.take_grad_slabs() if hasattr(net, "take_grad_slabs") else None
+        self._packed = None
         if slabs is not None:
+            pack = None
+            w = getattr(self, "_last_work", None)
+            if PACK_IN_OPTIMIZER and w is not None and not graph.capturing() and \
+                    getattr(self._optimizer, "supports_pack", False):
+                # the three sums Learner.run returns (reduce_loss_info) leave with this launch, in
+                # storage of their own: a fresh 3-float tensor per step, like the copy it replaces
+                import ctypes
+                vec = torch.empty((3,), dtype=torch.float32, device=net.flat_params.device)
+                src = w.__dict__.get("_pack_src")
+                if src is None:
+                    src = w._pack_src = (ctypes.c_void_p * 3)(
+                        w.loss.data_ptr(), w.field_sums.data_ptr(), w.field_sums.data_ptr() + 4)
+                pack = (src, vec)
+                self._packed = (w, vec)
             self._optimizer.apply_flat(net.flat_params, net.flat_grads, planes=planes,
-                                       grad_slabs=slabs)
+                                       grad_slabs=slabs, **({"pack": pack} if pack else {}))
             if planes is None:
                 self._refresh_prepared(net)
         elif planes is not None and getattr(self._optimizer, "supports_planes", False):

@@ -192,11 +192,30 @@ struct AaSlabSrc {
   long long off[AA_MAX_GRAD_SLABS];
 };
 
+// Up to eight fp32 scalars copied side by side by the launch's last workgroup: the Learner's
+// reduced LossInfo (train/learner.py:322-337) leaves with the optimizer launch instead of with a
+// launch of its own behind it (one node less on the stream every lane of the next iteration waits
+// for).  The sources were written by the loss launch, long before this one.
+#define AA_MAX_PACK 8
+struct AaPack {
+  const float* src[AA_MAX_PACK];
+  float* dst;
+  int n;
+};
+
 template <bool CENTERED, bool MOMENTUM, bool PLANES>
 __global__ void __launch_bounds__(AA_EW_THREADS)
 aa_rmsprop_slabs_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ ms,
                         float* __restrict__ mg, float* __restrict__ mom, int64_t n, float lr,
-                        float rho, float momentum, float eps, aa_plane_scatter S, AaSlabSrc G) {
+                        float rho, float momentum, float eps, aa_plane_scatter S, AaSlabSrc G,
+                        AaPack K) {
+  if (K.n > 0 && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < K.n) {
+    const float* src = K.src[0];
+#pragma unroll
+    for (int j = 1; j < AA_MAX_PACK; ++j)
+      if ((int)threadIdx.x == j) src = K.src[j];
+    K.dst[threadIdx.x] = *src;
+  }
   const float omr = 1.0f - rho;
   auto update4 = [&](int64_t i, const float4 gg) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -408,8 +427,32 @@ int aa_rmsprop_step_slabs(float* p, float* g, float* ms, float* mg, float* mom, 
                           float lr, float rho, float momentum, float eps,
                           const aa_plane_scatter* planes, const aa_grad_slabs* slabs,
                           void* stream) {
-  if (slabs == nullptr || slabs->n <= 0)
+  return aa_rmsprop_step_slabs_pack(p, g, ms, mg, mom, n, lr, rho, momentum, eps, planes, slabs,
+                                    nullptr, 0, nullptr, stream);
+}
+
+int aa_rmsprop_step_slabs_pack(float* p, float* g, float* ms, float* mg, float* mom, int64_t n,
+                               float lr, float rho, float momentum, float eps,
+                               const aa_plane_scatter* planes, const aa_grad_slabs* slabs,
+                               const float* const* pack_src_h, int32_t pack_n, float* pack_dst,
+                               void* stream) {
+  AaPack K;
+  K.n = 0;
+  K.dst = pack_dst;
+  for (int j = 0; j < AA_MAX_PACK; ++j) K.src[j] = nullptr;
+  if (pack_n > 0) {
+    if (pack_n > AA_MAX_PACK || pack_src_h == nullptr || pack_dst == nullptr)
+      return AA_ERR_INVALID;
+    for (int j = 0; j < pack_n; ++j) {
+      if (pack_src_h[j] == nullptr) return AA_ERR_INVALID;
+      K.src[j] = pack_src_h[j];
+    }
+    K.n = pack_n;
+  }
+  if (slabs == nullptr || slabs->n <= 0) {
+    if (K.n > 0) return AA_ERR_INVALID;     // (the packing rides in the slab-summing launch only)
     return aa_rmsprop_step_planes(p, g, ms, mg, mom, n, lr, rho, momentum, eps, planes, stream);
+  }
   if (!p || !g || !ms || n <= 0 || slabs->n > AA_MAX_GRAD_SLABS) return AA_ERR_INVALID;
   if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)ms | (uintptr_t)mg | (uintptr_t)mom) & 15) != 0)
     return AA_ERR_INVALID;
@@ -450,10 +493,10 @@ int aa_rmsprop_step_slabs(float* p, float* g, float* ms, float* mg, float* mom, 
   do {                                                                                          \
     if (pl)                                                                                     \
       hipLaunchKernelGGL((aa_rmsprop_slabs_kernel<C_, M_, true>), grid, block, 0, st, p, g, ms, \
-                         mg, mom, n, lr, rho, momentum, eps, S, G);                             \
+                         mg, mom, n, lr, rho, momentum, eps, S, G, K);                          \
     else                                                                                        \
       hipLaunchKernelGGL((aa_rmsprop_slabs_kernel<C_, M_, false>), grid, block, 0, st, p, g,    \
-                         ms, mg, mom, n, lr, rho, momentum, eps, S, G);                         \
+                         ms, mg, mom, n, lr, rho, momentum, eps, S, G, K);                      \
   } while (0)
   if (mg && mom) AA_RMS(true, true);
   else if (mg) AA_RMS(true, false);

@@ -881,26 +881,46 @@ aa_rb_gather_drawn_kernel(AaLeafSet leaves, AaRowGrid g, const int64_t* __restri
 // computed independently (expected < 4 applications: 2^(2h) < 4 n): no radix sort, no host
 // round trip, and the CPU oracle (oracle/perm.py) reproduces it bit for bit.  Replaces the
 // tf.data shuffle of train/ppo_learner.py:228-247, whose order the reference does not pin.
+// Round 5: the orbit of an index takes a geometric number of applications (2^(2h) is up to ~4 n:
+// four on average for n = 2,048 x 129), so with one index per lane a wave ran as long as its
+// unluckiest lane -- ~15-20 applications, 60 us for 264 K indices (rocprofv3, PPO configs[2]).
+// Now a wave owns a contiguous range of indices and a lane whose orbit has re-entered [0, n) stores
+// its result and takes the range's next index (ballot + prefix count): every lane applies the
+// network in every round until the range is exhausted.  Same permutation, bit for bit.
 __global__ void __launch_bounds__(256)
 aa_feistel_perm_kernel(int64_t n, int h, uint32_t k0, uint32_t k1, uint64_t call,
                        int64_t* __restrict__ out) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const uint64_t mask = (1ull << h) - 1ull;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    uint64_t x = (uint64_t)i;
-    do {
-      uint64_t l = x >> h, r = x & mask;
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t per = (n + n_waves - 1) / n_waves;
+  const int64_t lo = wid * per;
+  const int64_t hi = lo + per < n ? lo + per : n;
+  int64_t next = lo + 64;          // wave-uniform: the first index nobody has taken yet
+  int64_t mine = lo + lane;
+  bool active = mine < hi;
+  uint64_t x = (uint64_t)mine;
+  while (__ballot(active) != 0ull) {
+    uint64_t l = x >> h, r = x & mask;
 #pragma unroll
-      for (uint32_t round = 0; round < 4; ++round) {
-        const Philox4 f = philox4x32_10((uint32_t)r, round, (uint32_t)call, (uint32_t)(call >> 32),
-                                        k0, k1);
-        const uint64_t t = l ^ ((((uint64_t)f.y << 32) | f.x) & mask);
-        l = r;
-        r = t;
-      }
-      x = (l << h) | r;
-    } while (x >= (uint64_t)n);
-    out[i] = (int64_t)x;
+    for (uint32_t round = 0; round < 4; ++round) {
+      const Philox4 f = philox4x32_10((uint32_t)r, round, (uint32_t)call, (uint32_t)(call >> 32),
+                                      k0, k1);
+      const uint64_t t = l ^ ((((uint64_t)f.y << 32) | f.x) & mask);
+      l = r;
+      r = t;
+    }
+    x = (l << h) | r;
+    const bool done = active && x < (uint64_t)n;
+    if (done) out[mine] = (int64_t)x;
+    const unsigned long long dm = __ballot(done);
+    if (done) {
+      mine = next + __popcll(dm & ((1ull << lane) - 1ull));
+      x = (uint64_t)mine;
+      active = mine < hi;
+    }
+    next += __popcll(dm);
   }
 }
 
@@ -1264,8 +1284,10 @@ int aa_random_permutation(int64_t n, uint64_t seed, uint64_t call, int64_t* out,
   if (n <= 0 || out == nullptr || n > (1ll << 60)) return AA_ERR_INVALID;
   int h = 1;
   while ((1ull << (2 * h)) < (uint64_t)n) ++h;
+  // one wave per SIMD at most (1,024 of them): several indices per lane, so that lanes whose orbit
+  // is short refill from their wave's range instead of idling behind the longest one
   int64_t blocks = (n + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(aa_feistel_perm_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      (hipStream_t)stream, n, h, (uint32_t)seed, (uint32_t)(seed >> 32), call, out);
   return aa_launch_status();

@@ -466,8 +466,13 @@ def conv_pair_forward(x, w1, b1, s1, act1, y1, w2, b2, s2, act2, y2, prepared=No
 
 
 # ---- conv1 -> conv2 -> conv3 on uint8 frames in one launch (csrc/conv_triple_x6.h) ----------------
-# AA_FUSE_CONV_TRIPLE=0: conv1 stays its own launch in front of the fused pair (A/B measurements)
-CONV_TRIPLE = _os.environ.get("AA_FUSE_CONV_TRIPLE", "1") != "0"
+# OPT-IN (AA_FUSE_CONV_TRIPLE=1).  Measured on MI355X (profiles/r05_*_triple_*.txt): the launch beats
+# conv1 + pair in isolation (27.9 vs 11.5 + 21.9 us without the intermediate stores, 30.0 with) and
+# LOSES inside the DQN iteration on every box tried -- 0.3118 vs 0.3034 ms, 0.3684 vs 0.3550 ms,
+# and with AA_TRIPLE_FOR: none 0.3078, target 0.3117, all 0.3143, online+target 0.3183 ms: a
+# 28 us launch that owns every CU (153 KB of LDS per workgroup) leaves the other lanes' kernels
+# nothing to run beside, where the 11 us conv1 launch (two workgroups per CU) did.
+CONV_TRIPLE = _os.environ.get("AA_FUSE_CONV_TRIPLE", "0") == "1"
 _TRIPLE_WS = {}
 
 

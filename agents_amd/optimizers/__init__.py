@@ -144,15 +144,32 @@ class RMSprop(Optimizer):
 
     supports_planes = True
     supports_grad_slabs = True
+    supports_pack = True       # apply_flat(grad_slabs=..., pack=...) also copies a few scalars
 
-    def apply_flat(self, params, grads, planes=None, grad_slabs=None):
+    def apply_flat(self, params, grads, planes=None, grad_slabs=None, pack=None):
         """grad_slabs: an aa_grad_slabs (`Sequential.take_grad_slabs()`): those parameter ranges
-        take their gradient from unsummed split-K slabs instead of `grads`."""
+        take their gradient from unsummed split-K slabs instead of `grads`.
+        pack = (ctypes array of <= 8 device pointers to fp32 scalars, destination tensor): the
+        launch also copies those scalars side by side into the destination (with grad_slabs
+        only) -- the LossInfo sums Learner.run returns, without a copy launch of their own."""
         import ctypes
         lib = _lib.load()
         _lib.require_cuda(params, grads)
         names = ["ms"] + (["mg"] if self.centered else []) + (["mom"] if self.momentum > 0 else [])
         s = self._slot(params, names)
+        if pack is not None and grad_slabs is not None:
+            src, dst = pack
+            _lib.check(lib.aa_rmsprop_step_slabs_pack(
+                params.data_ptr(), grads.data_ptr(), s["ms"].data_ptr(),
+                s["mg"].data_ptr() if self.centered else None,
+                s["mom"].data_ptr() if self.momentum > 0 else None, params.numel(),
+                self.learning_rate, self.rho, self.momentum, self.epsilon,
+                None if planes is None else ctypes.byref(planes), ctypes.byref(grad_slabs),
+                src, len(src), dst.data_ptr(), _lib.stream_ptr()), "aa_rmsprop_step_slabs_pack")
+            graph.on_replay(self._bump_iterations)
+            return
+        if pack is not None:
+            raise ValueError("apply_flat(pack=...) needs grad_slabs")
         _lib.check(lib.aa_rmsprop_step_slabs(
             params.data_ptr(), grads.data_ptr(), s["ms"].data_ptr(),
             s["mg"].data_ptr() if self.centered else None,

@@ -132,6 +132,9 @@ class Learner:
             pre = hook(loss_info)
             if pre is not None:
                 loss_info = pre
+                if self.strategy.num_replicas_in_sync == 1 and \
+                        getattr(self._agent, "reduced_owns_storage", False):
+                    return loss_info       # already sums in storage of their own (one replica)
         flat = nest_utils.flatten(loss_info)
         idx = [i for i, t in enumerate(flat) if isinstance(t, torch.Tensor)]
         if not idx:

@@ -663,7 +663,13 @@ class GraphedTrain:
             return None
         return lanes.event_on(cur)
 
-    def _early_target_stream(self, lanes, dev):
+    def _early_target_stream(self, lanes, dev, cur=None):
+        if EARLY_TARGET == "main" and cur is not None:
+            # in stream order on the caller's stream, behind the optimizer launch: no event
+            # hand-over in front of the forward or behind it (round 5: the GPU timeline shows ~26 us
+            # between the early forward's end on the side stream and the gradient graph's first
+            # kernel on the caller's), at the price of not overlapping the optimizer launch
+            return cur
         if EARLY_TARGET == "side" and getattr(self._agent, "_side_stream", None) is not None:
             st = self._agent._side_stream(dev)
             if st is not None:
@@ -687,10 +693,11 @@ class GraphedTrain:
         rdy = lanes.ready.get(nxt.ptr0)
         if seq is None or rdy is None:
             return
-        st = self._early_target_stream(lanes, dev)
-        st.wait_event(grads_done)
-        if target_written:       # theta_target was updated behind the optimizer step, on this stream
-            st.wait_event(lanes.event_on(cur))
+        st = self._early_target_stream(lanes, dev, cur)
+        if st is not cur:
+            st.wait_event(grads_done)
+            if target_written:   # theta_target was updated behind the optimizer step, on this stream
+                st.wait_event(lanes.event_on(cur))
         st.wait_event(rdy)
         with _on_stream(st, cur):
             _mark("early_target.begin", st)

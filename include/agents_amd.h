@@ -501,6 +501,16 @@ int aa_rmsprop_step_slabs(float* p, float* g, float* ms, float* mg, float* mom, 
                           float lr, float rho, float momentum, float eps,
                           const aa_plane_scatter* planes /* nullable */,
                           const aa_grad_slabs* slabs /* nullable */, void* stream);
+/* aa_rmsprop_step_slabs whose launch also copies pack_n <= 8 fp32 device scalars side by side to
+ * pack_dst (pack_src_h: HOST array of device pointers): the replica-summed LossInfo that
+ * Learner.run returns (train/learner.py:322-337) -- loss, sum(td_loss), sum(td_error), written by
+ * the loss launch of the same step -- leaves in storage of its own without a copy launch behind the
+ * optimizer step.  slabs must be non-empty when pack_n > 0. */
+int aa_rmsprop_step_slabs_pack(float* p, float* g, float* ms, float* mg, float* mom, int64_t n,
+                               float lr, float rho, float momentum, float eps,
+                               const aa_plane_scatter* planes, const aa_grad_slabs* slabs,
+                               const float* const* pack_src_h, int32_t pack_n, float* pack_dst,
+                               void* stream);
 int aa_sgd_step(float* p, const float* g, int64_t n, float lr, void* stream);
 /* t = (1-tau)*t + tau*s  (soft_variables_update, utils/common.py:314-346) */
 int aa_soft_update(float* target, const float* source, int64_t n, float tau, void* stream);

@@ -14,6 +14,16 @@ from agents_amd import ops
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
+
+@pytest.fixture(autouse=True)
+def triple_on(monkeypatch):
+    """The kernel is opt-in (AA_FUSE_CONV_TRIPLE=1: it loses inside the DQN iteration, ops.py); these
+    tests switch it on."""
+    monkeypatch.setattr(ops, "CONV_TRIPLE", True)
+    ops._TRIPLE_WS.clear()
+    yield
+    ops._TRIPLE_WS.clear()
+
 ATARI = ((8, 8, 4, 32, "relu"), (4, 4, 2, 64, "relu"), (3, 3, 1, 64, "relu"))
 
 
