@@ -33,7 +33,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 TRIPLE_OP = "conv1+conv2+conv3.fwd(one launch)"
-PRIME_MIN = 300                # untimed iterations in front of --warmup (see main: priming)
+PRIME_MIN = 0                  # minimum untimed iterations in front of --warmup (see main: priming)
 CPU_RING_FRAMES = 256          # replay frames per env of the cpu_baseline leg (see cpu_baseline)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 PMC_FILE = os.path.join("profiles", "r04_pmc.json")   # committed rocprofv3 --pmc passes (isolated)
@@ -1010,10 +1010,13 @@ def main():
     # one train graph per ring slot: agents_amd/utils/graph.py).  Iterate until no capture has
     # happened for three consecutive iterations, the way the reference's harness discards its
     # first log window (tf_agents/benchmark/utils.py:89-180).  Same count on every rank.
-    # Round 5: and for at least PRIME_MIN iterations (~0.1 s): right behind the captures the loop
-    # still runs 3-5 % below its steady state (BENCH_r04: 0.3223 ms over the 20 timed steps,
-    # 0.3066 ms over the 300 behind them) -- the device clocks and the host's caches settle over a
-    # few hundred iterations.  `prime_steps` in the JSON line says how many ran.
+    # (AA_BENCH_PRIME_MIN=n primes for at least n iterations.  Round 5 checked whether the 3-5 %
+    # between the 20 timed steps of the driver's command line and the 300 steady ones behind them
+    # -- BENCH_r04: 0.3223 vs 0.3066 ms -- is a warm-up effect: it is not.  Same box, alternating:
+    # 6 priming iterations 0.3704 / 0.3706 ms, 300 of them 0.3638 / 0.3707 ms, steady 0.357-0.363
+    # either way (profiles/r05_f_prime.txt).  The difference is the protocol's: the timed region
+    # ends with a device synchronisation, i.e. with the drain of the last iteration the host had
+    # run ahead of -- one iteration's latency spread over 20 steps.)
     prime_min = int(os.environ.get("AA_BENCH_PRIME_MIN", str(PRIME_MIN)))
     prime_steps, quiet, seen = 0, 0, graph.capture_count()
     t_prime = time.perf_counter()
