@@ -116,6 +116,10 @@ _SIGNATURES = {
     "aa_abi_version": (c_int, []),
     "aa_rb_scatter_rows": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int,
                                    c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "aa_rb_scatter_rows_count": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64),
+                                         c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                         c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                         c_void_p]),
     "aa_rb_sample_rows": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_uint64,
                                   c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "aa_rb_sample_gather": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int,
@@ -180,6 +184,11 @@ _SIGNATURES = {
     "aa_dense_small_forward_slabs": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int32,
                                              c_void_p, c_int64, c_void_p, c_void_p, c_int32,
                                              c_int32, c_void_p, c_void_p]),
+    "aa_dense_small_forward_slabs_eps": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p,
+                                                 c_int32, c_void_p, c_int64, c_void_p, c_void_p,
+                                                 c_int32, c_int32, c_void_p, c_void_p, c_float,
+                                                 c_void_p, c_uint64, c_void_p, c_void_p, c_int64,
+                                                 c_void_p, c_int32, c_void_p]),
     "aa_dense_small_backward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32,
                                         c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                         c_void_p]),

@@ -33,6 +33,7 @@
 // Table-side accesses are non-temporal (a 28 GB table is streamed, never re-read soon); the batch
 // side stays cacheable (conv1 reads it next).
 #include "common.h"
+#include "agents_amd.h"
 
 #define AA_MAX_LEAVES 24
 #define AA_RB_CHUNK 32768  // compaction kernels: bytes of one row handled per workgroup per leaf
@@ -278,10 +279,64 @@ __device__ static inline void aa_arrivals_finish(int64_t* counter, int64_t* arri
 }
 
 // ---- add_batch: rows[b] = b*L + (last_id+1) mod L ------------------------------------------
+// Round 5: DynamicStepDriver's loop counter (counter[b] += step_type[b] != LAST; *total += the sum;
+// drivers/dynamic_step_driver.py:113,170 -- csrc/rollout.hip: aa_count_steps_kernel) rides in the
+// add_batch launch of the same loop body as ONE extra workgroup (the grid's last), outside the
+// arrival protocol of the copy: one launch and one graph node less per collect step.
+struct AaStepCount {
+  const int32_t* step_type;   // nullptr: no counting (the plain add_batch)
+  int64_t B;
+  int32_t* counter;           // nullable
+  int64_t* total;
+  int64_t* mailbox;           // nullable: host-visible {sequence, total}
+};
+
+__device__ static inline void aa_rb_count_steps(const AaStepCount& C) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int64_t b0 = threadIdx.x; b0 < C.B; b0 += 8 * (int64_t)blockDim.x) {
+    int st[8], cv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t b = b0 + u * (int64_t)blockDim.x;
+      const int64_t bc = b < C.B ? b : C.B - 1;         // clamped: unconditional loads
+      st[u] = C.step_type[bc];
+      cv[u] = C.counter != nullptr ? C.counter[bc] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t b = b0 + u * (int64_t)blockDim.x;
+      if (b < C.B) {
+        const int inc = st[u] != 2 ? 1 : 0;
+        if (C.counter != nullptr) C.counter[b] = cv[u] + inc;
+        s += (float)inc;
+      }
+    }
+  }
+  const float t = aa_block_sum(s, red);
+  if (threadIdx.x == 0) {
+    const int64_t tot = *C.total + (int64_t)(t + 0.5f);
+    *C.total = tot;
+    if (C.mailbox != nullptr) {
+      __hip_atomic_store(&C.mailbox[1], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+      const int64_t seq = __hip_atomic_load(&C.mailbox[0], __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_SYSTEM) + 1;
+      __hip_atomic_store(&C.mailbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(AA_RB_THREADS)
 aa_rb_scatter_kernel(AaLeafSet leaves, AaRowGrid g, int64_t* __restrict__ id_table,
-                     int64_t* last_id, int64_t* arrival, int64_t max_len, int64_t batch) {
+                     int64_t* last_id, int64_t* arrival, int64_t max_len, int64_t batch,
+                     AaStepCount cnt) {
   __shared__ AaSmallLeaves sm;
+  const unsigned n_groups = gridDim.x - (cnt.step_type != nullptr ? 1u : 0u);
+  if (blockIdx.x >= n_groups) {     // the counting workgroup: not part of the copy's protocol
+    aa_rb_count_steps(cnt);
+    return;
+  }
   unsigned long long ticket = 0;
   // last_id itself moves after every group has read it
   const int64_t id = aa_counter_read_arrive(last_id, arrival, &ticket) + 1;
@@ -323,7 +378,7 @@ aa_rb_scatter_kernel(AaLeafSet leaves, AaRowGrid g, int64_t* __restrict__ id_tab
       }
     }
   }
-  if (arrival != nullptr) aa_counter_finish(last_id, arrival, ticket, 1, gridDim.x);
+  if (arrival != nullptr) aa_counter_finish(last_id, arrival, ticket, 1, n_groups);
 }
 
 __global__ void aa_rb_bump_kernel(int64_t* last_id, int64_t inc) {
@@ -1060,8 +1115,25 @@ int aa_rb_scatter_rows(void* const* leaf_tables_h, const void* const* leaf_items
                        const int64_t* leaf_row_bytes_h, int n_leaves, int64_t* id_table,
                        int64_t* last_id_dev, int64_t* arrival_dev, int64_t batch, int64_t max_len,
                        void* stream) {
+  return aa_rb_scatter_rows_count(leaf_tables_h, leaf_items_h, leaf_row_bytes_h, n_leaves,
+                                  id_table, last_id_dev, arrival_dev, batch, max_len, nullptr, 0,
+                                  nullptr, nullptr, nullptr, stream);
+}
+
+int aa_rb_scatter_rows_count(void* const* leaf_tables_h, const void* const* leaf_items_h,
+                             const int64_t* leaf_row_bytes_h, int n_leaves, int64_t* id_table,
+                             int64_t* last_id_dev, int64_t* arrival_dev, int64_t batch,
+                             int64_t max_len, const int32_t* step_type, int64_t n_envs,
+                             int32_t* counter_dev, int64_t* total_dev, int64_t* mailbox,
+                             void* stream) {
   if (batch <= 0 || max_len <= 0 || id_table == nullptr || last_id_dev == nullptr)
     return AA_ERR_INVALID;
+  AaStepCount cnt = {};
+  if (step_type != nullptr) {
+    if (total_dev == nullptr || n_envs <= 0 || n_envs > (1 << 24)) return AA_ERR_INVALID;
+    cnt.step_type = step_type; cnt.B = n_envs; cnt.counter = counter_dev; cnt.total = total_dev;
+    cnt.mailbox = mailbox;
+  }
   AaLeafSet ls;
   int64_t max_rb = 0;
   int rc = aa_fill_leaves(ls, leaf_tables_h, (void* const*)leaf_items_h, leaf_row_bytes_h,
@@ -1075,8 +1147,9 @@ int aa_rb_scatter_rows(void* const* leaf_tables_h, const void* const* leaf_items
   hipStream_t st = (hipStream_t)stream;
   // last_id advances inside the launch (sharded arrival counters: AA_RB_ARRIVAL_WORDS = 144 zero words)
   int64_t* arrival = arrival_dev;
-  hipLaunchKernelGGL(aa_rb_scatter_kernel, dim3((unsigned)grid), dim3(AA_RB_THREADS), 0, st, ls,
-                     g, id_table, last_id_dev, arrival, max_len, batch);
+  hipLaunchKernelGGL(aa_rb_scatter_kernel, dim3((unsigned)grid + (step_type != nullptr ? 1u : 0u)),
+                     dim3(AA_RB_THREADS), 0, st, ls, g, id_table, last_id_dev, arrival, max_len,
+                     batch, cnt);
   if (arrival == nullptr)
     hipLaunchKernelGGL(aa_rb_bump_kernel, dim3(1), dim3(64), 0, st, last_id_dev, (int64_t)1);
   return aa_launch_status();

@@ -126,6 +126,8 @@ class _Slot:
 
 
 class Sequential(network.Network):
+    selected = False     # the last forward's head launch also selected the actions (forward(select=))
+
     def __init__(self, layers, input_spec=None, name=None, seed=None):
         super().__init__(input_tensor_spec=input_spec, state_spec=(), name=name or "Sequential")
         if not layers:
@@ -369,9 +371,13 @@ class Sequential(network.Network):
                                    device=dev)
         return s
 
-    def forward(self, x, slot=0, need_grad=False):
+    def forward(self, x, slot=0, need_grad=False, select=None):
         """Runs the stack on x [B, *input_shape]; returns the last layer's output buffer
-        (owned by the network, overwritten by the next forward on the same slot and batch)."""
+        (owned by the network, overwritten by the next forward on the same slot and batch).
+        select: action-selection arguments of a discrete policy (ops.dense_tail_forward): when the
+        stack ends in a hidden Dense + small head pair the head's launch draws the actions as well
+        and `self.selected` is True afterwards (else False: the caller selects itself)."""
+        self.selected = False
         self._require_built()
         _lib.require_cuda(x)
         spec = self._input_tensor_spec
@@ -487,9 +493,12 @@ class Sequential(network.Network):
                         and ops.dense_tail_supported(cur2, self._kviews[pi], self._kviews[pi + 1])):
                     # hidden layer + small head: the head sums the hidden layer's split-K slabs
                     s.xs[pi + 1] = s.ys[pi]
-                    ops.dense_tail_forward(cur2, self._kviews[pi], self._bviews[pi], l.activation,
-                                           s.ys[pi], self._kviews[pi + 1], self._bviews[pi + 1],
-                                           nxt.activation, s.ys[pi + 1])
+                    last_pair = select is not None and li + 2 == len(self._layers)
+                    done = ops.dense_tail_forward(
+                        cur2, self._kviews[pi], self._bviews[pi], l.activation, s.ys[pi],
+                        self._kviews[pi + 1], self._bviews[pi + 1], nxt.activation, s.ys[pi + 1],
+                        **({"select": select} if last_pair else {}))
+                    self.selected = bool(last_pair and done is True)
                     skip = 1
                 else:
                     ops.dense_forward(cur2, self._kviews[pi], self._bviews[pi], l.activation,

@@ -221,10 +221,13 @@ def dense_tail_supported(x, w1, w2):
             and H > SMALL_N and H % 4 == 0 and x.dtype == torch.float32)
 
 
-def dense_tail_forward(x, w1, b1, act1, h, w2, b2, act2, y):
+def dense_tail_forward(x, w1, b1, act1, h, w2, b2, act2, y, select=None):
     """h[M,H] = act1(x[M,K] @ w1 + b1); y[M,N] = act2(h @ w2 + b2), N <= SMALL_N.  Two launches
     when the first contraction is split-K (GEMM main loop, then the head summing the slabs in its
-    prologue), otherwise the plain pair; bit-identical to dense_forward twice either way."""
+    prologue), otherwise the plain pair; bit-identical to dense_forward twice either way.
+    select: dict(mask, epsilon, epsilon_dev, seed, call_counter, arrival, action_min, out) -- the
+    head's launch also draws the epsilon-greedy actions of its Q values (policies/q_policy.py);
+    returns True when it did (only the split-K form has the fused launch)."""
     require_cuda(x, w1, h, w2, y)
     lda = _rows_ok(x, "x"); _f32c(w1, "w1"); _f32c(h, "h"); _f32c(w2, "w2"); _f32c(y, "y")
     M, K = x.shape
@@ -244,6 +247,16 @@ def dense_tail_forward(x, w1, b1, act1, h, w2, b2, act2, y):
     splits = ctypes.c_int32(0)
     check(lib.aa_gemm_f32_slabs(ctypes.byref(d), ptr(ws), ws.numel() if ws is not None else 0,
                                 ctypes.byref(splits), stream_ptr()), "aa_gemm_f32_slabs")
+    if splits.value > 1 and select is not None:
+        out = select["out"]
+        check(lib.aa_dense_small_forward_slabs_eps(
+            ptr(ws), splits.value, M, H, ptr(b1), ACT[act1], ptr(h), H, ptr(w2), ptr(b2),
+            ACT[act2], N, ptr(y), ptr(select.get("mask")), float(select["epsilon"]),
+            select.get("epsilon_dev"), select["seed"], select["call_counter"],
+            select.get("arrival"), int(select["action_min"]), ptr(out),
+            1 if out.dtype == torch.int64 else 0, stream_ptr()),
+            "aa_dense_small_forward_slabs_eps")
+        return True
     if splits.value > 1:
         check(lib.aa_dense_small_forward_slabs(
             ptr(ws), splits.value, M, H, ptr(b1), ACT[act1], ptr(h), H, ptr(w2), ptr(b2),
@@ -251,7 +264,7 @@ def dense_tail_forward(x, w1, b1, act1, h, w2, b2, act2, y):
     else:
         check(lib.aa_dense_small_forward(ptr(h), H, ptr(w2), ptr(b2), ACT[act2], M, H, N, ptr(y),
                                          stream_ptr()), "aa_dense_small_forward")
-    return y
+    return False if select is not None else y
 
 
 def dense_dx(dz, w, out, mask_src=None, mask_act=None, force_cfg=0, force_splits=0):

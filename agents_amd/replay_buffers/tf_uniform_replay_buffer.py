@@ -139,19 +139,40 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
     def _num_frames(self):
         return min((self._last_id_host + 1) * self._batch_size, self._capacity)
 
-    def _add_batch(self, items):
-        """Writes one frame per env block (:182-209)."""
+    def _add_batch(self, items, count=None):
+        """Writes one frame per env block (:182-209).
+        count = (step_type int32 [n], counter int32 [n] or None, total int64 [1], mailbox device
+        pointer or None): the launch also runs DynamicStepDriver's loop counter on those step types
+        (a graphed driver body passes the time step it just produced: utils/graph.py)."""
         lib = _lib.load()
         graph.join_lanes(self._device)
         flat = self._data_table.check_values(items, self._batch_size)
         p = self._data_table.pack(flat)
         with torch.cuda.device(self._device):
-            _lib.check(lib.aa_rb_scatter_rows(
-                p.tables, p.ios, p.row_bytes, p.n, self._id_table.variables()[0].data_ptr(),
-                self._last_id.data_ptr(), self._scatter_arrival.data_ptr(), self._batch_size,
-                self._max_length, _lib.stream_ptr()),
-                "aa_rb_scatter_rows")
+            if count is None:
+                _lib.check(lib.aa_rb_scatter_rows(
+                    p.tables, p.ios, p.row_bytes, p.n, self._id_table.variables()[0].data_ptr(),
+                    self._last_id.data_ptr(), self._scatter_arrival.data_ptr(), self._batch_size,
+                    self._max_length, _lib.stream_ptr()),
+                    "aa_rb_scatter_rows")
+            else:
+                st, counter, total, mailbox = count
+                _lib.check(lib.aa_rb_scatter_rows_count(
+                    p.tables, p.ios, p.row_bytes, p.n, self._id_table.variables()[0].data_ptr(),
+                    self._last_id.data_ptr(), self._scatter_arrival.data_ptr(), self._batch_size,
+                    self._max_length, st.data_ptr(), st.numel(),
+                    None if counter is None else counter.data_ptr(), total.data_ptr(), mailbox,
+                    _lib.stream_ptr()), "aa_rb_scatter_rows_count")
         graph.on_replay(self._bump_last_id_host)
+
+    def add_batch_counting(self, items, step_type, counter, total, mailbox):
+        """`add_batch(items)` + the driver's step count of `step_type` in one launch (see
+        `_add_batch`).  Only for buffers whose add is the plain scatter (subclasses that extend
+        `_add_batch` -- the prioritized buffer -- do not offer it: `supports_counting_add`)."""
+        self._add_batch(items, count=(step_type, counter, total, mailbox))
+
+    def supports_counting_add(self):
+        return type(self)._add_batch is TFUniformReplayBuffer._add_batch
 
     def _bump_last_id_host(self):
         self._last_id_host += 1

@@ -53,6 +53,10 @@ def on_replay(fn):
         _CAPTURE.hooks.append(fn)
 
 
+# A/B knob AA_COUNT_IN_ADD=0: the driver's step counter stays a launch of its own in front of the
+# replay buffer's add_batch (bit-identical either way)
+COUNT_IN_ADD = os.environ.get("AA_COUNT_IN_ADD", "1") != "0"
+
 # A/B knob: replay the optimizer phase as its own HIP graph (0) or launch it directly (1)
 APPLY_EAGER = os.environ.get("AA_APPLY_EAGER", "1") != "0"
 
@@ -979,11 +983,26 @@ class GraphedDriverRun:
         drv = self._driver
         action_step = drv.policy.action(time_step, policy_state)
         next_time_step = drv.env.step(action_step.action)
-        # as early as possible: the host of the NEXT run is waiting for this post
-        self._count(next_time_step.step_type)
         traj = trajectory.from_transition(time_step, action_step, next_time_step)
-        for observer in drv._observers:
-            observer(traj)
+        # The step count of the NEXT body rides in the replay buffer's add_batch launch when the
+        # first observer is one (csrc/replay.hip: aa_rb_scatter_rows_count): one launch and one
+        # graph node less per body.  Otherwise its own launch, as early as possible (the host of
+        # the next run is waiting for the post).
+        fused = None
+        if COUNT_IN_ADD and drv._observers:
+            owner = getattr(drv._observers[0], "__self__", None)
+            if getattr(drv._observers[0], "__name__", "") == "add_batch" and \
+                    getattr(owner, "supports_counting_add", lambda: False)() and \
+                    next_time_step.step_type.dtype == torch.int32:
+                fused = owner
+        if fused is None:
+            self._count(next_time_step.step_type)
+        for k, observer in enumerate(drv._observers):
+            if k == 0 and fused is not None:
+                fused.add_batch_counting(traj, next_time_step.step_type, self._counter,
+                                         self._total, self._mbox_dev)
+            else:
+                observer(traj)
         return next_time_step
 
     def _read_post(self):

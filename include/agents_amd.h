@@ -43,6 +43,16 @@ int aa_rb_scatter_rows(void* const* leaf_tables_h, const void* const* leaf_items
                        const int64_t* leaf_row_bytes_h, int n_leaves, int64_t* id_table,
                        int64_t* last_id_dev, int64_t* arrival_dev /* nullable, see below */,
                        int64_t batch, int64_t max_len, void* stream);
+/* aa_rb_scatter_rows whose launch also runs DynamicStepDriver's loop counter on the step types of
+ * the time step the body just produced (aa_count_steps: counter[b] += step_type[b] != LAST, *total
+ * += the sum, posted to `mailbox`; drivers/dynamic_step_driver.py:113,170) as one extra workgroup.
+ * step_type == NULL: exactly aa_rb_scatter_rows. */
+int aa_rb_scatter_rows_count(void* const* leaf_tables_h, const void* const* leaf_items_h,
+                             const int64_t* leaf_row_bytes_h, int n_leaves, int64_t* id_table,
+                             int64_t* last_id_dev, int64_t* arrival_dev, int64_t batch,
+                             int64_t max_len, const int32_t* step_type, int64_t n_envs,
+                             int32_t* counter_dev, int64_t* total_dev, int64_t* mailbox,
+                             void* stream);
 /* `arrival_dev`: zero before the call and left zero; the kernel counts finished workgroups in it
  * so that the LAST one advances the counter every group has read (last_id, Philox call counter,
  * env step counter) -- no second one-thread launch.
@@ -214,6 +224,21 @@ int aa_dense_small_forward_slabs(const float* slabs, int32_t splits, int64_t M, 
                                  const float* bias1 /* nullable */, int32_t act1, float* h,
                                  int64_t ldh, const float* w, const float* bias /* nullable */,
                                  int32_t act, int32_t N, float* y, void* stream);
+/* aa_dense_small_forward_slabs whose launch also SELECTS the actions of the Q values it produces
+ * (EpsilonGreedyPolicy._action over QPolicy / GreedyPolicy: policies/epsilon_greedy_policy.py:
+ * 120-143, q_policy.py:150-194, greedy_policy.py:70-89): row m's wave restates
+ * aa_eps_greedy_action on row m -- same masked arg-max, same Philox stream (counter (m, call)),
+ * same epsilon mix -- so the actions equal the two-launch path's bit for bit.  arrival_dev: 144
+ * zero int64 words (NULL: the call counter is read but not advanced, as aa_eps_greedy_action does
+ * for epsilon == 0). */
+int aa_dense_small_forward_slabs_eps(const float* slabs, int32_t splits, int64_t M, int32_t K,
+                                     const float* bias1, int32_t act1, float* h, int64_t ldh,
+                                     const float* w, const float* bias, int32_t act, int32_t N,
+                                     float* y, const int32_t* mask, float epsilon,
+                                     const float* epsilon_dev, uint64_t seed,
+                                     int64_t* call_counter_dev, int64_t* arrival_dev,
+                                     int64_t action_min, void* actions_out,
+                                     int32_t actions_are_i64, void* stream);
 int aa_dense_small_dx(const float* dz, const float* w, const float* mask_src /* [M,K] nullable */,
                       int32_t mask_kind, int64_t M, int32_t K, int32_t N, float* dx, void* stream);
 /* aa_dense_small_dx and aa_dense_small_dw in one launch (same results): the backward pass of the

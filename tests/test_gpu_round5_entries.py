@@ -69,3 +69,97 @@ def test_early_target_forward_in_stream_order_is_bit_identical(dev, monkeypatch)
     assert torch.equal(w1["net"].flat_params, w2["net"].flat_params)
     assert torch.equal(w1["agent"]._target_q_network.flat_params,
                        w2["agent"]._target_q_network.flat_params)
+
+
+def test_actions_selected_by_the_head_launch_equal_the_select_launch(dev, monkeypatch):
+    """aa_dense_small_forward_slabs_eps: the Q head's launch draws the epsilon-greedy actions of its
+    own Q values -- bit-identical to head launch + aa_eps_greedy_action, with and without an action
+    mask, the Philox call counter advancing alike (policies/epsilon_greedy_policy.py:120-143)."""
+    from agents_amd import ops
+    from agents_amd.policies import q_policy
+    from agents_amd.specs import tensor_spec
+    from agents_amd.trajectories import time_step as ts
+    rng = np.random.default_rng(8)
+    M, K, H, A = 256, 3136, 512, 6
+    x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(dev)
+    w1 = torch.from_numpy((rng.standard_normal((K, H)) * 0.02).astype(np.float32)).to(dev)
+    b1 = torch.from_numpy(rng.standard_normal(H).astype(np.float32)).to(dev)
+    w2 = torch.from_numpy((rng.standard_normal((H, A)) * 0.05).astype(np.float32)).to(dev)
+    b2 = torch.from_numpy(rng.standard_normal(A).astype(np.float32)).to(dev)
+    mask = torch.from_numpy((rng.random((M, A)) > 0.4).astype(np.int32)).to(dev)
+    mask[:, 0] = 1
+    aspec = tensor_spec.BoundedTensorSpec((), torch.int64, 0, A - 1)
+    tss = ts.time_step_spec(tensor_spec.TensorSpec((4,), torch.float32))
+    for use_mask in (False, True):
+        for eps in (0.0, 0.3, 1.0):
+            pols = [q_policy._DiscretePolicy(tss, aspec, q_network=None, epsilon=eps, seed=77)
+                    for _ in range(2)]
+            for call in range(3):
+                h, y = torch.empty(M, H, device=dev), torch.empty(M, A, device=dev)
+                ops.dense_tail_forward(x, w1, b1, "relu", h, w2, b2, None, y)
+                want = pols[0].select(y, mask if use_mask else None, eps)
+                monkeypatch.setattr(pols[1], "_q_network", type("N", (), {"selected": False})())
+                sel = pols[1]._select_args(M, mask if use_mask else None, eps, dev)
+                h2, y2 = torch.empty_like(h), torch.empty_like(y)
+                done = ops.dense_tail_forward(x, w1, b1, "relu", h2, w2, b2, None, y2, select=sel)
+                assert done is True
+                assert torch.equal(y, y2) and torch.equal(h, h2)
+                assert torch.equal(want, sel["out"]), (use_mask, eps, call)
+                assert int(pols[0]._call_counter[0]) == int(pols[1]._call_counter[0])
+            if eps > 0:
+                assert int(pols[1]._call_counter[0]) == 3
+    # greedy with an all-but-one mask: the only allowed action
+    one = torch.zeros((M, A), dtype=torch.int32, device=dev)
+    one[:, 4] = 1
+    pol = q_policy._DiscretePolicy(tss, aspec, q_network=None, epsilon=0.5, seed=1)
+    monkeypatch.setattr(pol, "_q_network", type("N", (), {"selected": False})())
+    sel = pol._select_args(M, one, 0.5, dev)
+    ops.dense_tail_forward(x, w1, b1, "relu", torch.empty(M, H, device=dev), w2, b2, None,
+                           torch.empty(M, A, device=dev), select=sel)
+    assert bool((sel["out"] == 4).all())
+
+
+def test_collect_loop_with_and_without_the_fused_selection_is_bit_identical(dev, monkeypatch):
+    from agents_amd.policies import q_policy
+    monkeypatch.setattr(q_policy, "FUSE_SELECT", True)
+    w1, _, vals1 = _loop(dev, 10)
+    assert w1["net"].selected is not None
+    monkeypatch.setattr(q_policy, "FUSE_SELECT", False)
+    w2, _, vals2 = _loop(dev, 10)
+    assert vals1 == vals2
+    assert torch.equal(w1["net"].flat_params, w2["net"].flat_params)
+    for a, b in zip(w1["rb"]._data_table.variables(), w2["rb"]._data_table.variables()):
+        assert torch.equal(a, b)          # the replay holds the same actions and frames
+
+
+def test_step_count_inside_the_add_batch_launch_is_bit_identical(dev, monkeypatch):
+    """aa_rb_scatter_rows_count: the driver's loop counter as an extra workgroup of the replay
+    buffer's add launch == aa_count_steps + aa_rb_scatter_rows (same totals posted, same number of
+    loop bodies, same replay contents), also when runs need make-up bodies."""
+    from agents_amd.drivers import dynamic_step_driver
+
+    def run(fused, num_steps):
+        monkeypatch.setattr(graph, "COUNT_IN_ADD", fused)
+        w = bench.build_workload(dev, 0, 1, 32, 24, 32, seed=5)
+        env, rb, agent = w["env"], w["rb"], w["agent"]
+        env._p_end = 0.3                      # many boundary steps: runs need make-up bodies
+        drv = dynamic_step_driver.DynamicStepDriver(env, agent.collect_policy,
+                                                    observers=[rb.add_batch], num_steps=num_steps)
+        run_fn = common.function(drv.run)
+        ts_ = None
+        adds = []
+        for _ in range(12):
+            ts_, _ = run_fn(ts_)
+            adds.append(rb._get_last_id())
+        torch.cuda.synchronize()
+        g = graph.graphed_driver_run(drv)
+        return adds, [t.clone() for t in rb._data_table.variables()], \
+            int(g._total.item()), g.replays
+
+    for num_steps in (1, 32, 40):
+        a1, t1, tot1, rep1 = run(True, num_steps)
+        a0, t0, tot0, rep0 = run(False, num_steps)
+        assert a1 == a0 and tot1 == tot0 and rep1 == rep0 and rep1 > 0, num_steps
+        for x, y in zip(t1, t0):
+            assert torch.equal(x, y)
+    assert a1[-1] > 12        # num_steps = 40 with 32 envs: at least two bodies per run
