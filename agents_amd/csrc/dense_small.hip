@@ -101,9 +101,11 @@ aa_dense_small_fwd_slabs_kernel(const float* __restrict__ slab, int splits, int6
   float eps = 0.f;
   if (E.out != nullptr) {
     // every workgroup has the old counter value by the time the last arriver moves it
+    // (both words are requested here and used at the very end; the ARRIVAL -- a returning atomic
+    // -- happens at the end as well: in front of the slab loads it delayed every workgroup's first
+    // load by its round trip, 0.3011 vs 0.2903 ms per iteration, profiles/r05_h_fuse_select_ab.txt)
     call = E.call_dev != nullptr ? (uint64_t)(*E.call_dev) : 0ull;
     eps = E.epsilon_dev != nullptr ? *E.epsilon_dev : E.epsilon;
-    if (E.arrival != nullptr) aa_advance_sharded(E.call_dev, E.arrival, 1, gridDim.x);
   }
   const size_t MK = (size_t)M * K;
   float acc[N];
@@ -218,6 +220,9 @@ aa_dense_small_fwd_slabs_kernel(const float* __restrict__ slab, int splits, int6
     else
       reinterpret_cast<int32_t*>(E.out)[m] = (int32_t)v;
   }
+  // this workgroup has consumed the counter's old value (read at the top): the last arriver moves it
+  if (E.out != nullptr && E.arrival != nullptr)
+    aa_advance_sharded(E.call_dev, E.arrival, 1, gridDim.x);
 }
 
 template <int N>
