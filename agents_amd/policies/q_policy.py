@@ -17,10 +17,16 @@ from agents_amd.trajectories import policy_step
 from agents_amd.utils import graph, nest_utils
 
 
-# AA_FUSE_SELECT=0: the epsilon-greedy selection stays a launch of its own behind the Q-network's
-# forward (A/B measurements; the same actions bit for bit either way)
+# AA_FUSE_SELECT=1 (opt-in): the Q head's launch also draws the epsilon-greedy actions
+# (csrc/dense_small.hip: aa_dense_small_forward_slabs_eps) instead of a launch of its own behind the
+# forward.  The same actions bit for bit, one launch less per collect step -- and a slower DQN
+# iteration: 0.3011 vs 0.2903 ms with the counter's arrival in front of the slab loads, 0.3048 vs
+# 0.3031 ms (three alternating pairs) with it at the end of the kernel
+# (profiles/r05_h_fuse_select_ab.txt, r05_i_fuse_select_ab.txt): the serial selection in lane 0
+# lengthens every one of the head's 256 single-wave workgroups, and the collect lane's kernels run
+# beside the training stream's.
 import os as _os
-FUSE_SELECT = _os.environ.get("AA_FUSE_SELECT", "1") != "0"
+FUSE_SELECT = _os.environ.get("AA_FUSE_SELECT", "0") == "1"
 
 
 def _action_bounds(action_spec):
