@@ -23,6 +23,7 @@ AA_SAC_STD_EXP, AA_SAC_STD_CLIP_EXP = 0, 1
 AA_PPO_NSTATS = 8
 AA_PPO_DIST_STATS = 16 + 6 * 256
 
+AA_ERR_INVALID, AA_ERR_RANGE = -22, -34
 _ERRORS = {-22: "AA_ERR_INVALID (bad argument)", -34: "AA_ERR_RANGE (size / workspace)",
            -5: "AA_ERR_LAUNCH (HIP launch failure)", -62: "AA_ERR_TIMEOUT (mailbox wait)"}
 
@@ -145,6 +146,7 @@ _SIGNATURES = {
     "aa_marker": (c_int, [c_int32, c_void_p]),
     "aa_gemm_f32_workspace_bytes": (c_int64, [POINTER(GemmDesc)]),
     "aa_gemm_f32": (c_int, [POINTER(GemmDesc), c_void_p, c_int64, c_void_p]),
+    "aa_gemm_f32_pair": (c_int, [POINTER(GemmDesc), POINTER(GemmDesc), c_void_p]),
     "aa_gemm_f32_slabs": (c_int, [POINTER(GemmDesc), c_void_p, c_int64, POINTER(c_int32),
                                   c_void_p]),
     "aa_conv_pair_supported": (c_int, [c_int32, c_int32, c_int32, c_int32, POINTER(ConvLayerDesc),

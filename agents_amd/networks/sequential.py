@@ -1032,6 +1032,16 @@ class Sequential(network.Network):
                     issue_late_prep()
                     dz = s.dxs[i]
                     continue
+                if i > 0 and param_grads and ops.dense_dx_dw(
+                        dz2, self._kviews[i], s.dxs[i].view(B, -1), x, self._gkviews[i],
+                        mask_src=x if prev_act else None, mask_act=prev_act,
+                        bias_grad=self._gbviews[i]):
+                    # input and weight gradient in one launch on the chain's stream (both read dZ)
+                    if DX_FIRST and side_stream is not main:
+                        side_stream.wait_stream(main)     # the fork the two-launch form makes here
+                    issue_late_prep()
+                    dz = s.dxs[i]
+                    continue
                 if i > 0:
                     dx = s.dxs[i].view(B, -1)
                     if DX_FIRST:

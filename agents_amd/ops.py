@@ -333,6 +333,45 @@ def dense_dw(x, dz, out, force_cfg=0, force_splits=0, bias_grad=None):
     return out
 
 
+# AA_GROUP_DENSE_BWD=0: a Dense layer's input and weight gradient stay two launches (A/B)
+GROUP_DENSE_BWD = _os.environ.get("AA_GROUP_DENSE_BWD", "1") != "0"
+_PAIR_BWD_OK = {}
+
+
+def dense_dx_dw(dz, w, dx, x, dw, mask_src=None, mask_act=None, bias_grad=None):
+    """dense_dx(dz, w, dx, mask_src, mask_act) and dense_dw(x, dz, dw, bias_grad) in ONE launch
+    (csrc/gemm_dma.h: aa_gemm_dma_pair_kernel; every tile is computed by the code of its own single
+    launch: bit-identical).  Returns False -- nothing launched -- when the pair of shapes is not
+    one the library groups (the caller then issues the two launches)."""
+    if not GROUP_DENSE_BWD or FORCE_NO_DMA or _DMA_MODES is not None:
+        return False
+    require_cuda(dz, w, dx, x, dw, mask_src)
+    M, N = dz.shape
+    K, N2 = w.shape
+    if N != N2 or tuple(dx.shape) != (M, K) or tuple(x.shape) != (M, K) or \
+            tuple(dw.shape) != (K, N) or N <= SMALL_N:
+        return False
+    key = (M, N, K, x.stride(0), mask_src is not None, bias_grad is not None)
+    if _PAIR_BWD_OK.get(key) is False:
+        return False
+    for t in (dz, w, dx, dw):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            return False
+    lda = _rows_ok(x, "x")
+    da = gemm_desc(A=ptr(dz), B=ptr(w), C=ptr(dx), M=M, N=K, K=N, lda=N, ldb=N, ldc=K,
+                   a_mode=AA_A_ROW, b_mode=AA_B_COL, mask_src=ptr(mask_src), ldm=K,
+                   mask_kind=ACT[mask_act] if mask_src is not None else 0)
+    db = gemm_desc(A=ptr(x), B=ptr(dz), C=ptr(dw), M=K, N=N, K=M, lda=lda, ldb=N, ldc=N,
+                   a_mode=AA_A_COL, b_mode=AA_B_ROW, colsum_out=_bias_grad_ptr(bias_grad, N))
+    rc = _lib.load().aa_gemm_f32_pair(ctypes.byref(da), ctypes.byref(db), stream_ptr())
+    if rc == _lib.AA_ERR_RANGE:
+        _PAIR_BWD_OK[key] = False
+        return False
+    check(rc, "aa_gemm_f32_pair")
+    _PAIR_BWD_OK[key] = True
+    return True
+
+
 # ---- Conv2D (NHWC, VALID) -------------------------------------------------------------------
 def conv_out_hw(H, W, KH, KW, stride):
     return (H - KH) // stride + 1, (W - KW) // stride + 1

@@ -199,6 +199,14 @@ typedef struct aa_gemm_desc {
 
 int64_t aa_gemm_f32_workspace_bytes(const aa_gemm_desc* d);
 int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes, void* stream);
+/* Two independent contractions in ONE launch: the input gradient `a` (a_mode ROW, b_mode COL:
+ * dX = dZ W^T with the activation-derivative mask) and the weight gradient `b` (a_mode COL, b_mode
+ * ROW: dW = x^T dZ with the fused bias gradient) of one keras Dense layer -- both read the layer's dZ
+ * (tf.GradientTape, agents/dqn/dqn_agent.py:412-426).  Every tile is computed by the code of its
+ * own single launch (bit-identical to two aa_gemm_f32 calls).  Only for pairs that plan as unsplit
+ * LDS-DMA contractions on the instantiated tile shapes (fc1 of the Atari Q-network); otherwise
+ * AA_ERR_RANGE and nothing is launched. */
+int aa_gemm_f32_pair(const aa_gemm_desc* a, const aa_gemm_desc* b, void* stream);
 /* aa_gemm_f32 without the split-K reduce launch, for a consumer that sums the partial products in
  * its own prologue (aa_dense_small_forward_slabs): *splits_out = s > 1 -> `workspace` starts with
  * the raw fp32 slabs [s][M][N] (no bias, no activation) and C is untouched; *splits_out = 1 -> the

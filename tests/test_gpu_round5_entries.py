@@ -163,3 +163,36 @@ def test_step_count_inside_the_add_batch_launch_is_bit_identical(dev, monkeypatc
         for x, y in zip(t1, t0):
             assert torch.equal(x, y)
     assert a1[-1] > 12        # num_steps = 40 with 32 envs: at least two bodies per run
+
+
+def test_dense_input_and_weight_gradient_in_one_launch(dev, monkeypatch):
+    """aa_gemm_f32_pair: fc1's dX (with the ReLU mask) and dW (+ bias gradient) as one launch ==
+    the two launches, bit for bit; shapes the library does not group are refused (False) and left
+    untouched."""
+    from agents_amd import ops
+    rng = np.random.default_rng(12)
+    M, K, N = 256, 3136, 512
+    r = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(dev)
+    dz, w, x = r(M, N), r(K, N) * 0.05, torch.relu(r(M, K))
+    dx0, dw0, bg0 = torch.empty(M, K, device=dev), torch.empty(K, N, device=dev), \
+        torch.empty(N, device=dev)
+    ops.dense_dx(dz, w, dx0, mask_src=x, mask_act="relu")
+    ops.dense_dw(x, dz, dw0, bias_grad=bg0)
+    dx1, dw1, bg1 = torch.full_like(dx0, float("nan")), torch.full_like(dw0, float("nan")), \
+        torch.full_like(bg0, float("nan"))
+    monkeypatch.setattr(ops, "GROUP_DENSE_BWD", True)
+    assert ops.dense_dx_dw(dz, w, dx1, x, dw1, mask_src=x, mask_act="relu", bias_grad=bg1) is True
+    assert torch.equal(dx0, dx1) and torch.equal(dw0, dw1) and torch.equal(bg0, bg1)
+    ref = (dz.double() @ w.double().T) * (x > 0)
+    assert float((dx1.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # a pair that plans otherwise (a split-K weight gradient): refused, outputs untouched
+    M2, K2, N2 = 4096, 64, 64
+    dz2, w2, x2 = r(M2, N2), r(K2, N2), r(M2, K2)
+    dxn, dwn = torch.full((M2, K2), 7.0, device=dev), torch.full((K2, N2), 7.0, device=dev)
+    assert ops.dense_dx_dw(dz2, w2, dxn, x2, dwn) is False
+    assert bool((dxn == 7.0).all()) and bool((dwn == 7.0).all())
+    # the whole loop with and without the grouping: identical training
+    w_a, _, vals_a = _loop(dev, 8)
+    monkeypatch.setattr(ops, "GROUP_DENSE_BWD", False)
+    w_b, _, vals_b = _loop(dev, 8)
+    assert vals_a == vals_b and torch.equal(w_a["net"].flat_params, w_b["net"].flat_params)
