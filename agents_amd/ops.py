@@ -333,8 +333,12 @@ def dense_dw(x, dz, out, force_cfg=0, force_splits=0, bias_grad=None):
     return out
 
 
-# AA_GROUP_DENSE_BWD=0: a Dense layer's input and weight gradient stay two launches (A/B)
-GROUP_DENSE_BWD = _os.environ.get("AA_GROUP_DENSE_BWD", "1") != "0"
+# AA_GROUP_DENSE_BWD=1 (opt-in): a Dense layer's input and weight gradient as ONE launch
+# (aa_gemm_f32_pair).  Bit-identical -- and 9 % slower inside the DQN iteration: 0.3251 vs 0.2973 ms,
+# three alternating pairs (profiles/r05_k_group_dense_bwd_ab.txt): the input gradient sits on the
+# backward pass's critical chain and now ends with the weight gradient's tiles, which used to run
+# on the side branch beside conv3's input gradient.
+GROUP_DENSE_BWD = _os.environ.get("AA_GROUP_DENSE_BWD", "0") == "1"
 _PAIR_BWD_OK = {}
 
 
