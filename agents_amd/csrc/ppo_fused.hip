@@ -73,8 +73,13 @@ static long long* g_pf_stamps = nullptr;
 
 // Dynamic LDS image of a workgroup (one per CU: 89 KB).
 struct PfLds {
-  float Ws[2][PF_W * PF_PITCH];              // the current layer's weights of each group
-  float bs[2][PF_W];
+  // Round 5: EVERY layer's weights of both groups are resident (104 KB; 160 KB in all): they are
+  // requested at kernel start, land during the prologue and are committed once -- a layer step is
+  // then LDS reads + MFMAs behind ONE barrier.  (Until round 4 a group held one layer at a time:
+  // every step began with barrier / commit 17 KB / issue the next layer's loads / barrier, which the
+  // in-kernel timeline put at 1.5-3 us of each 1.7-4.2 us step.)
+  float Ws[2][PF_MAXL][PF_W * PF_PITCH];
+  float bs[2][PF_MAXL][PF_W];
   float X[PF_TS][PF_PITCH];                  // normalised observations (input of both networks)
   float H[2][PF_MAXL][PF_TS][PF_PITCH];      // layer outputs: [0] actor, [1] value
   float G[2][2][PF_TS][PF_PITCH];            // backward ping-pong per group
@@ -343,14 +348,22 @@ __global__ void __launch_bounds__(PF_THREADS) aa_ppo_fused_step_kernel(PfArgs P)
   float* slab = P.slabs + (int64_t)blockIdx.x * d.total;
   // source row of minibatch sample b (the shuffle's permutation slice), or b itself
   auto row_of = [&](int64_t b) -> int64_t { return d.rows != nullptr ? d.rows[b] : b; };
-  PfW wq;
+  PfW wq[PF_MAXL];
   PF_STAMP(0)
   if (tid == 0) S.nets[0] = d.actor;
   if (tid == 256) S.nets[1] = d.value;
-  // each group's first layer is in flight during the prologue below
-  if (grp == 0) pf_prefetch(d.params, d.actor, 0, gt, wq);
-  else pf_prefetch(d.params, d.value, 0, gt, wq);
-  for (int i = tid; i < 2 * PF_W * PF_PITCH; i += PF_THREADS) (&S.Ws[0][0])[i] = 0.f;
+  // every layer of this group's network is in flight during the prologue below
+  {
+    const aa_mlp_layout& mine = grp == 0 ? d.actor : d.value;
+#pragma unroll
+    for (int l = 0; l < PF_MAXL; ++l)
+      pf_prefetch(d.params, mine, l < mine.n_layers ? l : mine.n_layers - 1, gt, wq[l]);
+  }
+  {
+    float4* z = reinterpret_cast<float4*>(&S.Ws[0][0][0]);
+    constexpr int NZ = 2 * PF_MAXL * PF_W * PF_PITCH / 4;
+    for (int i = tid; i < NZ; i += PF_THREADS) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   for (int i = tid; i < 4 * PF_TS * PF_PITCH; i += PF_THREADS) (&S.G[0][0][0][0])[i] = 0.f;
 
   // ---- advantage moments over the WHOLE minibatch ----------------------------------------------------
@@ -430,21 +443,16 @@ __global__ void __launch_bounds__(PF_THREADS) aa_ppo_fused_step_kernel(PfArgs P)
   const int Lg = net.n_layers;
   const int Lmax = S.nets[0].n_layers > S.nets[1].n_layers ? S.nets[0].n_layers
                                                            : S.nets[1].n_layers;
-  float* Wg = S.Ws[grp];
-  float* bg = S.bs[grp];
-  // begin of a layer step of this group: the previous step's readers of Ws are done -> the
-  // prefetched weights go to LDS, the next step's loads are issued (`nl` = its layer or -1)
-  auto begin_step = [&](int l, int nl) {
-    pf_barrier();
-    if (l >= 0) pf_commit(net, l, gt, wq, Wg, bg);
-    if (nl >= 0) pf_prefetch(d.params, net, nl, gt, wq);
-    pf_barrier();
-  };
+  // the weights of all layers -> LDS (the zero fill above is complete: the barrier before stamp 2)
+#pragma unroll
+  for (int l = 0; l < PF_MAXL; ++l)
+    if (l < Lg) pf_commit(net, l, gt, wq[l], S.Ws[grp][l], S.bs[grp][l]);
   for (int i = 0; i < Lmax; ++i) {
     const int l = pf_fwd_layer(Lg, i);
-    const int nl = i + 1 < Lmax ? pf_fwd_layer(Lg, i + 1) : pf_bwd_layer(Lg, 0);
-    begin_step(l, nl);
-    if (l >= 0) pf_forward(net, l, gt, l == 0 ? S.X : S.H[grp][l - 1], S.H[grp][l], Wg, bg);
+    pf_barrier();      // the previous step's outputs (and, for i = 0, the committed weights)
+    if (l >= 0)
+      pf_forward(net, l, gt, l == 0 ? S.X : S.H[grp][l - 1], S.H[grp][l], S.Ws[grp][l],
+                 S.bs[grp][l]);
     PF_STAMP(3 + i)
   }
   pf_barrier();
@@ -572,11 +580,10 @@ __global__ void __launch_bounds__(PF_THREADS) aa_ppo_fused_step_kernel(PfArgs P)
   int cur = 0;
   for (int i = 0; i < Lmax; ++i) {
     const int l = pf_bwd_layer(Lg, i);
-    const int nl = i + 1 < Lmax ? pf_bwd_layer(Lg, i + 1) : -1;
-    begin_step(l, nl);             // (its first barrier also completes G[grp][cur])
+    pf_barrier();                  // completes G[grp][cur]
     if (l >= 0) {
-      pf_backward(net, l, gt, l == 0 ? S.X : S.H[grp][l - 1], S.G[grp][cur], S.G[grp][cur ^ 1], Wg,
-                  slab);
+      pf_backward(net, l, gt, l == 0 ? S.X : S.H[grp][l - 1], S.G[grp][cur], S.G[grp][cur ^ 1],
+                  S.Ws[grp][l], slab);
       cur ^= 1;
     }
     PF_STAMP(11 + i)
