@@ -197,3 +197,34 @@ def test_dense_input_and_weight_gradient_in_one_launch(dev, monkeypatch):
     monkeypatch.setattr(ops, "GROUP_DENSE_BWD", False)
     w_b, _, vals_b = _loop(dev, 8)
     assert vals_a == vals_b and torch.equal(w_a["net"].flat_params, w_b["net"].flat_params)
+
+
+def test_ppo_collect_loop_replayed_as_graphs_equals_the_eager_loop(dev):
+    """tools/bench_ppo.py now runs the PPO collect loop through common.function(driver.run) -- HIP
+    graph replays of the loop body, launched without a host wait per body (utils/graph.py) --: the
+    replay buffer must hold exactly what the eager driver loop leaves, over several iterations
+    with boundary steps (make-up bodies) and `clear()` in between."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "tools"))
+    import bench_ppo
+    from agents_amd.utils import nest_utils
+
+    def collect(graphed):
+        w = bench_ppo.build(dev, envs=64, steps=12, minibatch=64, epochs=1,
+                            episode_end_probability=0.05)
+        run = w["collect"] if graphed else w["collect_driver"].run
+        ts_, out = None, []
+        for _ in range(4):
+            w["rb"].clear()
+            ts_, _ = run(ts_)
+            torch.cuda.synchronize()
+            out.append([t.clone() for t in nest_utils.flatten(w["rb"].gather_all())])
+        return out
+
+    a, b = collect(True), collect(False)
+    for it, (xa, xb) in enumerate(zip(a, b)):
+        assert len(xa) == len(xb)
+        for ta, tb in zip(xa, xb):
+            assert ta.shape == tb.shape and torch.equal(ta, tb), it

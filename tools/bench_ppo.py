@@ -118,8 +118,11 @@ def build(dev, envs=2048, steps=128, minibatch=4096, epochs=10, after_train_step
                                  num_samples=1, num_epochs=epochs,
                                  minibatch_size=minibatch, shuffle_buffer_size=B * (T + 1),
                                  after_train_strategy_step_fn=after_train_step_fn)
+    # train_eval_clip_agent.py:248-251: `collect_driver.run = common.function(collect_driver.run)`
+    collect = common.function(drv.run)
     return dict(agent=agent, actor=actor, value=value, env=env, rb=rb, collect_driver=drv,
-                learner=lrn, raw_dataset_fn=raw_dataset_fn, obs_spec=obs, action_spec=act)
+                collect=collect, learner=lrn, raw_dataset_fn=raw_dataset_fn, obs_spec=obs,
+                action_spec=act)
 
 
 def run(args, dev=None, rank=0, world=1):
@@ -132,6 +135,10 @@ def run(args, dev=None, rank=0, world=1):
     B, T = args.envs, args.steps
     w = build(dev, B, T, args.minibatch, args.epochs, rank=rank)
     agent, rb, drv, lrn = w["agent"], w["rb"], w["collect_driver"], w["learner"]
+    # the driver loop replays as HIP graphs (one per environment output buffer), as the reference's
+    # script runs it under tf.function; AA_BENCH_PPO_EAGER_COLLECT=1 keeps the eager loop (A/B)
+    collect = drv.run if os.environ.get("AA_BENCH_PPO_EAGER_COLLECT") == "1" else w["collect"]
+    tsx = [None]
 
     def sync_all():
         if world > 1:
@@ -143,7 +150,7 @@ def run(args, dev=None, rank=0, world=1):
         sync_all()
         t0 = time.perf_counter()
         rb.clear()
-        drv.run()
+        tsx[0], _ = collect(tsx[0])
         sync_all()
         t1 = time.perf_counter()
         lrn._train_iter = lrn._norm_iter = None   # a fresh deterministic pass over the new data
