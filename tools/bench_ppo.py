@@ -135,9 +135,13 @@ def run(args, dev=None, rank=0, world=1):
     B, T = args.envs, args.steps
     w = build(dev, B, T, args.minibatch, args.epochs, rank=rank)
     agent, rb, drv, lrn = w["agent"], w["rb"], w["collect_driver"], w["learner"]
-    # the driver loop replays as HIP graphs (one per environment output buffer), as the reference's
-    # script runs it under tf.function; AA_BENCH_PPO_EAGER_COLLECT=1 keeps the eager loop (A/B)
-    collect = drv.run if os.environ.get("AA_BENCH_PPO_EAGER_COLLECT") == "1" else w["collect"]
+    # The eager driver loop.  AA_BENCH_PPO_GRAPHED_COLLECT=1 replays the loop body as HIP graphs
+    # (common.function(driver.run), bit-identical: tests/test_gpu_round5_entries.py) -- measured
+    # SLOWER here, same box: 9.85 M vs 12.7 M env steps/s (208 vs 161 us per body).  A PPO body is
+    # ~20 dependent launches of a few microseconds each; a HIP graph orders dependent nodes with
+    # completion signals (~8-10 us per edge on this runtime), the in-order stream dispatches them
+    # back to back, so the graph is GPU-bound above what the eager loop's host can issue.
+    collect = w["collect"] if os.environ.get("AA_BENCH_PPO_GRAPHED_COLLECT") == "1" else drv.run
     tsx = [None]
 
     def sync_all():
