@@ -25,7 +25,10 @@ def run(var, val, steps):
                          text=True)
     for line in reversed(out.stdout.strip().splitlines()):
         if line.startswith("{"):
-            return json.loads(line)["ms_per_step"]
+            d = json.loads(line)
+            print(f"    (host enqueue {d.get('host_enqueue_ms_per_step', 0):.4f} ms / step)",
+                  flush=True)
+            return d["ms_per_step"]
     raise RuntimeError(out.stderr[-2000:])
 
 
