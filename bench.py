@@ -36,7 +36,7 @@ TRIPLE_OP = "conv1+conv2+conv3.fwd(one launch)"
 PRIME_MIN = 0                  # minimum untimed iterations in front of --warmup (see main: priming)
 CPU_RING_FRAMES = 256          # replay frames per env of the cpu_baseline leg (see cpu_baseline)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
-PMC_FILE = os.path.join("profiles", "r04_pmc.json")   # committed rocprofv3 --pmc passes (isolated)
+PMC_FILE = os.path.join("profiles", "r05_pmc.json")   # committed rocprofv3 --pmc passes (isolated)
 # Set in the child of the in-loop profiling pass (see inloop_profile): the run brackets its timed
 # region and every isolated kernel case with aa_marker launches and reports their labels in order.
 TRACE_CHILD = os.environ.get("AA_BENCH_TRACE_CHILD") == "1"
@@ -1271,7 +1271,7 @@ def main():
                         "conv1.fwd(u8)": "conv1.fwd",
                         "replay.get_next(sample+gather 512 rows)": "replay.get_next"}
             pmc, pmc_src = {}, None
-            for cand in (PMC_FILE, os.path.join("profiles", "r03_pmc.json")):
+            for cand in (PMC_FILE, os.path.join("profiles", "r04_pmc.json")):
                 if os.path.exists(os.path.join(ROOT, cand)):
                     with open(os.path.join(ROOT, cand)) as fh:
                         pmc = json.load(fh).get("cases", {})

@@ -55,6 +55,7 @@ def main():
     elif args.name in ("conv123.fwd", "conv123.fwd.keep"):
         # the three convs on uint8 frames in one launch (csrc/conv_triple_x6.h); ".keep" also
         # stores the two intermediate activations (the online network's forward)
+        ops.CONV_TRIPLE = True        # (opt-in in the library: it loses inside the DQN loop)
         obs = torch.randint(0, 256, (S, 84, 84, 4), dtype=torch.uint8, generator=g).to(dev)
         ws_ = [r(8, 8, 4, 32) * 0.06, r(4, 4, 32, 64) * 0.04, r(3, 3, 64, 64) * 0.04]
         bs_ = [r(32), r(64), r(64)]
