@@ -729,7 +729,7 @@ def main_prioritized(args):
     # untimed until no HIP graph has been captured for a while: the sampled batches are fresh
     # tensors, and GraphedTrain gives an address set that comes back its own graph
     quiet, seen, primed = 0, graph.capture_count(), 0
-    while primed < 400 and quiet < 20:
+    while primed < 1200 and quiet < 100:    # (up to 16 address sets get a graph, then no more)
         step()
         primed += 1
         now = graph.capture_count()
