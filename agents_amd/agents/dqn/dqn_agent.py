@@ -228,7 +228,8 @@ class DqnAgent(tf_agent.TFAgent):
         key = (device.type, device.index)
         st = self._side_streams.get(key)
         if st is None:
-            st = self._side_streams[key] = ops.new_side_stream(device)
+            st = self._side_streams[key] = ops.new_side_stream(
+                device, priority=int(os.environ.get("AA_SIDE_PRIORITY", "0")))
         return st
 
     def _get_work(self, B, device):

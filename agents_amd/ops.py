@@ -90,8 +90,17 @@ class SideStream(torch.cuda.Stream):
     it with `side_line` so that its kernels take their scratch from the line's own buffers."""
 
 
-def new_side_stream(device):
-    st = SideStream(device=device)
+def new_side_stream(device, priority=0):
+    """priority > 0: a LOWER-priority stream where the runtime offers one (A/B knob
+    AA_SIDE_PRIORITY of DqnAgent: the weight-gradient branch behind the input-gradient chain)."""
+    st = None
+    if priority:
+        try:
+            st = SideStream(device=device, priority=int(priority))
+        except Exception:
+            st = None
+    if st is None:
+        st = SideStream(device=device)
     st.aa_line = next(_LINE_IDS)
     return st
 
