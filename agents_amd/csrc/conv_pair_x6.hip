@@ -113,29 +113,9 @@ __global__ void __launch_bounds__(256) aa_conv_pair_x6_split_kernel(CxLayer L0, 
 // ---- one layer of one frame -------------------------------------------------------------------
 // src: this layer's three LDS planes; results to global y, and (dst != nullptr) split into the
 // next layer's planes.  RT row tiles per wave (compile time).
-// The first four k-steps of a wave's filter fragments (its first column tile): a layer's caller
-// can request them BEFORE the barrier in front of the layer -- they depend on nothing the barrier
-// orders -- so that their L2 round trip (0.5-1 us, the first thing the k loop waits for) rides under
-// the staging / the previous layer's tail instead of behind the barrier (round 5).
-__device__ static inline void cx_preload_b(const CxLayer& L, CxFrag (&b)[4][3]) {
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int nct = L.Cout >> 4;
-  const int ct = wave & 3;
-  const size_t wstep = (size_t)nct * 3 * 64;
-  // (a wave without a column tile -- Cout < 64 -- loads tile 0's: valid memory, never used)
-  const uint4* wp = L.wf + (size_t)(ct < nct ? ct : 0) * 3 * 64 + lane;
-  const int last = L.ksteps - 1;
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int s = 0; s < 3; ++s) b[j][s].q = wp[(size_t)(j < last ? j : last) * wstep + s * 64];
-}
-
-template <int RT, bool PRE>
-__device__ static inline void cx_layer_impl(const CxLayer& L, const char* __restrict__ src, int img,
-                                            char* __restrict__ dst, const CxLayer& Ln,
-                                            CxFrag (&pre)[4][3]) {
+template <int RT>
+__device__ static inline void cx_layer(const CxLayer& L, const char* __restrict__ src, int img,
+                                       char* __restrict__ dst, const CxLayer& Ln) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, lr = lane & 15, lg = lane >> 4;
@@ -215,12 +195,9 @@ __device__ static inline void cx_layer_impl(const CxLayer& L, const char* __rest
     // refills are unconditional, with the index clamped to the last k-step: no branches in the
     // body.  Ring slot = k-step & 3; the 0-3 leftover steps reuse the slots in order.
     const int S = L.ksteps, last = S - 1;
-    CxFrag a0[RT][3], a1[RT][3];
-    CxFrag (&b)[4][3] = pre;            // the ring IS the caller's array (no copy)
-    if (!(PRE && ct == (wave & 3))) {   // (the wave's first column tile: requested by the caller)
+    CxFrag a0[RT][3], a1[RT][3], b[4][3];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) load_b(b[j], j < last ? j : last);
-    }
+    for (int j = 0; j < 4; ++j) load_b(b[j], j < last ? j : last);
     load_a(a0, L.tap[0]);
     auto step = [&](auto jc, int ks) {
       constexpr int J = decltype(jc)::value;
@@ -289,20 +266,6 @@ __device__ static inline void cx_layer_impl(const CxLayer& L, const char* __rest
   }
 }
 
-// (a register array is handed over by REFERENCE: through a pointer it would live in scratch)
-template <int RT>
-__device__ static inline void cx_layer(const CxLayer& L, const char* __restrict__ src, int img,
-                                       char* __restrict__ dst, const CxLayer& Ln) {
-  CxFrag none[4][3];
-  cx_layer_impl<RT, false>(L, src, img, dst, Ln, none);
-}
-template <int RT>
-__device__ static inline void cx_layer_pre(const CxLayer& L, const char* __restrict__ src, int img,
-                                           char* __restrict__ dst, const CxLayer& Ln,
-                                           CxFrag (&pre)[4][3]) {
-  cx_layer_impl<RT, true>(L, src, img, dst, Ln, pre);
-}
-
 template <int RT0, int RT1, int NW>
 __global__ void __launch_bounds__(NW * 64) aa_conv_pair_x6_kernel(CxParams P) {
   constexpr int NT = NW * 64;
@@ -319,8 +282,6 @@ __global__ void __launch_bounds__(NW * 64) aa_conv_pair_x6_kernel(CxParams P) {
     __syncthreads();   // the previous frame's readers are done
     CX_STAMP(0)
     const float4* xs = reinterpret_cast<const float4*>(P.x + (size_t)img * P.img_pitch);
-    CxFrag pb[4][3];
-    cx_preload_b(L0, pb);     // in flight during the frame's load and split
     // 8 x 16-byte loads in flight: a 20 x 20 x 32 frame (1,600 items) is ONE trip of the loop,
     // i.e. one memory round trip per frame instead of two
     for (int it0 = tid; it0 < n_item; it0 += 4 * NT) {
@@ -350,12 +311,11 @@ __global__ void __launch_bounds__(NW * 64) aa_conv_pair_x6_kernel(CxParams P) {
     CX_STAMP(1)
     __syncthreads();
     CX_STAMP(2)
-    cx_layer_pre<RT0 * 4 / NW>(L0, s_in, img, s_mid, L1, pb);
+    cx_layer<RT0 * 4 / NW>(L0, s_in, img, s_mid, L1);
     CX_STAMP(3)
-    cx_preload_b(L1, pb);     // in flight while this wave waits for the others at the barrier
     __syncthreads();
     CX_STAMP(4)
-    cx_layer_pre<RT1 * 4 / NW>(L1, s_mid, img, nullptr, L1, pb);
+    cx_layer<RT1 * 4 / NW>(L1, s_mid, img, nullptr, L1);
     CX_STAMP(5)
   }
 }
