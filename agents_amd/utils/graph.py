@@ -141,11 +141,11 @@ class Lanes:
         return ev
 
     def main_frontier(self):
-        return self.event_on(torch.cuda.current_stream(self.device))
+        return self.event_on(current_stream(self.device))
 
     def join(self):
         """The caller's stream waits for everything enqueued on the collect / sample lanes."""
-        cur = torch.cuda.current_stream(self.device)
+        cur = current_stream(self.device)
         if self.collect_done is not None:
             cur.wait_event(self.collect_done)
         if self.sample_done is not None:
@@ -294,6 +294,25 @@ def _capture_stream(device):
     if st is None:
         st = _CAPTURE_STREAM[key] = torch.cuda.Stream(key)
     return st
+
+
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_STREAM_OBJECTS = {}    # (device index, raw hipStream_t) -> torch.cuda.Stream
+
+
+def current_stream(device):
+    """`torch.cuda.current_stream(device)` for the loop's hot paths: the raw handle comes from
+    the C entry point, the Stream object wrapping it from a cache (the torch call resolves the
+    device index in Python and builds a new object every time: ~6 us, five times per iteration
+    of the DQN loop)."""
+    idx = device.index
+    if _RAW_STREAM is None or idx is None:
+        return torch.cuda.current_stream(device)
+    key = (idx, _RAW_STREAM(idx))
+    s = _STREAM_OBJECTS.get(key)
+    if s is None:
+        s = _STREAM_OBJECTS[key] = torch.cuda.current_stream(device)
+    return s
 
 
 REPLAY_TIMERS = None    # set to {} to accumulate {kind: [launches, host seconds]}
@@ -556,7 +575,7 @@ class GraphedTrain:
             return self._eager_train(experience, weights=weights)
         with _device_ctx(dev):
             lanes = _LANES.get((dev.type, dev.index)) if _LANES else None
-            cur = torch.cuda.current_stream(dev)     # (looked up once: ~2 us of host time each)
+            cur = current_stream(dev)     # (looked up once: ~2 us of host time each)
             use_early = False
             early, self._early = self._early, None
             if early is not None:
@@ -883,7 +902,7 @@ class GraphedSampler:
             else:
                 if lanes.collect_done is not None:
                     lanes.S.wait_event(lanes.collect_done)
-                cur = torch.cuda.current_stream(dev)
+                cur = current_stream(dev)
                 lanes.S.wait_event(lanes.event_on(cur))      # = the main frontier
                 if lanes.aux_done is not None:
                     # an early target forward may still be reading the slot this draw overwrites
@@ -1085,7 +1104,7 @@ class GraphedDriverRun:
                         raise
                     c = self._graphs[slot]
                 if lanes is not None and it == 0:
-                    cur = torch.cuda.current_stream(st.device)
+                    cur = current_stream(st.device)
                     lanes.C.wait_event(lanes.event_on(cur))      # = the main frontier
                     if lanes.sample_done is not None:
                         lanes.C.wait_event(lanes.sample_done)
@@ -1094,7 +1113,7 @@ class GraphedDriverRun:
                     # step in between, an environment without `host_epoch`): post it now.  What
                     # the abandoned post had added to the device total counts as consumed.
                     self._t_counted = self._read_post()
-                    with _on_stream(lanes.C, torch.cuda.current_stream(st.device)) \
+                    with _on_stream(lanes.C, current_stream(st.device)) \
                             if lanes is not None else contextlib.nullcontext():
                         self._count(time_step.step_type)
                     self._seq += 1
@@ -1112,7 +1131,7 @@ class GraphedDriverRun:
                     time_step = c.replay()
                 else:
                     if it > 0:
-                        cur = torch.cuda.current_stream(st.device)
+                        cur = current_stream(st.device)
                     with _on_stream(lanes.C, cur):
                         _mark("collect.begin", lanes.C)
                         time_step = c.replay()
