@@ -33,6 +33,7 @@
 #define AA_DW6_NXI 2     /* staging rounds of 512 x (8 channels) for the x rows of one ky */
 #define AA_DW6_NZI 2     /* ... for the dZ frame */
 #define AA_DW6_MAX_KS 4  /* 32-pixel k-steps per frame */
+#define AA_DW6_TP 68     /* floats per row of the epilogue's slab tile in LDS */
 
 struct Dw6P {
   const float* x;     // [n_img][H*W][Cin]
@@ -40,7 +41,9 @@ struct Dw6P {
   float* slab;        // [groups][KH*KW*Cin][Cout], then [groups][Cout] (column sums of dZ)
   int n_img, H, W, Cin, KH, KW, stride, OH, OW, Cout;
   int G, groups, per_xcd, want_db;
-  int xpitch, zpitch;   // bytes per pixel of the bf16 images (channels * 2 + pad)
+  int xpitch;           // bytes per pixel of the bf16 x images (channels * 2 + pad)
+  int zpair;            // bytes per PAIR of dZ pixels (2 x 128 + pad, see dw6_plan)
+  int xrow;             // bytes per image row of the x planes (W * xpitch + pad, see dw6_plan)
   int xplane, zplane;   // bytes per plane
   int xsh, zsh;         // log2(Cin / 8), log2(Cout / 8)
   unsigned m_ow, m_w;   // ceil(2^16 / OW), ceil(2^16 / W)
@@ -50,7 +53,7 @@ struct Dw6P {
 };
 #ifdef AA_DW6_DEBUG
 #define AA_DW6_DBG(P, bit) (((P).dbg & (bit)) != 0)
-static int g_dw6_dbg = 0, g_dw6_xpad = -1, g_dw6_zpad = -1;
+static int g_dw6_dbg = 0, g_dw6_xpad = -1, g_dw6_zpad = -1, g_dw6_xrowpad = -1;
 #else
 #define AA_DW6_DBG(P, bit) false
 #endif
@@ -115,12 +118,14 @@ __global__ void __launch_bounds__(AA_DW6_THREADS) aa_conv_dw_frame_x6_kernel(Dw6
       // in two halves of 32 lanes = two 16-lane groups = 8 rows of 32 bytes: with k = 8 g + 4 h + r
       // mapped to pixel 16 h + 4 g + r those are 8 CONSECUTIVE pixels, and a pixel stride of
       // 32 (mod 64) bytes spreads them over all 64 banks (k -> 8 g + 4 h + r itself would put
-      // pixels p and p + 8 in one half: same banks whatever the pitch).
+      // pixels p and p + 8 in one half: same banks whatever the pitch).  That is the x planes
+      // (with image rows padded so that the stride holds across the end of an output row); the
+      // dZ planes reach the same with pixel pairs (dw6_plan).
       const int p = 32 * ks + 16 * h + 4 * g + (j >> 2);
       const int pc = p < OHW ? p : OHW - 1;       // pad pixels: any valid x row (their dZ is 0)
       const int oy = cx_div(pc, P.m_ow), ox = pc - oy * P.OW;
-      xoff[ks][h] = (oy * P.W + ox * P.stride) * P.xpitch + (j & 3) * 8;
-      zoff[ks][h] = p * P.zpitch + (j & 3) * 8;
+      xoff[ks][h] = oy * P.xrow + ox * P.stride * P.xpitch + (j & 3) * 8;
+      zoff[ks][h] = (p >> 1) * P.zpair + (p & 1) * 128 + (j & 3) * 8;
     }
   // this wave's row tiles: rows (kx, ci) of the ky block, 16 per tile
   int toff[RTW];
@@ -177,7 +182,8 @@ __global__ void __launch_bounds__(AA_DW6_THREADS) aa_conv_dw_frame_x6_kernel(Dw6
                           px[u][1].x, px[u][1].y, px[u][1].z, px[u][1].w};
       uint4 f[3];
       cx_split8(a, f);
-      char* d = xpl + q * P.xpitch + o * 16;
+      const int qr = cx_div(q, P.m_w);
+      char* d = xpl + qr * P.xrow + (q - qr * P.W) * P.xpitch + o * 16;
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) dw6_store16(d + pl * P.xplane, f[pl]);
     }
@@ -194,7 +200,7 @@ __global__ void __launch_bounds__(AA_DW6_THREADS) aa_conv_dw_frame_x6_kernel(Dw6
       }
       uint4 f[3];
       cx_split8(a, f);
-      char* d = zpl + q * P.zpitch + o * 16;
+      char* d = zpl + (q >> 1) * P.zpair + (q & 1) * 128 + o * 16;
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) dw6_store16(d + pl * P.zplane, f[pl]);
     }
@@ -271,7 +277,9 @@ __global__ void __launch_bounds__(AA_DW6_THREADS) aa_conv_dw_frame_x6_kernel(Dw6
   if (AA_DW6_DBG(P, 4) && big[0][0][0] != 12345.f) return;
   __syncthreads();     // every wave is done with the planes
   {
-    float* tile = reinterpret_cast<float*>(dw6_lds);      // [rows_blk][80]: row pitch 320 bytes
+    // [rows_blk][AA_DW6_TP]: a store's four lane groups are rows 4 apart -- at 68 floats per row
+    // 16 banks apart (at 80: the same 16 banks, a 4-way conflict on every store)
+    float* tile = reinterpret_cast<float*>(dw6_lds);
 #pragma unroll
     for (int rt = 0; rt < RTW; ++rt)
 #pragma unroll
@@ -279,7 +287,7 @@ __global__ void __launch_bounds__(AA_DW6_THREADS) aa_conv_dw_frame_x6_kernel(Dw6
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = (rg * RTW + rt) * 16 + 4 * g + e;
-          tile[row * 80 + (cp * 2 + c) * 16 + j] = big[c][rt][e] + small[c][rt][e];
+          tile[row * AA_DW6_TP + (cp * 2 + c) * 16 + j] = big[c][rt][e] + small[c][rt][e];
         }
     __syncthreads();
     const int n4 = rows_blk * 16;          // float4 items: 16 per row (Cout = 64)
@@ -287,7 +295,7 @@ __global__ void __launch_bounds__(AA_DW6_THREADS) aa_conv_dw_frame_x6_kernel(Dw6
       const int row = q >> 4, c4 = q & 15;
       // streamed (non-temporal, 16 bytes per lane): the next reader is another kernel -- the slab
       // reduce -- on every XCD
-      const dw6_f32x4 v4 = *reinterpret_cast<const dw6_f32x4*>(tile + row * 80 + c4 * 4);
+      const dw6_f32x4 v4 = *reinterpret_cast<const dw6_f32x4*>(tile + row * AA_DW6_TP + c4 * 4);
       __builtin_nontemporal_store(v4, reinterpret_cast<dw6_f32x4*>(out + (size_t)row * P.Cout +
                                                                    c4 * 4));
     }
@@ -342,23 +350,37 @@ static int dw6_plan(const aa_conv_dx_desc* d, Dw6Plan* pl) {
   P.xsh = 0;
   while ((8 << P.xsh) < d->Cin) ++P.xsh;
   P.zsh = 3;                                                           // Cout = 64
-  // pixel pitches: a multiple of 16 bytes (16-byte staging stores) whose stride between
-  // consecutive output pixels (s pitches for x, one for dZ) is 32 mod 64 bytes -- see the kernel
+  // x pixel pitch: a multiple of 16 bytes (16-byte staging stores) whose stride between
+  // consecutive output pixels (s pitches) is 32 mod 64 bytes -- see the kernel
   auto pick = [](int bytes, int stride) {
     for (int pad = 0; pad <= 112; pad += 16)
       if (((bytes + pad) * stride) % 64 == 32) return bytes + pad;
     return bytes + 16;
   };
   P.xpitch = pick(d->Cin * 2, s);
-  P.zpitch = pick(d->Cout * 2, 1);
+  // dZ (128 bytes per pixel, read at consecutive pixels from a multiple of 8): pixel PAIRS of 256
+  // bytes, 32 bytes of pad per pair.  A staging store's 16 lanes write one pair = every bank once
+  // (at one pitch per pixel their 2 x 128 bytes + pad wrapped around 256 onto themselves), and a
+  // read's 8 pixels sit at 32-byte slots k + {0, 4} (mod 8), k = 0 .. 3: every bank once as well.
+  P.zpair = 288;
 #ifdef AA_DW6_DEBUG
   if (g_dw6_xpad >= 0) P.xpitch = d->Cin * 2 + g_dw6_xpad;
-  if (g_dw6_zpad >= 0) P.zpitch = d->Cout * 2 + g_dw6_zpad;
+  if (g_dw6_zpad >= 0) P.zpair = 256 + g_dw6_zpad;
 #endif
-  P.xplane = P.OH * d->W * P.xpitch;
-  P.zplane = pl->ks * 32 * P.zpitch;
+  // image rows of the x planes: the 8 consecutive output pixels of a read's half wave usually
+  // cross an image row (OW = 7 or 9 here); their 32-byte rows keep landing on 8 different bank
+  // octets if stepping over the row end moves the address like one more pixel step does,
+  // mod 256 bytes: xrow = OW * s * xpitch (mod 256).  (At xrow = W * xpitch nearly every x read
+  // had a 2-way conflict: half of the kernel's LDS conflict cycles.)
+  P.xrow = d->W * P.xpitch;
+  while ((P.xrow - P.OW * s * P.xpitch) % 256 != 0) P.xrow += 16;
+#ifdef AA_DW6_DEBUG
+  if (g_dw6_xrowpad >= 0) P.xrow = d->W * P.xpitch + g_dw6_xrowpad;
+#endif
+  P.xplane = P.OH * P.xrow;
+  P.zplane = pl->ks * 16 * P.zpair;
   pl->lds = 3 * (size_t)P.xplane + 3 * (size_t)P.zplane;
-  const size_t tile_bytes = (size_t)d->KW * d->Cin * 320;              // the slab tile (epilogue)
+  const size_t tile_bytes = (size_t)d->KW * d->Cin * AA_DW6_TP * 4;    // the slab tile (epilogue)
   if (pl->lds < tile_bytes) pl->lds = tile_bytes;
   if (pl->lds < (size_t)AA_DW6_THREADS * 8 * 4) pl->lds = (size_t)AA_DW6_THREADS * 8 * 4;
   if (pl->lds > 160 * 1024) return AA_ERR_RANGE;

@@ -98,6 +98,19 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (argc > 2 && argv[2][0] == 'l') {   // round 5: image-row pad of the x planes / dZ pair pad, on / off
+    for (int v : {0, 1, 2, 3, 0, 1, 2, 3}) {
+      g_dw6_xrowpad = (v & 1) ? 0 : -1;      // 0: rows at W x pitch (rounds 2-4)
+      g_dw6_zpad = (v & 2) ? 64 : -1;        // 64: a pair = 2 x 160 bytes (the old per-pixel pitch)
+      printf("x rows %s, dZ pair pad %s: ", (v & 1) ? "unpadded" : "padded",
+             (v & 2) ? "64" : "32");
+      run("conv2.dW", n, 20, 20, 32, 4, 2, 64, true);
+      printf("x rows %s, dZ pair pad %s: ", (v & 1) ? "unpadded" : "padded",
+             (v & 2) ? "64" : "32");
+      run("conv3.dW", n, 9, 9, 64, 3, 1, 64, true);
+    }
+    return 0;
+  }
   if (argc > 2) {   // ablation timings (results are wrong by construction)
     for (int m : {0, 1, 2, 3, 4, 7}) {
       g_dw6_dbg = m;
