@@ -44,6 +44,9 @@ _TRIPLE_FOR_DEFAULT = "all"
 # AA_PACK_IN_OPTIMIZER=0: Learner.run's LossInfo scalars are packed by a launch of their own behind
 # the optimizer step (A/B measurements; same values either way)
 PACK_IN_OPTIMIZER = os.environ.get("AA_PACK_IN_OPTIMIZER", "1") != "0"
+# AA_SPLIT_LAST_DW=1: GraphedTrain records the gradient phase as two graphs around the first
+# layer's weight gradient and starts the next step's early target forward between them (round 5)
+SPLIT_LAST_DW = os.environ.get("AA_SPLIT_LAST_DW", "0") == "1"
 
 
 class DqnLossInfo(collections.namedtuple("DqnLossInfo", ("td_loss", "td_error"))):
@@ -421,15 +424,33 @@ class DqnAgent(tf_agent.TFAgent):
         k = net.dense_tail_start()
         return k if 0 < k < len(net._param_layers) else None
 
-    def _train_phase_grads_a(self, experience, weights, q_next_target=None):
+    def _last_dw_split(self):
+        """1 when the gradient phase may be recorded as two graphs around the FIRST layer's weight
+        gradient (the last launch of the backward chain; utils/graph.py: GraphedTrain starts the
+        next step's early target forward between them), else None: needs a lone replica with
+        nothing between backward and the optimizer step."""
+        net = self._q_network
+        if not SPLIT_LAST_DW or self.gradient_hook is not None or \
+                self.gradient_hook_async is not None or net.has_regularization or \
+                self._gradient_clipping is not None or not hasattr(net, "backward_resume") or \
+                len(getattr(net, "_param_layers", ())) < 2:
+            return None
+        return 1
+
+    def _train_phase_grads_a(self, experience, weights, q_next_target=None, split=None):
+        """`split`: the layer the first half stops above (default: the data-parallel bucket split)."""
         net = self._q_network
         w = self._forward_and_loss(experience, self._td_errors_loss_fn, self._gamma,
                                    self._reward_scale_factor, weights, need_grad=True,
                                    q_next_target=q_next_target)
+        self._last_work = w
         self._bucket_B = w.dq.shape[0]
+        self._split_at = self._bucket_split() if split is None else split
         extra = {"head_done": True} if w.head_done else {}
+        if split is not None and self._optimizer_sums_slabs(net):
+            extra["keep_dw_slabs"] = True
         net.backward(w.dq, slot="train", side_stream=self._side_stream(w.dq.device),
-                     stop_layer=self._bucket_split(), **extra)
+                     stop_layer=self._split_at, **extra)
         return tf_agent.LossInfo(w.loss.reshape(()),
                                  DqnLossInfo(td_loss=w.td_loss, td_error=w.td_error))
 
@@ -437,7 +458,7 @@ class DqnAgent(tf_agent.TFAgent):
         net = self._q_network
         net.backward_resume(self._bucket_B, slot="train",
                             side_stream=self._side_stream(net.flat_grads.device),
-                            from_layer=self._bucket_split())
+                            from_layer=self._split_at)
 
     def _optimizer_sums_slabs(self, net):
         """Nothing reads flat_grads between backward and the optimizer step (no clipping, no

@@ -917,7 +917,11 @@ class Sequential(network.Network):
         n = len(self._param_layers)
         top = self._param_layers[-1]
         self._grad_slabs = None
-        self._keep_dw_slabs = bool(keep_dw_slabs) and stop_layer == 0 and param_grads
+        # with stop_layer > 0 the kept slabs of this call's layers wait in `_pending_keep` for
+        # `backward_resume`, which adds the remaining layers' and builds the aa_grad_slabs
+        self._keep_dw_slabs = bool(keep_dw_slabs) and param_grads
+        self._keep_resume = self._keep_dw_slabs and stop_layer > 0
+        self._pending_keep = None
         if top.activation is not None:
             _lib.check(lib.aa_act_backward(dout.data_ptr(), s.ys[-1].data_ptr(),
                                            ops.ACT[top.activation], dout.numel(),
@@ -949,6 +953,8 @@ class Sequential(network.Network):
     def backward_resume(self, B, slot=0, side_stream=None, from_layer=1):
         """Continues a `backward(..., stop_layer=from_layer)`: layers from_layer-1 .. 0."""
         s = self._slots[(slot, B)]
+        self._keep_dw_slabs = getattr(self, "_pending_keep", None) is not None
+        self._keep_resume = False
         self._backward_range(s, B, s.dxs[from_layer], from_layer - 1, 0, side_stream, True, None)
 
     def grad_buckets(self, split_layer):
@@ -988,9 +994,13 @@ class Sequential(network.Network):
                 dx_prep_pending = self._hoist_dx_prep(s, B, hi, lo, fork_event=prep_fork)
                 prep_fork = None
 
+        side_used = False
+
         def on_side(fn, fork=True):
+            nonlocal side_used
             if side_stream is main:
                 return fn()
+            side_used = True
             if fork:
                 side_stream.wait_stream(main)  # dZ of this layer is ready once main gets here
             with ops.side_line(side_stream):
@@ -1002,8 +1012,11 @@ class Sequential(network.Network):
         self._keep_dw_slabs = False
         if keep and getattr(self, "_kept_ws", None) is None:
             self._kept_ws = ops.new_kept_workspaces()     # this network's own (advisor, round 4)
-        pending_dw = ops.PendingDwReduce(keep=keep, kept_ws=self._kept_ws if keep else None) \
-            if (keep or side_stream is not main) else None
+        pending_dw = getattr(self, "_pending_keep", None) if keep else None
+        self._pending_keep = None
+        if pending_dw is None:
+            pending_dw = ops.PendingDwReduce(keep=keep, kept_ws=self._kept_ws if keep else None) \
+                if (keep or side_stream is not main) else None
 
         for i in range(hi, lo - 1, -1):
             l = self._param_layers[i]
@@ -1100,9 +1113,13 @@ class Sequential(network.Network):
             main.wait_stream(self._prep_stream)
         if pending_dw is not None and pending_dw.items:
             on_side(lambda: ops.conv_dw_flush(pending_dw), fork=False)
-        if keep:
+        if keep and getattr(self, "_keep_resume", False):
+            self._pending_keep = pending_dw          # backward_resume continues this list
+        elif keep:
             self._grad_slabs = ops.grad_slabs(pending_dw, self.flat_grads)
-        if side_stream is not main:
+        if side_stream is not main and (side_used or lo > 0 or hi > lo):
+            # (a resumed range of layer 0 alone with its weight gradient on main has not touched
+            # the side stream: nothing to join -- and under capture nothing that could be joined)
             main.wait_stream(side_stream)
 
     def _first_div(self):

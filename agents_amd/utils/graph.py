@@ -383,6 +383,7 @@ class _Entry:
         self.g_apply = None       # _Captured: optimizer (shared by every entry of a signature)
         self.apply_state = None   # agent._apply_state() after this entry's gradient phase
         self.g_grads_b = None     # _Captured, bucket mode: second half of the backward
+        self.split_last = False   # g_grads_b = the first layer's weight gradient alone (one replica)
         self.captured = None      # _Captured, whole mode (part (a) when the agent splits it)
         self.captured_b = None    # _Captured, whole mode, part (b)
         self.out = None
@@ -622,6 +623,27 @@ class GraphedTrain:
                 if lanes is not None:
                     lanes.join()
                 e.captured.replay()
+            elif e.split_last:
+                # [forward + loss + backward down to the second layer] -> mark for the early target
+                # forward of the next step -> [first layer's weight gradient] -> optimizer
+                _mark("train.begin")
+                (e.g_grads_nt if use_early else e.g_grads).replay()
+                grads_done = self._early_mark(lanes, cur)
+                e.g_grads_b.replay()
+                _mark("train.grads_done")
+                if lanes is not None and lanes.collect_done is not None:
+                    cur.wait_event(lanes.collect_done)
+                if hasattr(agent, "_set_apply_state"):
+                    agent._set_apply_state(e.apply_state_nt if use_early else e.apply_state)
+                if APPLY_EAGER:
+                    agent._train_phase_apply()
+                else:
+                    e.g_apply.replay()
+                _mark("train.apply_done")
+                tw = getattr(agent, "_target_writes", None)
+                agent._train_phase_host()
+                self._issue_early_target(e, lanes, dev, cur, grads_done,
+                                         getattr(agent, "_target_writes", None) != tw)
             elif e.g_grads_b is not None:
                 # bucket mode (data-parallel): [forward + loss + dense-tail backward] -> start the
                 # all-reduce of the tail's gradients -> [conv backward] overlaps it -> all-reduce
@@ -731,7 +753,7 @@ class GraphedTrain:
         self._early = (nxt, done, self._agent._early_target_key(), seq)
         self.early_issued += 1
 
-    def _capture_early(self, e, bucketed):
+    def _capture_early(self, e, bucketed, split=None):
         """Per ring slot: the target forward alone, and the gradient phase that reads its output."""
         from agents_amd import ops
         agent = self._agent
@@ -746,8 +768,14 @@ class GraphedTrain:
             q_t = gt.capture(lambda: agent._train_phase_target(e.static_in))
         phase = agent._train_phase_grads_a if bucketed else agent._train_phase_grads
         gn = _Captured("train.grads")
-        gn.capture(lambda: phase(e.static_in, None, q_next_target=q_t))
-        e.apply_state_nt = agent._apply_state() if hasattr(agent, "_apply_state") else None
+        if split is not None:
+            gn.capture(lambda: agent._train_phase_grads_a(e.static_in, None, q_next_target=q_t,
+                                                          split=split))
+            # (its second half is e.g_grads_b: same launches on the same buffers, same slabs)
+            e.apply_state_nt = e.apply_state
+        else:
+            gn.capture(lambda: phase(e.static_in, None, q_next_target=q_t))
+            e.apply_state_nt = agent._apply_state() if hasattr(agent, "_apply_state") else None
         e.g_target, e.g_grads_nt = gt, gn
 
     def _capture(self, e, experience, weights, clone=True, g_apply=None, ring=False):
@@ -776,11 +804,21 @@ class GraphedTrain:
             bucketed = (getattr(agent, "gradient_hook_async", None) is not None and
                         hasattr(agent, "_train_phase_grads_a") and
                         agent._bucket_split() is not None and BUCKETED_ALLREDUCE)
+            # one replica, nothing between backward and the optimizer: the first layer's weight
+            # gradient (the last launch of the backward chain) as a graph of its own, so that the
+            # early target forward of the next step can start in front of it
+            split = None
+            if not bucketed and hasattr(agent, "_last_dw_split") and ring and not clone and \
+                    weights is None:
+                split = agent._last_dw_split()
+            e.split_last = split is not None
             e.g_grads = _Captured("train.grads")
             e.out = e.g_grads.capture(
                 (lambda: agent._train_phase_grads_a(e.static_in, w_arg)) if bucketed else
+                (lambda: agent._train_phase_grads_a(e.static_in, w_arg, split=split))
+                if split is not None else
                 (lambda: agent._train_phase_grads(e.static_in, w_arg)))
-            if bucketed:
+            if bucketed or split is not None:
                 e.g_grads_b = _Captured("train.grads_b")
                 e.g_grads_b.capture(agent._train_phase_grads_b)
             # what the optimizer phase takes over from THIS entry's gradient phase besides
@@ -797,7 +835,7 @@ class GraphedTrain:
             if ring and not clone and weights is None and EARLY_TARGET != "0" and \
                     hasattr(agent, "_train_phase_target") and \
                     hasattr(agent, "_early_target_key"):
-                self._capture_early(e, bucketed)
+                self._capture_early(e, bucketed, split)
 
     def static_inputs(self, experience_like=None):
         """Static input nest of the (single) captured signature, or None before capture."""

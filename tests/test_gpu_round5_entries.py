@@ -71,6 +71,32 @@ def test_early_target_forward_in_stream_order_is_bit_identical(dev, monkeypatch)
                        w2["agent"]._target_q_network.flat_params)
 
 
+def test_gradient_phase_split_in_front_of_the_first_layers_weight_gradient(dev, monkeypatch):
+    """AA_SPLIT_LAST_DW: the gradient phase as two graphs (everything down to the second layer |
+    the first layer's weight gradient), the early target forward of the next step started
+    between them: the same training, bit for bit, slabs of all three conv layers kept."""
+    monkeypatch.setattr(dqn_agent, "SPLIT_LAST_DW", False)
+    w1, _, vals1 = _loop(dev, 16)
+    g1 = graph.graphed_train(w1["agent"])
+    monkeypatch.setattr(dqn_agent, "SPLIT_LAST_DW", True)
+    w2, _, vals2 = _loop(dev, 16)
+    g2 = graph.graphed_train(w2["agent"])
+    ents = [e for b in g2._cache.values() for e in b.values()]
+    assert any(e.split_last for e in ents), "no entry was recorded in two halves"
+    assert not any(e.split_last for b in g1._cache.values() for e in b.values())
+    split = [e for e in ents if e.split_last]
+    n_kept = {e.apply_state[0].n for b in g1._cache.values() for e in b.values()
+              if e.apply_state is not None}
+    assert n_kept and all(e.apply_state is not None and {e.apply_state[0].n} == n_kept
+                          for e in split), \
+        "the optimizer does not get the slabs the unsplit backward leaves"
+    assert g1.early_hits > 4 and g2.early_hits > 4
+    assert vals1 == vals2
+    assert torch.equal(w1["net"].flat_params, w2["net"].flat_params)
+    assert torch.equal(w1["agent"]._target_q_network.flat_params,
+                       w2["agent"]._target_q_network.flat_params)
+
+
 def test_actions_selected_by_the_head_launch_equal_the_select_launch(dev, monkeypatch):
     """aa_dense_small_forward_slabs_eps: the Q head's launch draws the epsilon-greedy actions of its
     own Q values -- bit-identical to head launch + aa_eps_greedy_action, with and without an action
