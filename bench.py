@@ -122,8 +122,8 @@ def compact_line(out):
     line["config"] = cfg
     if "learner_steps_per_sec" in out:
         line["learner_steps_per_sec"] = out["learner_steps_per_sec"]
-    for k in ("env_steps_per_sec", "host_enqueue_ms_per_step",
-              "prime_steps", "captures_in_timed_region", "final_loss", "step_algorithmic_gflop",
+    for k in ("env_steps_per_sec", "host_enqueue_ms_per_step", "host_wait_ms_per_step",
+              "host_work_ms_per_step", "prime_steps", "captures_in_timed_region", "final_loss", "step_algorithmic_gflop",
               "step_mfma_frac", "kernel_time_sum_ms", "steady_ms_per_step", "steady_steps",
               "rccl_ranks", "dominant_device_kernel", "lanes", "lane_probe"):
         if k in out:
@@ -1073,10 +1073,15 @@ def main():
     if hasattr(lrn.strategy, "reset_stats"):
         lrn.strategy.reset_stats()
     mark("loop.begin")
+    wait0 = getattr(collect_run, "wait_seconds", 0.0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss_info = step()
     t_enqueue = time.perf_counter() - t0     # host time to issue the steps (the GPU trails behind)
+    # ... of which the host WAITED for the GPU (the driver's step-count post of the previous
+    # collect step: the one point where the loop throttles the host).  enqueue - wait = host WORK;
+    # the loop is host-bound when that equals ms_per_step, GPU-bound when the wait is what fills it
+    t_wait = getattr(collect_run, "wait_seconds", 0.0) - wait0
     graph.join_lanes(dev)
     sync_all()
     dt = time.perf_counter() - t0
@@ -1208,6 +1213,8 @@ def main():
         "prime_steps": prime_steps, "prime_seconds": t_prime,
         "captures_in_timed_region": captures_in_timed_region,
         "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3,
+        "host_wait_ms_per_step": t_wait / args.steps * 1e3,
+        "host_work_ms_per_step": (t_enqueue - t_wait) / args.steps * 1e3,
         "learner_steps_per_sec": steps_per_sec,
         "env_steps_per_sec": steps_per_sec * args.envs * world,
         "replay_rows_gathered_per_sec": steps_per_sec * S * 2 * world,
