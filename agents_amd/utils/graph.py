@@ -296,7 +296,8 @@ def _capture_stream(device):
     return st
 
 
-_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) \
+    if os.environ.get("AA_RAW_STREAM", "0") == "1" else None     # opt-in: see _lib.stream_ptr
 _STREAM_OBJECTS = {}    # (device index, raw hipStream_t) -> torch.cuda.Stream
 
 
