@@ -368,9 +368,9 @@ import os as _os
 # torch.cuda.current_stream() (saves ~6-10 us of host time per DQN iteration).  OFF by default: with
 # it on, the full GPU suite in ONE process died twice in hipGraphLaunch at its 671st test
 # (tests/test_gpu_opt_slabs.py, which passes alone and behind any shorter prefix) and passed with it
-# off (tools/bisect_segv.sh, profiles/r05_y_*).  Cause not established -- the suspicion is that the
-# Python objects the slow path allocates are what triggers the cyclic GC that frees dead agents'
-# HIP graphs in a long process.
+# off (tools/bisect_segv.sh, profiles/r05_y_*).  What fits: the Python objects the slow path
+# allocates are what triggers the cyclic GC that frees dead agents' HIP graphs in a long process
+# (with a gc.collect() after every test module the suite passes with this on as well).
 _RAW_OK = _os.environ.get("AA_RAW_STREAM", "0") == "1"
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) if _RAW_OK else None
 _GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
