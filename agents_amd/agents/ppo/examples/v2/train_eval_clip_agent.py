@@ -51,7 +51,6 @@ def train_eval(
         env_name="HalfCheetah-v2",
         env_load_fn=suite_synthetic.load,
         random_seed=None,
-        # TODO(b/127576522): rename to policy_fc_layers.
         actor_fc_layers=(200, 100),
         value_fc_layers=(200, 100),
         use_rnns=False,
