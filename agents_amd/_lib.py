@@ -364,14 +364,14 @@ def check(rc, what):
 
 
 import os as _os
-# AA_RAW_STREAM=1 (opt-in): the current stream's handle from torch's C entry points instead of
-# torch.cuda.current_stream() (saves ~6-10 us of host time per DQN iteration).  OFF by default: with
-# it on, the full GPU suite in ONE process died twice in hipGraphLaunch at its 671st test
-# (tests/test_gpu_opt_slabs.py, which passes alone and behind any shorter prefix) and passed with it
-# off (tools/bisect_segv.sh, profiles/r05_y_*).  What fits: the Python objects the slow path
-# allocates are what triggers the cyclic GC that frees dead agents' HIP graphs in a long process
-# (with a gc.collect() after every test module the suite passes with this on as well).
-_RAW_OK = _os.environ.get("AA_RAW_STREAM", "0") == "1"
+# The current stream's handle from torch's C entry points instead of torch.cuda.current_stream()
+# (saves ~6-10 us of host time per DQN iteration; -1.8 % on the iteration, round 5).  Default ON
+# since round 6; AA_RAW_STREAM=0 is the A/B knob.  History: with this on, round 5's full GPU suite
+# died in hipGraphLaunch at its 671st test and the path was made opt-in; the dead agents of earlier
+# tests were then only released by the cyclic collector, which the slower path happened to trigger
+# more often.  Graphs are now released by reference count and destroyed on an idle device
+# (utils/graph.py: _GRAVEYARD; tests/test_gpu_lifetime.py).
+_RAW_OK = _os.environ.get("AA_RAW_STREAM", "1") != "0"
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) if _RAW_OK else None
 _GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
 

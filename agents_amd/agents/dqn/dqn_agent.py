@@ -188,7 +188,11 @@ class DqnAgent(tf_agent.TFAgent):
         return greedy, collect_policy
 
     def _get_target_updater(self, tau=1.0, period=1):
+        import weakref
+        me = weakref.ref(self)      # (the agent owns the updater: no cycle through the closure)
+
         def update():
+            self = me()
             self._target_writes += 1
             out = common.soft_variables_update(self._q_network.flat_params,
                                                self._target_q_network.flat_params, tau)

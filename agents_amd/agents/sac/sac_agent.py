@@ -209,7 +209,7 @@ class SacAgent(tf_agent.TFAgent):
         # device-resident call counter.
         self._loss_policy = SacPolicy(time_step_spec, action_spec, actor_network, training=False,
                                       seed=seed + 2)
-        self._update_target = common.Periodically(self._soft_update_targets,
+        self._update_target = common.Periodically(common.weak_method(self._soft_update_targets),
                                                   self._target_update_period, "update_targets")
         super().__init__(time_step_spec, action_spec, policy=policy, collect_policy=policy,
                          train_sequence_length=2, debug_summaries=debug_summaries,

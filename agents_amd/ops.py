@@ -42,6 +42,11 @@ class _Workspace:
             self._buf[key] = buf
         return buf
 
+    def release(self, tag):
+        """Drops the buffers of scope `tag` (its owner's graphs are gone or parked for good)."""
+        for key in [k for k in self._buf if k[2] == tag]:
+            del self._buf[key]
+
     def reserve(self, tag, device):
         """Gives scope `tag` its own buffer, as large as the main line's current one."""
         main = self._buf.get((device.type, device.index, None, None))
@@ -83,6 +88,13 @@ class workspace_scope:
         global _SCOPE
         _SCOPE = self._prev
         return False
+
+
+def release_scope(tag):
+    """Forgets the scratch of a `workspace_scope` whose owner is going away (utils/graph.py:
+    scopes are named after `id(owner)`, which the interpreter hands out again)."""
+    for ws in (_WS, _WS2, _WS3):
+        ws.release(tag)
 
 
 class SideStream(torch.cuda.Stream):

@@ -13,7 +13,11 @@ Behaviour contract taken from the reference:
 class IntervalTrigger:
     def __init__(self, interval, fn, start=0):
         self._every = interval
-        self._callback = fn
+        # a bound method of the trigger itself (the subclasses in triggers.py) is kept as the plain
+        # function: trigger -> bound method -> trigger would be a reference cycle that keeps the
+        # checkpointed agent alive until the cyclic collector runs
+        self._callback_is_own = getattr(fn, "__self__", None) is self
+        self._callback = fn.__func__ if self._callback_is_own else fn
         self._start0 = start
         self._fired_at = start
 
@@ -29,7 +33,10 @@ class IntervalTrigger:
     def __call__(self, value, force_trigger=False):
         if self.enabled and self._due(value, force_trigger):
             self._fired_at = value
-            self._callback()
+            if self._callback_is_own:
+                self._callback(self)
+            else:
+                self._callback()
 
     def reset(self):
         self._fired_at = self._start0

@@ -137,6 +137,19 @@ def soft_variables_update(source_variables, target_variables, tau=1.0, tau_non_t
                                           _lib.stream_ptr()), "aa_soft_update")
 
 
+def weak_method(bound):
+    """`bound` (a bound method) as a callable that does not keep its object alive: for callbacks an
+    object stores on ITSELF (agent._update_target = Periodically(agent._soft_update...)), where the
+    bound method would close a reference cycle and leave the object -- with its device memory and
+    HIP graphs -- to the cyclic collector."""
+    import weakref
+    ref = weakref.WeakMethod(bound)
+
+    def call(*args, **kwargs):
+        return ref()(*args, **kwargs)
+    return call
+
+
 class Periodically:
     """Runs `body` every `period` calls (common.py:450-507): period None -> never, 1 -> always,
     else when the call count is a positive multiple of period."""

@@ -20,7 +20,9 @@ with `on_replay`, which runs them before every replay.
 import contextlib
 import gc
 import os
+import sys
 import time
+import weakref
 
 import torch
 
@@ -49,6 +51,24 @@ def on_replay(fn):
     every replay of that graph (capture itself executes nothing, so it is not run now)."""
     if _CAPTURE is None:
         fn()
+        return
+    obj, func = getattr(fn, "__self__", None), getattr(fn, "__func__", None)
+    if obj is not None and func is not None:
+        # A bound method is kept as (weak object, function): the hook advances a HOST mirror of
+        # `obj`; a graph recorded for an agent must not keep that agent alive through
+        # `agent._bump_counter` (agent -> graphs -> hook -> agent is a cycle only the collector
+        # frees).  What a graph touches on the DEVICE is kept alive by the graph's owner.
+        try:
+            ref = weakref.ref(obj)
+        except TypeError:
+            _CAPTURE.hooks.append(fn)
+            return
+
+        def hook(ref=ref, func=func):
+            o = ref()
+            if o is not None:
+                func(o)
+        _CAPTURE.hooks.append(hook)
     else:
         _CAPTURE.hooks.append(fn)
 
@@ -239,6 +259,10 @@ _BATCH_DEPTH = 0
 _CAPTURE_STREAM = {}
 
 
+def _finalizing():
+    return sys.is_finalizing()
+
+
 def capture_count():
     """Number of HIP-graph captures this module has recorded.  A caller that wants its timed
     region free of captures runs its loop until this stops changing (bench.py's priming)."""
@@ -258,7 +282,10 @@ def capture_batch():
     was = False
     if outer:
         torch.cuda.synchronize()
+        # (kept: objects of the CALLER's cycles that own device memory or graphs -- this module's
+        # own objects no longer need the collector to be released)
         gc.collect()
+        release_dead(synchronize=False)
         was = gc.isenabled()
         gc.disable()
     _BATCH_DEPTH += 1
@@ -297,7 +324,7 @@ def _capture_stream(device):
 
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) \
-    if os.environ.get("AA_RAW_STREAM", "0") == "1" else None     # opt-in: see _lib.stream_ptr
+    if os.environ.get("AA_RAW_STREAM", "1") != "0" else None     # A/B knob: see _lib.stream_ptr
 _STREAM_OBJECTS = {}    # (device index, raw hipStream_t) -> torch.cuda.Stream
 
 
@@ -327,6 +354,45 @@ def _mark(tag, stream=None):
         TIMELINE.append((tag, ev))
 
 
+# ---- lifetime of the recorded graphs ------------------------------------------------------------
+# A `_Captured` is owned by exactly one Graphed* object, which is owned by its agent / driver /
+# dataset iterator; the back-pointers (GraphedTrain -> agent, GraphedDriverRun -> driver) are weak,
+# so dropping the owner releases its graphs by reference count -- no cyclic collection involved.
+# The hipGraphExec itself is NOT destroyed at that moment: `close()` parks the torch CUDAGraph in
+# `_GRAVEYARD` (a finaliser may run anywhere -- in the middle of somebody else's stream capture,
+# where a HIP call is illegal, or while the last replay is still executing on the device) and the
+# graveyard is emptied at the next point where this module knows the device to be idle: the start
+# of a capture batch, `release_dead()`, or -- so that a process that only drops agents cannot pile
+# them up -- as soon as `_GRAVEYARD_MAX` graphs wait, behind a device synchronisation of its own.
+_GRAVEYARD = []
+_GRAVEYARD_MAX = 32
+_LIVE_GRAPHS = 0        # recorded and not yet closed (tests/test_gpu_lifetime.py watches it)
+
+
+def live_graphs():
+    """(recorded graphs not yet closed, closed graphs waiting for an idle device)."""
+    return _LIVE_GRAPHS, len(_GRAVEYARD)
+
+
+def release_dead(synchronize=True):
+    """Destroys the hipGraphExecs of closed graphs.  With `synchronize` the device is made idle
+    first (what a caller outside this module wants); capture_batch() passes False right after its
+    own synchronisation.  A no-op while a capture is being recorded."""
+    if not _GRAVEYARD or _CAPTURE is not None:
+        return 0
+    if synchronize:
+        torch.cuda.synchronize()
+    dead = _GRAVEYARD[:]
+    del _GRAVEYARD[:len(dead)]
+    n = len(dead)
+    del dead            # CUDAGraph.__del__ -> hipGraphExecDestroy, its private pool is released
+    # ... to the caching allocator's list of freeable pools, which only an out-of-memory retry or
+    # empty_cache() returns to the device: without this a process that builds and drops agents
+    # grows by a 20 MiB segment per recorded graph (tools/lifetime_probe.py)
+    torch.cuda.empty_cache()
+    return n
+
+
 class _Captured:
     """A torch CUDAGraph plus the host hooks registered while it was captured."""
 
@@ -335,6 +401,25 @@ class _Captured:
         self.hooks = []
         self.out = None
         self.kind = kind
+
+    def close(self):
+        """Gives up the graph (see `_GRAVEYARD`) and everything its hooks keep alive."""
+        global _LIVE_GRAPHS
+        g, self.graph = self.graph, None
+        self.hooks = []
+        self.out = None
+        if g is not None:
+            _LIVE_GRAPHS -= 1
+            _GRAVEYARD.append(g)
+            if len(_GRAVEYARD) >= _GRAVEYARD_MAX and _BATCH_DEPTH == 0 and _CAPTURE is None \
+                    and not _finalizing():
+                release_dead()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown
+            pass
 
     def capture(self, fn):
         """Records `fn()`.  torch.cuda.graph() is not used: its __enter__ synchronises the device
@@ -358,6 +443,8 @@ class _Captured:
             finally:
                 _CAPTURE = None
         _CAPTURES += 1
+        global _LIVE_GRAPHS
+        _LIVE_GRAPHS += 1
         self.graph = g
         self.hooks = ctx.hooks
         return self.out
@@ -399,6 +486,16 @@ class _Entry:
         # all-reduce stale gradients -- such a call takes the eager path instead
         self.cap_key = None
 
+    def close(self):
+        for name in ("g_grads", "g_apply", "g_grads_b", "captured", "captured_b", "g_target",
+                     "g_grads_nt"):
+            c = getattr(self, name)
+            if c is not None:
+                c.close()
+                setattr(self, name, None)
+        self.static_in = self.static_w = self.out = None
+        self.apply_state = self.apply_state_nt = None
+
 
 def _sig(experience, weights):
     leaves = nest_utils.flatten(experience)
@@ -433,10 +530,7 @@ class GraphedTrain:
     time (somebody else's static buffers, e.g. PPOLearner's minibatch) gets its own graph."""
 
     def __init__(self, agent):
-        self._agent = agent
-        # the class's own method: `tf_agent.train = common.function(tf_agent.train)` (the PPO and
-        # SAC scripts) rebinds the INSTANCE attribute to this object
-        self._eager_train = type(agent).train.__get__(agent)
+        self._agent = agent    # (a weak reference: see the property)
         self._cache = {}       # signature -> {input address tuple | None: _Entry}
         self._warm = {}
         self._seen = {}
@@ -458,9 +552,61 @@ class GraphedTrain:
         self.early_hits = 0
         self.early_issued = 0
 
+    # The agent owns this object (`agent._graphed_train`, and `agent.train` itself where a script
+    # rebinds it: `tf_agent.train = common.function(tf_agent.train)`); the pointer back is weak, so
+    # agent and graphs are released by reference count the moment the agent is dropped.
+    @property
+    def _agent(self):
+        a = self._agent_ref()
+        if a is None:
+            raise ReferenceError(
+                "the agent of this graphed train function has been released; keep a reference to "
+                "the agent for as long as the function returned by common.function(agent.train) "
+                "is used")
+        return a
+
+    @_agent.setter
+    def _agent(self, agent):
+        try:
+            self._agent_ref = weakref.ref(agent)
+        except TypeError:            # not weakly referencable (a stand-in in a test)
+            self._agent_ref = lambda: agent
+
     @property
     def agent(self):
         return self._agent
+
+    def _eager_train(self, experience, weights=None, **kwargs):
+        # the class's own method: `tf_agent.train = common.function(tf_agent.train)` (the PPO and
+        # SAC scripts) rebinds the INSTANCE attribute to this object
+        agent = self._agent
+        return type(agent).train(agent, experience, weights=weights, **kwargs)
+
+    def close(self):
+        """Releases every recorded graph, their static inputs and the scratch of the early target
+        forward.  Called when the agent goes away (weakref.finalize in `graphed_train`) and by
+        `__del__`; the object falls back to recording again if it is called afterwards."""
+        for bound in self._cache.values():
+            for e in bound.values():
+                e.close()
+        for e in list(self._succ) + list(self._succ.values()):
+            e.close()
+        self._cache.clear()
+        self._fast.clear()
+        self._succ.clear()
+        self._seen.clear()
+        self._prev_entry = None
+        self._early = None
+        if self._early_sized:
+            from agents_amd import ops
+            ops.release_scope(("early_target", id(self)))
+            self._early_sized = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown
+            pass
 
     def _entry_for(self, sig, ptrs, experience, weights, dev):
         bound = self._cache.setdefault(sig, {})
@@ -848,7 +994,8 @@ class GraphedTrain:
 
 
 def graphed_train(agent):
-    """One GraphedTrain per agent (shared by common.function and the Learner)."""
+    """One GraphedTrain per agent (shared by common.function and the Learner).  The agent owns it;
+    it points back weakly."""
     g = getattr(agent, "_graphed_train", None)
     if g is None:
         g = GraphedTrain(agent)
@@ -898,15 +1045,28 @@ class GraphedSampler:
         for exp in self.ring_experiences():
             _RING_OWNER[nest_utils.flatten(exp)[0].data_ptr()] = self._ref
 
-    def __del__(self):
+    def close(self):
+        """Releases the ring's graphs and output buffers and what the module keeps per slot."""
         # only OUR registrations: the addresses may have been reused by a younger ring since
+        ref = getattr(self, "_ref", None)
+        for c in self._ring:
+            if c is None:
+                continue
+            if c.out is not None:
+                p0 = nest_utils.flatten(c.out[0])[0].data_ptr()
+                if ref is not None and _RING_OWNER.get(p0) is ref:
+                    del _RING_OWNER[p0]
+                    for lanes in list(_LANES.values()) + list(_LANES_PARKED.values()):
+                        lanes.ready.pop(p0, None)
+                        lanes.ready_seq.pop(p0, None)
+            c.close()
+        self._ring = [None] * len(self._ring)
+        self._stamped = None
+        self._warm = 0
+
+    def __del__(self):
         try:
-            ref = getattr(self, "_ref", None)
-            for c in self._ring:
-                if c is not None and c.out is not None:
-                    p0 = nest_utils.flatten(c.out[0])[0].data_ptr()
-                    if ref is not None and _RING_OWNER.get(p0) is ref:
-                        del _RING_OWNER[p0]
+            self.close()
         except Exception:      # interpreter shutdown
             pass
 
@@ -987,8 +1147,7 @@ class GraphedDriverRun:
     tracing.  Otherwise every call falls through to the eager `driver.run`."""
 
     def __init__(self, driver):
-        self._driver = driver
-        self._eager_run = driver.run          # bound method, captured before any patching
+        self._driver_ref = weakref.ref(driver)    # the driver owns this object (`_graphed_run`)
         self._graphs = {}
         self._warm = 0
         self._seq = 0                          # mailbox posts issued so far
@@ -1002,13 +1161,47 @@ class GraphedDriverRun:
         self.enabled = hasattr(driver.env, "graph_ring") and not driver._transition_observers
         self.replays = 0
 
-    def __del__(self):
-        # Back to the free list, NOT hipHostFree: the collector can run this at any point,
-        # including in the middle of another object's stream capture, where a synchronising HIP
-        # call would invalidate the capture (seen as an intermittent crash in the test suite).
+    @property
+    def _driver(self):
+        d = self._driver_ref()
+        if d is None:
+            raise ReferenceError(
+                "the driver of this graphed run function has been released; keep a reference to "
+                "the driver for as long as the function returned by common.function(driver.run) "
+                "is used")
+        return d
+
+    def _eager_run(self, time_step=None, policy_state=None, maximum_iterations=None):
+        # the class's own method: `collect_driver.run = common.function(collect_driver.run)`
+        # (train_eval.py:234-237) rebinds the INSTANCE attribute to this object
+        drv = self._driver
+        return type(drv).run(drv, time_step, policy_state, maximum_iterations)
+
+    def close(self):
+        """Releases the recorded loop bodies (see `_GRAVEYARD`), their scratch and the mailbox."""
+        graphs, self._graphs = self._graphs, {}
+        for c in graphs.values():
+            c.close()
+        if graphs:
+            from agents_amd import ops
+            ops.release_scope(("collect", id(self)))
+        # Back to the free list, NOT hipHostFree: a finaliser can run at any point, including in
+        # the middle of another object's stream capture, where a synchronising HIP call would
+        # invalidate the capture (seen as an intermittent crash in the test suite).  The next owner
+        # synchronises before it resets the words (`_setup`): the bodies parked in the graveyard
+        # are never replayed again, and the last replay in flight has finished by then.
         if self._mbox_host is not None:
             _FREE_MAILBOXES.append((self._mbox_host, self._mbox_dev))
             self._mbox_host = None
+        self._total = self._counter = None
+        self._pub = None
+        self._seq = self._t_counted = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown
+            pass
 
     def _setup(self, dev, B):
         import ctypes

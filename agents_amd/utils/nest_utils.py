@@ -43,18 +43,21 @@ def _rebuild(structure, children):
     return type(structure)(children)
 
 
+def _pack(s, flat, pos):
+    if not is_nested(s):
+        v = flat[pos[0]]
+        pos[0] += 1
+        return v
+    return _rebuild(s, [_pack(c, flat, pos) for c in _children(s)])
+
+
 def pack_sequence_as(structure, flat):
+    # (module-level recursion: a local `def rec` that calls itself is a reference cycle through
+    # its own closure cell, and these cycles held the device tensors of every packed nest until
+    # the cyclic collector ran -- tools/lifetime_probe.py)
     flat = list(flat)
     pos = [0]
-
-    def rec(s):
-        if not is_nested(s):
-            v = flat[pos[0]]
-            pos[0] += 1
-            return v
-        return _rebuild(s, [rec(c) for c in _children(s)])
-
-    out = rec(structure)
+    out = _pack(structure, flat, pos)
     if pos[0] != len(flat):
         raise ValueError(f"pack_sequence_as: structure has {pos[0]} leaves, got {len(flat)}")
     return out
@@ -70,35 +73,38 @@ def map_structure(fn, *structures):
     return _rebuild(first, [map_structure(fn, *cs) for cs in zip(*kids)])
 
 
+def _mismatch(x, y):
+    """None if the nests agree in structure, else the reason of the first difference."""
+    if is_nested(x) != is_nested(y):
+        return "one is a leaf, the other a sequence"
+    if not is_nested(x):
+        return None
+    if isinstance(x, dict) != isinstance(y, dict):
+        return "dict vs non-dict"
+    if isinstance(x, dict):
+        if sorted(x) != sorted(y):
+            return f"dict keys differ {sorted(x)} vs {sorted(y)}"
+    else:
+        if _is_namedtuple(x) != _is_namedtuple(y):
+            return "namedtuple vs plain sequence"
+        if _is_namedtuple(x) and type(x).__name__ != type(y).__name__:
+            return f"namedtuple types differ {type(x).__name__} vs {type(y).__name__}"
+        if len(x) != len(y):
+            return f"lengths differ {len(x)} vs {len(y)}"
+    for cx, cy in zip(_children(x), _children(y)):
+        why = _mismatch(cx, cy)
+        if why is not None:
+            return why
+    return None
+
+
 def assert_same_structure(a, b, message=None):
     """Raises ValueError if the two nests differ in structure (types of sequences, dict keys)."""
-
-    def fail(why):
+    why = _mismatch(a, b)
+    if why is not None:
         raise ValueError((message + ": " if message else "") +
                          f"The two structures do not match: {why}.\nFirst: {_brief(a)}\n"
                          f"Second: {_brief(b)}")
-
-    def rec(x, y):
-        if is_nested(x) != is_nested(y):
-            fail("one is a leaf, the other a sequence")
-        if not is_nested(x):
-            return
-        if isinstance(x, dict) != isinstance(y, dict):
-            fail("dict vs non-dict")
-        if isinstance(x, dict):
-            if sorted(x) != sorted(y):
-                fail(f"dict keys differ {sorted(x)} vs {sorted(y)}")
-        else:
-            if _is_namedtuple(x) != _is_namedtuple(y):
-                fail("namedtuple vs plain sequence")
-            if _is_namedtuple(x) and type(x).__name__ != type(y).__name__:
-                fail(f"namedtuple types differ {type(x).__name__} vs {type(y).__name__}")
-            if len(x) != len(y):
-                fail(f"lengths differ {len(x)} vs {len(y)}")
-        for cx, cy in zip(_children(x), _children(y)):
-            rec(cx, cy)
-
-    rec(a, b)
 
 
 def _brief(x):

@@ -37,18 +37,3 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     return torch.device("cuda", 0)
-
-
-@pytest.fixture(autouse=True, scope="module")
-def _release_dead_gpu_objects():
-    """After each test module: collect reference cycles, so that the HIP graphs, streams and buffers
-    of its agents are released before the next module records its own (round 5: the whole GPU
-    suite in one process died in hipGraphLaunch at its 671st test with a host path that allocated
-    fewer Python objects -- i.e. ran the cyclic GC less often -- and passed without it)."""
-    yield
-    import gc
-    if "torch" in sys.modules:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-    gc.collect()

@@ -48,6 +48,9 @@ class _Graph:
     def replay(self):
         self.replays += 1
 
+    def close(self):
+        pass
+
 
 class _Agent:
     """What GraphedTrain needs from an agent to consider early target forwards."""
@@ -82,7 +85,8 @@ def _entry(ptr0, with_target=True):
 def gt(monkeypatch):
     monkeypatch.setattr(graph.torch.cuda, "set_stream", lambda s: None)
     monkeypatch.setattr(graph, "EARLY_TARGET", "side")
-    return graph.GraphedTrain(_Agent())
+    agent = _Agent()      # the agent owns its GraphedTrain; the pointer back is weak
+    yield graph.GraphedTrain(agent)
 
 
 def test_successor_is_learned_and_forward_is_issued_behind_its_dependencies(gt):
