@@ -345,7 +345,11 @@ class DqnAgent(tf_agent.TFAgent):
         self.reduced_owns_storage = False
         packed = getattr(self, "_packed", None)
         if packed is not None and td is packed[0].td_loss and extra.td_error is packed[0].td_error \
+                and packed[2] + 1 == int(self._train_step_counter) \
                 and not self._q_network.has_regularization:
+            # (the step tag: only the eager optimizer phase refreshes `_packed`; a step whose
+            # optimizer phase REPLAYED from its graph must not be answered with an older step's
+            # sums -- the work-buffer branch below serves it)
             # the optimizer launch of this step already copied the three sums into storage of
             # their own (`_train_phase_apply`): nothing left to launch
             v = packed[1].unbind(0)
@@ -512,7 +516,7 @@ class DqnAgent(tf_agent.TFAgent):
                     src = w._pack_src = (ctypes.c_void_p * 3)(
                         w.loss.data_ptr(), w.field_sums.data_ptr(), w.field_sums.data_ptr() + 4)
                 pack = (src, vec)
-                self._packed = (w, vec)
+                self._packed = (w, vec, int(self._train_step_counter))
             self._optimizer.apply_flat(net.flat_params, net.flat_grads, planes=planes,
                                        grad_slabs=slabs, **({"pack": pack} if pack else {}))
             if planes is None:

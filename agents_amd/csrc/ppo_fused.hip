@@ -71,7 +71,8 @@ static long long* g_pf_stamps = nullptr;
   if (P.stamps != nullptr && threadIdx.x == 0)                                   \
     P.stamps[(size_t)blockIdx.x * 32 + (i)] = wall_clock64();
 
-// Dynamic LDS image of a workgroup (one per CU: 89 KB).
+// Dynamic LDS image of a workgroup (one per CU: ~156 KB of gfx950's 160 KB -- the static_assert
+// behind the struct is the guard; a new field or a larger PF_MD must fit under it).
 struct PfLds {
   // Round 5: EVERY layer's weights of both groups are resident (104 KB; 160 KB in all): they are
   // requested at kernel start, land during the prologue and are committed once -- a layer step is
@@ -92,6 +93,7 @@ struct PfLds {
   float dbias[PF_TS][PF_MD];
   float scale[PF_MD], logs[PF_MD], dsp[PF_MD];
 };
+static_assert(sizeof(PfLds) <= 160 * 1024, "PfLds must fit the 160 KB of LDS a gfx950 CU has");
 
 __device__ static inline float pf_softplus(float x) {
   return x > 0.f ? x + log1pf(expf(-x)) : log1pf(expf(x));
@@ -797,7 +799,7 @@ int aa_ppo_fused_epoch(const aa_ppo_fused_desc* dsc, const int64_t* rows_dev, in
   if (workspace_bytes < aa_ppo_fused_workspace_bytes(d.N, d.total)) return AA_ERR_RANGE;
   const int64_t n_wg = (d.N + PF_TS - 1) / PF_TS;
   if (n_wg > 0x7fffffffLL) return AA_ERR_RANGE;
-  // 89 KB of dynamic LDS: the attribute belongs to the CURRENT device's function object, so it
+  // sizeof(PfLds) of dynamic LDS (see the static_assert): the attribute belongs to the CURRENT device's function object, so it
   // is granted once per device ordinal (a process that steps agents on two GPUs needs it on both)
   static bool lds_granted[64] = {};
   int dev_ord = 0;

@@ -1137,6 +1137,11 @@ class Sequential(network.Network):
 
 
 # ---- wide MLPs: several networks of one layout per launch (csrc/mlp_wide.hip) ---------------------
+# Measurement aid (tools/bench_sac.py): set to a list and every forward_wide call appends
+# (networks, batch, layer widths) -- the per-launch work a roofline of the kernel is computed from.
+WIDE_FWD_LOG = None
+
+
 def _wide_group(nets, B):
     if not 1 <= len(nets) <= 4:
         raise ValueError("a wide-MLP launch takes 1..4 networks")
@@ -1195,6 +1200,8 @@ def forward_wide(nets, xs, slot=0, need_grad=False, x2s=None, slots=None, need_g
         for i in range(n):
             d.y[g][i] = s.ys[i].data_ptr()
         outs.append(s.ys[-1])
+    if WIDE_FWD_LOG is not None:
+        WIDE_FWD_LOG.append((len(nets), B, [int(lay.dims[i]) for i in range(n + 1)]))
     with torch.cuda.device(xs[0].device):
         _lib.check(_lib.load().aa_mlp_wide_forward(ctypes.byref(d), _lib.stream_ptr()),
                    "aa_mlp_wide_forward")

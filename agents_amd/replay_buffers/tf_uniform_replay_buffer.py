@@ -172,7 +172,10 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
         self._add_batch(items, count=(step_type, counter, total, mailbox))
 
     def supports_counting_add(self):
-        return type(self)._add_batch is TFUniformReplayBuffer._add_batch
+        # neither hook of the add path is overridden: a subclass that extends the PUBLIC
+        # `add_batch` (preprocessing, bookkeeping) must see every add of a graphed driver too
+        return type(self)._add_batch is TFUniformReplayBuffer._add_batch and \
+            type(self).add_batch is replay_buffer.ReplayBuffer.add_batch
 
     def _bump_last_id_host(self):
         self._last_id_host += 1

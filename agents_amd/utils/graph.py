@@ -546,7 +546,7 @@ class GraphedTrain:
         # early target forward (phase mode, overlap on, batches in sampler ring slots)
         self._succ = {}          # entry -> entry of the call that followed it (the ring is cyclic)
         self._prev_entry = None
-        self._early = None       # (entry, done event, agent._early_target_key(), draw number)
+        self._early = None       # (entry, done event, agent._early_target_key(), draw number, device)
         self._early_stream = None
         self._early_sized = False
         self.early_hits = 0
@@ -673,7 +673,11 @@ class GraphedTrain:
         network's activation slot -- whatever the agent's eager path joins or does not join."""
         early, self._early = self._early, None
         if early is not None and not capturing():
-            torch.cuda.current_stream().wait_event(early[1])
+            # on the device the forward was issued on (an eager fall-back runs on the agent's
+            # device stream, which need not be the process's current device)
+            dev = early[4] if len(early) > 4 else None
+            (torch.cuda.current_stream(dev) if dev is not None
+             else torch.cuda.current_stream()).wait_event(early[1])
         return early
 
     def __call__(self, experience, weights=None, **kwargs):
@@ -897,7 +901,7 @@ class GraphedTrain:
             done = lanes.event_on(st)
             _mark("early_target.done", st)
         lanes.aux_done = done
-        self._early = (nxt, done, self._agent._early_target_key(), seq)
+        self._early = (nxt, done, self._agent._early_target_key(), seq, dev)
         self.early_issued += 1
 
     def _capture_early(self, e, bucketed, split=None):

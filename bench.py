@@ -37,6 +37,8 @@ PRIME_MIN = 0                  # minimum untimed iterations in front of --warmup
 CPU_RING_FRAMES = 256          # replay frames per env of the cpu_baseline leg (see cpu_baseline)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 PMC_FILE = os.path.join("profiles", "r05_pmc.json")   # committed rocprofv3 --pmc passes (isolated)
+PMC_OTHER_FILE = os.path.join("profiles", "r06_pmc_other.json")   # ... of the PPO / SAC kernels
+L2_PEAK_GBS = 34500.0          # MI355X_MICROARCH.md: L2 aggregate (8 XCDs x 4 MiB), ~34.5 TB/s
 # Set in the child of the in-loop profiling pass (see inloop_profile): the run brackets its timed
 # region and every isolated kernel case with aa_marker launches and reports their labels in order.
 TRACE_CHILD = os.environ.get("AA_BENCH_TRACE_CHILD") == "1"
@@ -96,12 +98,20 @@ def _compact_other(o):
         return {"error": str((o or {}).get("error", "missing"))[:160]}
     c = {"value": _r(o.get("value")), "unit": o.get("unit"), "ms_per_step": _r(o.get("ms_per_step")),
          "steps": o.get("steps")}
-    for k in ("train_minibatch_steps_per_sec", "collect_env_steps_per_sec", "env_steps_per_sec"):
+    for k in ("train_minibatch_steps_per_sec", "collect_env_steps_per_sec", "env_steps_per_sec",
+              "replay_rows_per_sec"):
         if k in o:
             c[k] = _r(o[k])
+    rows = (o.get("config") or {}).get("replay_rows_per_gpu")
+    if rows:
+        c["config"] = {"replay_rows_per_gpu": rows,
+                       "replay_bytes_per_gpu": (o.get("config") or {}).get("replay_bytes_per_gpu")}
     rf = o.get("roofline") or {}
     c["roofline"] = {k: _r(rf.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac",
-                                                "traffic", "avg_launch_ms")}
+                                                "traffic", "avg_launch_ms", "launches_per_step",
+                                                "algorithmic_bytes_per_launch",
+                                                "algorithmic_flop_per_launch", "duration_source")}
+    c["roofline"]["kernel"] = str(rf.get("kernel", ""))[:40]
     cb = o.get("cpu_baseline")
     if cb:
         c["cpu_baseline"] = {k: _r(cb.get(k)) for k in ("value", "unit", "cores", "kind")}
@@ -122,7 +132,7 @@ def compact_line(out):
     line["config"] = cfg
     if "learner_steps_per_sec" in out:
         line["learner_steps_per_sec"] = out["learner_steps_per_sec"]
-    for k in ("env_steps_per_sec", "host_enqueue_ms_per_step", "host_wait_ms_per_step",
+    for k in ("replay_rows_per_sec", "env_steps_per_sec", "host_enqueue_ms_per_step", "host_wait_ms_per_step",
               "host_work_ms_per_step", "prime_steps", "captures_in_timed_region", "final_loss", "step_algorithmic_gflop",
               "step_mfma_frac", "kernel_time_sum_ms", "steady_ms_per_step", "steady_steps",
               "rccl_ranks", "dominant_device_kernel", "lanes", "lane_probe"):
@@ -572,6 +582,75 @@ def inloop_profile(args, trace_out=None, timeout=420):
     return out
 
 
+def inloop_other(name, steps, timeout=300):
+    """`bench.py --config name` re-run under `rocprofv3 --kernel-trace` in a child process:
+    {kernel name: {launches_per_step, avg_us}} of its timed loop (between the child's loop.begin /
+    loop.end marker dispatches), or {"error": ...}."""
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return {"error": "rocprofv3 not found"}
+    tmp = tempfile.mkdtemp(prefix=f"aa_inloop_{name}_", dir="/tmp")
+    cmd = [prof, "--kernel-trace", "-d", tmp, "-o", "inloop", "--", sys.executable,
+           os.path.join(ROOT, "bench.py"), "--config", name, "--steps", str(steps),
+           "--no-cpu-baseline", "--no-inloop"]
+    env = dict(os.environ, AA_BENCH_TRACE_CHILD="1", TMPDIR="/tmp")
+    try:
+        r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True,
+                           timeout=timeout)
+    except subprocess.TimeoutExpired:
+        shutil.rmtree(tmp, ignore_errors=True)
+        return {"error": f"profiling pass exceeded {timeout}s"}
+    child = None
+    for line in reversed(r.stdout.strip().splitlines()):
+        if line.startswith("{") and "trace_child" in line:
+            child = json.loads(line)
+            break
+    try:
+        if r.returncode != 0 or child is None:
+            return {"error": f"profiling pass failed (rc {r.returncode}): {r.stderr[-400:]}"}
+        trace = _read_kernel_trace(tmp)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    marks = [i for i, k in enumerate(trace) if "aa_marker_kernel" in k[0]]
+    labels = child["marks"]
+    if len(marks) != len(labels) or "loop.begin" not in labels:
+        return {"error": f"{len(marks)} marker dispatches in the trace for {len(labels)} marks"}
+    i0, i1 = marks[labels.index("loop.begin")], marks[labels.index("loop.end")]
+    acc = {}
+    for kname, st, en in trace[i0 + 1:i1]:
+        e = acc.setdefault(kname, [0, 0])
+        e[0] += 1
+        e[1] += en - st
+    n = child["loop_steps"]
+    kernels = {k: {"launches_per_step": c / n, "avg_us": t / c / 1e3} for k, (c, t) in acc.items()}
+    return {"steps": n, "ms_per_step_under_profiler": child["ms_per_step"],
+            "kernel_time_sum_us_per_step": sum(t for c, t in acc.values()) / n / 1e3,
+            "launches_per_step": sum(c for c, t in acc.values()) / n,
+            "gpu_wall_us_per_step": (trace[i1][1] - trace[i0][2]) / n / 1e3, "kernels": kernels}
+
+
+def _write_kernel_table(path, kernels):
+    with open(path, "w") as fh:
+        fh.write("name,launches_per_step,avg_us,us_per_step\n")
+        for n, k in sorted(kernels.items(),
+                           key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches_per_step"]):
+            fh.write(f"\"{n}\",{k['launches_per_step']:.3f},{k['avg_us']:.3f},"
+                     f"{k['avg_us'] * k['launches_per_step']:.3f}\n")
+
+
+def _pmc_other(name):
+    """Counter record of a --config ppo / sac kernel from the committed --pmc passes
+    (profiles/r06_pmc_other.json, made by tools/profile_r06.sh), or {}."""
+    try:
+        with open(os.path.join(ROOT, PMC_OTHER_FILE)) as fh:
+            return json.load(fh).get(name, {})
+    except (OSError, ValueError):
+        return {}
+
+
 def run_other_config(name, steps, timeout=300):
     """`bench.py --config ppo|sac` in a child process: its JSON line (or {"error": ...})."""
     import subprocess
@@ -792,7 +871,10 @@ def main_prioritized(args):
 def main_other_config(args):
     """`--config ppo` / `--config sac`: BASELINE.json configs[2] and configs[4] at one GPU -- parity
     configurations, measured for the record with the same JSON contract (the graded metric is the
-    DQN line).  A "step" is one iteration of the config's train_eval loop."""
+    DQN line).  A "step" is one iteration of the config's train_eval loop.  `roofline` is the
+    DOMINANT KERNEL of the loop with its duration INSIDE the loop (a rocprofv3 --kernel-trace child
+    pass, like the DQN line's), algorithmic flop and bytes per launch, and the counter traffic of
+    the committed --pmc pass."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     # `--gpus N`: one process per GPU, weak scaling like the DQN line (per-rank environments and
     # replay shard, gradients SUM all-reduced per train step through the Learner's strategy);
@@ -801,19 +883,64 @@ def main_other_config(args):
     from agents_amd import _lib
     _lib.load()
     par = "single" if world == 1 else f"dp{world}"
+    want_inloop = not args.no_inloop and not TRACE_CHILD and world == 1
     if args.config == "ppo":
         import bench_ppo
         a = argparse.Namespace(envs=2048, steps=128, minibatch=4096, epochs=10,
-                               iters=max(args.steps, 1) if args.steps_given else 3)
+                               iters=max(args.steps, 1) if args.steps_given else 3,
+                               mark=mark if TRACE_CHILD else None)
         r = bench_ppo.run(a, dev=dev, rank=rank, world=world)
         r.pop("agent")
         it_s = r["iteration_s"]
         n_mb = r["minibatch_steps_per_iteration"]
+        if TRACE_CHILD:
+            print(json.dumps({"trace_child": True, "marks": MARKS, "loop_steps": a.iters,
+                              "ms_per_step": it_s * 1e3}), flush=True)
+            return
         # actor + value MLPs (17-64-64-6, 17-64-64-1): forward + backward = 6 flop per weight
-        # and frame; one minibatch step also gathers 4,096 rows of 10 leaves (172 B) twice
+        # and frame
         weights = (17 * 64 + 64 * 64 + 64 * 6) + (17 * 64 + 64 * 64 + 64 * 1)
         flop = 6.0 * weights * 4096
+        # K1 (aa_ppo_fused_step_kernel) per launch: gathers 4,096 rows of 10 leaves (172 B: obs
+        # 17, action 6, old loc / scale 6 + 6, return, advantage, weight, step type ...), reads
+        # the parameters once per workgroup (from L2), writes one gradient slab per workgroup of
+        # 16 frames (256 slabs x total_params x 4 B) -- the slabs are the traffic
+        total = r.get("total_params", 11085)
+        n_wg = 4096 // 16
+        k1_bytes = 4096 * 172 + n_wg * total * 4 + total * 4
         mb_ms = r["train_s_per_iteration"] / n_mb * 1e3
+        il = inloop_other("ppo", 2) if want_inloop else None
+        k1 = None
+        if il and "error" not in il:
+            k1 = next((v for k, v in il["kernels"].items() if "aa_ppo_fused_step_kernel" in k), None)
+            if args.trace_out:
+                _write_kernel_table(args.trace_out, il["kernels"])
+        elif il:
+            log(f"[bench] ppo in-loop pass failed: {il['error']}")
+        pmc = _pmc_other("ppo_fused_step")
+        k1_ms = k1["avg_us"] / 1e3 if k1 else None
+        roof = {"kernel": "aa_ppo_fused_step_kernel (K1 of the 3-launch minibatch step: row "
+                          "gather, both (64,64) MLPs forward + backward, loss; csrc/ppo_fused.hip)",
+                "bound": "hbm",
+                "achieved": k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms else None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": k1_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k1_ms else None,
+                "traffic": pmc.get("bytes_per_launch"),
+                "traffic_source": PMC_OTHER_FILE if pmc else None,
+                "avg_launch_ms": k1_ms,
+                "launches_per_step": k1["launches_per_step"] if k1 else None,
+                "duration_source": "in-loop rocprofv3" if k1 else "unmeasured (no profiler pass)",
+                "algorithmic_bytes_per_launch": k1_bytes, "algorithmic_flop_per_launch": flop,
+                "flop_frac_of_fp32_mfma_peak": (flop / (k1_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS
+                                                if k1_ms else None),
+                "mfma_busy": pmc.get("mfma_busy"),
+                "minibatch_step_us": mb_ms * 1e3,
+                "note": "launch / latency bound, as SURVEY.md 8(d) says of the (64,64) MLPs: 0.27 "
+                        "GFLOP and 12 MB per launch are 2 us of either pipe; the launch is "
+                        "staging + 6 layer steps behind barriers + the slab store (in-kernel "
+                        "timeline: DESIGN.md).  The minibatch step is K1 + reduce + apply = "
+                        "minibatch_step_us; that figure, not frac, is what the config is "
+                        "judged by"}
         out = {"metric": "PPO frames trained per second (minibatch steps/s x 4096), configs[2] "
                          "HalfCheetah-shaped", "value": r["train_frames_per_sec"],
                "unit": "frames/s", "n_gpus": world, "steps": a.iters, "warmup": 1,
@@ -825,20 +952,8 @@ def main_other_config(args):
                "rccl_ranks": world, "collectives": r.get("collectives"),
                "collect_env_steps_per_sec": r["collect_env_steps_per_sec"],
                "train_minibatch_steps_per_sec": r["train_minibatch_steps_per_sec"],
-               "roofline": {"kernel": "PPOClipAgent.train minibatch step: 3 launches "
-                                      "(aa_ppo_fused_step / _reduce / _apply: row gather, both MLPs "
-                                      "forward + backward, loss, clip, Adam; csrc/ppo_fused.hip), "
-                                      "a whole epoch of them per host call", "bound": "mfma",
-                            "achieved": flop / mb_ms / 1e9, "peak": MFMA_F32_PEAK_TFLOPS,
-                            "unit": "TFLOP/s", "frac": flop / mb_ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
-                            "traffic": None, "algorithmic_flop_per_launch": flop,
-                            "avg_launch_ms": mb_ms,
-                            "note": "a 64-wide MLP on 4,096 frames is 0.27 GFLOP per step; K1 "
-                                    "runs every layer padded to 64x64 on v_mfma_f32_16x16x4_f32 "
-                                    "out of LDS (17-wide inputs and 6-/1-wide heads multiply "
-                                    "zeros), so frac counts algorithmic flop only; the step is "
-                                    "bound by staging, barriers and launch latency, not the "
-                                    "matrix pipe (in-kernel timeline: DESIGN.md)"}}
+               "replay_rows_per_sec": world * 2048 * 129 / it_s,   # gather_all rows per iteration
+               "roofline": roof, "inloop": il}
         if not args.no_cpu_baseline and rank == 0 and world == 1:
             th, ncpu, cands = _best_threads(lambda n, t: bench_ppo.cpu_baseline(4096, n, t))
             sps = bench_ppo.cpu_baseline(4096, 200, th)
@@ -850,42 +965,75 @@ def main_other_config(args):
                                              f"(fastest of {cands})"}
     else:
         import bench_sac
-        a = argparse.Namespace(envs=4096, max_length=64, batch=256,
-                               iters=args.steps if args.steps_given else 200)
+        a = argparse.Namespace(envs=4096, max_length=args.sac_max_length, batch=256,
+                               iters=args.steps if args.steps_given else 200,
+                               mark=mark if TRACE_CHILD else None)
         r = bench_sac.run(a, dev=dev, rank=rank, world=world)
         dt = r["ms_per_iteration"]
-        O, A, H = 376, 17, 256
-        actor = O * H + H * H + H * 2 * A
-        critic = (O + A) * H + H * H + H
-        # critic phase: 2 target + 2 online critics fwd, 2 bwd, actor fwd (next); actor phase: actor
-        # fwd + bwd, 2 critics fwd + input-grad; alpha phase: actor fwd; collect: actor fwd on 4,096
-        flop = 2.0 * 256 * (critic * (2 + 2 + 4 + 2 + 4) + actor * (1 + 3 + 1)) + 2.0 * 4096 * actor
+        if TRACE_CHILD:
+            print(json.dumps({"trace_child": True, "marks": MARKS, "loop_steps": a.iters,
+                              "ms_per_step": dt}), flush=True)
+            return
+        # aa_mlp_wide_fwd_kernel: a workgroup takes 4 samples through the WHOLE network and
+        # streams every layer's weights from L2 (VALU fp32 FMAs, no MFMA: csrc/mlp_wide.hip).
+        # Per launch of (n networks, batch B, widths d0..dn): flop = 2 B n sum(d_i d_{i+1});
+        # L2 -> CU stream = n ceil(B/4) x weight bytes; HBM side = weights once + inputs + outputs.
+        launches = r.get("wide_fwd_launches") or []
+        fl = l2b = hbm = 0.0
+        for n_nets, B, dims in launches:
+            w_el = sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(len(dims) - 1))
+            fl += 2.0 * B * n_nets * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
+            l2b += n_nets * -(-B // 4) * w_el * 4.0
+            hbm += n_nets * (w_el * 4.0 + B * 4.0 * sum(dims))
+        n_l = max(len(launches), 1)
+        il = inloop_other("sac", 100) if want_inloop else None
+        kf = None
+        if il and "error" not in il:
+            kf = next((v for k, v in il["kernels"].items() if "aa_mlp_wide_fwd_kernel" in k), None)
+            if args.trace_out:
+                _write_kernel_table(args.trace_out, il["kernels"])
+        elif il:
+            log(f"[bench] sac in-loop pass failed: {il['error']}")
+        pmc = _pmc_other("mlp_wide_fwd")
+        kf_ms = kf["avg_us"] / 1e3 if kf else None
+        roof = {"kernel": f"aa_mlp_wide_fwd_kernel ({len(launches)} launches per iteration: "
+                          "actor / twin-critic / 4-critic forwards of whole (256,256) MLPs; "
+                          "csrc/mlp_wide.hip)",
+                "bound": "l2",
+                "achieved": l2b / n_l / (kf_ms * 1e-3) / 1e9 if kf_ms else None,
+                "peak": L2_PEAK_GBS, "unit": "GB/s",
+                "frac": l2b / n_l / (kf_ms * 1e-3) / 1e9 / L2_PEAK_GBS if kf_ms else None,
+                "traffic": pmc.get("bytes_per_launch"),
+                "traffic_source": PMC_OTHER_FILE if pmc else None,
+                "avg_launch_ms": kf_ms,
+                "launches_per_step": kf["launches_per_step"] if kf else None,
+                "duration_source": "in-loop rocprofv3" if kf else "unmeasured (no profiler pass)",
+                "algorithmic_bytes_per_launch": l2b / n_l,
+                "algorithmic_hbm_bytes_per_launch": hbm / n_l,
+                "algorithmic_flop_per_launch": fl / n_l,
+                "flop_frac_of_fp32_peak": (fl / n_l / (kf_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS
+                                           if kf_ms else None),
+                "note": "averages over the launches of one iteration (listed in the detail "
+                        "record).  The bytes are the L2 -> CU weight stream (every workgroup of 4 "
+                        "samples reads its network's 0.66 MB), which is what bounds the kernel; "
+                        "the HBM side is the weights once.  256-row launches put 64 workgroups "
+                        "per network on 256 CUs: the chip-level fraction is low by shape, the "
+                        "per-CU stream (0.66 MB in ~13 us = 50 GB/s of a CU's ~150) is the "
+                        "kernel-quality figure"}
         out = {"metric": "SAC learner steps/sec (batch 256) + 4,096-env collect, configs[4] at 1 GPU",
                "value": r["learner_steps_per_sec"], "unit": "steps/s", "n_gpus": world,
                "steps": a.iters, "warmup": 40, "ms_per_step": dt, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": r["workload"] + "; step = 1 collect step (4096 envs) + "
                           "sample 256x2 + 1 SacAgent.train, per GPU (global batch "
-                          f"{256 * world})", "parallelism": par},
+                          f"{256 * world})", "parallelism": par,
+                          "replay_rows_per_gpu": r["replay_rows"],
+                          "replay_bytes_per_gpu": r["replay_bytes"]},
                "env_steps_per_sec": r["env_steps_per_sec"],
                "trained_transitions_per_sec": r["trained_transitions_per_sec"],
+               "replay_rows_per_sec": r["replay_rows_per_sec"],
                "rccl_ranks": world, "collectives": r.get("collectives"),
-               "roofline": {"kernel": "one SAC iteration: 36 launches (train step 25: whole "
-                                      "(256,256) MLPs forward in one launch and backward in two, "
-                                      "twin critics per launch, csrc/mlp_wide.hip; collect 10; "
-                                      "draw 1), train step replayed as two HIP graphs beside the "
-                                      "collect graph",
-                            "bound": "mfma", "achieved": flop / dt / 1e9,
-                            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": flop / dt / 1e9 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                            "algorithmic_flop_per_launch": flop, "avg_launch_ms": dt,
-                            "note": "256-wide MLPs at batch 256: every launch is bound by what "
-                                    "ONE CU can stream from L2 and multiply (forward 13 us, "
-                                    "gradient chain 17 us, weight gradients 7-10 us per launch; "
-                                    "in-kernel timelines in DESIGN.md); frac against the fp32 MFMA "
-                                    "peak is what the shape allows, not a kernel-quality figure; "
-                                    "the collect forward on 4,096 envs is the only launch that "
-                                    "fills the chip"}}
+               "roofline": roof, "wide_fwd_launches": launches, "inloop": il}
         if not args.no_cpu_baseline and rank == 0 and world == 1:
             th, ncpu, cands = _best_threads(lambda n, t: bench_sac.cpu_baseline(256, n, t))
             sps = bench_sac.cpu_baseline(256, 300, th)
@@ -941,6 +1089,9 @@ def main():
     ap.add_argument("--inloop-steps", type=int, default=100)
     ap.add_argument("--trace-out", default=None,
                     help="write the in-loop per-kernel table (CSV) here")
+    ap.add_argument("--sac-max-length", type=int, default=1000,
+                    help="--config sac: replay frames per env (1000 x 4096 envs = configs[4]'s "
+                         "4 M-row / 6.5 GB replay)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short --config ppo / --config sac runs appended to the line")
     ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
@@ -1106,6 +1257,16 @@ def main():
                        "ranks": lrn.strategy.num_replicas_in_sync}
         lrn.strategy.profile = False
         lrn.strategy.reset_stats()
+        # a data-parallel line is only one if every step moved the WHOLE gradient buffer through
+        # the communicator of --gpus ranks (+ the 3 LossInfo sums Learner.run reduces): anything
+        # else -- a rank on its own, a skipped bucket -- must not print a number
+        grad_bytes = w["net"].flat_params.numel() * 4
+        got = collectives["allreduce_bytes_per_step"]
+        if collectives["ranks"] != args.gpus or not grad_bytes <= got <= grad_bytes + 64:
+            raise SystemExit(
+                f"[bench] data-parallel check failed: communicator of {collectives['ranks']} ranks "
+                f"for --gpus {args.gpus}; {got:.0f} all-reduce bytes per step, expected "
+                f"{grad_bytes} gradient bytes (+ <= 64 of LossInfo sums)")
     # `--steps 20` times ~8 ms of wall clock: a second, longer region of the same loop right after
     # it says whether the short one was representative (reported beside it, never instead of it)
     steady = None
@@ -1217,7 +1378,8 @@ def main():
         "host_work_ms_per_step": (t_enqueue - t_wait) / args.steps * 1e3,
         "learner_steps_per_sec": steps_per_sec,
         "env_steps_per_sec": steps_per_sec * args.envs * world,
-        "replay_rows_gathered_per_sec": steps_per_sec * S * 2 * world,
+        # SURVEY.md 8(d) reads "replay samples/sec" as the rows get_next returns: S x T per step
+        "replay_rows_per_sec": steps_per_sec * S * 2 * world,
         "final_loss": loss_val, "rccl_ranks": world, "collectives": collectives,
         "lanes": lanes_mode,
         "config": {"workload": "configs[1]: DQN Atari Pong-shaped (84x84x4 uint8 stack), replay "

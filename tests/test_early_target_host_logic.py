@@ -103,7 +103,7 @@ def test_successor_is_learned_and_forward_is_issued_behind_its_dependencies(gt):
     side = gt.agent.side
     # on the agent's side stream, behind this step's gradient graph and the draw of b's slot
     assert side.waits == [g3, lanes.ready[200]] and b.g_target.replays == 1
-    nxt, done, key, seq = gt._early
+    nxt, done, key, seq = gt._early[:4]
     assert nxt is b and key == gt.agent.key and seq == 7 and lanes.aux_done is done
     assert done.tag == ("on", "side") and gt.early_issued == 1
 

@@ -170,11 +170,14 @@ def run(args, dev=None, rank=0, world=1):
         strategy.reset_stats()
     tc = tt = 0.0
     steps = 0
+    mark = getattr(args, "mark", None) or (lambda label: None)
+    mark("loop.begin")
     for _ in range(args.iters):
         c, t, n, loss = one_iteration()
         tc += c
         tt += t
         steps += n
+    mark("loop.end")
     coll = None
     if world > 1:
         import torch.distributed as dist
@@ -202,6 +205,7 @@ def run(args, dev=None, rank=0, world=1):
            "iteration_s": (tc + tt) / args.iters, "final_loss": loss, "n_gpus": world,
            "collectives": coll}
     out["frames_per_iteration"] = frames
+    out["total_params"] = int(agent.flat_params.numel())
     out["agent"] = agent
     return out
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """BASELINE.json configs[4] at one GPU (a parity configuration; measured for the record): SAC on
-Humanoid-shaped synthetic data -- obs f32[376], action f32[17], 4,096 parallel envs, replay shard
-4096 x 64 frames, batch 256, actor (256,256) with tanh-Normal projection, twin critics (256,256),
+Humanoid-shaped synthetic data -- obs f32[376], action f32[17], 4,096 parallel envs, replay
+4096 x 1000 frames = 4.1 M rows = 6.5 GB (configs[4]'s "replay cap=4M"), batch 256, actor (256,256) with tanh-Normal projection, twin critics (256,256),
 three Adam(3e-4), tau 0.005 every step (tf_agents/examples/sac/haarnoja18/sac_train_eval.py:182-199;
 SURVEY.md §8d config 5).  One iteration = 1 collect step (4,096 envs) + 1 SacAgent.train.
     python tools/bench_sac.py [--iters 200]"""
@@ -45,7 +45,7 @@ def cpu_baseline(batch, steps, threads):
     return steps / (time.perf_counter() - t0)
 
 
-def build(dev, envs=4096, max_length=64, batch=256, record_noise=False, prefill=True, rank=0):
+def build(dev, envs=4096, max_length=1000, batch=256, record_noise=False, prefill=True, rank=0):
     """configs[4] at one GPU as this benchmark runs it (also what
     tests/test_gpu_bench_config_sac.py checks against oracle/sac.py).  `rank`: data-parallel
     replica index -- its own environment and replay streams; the networks are seeded alike (and the
@@ -137,9 +137,17 @@ def run(args, dev=None, rank=0, world=1):
         torch.cuda.synchronize()
 
     strategy = lrn.strategy
+    # the per-launch work of the wide-MLP forward kernel (the roofline's numerator): the first
+    # iteration runs every launch of the loop eagerly, i.e. through the Python wrappers
+    from agents_amd.networks import sequential
+    sequential.WIDE_FWD_LOG = []
+    step()
+    fwd_log, sequential.WIDE_FWD_LOG = sequential.WIDE_FWD_LOG, None
     for _ in range(40):
         step()
     sync_all()
+    mark = getattr(args, "mark", None) or (lambda label: None)
+    mark("loop.begin")
     if hasattr(strategy, "reset_stats"):
         strategy.reset_stats()
     t0 = time.perf_counter()
@@ -148,6 +156,7 @@ def run(args, dev=None, rank=0, world=1):
     t_host = (time.perf_counter() - t0) / args.iters    # the host is done enqueueing here
     sync_all()
     dt = (time.perf_counter() - t0) / args.iters
+    mark("loop.end")
     coll = None
     if world > 1:
         import torch.distributed as dist
@@ -195,12 +204,19 @@ def run(args, dev=None, rank=0, world=1):
     row = 4 + 376 * 4 + 17 * 4 + 4 + 4 + 4
     return ({
         "workload": "configs[4] at 1 GPU: SAC Humanoid-shaped, %d envs, batch %d, actor/critics "
-                    "(256,256)" % (args.envs, args.batch),
+                    "(256,256), replay %d x %d = %.2f M rows (%.1f GB)" % (
+                        args.envs, args.batch, args.envs, args.max_length,
+                        args.envs * args.max_length / 1e6,
+                        args.envs * args.max_length * row / 1e9),
         "ms_per_iteration": dt * 1e3, "host_enqueue_ms_per_iteration": t_host * 1e3,
         "learner_steps_per_sec": 1.0 / dt,
         "env_steps_per_sec": world * args.envs / dt,
         "trained_transitions_per_sec": world * args.batch / dt,
-        "replay_row_bytes": row, "final_loss": float(li.loss), "n_gpus": world,
+        "replay_row_bytes": row, "replay_rows": args.envs * args.max_length,
+        "replay_bytes": args.envs * args.max_length * row,
+        "replay_rows_per_sec": world * args.batch * 2 / dt,      # S x T rows returned by get_next
+        "wide_fwd_launches": fwd_log,
+        "final_loss": float(li.loss), "n_gpus": world,
         "collectives": coll,
         "train_graph_replays": graph.graphed_train(agent).replays})
 
@@ -208,7 +224,8 @@ def run(args, dev=None, rank=0, world=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=4096)
-    ap.add_argument("--max-length", type=int, default=64)
+    ap.add_argument("--max-length", type=int, default=1000,
+                    help="replay frames per env (1000 x 4096 envs = configs[4]'s 4 M-row cap)")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--no-overlap", action="store_true")
