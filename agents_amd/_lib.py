@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("AA_LIB_PATH") or os.path.join(_PKG_DIR, "libagents_am
 AA_ACT_NONE, AA_ACT_RELU, AA_ACT_TANH = 0, 1, 2
 AA_A_ROW, AA_A_COL, AA_A_PATCH, AA_A_PATCH_U8, AA_A_PATCH_T, AA_A_PATCH_T_U8 = 0, 1, 2, 3, 4, 5
 AA_B_ROW, AA_B_COL = 0, 1
-AA_LOSS_HUBER, AA_LOSS_SQUARED = 0, 1
+AA_LOSS_HUBER, AA_LOSS_SQUARED, AA_LOSS_TARGETS = 0, 1, 2
 AA_OBS_U8, AA_OBS_F32 = 0, 1
 AA_SAC_STD_EXP, AA_SAC_STD_CLIP_EXP = 0, 1
 AA_PPO_NSTATS = 8
@@ -274,6 +274,9 @@ _SIGNATURES = {
     "aa_eps_greedy_action": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p,
                                      c_uint64, c_void_p, c_void_p, c_int64, c_void_p, c_int32,
                                      c_void_p]),
+    "aa_boltzmann_action": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p,
+                                    c_uint64, c_void_p, c_void_p, c_int64, c_void_p, c_int32,
+                                    c_void_p, c_int32, c_void_p]),
     "aa_vecenv_random_step": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_float, c_float,
                                       c_float, c_uint64, c_void_p, c_void_p, c_int32, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -86,8 +86,7 @@ class DqnAgent(tf_agent.TFAgent):
             raise ValueError(
                 "Configured both epsilon_greedy value {} and temperature {}, however only one of "
                 "them can be used for exploration.".format(epsilon_greedy, boltzmann_temperature))
-        if boltzmann_temperature is not None:
-            raise NotImplementedError("Boltzmann exploration is outside the hot-path scope")
+        self._boltzmann_temperature = boltzmann_temperature
         self._observation_and_action_constraint_splitter = \
             observation_and_action_constraint_splitter
         self._q_network = q_network
@@ -179,7 +178,12 @@ class DqnAgent(tf_agent.TFAgent):
                                   emit_log_probability=emit_log_probability,
                                   observation_and_action_constraint_splitter=splitter,
                                   seed=self._seed)
-        collect_policy = q_policy.EpsilonGreedyPolicy(policy, epsilon=self._epsilon_greedy)
+        if self._boltzmann_temperature is not None:       # dqn_agent.py:357-360
+            from agents_amd.policies import boltzmann_policy
+            collect_policy = boltzmann_policy.BoltzmannPolicy(
+                policy, temperature=self._boltzmann_temperature)
+        else:
+            collect_policy = q_policy.EpsilonGreedyPolicy(policy, epsilon=self._epsilon_greedy)
         greedy = q_policy.GreedyPolicy(policy)
         target_policy = q_policy.QPolicy(time_step_spec, action_spec,
                                          q_network=self._target_q_network,
@@ -247,12 +251,44 @@ class DqnAgent(tf_agent.TFAgent):
         return w
 
     def _loss_kind(self, fn):
-        kind = getattr(fn, "aa_loss_kind", None)
-        if kind is None:
-            raise NotImplementedError(
-                "td_errors_loss_fn must be common.element_wise_huber_loss or "
-                "common.element_wise_squared_loss (the fused loss kernel implements those two)")
-        return kind
+        """AA_LOSS_HUBER / AA_LOSS_SQUARED for the two `common.*` functions (the fused loss kernel
+        implements them), None for any other callable (`_custom_loss`)."""
+        return getattr(fn, "aa_loss_kind", None)
+
+    def _custom_loss(self, fn, w, experience, weights, B, need_grad):
+        """An arbitrary `td_errors_loss_fn(td_targets, q_values)` (agents/dqn/dqn_agent.py:114,
+        250-251, 458): the kernel has left td_targets in w.td_loss and q_values in w.td_error
+        (AA_LOSS_TARGETS); the callable is evaluated on those two [B] tensors with torch, its
+        derivative with respect to q_values comes from torch.autograd, and mask / weights /
+        aggregation follow `_loss` (:514-538) and `common.aggregate_losses` (common.py:1400-1476).
+        This path is NOT captured into HIP graphs (`graph_train_ok` is False for such an agent: the
+        train step runs eagerly), and it is the one place of the DQN train step where torch
+        evaluates arithmetic -- the user's own."""
+        td_targets = w.td_loss.clone()
+        q = w.td_error.clone().requires_grad_(need_grad)
+        with torch.enable_grad() if need_grad else torch.no_grad():
+            elem = fn(td_targets, q)
+            if elem.shape != q.shape:
+                raise ValueError("td_errors_loss_fn must return one loss per sample: got shape "
+                                 f"{tuple(elem.shape)} for {tuple(q.shape)} q-values")
+            valid = (experience.step_type[:, 0] != 2).to(torch.float32)
+            td_loss = valid * elem
+            weighted = td_loss
+            if weights is not None:
+                # tf.math.multiply_no_nan(losses, weights)
+                weighted = torch.where(weights == 0, torch.zeros_like(td_loss), td_loss * weights)
+            total = weighted.sum() / float(B * self.num_replicas)
+            if need_grad:
+                (gq,) = torch.autograd.grad(total, q)
+                acts = experience.action[:, 0] if experience.action.dim() == 2 \
+                    else experience.action
+                w.dq.zero_()
+                w.dq.scatter_(1, acts.to(torch.int64).reshape(B, 1), gq.reshape(B, 1))
+        w.td_error.copy_(valid * (td_targets - q.detach()))
+        w.td_loss.copy_(td_loss.detach())
+        w.loss.copy_(total.detach().reshape(1))
+        w.field_sums[0] = w.td_loss.sum()
+        w.field_sums[1] = w.td_error.sum()
 
     def _early_target_key(self):
         """Changes whenever a target forward computed earlier (GraphedTrain's early target
@@ -326,14 +362,21 @@ class DqnAgent(tf_agent.TFAgent):
         head = None
         if need_grad and hasattr(self._q_network, "fusable_head"):
             head = self._q_network.fusable_head(B, "train")
+        fn = td_errors_loss_fn or self._td_errors_loss_fn
+        kind = self._loss_kind(fn)
+        if kind is None:
+            head = None       # the head's backward needs dL/dq, which torch produces below
         w.head_done = head is not None
         ops.dqn_td_loss(q_online, q_next_target, q_next_select, next_mask,
                         experience.action, experience.reward.contiguous(),
                         experience.discount.contiguous(), st.contiguous(), weights,
                         self._gamma, reward_scale_factor,
-                        self._loss_kind(td_errors_loss_fn or self._td_errors_loss_fn),
+                        _lib.AA_LOSS_TARGETS if kind is None else kind,
                         float(B * self.num_replicas), w.loss, w.td_loss, w.td_error, w.dq,
                         gamma_loss=gamma, field_sums_out=w.field_sums, head=head)
+        if kind is None:
+            self._custom_loss(fn, w, experience if st is experience.step_type else
+                              experience._replace(step_type=st), weights, B, need_grad)
         return w
 
     def reduce_loss_info(self, loss_info):
@@ -476,6 +519,12 @@ class DqnAgent(tf_agent.TFAgent):
             self._gradient_clipping is None and not net.has_regularization and \
             getattr(self._optimizer, "supports_grad_slabs", False) and \
             hasattr(net, "take_grad_slabs")
+
+    @property
+    def graph_train_ok(self):
+        """False when the train step cannot be recorded into HIP graphs: a td_errors_loss_fn other
+        than the two fused ones is evaluated by torch (with autograd) inside the step."""
+        return self._loss_kind(self._td_errors_loss_fn) is not None
 
     def _graph_capture_key(self):
         """What `_train_phase_grads` decides on the host while it is recorded (GraphedTrain replays

@@ -55,10 +55,14 @@ class PPOAgent(tf_agent.TFAgent):
             raise TypeError("actor_net must be an instance of a network.Network.")
         if not isinstance(value_net, network.Network):
             raise TypeError("value_net must be an instance of a network.Network.")
-        if shared_vars_l2_reg:
-            raise NotImplementedError("networks with shared variables are not supported")
-        if not aggregate_losses_across_replicas:
-            raise NotImplementedError("aggregate_losses_across_replicas=False")
+        # shared_vars_l2_reg (ppo_agent.py:1130-1146) penalises the variables the actor and the
+        # value network SHARE; the networks here own disjoint segments of one flat buffer, so
+        # the set is empty and the term is identically zero: accepted, nothing to compute.
+        self._shared_vars_l2_reg = shared_vars_l2_reg
+        # aggregate_losses_across_replicas=False (ppo_agent.py:1170-1181, 1281-1292, 1403-1408):
+        # policy-gradient, value and entropy terms are tf.reduce_mean over the LOCAL batch instead
+        # of common.aggregate_losses' sum / (batch x replicas); see `_loss_denominator`
+        self._aggregate_losses_across_replicas = bool(aggregate_losses_across_replicas)
         actor_net.create_variables(time_step_spec.observation)
         value_net.create_variables(time_step_spec.observation)
         self._optimizer = optimizer
@@ -294,6 +298,12 @@ class PPOAgent(tf_agent.TFAgent):
         return self._preprocess(experience)
 
     # ---- loss ------------------------------------------------------------------------------------
+    def _loss_denominator(self, N):
+        """What the per-sample loss terms are divided by: N x replicas
+        (tf.nn.compute_average_loss inside common.aggregate_losses, utils/common.py:1462-1467) or,
+        with aggregate_losses_across_replicas=False, N (tf.reduce_mean on the replica)."""
+        return float(N * (self.num_replicas if self._aggregate_losses_across_replicas else 1))
+
     def l2_regularization_loss(self, debug_summaries=False):
         """policy_l2_reg * sum(actor kernels^2) + value_function_l2_reg * sum(value kernels^2),
         divided by the replica count (ppo_agent.py:1088-1157)."""
@@ -371,7 +381,7 @@ class PPOAgent(tf_agent.TFAgent):
             vpred.data_ptr(), _lib.ptr(old_vpred) if self._value_clipping > 0 else None,
             weights.data_ptr(), N, self._D, self._importance_ratio_clipping,
             self._value_clipping, self._value_pred_loss_coef, self._entropy_regularization,
-            float(N * self.num_replicas), self._log_prob_clipping,
+            self._loss_denominator(N), self._log_prob_clipping,
             _lib.ptr(self._adaptive_kl_beta) if use_kl else None, kl_cut_coef,
             self._kl_cutoff_factor * self._adaptive_kl_target,
             w["dloc"].data_ptr() if training else None,
@@ -603,7 +613,7 @@ class PPOAgent(tf_agent.TFAgent):
         d.act_mean, d.act_mag = _lib.ptr(a._mean), _lib.ptr(a._mag)
         d.clip_eps, d.value_clip = self._importance_ratio_clipping, self._value_clipping
         d.c_v, d.c_e = self._value_pred_loss_coef, self._entropy_regularization
-        d.denom, d.logp_clip, d.adv_eps = float(N * self.num_replicas), \
+        d.denom, d.logp_clip, d.adv_eps = self._loss_denominator(N), \
             self._log_prob_clipping, 1e-8
         return d, fw
 

@@ -88,6 +88,14 @@ __device__ static inline int64_t aa_td_sample(const TdArgs& P, int64_t b, float&
   const float td_target = rewards + discounts * next_q;
   td_error = td_target - q;
   float dloss_dq;
+  if (P.loss_kind == AA_LOSS_TARGETS) {
+    // the caller evaluates its own td_errors_loss_fn(td_targets, q_values) on these two vectors
+    loss = td_target;
+    td_error = q;
+    weighted = 0.f;
+    gq = 0.f;
+    return act;
+  }
   if (P.loss_kind == AA_LOSS_HUBER) {
     // tf.compat.v1.losses.huber_loss(labels=td_target, predictions=q, delta=1)
     const float err = q - td_target;
@@ -137,7 +145,8 @@ __device__ static inline void aa_td_all(const TdArgs& P, bool write_out, float* 
   if (!write_out) return;
   const float total = aa_block_sum(local, red);
   if (threadIdx.x == 0) P.loss_out[0] = total / P.global_batch;
-  if (P.field_sums_out != nullptr) {   // the Learner's SUM over all axes of the LossInfo fields
+  if (P.field_sums_out != nullptr && P.loss_kind != AA_LOSS_TARGETS) {
+    // the Learner's SUM over all axes of the LossInfo fields
     const float s0 = aa_block_sum(sum_loss, red);
     const float s1 = aa_block_sum(sum_err, red);
     if (threadIdx.x == 0) { P.field_sums_out[0] = s0; P.field_sums_out[1] = s1; }
@@ -187,7 +196,8 @@ static int aa_td_args(TdArgs* P, const float* q_online, const float* q_next_targ
       td_loss_out == nullptr || td_error_out == nullptr || dq_out == nullptr)
     return AA_ERR_INVALID;
   if (B <= 0 || T < 2 || A <= 0 || !(global_batch > 0.f)) return AA_ERR_INVALID;
-  if (loss_kind != AA_LOSS_HUBER && loss_kind != AA_LOSS_SQUARED) return AA_ERR_INVALID;
+  if (loss_kind != AA_LOSS_HUBER && loss_kind != AA_LOSS_SQUARED && loss_kind != AA_LOSS_TARGETS)
+    return AA_ERR_INVALID;
   // float32(gamma ** (n-1)) with the power taken in float64 (python-float semantics)
   double gp = 1.0;
   for (int t = 0; t < T - 2; ++t) gp *= gamma;
@@ -240,6 +250,7 @@ extern "C" int aa_dqn_loss_head_backward(
                             gamma_loss, reward_scale, loss_kind, global_batch, loss_out,
                             td_loss_out, td_error_out, dq_out, field_sums_out);
   if (rc != AA_OK) return rc;
+  if (loss_kind == AA_LOSS_TARGETS) return AA_ERR_INVALID;   // no dL/dq to back-propagate
   if (!x || !w || !dx || !dw || K <= 0 || ldx < K) return AA_ERR_INVALID;
   if (A > AA_SMALLN_MAX || B > 512) return AA_ERR_RANGE;
   const unsigned n_dw = (unsigned)((K + 63) / 64);

@@ -65,6 +65,57 @@ __global__ void aa_eps_greedy_kernel(const float* __restrict__ q, const int32_t*
     reinterpret_cast<int32_t*>(out)[b] = (int32_t)v;
 }
 
+// BoltzmannPolicy over a Q table (see include/agents_amd.h: aa_boltzmann_action).  The softmax CDF
+// is evaluated in float64 so that the numpy restatement (oracle/policy.py) picks the same action
+// unless u * sum lands within ~1e-16 relative of a partial sum.
+template <bool I64>
+__global__ void aa_boltzmann_kernel(const float* __restrict__ q, const int32_t* __restrict__ mask,
+                                    int64_t B, int A, float temperature,
+                                    const float* __restrict__ temperature_dev, uint32_t k0,
+                                    uint32_t k1, int64_t* call_dev, int64_t* arrival,
+                                    int64_t action_min, void* __restrict__ out,
+                                    float* __restrict__ logits_out, int sample) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const float T = temperature_dev != nullptr ? *temperature_dev : temperature;
+  const uint64_t call = (sample && call_dev != nullptr) ? (uint64_t)(*call_dev) : 0ull;
+  if (sample && arrival != nullptr) aa_advance_when_all_done(call_dev, arrival, 1, gridDim.x);
+  if (b >= B) return;
+  float lmax = -FLT_MAX;
+  int last_ok = -1;
+  for (int a = 0; a < A; ++a) {
+    const bool ok = mask == nullptr || mask[b * A + a] != 0;
+    const float l = ok ? q[b * A + a] / T : -FLT_MAX;
+    if (logits_out != nullptr) logits_out[b * A + a] = l;
+    if (ok) last_ok = a;
+    lmax = l > lmax ? l : lmax;
+  }
+  if (!sample || out == nullptr) return;
+  double total = 0.0;
+  for (int a = 0; a < A; ++a) {
+    const bool ok = mask == nullptr || mask[b * A + a] != 0;
+    if (ok) total += exp((double)(q[b * A + a] / T) - (double)lmax);
+  }
+  const Philox4 r = philox4x32_10((uint32_t)b, (uint32_t)((uint64_t)b >> 32), (uint32_t)call,
+                                  (uint32_t)(call >> 32), k0, k1);
+  const double thr = (double)aa_u01(r.x) * total;
+  int act = last_ok < 0 ? 0 : last_ok;
+  double cum = 0.0;
+  for (int a = 0; a < A; ++a) {
+    const bool ok = mask == nullptr || mask[b * A + a] != 0;
+    if (!ok) continue;
+    cum += exp((double)(q[b * A + a] / T) - (double)lmax);
+    if (cum > thr) {
+      act = a;
+      break;
+    }
+  }
+  const int64_t v = action_min + act;
+  if (I64)
+    reinterpret_cast<int64_t*>(out)[b] = v;
+  else
+    reinterpret_cast<int32_t*>(out)[b] = (int32_t)v;
+}
+
 // Synthetic env.  Per env b and step s:
 //   header draw  Philox(counter = (0xFFFFFFFF, b, s_lo, s_hi), key = seed):
 //       x0 -> episode end iff u01(x0) < p_end ; x1 -> reward: u<.05 -> -1, u<.95 -> 0, else +1
@@ -246,6 +297,31 @@ int aa_eps_greedy_action(const float* q, const int32_t* mask, int64_t B, int32_t
                        epsilon_dev, (uint32_t)seed, (uint32_t)(seed >> 32), call_counter_dev,
                        arrival, action_min, actions_out);
   if (arrival_dev != nullptr && arrival == nullptr)   // large grid: one-thread bump launch
+    hipLaunchKernelGGL(aa_counter_bump_kernel, dim3(1), dim3(64), 0, st, call_counter_dev);
+  return aa_launch_status();
+}
+
+int aa_boltzmann_action(const float* q, const int32_t* mask, int64_t B, int32_t A,
+                        float temperature, const float* temperature_dev, uint64_t seed,
+                        int64_t* call_counter_dev, int64_t* arrival_dev, int64_t action_min,
+                        void* actions_out, int32_t actions_are_i64, float* logits_out,
+                        int32_t sample, void* stream) {
+  if (!q || B <= 0 || A <= 0 || (!actions_out && !logits_out)) return AA_ERR_INVALID;
+  if (sample && (!actions_out || !call_counter_dev)) return AA_ERR_INVALID;
+  if (temperature_dev == nullptr && !(temperature > 0.f)) return AA_ERR_INVALID;
+  const dim3 grid((unsigned)((B + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  int64_t* arrival = (sample && arrival_dev != nullptr && grid.x <= AA_MAX_ARRIVAL_GROUPS)
+                         ? arrival_dev : nullptr;
+  if (actions_are_i64)
+    hipLaunchKernelGGL(aa_boltzmann_kernel<true>, grid, block, 0, st, q, mask, B, A, temperature,
+                       temperature_dev, (uint32_t)seed, (uint32_t)(seed >> 32), call_counter_dev,
+                       arrival, action_min, actions_out, logits_out, sample);
+  else
+    hipLaunchKernelGGL(aa_boltzmann_kernel<false>, grid, block, 0, st, q, mask, B, A, temperature,
+                       temperature_dev, (uint32_t)seed, (uint32_t)(seed >> 32), call_counter_dev,
+                       arrival, action_min, actions_out, logits_out, sample);
+  if (sample && arrival_dev != nullptr && arrival == nullptr)   // large grid: one-thread bump
     hipLaunchKernelGGL(aa_counter_bump_kernel, dim3(1), dim3(64), 0, st, call_counter_dev);
   return aa_launch_status();
 }

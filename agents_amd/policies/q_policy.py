@@ -36,6 +36,43 @@ def _action_bounds(action_spec):
     return spec, lo, hi
 
 
+class Categorical:
+    """What `policy.distribution(time_step).action` exposes of tfp Categorical: `logits` [B, A]
+    and `mode()` (first arg-max, greedy_policy.py:70-89)."""
+
+    def __init__(self, logits, policy):
+        self.logits = logits
+        self._policy = policy
+
+    def mode(self):
+        return self._policy.select(self.logits, None, 0.0)
+
+
+def distribution_of(policy, time_step, temperature):
+    """Categorical(logits = masked Q / temperature) of a discrete Q policy."""
+    obs = time_step.observation
+    mask = None
+    if policy._observation_and_action_constraint_splitter is not None:
+        obs, mask = policy._observation_and_action_constraint_splitter(obs)
+    batched = time_step.step_type.dim() > 0
+    if not batched:
+        obs = nest_utils.map_structure(lambda t: t.unsqueeze(0), obs)
+        mask = None if mask is None else mask.unsqueeze(0)
+    B = nest_utils.flatten(obs)[0].shape[0]
+    dev = nest_utils.flatten(obs)[0].device
+    graph.join_lanes(dev)
+    with torch.cuda.device(dev):
+        q = policy._q_values(obs, B, dev)
+        logits = torch.empty_like(q)
+        if mask is not None:
+            mask = mask.to(torch.int32).contiguous()
+        _lib.check(_lib.load().aa_boltzmann_action(
+            q.data_ptr(), None if mask is None else mask.data_ptr(), B, policy._num_actions,
+            float(temperature), None, 0, None, None, policy._lo, None, 0, logits.data_ptr(), 0,
+            _lib.stream_ptr()), "aa_boltzmann_action")
+    return policy_step.PolicyStep(Categorical(logits, policy), (), ())
+
+
 class _DiscretePolicy(tf_policy.TFPolicy):
     """Shared machinery: run (optional) Q-network, then the fused select kernel."""
 
@@ -66,6 +103,10 @@ class _DiscretePolicy(tf_policy.TFPolicy):
 
     def _variables(self):
         return self._q_network.variables if self._q_network is not None else []
+
+    def _distribution(self, time_step, policy_state):
+        """Categorical over the (masked) Q values (q_policy.py:150-194)."""
+        return distribution_of(self, time_step, 1.0)
 
     @property
     def q_network(self):
@@ -208,6 +249,13 @@ class QPolicy(_DiscretePolicy):
                  name=None, seed=0):
         if validate_action_spec:
             _, lo, _ = _action_bounds(action_spec)
+        # q_policy.py:96-101: the policy creates the network's variables from the (split)
+        # observation spec if nobody has yet
+        if q_network is not None and not getattr(q_network, "_built", True):
+            net_spec = time_step_spec.observation
+            if observation_and_action_constraint_splitter is not None:
+                net_spec, _ = observation_and_action_constraint_splitter(net_spec)
+            q_network.create_variables(net_spec)
         super().__init__(time_step_spec, action_spec, q_network=q_network, epsilon=0.0, seed=seed,
                          observation_and_action_constraint_splitter=
                          observation_and_action_constraint_splitter,

@@ -682,7 +682,10 @@ class GraphedTrain:
 
     def __call__(self, experience, weights=None, **kwargs):
         agent = self._agent
-        if not self.enabled or kwargs or getattr(agent, "check_numerics", False) or capturing():
+        if not self.enabled or kwargs or getattr(agent, "check_numerics", False) or capturing() \
+                or not getattr(agent, "graph_train_ok", True):
+            # (graph_train_ok False: a DqnAgent with a td_errors_loss_fn of the caller's own, which
+            # torch evaluates -- with autograd -- in the middle of the step)
             self._consume_early()
             return self._eager_train(experience, weights=weights, **kwargs)
         if self._whole and (getattr(agent, "gradient_hook", None) is not None or

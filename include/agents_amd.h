@@ -420,6 +420,11 @@ int aa_col2im_f32(const float* dcol, int32_t n_img, int32_t H, int32_t W, int32_
  * ========================================================================================= */
 #define AA_LOSS_HUBER 0
 #define AA_LOSS_SQUARED 1
+/* No element-wise loss: td_loss_out[b] := td_targets[b] and td_error_out[b] := q_values[b] -- the two
+ * arguments of the caller's own td_errors_loss_fn(td_targets, q_values) (agents/dqn/dqn_agent.py:114,
+ * 250-251, 458) -- unmasked; loss_out := 0, dq_out := 0, field sums untouched.  aa_dqn_td_loss[_sums]
+ * only (the fused head backward needs dL/dq). */
+#define AA_LOSS_TARGETS 2
 
 /* Inputs are the [B,T] trajectory fields (T = n_step+1) and the three Q tables [B,A].
  * Computes the n-step return/discount, td_targets, td_error, element-wise loss, the
@@ -566,6 +571,23 @@ int aa_eps_greedy_action(const float* q, const int32_t* mask /* nullable [B,A] *
                          int64_t* arrival_dev /* nullable: advance *call_counter_dev in-kernel */,
                          int64_t action_min, void* actions_out, int32_t actions_are_i64,
                          void* stream);
+
+/* BoltzmannPolicy._action over QPolicy (policies/boltzmann_policy.py:83-101: the wrapped policy's
+ * Categorical with logits / temperature, sampled; policies/q_policy.py:175-180: masked actions get
+ * logits = float32 min; DqnAgent's collect policy when boltzmann_temperature is given,
+ * agents/dqn/dqn_agent.py:357-360).  Per row b: l_a = q[b,a] / T (IEEE float32 division), masked
+ * l_a = -FLT_MAX; p_a = exp(l_a - max l) evaluated and accumulated in FLOAT64 in action order;
+ * u = u01(word 0 of Philox(counter = (b, call), key = seed)); the action is the first allowed a
+ * whose running sum exceeds u * sum_a p_a (the last allowed one if rounding leaves none).
+ * temperature_dev (nullable) overrides `temperature` (a schedule refreshed by the host between
+ * graph replays).  logits_out (nullable [B,A]) receives l -- `distribution().action.logits`.
+ * sample == 0: no draw, no counter advance; actions_out may be NULL (logits only). */
+int aa_boltzmann_action(const float* q, const int32_t* mask /* nullable [B,A] */, int64_t B,
+                        int32_t A, float temperature, const float* temperature_dev /* nullable */,
+                        uint64_t seed, int64_t* call_counter_dev,
+                        int64_t* arrival_dev /* nullable: advance *call_counter_dev in-kernel */,
+                        int64_t action_min, void* actions_out, int32_t actions_are_i64,
+                        float* logits_out /* nullable */, int32_t sample, void* stream);
 
 /* DynamicStepDriver loop counter: counter[b] += (step_type[b] != LAST); *total_dev += the sum
  * (drivers/dynamic_step_driver.py:113,170).  counter_dev nullable.  mailbox (nullable) is a

@@ -80,7 +80,12 @@ def td_loss_from_q(q_online, q_next_target, actions, reward, discount, step_type
     discounts = (f32(gamma_loss) * final_disc).astype(f32)
     td_targets = (rewards + (discounts * next_q).astype(f32)).astype(f32)
     td_error = (td_targets - q).astype(f32)
-    if loss == "huber":
+    if callable(loss):
+        # a td_errors_loss_fn of the caller's own (dqn_agent.py:114, 250-251, 458): the callable
+        # returns (element-wise loss, its derivative with respect to q) as float32 arrays
+        td_loss, dl_dq = loss(td_targets, q)
+        td_loss, dl_dq = np.asarray(td_loss, f32), np.asarray(dl_dq, f32)
+    elif loss == "huber":
         td_loss = huber(td_targets, q)
         err = (q - td_targets).astype(f32)
         dl_dq = np.clip(err, -1.0, 1.0).astype(f32)

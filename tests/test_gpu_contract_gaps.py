@@ -1,0 +1,301 @@
+"""GPU: constructor arguments of SURVEY.md §8(b) that used to raise and now work.
+
+  DqnAgent(td_errors_loss_fn=<any callable>)      tf_agents/agents/dqn/dqn_agent.py:114,250-251,458
+  DqnAgent(boltzmann_temperature=...) / BoltzmannPolicy
+                                                  dqn_agent.py:357-360, policies/boltzmann_policy.py
+  QNetwork(preprocessing_layers=...)              networks/q_network.py:70-79
+  PPOAgent(aggregate_losses_across_replicas=False, shared_vars_l2_reg=...)
+                                                  agents/ppo/ppo_agent.py:131,152,1170-1181,1281-1292,
+                                                  1403-1408
+Each against a known answer of the reference's tests or against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from agents_amd import optimizers
+from agents_amd.agents.dqn import dqn_agent
+from agents_amd.networks import layers as L
+from agents_amd.networks import q_network, sequential
+from agents_amd.policies import boltzmann_policy, q_policy
+from agents_amd.specs import tensor_spec
+from agents_amd.trajectories import time_step as ts
+from agents_amd.trajectories import trajectory
+from agents_amd.utils import common
+from oracle import dqn as odqn
+from oracle import nets as onets
+from oracle import optim as ooptim
+from oracle import policy as opolicy
+
+pytestmark = pytest.mark.gpu
+FIRST, MID, LAST = 0, 1, 2
+
+
+def dummy_net():
+    return sequential.Sequential([L.Dense(2, kernel_initializer=L.Constant([[2, 1], [1, 1]]),
+                                          bias_initializer=L.Constant([1, 1]))])
+
+
+def specs():
+    obs = tensor_spec.TensorSpec((2,), torch.float32)
+    return ts.time_step_spec(obs), tensor_spec.BoundedTensorSpec((), torch.int32, 0, 1)
+
+
+def two_frame(dev, next_obs, first=FIRST):
+    def col(vals, dt):
+        return torch.tensor(np.stack([np.asarray(v) for v in vals], 1), dtype=dt, device=dev)
+    return trajectory.Trajectory(
+        step_type=col([[first] * 2, [MID] * 2], torch.int32),
+        observation=col([[[1, 2], [3, 4]], next_obs], torch.float32),
+        action=col([[0, 1], [0, 1]], torch.int32), policy_info=(),
+        next_step_type=col([[MID] * 2, [MID] * 2], torch.int32),
+        reward=col([[10, 20], [10, 20]], torch.float32),
+        discount=col([[.9, .9], [.9, .9]], torch.float32))
+
+
+# ---- arbitrary td_errors_loss_fn ---------------------------------------------------------------------
+def test_custom_loss_fn_reproduces_the_known_answers(dev):
+    """The reference's testLoss numbers (dqn_agent_test.py:178-218: 26.0, td_loss 19.8 / 32.2)
+    through a PLAIN callable -- same arithmetic as common.element_wise_huber_loss but without the
+    tag the fused kernel dispatches on -- and an L1 loss by hand: |20.3| and |32.7| -> 26.5."""
+    tss, aspec = specs()
+    huber = lambda y, q: common.element_wise_huber_loss(y, q)       # noqa: E731
+    assert not hasattr(huber, "aa_loss_kind")
+    with torch.cuda.device(dev):
+        agent = dqn_agent.DqnAgent(tss, aspec, q_network=dummy_net(), optimizer=None,
+                                   td_errors_loss_fn=huber)
+        assert not agent.graph_train_ok
+        loss, extra = agent._loss(two_frame(dev, [[5, 6], [7, 8]]), td_errors_loss_fn=huber)
+        np.testing.assert_allclose(loss.item(), 26.0, rtol=1e-6)
+        np.testing.assert_allclose(extra.td_loss.cpu().numpy(), [19.8, 32.2], rtol=1e-6)
+        np.testing.assert_allclose(extra.td_error.cpu().numpy(), [20.3, 32.7], rtol=1e-6)
+        l1 = lambda y, q: (y - q).abs()                             # noqa: E731
+        loss, extra = agent._loss(two_frame(dev, [[5, 6], [7, 8]]), td_errors_loss_fn=l1)
+        np.testing.assert_allclose(loss.item(), 26.5, rtol=1e-6)
+        # a LAST first frame is masked out of loss and td_error (dqn_agent.py:514-531)
+        loss, extra = agent._loss(two_frame(dev, [[5, 6], [7, 8]], first=LAST),
+                                  td_errors_loss_fn=l1)
+        assert loss.item() == 0.0 and extra.td_error.abs().sum().item() == 0.0
+        with pytest.raises(ValueError, match="one loss per sample"):
+            agent._loss(two_frame(dev, [[5, 6], [7, 8]]), td_errors_loss_fn=lambda y, q: q.sum())
+
+
+@pytest.mark.parametrize("kind", ["plain_huber", "log_cosh"])
+def test_custom_loss_fn_train_steps_match_the_oracle(dev, kind):
+    """Three train steps (weights given, one masked row) with a callable loss: losses 1e-5,
+    parameters 2e-5 * max|p| against OracleDqnAgent driven by the same function and its analytic
+    derivative.  `plain_huber` must also equal the FUSED huber agent step for step (1e-6)."""
+    rng = np.random.default_rng(0)
+    B, A, O = 32, 4, 6
+    obs_spec = tensor_spec.TensorSpec((O,), torch.float32)
+    tss, aspec = ts.time_step_spec(obs_spec), tensor_spec.BoundedTensorSpec((), torch.int64, 0, A - 1)
+    layers = onets.mlp_q_layers((16,), A, "relu")
+    params = onets.init_params(layers, (O,), seed=4)
+    if kind == "plain_huber":
+        fn = lambda y, q: common.element_wise_huber_loss(y, q)      # noqa: E731
+        ofn = lambda y, q: (odqn.huber(y, q), np.clip(q - y, -1.0, 1.0).astype(np.float32))  # noqa: E731
+    else:
+        fn = lambda y, q: torch.log(torch.cosh(q - y))              # noqa: E731
+        ofn = lambda y, q: (np.log(np.cosh((q - y).astype(np.float64))).astype(np.float32),  # noqa: E731
+                            np.tanh((q - y).astype(np.float64)).astype(np.float32))
+
+    def make(loss_fn):
+        net = sequential.Sequential([L.Dense(16, "relu"), L.Dense(A)])
+        ag = dqn_agent.DqnAgent(tss, aspec, q_network=net, optimizer=optimizers.Adam(1e-2),
+                                td_errors_loss_fn=loss_fn, gamma=0.9, target_update_period=2)
+        net.set_weights([p.numpy() for p in params])
+        ag.initialize()
+        return ag, net
+
+    with torch.cuda.device(dev):
+        agent, net = make(fn)
+        fused, fnet = make(common.element_wise_huber_loss) if kind == "plain_huber" else (None, None)
+    oracle = odqn.OracleDqnAgent(layers, (O,), A, [p.clone() for p in params],
+                                 optimizer=ooptim.Adam(1e-2), gamma=0.9, loss=ofn,
+                                 target_update_period=2)
+    for step in range(3):
+        obs = rng.normal(size=(B, 2, O)).astype(np.float32) * 0.5
+        act = rng.integers(0, A, size=(B, 2))
+        rew = rng.normal(size=(B, 2)).astype(np.float32) * (0.3 if kind == "log_cosh" else 1.0)
+        disc = np.full((B, 2), 0.9, np.float32)
+        st = np.full((B, 2), MID, np.int32)
+        st[3, 0] = LAST
+        w = rng.uniform(0.5, 1.5, size=B).astype(np.float32)
+        w[5] = 0.0
+        exp = trajectory.Trajectory(
+            step_type=torch.tensor(st, device=dev), observation=torch.tensor(obs, device=dev),
+            action=torch.tensor(act, device=dev), policy_info=(),
+            next_step_type=torch.tensor(st, device=dev), reward=torch.tensor(rew, device=dev),
+            discount=torch.tensor(disc, device=dev))
+        li = agent.train(exp, weights=torch.tensor(w, device=dev))
+        total, aux, _ = oracle.train(torch.tensor(obs), act, rew, disc, st, weights=w)
+        np.testing.assert_allclose(li.loss.item(), float(total), rtol=1e-5)
+        np.testing.assert_allclose(li.extra.td_loss.cpu().numpy(), aux["td_loss"], rtol=2e-5,
+                                   atol=2e-6)
+        np.testing.assert_allclose(li.extra.td_error.cpu().numpy(), aux["td_error"], rtol=2e-4,
+                                   atol=2e-5)
+        if fused is not None:
+            lf = fused.train(exp, weights=torch.tensor(w, device=dev))
+            np.testing.assert_allclose(li.loss.item(), lf.loss.item(), rtol=1e-6)
+            np.testing.assert_allclose(net.flat_params.cpu().numpy(),
+                                       fnet.flat_params.cpu().numpy(), rtol=0, atol=2e-6)
+    got = [a for a in net.get_weights()]
+    for g, p in zip(got, oracle.params):
+        ref = p.detach().numpy()
+        assert np.abs(g - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    # common.function(agent.train) takes the eager path for such an agent, call after call
+    train = common.function(agent.train)
+    for _ in range(4):
+        train(exp)
+    assert train.replays == 0
+
+
+# ---- Boltzmann -------------------------------------------------------------------------------------
+class _BoltzNet:
+    """DummyNet of boltzmann_policy_test.py:33-57: Dense(2), kernel [[1, 1.5], [1, 1.5]], bias 1."""
+
+    @staticmethod
+    def make():
+        return sequential.Sequential([L.Dense(2, kernel_initializer=L.Constant([[1, 1.5], [1, 1.5]]),
+                                              bias_initializer=L.Constant([1, 1]))])
+
+
+def test_boltzmann_policy_reference_cases(dev):
+    tss, aspec = specs()
+    with torch.cuda.device(dev):
+        wrapped = q_policy.QPolicy(tss, aspec, q_network=_BoltzNet.make())
+        policy = boltzmann_policy.BoltzmannPolicy(wrapped, temperature=0.9)
+        assert policy.time_step_spec == tss and policy.action_spec == aspec          # testBuild
+        step = policy.action(ts.restart(torch.tensor([[1., 2.], [3., 4.]], device=dev),
+                                        batch_size=2))
+        assert tuple(step.action.shape) == (2,) and step.action.dtype == torch.int32  # testAction
+        one = ts.restart(torch.tensor([[1., 2.]], device=dev), batch_size=1)
+        assert policy.distribution(one).action.mode().cpu().tolist() == [1]     # testDistribution
+        half = boltzmann_policy.BoltzmannPolicy(wrapped, temperature=0.5)
+        assert wrapped.distribution(one).action.logits.cpu().tolist() == [[4.0, 5.5]]   # testLogits
+        assert half.distribution(one).action.logits.cpu().tolist() == [[8.0, 11.0]]
+        with pytest.raises(ValueError, match="parameterized by logits"):
+            boltzmann_policy.BoltzmannPolicy(q_policy.RandomTFPolicy(tss, aspec))
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_boltzmann_actions_match_the_oracle(dev, masked):
+    """Actions bit-exact vs oracle/policy.py call after call (the call counter advances the
+    stream), int64 actions with a non-zero minimum, optional action mask; a callable temperature
+    is re-read per call."""
+    B, A = 3000, 6
+    rng = np.random.default_rng(1)
+    obs_spec = tensor_spec.TensorSpec((5,), torch.float32)
+    aspec = tensor_spec.BoundedTensorSpec((), torch.int64, 2, A + 1)
+    splitter = None
+    tspec = ts.time_step_spec(obs_spec)
+    if masked:
+        tspec = ts.time_step_spec((obs_spec, tensor_spec.BoundedTensorSpec((A,), torch.int32, 0, 1)))
+        splitter = lambda o: (o[0], o[1])                              # noqa: E731
+    temp = {"t": 0.8}
+    with torch.cuda.device(dev):
+        net = sequential.Sequential([L.Dense(A)], seed=1)
+        wrapped = q_policy.QPolicy(tspec, aspec, q_network=net,
+                                   observation_and_action_constraint_splitter=splitter, seed=77)
+        policy = boltzmann_policy.BoltzmannPolicy(wrapped, temperature=lambda: temp["t"])
+        for call in range(3):
+            temp["t"] = (0.8, 0.25, 3.0)[call]
+            x = torch.tensor(rng.normal(size=(B, 5)).astype(np.float32) * 2, device=dev)
+            m = None
+            obs = x
+            if masked:
+                m = rng.integers(0, 2, size=(B, A)).astype(np.int32)
+                m[np.arange(B), rng.integers(0, A, size=B)] = 1          # at least one allowed
+                obs = (x, torch.tensor(m, device=dev))
+            step = policy.action(ts.restart(obs, batch_size=B))
+            q = wrapped.q_values(ts.restart(obs, batch_size=B)).cpu().numpy()
+            want = opolicy.boltzmann_actions(q, temp["t"], seed=policy._seed, call=call, mask=m,
+                                             action_min=2)
+            got = step.action.cpu().numpy()
+            assert got.dtype == np.int64 and np.array_equal(got, want), call
+
+
+def test_dqn_agent_with_boltzmann_collect_policy(dev):
+    tss, aspec = specs()
+    with torch.cuda.device(dev):
+        with pytest.raises(ValueError, match="only one of them"):
+            dqn_agent.DqnAgent(tss, aspec, q_network=dummy_net(), optimizer=None,
+                               boltzmann_temperature=0.5)        # epsilon_greedy defaults to 0.1
+        agent = dqn_agent.DqnAgent(tss, aspec, q_network=dummy_net(), optimizer=None,
+                                   epsilon_greedy=None, boltzmann_temperature=0.5)
+        assert isinstance(agent.collect_policy, boltzmann_policy.BoltzmannPolicy)
+        # Q(obs) = (2 o0 + o1 + 1, o0 + o1 + 1): at T = 0.5 on (1, 2) / (30, -40) the second row is
+        # (21, -9) / 0.5: action 0 with probability 1 - e^-60
+        obs = torch.tensor([[1., 2.], [30., -40.]], device=dev).repeat(512, 1)
+        a = agent.collect_policy.action(ts.restart(obs, batch_size=1024)).action.cpu().numpy()
+        assert (a[1::2] == 0).all()
+        p1 = 1.0 / (1.0 + np.exp((5.0 - 4.0) / 0.5))     # row (1, 2): Q = (5, 4)
+        assert abs((a[0::2] == 1).mean() - p1) < 0.07
+
+
+# ---- QNetwork(preprocessing_layers=...) ------------------------------------------------------------------
+def test_q_network_preprocessing_layers(dev):
+    obs_spec = tensor_spec.TensorSpec((12, 12, 4), torch.uint8)
+    aspec = tensor_spec.BoundedTensorSpec((), torch.int64, 0, 3)
+    with torch.cuda.device(dev):
+        net = q_network.QNetwork(obs_spec, aspec, preprocessing_layers=L.Rescale(255.0),
+                                 conv_layer_params=((8, 4, 4),), fc_layer_params=(16,), seed=3)
+        ref = sequential.Sequential([L.Rescale(255.0), L.Conv2D(8, 4, 4, "relu"), L.Flatten(),
+                                     L.Dense(16, "relu"), L.Dense(4)], seed=3)
+        net.create_variables(obs_spec)
+        ref.create_variables(obs_spec)
+        ref.set_weights(net.get_weights())
+        x = torch.randint(0, 256, (5, 12, 12, 4), dtype=torch.uint8, device=dev)
+        assert torch.equal(net.forward(x), ref.forward(x))
+        cp = net.copy(name="Target")
+        cp.create_variables(obs_spec)
+        assert len(cp.layers) == len(net.layers)
+    with pytest.raises(TypeError, match="agents_amd.networks.layers"):
+        q_network.QNetwork(obs_spec, aspec, preprocessing_layers=lambda x: x / 255)
+    with pytest.raises(NotImplementedError):
+        q_network.QNetwork(obs_spec, aspec, preprocessing_layers={"a": L.Rescale(255.0)})
+
+
+# ---- PPO: aggregate_losses_across_replicas=False ---------------------------------------------------
+def test_ppo_reduce_mean_losses_ignore_the_replica_count(dev):
+    """With aggregate_losses_across_replicas=False the loss terms are tf.reduce_mean over the local
+    batch (ppo_agent.py:1170-1181, 1281-1292, 1403-1408): on `num_replicas = 4` they equal the
+    one-replica values, where the default divides them by 4 (common.py:1462-1467)."""
+    from agents_amd.agents.ppo import ppo_actor_network as pan
+    from agents_amd.agents.ppo import ppo_clip_agent
+    obs = tensor_spec.BoundedTensorSpec((5,), torch.float32, -1.0, 1.0)
+    act = tensor_spec.BoundedTensorSpec((2,), torch.float32, -1.0, 1.0)
+    tss = ts.time_step_spec(obs)
+
+    def make(aggregate, replicas):
+        actor = pan.PPOActorNetwork().create_sequential_actor_net((8,), act, seed=1)
+        value = pan.value_network((8,), "tanh", seed=2)
+        ag = ppo_clip_agent.PPOClipAgent(
+            tss, act, optimizers.Adam(1e-3), actor_net=actor, value_net=value,
+            importance_ratio_clipping=0.2, num_epochs=1, normalize_observations=False,
+            normalize_rewards=False, use_gae=True, entropy_regularization=0.01,
+            shared_vars_l2_reg=0.5, aggregate_losses_across_replicas=aggregate)
+        ag.initialize()
+        ag.num_replicas = replicas
+        return ag
+
+    B, T1, D = 6, 5, 2
+    rng = np.random.default_rng(0)
+    f = lambda a, dt=torch.float32: torch.tensor(a, dtype=dt, device=dev)      # noqa: E731
+    obs_ = rng.uniform(-0.5, 0.5, size=(B, T1, 5)).astype(np.float32)
+    loc = rng.normal(size=(B, T1, D)).astype(np.float32) * 0.3
+    scale = rng.uniform(0.5, 1.5, size=(B, T1, D)).astype(np.float32)
+    act_ = np.clip(loc + scale * rng.normal(size=(B, T1, D)), -1, 1).astype(np.float32)
+    with torch.cuda.device(dev):
+        exp = trajectory.Trajectory(
+            step_type=f(np.ones((B, T1)), torch.int32), observation=f(obs_), action=f(act_),
+            policy_info={"dist_params": {"loc": f(loc), "scale": f(scale)}},
+            next_step_type=f(np.ones((B, T1)), torch.int32),
+            reward=f(rng.normal(size=(B, T1))), discount=f(np.ones((B, T1))))
+        stats = {}
+        for k in ((True, 1), (True, 4), (False, 4)):
+            li = make(*k).train(exp)
+            stats[k] = (float(li.extra.policy_gradient_loss), float(li.extra.value_estimation_loss),
+                        float(li.extra.entropy_regularization_loss))
+    base, div4, mean4 = stats[(True, 1)], stats[(True, 4)], stats[(False, 4)]
+    np.testing.assert_allclose(mean4, base, rtol=1e-6)
+    np.testing.assert_allclose(np.asarray(div4) * 4.0, base, rtol=1e-5)
