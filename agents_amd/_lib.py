@@ -123,6 +123,8 @@ _SIGNATURES = {
                                          c_void_p]),
     "aa_rb_sample_rows": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_uint64,
                                   c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "aa_rb_draw_tf_host": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int64, c_uint64, c_uint64,
+                                   c_uint64, c_uint64, c_void_p, c_void_p]),
     "aa_rb_sample_gather": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                     c_int64, c_int64, c_uint64, c_uint64, c_void_p, c_void_p,

@@ -1176,6 +1176,45 @@ int aa_rb_sample_rows(const int64_t* last_id_dev, int64_t batch, int64_t max_len
   return aa_launch_status();
 }
 
+static inline uint64_t aa_tf_uniform_u64(uint64_t seed, uint64_t seed2, uint64_t block, int half) {
+  // PhiloxRandom(seed, seed2) skipped to `block`: counter = (block lo, block hi, seed2 lo, seed2 hi)
+  const Philox4 r = philox4x32_10((uint32_t)block, (uint32_t)(block >> 32), (uint32_t)seed2,
+                                  (uint32_t)(seed2 >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+  return half == 0 ? (((uint64_t)r.y << 32) | r.x) : (((uint64_t)r.w << 32) | r.z);
+}
+
+int aa_rb_draw_tf_host(int64_t last_id, int64_t batch, int64_t max_len, int64_t S, int64_t T,
+                       uint64_t seed, uint64_t seed2_ids, uint64_t seed2_seg, uint64_t base_blocks,
+                       int64_t* rows_out_h, float* prob_out_h) {
+  if (S <= 0 || T <= 0 || batch <= 0 || max_len <= 0 || rows_out_h == nullptr)
+    return AA_ERR_INVALID;
+  int64_t min_id, max_id;
+  if (last_id < max_len) {
+    min_id = 0;
+    max_id = last_id + 1 - T + 1;
+    if (max_id < 0) max_id = 0;
+  } else {
+    min_id = last_id + 1 - max_len;
+    max_id = last_id + 1 - T + 1;
+  }
+  const int64_t num_ids = max_id - min_id;
+  if (num_ids <= 0) return AA_ERR_RANGE;
+  for (int64_t s = 0; s < S; ++s) {
+    const uint64_t blk = base_blocks + (uint64_t)(s >> 1);
+    const uint64_t a = aa_tf_uniform_u64(seed, seed2_ids, blk, (int)(s & 1));
+    const uint64_t c = aa_tf_uniform_u64(seed, seed2_seg, blk, (int)(s & 1));
+    const int64_t id = min_id + (int64_t)(a % (uint64_t)num_ids);
+    const int64_t seg = (int64_t)(c % (uint64_t)batch);
+    for (int64_t t = 0; t < T; ++t) {
+      int64_t m = (id + t) % max_len;
+      if (m < 0) m += max_len;
+      rows_out_h[s * T + t] = m + seg * max_len;
+    }
+  }
+  if (prob_out_h != nullptr) *prob_out_h = 1.0f / (float)(num_ids * batch);
+  return AA_OK;
+}
+
 static int aa_rb_sample_gather_launch(const void* const* leaf_tables_h, void* const* leaf_out_h,
                                       const int64_t* leaf_row_bytes_h, int n_leaves,
                                       const int64_t* id_table, int64_t* ids_out, float* prob_out,

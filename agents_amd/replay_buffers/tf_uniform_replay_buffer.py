@@ -68,7 +68,31 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
 
     def __init__(self, data_spec, batch_size, max_length=1000, scope="TFUniformReplayBuffer",
                  device=None, table_fn=table.Table, dataset_drop_remainder=False,
-                 dataset_window_shift=None, stateful_dataset=False, seed=0, dataset_ring=8):
+                 dataset_window_shift=None, stateful_dataset=False, seed=0, dataset_ring=8,
+                 rng="philox"):
+        """`seed`, `dataset_ring`, `rng` are this package's additions (the reference's sampling is
+        unseeded).  rng="philox" (default): the package's own Philox stream (counter = (sample,
+        call), key = seed; oracle/philox.py).  rng="tf": the two draws of `_get_next` in
+        TensorFlow's stream LAYOUT -- seed = (global seed, op seed of the id draw[, op seed of the
+        env-block draw = the former + 1]), blocks advancing by 256 x outputs per call (SURVEY.md
+        Appendix B; include/agents_amd.h: aa_rb_draw_tf_host) -- so that replay indices can be
+        compared with a fixture from a seeded TensorFlow run the day one exists.  UNVERIFIED
+        against TensorFlow (none is installed here): parity of the stream stays unpinned.  The
+        draw is made on the host and the rows are uploaded, so datasets are not graphed in this
+        mode: it is a checking aid, not the fast path."""
+        if rng not in ("philox", "tf"):
+            raise ValueError("rng must be 'philox' or 'tf'")
+        self._rng = rng
+        self._tf_seeds = None
+        self._tf_blocks = 0              # Philox blocks both TF-layout streams have consumed
+        if rng == "tf":
+            sd = tuple(int(v) for v in (seed if isinstance(seed, (tuple, list)) else (seed, 0)))
+            if len(sd) == 2:
+                sd = sd + (sd[1] + 1,)
+            if len(sd) != 3:
+                raise ValueError("rng='tf': seed = (global seed, op seed[, second op seed])")
+            self._tf_seeds = tuple(v & 0xFFFFFFFFFFFFFFFF for v in sd)
+            seed = sd[0]
         self._batch_size = int(batch_size)
         self._max_length = int(max_length)
         capacity = self._batch_size * self._max_length
@@ -191,7 +215,7 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
     # ---- stamped draws: the host mirrors of last_id / the call counter ride in the launch ------
     def supports_stamped_draws(self):
         """True when `draw_into` reproduces `get_next` (no subclass sampler in the way)."""
-        return STAMPED_DRAWS and \
+        return STAMPED_DRAWS and self._rng == "philox" and \
             type(self)._sample_rows is TFUniformReplayBuffer._sample_rows and \
             type(self)._get_next is TFUniformReplayBuffer._get_next
 
@@ -221,7 +245,29 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
             _lib.stream_ptr()), "aa_rb_sample_gather_stamped")
         self._sample_calls += 1
 
+    def _sample_rows_tf(self, S, T):
+        """rng="tf": the draw on the host in TensorFlow's stream layout, rows uploaded."""
+        import ctypes
+        if graph.capturing():
+            raise RuntimeError("rng='tf' draws on the host: get_next cannot be captured")
+        rows_h = torch.empty((S, T), dtype=torch.int64).pin_memory()
+        prob = ctypes.c_float(0.0)
+        g, op_ids, op_seg = self._tf_seeds
+        rc = _lib.load().aa_rb_draw_tf_host(
+            self._last_id_host, self._batch_size, self._max_length, S, T, g, op_ids, op_seg,
+            self._tf_blocks, rows_h.data_ptr(), ctypes.byref(prob))
+        if rc == -34:       # AA_ERR_RANGE: the valid id range is empty
+            raise RuntimeError(_EMPTY_SAMPLE)
+        _lib.check(rc, "aa_rb_draw_tf_host")
+        self._tf_blocks += S * 256          # ReserveRandomOutputs(output size, 256), both ops
+        self._sample_calls += 1
+        rows = rows_h.to(self._device, non_blocking=True)
+        probs = torch.full((S,), prob.value, dtype=torch.float32, device=self._device)
+        return rows, probs
+
     def _sample_rows(self, S, T):
+        if self._rng == "tf":
+            return self._sample_rows_tf(S, T)
         lib = _lib.load()
         rows = torch.empty((S, T), dtype=torch.int64, device=self._device)
         probs = torch.empty((S,), dtype=torch.float32, device=self._device)
@@ -241,7 +287,8 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
         S = 1 if sample_batch_size is None else int(sample_batch_size)
         T = 1 if num_steps is None else int(num_steps)
         with torch.cuda.device(self._device):
-            if type(self)._sample_rows is TFUniformReplayBuffer._sample_rows:
+            if type(self)._sample_rows is TFUniformReplayBuffer._sample_rows and \
+                    self._rng == "philox":
                 # draw + gather + counter advance in ONE launch (csrc/replay.hip)
                 lib = _lib.load()
                 ids = torch.empty((S, T), dtype=torch.int64, device=self._device)
@@ -301,6 +348,8 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
             # the iterator replays a HIP graph of (sample, gather) after two eager draws; its
             # elements live in a ring of static buffers (graph.GraphedSampler)
             n_ring = self._dataset_ring if ring is None else ring
+            if self._rng != "philox":
+                n_ring = 0        # host-made draws: nothing to replay from a graph
             if n_ring <= 0:
                 while True:
                     yield self.get_next(sample_batch_size, num_steps, time_stacked=True)
@@ -374,7 +423,8 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
         graph.join_lanes(self._device)
         return {"tables": [v.clone() for v in self._data_table.variables()],
                 "ids": self._id_table.variables()[0].clone(), "last_id": self._last_id_host,
-                "sample_calls": self._sample_calls, "seed": self._seed}
+                "sample_calls": self._sample_calls, "seed": self._seed,
+                "tf_blocks": self._tf_blocks}
 
     def load_state_dict(self, sd):
         graph.join_lanes(self._device)
@@ -386,6 +436,7 @@ class TFUniformReplayBuffer(replay_buffer.ReplayBuffer):
         self._sample_calls = int(sd["sample_calls"])
         self._sample_calls_dev.fill_(self._sample_calls)
         self._seed = int(sd["seed"])
+        self._tf_blocks = int(sd.get("tf_blocks", 0))
 
 
 def _windows(seq, size, shift, drop_remainder):

@@ -76,6 +76,23 @@ int aa_rb_sample_rows(const int64_t* last_id_dev, int64_t batch, int64_t max_len
                       graph advances the stream without new kernel arguments */,
                       int64_t* rows_out, float* prob_out, int* err_flag_dev, void* stream);
 
+/* The same draw in TensorFlow's stream LAYOUT, made on the HOST (rng="tf" of TFUniformReplayBuffer;
+ * SURVEY.md Appendix B; NOT verified against a TensorFlow run -- no TF here -- and labelled so
+ * wherever it is used).  What tf.random.uniform(shape=[S], minval, maxval, dtype=int64) is known
+ * to do (tensorflow/core: GuardedPhiloxRandom::Init(seed, seed2), ReserveRandomOutputs(n, 256),
+ * FillPhiloxRandom with UniformDistribution<PhiloxRandom, int64>):
+ *   key = (seed lo32, seed hi32); counter words 2, 3 = (seed2 lo32, seed2 hi32); counter words 0, 1
+ *   = a 64-bit block index that starts at 0 and advances by n x 256 per op execution;
+ *   output j of an execution takes Philox block (base + j / 2), words 2 (j % 2) and 2 (j % 2) + 1
+ *   as the low and high half of a uint64 x, and returns minval + x mod (maxval - minval).
+ * The replay buffer's two draws are two ops (tf_uniform_replay_buffer.py:265-272): ids from the
+ * op seeded (seed, seed2_ids), env blocks from (seed, seed2_seg); base_blocks = blocks both ops
+ * have consumed so far.  rows_out_h[S*T] (HOST memory) as aa_rb_sample_rows; *prob_out_h as there.
+ * Returns AA_ERR_RANGE when the valid id range is empty. */
+int aa_rb_draw_tf_host(int64_t last_id, int64_t batch, int64_t max_len, int64_t S, int64_t T,
+                       uint64_t seed, uint64_t seed2_ids, uint64_t seed2_seg, uint64_t base_blocks,
+                       int64_t* rows_out_h, float* prob_out_h);
+
 /* get_next in ONE launch: the draw of aa_rb_sample_rows (same Philox stream, same mapping, bit for
  * bit) is recomputed by every workgroup of sample s, which then copies row (id+t) mod L + block*L
  * of every leaf into out[s*T + t]; ids_out[s*T+t] = id_table[row] (nullable), prob_out[s]

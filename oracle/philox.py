@@ -57,3 +57,24 @@ def uniform_bounded(lo, hi, n_rows, seed, call):
     l, h = lo[d], hi[d]
     v = (l + ((h - l).astype(np.float32) * u01(r0)).astype(np.float32)).astype(np.float32)
     return np.where(v < h, v, l).reshape(n_rows, D)
+
+
+def tf_uniform_u64(seed, seed2, base_block, n):
+    """The n raw 64-bit words behind one execution of tf.random.uniform(shape=[n], dtype=int64) in
+    TensorFlow's stream LAYOUT (from general knowledge of tensorflow/core --
+    NOT in /root/reference and NOT verified against a TensorFlow run: no TF in this image):
+      GuardedPhiloxRandom::Init(seed, seed2)  -> key = (seed lo32, seed hi32), counter words 2, 3 =
+                                                 (seed2 lo32, seed2 hi32), counter words 0, 1 = 0
+      ReserveRandomOutputs(n, 256)            -> an execution starts at the generator's current
+                                                 64-bit block index and advances it by n * 256
+      UniformDistribution<PhiloxRandom, int64>-> output j = words 2 (j % 2), 2 (j % 2) + 1 (low,
+                                                 high) of Philox block base + j // 2
+    The caller maps with minval + x mod (maxval - minval), as the op does."""
+    j = np.arange(n, dtype=np.uint64)
+    blk = np.uint64(base_block) + (j >> np.uint64(1))
+    x0, x1, x2, x3 = philox4x32_10(blk & MASK, blk >> np.uint64(32), int(seed2) & 0xFFFFFFFF,
+                                   (int(seed2) >> 32) & 0xFFFFFFFF, int(seed) & 0xFFFFFFFF,
+                                   (int(seed) >> 32) & 0xFFFFFFFF)
+    lo = np.where(j & np.uint64(1), x2, x0).astype(np.uint64)
+    hi = np.where(j & np.uint64(1), x3, x1).astype(np.uint64)
+    return (hi << np.uint64(32)) | lo

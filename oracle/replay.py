@@ -39,6 +39,15 @@ def raw_draws(seed, call, n):
     return a, c
 
 
+def raw_draws_tf_layout(seed, seed2_ids, seed2_seg, base_block, n):
+    """The two draws of `_get_next` (tf_uniform_replay_buffer.py:265-272) as two TensorFlow ops
+    with op seeds seed2_ids / seed2_seg under one global seed, both `base_block` Philox blocks into
+    their streams (philox.tf_uniform_u64: layout from general knowledge of TF core, UNVERIFIED
+    against TensorFlow -- parity unpinned)."""
+    return (philox.tf_uniform_u64(seed, seed2_ids, base_block, n),
+            philox.tf_uniform_u64(seed, seed2_seg, base_block, n))
+
+
 def rows_from_draws(id_raw, block_raw, last_id, batch_size, max_length, num_steps):
     """rows[S,T], probabilities[S] from raw 64-bit draws (:242-292)."""
     T = 1 if num_steps is None else num_steps

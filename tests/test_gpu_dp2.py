@@ -127,10 +127,9 @@ def _dqn_worker(rank, world, port, *args):
     _run_guarded(_dqn_body, rank, world, port, args)
 
 
-def _spawn(target, args, limit=150.0):
+def _spawn(target, args, limit=150.0, world=2):
     import queue
     import time
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -192,6 +191,40 @@ def test_dqn_two_replicas_equal_one_process_on_the_global_batch(dev, bucketed, c
     np.testing.assert_allclose(r0["losses"], ref_losses, rtol=1e-5, atol=1e-7)
     scale = float(np.abs(ref).max())
     assert float(np.abs(r0["params"] - ref).max()) <= 2e-5 * scale
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("world", [4, 8])
+def test_dqn_replicas_are_rank_count_agnostic(dev, world):
+    """The same body at world size 4 and 8 (every rank on cuda:0, gloo): the partitioning of
+    SURVEY.md 8(e) does not depend on the rank count -- every replica ends bit-identical to rank 0
+    (parameters, target network, losses, step), through the HIP graphs in bucket mode, and equal
+    to ONE process training on the concatenated global batch of world x 24 transitions to 1e-5
+    (losses) / 2e-5 x max|p| (parameters); the reference's contract is 1e-2
+    (tf_agents/train/learner_test.py:446-562)."""
+    res = _spawn(_dqn_worker, (True, None), limit=330.0, world=world)
+    r0 = res[0]
+    assert len(res) == world and r0["bucket_mode"] and r0["replays"] == STEPS - 2
+    for r in res[1:]:
+        assert r["changed_by_broadcast"], f"rank {r['rank']} kept its own initial weights"
+        np.testing.assert_array_equal(r0["init"], r["init"])
+        np.testing.assert_array_equal(r0["params"], r["params"])
+        np.testing.assert_array_equal(r0["target"], r["target"])
+        assert r0["losses"] == r["losses"] and r["step"] == STEPS
+    from agents_amd.train import learner
+    from agents_amd.utils import common
+    with torch.cuda.device(dev):
+        agent, net = _dqn(dev, seed=0)
+        net.flat_params.copy_(torch.as_tensor(r0["init"], device=dev))
+        lrn = learner.Learner(None, common.Variable(0), agent)
+        ref_losses = []
+        for b in _batches(STEPS, world * B_LOCAL):
+            li = lrn.run(iterations=1,
+                         iterator=iter([(_experience(b, slice(None), dev), None)]))
+            ref_losses.append(float(li.loss))
+        ref = net.flat_params.cpu().numpy()
+    np.testing.assert_allclose(r0["losses"], ref_losses, rtol=1e-5, atol=1e-7)
+    assert float(np.abs(r0["params"] - ref).max()) <= 2e-5 * float(np.abs(ref).max())
 
 
 # ---- PPO: the gradient hook runs once per epoch inside _train ------------------------------------

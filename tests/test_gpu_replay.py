@@ -446,3 +446,46 @@ def test_far_rows(dev):
         hits, far = hits + h, far + fr
     assert hits > 0                                  # ~9 of 15,000 ids are written: a few dozen rows
     _arrivals_consistent(rb)
+
+
+def test_tf_layout_draws_match_the_oracle_twin(dev):
+    """rng="tf": the two draws of `_get_next` in TensorFlow's Philox LAYOUT (SURVEY.md Appendix B:
+    key = global seed, counter high words = op seed, 256 x outputs blocks reserved per execution,
+    two int64 per block, minval + x mod range).  Rows / ids / probabilities bit-exact against the
+    numpy twin (oracle/philox.py: tf_uniform_u64) over calls of different sizes, through get_next
+    and through the dataset.  UNVERIFIED against TensorFlow itself: there is no TF here, and the
+    reference's own draws are unseeded -- this pins the option to its documented layout only."""
+    from oracle import replay as oreplay
+    B_env, L_, = 5, 7
+    spec = (tensor_spec.TensorSpec((3,), torch.float32), tensor_spec.TensorSpec((), torch.int32))
+    rb = rb_lib.TFUniformReplayBuffer(spec, batch_size=B_env, max_length=L_, device=dev,
+                                      seed=(1234, 7), rng="tf")
+    ora = oreplay.OracleReplayBuffer([(3,), ()], [np.float32, np.int32], B_env, L_)
+    rng = np.random.default_rng(0)
+    with pytest.raises(RuntimeError, match="is empty"):
+        rb.get_next(4, 2)
+    for i in range(11):       # wraps the 7-frame ring
+        a = rng.normal(size=(B_env, 3)).astype(np.float32)
+        b = rng.integers(0, 100, size=(B_env,)).astype(np.int32)
+        rb.add_batch((torch.tensor(a, device=dev), torch.tensor(b, device=dev)))
+        ora.add_batch([a, b])
+    blocks = 0
+    it = iter(rb.as_dataset(sample_batch_size=6, num_steps=2))
+    for k, (S, T) in enumerate([(4, 2), (9, 3), (1, 1), (6, 2), (6, 2)]):
+        a_raw, c_raw = oreplay.raw_draws_tf_layout(1234, 7, 8, blocks, S)
+        rows, probs = oreplay.rows_from_draws(a_raw, c_raw, ora.last_id, B_env, L_, T)
+        blocks += S * 256
+        data, info = next(it) if k >= 3 else rb.get_next(S, T)
+        assert np.array_equal(info.ids.cpu().numpy(), ora.id_table[rows])
+        assert np.array_equal(info.probabilities.cpu().numpy(), probs)
+        for got, tab in zip(data, ora.tables):
+            assert np.array_equal(got.cpu().numpy(), tab[rows])
+    assert rb._tf_blocks == blocks
+    sd = rb.state_dict()
+    rb2 = rb_lib.TFUniformReplayBuffer(spec, batch_size=B_env, max_length=L_, device=dev,
+                                       seed=(1234, 7, 8), rng="tf")
+    rb2.load_state_dict(sd)
+    x, y = rb.get_next(5, 2), rb2.get_next(5, 2)
+    assert torch.equal(x[1].ids, y[1].ids)
+    with pytest.raises(ValueError):
+        rb_lib.TFUniformReplayBuffer(spec, batch_size=2, max_length=4, device=dev, rng="mt19937")

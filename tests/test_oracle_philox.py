@@ -30,3 +30,24 @@ def test_vectorised_matches_scalar():
 def test_u01_range():
     u = philox.u01(np.array([0, 0xffffffff, 0x80000000], dtype=np.uint32))
     assert u.dtype == np.float32 and u[0] == 0.0 and u[1] < 1.0 and u[2] == 0.5
+
+
+def test_tf_layout_host_draw_matches_the_numpy_twin(lib):
+    """aa_rb_draw_tf_host is host code (no GPU): rows and probability against oracle/philox.py's
+    tf_uniform_u64 + oracle/replay.py's mapping, over ring states (not full / wrapped), odd sample
+    counts (two int64 per Philox block) and block offsets beyond 2^32."""
+    import ctypes
+
+    from oracle import replay as oreplay
+    for last_id, batch, L_, S, T, base in [(3, 4, 10, 5, 2, 0), (25, 3, 10, 8, 3, 1280),
+                                           (9, 1, 10, 1, 1, 256), (99, 7, 13, 33, 4, (1 << 33) + 5)]:
+        rows = (ctypes.c_int64 * (S * T))()
+        prob = ctypes.c_float(0.0)
+        rc = lib.aa_rb_draw_tf_host(last_id, batch, L_, S, T, 0x1234567890, 11, 12, base, rows,
+                                    ctypes.byref(prob))
+        assert rc == 0
+        a, c = oreplay.raw_draws_tf_layout(0x1234567890, 11, 12, base, S)
+        want, probs = oreplay.rows_from_draws(a, c, last_id, batch, L_, T)
+        assert np.array_equal(np.asarray(rows[:]).reshape(S, T), want)
+        assert np.float32(prob.value) == probs[0]
+    assert lib.aa_rb_draw_tf_host(0, 4, 10, 2, 2, 1, 2, 3, 0, rows, ctypes.byref(prob)) == -34
