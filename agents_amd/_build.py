@@ -41,6 +41,7 @@ SOURCES = [
     ("ppo_fused.hip", ["-ffp-contract=off"]),
     ("sac.hip", ["-ffp-contract=off"]),
     ("normalizer.hip", ["-ffp-contract=off"]),
+    ("runtime_guard.hip", []),
 ]
 HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
     [os.path.join(INCLUDE, "agents_amd.h")]

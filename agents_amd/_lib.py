@@ -25,7 +25,9 @@ AA_PPO_DIST_STATS = 16 + 6 * 256
 
 AA_ERR_INVALID, AA_ERR_RANGE = -22, -34
 _ERRORS = {-22: "AA_ERR_INVALID (bad argument)", -34: "AA_ERR_RANGE (size / workspace)",
-           -5: "AA_ERR_LAUNCH (HIP launch failure)", -62: "AA_ERR_TIMEOUT (mailbox wait)"}
+           -5: "AA_ERR_LAUNCH (HIP launch failure)", -62: "AA_ERR_TIMEOUT (mailbox wait)",
+           -95: "AA_ERR_UNSUPPORTED (HIP runtime version / layout not the analysed one)"}
+AA_ERR_UNSUPPORTED = -95
 
 
 class AgentsAmdError(RuntimeError):
@@ -148,7 +150,6 @@ _SIGNATURES = {
     "aa_marker": (c_int, [c_int32, c_void_p]),
     "aa_gemm_f32_workspace_bytes": (c_int64, [POINTER(GemmDesc)]),
     "aa_gemm_f32": (c_int, [POINTER(GemmDesc), c_void_p, c_int64, c_void_p]),
-    "aa_gemm_f32_pair": (c_int, [POINTER(GemmDesc), POINTER(GemmDesc), c_void_p]),
     "aa_gemm_f32_slabs": (c_int, [POINTER(GemmDesc), c_void_p, c_int64, POINTER(c_int32),
                                   c_void_p]),
     "aa_conv_pair_supported": (c_int, [c_int32, c_int32, c_int32, c_int32, POINTER(ConvLayerDesc),
@@ -163,13 +164,6 @@ _SIGNATURES = {
     "aa_conv_pair_x6_phase": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                       POINTER(ConvLayerDesc), POINTER(ConvLayerDesc), c_void_p,
                                       c_int64, c_int32, c_void_p]),
-    "aa_conv_triple_x6_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32,
-                                                    POINTER(ConvLayerDesc), POINTER(ConvLayerDesc),
-                                                    POINTER(ConvLayerDesc)]),
-    "aa_conv_triple_x6_phase": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
-                                        c_float, POINTER(ConvLayerDesc), POINTER(ConvLayerDesc),
-                                        POINTER(ConvLayerDesc), c_void_p, c_int64, c_int32,
-                                        c_void_p]),
     "aa_conv_dx_frame_supported": (c_int, [POINTER(ConvDxDesc)]),
     "aa_conv_dx_frame": (c_int, [POINTER(ConvDxDesc), c_void_p]),
     "aa_conv_dx_frame_x6_workspace_bytes": (c_int64, [POINTER(ConvDxDesc)]),
@@ -188,11 +182,6 @@ _SIGNATURES = {
     "aa_dense_small_forward_slabs": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int32,
                                              c_void_p, c_int64, c_void_p, c_void_p, c_int32,
                                              c_int32, c_void_p, c_void_p]),
-    "aa_dense_small_forward_slabs_eps": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p,
-                                                 c_int32, c_void_p, c_int64, c_void_p, c_void_p,
-                                                 c_int32, c_int32, c_void_p, c_void_p, c_float,
-                                                 c_void_p, c_uint64, c_void_p, c_void_p, c_int64,
-                                                 c_void_p, c_int32, c_void_p]),
     "aa_dense_small_backward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32,
                                         c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                         c_void_p]),
@@ -276,6 +265,11 @@ _SIGNATURES = {
     "aa_eps_greedy_action": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p,
                                      c_uint64, c_void_p, c_void_p, c_int64, c_void_p, c_int32,
                                      c_void_p]),
+    "aa_hip_graph_exec_spread": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32)]),
+    "aa_hip_graph_instantiate": (c_int, [c_void_p, c_int32, POINTER(c_void_p), POINTER(c_int32),
+                                         POINTER(c_int32), POINTER(c_int32)]),
+    "aa_hip_graph_launch": (c_int, [c_void_p, c_void_p]),
+    "aa_hip_graph_exec_destroy": (c_int, [c_void_p]),
     "aa_boltzmann_action": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p,
                                     c_uint64, c_void_p, c_void_p, c_int64, c_void_p, c_int32,
                                     c_void_p, c_int32, c_void_p]),
@@ -357,7 +351,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 14:
+    if lib.aa_abi_version() != 15:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -39,14 +39,10 @@ from agents_amd.utils import common, graph, nest_utils
 _SINGLE_STREAM = os.environ.get("AA_TRAIN_SINGLE_STREAM", "0") == "1"
 # AA_OPT_SUMS_SLABS=0: the conv weight gradients' slabs are summed by reduce launches into
 # flat_grads even when nothing but the optimizer reads them (A/B measurements; bit-identical)
-OPT_SUMS_SLABS = os.environ.get("AA_OPT_SUMS_SLABS", "1") != "0"
-_TRIPLE_FOR_DEFAULT = "all"
+OPT_SUMS_SLABS = True
 # AA_PACK_IN_OPTIMIZER=0: Learner.run's LossInfo scalars are packed by a launch of their own behind
 # the optimizer step (A/B measurements; same values either way)
-PACK_IN_OPTIMIZER = os.environ.get("AA_PACK_IN_OPTIMIZER", "1") != "0"
-# AA_SPLIT_LAST_DW=1: GraphedTrain records the gradient phase as two graphs around the first
-# layer's weight gradient and starts the next step's early target forward between them (round 5)
-SPLIT_LAST_DW = os.environ.get("AA_SPLIT_LAST_DW", "0") == "1"
+PACK_IN_OPTIMIZER = True
 
 
 class DqnLossInfo(collections.namedtuple("DqnLossInfo", ("td_loss", "td_error"))):
@@ -132,18 +128,6 @@ class DqnAgent(tf_agent.TFAgent):
                          summarize_grads_and_vars=summarize_grads_and_vars,
                          train_step_counter=train_step_counter,
                          training_data_spec=training_data_spec)
-        # AA_TRIPLE_FOR: which of the three forwards of an iteration take the one-launch conv stack
-        # (csrc/conv_triple_x6.h) -- a comma list of policy / online / target; default: see DESIGN.md
-        which = os.environ.get("AA_TRIPLE_FOR", _TRIPLE_FOR_DEFAULT)
-        if which != "all" and hasattr(q_network, "triple_slots"):
-            names = {w for w in which.split(",") if w}
-            q_slots = set()
-            if "policy" in names:
-                q_slots |= {"collect", "policy", "greedy", "call"}
-            if "online" in names:
-                q_slots |= {"train", "next"}
-            q_network.triple_slots = q_slots
-            self._target_q_network.triple_slots = None if "target" in names else set()
         self._work = {}
         self._side_streams = {}
         self._seg_offsets = None
@@ -239,8 +223,7 @@ class DqnAgent(tf_agent.TFAgent):
         key = (device.type, device.index)
         st = self._side_streams.get(key)
         if st is None:
-            st = self._side_streams[key] = ops.new_side_stream(
-                device, priority=int(os.environ.get("AA_SIDE_PRIORITY", "0")))
+            st = self._side_streams[key] = ops.new_side_stream(device)
         return st
 
     def _get_work(self, B, device):
@@ -475,31 +458,16 @@ class DqnAgent(tf_agent.TFAgent):
         k = net.dense_tail_start()
         return k if 0 < k < len(net._param_layers) else None
 
-    def _last_dw_split(self):
-        """1 when the gradient phase may be recorded as two graphs around the FIRST layer's weight
-        gradient (the last launch of the backward chain; utils/graph.py: GraphedTrain starts the
-        next step's early target forward between them), else None: needs a lone replica with
-        nothing between backward and the optimizer step."""
-        net = self._q_network
-        if not SPLIT_LAST_DW or self.gradient_hook is not None or \
-                self.gradient_hook_async is not None or net.has_regularization or \
-                self._gradient_clipping is not None or not hasattr(net, "backward_resume") or \
-                len(getattr(net, "_param_layers", ())) < 2:
-            return None
-        return 1
-
-    def _train_phase_grads_a(self, experience, weights, q_next_target=None, split=None):
-        """`split`: the layer the first half stops above (default: the data-parallel bucket split)."""
+    def _train_phase_grads_a(self, experience, weights, q_next_target=None):
+        """First half of the gradient phase: everything above the data-parallel bucket split."""
         net = self._q_network
         w = self._forward_and_loss(experience, self._td_errors_loss_fn, self._gamma,
                                    self._reward_scale_factor, weights, need_grad=True,
                                    q_next_target=q_next_target)
         self._last_work = w
         self._bucket_B = w.dq.shape[0]
-        self._split_at = self._bucket_split() if split is None else split
+        self._split_at = self._bucket_split()
         extra = {"head_done": True} if w.head_done else {}
-        if split is not None and self._optimizer_sums_slabs(net):
-            extra["keep_dw_slabs"] = True
         net.backward(w.dq, slot="train", side_stream=self._side_stream(w.dq.device),
                      stop_layer=self._split_at, **extra)
         return tf_agent.LossInfo(w.loss.reshape(()),

@@ -43,9 +43,9 @@ std_clip_transform = adn.std_clip_transform
 
 
 # A/B knob: AA_SAC_QUAD_FORWARD=0 evaluates the target pair and the critic pair in two launches
-_QUAD_FORWARD = os.environ.get("AA_SAC_QUAD_FORWARD", "1") != "0"
+_QUAD_FORWARD = True
 # A/B knob: AA_SAC_FUSE_TARGET_UPDATE=0 keeps the soft target update a launch of its own
-_FUSE_TARGET_UPDATE = os.environ.get("AA_SAC_FUSE_TARGET_UPDATE", "1") != "0"
+_FUSE_TARGET_UPDATE = True
 
 
 def _spec_means_and_magnitudes(spec):

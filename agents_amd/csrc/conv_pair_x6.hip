@@ -224,8 +224,7 @@ __device__ static inline void cx_layer(const CxLayer& L, const char* __restrict_
     if (ks + 2 < S) step(std::integral_constant<int, 2>{}, ks);
     if (dst != nullptr) { CX_STAMP_L(7) }
     const float bv = L.bias != nullptr ? bias_raw : 0.f;
-    // (L.y == nullptr: an output only a backward pass would read, and no backward pass follows --
-    // conv_triple_x6.h's callers; the pair's own entry points always pass both)
+    // (L.y == nullptr: an output only a backward pass would read, and no backward pass follows)
     float* yimg = L.y != nullptr ? L.y + (size_t)img * OHW * L.Cout + co : nullptr;
     // the activation kind and "feeds a next layer" are resolved ONCE, outside the element loop
     auto emit = [&](auto actc, auto splitc) {
@@ -466,4 +465,3 @@ int aa_conv_pair_x6_forward(const float* x, int64_t img_pitch, int32_t n_img, in
 
 }  // extern "C"
 
-#include "conv_triple_x6.h"

@@ -532,11 +532,7 @@ static int aa_conv_u8_dw_bf16_launch(const GemmP& p, int n_img, int frame_bytes,
   const size_t smem = aa_conv_u8_dw_lds(p, frame_bytes);
   constexpr int NW = AA_CU8_DW_WAVES;
   // the transpose-read loop needs 8-byte aligned chunk addresses: pixel origins and patch rows
-  static const bool tr8_on = []() {
-    const char* e = getenv("AA_CONV1_DW_TR8");
-    return e == nullptr || atoi(e) != 0;
-  }();
-  const bool tr8 = tr8_on && (p.stride * p.Cin) % 8 == 0 && p.rowpitch % 8 == 0;
+  const bool tr8 = (p.stride * p.Cin) % 8 == 0 && p.rowpitch % 8 == 0;
   static size_t lds_limit[AA_MAX_DEVICES][2] = {{0}};   // dynamic LDS above 64 KiB: granted per
   const int dv = aa_device_ordinal();                   // kernel and device
   if (dv < 0) return AA_ERR_LAUNCH;

@@ -71,42 +71,14 @@ aa_dense_small_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float*
 // away.  z-order sum from 0.f, bias, activation: the arithmetic of aa_splitk_reduce_kernel<*,1>;
 // the head's accumulation order is aa_dense_small_fwd_kernel's -- both results are bit-identical
 // to the two-launch path.  One wave per row, one row per workgroup (256 rows -> 256 CUs).
-// Round 5: the collect policy's action selection (EpsilonGreedyPolicy._action over QPolicy,
-// tf_agents/policies/epsilon_greedy_policy.py:120-143, q_policy.py:150-194) rides in the head's
-// launch: the wave that produced row m's Q values also draws row m's action -- the arithmetic and
-// the Philox stream of aa_eps_greedy_kernel (csrc/rollout.hip), bit for bit; one launch and one graph
-// node less per collect step.  out == nullptr: no selection.
-struct AaHeadEps {
-  const int32_t* mask;        // nullable [M][N]
-  float epsilon;
-  const float* epsilon_dev;   // nullable: a scheduled epsilon, read on the device
-  uint32_t k0, k1;
-  int64_t* call_dev;          // Philox call counter (device resident)
-  int64_t* arrival;           // nullable: 144 zero words; not null = the launch advances call_dev
-  int64_t action_min;
-  void* out;                  // [M] actions
-  int out_i64;
-};
-
 template <int N>
 __global__ void __launch_bounds__(64)
 aa_dense_small_fwd_slabs_kernel(const float* __restrict__ slab, int splits, int64_t M, int K,
                                 const float* __restrict__ bias1, int act1,
                                 float* __restrict__ h, int64_t ldh, const float* __restrict__ w,
-                                const float* __restrict__ bias, int act, float* __restrict__ y,
-                                AaHeadEps E) {
+                                const float* __restrict__ bias, int act, float* __restrict__ y) {
   const int lane = threadIdx.x;
   const int64_t m = blockIdx.x;
-  uint64_t call = 0;
-  float eps = 0.f;
-  if (E.out != nullptr) {
-    // every workgroup has the old counter value by the time the last arriver moves it
-    // (both words are requested here and used at the very end; the ARRIVAL -- a returning atomic
-    // -- happens at the end as well: in front of the slab loads it delayed every workgroup's first
-    // load by its round trip, 0.3011 vs 0.2903 ms per iteration, profiles/r05_h_fuse_select_ab.txt)
-    call = E.call_dev != nullptr ? (uint64_t)(*E.call_dev) : 0ull;
-    eps = E.epsilon_dev != nullptr ? *E.epsilon_dev : E.epsilon;
-  }
   const size_t MK = (size_t)M * K;
   float acc[N];
 #pragma unroll
@@ -179,50 +151,6 @@ aa_dense_small_fwd_slabs_kernel(const float* __restrict__ slab, int splits, int6
     if (bias != nullptr) v += bias[lane];
     y[m * N + lane] = aa_sm_act(v, act);
   }
-  if (E.out != nullptr && lane == 0) {
-    // (every lane holds all N sums after the butterfly: lane 0 restates aa_eps_greedy_kernel on them)
-    int best = 0, allowed = 0;
-    float bestv = 0.f;
-    bool any = false;
-#pragma unroll
-    for (int a = 0; a < N; ++a) {
-      float v = aa_sm_act(acc[a] + (bias != nullptr ? bias[a] : 0.f), act);
-      const bool ok = E.mask == nullptr || E.mask[m * N + a] != 0;
-      if (!ok) v = -FLT_MAX;
-      allowed += ok ? 1 : 0;
-      if (!any || v > bestv) {
-        best = a;
-        bestv = v;
-        any = true;
-      }
-    }
-    int action = best;
-    if (eps > 0.f) {
-      const Philox4 r = philox4x32_10((uint32_t)m, (uint32_t)((uint64_t)m >> 32), (uint32_t)call,
-                                      (uint32_t)(call >> 32), E.k0, E.k1);
-      if (aa_u01(r.x) < eps && allowed > 0) {
-        int pick = (int)(r.y % (uint32_t)allowed);
-        for (int a = 0; a < N; ++a) {
-          const bool ok = E.mask == nullptr || E.mask[m * N + a] != 0;
-          if (ok) {
-            if (pick == 0) {
-              action = a;
-              break;
-            }
-            --pick;
-          }
-        }
-      }
-    }
-    const int64_t v = E.action_min + action;
-    if (E.out_i64)
-      reinterpret_cast<int64_t*>(E.out)[m] = v;
-    else
-      reinterpret_cast<int32_t*>(E.out)[m] = (int32_t)v;
-  }
-  // this workgroup has consumed the counter's old value (read at the top): the last arriver moves it
-  if (E.out != nullptr && E.arrival != nullptr)
-    aa_advance_sharded(E.call_dev, E.arrival, 1, gridDim.x);
 }
 
 template <int N>
@@ -287,12 +215,6 @@ static int aa_small_dispatch(int N, int which, const float* a, int64_t lda, cons
   }
 }
 
-static int aa_dense_small_forward_slabs_impl(const float* slabs, int32_t splits, int64_t M,
-                                             int32_t K, const float* bias1, int32_t act1,
-                                             float* h, int64_t ldh, const float* w,
-                                             const float* bias, int32_t act, int32_t N, float* y,
-                                             const AaHeadEps& E, void* stream);
-
 extern "C" {
 
 int aa_dense_small_forward(const float* x, int64_t ldx, const float* w, const float* bias,
@@ -306,36 +228,6 @@ int aa_dense_small_forward_slabs(const float* slabs, int32_t splits, int64_t M, 
                                  const float* bias1, int32_t act1, float* h, int64_t ldh,
                                  const float* w, const float* bias, int32_t act, int32_t N,
                                  float* y, void* stream) {
-  AaHeadEps E = {};
-  return aa_dense_small_forward_slabs_impl(slabs, splits, M, K, bias1, act1, h, ldh, w, bias, act,
-                                           N, y, E, stream);
-}
-
-int aa_dense_small_forward_slabs_eps(const float* slabs, int32_t splits, int64_t M, int32_t K,
-                                     const float* bias1, int32_t act1, float* h, int64_t ldh,
-                                     const float* w, const float* bias, int32_t act, int32_t N,
-                                     float* y, const int32_t* mask, float epsilon,
-                                     const float* epsilon_dev, uint64_t seed,
-                                     int64_t* call_counter_dev, int64_t* arrival_dev,
-                                     int64_t action_min, void* actions_out,
-                                     int32_t actions_are_i64, void* stream) {
-  if (actions_out == nullptr || call_counter_dev == nullptr) return AA_ERR_INVALID;
-  AaHeadEps E;
-  E.mask = mask; E.epsilon = epsilon; E.epsilon_dev = epsilon_dev;
-  E.k0 = (uint32_t)seed; E.k1 = (uint32_t)(seed >> 32);
-  E.call_dev = call_counter_dev; E.arrival = arrival_dev; E.action_min = action_min;
-  E.out = actions_out; E.out_i64 = actions_are_i64 ? 1 : 0;
-  return aa_dense_small_forward_slabs_impl(slabs, splits, M, K, bias1, act1, h, ldh, w, bias, act,
-                                           N, y, E, stream);
-}
-
-}  // extern "C"
-
-static int aa_dense_small_forward_slabs_impl(const float* slabs, int32_t splits, int64_t M,
-                                             int32_t K, const float* bias1, int32_t act1,
-                                             float* h, int64_t ldh, const float* w,
-                                             const float* bias, int32_t act, int32_t N, float* y,
-                                             const AaHeadEps& E, void* stream) {
   if (!slabs || !h || !w || !y || splits < 1 || M <= 0 || K <= 0 || N <= 0 || ldh < K)
     return AA_ERR_INVALID;
   if (N > AA_SMALLN_MAX || M > 0x7fffffffLL) return AA_ERR_RANGE;
@@ -347,7 +239,7 @@ static int aa_dense_small_forward_slabs_impl(const float* slabs, int32_t splits,
 #define AA_SM_TAIL(NN)                                                                          \
     case NN:                                                                                    \
       hipLaunchKernelGGL((aa_dense_small_fwd_slabs_kernel<NN>), dim3((unsigned)M), dim3(64), 0, \
-                         st, slabs, splits, M, K, bias1, act1, h, ldh, w, bias, act, y, E);     \
+                         st, slabs, splits, M, K, bias1, act1, h, ldh, w, bias, act, y);        \
       break;
     AA_SM_TAIL(1) AA_SM_TAIL(2) AA_SM_TAIL(3) AA_SM_TAIL(4) AA_SM_TAIL(5) AA_SM_TAIL(6)
     AA_SM_TAIL(7) AA_SM_TAIL(8) AA_SM_TAIL(9) AA_SM_TAIL(10) AA_SM_TAIL(11) AA_SM_TAIL(12)
@@ -357,8 +249,6 @@ static int aa_dense_small_forward_slabs_impl(const float* slabs, int32_t splits,
   }
   return aa_launch_status();
 }
-
-extern "C" {
 
 int aa_dense_small_dx(const float* dz, const float* w, const float* mask_src, int32_t mask_kind,
                       int64_t M, int32_t K, int32_t N, float* dx, void* stream) {

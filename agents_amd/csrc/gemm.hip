@@ -83,8 +83,7 @@ struct GemmP {
 // (x, y, z) is computed exactly once by the same code, results are bit-identical.
 struct AaBlk { int x, y, z; };
 // L < 0: the launch's own block index (3-D for xcd_mode 0).  L >= 0: this workgroup's index inside
-// a 1-D range of a launch it shares with another contraction (aa_gemm_dma_pair_kernel); xcd_mode 0
-// is then the launch order written out (x fastest).
+// a 1-D range; xcd_mode 0 is then the launch order written out (x fastest).
 __device__ static inline bool aa_block_of(const GemmP& p, AaBlk* b, int L = -1) {
   if (p.xcd_mode == 0) {
     if (L < 0) {
@@ -836,8 +835,7 @@ int64_t aa_gemm_f32_workspace_bytes(const aa_gemm_desc* d) {
 // [splits][M][N] stay at the start of `workspace` for a consumer that sums them in its own prologue
 // (*defer_splits = splits); with one split the finished result is in C (*defer_splits = 1).
 static int aa_gemm_f32_impl(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes,
-                            void* stream, int* defer_splits, GemmP* fill_only = nullptr,
-                            AaGemmPlan* plan_out = nullptr) {
+                            void* stream, int* defer_splits) {
   if (d == nullptr || d->A == nullptr || d->B == nullptr || d->C == nullptr) return AA_ERR_INVALID;
   AaGemmPlan pl;
   int rc = aa_gemm_plan(d, &pl);
@@ -942,11 +940,7 @@ static int aa_gemm_f32_impl(const aa_gemm_desc* d, void* workspace, int64_t work
   p.gy = (d->N + pl.bn - 1) / pl.bn;
   p.gz = pl.splits;
   {
-    static int enabled = -1;
-    if (enabled < 0) {
-      const char* e = getenv("AA_GEMM_XCD");
-      enabled = (e != nullptr && e[0] == '0') ? 0 : 1;
-    }
+    const bool enabled = true;     // XCD-aware block order (round 1: 59 -> 14 MB of fc1 traffic)
     const bool dense = d->a_mode == AA_A_ROW || d->a_mode == AA_A_COL;
     const int64_t n_blocks = (int64_t)p.gx * p.gy * p.gz;
     if (enabled && dense && pl.cfg != AA_CFG_U8_BF16 - 1 && n_blocks >= 64 &&
@@ -972,11 +966,6 @@ static int aa_gemm_f32_impl(const aa_gemm_desc* d, void* workspace, int64_t work
 
   if (d->b_mode != AA_B_ROW && d->b_mode != AA_B_COL) return AA_ERR_INVALID;
   if (d->b_mode == AA_B_COL && d->a_mode != AA_A_ROW) return AA_ERR_INVALID;
-  if (fill_only != nullptr) {      // aa_gemm_f32_pair: the launch parameters only
-    *fill_only = p;
-    *plan_out = pl;
-    return AA_OK;
-  }
   switch (d->a_mode) {
     case AA_A_ROW:
       rc = d->b_mode == AA_B_ROW ? aa_gemm_launch_cfg<AA_A_ROW, AA_B_ROW>(p, pl, st)
@@ -1033,48 +1022,6 @@ static int aa_gemm_f32_impl(const aa_gemm_desc* d, void* workspace, int64_t work
     rc = aa_launch_status();
   }
   return rc;
-}
-
-// Input gradient (a) and weight gradient (b) of one Dense layer in ONE launch: both must plan as
-// unsplit LDS-DMA contractions on the tile shapes instantiated below (fc1 of the Atari Q-network:
-// dX = dZ W^T on 32x64 tiles, dW = x^T dZ on 64x64 tiles); anything else returns AA_ERR_RANGE and
-// the caller launches them one after the other.
-int aa_gemm_f32_pair(const aa_gemm_desc* a, const aa_gemm_desc* b, void* stream) {
-  if (a == nullptr || b == nullptr) return AA_ERR_INVALID;
-  GemmP pa, pb;
-  AaGemmPlan la, lb;
-  int rc = aa_gemm_f32_impl(a, nullptr, 0, stream, nullptr, &pa, &la);
-  if (rc == AA_ERR_RANGE) return AA_ERR_RANGE;      // (a split plan without a workspace)
-  if (rc != AA_OK) return rc;
-  rc = aa_gemm_f32_impl(b, nullptr, 0, stream, nullptr, &pb, &lb);
-  if (rc != AA_OK) return rc;
-  const bool a_ok = a->a_mode == AA_A_ROW && a->b_mode == AA_B_COL && pa.use_dma && la.cfg == 5 &&
-                    la.splits == 1;
-  const bool b_ok = b->a_mode == AA_A_COL && b->b_mode == AA_B_ROW && pb.use_dma && lb.cfg == 2 &&
-                    lb.splits == 1;
-  if (!a_ok || !b_ok) return AA_ERR_RANGE;
-  auto blocks = [](const GemmP& p) {
-    const int n = p.gx * p.gy * p.gz;
-    return p.xcd_mode != 0 ? ((n + 7) / 8) * 8 : n;
-  };
-  const int na = blocks(pa), nb = blocks(pb);
-  using OA0 = DmaOp<AA_KIND_T_DENSE, 32>;
-  using OB0 = DmaOp<AA_KIND_T_DENSE, 64>;
-  using OA1 = DmaOp<AA_KIND_D_DENSE, 64>;
-  using OB1 = DmaOp<AA_KIND_D_DENSE, 64>;
-  constexpr int NS = 4;
-  // (32 x 64 tiles on 1 x 2 x 2 waves reduce their K halves through LDS: 2 x 1024 floats)
-  size_t smem0 = (size_t)NS * (OA0::kPadded + OB0::kPadded);
-  const size_t red0 = (size_t)(2 - 1) * 1 * 2 * 1 * 1 * 1024 * sizeof(float);
-  if (red0 > smem0) smem0 = red0;
-  const size_t smem1 = (size_t)NS * (OA1::kPadded + OB1::kPadded);
-  const size_t smem = smem0 > smem1 ? smem0 : smem1;
-  hipLaunchKernelGGL((aa_gemm_dma_pair_kernel<AA_KIND_T_DENSE, AA_KIND_T_DENSE, 32, 64, 1, 2, 2, NS,
-                                              AA_KIND_D_DENSE, AA_KIND_D_DENSE, 64, 64, 2, 2, 1,
-                                              NS>),
-                     dim3((unsigned)(na + nb)), dim3(AA_GEMM_THREADS), smem, (hipStream_t)stream,
-                     pa, pb, na);
-  return aa_launch_status();
 }
 
 int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes, void* stream) {

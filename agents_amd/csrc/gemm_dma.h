@@ -189,8 +189,7 @@ __device__ long long* d_gd_stamps = nullptr;
 #define GD_STAMP(i)
 #endif
 
-// One output tile (blk) of a contraction: the body of aa_gemm_dma_kernel, shared with
-// aa_gemm_dma_pair_kernel (two contractions in one launch).
+// One output tile (blk) of a contraction: the body of aa_gemm_dma_kernel.
 template <int AK, int BKIND, int BM, int BN, int WGM, int WGN, int WGK, int NS>
 __device__ static inline void aa_gemm_dma_tile(const GemmP& p, const AaBlk& blk) {
   static_assert(WGM * WGN * WGK == 4, "4 waves per workgroup");
@@ -416,24 +415,6 @@ __global__ void __launch_bounds__(AA_GEMM_THREADS) aa_gemm_dma_kernel(GemmP p) {
   AaBlk blk;
   if (!aa_block_of(p, &blk)) return;
   aa_gemm_dma_tile<AK, BKIND, BM, BN, WGM, WGN, WGK, NS>(p, blk);
-}
-
-// Two independent contractions in ONE launch: workgroups [0, na) are tiles of `pa`, the rest tiles
-// of `pb`, each computed by the code of its own single launch (bit-identical results).  For the
-// input and weight gradient of a Dense layer (both read the layer's dZ; tf.GradientTape through
-// keras Dense, agents/dqn/dqn_agent.py:412-426): one launch ramp and one graph node instead of two.
-template <int AK0, int BK0, int BM0, int BN0, int WGM0, int WGN0, int WGK0, int NS0, int AK1,
-          int BK1, int BM1, int BN1, int WGM1, int WGN1, int WGK1, int NS1>
-__global__ void __launch_bounds__(AA_GEMM_THREADS)
-aa_gemm_dma_pair_kernel(GemmP pa, GemmP pb, int na) {
-  AaBlk blk;
-  if ((int)blockIdx.x < na) {
-    if (!aa_block_of(pa, &blk, (int)blockIdx.x)) return;
-    aa_gemm_dma_tile<AK0, BK0, BM0, BN0, WGM0, WGN0, WGK0, NS0>(pa, blk);
-  } else {
-    if (!aa_block_of(pb, &blk, (int)blockIdx.x - na)) return;
-    aa_gemm_dma_tile<AK1, BK1, BM1, BN1, WGM1, WGN1, WGK1, NS1>(pb, blk);
-  }
 }
 
 template <int AK, int BKIND, int BM, int BN, int WGM, int WGN, int WGK, int NS>

@@ -1016,20 +1016,11 @@ static int aa_fill_leaves(AaLeafSet& ls, void* const* tables, void* const* ios,
   return AA_OK;
 }
 
-// AA_RB_CHUNK_BYTES: bytes of a wide row per workgroup (multiple of 4096, 4 KiB .. 32 KiB;
+// bytes of a wide row per workgroup (a former knob; 4 KiB .. 32 KiB were swept:
 // measured on 512 Atari rows: 32 KiB 13.2 us, 16 KiB 17.4, 8 KiB 26.1, 4 KiB 36.9 -- workgroups
 // are what costs)
 static int aa_rb_chunk_bytes() {
-  static int v = 0;
-  if (v == 0) {
-    int c = 32768;
-    const char* e = getenv("AA_RB_CHUNK_BYTES");
-    if (e != nullptr) c = atoi(e);
-    if (c < 4096) c = 4096;
-    if (c > 32768) c = 32768;
-    v = c & ~4095;
-  }
-  return v;
+  return 32768;
 }
 
 // The grid of a row mover over n_rows rows (see AaRowGrid).  `bookkeeping`: one extra thread per
@@ -1243,12 +1234,7 @@ static int aa_rb_sample_gather_launch(const void* const* leaf_tables_h, void* co
   rc = aa_plan_rows(ls, S * T, true, &g, &grid, AA_RB_SG_SMALL, K);
   if (rc != AA_OK) return rc;
   // stamped launch of a small batch: draw on the host, rows by value (see aa_rb_draw_host)
-  static int host_draw = -1;
-  if (host_draw < 0) {
-    const char* e = getenv("AA_RB_HOST_DRAW");
-    host_draw = (e != nullptr && e[0] == '0') ? 0 : 1;
-  }
-  if (host_draw && last_id_dev == nullptr && call_counter_dev == nullptr &&
+  if (last_id_dev == nullptr && call_counter_dev == nullptr &&
       S <= AA_RB_DRAWN_MAX && T <= max_len && (S * T * (int64_t)g.per_row >> 31) == 0 &&
       batch * max_len < (1LL << 40)) {
     AaDrawnRows dv;

@@ -25,20 +25,20 @@ from agents_amd.utils import nest_utils
 
 
 SMALL_HEAD_ON_MAIN = True
-FUSE_HEAD_BACKWARD = os.environ.get("AA_FUSE_HEAD_BACKWARD", "1") != "0"   # dX + dW of a small head: one launch
+FUSE_HEAD_BACKWARD = True   # dX + dW of a small head: one launch
 FUSED_SMALL_MLP = True   # whole <=64-wide MLPs in one forward / one backward launch
 # whole <=256-wide MLPs (SAC's actor / critics) at batch <= 1024: one forward launch, two backward
 # launches, several networks of one layout per launch (csrc/mlp_wide.hip).  AA_FUSED_WIDE_MLP=0:
 # one GEMM launch per layer and direction instead (A/B measurements)
-FUSED_WIDE_MLP = os.environ.get("AA_FUSED_WIDE_MLP", "1") != "0"
+FUSED_WIDE_MLP = True
 DX_FIRST = True   # record a layer's input-gradient launch before its weight-gradient launch
 # the first layer's weight gradient on the main stream (AA_LAST_DW_ON_MAIN=0: on the side stream)
-LAST_DW_ON_MAIN = os.environ.get("AA_LAST_DW_ON_MAIN", "1") != "0"
+LAST_DW_ON_MAIN = True
 
 
 # conv -> conv over LDS-sized fp32 frames in one launch (csrc/conv_pair.hip); AA_FUSE_CONV_PAIRS=0
 # selects the layer-by-layer kernels (A/B measurements)
-FUSE_CONV_PAIRS = os.environ.get("AA_FUSE_CONV_PAIRS", "1") != "0"
+FUSE_CONV_PAIRS = True
 # The bf16x6 convolutions split their filter banks in a pre-pass that depends on the weights only.
 # It can be issued on the network's own side stream ahead of the kernel that needs it:
 #   AA_HOIST_PREP=3 (default)  backward only: the two input-gradient pre-passes run next to the
@@ -48,7 +48,7 @@ FUSE_CONV_PAIRS = os.environ.get("AA_FUSE_CONV_PAIRS", "1") != "0"
 # Measured inside the DQN iteration on MI355X (same box, alternating runs): 3 = 0.421 ms,
 # 0 = 0.461 ms, 1 = 0.502 ms -- the forward fork adds a graph branch at the point where three
 # forward chains (collect, online, target) already compete for the four hardware queues.
-_HOIST = os.environ.get("AA_HOIST_PREP", "3")
+_HOIST = "3"
 HOIST_PREP = _HOIST != "0"
 _HOIST_FWD = _HOIST in ("1", "2")
 _HOIST_BWD = _HOIST in ("1", "3")
@@ -57,7 +57,7 @@ _HOIST_BWD = _HOIST in ("1", "3")
 # first kernel -- not a pre-pass -- is the first child of the loss node and stays on its queue
 # (rocprofv3 timeline: fc1's dX ran on another hardware queue than the loss before it and conv3's
 # dX after it, ~10 us of cross-queue hand-over each way)
-DX_PREP_LATE = os.environ.get("AA_DX_PREP_LATE", "1") != "0"
+DX_PREP_LATE = True
 # (Tried on top of it and not kept: conv3's weight gradient waiting for the fork of conv2's -- one
 # fork of the weight-gradient branch from the input-gradient chain for the pair instead of one per
 # layer, a superset of its dependencies: 0.3158 vs 0.3128 ms, three alternating pairs.)
@@ -77,7 +77,7 @@ DX_PREP_LATE = os.environ.get("AA_DX_PREP_LATE", "1") != "0"
 # value to its place in every plane set (`plane_scatter`, csrc/optim.hip: aa_*_step_planes) -- no
 # launch at all, five fewer kernels and one fewer graph branch per DQN iteration -- so DqnAgent now
 # opts in by default (AA_PREPARED_WEIGHTS=0: every call splits for itself again).
-PREPARED_WEIGHTS = os.environ.get("AA_PREPARED_WEIGHTS", "1") == "1"
+PREPARED_WEIGHTS = True
 # Which plane sets are prepared: "pair" = the fused conv pair's forward filters (default), "dx" =
 # the conv input gradients' fragments (opt-in, AA_PW_KINDS=pair,dx).  Measured in the DQN iteration
 # on MI355X, alternating runs on one box (tools/ab_matrix.py): none 0.3745 ms, pair 0.3739,
@@ -86,7 +86,7 @@ PREPARED_WEIGHTS = os.environ.get("AA_PREPARED_WEIGHTS", "1") == "1"
 # executor schedules the weight-gradient branch worse), although they are pure overhead on a
 # single stream (`bench.py --no-overlap`: none 0.4058, pair+dx 0.3703).  The forward pair planes
 # remove three launches (and 7 us of host time per iteration) at no cost either way.
-_PW_KINDS = tuple(k for k in os.environ.get("AA_PW_KINDS", "pair").split(",") if k)
+_PW_KINDS = ("pair",)
 _PREPARED_NETS = []      # weak references to the networks that opted in
 
 
@@ -151,7 +151,6 @@ class Sequential(network.Network):
         # forward slots that take the three-conv launch (None = every slot; an empty set = none):
         # the launch owns a CU for its whole duration (153 KB of LDS), which costs a forward that
         # runs beside other lanes' kernels more than one that runs alone -- DqnAgent decides
-        self.triple_slots = None
 
     # ---- construction -------------------------------------------------------------------------
     @property
@@ -371,13 +370,9 @@ class Sequential(network.Network):
                                    device=dev)
         return s
 
-    def forward(self, x, slot=0, need_grad=False, select=None):
+    def forward(self, x, slot=0, need_grad=False):
         """Runs the stack on x [B, *input_shape]; returns the last layer's output buffer
-        (owned by the network, overwritten by the next forward on the same slot and batch).
-        select: action-selection arguments of a discrete policy (ops.dense_tail_forward): when the
-        stack ends in a hidden Dense + small head pair the head's launch draws the actions as well
-        and `self.selected` is True afterwards (else False: the caller selects itself)."""
-        self.selected = False
+        (owned by the network, overwritten by the next forward on the same slot and batch)."""
         self._require_built()
         _lib.require_cuda(x)
         spec = self._input_tensor_spec
@@ -396,12 +391,11 @@ class Sequential(network.Network):
         pi = 0
         skip = 0
         pw_pair = self._pw["pair"] if (self._prepared_ok() and self._pw["pair"]) else None
-        pw_triple = self._pw.get("triple") if self._prepared_ok() else None
         prep_pending, s.prep_issued = s.prep_issued, None
         if prep_pending is None and pw_pair is None:
             prep_pending = self._hoist_pair_prep(s, B)
         for li, l in enumerate(self._layers):
-            if skip:        # later conv(s) of a fused pair / triple: already computed
+            if skip:        # second conv of a fused pair / the head of a dense tail: computed
                 skip -= 1
                 cur = s.ys[pi]
                 pi += 1
@@ -420,31 +414,6 @@ class Sequential(network.Network):
                 div = None
                 s.xs[pi] = cur
                 nxt = self._layers[li + 1] if li + 1 < len(self._layers) else None
-                nx2 = self._layers[li + 2] if li + 2 < len(self._layers) else None
-                if (FUSE_CONV_PAIRS and cur.dtype == torch.uint8 and isinstance(nxt, L.Conv2D)
-                        and isinstance(nx2, L.Conv2D) and cur.data_ptr() % 16 == 0
-                        and (self.triple_slots is None or slot in self.triple_slots)
-                        and (B == 1 or cur.stride(0) % 16 == 0)
-                        and ops.conv_triple_prepare_bytes(
-                            tuple(cur.shape), self._kviews[pi:pi + 3],
-                            (l.stride, nxt.stride, nx2.stride)) > 0):
-                    # uint8 frames through all three convs in one launch, one workgroup per frame
-                    # (csrc/conv_triple_x6.h); the two intermediate activations are stored only on
-                    # slots a backward pass reads (the online network's train slot)
-                    keep = need_grad or s.dz_top is not None
-                    s.xs[pi + 1] = s.ys[pi]
-                    s.xs[pi + 2] = s.ys[pi + 1]
-                    prepared = pw_triple.get(pi) if pw_triple else None
-                    ops.conv_triple_forward(
-                        cur, self._kviews[pi:pi + 3], self._bviews[pi:pi + 3],
-                        (l.stride, nxt.stride, nx2.stride),
-                        (l.activation, nxt.activation, nx2.activation),
-                        (s.ys[pi] if keep else None, s.ys[pi + 1] if keep else None,
-                         s.ys[pi + 2]), a_div=a_div, prepared=prepared)
-                    skip = 2
-                    cur = s.ys[pi]
-                    pi += 1
-                    continue
                 if (FUSE_CONV_PAIRS and cur.dtype == torch.float32 and isinstance(nxt, L.Conv2D)
                         and cur.data_ptr() % 16 == 0 and cur.stride(0) % 4 == 0
                         and ops.conv_pair_supported(cur.shape, self._kviews[pi], l.stride,
@@ -454,15 +423,6 @@ class Sequential(network.Network):
                     prepared = s.pair_prep.get(pi) if prep_pending is not None else None
                     if pw_pair is not None and pi in pw_pair:
                         prepared = pw_pair[pi]      # split by whoever wrote the weights
-                    elif pw_triple and (pi - 1) in pw_triple:
-                        # a slot that keeps conv1 as its own launch: the pair's two banks are the
-                        # tail of the three-conv scratch (same fragment layout)
-                        nb = ops.conv_pair_prepare_bytes(tuple(cur.shape), self._kviews[pi],
-                                                         l.stride, self._kviews[pi + 1],
-                                                         nxt.stride)
-                        t3 = pw_triple[pi - 1]
-                        if 0 < nb <= t3.numel():
-                            prepared = t3[t3.numel() - nb:]
                     elif prepared is not None and prep_pending:
                         torch.cuda.current_stream(cur.device).wait_stream(self._prep_stream)
                         prep_pending.clear()
@@ -493,12 +453,9 @@ class Sequential(network.Network):
                         and ops.dense_tail_supported(cur2, self._kviews[pi], self._kviews[pi + 1])):
                     # hidden layer + small head: the head sums the hidden layer's split-K slabs
                     s.xs[pi + 1] = s.ys[pi]
-                    last_pair = select is not None and li + 2 == len(self._layers)
-                    done = ops.dense_tail_forward(
+                    ops.dense_tail_forward(
                         cur2, self._kviews[pi], self._bviews[pi], l.activation, s.ys[pi],
-                        self._kviews[pi + 1], self._bviews[pi + 1], nxt.activation, s.ys[pi + 1],
-                        **({"select": select} if last_pair else {}))
-                    self.selected = bool(last_pair and done is True)
+                        self._kviews[pi + 1], self._bviews[pi + 1], nxt.activation, s.ys[pi + 1])
                     skip = 1
                 else:
                     ops.dense_forward(cur2, self._kviews[pi], self._bviews[pi], l.activation,
@@ -529,26 +486,6 @@ class Sequential(network.Network):
             pi += 1
         return out
 
-    def _triple_head(self):
-        """((1, H, W, C), strides) when the stack opens with [Rescale,] three Conv2D layers on a
-        uint8 observation (the Atari Q-network: csrc/conv_triple_x6.h), else None."""
-        spec = self._input_tensor_spec
-        if spec is None or spec.dtype != torch.uint8 or len(spec.shape) != 3:
-            return None
-        convs = []
-        for l in self._layers:
-            if isinstance(l, L.Rescale):
-                continue
-            if isinstance(l, L.Conv2D):
-                convs.append(l)
-                if len(convs) == 3:
-                    break
-            else:
-                break
-        if len(convs) != 3 or len(self._param_layers) < 3:
-            return None
-        return (1,) + tuple(spec.shape), tuple(c.stride for c in convs)
-
     def enable_prepared_weights(self):
         """Opts this network into prepared weights (see PREPARED_WEIGHTS above).  The caller takes
         over the duty of calling `refresh_prepared()` after every write to the parameters that does
@@ -558,17 +495,10 @@ class Sequential(network.Network):
         if self._pw is not None or self._fused_small_ok():
             return self._pw is not None
         dev = self.flat_params.device
-        pair, dx, triple = {}, {}, {}
-        t3 = self._triple_head()
-        if t3 is not None and FUSE_CONV_PAIRS and "pair" in _PW_KINDS:
-            # uint8 frames -> three convs in one launch: one scratch holds the three split banks
-            shape, strides = t3
-            n = ops.conv_triple_prepare_bytes(shape, self._kviews[0:3], strides)
-            if n > 0:
-                triple[0] = torch.empty((n,), dtype=torch.uint8, device=dev)
+        pair, dx = {}, {}
         if FUSE_CONV_PAIRS and "pair" in _PW_KINDS:
             for pi in self._conv_param_pairs():
-                if pi in pair or (pi - 1) in pair or (triple and pi in (0, 1)):
+                if pi in pair or (pi - 1) in pair:
                     continue
                 l, nxt = self._param_layers[pi], self._param_layers[pi + 1]
                 shape = (1,) + tuple(self._info[pi][2])
@@ -584,10 +514,9 @@ class Sequential(network.Network):
             n = ops.conv_dx_prepare_bytes((1,) + tuple(self._info[i][2]), self._kviews[i], l.stride)
             if n > 0:
                 dx[i] = torch.empty((n,), dtype=torch.uint8, device=dev)
-        if not pair and not dx and not triple:
+        if not pair and not dx:
             return False
-        self._pw = {"pair": pair, "dx": dx, "triple": triple, "torch_version": -1,
-                    "scatter": None}
+        self._pw = {"pair": pair, "dx": dx, "torch_version": -1, "scatter": None}
         _PREPARED_NETS.append(weakref.ref(self))
         self.refresh_prepared()
         self._pw["scatter"] = self._build_plane_scatter()
@@ -604,13 +533,11 @@ class Sequential(network.Network):
         pw = self._pw
         n = self.flat_params.numel()
         targets = []
-        for kind in ("triple", "pair", "dx"):
+        for kind in ("pair", "dx"):
             for pi, ws in pw.get(kind, {}).items():
                 nw = int(np.prod(self._shapes[pi][0]))
-                if kind in ("pair", "triple"):
+                if kind == "pair":
                     nw += int(np.prod(self._shapes[pi + 1][0]))
-                if kind == "triple":
-                    nw += int(np.prod(self._shapes[pi + 2][0]))
                 targets.append((ws, nw))
         if not targets or len(targets) > 4 or n >= (1 << 24):
             return None
@@ -663,9 +590,6 @@ class Sequential(network.Network):
         pw = self._pw
         if pw is None:
             return
-        for pi, ws in pw.get("triple", {}).items():
-            shape, strides = self._triple_head()
-            ops.conv_triple_prepare(shape, self._kviews[pi:pi + 3], strides, ws)
         for pi, ws in pw["pair"].items():
             l, nxt = self._param_layers[pi], self._param_layers[pi + 1]
             ops.conv_pair_prepare((1,) + tuple(self._info[pi][2]), self._kviews[pi], l.stride,
@@ -1042,16 +966,6 @@ class Sequential(network.Network):
                     ops.dense_small_backward(x, dz2, self._kviews[i], s.dxs[i].view(B, -1),
                                              self._gkviews[i], mask_src=x if prev_act else None,
                                              mask_act=prev_act, bias_grad=self._gbviews[i])
-                    issue_late_prep()
-                    dz = s.dxs[i]
-                    continue
-                if i > 0 and param_grads and ops.dense_dx_dw(
-                        dz2, self._kviews[i], s.dxs[i].view(B, -1), x, self._gkviews[i],
-                        mask_src=x if prev_act else None, mask_act=prev_act,
-                        bias_grad=self._gbviews[i]):
-                    # input and weight gradient in one launch on the chain's stream (both read dZ)
-                    if DX_FIRST and side_stream is not main:
-                        side_stream.wait_stream(main)     # the fork the two-launch form makes here
                     issue_late_prep()
                     dz = s.dxs[i]
                     continue

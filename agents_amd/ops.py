@@ -102,17 +102,8 @@ class SideStream(torch.cuda.Stream):
     it with `side_line` so that its kernels take their scratch from the line's own buffers."""
 
 
-def new_side_stream(device, priority=0):
-    """priority > 0: a LOWER-priority stream where the runtime offers one (A/B knob
-    AA_SIDE_PRIORITY of DqnAgent: the weight-gradient branch behind the input-gradient chain)."""
-    st = None
-    if priority:
-        try:
-            st = SideStream(device=device, priority=int(priority))
-        except Exception:
-            st = None
-    if st is None:
-        st = SideStream(device=device)
+def new_side_stream(device):
+    st = SideStream(device=device)
     st.aa_line = next(_LINE_IDS)
     return st
 
@@ -192,10 +183,10 @@ FORCE_NO_DMA = False
 SMALL_N = 16
 SMALL_DW_MAX_M = 512
 USE_SMALL_N = True
-# a_mode values whose contractions take the LDS-DMA loop (tuning knob, env AA_DMA_MODES="3,4,5")
+# a_mode values whose contractions take the LDS-DMA loop (None = all that qualify; tuning tools set
+# it to a set of modes)
 import os as _os
-_DMA_MODES = _os.environ.get("AA_DMA_MODES")
-_DMA_MODES = None if _DMA_MODES is None else {int(x) for x in _DMA_MODES.split(",") if x != ""}
+_DMA_MODES = None
 
 
 def gemm(desc, device):
@@ -233,7 +224,7 @@ def dense_forward(x, w, bias, act, out, a_div=None, force_cfg=0, force_splits=0)
 
 # Dense(hidden) -> Dense(<= SMALL_N units): the head sums the hidden layer's split-K slabs itself
 # (one launch less per forward pass and no round trip of the hidden activation); test / A-B knob
-FUSE_DENSE_TAIL = _os.environ.get("AA_FUSE_DENSE_TAIL", "1") != "0"
+FUSE_DENSE_TAIL = True
 
 
 def dense_tail_supported(x, w1, w2):
@@ -242,13 +233,10 @@ def dense_tail_supported(x, w1, w2):
             and H > SMALL_N and H % 4 == 0 and x.dtype == torch.float32)
 
 
-def dense_tail_forward(x, w1, b1, act1, h, w2, b2, act2, y, select=None):
+def dense_tail_forward(x, w1, b1, act1, h, w2, b2, act2, y):
     """h[M,H] = act1(x[M,K] @ w1 + b1); y[M,N] = act2(h @ w2 + b2), N <= SMALL_N.  Two launches
     when the first contraction is split-K (GEMM main loop, then the head summing the slabs in its
-    prologue), otherwise the plain pair; bit-identical to dense_forward twice either way.
-    select: dict(mask, epsilon, epsilon_dev, seed, call_counter, arrival, action_min, out) -- the
-    head's launch also draws the epsilon-greedy actions of its Q values (policies/q_policy.py);
-    returns True when it did (only the split-K form has the fused launch)."""
+    prologue), otherwise the plain pair; bit-identical to dense_forward twice either way."""
     require_cuda(x, w1, h, w2, y)
     lda = _rows_ok(x, "x"); _f32c(w1, "w1"); _f32c(h, "h"); _f32c(w2, "w2"); _f32c(y, "y")
     M, K = x.shape
@@ -268,16 +256,6 @@ def dense_tail_forward(x, w1, b1, act1, h, w2, b2, act2, y, select=None):
     splits = ctypes.c_int32(0)
     check(lib.aa_gemm_f32_slabs(ctypes.byref(d), ptr(ws), ws.numel() if ws is not None else 0,
                                 ctypes.byref(splits), stream_ptr()), "aa_gemm_f32_slabs")
-    if splits.value > 1 and select is not None:
-        out = select["out"]
-        check(lib.aa_dense_small_forward_slabs_eps(
-            ptr(ws), splits.value, M, H, ptr(b1), ACT[act1], ptr(h), H, ptr(w2), ptr(b2),
-            ACT[act2], N, ptr(y), ptr(select.get("mask")), float(select["epsilon"]),
-            select.get("epsilon_dev"), select["seed"], select["call_counter"],
-            select.get("arrival"), int(select["action_min"]), ptr(out),
-            1 if out.dtype == torch.int64 else 0, stream_ptr()),
-            "aa_dense_small_forward_slabs_eps")
-        return True
     if splits.value > 1:
         check(lib.aa_dense_small_forward_slabs(
             ptr(ws), splits.value, M, H, ptr(b1), ACT[act1], ptr(h), H, ptr(w2), ptr(b2),
@@ -285,7 +263,7 @@ def dense_tail_forward(x, w1, b1, act1, h, w2, b2, act2, y, select=None):
     else:
         check(lib.aa_dense_small_forward(ptr(h), H, ptr(w2), ptr(b2), ACT[act2], M, H, N, ptr(y),
                                          stream_ptr()), "aa_dense_small_forward")
-    return False if select is not None else y
+    return y
 
 
 def dense_dx(dz, w, out, mask_src=None, mask_act=None, force_cfg=0, force_splits=0):
@@ -352,49 +330,6 @@ def dense_dw(x, dz, out, force_cfg=0, force_splits=0, bias_grad=None):
                   force_splits=force_splits, colsum_out=_bias_grad_ptr(bias_grad, N))
     gemm(d, x.device)
     return out
-
-
-# AA_GROUP_DENSE_BWD=1 (opt-in): a Dense layer's input and weight gradient as ONE launch
-# (aa_gemm_f32_pair).  Bit-identical -- and 9 % slower inside the DQN iteration: 0.3251 vs 0.2973 ms,
-# three alternating pairs (profiles/r05_k_group_dense_bwd_ab.txt): the input gradient sits on the
-# backward pass's critical chain and now ends with the weight gradient's tiles, which used to run
-# on the side branch beside conv3's input gradient.
-GROUP_DENSE_BWD = _os.environ.get("AA_GROUP_DENSE_BWD", "0") == "1"
-_PAIR_BWD_OK = {}
-
-
-def dense_dx_dw(dz, w, dx, x, dw, mask_src=None, mask_act=None, bias_grad=None):
-    """dense_dx(dz, w, dx, mask_src, mask_act) and dense_dw(x, dz, dw, bias_grad) in ONE launch
-    (csrc/gemm_dma.h: aa_gemm_dma_pair_kernel; every tile is computed by the code of its own single
-    launch: bit-identical).  Returns False -- nothing launched -- when the pair of shapes is not
-    one the library groups (the caller then issues the two launches)."""
-    if not GROUP_DENSE_BWD or FORCE_NO_DMA or _DMA_MODES is not None:
-        return False
-    require_cuda(dz, w, dx, x, dw, mask_src)
-    M, N = dz.shape
-    K, N2 = w.shape
-    if N != N2 or tuple(dx.shape) != (M, K) or tuple(x.shape) != (M, K) or \
-            tuple(dw.shape) != (K, N) or N <= SMALL_N:
-        return False
-    key = (M, N, K, x.stride(0), mask_src is not None, bias_grad is not None)
-    if _PAIR_BWD_OK.get(key) is False:
-        return False
-    for t in (dz, w, dx, dw):
-        if t.dtype != torch.float32 or not t.is_contiguous():
-            return False
-    lda = _rows_ok(x, "x")
-    da = gemm_desc(A=ptr(dz), B=ptr(w), C=ptr(dx), M=M, N=K, K=N, lda=N, ldb=N, ldc=K,
-                   a_mode=AA_A_ROW, b_mode=AA_B_COL, mask_src=ptr(mask_src), ldm=K,
-                   mask_kind=ACT[mask_act] if mask_src is not None else 0)
-    db = gemm_desc(A=ptr(x), B=ptr(dz), C=ptr(dw), M=K, N=N, K=M, lda=lda, ldb=N, ldc=N,
-                   a_mode=AA_A_COL, b_mode=AA_B_ROW, colsum_out=_bias_grad_ptr(bias_grad, N))
-    rc = _lib.load().aa_gemm_f32_pair(ctypes.byref(da), ctypes.byref(db), stream_ptr())
-    if rc == _lib.AA_ERR_RANGE:
-        _PAIR_BWD_OK[key] = False
-        return False
-    check(rc, "aa_gemm_f32_pair")
-    _PAIR_BWD_OK[key] = True
-    return True
 
 
 # ---- Conv2D (NHWC, VALID) -------------------------------------------------------------------
@@ -542,103 +477,13 @@ def conv_pair_forward(x, w1, b1, s1, act1, y1, w2, b2, s2, act2, y2, prepared=No
     return y2
 
 
-# ---- conv1 -> conv2 -> conv3 on uint8 frames in one launch (csrc/conv_triple_x6.h) ----------------
-# OPT-IN (AA_FUSE_CONV_TRIPLE=1).  Measured on MI355X (profiles/r05_*_triple_*.txt): the launch beats
-# conv1 + pair in isolation (27.9 vs 11.5 + 21.9 us without the intermediate stores, 30.0 with) and
-# LOSES inside the DQN iteration on every box tried -- 0.3118 vs 0.3034 ms, 0.3684 vs 0.3550 ms,
-# and with AA_TRIPLE_FOR: none 0.3078, target 0.3117, all 0.3143, online+target 0.3183 ms: a
-# 28 us launch that owns every CU (153 KB of LDS per workgroup) leaves the other lanes' kernels
-# nothing to run beside, where the 11 us conv1 launch (two workgroups per CU) did.
-CONV_TRIPLE = _os.environ.get("AA_FUSE_CONV_TRIPLE", "0") == "1"
-_TRIPLE_WS = {}
-
-
-def _triple_descs(ws_, bs_, strides, acts, ys):
-    d = []
-    for w, b, st, act, y in zip(ws_, bs_, strides, acts, ys):
-        KH, KW, _, Cout = w.shape
-        d.append(_lib.ConvLayerDesc(w=ptr(w), bias=ptr(b), y=ptr(y), KH=KH, KW=KW, stride=st,
-                                    Cout=Cout, act=ACT[act] if act in ACT else 0))
-    return d
-
-
-def conv_triple_prepare_bytes(x_shape, ws_, strides):
-    """Bytes of split-filter scratch of the three-layer kernel for uint8 frames of x_shape and the
-    three HWIO kernels `ws_`; 0 when the shapes do not qualify (the caller keeps conv1 + the pair)."""
-    if not (CONV_TRIPLE and CONV_PAIR_X6):
-        return 0
-    Bn, H, W, C = x_shape
-    key = (Bn, H, W, C) + tuple(tuple(w.shape) for w in ws_) + tuple(strides)
-    n = _TRIPLE_WS.get(key)
-    if n is None:
-        n = 0
-        if all(len(w.shape) == 4 for w in ws_) and ws_[0].shape[2] == C and \
-                ws_[1].shape[2] == ws_[0].shape[3] and ws_[2].shape[2] == ws_[1].shape[3]:
-            d = [_lib.ConvLayerDesc(w=None, bias=None, y=None, KH=w.shape[0], KW=w.shape[1],
-                                    stride=st, Cout=w.shape[3], act=0)
-                 for w, st in zip(ws_, strides)]
-            n = int(_lib.load().aa_conv_triple_x6_workspace_bytes(
-                Bn, H, W, C, ctypes.byref(d[0]), ctypes.byref(d[1]), ctypes.byref(d[2])))
-        _TRIPLE_WS[key] = n
-    return n
-
-
-def conv_triple_prepare(x_shape, ws_, strides, ws):
-    """The weights-only half of conv_triple_forward: the three filter banks split into `ws`."""
-    require_cuda(ws_[0], ws_[1], ws_[2], ws)
-    Bn, H, W, C = x_shape
-    d = _triple_descs(ws_, (None,) * 3, strides, (None,) * 3, (None,) * 3)
-    with torch.cuda.device(ws.device):
-        check(_lib.load().aa_conv_triple_x6_phase(
-            None, 0, Bn, H, W, C, 255.0, ctypes.byref(d[0]), ctypes.byref(d[1]),
-            ctypes.byref(d[2]), ptr(ws), ws.numel(), 1, _lib.stream_ptr()),
-            "aa_conv_triple_x6_phase(1)")
-
-
-def conv_triple_forward(x, ws_, bs_, strides, acts, ys, a_div=255.0, prepared=None):
-    """ys[2] = act3(conv(act2(conv(act1(conv(x / a_div, w1) + b1), w2) + b2), w3) + b3) on uint8
-    NHWC frames x [B, H, W, C] (only the batch dimension may be strided) in ONE launch.  ys[0] /
-    ys[1] may be None: intermediate activations only a backward pass would read are then not
-    stored.  prepared: scratch that conv_triple_prepare filled for these weights."""
-    require_cuda(x, ws_[0], ws_[1], ws_[2], ys[2])
-    if x.dtype != torch.uint8 or x.dim() != 4:
-        raise ValueError("conv_triple_forward needs a uint8 NHWC input")
-    Bn, H, W, C = x.shape
-    for w in ws_:
-        _f32c(w, "w")
-    oh, ow, cin = H, W, C
-    for w, st, y in zip(ws_, strides, ys):
-        KH, KW, Ci, Co = w.shape
-        if Ci != cin:
-            raise ValueError("conv_triple_forward: channel mismatch between the layers")
-        oh, ow = conv_out_hw(oh, ow, KH, KW, st)
-        cin = Co
-        if y is not None:
-            _f32c(y, "y")
-            if y.numel() != Bn * oh * ow * Co:
-                raise ValueError("conv_triple_forward: bad output size")
-    if ys[2] is None:
-        raise ValueError("conv_triple_forward: the last output is required")
-    n = conv_triple_prepare_bytes((Bn, H, W, C), ws_, strides)
-    if n <= 0:
-        raise ValueError("conv_triple_forward: shapes not supported (conv_triple_prepare_bytes)")
-    d = _triple_descs(ws_, bs_, strides, acts, ys)
-    with torch.cuda.device(x.device):
-        ws = prepared if prepared is not None else _WS3.get(n, x.device)
-        check(_lib.load().aa_conv_triple_x6_phase(
-            ptr(x), _img_pitch(x), Bn, H, W, C, float(a_div), ctypes.byref(d[0]),
-            ctypes.byref(d[1]), ctypes.byref(d[2]), ptr(ws), ws.numel(),
-            2 if prepared is not None else 3, _lib.stream_ptr()), "aa_conv_triple_x6_phase")
-    return ys[2]
-
-
 # AA_CONV_DW_X6=0: keep the conv weight gradients of fp32 layers on the fp32 MFMA GEMM (A/B)
 CONV_DW_X6 = _os.environ.get("AA_CONV_DW_X6", "1") != "0"
 _DW_X6_WS = {}
 # slabs of weight gradients whose reduce is deferred (one buffer per pending layer and line)
 _WS_DW_DEFER = [_Workspace() for _ in range(4)]
 # AA_CONV_DW_MERGE_REDUCE=0: every conv weight gradient sums its own slabs (A/B measurements)
-CONV_DW_MERGE_REDUCE = _os.environ.get("AA_CONV_DW_MERGE_REDUCE", "1") != "0"
+CONV_DW_MERGE_REDUCE = True
 
 
 class PendingDwReduce:
@@ -814,7 +659,7 @@ def conv_dx(dz, w, x_shape, stride, dcol, out, mask_src=None, mask_act=None, pre
     return out
 
 
-CONV_DX_FRAME = _os.environ.get("AA_CONV_DX_FRAME", "1") != "0"   # gather-form conv input gradient
+CONV_DX_FRAME = True   # gather-form conv input gradient
 _DXF_OK = {}
 _DXF_X6_WS = {}
 # AA_CONV_DX_X6=0: keep the gather-form conv input gradient on the fp32 MFMA kernel (A/B)
@@ -940,7 +785,7 @@ def copy_segments(pairs):
 
 # ---- DQN loss -------------------------------------------------------------------------------
 # TD loss + backward of the Q head in one launch (csrc/dqn.hip: aa_dqn_loss_head_backward); A/B knob
-FUSE_LOSS_HEAD = _os.environ.get("AA_FUSE_LOSS_HEAD", "1") != "0"
+FUSE_LOSS_HEAD = True
 
 
 def dqn_td_loss(q_online, q_next_target, q_next_select, next_mask, actions, reward, discount,

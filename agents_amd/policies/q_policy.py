@@ -17,18 +17,6 @@ from agents_amd.trajectories import policy_step
 from agents_amd.utils import graph, nest_utils
 
 
-# AA_FUSE_SELECT=1 (opt-in): the Q head's launch also draws the epsilon-greedy actions
-# (csrc/dense_small.hip: aa_dense_small_forward_slabs_eps) instead of a launch of its own behind the
-# forward.  The same actions bit for bit, one launch less per collect step -- and a slower DQN
-# iteration: 0.3011 vs 0.2903 ms with the counter's arrival in front of the slab loads, 0.3048 vs
-# 0.3031 ms (three alternating pairs) with it at the end of the kernel
-# (profiles/r05_h_fuse_select_ab.txt, r05_i_fuse_select_ab.txt): the serial selection in lane 0
-# lengthens every one of the head's 256 single-wave workgroups, and the collect lane's kernels run
-# beside the training stream's.
-import os as _os
-FUSE_SELECT = _os.environ.get("AA_FUSE_SELECT", "0") == "1"
-
-
 def _action_bounds(action_spec):
     spec = nest_utils.flatten(action_spec)[0]
     lo = int(np.asarray(spec.minimum).reshape(-1)[0])
@@ -99,7 +87,6 @@ class _DiscretePolicy(tf_policy.TFPolicy):
         self._eps_host = None
         self._zero_q = {}
         self._slot = "policy"
-        self._arrival = None     # arrival words of a Q-head launch that selects the actions itself
 
     def _variables(self):
         return self._q_network.variables if self._q_network is not None else []
@@ -116,15 +103,13 @@ class _DiscretePolicy(tf_policy.TFPolicy):
         e = self._epsilon
         return float(e() if callable(e) else e)
 
-    def _q_values(self, observation, B, device, select=None):
+    def _q_values(self, observation, B, device):
         if self._q_network is None:
             z = self._zero_q.get((B, device))
             if z is None:
                 z = torch.zeros((B, self._num_actions), dtype=torch.float32, device=device)
                 self._zero_q[(B, device)] = z
             return z
-        if select is not None:
-            return self._q_network.forward(observation, slot=self._slot, select=select)
         return self._q_network.forward(observation, slot=self._slot)
 
     def q_values(self, time_step):
@@ -140,31 +125,6 @@ class _DiscretePolicy(tf_policy.TFPolicy):
             self._call_counter = torch.tensor([getattr(self, "_pending_counter", 0), 0],
                                               dtype=torch.int64).to(dev)
         return self._call_counter
-
-    def _select_args(self, B, mask, epsilon, dev):
-        """Arguments for a Q-network whose head launch selects the actions itself
-        (Sequential.forward(select=...)); None when this policy / network pair cannot."""
-        net = self._q_network
-        if not FUSE_SELECT or net is None or not hasattr(net, "selected") or B > (1 << 20):
-            return None
-        self._counter(dev)
-        if self._arrival is None:
-            self._arrival = torch.zeros((144,), dtype=torch.int64, device=dev)
-        out = torch.empty((B,) + tuple(self._spec.shape), dtype=self._spec.dtype, device=dev)
-        if mask is not None:
-            mask = mask.to(torch.int32).contiguous() if mask.dtype != torch.int32 else \
-                mask.contiguous()
-        eps_ptr = None
-        if callable(self._epsilon):
-            if self._eps_dev is None:
-                self._eps_dev = torch.zeros((1,), dtype=torch.float32, device=dev)
-            graph.on_replay(self._refresh_epsilon)
-            eps_ptr = self._eps_dev.data_ptr()
-        advance = epsilon > 0 or eps_ptr is not None
-        return dict(mask=mask, epsilon=float(epsilon), epsilon_dev=eps_ptr, seed=self._seed,
-                    call_counter=self._call_counter.data_ptr(),
-                    arrival=self._arrival.data_ptr() if advance else None,
-                    action_min=self._lo, out=out)
 
     def select(self, q, mask, epsilon, out=None):
         """Fused masked arg-max + epsilon mix on a [B, A] Q table -> actions [B]."""
@@ -229,12 +189,7 @@ class _DiscretePolicy(tf_policy.TFPolicy):
         graph.join_lanes(dev)
         with torch.cuda.device(dev):
             eps = self._get_epsilon()
-            sel = self._select_args(B, mask, eps, dev)
-            q = self._q_values(obs, B, dev, select=sel)
-            if sel is not None and getattr(self._q_network, "selected", False):
-                actions = sel["out"]      # drawn by the Q head's own launch
-            else:
-                actions = self.select(q, mask, eps)
+            actions = self.select(self._q_values(obs, B, dev), mask, eps)
         if not batched:
             actions = actions.squeeze(0)
         return policy_step.PolicyStep(actions, policy_state, ())

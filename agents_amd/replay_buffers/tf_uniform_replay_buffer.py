@@ -38,7 +38,7 @@ _EMPTY_DATASET = ("TFUniformReplayBuffer is empty. Make sure to add items before
 
 
 # AA_RB_STAMPED=0: graphed datasets replay the device-counter launch instead of stamping (A/B)
-STAMPED_DRAWS = os.environ.get("AA_RB_STAMPED", "1") != "0"
+STAMPED_DRAWS = True
 
 
 def _valid_range_ids(last_id, max_length, num_steps=None):

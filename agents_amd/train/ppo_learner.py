@@ -30,7 +30,7 @@ from agents_amd.utils import nest_utils
 
 
 # AA_PPO_FUSED_EPOCHS=0: always one `agent.train` call per gathered minibatch (A/B, tests)
-FUSED_EPOCHS = os.environ.get("AA_PPO_FUSED_EPOCHS", "1") != "0"
+FUSED_EPOCHS = True
 
 
 class PPOLearner:

@@ -75,34 +75,24 @@ def on_replay(fn):
 
 # A/B knob AA_COUNT_IN_ADD=0: the driver's step counter stays a launch of its own in front of the
 # replay buffer's add_batch (bit-identical either way)
-COUNT_IN_ADD = os.environ.get("AA_COUNT_IN_ADD", "1") != "0"
+COUNT_IN_ADD = True
 
 # A/B knob: replay the optimizer phase as its own HIP graph (0) or launch it directly (1)
-APPLY_EAGER = os.environ.get("AA_APPLY_EAGER", "1") != "0"
+APPLY_EAGER = True
 
 
-# A/B knob AA_EARLY_TARGET: with overlap on, GraphedTrain runs the target network's forward of the
-# NEXT train step right behind the gradient graph of this one, next to the optimizer launch (see
-# GraphedTrain._issue_early_target).  0 = off; "side" (default) = on the agent's side stream,
-# "new" = on a stream of its own, "S" = on the sample lane's stream.  Same box, 400 iterations,
-# two alternating rounds (DQN configs[1]): off 0.3458 ms, side 0.3319, new 0.3318, S 0.3771 (the
-# sample lane shares a hardware queue with the collect lane: the next collect step queues up
-# behind the early forward).  Tried and removed: the early forward in stream order on the caller's
-# stream behind the gradient graph with the OPTIMIZER launch moved to the side stream instead
-# (no event hand-over in front of the forward): 0.4351 vs 0.3639 ms, three alternating pairs --
-# the forward then took 107 us and the optimizer step ended 59 us after the gradients; the early
-# forward on a HIGH-priority stream of its own (0.973 vs 0.318 ms); a step on an early forward
-# replaying its gradient phase as two graphs, online forward | loss + backward behind the early
-# forward's event, so that the online forward need not wait for it (0.3277 vs 0.3232 ms, three
-# pairs: the second graph launch costs the host and the stream more than the wait); the early
-# forward launched DURING the previous step instead of behind it -- through a second activation
-# slot of the target network, behind that iteration's replay draw, so that the next gradient graph
-# never waits for it (it then starts 41 us after the optimizer step instead of 85) -- 0.3209 vs
-# 0.3170 ms, three pairs: the gradient graph takes 277 us instead of 216 (its forward shares the
-# device with the collect step's again, its backward with the early forward).
-EARLY_TARGET = os.environ.get("AA_EARLY_TARGET", "side")
-if EARLY_TARGET in ("1", "on", "true"):
-    EARLY_TARGET = "side"
+# AA_EARLY_TARGET (0 = off, default on): with overlap on, GraphedTrain runs the target network's
+# forward of the NEXT train step right behind the gradient graph of this one, on the agent's side
+# stream, next to the optimizer launch (see GraphedTrain._issue_early_target): 0.3458 -> 0.3319 ms
+# per DQN iteration (round 4).  Variants that were measured and removed ("Round 4, second
+# session" and "Round 5"; git history has the code): a stream of its own (same), the sample lane's
+# stream (0.3771: it shares a hardware queue with the collect lane), stream order on the caller's
+# stream (0.3545 vs 0.2959), a high-priority stream (0.973), the gradient phase as two graphs
+# around the forward's event (0.3277 vs 0.3232) or around the first layer's weight gradient
+# (0.3214 vs 0.2974), the forward launched during the previous step through a second activation
+# slot (0.3209 vs 0.3170).
+EARLY_TARGET = "0" if os.environ.get("AA_EARLY_TARGET", "side") in ("0", "off", "false") \
+    else "side"
 
 
 class Lanes:
@@ -126,14 +116,7 @@ class Lanes:
 
     def __init__(self, device):
         self.device = device
-        # A/B knob AA_COLLECT_PRIORITY: HIP stream priority of the collect lane (0 = default; a
-        # positive number = lower priority where the runtime offers one) -- the policy forward is
-        # the one chain of the iteration with slack
-        pri = int(os.environ.get("AA_COLLECT_PRIORITY", "0"))
-        try:
-            self.C = torch.cuda.Stream(device, priority=pri) if pri else torch.cuda.Stream(device)
-        except Exception:
-            self.C = torch.cuda.Stream(device)
+        self.C = torch.cuda.Stream(device)
         self.S = torch.cuda.Stream(device)
         self.collect_done = None
         self.sample_done = None
@@ -343,6 +326,22 @@ def current_stream(device):
     return s
 
 
+def _bind_launch():
+    from agents_amd import _lib
+    return _lib.load().aa_hip_graph_launch, _lib.stream_ptr
+
+
+class _Lazy:
+    """Resolves the library's launch entry on first use (importing this module must not load it)."""
+
+    def __call__(self, *a):
+        global _GRAPH_LAUNCH, _STREAM_PTR
+        _GRAPH_LAUNCH, _STREAM_PTR = _bind_launch()
+        return _GRAPH_LAUNCH(*a)
+
+
+_GRAPH_LAUNCH = _Lazy()
+_STREAM_PTR = lambda: _bind_launch()[1]()       # noqa: E731  (replaced with the first launch)
 REPLAY_TIMERS = None    # set to {} to accumulate {kind: [launches, host seconds]}
 TIMELINE = None         # set to [] to collect (tag, timing event) marks around the graph launches
 
@@ -385,7 +384,7 @@ def release_dead(synchronize=True):
     dead = _GRAVEYARD[:]
     del _GRAVEYARD[:len(dead)]
     n = len(dead)
-    del dead            # CUDAGraph.__del__ -> hipGraphExecDestroy, its private pool is released
+    del dead            # _Exec.__del__ -> hipGraphExecDestroy; CUDAGraph.__del__ releases the pool
     # ... to the caching allocator's list of freeable pools, which only an out-of-memory retry or
     # empty_cache() returns to the device: without this a process that builds and drops agents
     # grows by a 20 MiB segment per recorded graph (tools/lifetime_probe.py)
@@ -393,24 +392,86 @@ def release_dead(synchronize=True):
     return n
 
 
+# ---- a HIP-runtime fault in hipGraphLaunch, and the guard against it -----------------------------
+# (csrc/runtime_guard.hip has the analysis.)  A recorded graph with side branches gets n internal
+# "parallel" streams when it is instantiated; each lands on the hardware queue that has the fewest
+# streams at that moment, and hipGraphLaunch reads past their list -- SIGSEGV -- when two of them
+# share the LAUNCH stream's queue.  That needs unevenly loaded queues, i.e. a process that has
+# destroyed other graph execs: the GPU suite's 671st test in rounds 5 and 6, never the benchmark.
+# The guard: keep the captured hipGraph (torch CUDAGraph(keep_graph=True), which also owns the
+# capture's memory pool) and let the library instantiate it: where two of the fresh exec's parallel
+# streams share a queue the exec is destroyed, one ballast stream evens the queue loads out, and
+# the graph is instantiated again (csrc/runtime_guard.hip: aa_hip_graph_instantiate).  Streams on
+# pairwise different queues are safe for EVERY launch stream.  Replays launch that exec directly
+# (aa_hip_graph_launch = hipGraphLaunch on the current stream: what torch's replay() does).
+# Capture time only (a few instantiations of ~100 us each); on any other runtime version the
+# library instantiates once and checks nothing.
+EXEC_GUARD = True           # tests switch it off to show the hazard without meeting it
+exec_guard_stats = {"execs": 0, "respread": 0, "instantiations": 0, "unsupported": 0}
+
+
+class _Exec:
+    """A hipGraphExec of our own (see above), destroyed with the object."""
+    __slots__ = ("ptr", "streams", "worst")
+
+    def __init__(self, g):
+        import ctypes
+        from agents_amd import _lib
+        ex, n, worst, tries = ctypes.c_void_p(), ctypes.c_int32(0), ctypes.c_int32(0), \
+            ctypes.c_int32(0)
+        self.ptr = None
+        rc = _lib.load().aa_hip_graph_instantiate(
+            g.raw_cuda_graph(), 1 if EXEC_GUARD else 0, ctypes.byref(ex), ctypes.byref(n),
+            ctypes.byref(worst), ctypes.byref(tries))
+        if rc == _lib.AA_ERR_RANGE:
+            raise RuntimeError(
+                "could not spread a HIP graph's parallel streams over different hardware queues "
+                "(hipGraphLaunch of this runtime would read out of bounds): set "
+                "DEBUG_HIP_FORCE_GRAPH_QUEUES=1 to record linear graphs")
+        _lib.check(rc, "aa_hip_graph_instantiate")
+        self.ptr, self.streams, self.worst = ex.value, n.value, worst.value
+        exec_guard_stats["execs"] += 1
+        exec_guard_stats["instantiations"] += tries.value
+        exec_guard_stats["respread"] += int(tries.value > 1)
+        exec_guard_stats["unsupported"] += int(n.value < 0)
+
+    def __del__(self):
+        ptr, self.ptr = self.ptr, None
+        if ptr is not None:
+            try:
+                from agents_amd import _lib
+                _lib.load().aa_hip_graph_exec_destroy(ptr)
+            except Exception:       # interpreter shutdown
+                pass
+
+
 class _Captured:
     """A torch CUDAGraph plus the host hooks registered while it was captured."""
 
     def __init__(self, kind="graph"):
-        self.graph = None
+        self.graph = None         # torch CUDAGraph: the captured hipGraph and its memory pool
+        self.exec = None          # _Exec: the instantiated graph that replays launch
         self.hooks = []
         self.out = None
         self.kind = kind
+
+    @property
+    def spread(self):
+        """(streams of the exec, most parallel streams on one hardware queue), or None when the
+        runtime is not the one the guard knows."""
+        e = self.exec
+        return None if e is None or e.streams < 0 else (e.streams, e.worst)
 
     def close(self):
         """Gives up the graph (see `_GRAVEYARD`) and everything its hooks keep alive."""
         global _LIVE_GRAPHS
         g, self.graph = self.graph, None
+        ex, self.exec = self.exec, None
         self.hooks = []
         self.out = None
         if g is not None:
             _LIVE_GRAPHS -= 1
-            _GRAVEYARD.append(g)
+            _GRAVEYARD.append((ex, g))       # (released in this order: the exec, then its graph)
             if len(_GRAVEYARD) >= _GRAVEYARD_MAX and _BATCH_DEPTH == 0 and _CAPTURE is None \
                     and not _finalizing():
                 release_dead()
@@ -430,7 +491,7 @@ class _Captured:
         if _CAPTURE is not None:
             raise RuntimeError("nested HIP-graph capture")
         ctx = _CaptureCtx()
-        g = torch.cuda.CUDAGraph()
+        g = torch.cuda.CUDAGraph(keep_graph=True)     # the hipGraph stays: see _Exec
         with capture_batch():
             _CAPTURE = ctx
             try:
@@ -442,6 +503,7 @@ class _Captured:
                         g.capture_end()
             finally:
                 _CAPTURE = None
+            self.exec = _Exec(g)
         _CAPTURES += 1
         global _LIVE_GRAPHS
         _LIVE_GRAPHS += 1
@@ -453,10 +515,12 @@ class _Captured:
         for h in self.hooks:
             h()
         if REPLAY_TIMERS is None:
-            self.graph.replay()
+            if _GRAPH_LAUNCH(self.exec.ptr, _STREAM_PTR()):
+                raise RuntimeError("hipGraphLaunch failed")
         else:     # host cost of the launch per kind of graph (bench.py --host-profile)
             t0 = time.perf_counter()
-            self.graph.replay()
+            if _GRAPH_LAUNCH(self.exec.ptr, _STREAM_PTR()):
+                raise RuntimeError("hipGraphLaunch failed")
             acc = REPLAY_TIMERS.setdefault(self.kind, [0, 0.0])
             acc[0] += 1
             acc[1] += time.perf_counter() - t0
@@ -471,7 +535,6 @@ class _Entry:
         self.g_apply = None       # _Captured: optimizer (shared by every entry of a signature)
         self.apply_state = None   # agent._apply_state() after this entry's gradient phase
         self.g_grads_b = None     # _Captured, bucket mode: second half of the backward
-        self.split_last = False   # g_grads_b = the first layer's weight gradient alone (one replica)
         self.captured = None      # _Captured, whole mode (part (a) when the agent splits it)
         self.captured_b = None    # _Captured, whole mode, part (b)
         self.out = None
@@ -547,7 +610,6 @@ class GraphedTrain:
         self._succ = {}          # entry -> entry of the call that followed it (the ring is cyclic)
         self._prev_entry = None
         self._early = None       # (entry, done event, agent._early_target_key(), draw number, device)
-        self._early_stream = None
         self._early_sized = False
         self.early_hits = 0
         self.early_issued = 0
@@ -777,27 +839,6 @@ class GraphedTrain:
                 if lanes is not None:
                     lanes.join()
                 e.captured.replay()
-            elif e.split_last:
-                # [forward + loss + backward down to the second layer] -> mark for the early target
-                # forward of the next step -> [first layer's weight gradient] -> optimizer
-                _mark("train.begin")
-                (e.g_grads_nt if use_early else e.g_grads).replay()
-                grads_done = self._early_mark(lanes, cur)
-                e.g_grads_b.replay()
-                _mark("train.grads_done")
-                if lanes is not None and lanes.collect_done is not None:
-                    cur.wait_event(lanes.collect_done)
-                if hasattr(agent, "_set_apply_state"):
-                    agent._set_apply_state(e.apply_state_nt if use_early else e.apply_state)
-                if APPLY_EAGER:
-                    agent._train_phase_apply()
-                else:
-                    e.g_apply.replay()
-                _mark("train.apply_done")
-                tw = getattr(agent, "_target_writes", None)
-                agent._train_phase_host()
-                self._issue_early_target(e, lanes, dev, cur, grads_done,
-                                         getattr(agent, "_target_writes", None) != tw)
             elif e.g_grads_b is not None:
                 # bucket mode (data-parallel): [forward + loss + dense-tail backward] -> start the
                 # all-reduce of the tail's gradients -> [conv backward] overlaps it -> all-reduce
@@ -863,20 +904,12 @@ class GraphedTrain:
         return lanes.event_on(cur)
 
     def _early_target_stream(self, lanes, dev, cur=None):
-        if EARLY_TARGET == "main" and cur is not None:
-            # in stream order on the caller's stream, behind the optimizer launch: no event
-            # hand-over in front of the forward or behind it (round 5: the GPU timeline shows ~26 us
-            # between the early forward's end on the side stream and the gradient graph's first
-            # kernel on the caller's), at the price of not overlapping the optimizer launch
-            return cur
-        if EARLY_TARGET == "side" and getattr(self._agent, "_side_stream", None) is not None:
+        """The agent's side stream (the weight-gradient branch's, idle behind the gradient graph);
+        the sample lane for an agent that keeps everything on one stream."""
+        if getattr(self._agent, "_side_stream", None) is not None:
             st = self._agent._side_stream(dev)
             if st is not None:
                 return st
-        if EARLY_TARGET == "new":
-            if self._early_stream is None:
-                self._early_stream = torch.cuda.Stream(dev)
-            return self._early_stream
         return lanes.S
 
     def _issue_early_target(self, e, lanes, dev, cur, grads_done, target_written):
@@ -907,7 +940,7 @@ class GraphedTrain:
         self._early = (nxt, done, self._agent._early_target_key(), seq, dev)
         self.early_issued += 1
 
-    def _capture_early(self, e, bucketed, split=None):
+    def _capture_early(self, e, bucketed):
         """Per ring slot: the target forward alone, and the gradient phase that reads its output."""
         from agents_amd import ops
         agent = self._agent
@@ -922,14 +955,8 @@ class GraphedTrain:
             q_t = gt.capture(lambda: agent._train_phase_target(e.static_in))
         phase = agent._train_phase_grads_a if bucketed else agent._train_phase_grads
         gn = _Captured("train.grads")
-        if split is not None:
-            gn.capture(lambda: agent._train_phase_grads_a(e.static_in, None, q_next_target=q_t,
-                                                          split=split))
-            # (its second half is e.g_grads_b: same launches on the same buffers, same slabs)
-            e.apply_state_nt = e.apply_state
-        else:
-            gn.capture(lambda: phase(e.static_in, None, q_next_target=q_t))
-            e.apply_state_nt = agent._apply_state() if hasattr(agent, "_apply_state") else None
+        gn.capture(lambda: phase(e.static_in, None, q_next_target=q_t))
+        e.apply_state_nt = agent._apply_state() if hasattr(agent, "_apply_state") else None
         e.g_target, e.g_grads_nt = gt, gn
 
     def _capture(self, e, experience, weights, clone=True, g_apply=None, ring=False):
@@ -958,21 +985,11 @@ class GraphedTrain:
             bucketed = (getattr(agent, "gradient_hook_async", None) is not None and
                         hasattr(agent, "_train_phase_grads_a") and
                         agent._bucket_split() is not None and BUCKETED_ALLREDUCE)
-            # one replica, nothing between backward and the optimizer: the first layer's weight
-            # gradient (the last launch of the backward chain) as a graph of its own, so that the
-            # early target forward of the next step can start in front of it
-            split = None
-            if not bucketed and hasattr(agent, "_last_dw_split") and ring and not clone and \
-                    weights is None:
-                split = agent._last_dw_split()
-            e.split_last = split is not None
             e.g_grads = _Captured("train.grads")
             e.out = e.g_grads.capture(
                 (lambda: agent._train_phase_grads_a(e.static_in, w_arg)) if bucketed else
-                (lambda: agent._train_phase_grads_a(e.static_in, w_arg, split=split))
-                if split is not None else
                 (lambda: agent._train_phase_grads(e.static_in, w_arg)))
-            if bucketed or split is not None:
+            if bucketed:
                 e.g_grads_b = _Captured("train.grads_b")
                 e.g_grads_b.capture(agent._train_phase_grads_b)
             # what the optimizer phase takes over from THIS entry's gradient phase besides
@@ -989,7 +1006,7 @@ class GraphedTrain:
             if ring and not clone and weights is None and EARLY_TARGET != "0" and \
                     hasattr(agent, "_train_phase_target") and \
                     hasattr(agent, "_early_target_key"):
-                self._capture_early(e, bucketed, split)
+                self._capture_early(e, bucketed)
 
     def static_inputs(self, experience_like=None):
         """Static input nest of the (single) captured signature, or None before capture."""

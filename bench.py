@@ -32,7 +32,6 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
-TRIPLE_OP = "conv1+conv2+conv3.fwd(one launch)"
 PRIME_MIN = 0                  # minimum untimed iterations in front of --warmup (see main: priming)
 CPU_RING_FRAMES = 256          # replay frames per env of the cpu_baseline leg (see cpu_baseline)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
@@ -338,21 +337,9 @@ def kernel_breakdown(w, S, reps=20):
     out.append(("replay.add_batch(scatter 256 rows)", timeit(lambda: rb.add_batch(traj)), 1, 0.0,
                 256 * (2.0 * ROW_BYTES + 8)))
     from agents_amd.networks import sequential as _seq
-    triple = _seq.FUSE_CONV_PAIRS and ops.conv_triple_prepare_bytes(
-        tuple(obs_t.shape), kv[0:3], (4, 2, 1)) > 0 and obs_t.stride(0) % 16 == 0
-    if triple:
-        # what the network runs: the three convs on the uint8 frames in ONE launch
-        # (csrc/conv_triple_x6.h); timed with the intermediate activations stored, as the online
-        # network's forward does (the policy's and the target network's do not store them)
-        out.append((TRIPLE_OP, timeit(lambda: ops.conv_triple_forward(
-            obs_t, kv[0:3], bv[0:3], (4, 2, 1), ("relu",) * 3, slot.ys[0:3], a_div=255.0)), 3,
-            f(m[0] + m[1] + m[2]), 0))
-    else:
-        out.append(("conv1.fwd(u8)", timeit(lambda: ops.conv_forward(
-            obs_t, kv[0], bv[0], 4, "relu", slot.ys[0], a_div=255.0)), 3, f(m[0]), 0))
-    if triple:
-        pass
-    elif _seq.FUSE_CONV_PAIRS and ops.conv_pair_supported(tuple(slot.ys[0].shape), kv[1], 2, kv[2], 1):
+    out.append(("conv1.fwd(u8)", timeit(lambda: ops.conv_forward(
+        obs_t, kv[0], bv[0], 4, "relu", slot.ys[0], a_div=255.0)), 3, f(m[0]), 0))
+    if _seq.FUSE_CONV_PAIRS and ops.conv_pair_supported(tuple(slot.ys[0].shape), kv[1], 2, kv[2], 1):
         # what the network runs: both layers in one launch (csrc/conv_pair.hip)
         out.append(("conv2+conv3.fwd(fused)", timeit(lambda: ops.conv_pair_forward(
             slot.ys[0], kv[1], bv[1], 2, "relu", slot.ys[1], kv[2], bv[2], 1, "relu",
@@ -452,10 +439,6 @@ def kernel_breakdown(w, S, reps=20):
     opt.iterations = iters
 
     def products(name):
-        if name == TRIPLE_OP:
-            # conv1: three products per fp32 product (a byte is one bf16 piece), conv2 / conv3:
-            # six -- the flop-weighted mean is what the launch puts on the bf16 pipe
-            return (3.0 * m[0] + 6.0 * (m[1] + m[2])) / (m[0] + m[1] + m[2])
         if name.startswith("conv1."):
             return 3
         if name == "conv2+conv3.fwd(fused)":
@@ -1168,7 +1151,7 @@ def main():
     # either way (profiles/r05_f_prime.txt).  The difference is the protocol's: the timed region
     # ends with a device synchronisation, i.e. with the drain of the last iteration the host had
     # run ahead of -- one iteration's latency spread over 20 steps.)
-    prime_min = int(os.environ.get("AA_BENCH_PRIME_MIN", str(PRIME_MIN)))
+    prime_min = PRIME_MIN
     prime_steps, quiet, seen = 0, 0, graph.capture_count()
     t_prime = time.perf_counter()
     while (prime_steps < 64 and quiet < 3) or prime_steps < prime_min:
@@ -1431,7 +1414,7 @@ def main():
             # HBM bytes and matrix-pipe busy per launch come from COMMITTED rocprofv3 --pmc passes
             # (isolated launches, one counter set per pass: tools/pmc_r02.sh, run by tools/profile_r03.sh); they are not
             # re-measured by this run and are labelled so
-            pmc_case = {"conv2+conv3.fwd(fused)": "conv23.fwd", TRIPLE_OP: "conv123.fwd.keep",
+            pmc_case = {"conv2+conv3.fwd(fused)": "conv23.fwd",
                         "fc1.fwd": "fc1.fwd",
                         "fc1+fc2.fwd(head sums fc1's slabs)": "fc1.fwd",
                         "fc1.dX": "fc1.dX", "fc1.dW(+bias grad)": "fc1.dW",

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 14
+#define AA_ABI_VERSION 15
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -163,6 +163,31 @@ int aa_rb_range_rows(int64_t start_id, int64_t n_ids, int64_t batch, int64_t max
 /* *counter += inc (device-side step / id counters; tf.Variable.assign_add). */
 int aa_counter_add(int64_t* counter_dev, int64_t inc, void* stream);
 
+/* ---- HIP-runtime guard (no reference counterpart; csrc/runtime_guard.hip) --------------------
+ * hipGraphLaunch of this image's runtime (version 70051831) faults when two of a graph exec's
+ * internal parallel streams share the launch stream's hardware queue.  The graph wrappers
+ * (agents_amd/utils/graph.py) instantiate every recorded graph until its parallel streams are
+ * spread over different queues, and launch the exec that results themselves:
+ *   aa_hip_graph_exec_spread    *n_streams_out = the exec's stream count (1 = linear graph),
+ *                               *max_on_one_queue_out = the largest number of its parallel
+ *                               streams on one queue (<= 1 is safe for every launch stream);
+ *                               AA_ERR_UNSUPPORTED on any other runtime version / object layout
+ *   aa_hip_graph_instantiate    hipGraphInstantiate of `graph` (a hipGraph_t), repeated -- the
+ *                               exec destroyed, one ballast stream added -- while guard != 0 and
+ *                               two parallel streams share a queue; on another runtime version
+ *                               one plain instantiation (*n_streams_out = -1).  AA_ERR_RANGE
+ *                               after 256 attempts
+ *   aa_hip_graph_launch         hipGraphLaunch(exec, stream)
+ *   aa_hip_graph_exec_destroy   hipGraphExecDestroy (the caller makes sure no launch is in
+ *                               flight) */
+#define AA_ERR_UNSUPPORTED (-95)
+int aa_hip_graph_exec_spread(void* graph_exec, int32_t* n_streams_out,
+                             int32_t* max_on_one_queue_out);
+int aa_hip_graph_instantiate(void* graph, int32_t guard, void** exec_out, int32_t* n_streams_out,
+                             int32_t* max_on_one_queue_out, int32_t* attempts_out);
+int aa_hip_graph_launch(void* graph_exec, void* stream);
+int aa_hip_graph_exec_destroy(void* graph_exec);
+
 /* A one-thread no-op dispatch named aa_marker_kernel: measurement aid, not part of any reference
  * path.  bench.py brackets its timed region (and every isolated kernel case) with markers and
  * reads rocprofv3's kernel trace by position between them -- the in-loop kernel durations of the
@@ -216,14 +241,6 @@ typedef struct aa_gemm_desc {
 
 int64_t aa_gemm_f32_workspace_bytes(const aa_gemm_desc* d);
 int aa_gemm_f32(const aa_gemm_desc* d, void* workspace, int64_t workspace_bytes, void* stream);
-/* Two independent contractions in ONE launch: the input gradient `a` (a_mode ROW, b_mode COL:
- * dX = dZ W^T with the activation-derivative mask) and the weight gradient `b` (a_mode COL, b_mode
- * ROW: dW = x^T dZ with the fused bias gradient) of one keras Dense layer -- both read the layer's dZ
- * (tf.GradientTape, agents/dqn/dqn_agent.py:412-426).  Every tile is computed by the code of its
- * own single launch (bit-identical to two aa_gemm_f32 calls).  Only for pairs that plan as unsplit
- * LDS-DMA contractions on the instantiated tile shapes (fc1 of the Atari Q-network); otherwise
- * AA_ERR_RANGE and nothing is launched. */
-int aa_gemm_f32_pair(const aa_gemm_desc* a, const aa_gemm_desc* b, void* stream);
 /* aa_gemm_f32 without the split-K reduce launch, for a consumer that sums the partial products in
  * its own prologue (aa_dense_small_forward_slabs): *splits_out = s > 1 -> `workspace` starts with
  * the raw fp32 slabs [s][M][N] (no bias, no activation) and C is untouched; *splits_out = 1 -> the
@@ -249,21 +266,6 @@ int aa_dense_small_forward_slabs(const float* slabs, int32_t splits, int64_t M, 
                                  const float* bias1 /* nullable */, int32_t act1, float* h,
                                  int64_t ldh, const float* w, const float* bias /* nullable */,
                                  int32_t act, int32_t N, float* y, void* stream);
-/* aa_dense_small_forward_slabs whose launch also SELECTS the actions of the Q values it produces
- * (EpsilonGreedyPolicy._action over QPolicy / GreedyPolicy: policies/epsilon_greedy_policy.py:
- * 120-143, q_policy.py:150-194, greedy_policy.py:70-89): row m's wave restates
- * aa_eps_greedy_action on row m -- same masked arg-max, same Philox stream (counter (m, call)),
- * same epsilon mix -- so the actions equal the two-launch path's bit for bit.  arrival_dev: 144
- * zero int64 words (NULL: the call counter is read but not advanced, as aa_eps_greedy_action does
- * for epsilon == 0). */
-int aa_dense_small_forward_slabs_eps(const float* slabs, int32_t splits, int64_t M, int32_t K,
-                                     const float* bias1, int32_t act1, float* h, int64_t ldh,
-                                     const float* w, const float* bias, int32_t act, int32_t N,
-                                     float* y, const int32_t* mask, float epsilon,
-                                     const float* epsilon_dev, uint64_t seed,
-                                     int64_t* call_counter_dev, int64_t* arrival_dev,
-                                     int64_t action_min, void* actions_out,
-                                     int32_t actions_are_i64, void* stream);
 int aa_dense_small_dx(const float* dz, const float* w, const float* mask_src /* [M,K] nullable */,
                       int32_t mask_kind, int64_t M, int32_t K, int32_t N, float* dx, void* stream);
 /* aa_dense_small_dx and aa_dense_small_dw in one launch (same results): the backward pass of the
@@ -336,27 +338,6 @@ int aa_conv_pair_x6_phase(const float* x, int64_t img_pitch, int32_t n_img, int3
                           const aa_conv_layer_desc* second, void* workspace,
                           int64_t workspace_bytes, int32_t phases, void* stream);
 
-/* The whole convolutional stack of the Mnih-15 Q-network in ONE launch (csrc/conv_triple_x6.h):
- * y1 = act1(conv(x / a_div, w1) + b1) on uint8 frames (the Lambda(x / 255) + first Conv2D of
- * examples/dqn/mnih15/dqn_train_eval_atari.py:80-112; QNetwork / EncodingNetwork forward,
- * networks/encoding_network.py:222-359), then the pair above on y1 -- one workgroup per frame, y1
- * handed from the first layer's epilogue to the second layer's LDS planes without a trip through
- * memory.  first->y and second->y may be NULL (activations only a backward pass would read are
- * then not stored); third->y is always written.  x: uint8 NHWC, `img_pitch` BYTES between frames
- * (0 = dense), 16-byte aligned.  Limits: KW * Cin % 32 == 0 with at most 8 such 32-byte steps per
- * patch, first Cout in {16, 32, 64, 128}, the pair's limits for layers two and three, the frame's
- * bytes <= the third layer's LDS planes (aa_conv_triple_x6_workspace_bytes returns 0 when a shape
- * does not qualify; the call then returns AA_ERR_RANGE and aa_gemm_f32 + aa_conv_pair_x6_* remain
- * the path).  phases as for aa_conv_pair_x6_phase; workspace = the three split filter banks. */
-int64_t aa_conv_triple_x6_workspace_bytes(int32_t n_img, int32_t H, int32_t W, int32_t Cin,
-                                          const aa_conv_layer_desc* first,
-                                          const aa_conv_layer_desc* second,
-                                          const aa_conv_layer_desc* third);
-int aa_conv_triple_x6_phase(const uint8_t* x, int64_t img_pitch, int32_t n_img, int32_t H,
-                            int32_t W, int32_t Cin, float a_div,
-                            const aa_conv_layer_desc* first, const aa_conv_layer_desc* second,
-                            const aa_conv_layer_desc* third, void* workspace,
-                            int64_t workspace_bytes, int32_t phases, void* stream);
 
 /* Input gradient of a VALID Conv2D in gather form, one workgroup per frame (no column-gradient
  * slab, no col2im): dx[b,iy,ix,ci] = act'(mask_src[b,iy,ix,ci]) * sum over the patches containing

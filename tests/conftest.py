@@ -37,3 +37,16 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     return torch.device("cuda", 0)
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _graph_stats(request):
+    """AA_TEST_GRAPH_STATS=1: after every test module, one stderr line with the HIP graphs this
+    process holds (recorded and not closed, closed and waiting for an idle device, recorded in
+    all) -- the bookkeeping behind tests/test_gpu_lifetime.py, for hunting a leak across a run."""
+    yield
+    if os.environ.get("AA_TEST_GRAPH_STATS") == "1" and "agents_amd.utils.graph" in sys.modules:
+        g = sys.modules["agents_amd.utils.graph"]
+        live, parked = g.live_graphs()
+        print(f"\n[graph stats] after {request.module.__name__}: live {live}, parked {parked}, "
+              f"recorded so far {g.capture_count()}", file=sys.stderr, flush=True)

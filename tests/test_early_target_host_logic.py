@@ -139,9 +139,6 @@ def test_reasons_not_to_issue(gt, monkeypatch, why):
 def test_stream_choice(gt, monkeypatch):
     lanes = _Lanes()
     assert gt._early_target_stream(lanes, None) is gt.agent.side
-    monkeypatch.setattr(graph, "EARLY_TARGET", "S")
-    assert gt._early_target_stream(lanes, None) is lanes.S
-    monkeypatch.setattr(graph, "EARLY_TARGET", "side")
     gt.agent._side_stream = lambda dev: None       # AA_TRAIN_SINGLE_STREAM=1: no side stream
     assert gt._early_target_stream(lanes, None) is lanes.S
 

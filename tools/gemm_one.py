@@ -52,20 +52,6 @@ def main():
         dcol = torch.empty(S * npix * wsh[0] * wsh[1] * wsh[2], device=dev)
         ops.CONV_DX_FRAME = not args.no_dma      # --no-dma selects the GEMM + col2im path here
         fn = lambda: ops.conv_dx(dz, w, xs, strd, dcol, dx, mask_src=y, mask_act="relu")
-    elif args.name in ("conv123.fwd", "conv123.fwd.keep"):
-        # the three convs on uint8 frames in one launch (csrc/conv_triple_x6.h); ".keep" also
-        # stores the two intermediate activations (the online network's forward)
-        ops.CONV_TRIPLE = True        # (opt-in in the library: it loses inside the DQN loop)
-        obs = torch.randint(0, 256, (S, 84, 84, 4), dtype=torch.uint8, generator=g).to(dev)
-        ws_ = [r(8, 8, 4, 32) * 0.06, r(4, 4, 32, 64) * 0.04, r(3, 3, 64, 64) * 0.04]
-        bs_ = [r(32), r(64), r(64)]
-        keep = args.name.endswith(".keep")
-        ys = [r(S, 20, 20, 32) if keep else None, r(S, 9, 9, 64) if keep else None, r(S, 7, 7, 64)]
-        n = ops.conv_triple_prepare_bytes((S, 84, 84, 4), ws_, (4, 2, 1))
-        planes = torch.empty((n,), dtype=torch.uint8, device=dev)
-        ops.conv_triple_prepare((S, 84, 84, 4), ws_, (4, 2, 1), planes)
-        fn = lambda: ops.conv_triple_forward(obs, ws_, bs_, (4, 2, 1), ("relu",) * 3, ys,
-                                             prepared=planes)
     elif args.name == "fc1.fwd":
         x, w, b, y = r(S, 3136), r(3136, 512), r(512), r(S, 512)
         w2, b2, q = r(512, 6), r(6), r(S, 6)

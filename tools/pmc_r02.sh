@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/pmc2
 mkdir -p $OUT
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
-for case in ${AA_PMC_CASES:-conv123.fwd.keep conv23.fwd conv2.dX conv3.dX conv2.dW conv3.dW fc1.fwd fc1.dW fc1.dX replay.get_next conv1.fwd}; do
+for case in ${AA_PMC_CASES:-conv23.fwd conv2.dX conv3.dX conv2.dW conv3.dW fc1.fwd fc1.dW fc1.dX replay.get_next conv1.fwd}; do
   rocprofv3 --pmc $SQ GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/${case}_SQ -o r -- \
     python tools/gemm_one.py $case --reps 8 --no-time > $OUT/${case}_SQ.log 2>&1
   for ctr in FETCH_SIZE WRITE_SIZE; do
