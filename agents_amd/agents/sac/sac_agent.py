@@ -83,9 +83,10 @@ class SacPolicy(tf_policy.TFPolicy):
             self._arrival = torch.zeros((16,), dtype=torch.int64, device=dev)
         return self._dev_consts
 
-    def sample(self, observation, slot, need_grad=False, eps=None, save=None):
+    def sample(self, observation, slot, need_grad=False, eps=None, save=None, out=None):
         """(action [B,A], log_pi [B], z) for a batch of observations; `save` = dict of [B,A]
-        buffers (tanh, sigma, eps) kept for the backward pass."""
+        buffers (tanh, sigma, eps) kept for the backward pass; `out` = a contiguous float32 [B,A]
+        tensor of the caller's that receives the action instead of the slot's own buffer."""
         lib = _lib.load()
         dev = observation.device
         mean, mag = self._consts(dev)
@@ -103,12 +104,12 @@ class SacPolicy(tf_policy.TFPolicy):
         _lib.check(lib.aa_sac_sample(
             z.data_ptr(), B, self._A, mean.data_ptr(), mag.data_ptr(),
             self._actor_network.projection.std_kind, _lib.ptr(eps), self._seed,
-            self._call_counter.data_ptr(), self._arrival.data_ptr(), b["action"].data_ptr(),
-            b["logp"].data_ptr(),
+            self._call_counter.data_ptr(), self._arrival.data_ptr(),
+            (b["action"] if out is None else out).data_ptr(), b["logp"].data_ptr(),
             _lib.ptr(save["tanh"]) if save else None, _lib.ptr(save["sigma"]) if save else None,
             _lib.ptr(save["eps"]) if save else None, st), "aa_sac_sample")
         # (the launch itself advances the call counter when it drew the noise)
-        return b["action"], b["logp"], z
+        return (b["action"] if out is None else out), b["logp"], z
 
     def state_dict(self):
         return {"call_counter": None if self._call_counter is None
@@ -126,8 +127,11 @@ class SacPolicy(tf_policy.TFPolicy):
             obs = obs.unsqueeze(0)
         graph.join_lanes(obs.device)
         with torch.cuda.device(obs.device):
-            action, _, _ = self.sample(obs, slot="policy")
-            action = action.reshape((obs.shape[0],) + tuple(self._spec.shape)).clone()
+            # the sample kernel writes the caller's tensor (a fresh one per call; inside a captured
+            # driver body a static one of the graph's pool): no copy of the slot's buffer
+            action = torch.empty((obs.shape[0], self._A), dtype=torch.float32, device=obs.device)
+            self.sample(obs, slot="policy", out=action)
+            action = action.reshape((obs.shape[0],) + tuple(self._spec.shape))
         if not batched:
             action = action.squeeze(0)
         return policy_step.PolicyStep(action, policy_state, ())
@@ -513,6 +517,13 @@ class SacAgent(tf_agent.TFAgent):
             self._alpha_loss_weight = weight
 
     # ---- train ----------------------------------------------------------------------------------
+    def _critic_bodies(self):
+        """The Sequentials behind `_critic_params`, in its order (per-variable clipping)."""
+        out = []
+        for c in (self._critic_network_1, self._critic_network_2):
+            out += c.bodies if hasattr(c, "bodies") else [c.body]
+        return out
+
     def _apply(self, optimizer, params, grads, net_for_clip=None, soft_target=None):
         if self._gradient_clipping is not None:
             self._clip(params, grads, net_for_clip)
@@ -574,7 +585,7 @@ class SacAgent(tf_agent.TFAgent):
             closs = self._critic_phase(obs, actions, next_obs, reward, discount, wts, True,
                                        eps_next=eps.get("next"))
             self._apply(self._critic_optimizer, self._critic_params, self._critic_grads,
-                        [self._critic_network_1.body, self._critic_network_2.body],
+                        self._critic_bodies(),
                         soft_target=(self._target_params, self._target_update_tau)
                         if self._fuse_target_update() else None)
         self._part_a = (obs, wts, closs, eps)

@@ -3,8 +3,12 @@
 Counterpart of tf_agents/agents/ddpg/critic_network.py:30-190 (the class the SAC example
 instantiates, examples/sac/haarnoja18/sac_train_eval.py:182-190): observation and action are
 concatenated and passed through `joint_fc_layer_params` Dense(relu) layers and a final Dense(1).
-The optional per-input pre-layers (`observation_fc_layer_params`, `action_fc_layer_params`,
-conv layers) are not implemented -- the SAC configuration leaves them at None.
+The optional per-input towers `observation_fc_layer_params` / `action_fc_layer_params`
+(critic_network.py:126-145: Dense(activation_fn) stacks applied to each input before the
+concatenation, :163-185) are `Sequential`s of their own in front of the joint body; the
+convolutional observation encoder and the dropout lists are not implemented -- the SAC
+configuration leaves all of them at None, and only the tower-less layout takes the twin-critic
+fast path (`pair_ok`).
 
 The body is a `networks.sequential.Sequential` on the concatenated input (fp32 MFMA GEMMs, the
 small-N kernels for the 1-unit head).  `backward` can return d Q / d action: SAC's actor loss
@@ -29,10 +33,10 @@ class CriticNetwork(network.Network):
                  activation_fn="relu", output_activation_fn=None, kernel_initializer=None,
                  last_kernel_initializer=None, last_layer=None, name="CriticNetwork", seed=None):
         super().__init__(input_tensor_spec=input_tensor_spec, state_spec=(), name=name)
-        if any(p for p in (observation_conv_layer_params, observation_fc_layer_params,
-                           observation_dropout_layer_params, action_fc_layer_params,
+        if any(p for p in (observation_conv_layer_params, observation_dropout_layer_params,
                            action_dropout_layer_params, joint_dropout_layer_params)):
-            raise NotImplementedError("only joint_fc_layer_params are implemented")
+            raise NotImplementedError("convolutional observation encoders and dropout layers "
+                                      "are not implemented")
         if last_layer is not None:
             raise NotImplementedError("last_layer is not supported")
         obs_spec, act_spec = input_tensor_spec
@@ -43,6 +47,8 @@ class CriticNetwork(network.Network):
         self._obs_dim = int(np.prod(nest_utils.flatten(obs_spec)[0].shape))
         self._act_dim = int(np.prod(nest_utils.flatten(act_spec)[0].shape)) or 1
         self._ctor = dict(input_tensor_spec=input_tensor_spec,
+                          observation_fc_layer_params=observation_fc_layer_params,
+                          action_fc_layer_params=action_fc_layer_params,
                           joint_fc_layer_params=joint_fc_layer_params,
                           activation_fn=activation_fn, output_activation_fn=output_activation_fn,
                           kernel_initializer=kernel_initializer,
@@ -50,13 +56,27 @@ class CriticNetwork(network.Network):
         # reference defaults: VarianceScaling(1/3, fan_in, uniform); last layer U(-0.003, 0.003)
         ki = kernel_initializer or L.VarianceScaling(1.0 / 3.0, "fan_in", "uniform")
         lki = last_kernel_initializer or L.RandomUniform(-0.003, 0.003)
+        self._seed = seed
+
+        def tower(params, in_dim, k):
+            # utils.mlp_layers(None, fc_layer_params, None, activation_fn, kernel_initializer)
+            if not params:
+                return None, in_dim
+            net = sequential.Sequential(
+                [L.Dense(int(n), activation_fn, kernel_initializer=ki) for n in params],
+                input_spec=tensor_spec.TensorSpec((in_dim,), torch.float32),
+                seed=None if seed is None else seed + 7919 * k)
+            return net, int(params[-1])
+
+        self._obs_tower, self._fo = tower(observation_fc_layer_params, self._obs_dim, 1)
+        self._act_tower, self._fa = tower(action_fc_layer_params, self._act_dim, 2)
         layers = [L.Dense(int(n), activation_fn, kernel_initializer=ki)
                   for n in (joint_fc_layer_params or ())]
         layers.append(L.Dense(1, output_activation_fn, kernel_initializer=lki))
-        self._seed = seed
         self._body = sequential.Sequential(
-            layers, input_spec=tensor_spec.TensorSpec((self._obs_dim + self._act_dim,),
-                                                      torch.float32), seed=seed)
+            layers, input_spec=tensor_spec.TensorSpec((self._fo + self._fa,), torch.float32),
+            seed=seed)
+        self._flat = None        # (params, grads) of all parts when there are towers
         self._inputs = {}
 
     # ---- parameters -------------------------------------------------------------------------
@@ -64,33 +84,62 @@ class CriticNetwork(network.Network):
     def body(self):
         return self._body
 
+    @property
+    def bodies(self):
+        """The network's `Sequential`s in the order of its flat parameter buffer (= the order the
+        reference creates the layers in: observation tower, action tower, joint stack)."""
+        return [n for n in (self._obs_tower, self._act_tower, self._body) if n is not None]
+
+    @property
+    def has_towers(self):
+        return self._obs_tower is not None or self._act_tower is not None
+
     def create_variables(self, input_tensor_spec=None, device=None, **kwargs):
-        self._body.create_variables(device=device)
+        for n in self.bodies:
+            n.create_variables(device=device)
+        if self.has_towers and self._flat is None:
+            total = sum(n.flat_size for n in self.bodies)
+            dev = self._body.flat_params.device
+            self._bind(torch.empty((total,), dtype=torch.float32, device=dev),
+                       torch.zeros((total,), dtype=torch.float32, device=dev))
         self._built = True
         return ()
 
+    def _bind(self, flat_params, flat_grads):
+        off = 0
+        for n in self.bodies:
+            k = n.flat_size
+            n.rebind(flat_params[off:off + k], flat_grads[off:off + k])
+            off += k
+        self._flat = (flat_params, flat_grads)
+
     @property
     def flat_params(self):
-        return self._body.flat_params
+        return self._flat[0] if self.has_towers else self._body.flat_params
 
     @property
     def flat_grads(self):
-        return self._body.flat_grads
+        return self._flat[1] if self.has_towers else self._body.flat_grads
 
     @property
     def flat_size(self):
-        return self._body.flat_size
+        return sum(n.flat_size for n in self.bodies)
 
     def rebind(self, flat_params, flat_grads):
-        self._body.rebind(flat_params, flat_grads)
+        if not self.has_towers:
+            self._body.rebind(flat_params, flat_grads)
+            return
+        if flat_params.numel() != self.flat_size or flat_grads.numel() != self.flat_size:
+            raise ValueError(f"rebind needs views of {self.flat_size} elements")
+        self._bind(flat_params, flat_grads)
 
     @property
     def variables(self):
-        return self._body.variables
+        return [v for n in self.bodies for v in n.variables]
 
     @property
     def has_regularization(self):
-        return self._body.has_regularization
+        return any(n.has_regularization for n in self.bodies)
 
     def copy(self, **kwargs):
         args = dict(self._ctor)
@@ -99,22 +148,50 @@ class CriticNetwork(network.Network):
         return CriticNetwork(seed=seed, **args)
 
     def set_weights(self, arrays):
-        self._body.set_weights(arrays)
+        arrays = list(arrays)
+        for n in self.bodies:
+            k = len(n.variables)
+            n.set_weights(arrays[:k])
+            arrays = arrays[k:]
+        if arrays:
+            raise ValueError("set_weights: more arrays than variables")
 
     def get_weights(self):
-        return self._body.get_weights()
+        return [w for n in self.bodies for w in n.get_weights()]
 
     # ---- execution ----------------------------------------------------------------------------
     def _input(self, slot, B, dev):
         key = (slot, B)
         buf = self._inputs.get(key)
         if buf is None:
-            buf = {"x": torch.empty((B, self._obs_dim + self._act_dim), dtype=torch.float32,
-                                    device=dev),
-                   "dx": torch.empty((B, self._obs_dim + self._act_dim), dtype=torch.float32,
-                                     device=dev)}
+            f = lambda n: torch.empty((B, n), dtype=torch.float32, device=dev)
+            buf = {"x": f(self._fo + self._fa), "dx": f(self._fo + self._fa)}
+            if self._obs_tower is not None:
+                buf["o_in"], buf["do"] = f(self._obs_dim), f(self._fo)
+            if self._act_tower is not None:
+                buf["a_in"], buf["da_feat"], buf["da"] = f(self._act_dim), f(self._fa), \
+                    f(self._act_dim)
             self._inputs[key] = buf
         return buf
+
+    def _forward_towers(self, o2, a2, buf, slot, need_grad):
+        """critic_network.py:163-185: each input through its Dense stack, then the concatenation."""
+        def through(net, src, stage):
+            if net is None:
+                return src
+            if src.dtype != torch.float32 or not src.is_contiguous():
+                stage.copy_(src)          # tf.cast(..., tf.float32) / a strided slice
+                src = stage
+            return net.forward(src, slot=slot, need_grad=need_grad)
+        of = through(self._obs_tower, o2, buf.get("o_in"))
+        af = through(self._act_tower, a2, buf.get("a_in"))
+        if of.dtype == torch.float32 and af.dtype == torch.float32 and \
+                of.stride(-1) == 1 and af.stride(-1) == 1:
+            ops.copy_segments([(of, buf["x"][:, :self._fo]), (af, buf["x"][:, self._fo:])])
+        else:
+            buf["x"][:, :self._fo].copy_(of)
+            buf["x"][:, self._fo:].copy_(af)
+        return self._body.forward(buf["x"], slot=slot, need_grad=need_grad)
 
     def forward(self, observation, action, slot=0, need_grad=False, x_cat=None):
         """q[B] for observation [B, *obs] and action [B, *act] (buffer owned by the network).
@@ -123,6 +200,9 @@ class CriticNetwork(network.Network):
         backward pass of this slot."""
         B = observation.shape[0]
         buf = self._input(slot, B, observation.device)
+        if self.has_towers:      # (x_cat is the RAW [obs | act] row: not this layout's joint input)
+            return self._forward_towers(observation.reshape(B, -1), action.reshape(B, -1), buf,
+                                        slot, need_grad).view(B)
         if x_cat is not None:
             if tuple(x_cat.shape) != (B, self._obs_dim + self._act_dim) or \
                     not x_cat.is_contiguous() or x_cat.dtype != torch.float32:
@@ -144,11 +224,41 @@ class CriticNetwork(network.Network):
         """Backpropagates d loss / d q [B]; returns d loss / d action [B, act] if asked."""
         B = dq.shape[0]
         buf = self._inputs[(slot, B)]
+        if self.has_towers:
+            return self._backward_towers(dq, buf, slot, param_grads, want_action_grad, side_stream)
         self._body.backward(dq.view(B, 1), slot=slot, side_stream=side_stream,
                             param_grads=param_grads,
                             input_grad=buf["dx"] if want_action_grad else None,
                             input_grad_cols=(self._obs_dim, self._obs_dim + self._act_dim))
         return buf["dx"][:, self._obs_dim:] if want_action_grad else None
+
+    def _backward_towers(self, dq, buf, slot, param_grads, want_action_grad, side_stream):
+        B = dq.shape[0]
+        fo, fa = self._fo, self._fa
+        need_o = self._obs_tower is not None and param_grads
+        need_a = want_action_grad or (self._act_tower is not None and param_grads)
+        cols = (0 if need_o else fo, fo + fa if need_a else fo)
+        want_dx = cols[1] > cols[0]
+        self._body.backward(dq.view(B, 1), slot=slot, side_stream=side_stream,
+                            param_grads=param_grads, input_grad=buf["dx"] if want_dx else None,
+                            input_grad_cols=cols if want_dx else None)
+        # the towers take contiguous [B, features] gradients: both slices in one launch
+        segs = []
+        if need_o:
+            segs.append((buf["dx"][:, :fo], buf["do"]))
+        if need_a and self._act_tower is not None:
+            segs.append((buf["dx"][:, fo:], buf["da_feat"]))
+        if segs:
+            ops.copy_segments(segs)
+        if need_o:
+            self._obs_tower.backward(buf["do"], slot=slot, param_grads=True)
+        if not need_a:
+            return None
+        if self._act_tower is None:
+            return buf["dx"][:, fo:]
+        self._act_tower.backward(buf["da_feat"], slot=slot, param_grads=param_grads,
+                                 input_grad=buf["da"] if want_action_grad else None)
+        return buf["da"] if want_action_grad else None
 
     def call(self, inputs, step_type=None, network_state=(), training=False, **kwargs):
         obs, act = inputs
@@ -163,7 +273,7 @@ def pair_ok(c1, c2, observation, action):
     B = int(observation.shape[0])
     o2, a2 = observation.reshape(B, -1), action.reshape(B, -1)
     return (isinstance(c1, CriticNetwork) and isinstance(c2, CriticNetwork) and
-            c1.body.wide_ok(B) and c1.body.wide_key() is not None and
+            not c1.has_towers and not c2.has_towers and c1.body.wide_ok(B) and c1.body.wide_key() is not None and
             c1.body.wide_key() == c2.body.wide_key() and
             o2.dtype == torch.float32 and a2.dtype == torch.float32 and o2.is_cuda and
             o2.stride(1) == 1 and a2.stride(1) == 1 and

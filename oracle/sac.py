@@ -102,7 +102,8 @@ class OracleSacAgent:
                  target_update_period=1, initial_log_alpha=0.0, target_entropy=None,
                  std_kind="exp", critic_loss_weight=0.5, actor_loss_weight=1.0,
                  alpha_loss_weight=1.0, td_errors_loss_fn=squared_difference,
-                 use_log_alpha_in_alpha_loss=True, dtype=torch.float32):
+                 use_log_alpha_in_alpha_loss=True, dtype=torch.float32, critic_obs_fc=(),
+                 critic_act_fc=()):
         # dtype=torch.float64: the same training in double precision (parameters, forwards, losses,
         # Adam arithmetic with the same fp32-rounded hyper-parameters) -- the yardstick of the
         # free-running envelope test (tests/test_gpu_free_running.py)
@@ -113,6 +114,10 @@ class OracleSacAgent:
         self.A = act_dim
         self.actor_layers = nets.mlp_q_layers(actor_fc, 2 * act_dim, "relu")
         self.critic_layers = nets.mlp_q_layers(critic_fc, 1, "relu")
+        # CriticNetwork's optional per-input Dense(relu) towers (agents/ddpg/critic_network.py:126-145,
+        # :163-185); their parameters come first in a critic's list: observation, action, joint
+        tower = lambda fc: [{"kind": "dense", "units": int(u), "act": "relu"} for u in fc]
+        self.critic_obs_layers, self.critic_act_layers = tower(critic_obs_fc), tower(critic_act_fc)
         self.actor = [p.clone().requires_grad_(True) for p in actor_params]
         self.c1 = [p.clone().requires_grad_(True) for p in critic1_params]
         self.c2 = [p.clone().requires_grad_(True) for p in critic2_params]
@@ -153,6 +158,17 @@ class OracleSacAgent:
         return out
 
     def q(self, params, obs, act, masks=None, tag=""):
+        no, na = 2 * len(self.critic_obs_layers), 2 * len(self.critic_act_layers)
+        if no or na:
+            if masks is not None:
+                raise NotImplementedError("activation masks with critic towers")
+            o, a = obs.to(self.dtype), act.to(self.dtype)
+            if no:
+                o = nets.forward(self.critic_obs_layers, params[:no], o, dtype=self.dtype)
+            if na:
+                a = nets.forward(self.critic_act_layers, params[no:no + na], a, dtype=self.dtype)
+            return nets.forward(self.critic_layers, params[no + na:], torch.cat([o, a], -1),
+                                dtype=self.dtype).reshape(-1)
         return self._mlp(self.critic_layers, params,
                          torch.cat([obs.to(self.dtype), act.to(self.dtype)], -1), masks,
                          tag).reshape(-1)

@@ -299,3 +299,164 @@ def test_ppo_reduce_mean_losses_ignore_the_replica_count(dev):
     base, div4, mean4 = stats[(True, 1)], stats[(True, 4)], stats[(False, 4)]
     np.testing.assert_allclose(mean4, base, rtol=1e-6)
     np.testing.assert_allclose(np.asarray(div4) * 4.0, base, rtol=1e-5)
+
+
+# ---- CriticNetwork(observation_fc_layer_params, action_fc_layer_params) --------------------------
+# tf_agents/agents/ddpg/critic_network.py:126-145 (the towers), :163-185 (call)
+def _tower_reference(weights, n_obs_layers, n_act_layers, obs, act):
+    """float64 autograd restatement of CriticNetwork.call on the network's own weights."""
+    ws = [torch.from_numpy(np.asarray(w)).double().requires_grad_(True) for w in weights]
+    o, a = obs.double(), act.double().requires_grad_(True)
+    k = 0
+    h = o
+    for _ in range(n_obs_layers):
+        h = torch.relu(h @ ws[k] + ws[k + 1])
+        k += 2
+    g = a
+    for _ in range(n_act_layers):
+        g = torch.relu(g @ ws[k] + ws[k + 1])
+        k += 2
+    j = torch.cat([h, g], -1)
+    while k < len(ws) - 2:
+        j = torch.relu(j @ ws[k] + ws[k + 1])
+        k += 2
+    q = (j @ ws[k] + ws[k + 1]).reshape(-1)
+    return q, ws, a
+
+
+@pytest.mark.parametrize("obs_fc,act_fc,joint_fc,B", [
+    ((24,), (12,), (32, 32), 8),            # <= 64 wide: the fused small-MLP kernels
+    ((160, 96), None, (128,), 64),          # observation tower only, wide-MLP kernels
+    (None, (48,), (300,), 33),              # action tower only, general GEMM path, ragged batch
+    ((400, 300), (300,), (300, 200), 256)])  # the DDPG paper's layout
+def test_critic_network_towers_match_autograd(dev, obs_fc, act_fc, joint_fc, B):
+    from agents_amd.networks import critic_network
+    OD, AD = 17, 6
+    obs_spec = tensor_spec.TensorSpec((OD,), torch.float32)
+    act_spec = tensor_spec.BoundedTensorSpec((AD,), torch.float32, -1.0, 1.0)
+    net = critic_network.CriticNetwork((obs_spec, act_spec), observation_fc_layer_params=obs_fc,
+                                       action_fc_layer_params=act_fc,
+                                       joint_fc_layer_params=joint_fc,
+                                       kernel_initializer=L.GlorotUniform(),
+                                       last_kernel_initializer=L.GlorotUniform(), seed=5)
+    net.create_variables(device=dev)
+    assert net.has_towers and net.flat_size == sum(n.flat_size for n in net.bodies) and \
+        net.flat_params.numel() == net.flat_size
+    g = torch.Generator().manual_seed(3)
+    obs, act = torch.randn(B, OD, generator=g), torch.rand(B, AD, generator=g) * 2 - 1
+    dq = torch.randn(B, generator=g)
+    q_ref, ws, a_ref = _tower_reference(net.get_weights(), len(obs_fc or ()), len(act_fc or ()),
+                                        obs, act)
+    (q_ref * dq.double()).sum().backward()
+    q = net.forward(obs.to(dev), act.to(dev), slot="t", need_grad=True)
+    np.testing.assert_allclose(q.cpu().numpy(), q_ref.detach().numpy(), rtol=2e-5, atol=2e-6)
+    da = net.backward(dq.to(dev), slot="t", want_action_grad=True)
+    torch.cuda.synchronize()
+    scale = max(float(w.grad.abs().max()) for w in ws)
+    grads = [gv for n in net.bodies for gv in n.gradients]     # views of net.flat_grads
+    assert len(grads) == len(ws)
+    for got, w in zip(grads, ws):
+        np.testing.assert_allclose(got.cpu().numpy().reshape(w.shape), w.grad.numpy(), rtol=1e-4,
+                                   atol=2e-6 * scale)
+    np.testing.assert_allclose(da.cpu().numpy(), a_ref.grad.numpy(), rtol=1e-4,
+                               atol=2e-6 * float(a_ref.grad.abs().max()))
+    # the actor loss's use: the action gradient alone leaves the parameter gradients untouched
+    before = net.flat_grads.clone()
+    q2 = net.forward(obs.to(dev), act.to(dev), slot="t", need_grad=True)
+    da2 = net.backward(dq.to(dev), slot="t", param_grads=False, want_action_grad=True)
+    assert torch.equal(q2, q) and torch.equal(da2, da) and torch.equal(net.flat_grads, before)
+    # set_weights / copy keep the layout
+    twin = net.copy(name="twin")
+    twin.create_variables(device=dev)
+    twin.set_weights(net.get_weights())
+    assert torch.equal(twin.forward(obs.to(dev), act.to(dev), slot="t"), q)
+
+
+def test_critic_network_rejects_what_is_not_implemented():
+    from agents_amd.networks import critic_network
+    spec = (tensor_spec.TensorSpec((4,), torch.float32),
+            tensor_spec.BoundedTensorSpec((2,), torch.float32, -1.0, 1.0))
+    with pytest.raises(NotImplementedError):
+        critic_network.CriticNetwork(spec, observation_conv_layer_params=[(8, 3, 1)])
+    with pytest.raises(NotImplementedError):
+        critic_network.CriticNetwork(spec, joint_fc_layer_params=(8,),
+                                     joint_dropout_layer_params=(0.1,))
+
+
+def test_sac_agent_with_tower_critics_matches_the_oracle(dev):
+    """SacAgent.train with CriticNetwork towers (the twin critics then run one by one: `pair_ok`
+    is for the tower-less layout) against oracle/sac.py with the same towers, three steps."""
+    from agents_amd.agents.sac import sac_agent
+    from agents_amd.networks import actor_distribution_network as adn
+    from agents_amd.networks import critic_network
+    from oracle import sac as osac
+    OD, A, B = 11, 3, 64
+    OBS = tensor_spec.BoundedTensorSpec((OD,), torch.float32, -1.0, 1.0)
+    ACT = tensor_spec.BoundedTensorSpec((A,), torch.float32, [-1.0, -2.0, 0.0], [1.0, 2.0, 4.0])
+    actor = adn.ActorDistributionNetwork(
+        OBS, ACT, fc_layer_params=(32, 32),
+        continuous_projection_net=lambda spec: adn.TanhNormalProjectionNetwork(
+            spec, std_transform="clip_exp"), seed=1)
+    critic = critic_network.CriticNetwork(
+        (OBS, ACT), observation_fc_layer_params=(40,), action_fc_layer_params=(16,),
+        joint_fc_layer_params=(32, 32), kernel_initializer=L.GlorotUniform(),
+        last_kernel_initializer=L.GlorotUniform(), seed=2)
+    agent = sac_agent.SacAgent(
+        ts.time_step_spec(OBS), ACT, critic_network=critic, actor_network=actor,
+        actor_optimizer=optimizers.Adam(3e-3), critic_optimizer=optimizers.Adam(3e-3),
+        alpha_optimizer=optimizers.Adam(3e-3), target_update_tau=0.05, target_update_period=1,
+        td_errors_loss_fn=common.element_wise_squared_loss, gamma=0.99, reward_scale_factor=0.5,
+        gradient_clipping=None)
+    agent.initialize()
+    host = lambda net: [torch.from_numpy(np.asarray(w).copy()) for w in net.get_weights()]
+    mean, mag = sac_agent._spec_means_and_magnitudes(ACT)
+    oracle = osac.OracleSacAgent(
+        OD, A, (32, 32), (32, 32), mean, mag, host(actor), host(agent.critic_networks[0]),
+        host(agent.critic_networks[1]), actor_lr=3e-3, critic_lr=3e-3, alpha_lr=3e-3, gamma=0.99,
+        reward_scale_factor=0.5, tau=0.05, std_kind="clip_exp", critic_obs_fc=(40,),
+        critic_act_fc=(16,))
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s: torch.randn(*s, generator=g)
+    close = lambda a, b, **kw: np.testing.assert_allclose(
+        np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, dtype=np.float64),
+        np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b, dtype=np.float64), **kw)
+    for step in range(3):
+        obs = torch.tanh(r(B, 2, OD))
+        act = torch.from_numpy(mean) + torch.from_numpy(mag) * torch.tanh(r(B, 2, A))
+        reward, discount = r(B, 2), (torch.rand(B, 2, generator=g) > 0.1).float()
+        exp = trajectory.Trajectory(
+            step_type=torch.ones(B, 2, dtype=torch.int32), observation=obs, action=act,
+            policy_info=(), next_step_type=torch.ones(B, 2, dtype=torch.int32), reward=reward,
+            discount=discount)
+        eps = {k: r(B, A) for k in ("next", "actor", "alpha")}
+        from agents_amd.utils import nest_utils
+        li = agent.train(nest_utils.map_structure(lambda t: t.to(dev), exp),
+                         eps={k: v.to(dev) for k, v in eps.items()})
+        out = oracle.train(obs[:, 0], act[:, 0], obs[:, 1], reward[:, 0], discount[:, 0],
+                           eps["next"], eps["actor"], eps["alpha"])
+        close(li.extra.critic_loss, out["critic_loss"], rtol=1e-5)
+        close(li.extra.actor_loss, out["actor_loss"], rtol=1e-5, atol=1e-5)
+        close(li.extra.alpha_loss, out["alpha_loss"], rtol=1e-5, atol=1e-6)
+    for net, o in zip(agent.critic_networks, (oracle.c1, oracle.c2)):
+        assert len(net.variables) == len(o) == 10
+        for v, ov in zip(net.variables, o):
+            close(v, ov, rtol=2e-4, atol=2e-5)
+    for net, o in zip(agent.target_critic_networks, (oracle.t1, oracle.t2)):
+        for v, ov in zip(net.variables, o):
+            close(v, ov, rtol=2e-4, atol=2e-5)
+    for v, o in zip(agent.actor_network.variables, oracle.actor):
+        close(v, o, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("kw,n_vars", [
+    (dict(observation_fc_layer_params=[20, 10]), 6),      # critic_network_test.py:59-75
+    (dict(action_fc_layer_params=[20]), 4),               # :77-92
+    (dict(joint_fc_layer_params=[20]), 4)])               # :94-109
+def test_critic_network_reference_shape_cases(dev, kw, n_vars):
+    from agents_amd.networks import critic_network
+    obs_spec = tensor_spec.TensorSpec((5,), torch.float32)
+    act_spec = tensor_spec.TensorSpec((2,), torch.float32)
+    net = critic_network.CriticNetwork((obs_spec, act_spec), **kw)
+    net.create_variables(device=dev)
+    q, _ = net((torch.rand(3, 5, device=dev), torch.rand(3, 2, device=dev)))
+    assert tuple(q.shape) == (3,) and len(net.variables) == n_vars
