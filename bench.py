@@ -35,7 +35,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 PRIME_MIN = 0                  # minimum untimed iterations in front of --warmup (see main: priming)
 CPU_RING_FRAMES = 256          # replay frames per env of the cpu_baseline leg (see cpu_baseline)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
-PMC_FILE = os.path.join("profiles", "r05_pmc.json")   # committed rocprofv3 --pmc passes (isolated)
+PMC_FILE = os.path.join("profiles", "r06_pmc.json")   # committed rocprofv3 --pmc passes (isolated)
 PMC_OTHER_FILE = os.path.join("profiles", "r06_pmc_other.json")   # ... of the PPO / SAC kernels
 L2_PEAK_GBS = 34500.0          # MI355X_MICROARCH.md: L2 aggregate (8 XCDs x 4 MiB), ~34.5 TB/s
 # Set in the child of the in-loop profiling pass (see inloop_profile): the run brackets its timed
@@ -1423,7 +1423,7 @@ def main():
                         "conv1.fwd(u8)": "conv1.fwd",
                         "replay.get_next(sample+gather 512 rows)": "replay.get_next"}
             pmc, pmc_src = {}, None
-            for cand in (PMC_FILE, os.path.join("profiles", "r04_pmc.json")):
+            for cand in (PMC_FILE, os.path.join("profiles", "r05_pmc.json")):
                 if os.path.exists(os.path.join(ROOT, cand)):
                     with open(os.path.join(ROOT, cand)) as fh:
                         pmc = json.load(fh).get("cases", {})
