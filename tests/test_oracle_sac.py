@@ -105,6 +105,39 @@ def test_oracle_train_step_runs_and_updates():
     assert not torch.equal(ag.t1[0], c1[0])
 
 
+def test_critic_towers_follow_the_reference_call():
+    """OracleSacAgent.q with CriticNetwork's per-input towers (agents/ddpg/critic_network.py:
+    126-145, call :163-185): each input through its Dense(relu) stack, concatenation, joint stack --
+    against the formula written out in numpy; parameter order observation, action, joint."""
+    rng = np.random.default_rng(4)
+    OD, A, B = 5, 2, 6
+    shapes = [(OD, 7), (7,), (A, 3), (3,), (7 + 3, 8), (8,), (8, 1), (1,)]
+    params = [torch.from_numpy(rng.standard_normal(sh).astype(np.float32)) for sh in shapes]
+    al = osac.nets.mlp_q_layers((4,), 2 * A)
+    ap = osac.nets.init_params(al, (OD,), seed=1)
+    ag = osac.OracleSacAgent(OD, A, (4,), (8,), [0.0, 0.0], [1.0, 1.0], ap, params, params,
+                             critic_obs_fc=(7,), critic_act_fc=(3,))
+    obs = rng.standard_normal((B, OD)).astype(np.float32)
+    act = rng.standard_normal((B, A)).astype(np.float32)
+    w = [p.numpy().astype(np.float64) for p in params]
+    relu = lambda v: np.maximum(v, 0.0)
+    o = relu(obs @ w[0] + w[1])
+    a = relu(act @ w[2] + w[3])
+    j = relu(np.concatenate([o, a], -1) @ w[4] + w[5])
+    want = (j @ w[6] + w[7]).reshape(-1)
+    got = ag.q(ag.c1, torch.from_numpy(obs), torch.from_numpy(act)).detach().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    # the tower-less layout is untouched: concat(obs, act) straight into the joint stack
+    cl = osac.nets.mlp_q_layers((8,), 1)
+    c = osac.nets.init_params(cl, (OD + A,), seed=2)
+    plain = osac.OracleSacAgent(OD, A, (4,), (8,), [0.0, 0.0], [1.0, 1.0], ap, c, c)
+    x = np.concatenate([obs, act], -1).astype(np.float64)
+    wc = [p.numpy().astype(np.float64) for p in c]
+    want2 = (relu(x @ wc[0] + wc[1]) @ wc[2] + wc[3]).reshape(-1)
+    got2 = plain.q(plain.c1, torch.from_numpy(obs), torch.from_numpy(act)).detach().numpy()
+    np.testing.assert_allclose(got2, want2, rtol=1e-5, atol=1e-6)
+
+
 def test_golden_file_lists_the_same_numbers():
     import json
     import os
