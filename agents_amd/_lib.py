@@ -71,6 +71,15 @@ class MlpWideFwd(Structure):
                 ("x2", c_void_p * 4), ("ldx2", c_int64 * 4), ("y", (c_void_p * 4) * 4)]
 
 
+class SacSampleTail(Structure):
+    """aa_sac_sample_tail (include/agents_amd.h)."""
+    _fields_ = [("net", c_int32), ("A", c_int32), ("std_kind", c_int32), ("act_mean", c_void_p),
+                ("act_mag", c_void_p), ("eps_in", c_void_p), ("seed", c_uint64),
+                ("call_counter_dev", c_void_p), ("arrival_dev", c_void_p), ("action", c_void_p),
+                ("logp", c_void_p), ("save_tanh", c_void_p), ("save_sigma", c_void_p),
+                ("save_eps", c_void_p)]
+
+
 class MlpWideBwd(Structure):
     """aa_mlp_wide_bwd (include/agents_amd.h)."""
     _fields_ = [("layout", MlpLayout), ("n_nets", c_int32), ("x_split", c_int32), ("B", c_int64),
@@ -195,6 +204,7 @@ _SIGNATURES = {
     "aa_mlp_small_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "aa_mlp_wide_supported": (c_int, [POINTER(MlpLayout), c_int64]),
     "aa_mlp_wide_forward": (c_int, [POINTER(MlpWideFwd), c_void_p]),
+    "aa_mlp_wide_forward_sample": (c_int, [POINTER(MlpWideFwd), POINTER(SacSampleTail), c_void_p]),
     "aa_mlp_wide_backward": (c_int, [POINTER(MlpWideBwd), c_void_p]),
     "aa_mlp_wide_debug_stamps": (c_int, [c_void_p]),
     "aa_mlp_small_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int32, POINTER(c_int32),
@@ -351,7 +361,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 15:
+    if lib.aa_abi_version() != 16:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

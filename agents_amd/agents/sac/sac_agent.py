@@ -46,6 +46,9 @@ std_clip_transform = adn.std_clip_transform
 _QUAD_FORWARD = True
 # A/B knob: AA_SAC_FUSE_TARGET_UPDATE=0 keeps the soft target update a launch of its own
 _FUSE_TARGET_UPDATE = True
+# AA_SAC_FUSE_SAMPLE=0: the actor's tanh-normal sample stays a launch of its own behind the
+# network's forward (A/B measurements; bit-identical either way)
+_FUSE_SAMPLE = os.environ.get("AA_SAC_FUSE_SAMPLE", "1") != "0"
 
 
 def _spec_means_and_magnitudes(spec):
@@ -92,14 +95,35 @@ class SacPolicy(tf_policy.TFPolicy):
         mean, mag = self._consts(dev)
         if observation.dtype != torch.float32:     # float64 / integer observation specs
             observation = observation.to(torch.float32)
-        z = self._actor_network.forward(observation, slot=slot, need_grad=need_grad)
-        B = z.shape[0]
+        B = int(observation.shape[0])
         key = (slot, B)
         b = self._bufs.get(key)
         if b is None:
             b = {"action": torch.empty((B, self._A), dtype=torch.float32, device=dev),
                  "logp": torch.empty((B,), dtype=torch.float32, device=dev)}
             self._bufs[key] = b
+        net = self._actor_network
+        if _FUSE_SAMPLE and getattr(net, "forward_sample_ok", None) is not None and \
+                net.forward_sample_ok(observation):
+            # the actor's forward launch also draws the sample of its own head output (the
+            # workgroup that produced a row's [mean | raw_std] has it in LDS): aa_sac_sample's
+            # arithmetic and Philox counters, one launch less on the train step's chain
+            t = _lib.SacSampleTail()
+            t.net, t.A, t.std_kind = 0, self._A, net.projection.std_kind
+            t.act_mean, t.act_mag = mean.data_ptr(), mag.data_ptr()
+            t.eps_in = _lib.ptr(eps)
+            t.seed = self._seed
+            t.call_counter_dev = self._call_counter.data_ptr()
+            t.arrival_dev = self._arrival.data_ptr()
+            t.action = (b["action"] if out is None else out).data_ptr()
+            t.logp = b["logp"].data_ptr()
+            if save:
+                t.save_tanh, t.save_sigma, t.save_eps = (_lib.ptr(save["tanh"]),
+                                                         _lib.ptr(save["sigma"]),
+                                                         _lib.ptr(save["eps"]))
+            z = net.forward_sample(observation, t, slot=slot, need_grad=need_grad)
+            return (b["action"] if out is None else out), b["logp"], z
+        z = net.forward(observation, slot=slot, need_grad=need_grad)
         st = _lib.stream_ptr()
         _lib.check(lib.aa_sac_sample(
             z.data_ptr(), B, self._A, mean.data_ptr(), mag.data_ptr(),

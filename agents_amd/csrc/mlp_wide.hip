@@ -37,6 +37,7 @@
 // run-time loop over the layers (unrolled, a chain kernel was 100 KB of code per launch).
 #include "common.h"
 #include "agents_amd.h"
+#include "sac_sample.h"
 
 #define MW_THREADS 512
 #define MW_WAVES 8
@@ -66,12 +67,28 @@ struct MwNetF {
   int64_t ldx, ldx2;
   float* y[AA_MLP_MAX_LAYERS];
 };
+// The SAC actor's sample tail (aa_mlp_wide_forward_sample): net < 0 = none.
+struct MwTail {
+  int net, A, std_kind;
+  const float* act_mean;
+  const float* act_mag;
+  const float* eps_in;
+  uint32_t seed_lo, seed_hi;
+  int64_t* call_counter;
+  int64_t* arrival;
+  float* action;
+  float* logp;
+  float* save_tanh;
+  float* save_sigma;
+  float* save_eps;
+};
 struct MwFwdP {
   aa_mlp_layout lay;
   MwNetF net[AA_MLPW_MAX_NETS];
   int64_t B;
   int x_split;
   long long* stamps;   // nullable (aa_mlp_wide_debug_stamps): [workgroup][16] wall_clock64 ticks
+  MwTail tail;
 };
 static long long* g_mw_stamps = nullptr;
 #define MW_STAMP(i)                                  \
@@ -257,6 +274,43 @@ __global__ void __launch_bounds__(MW_THREADS) aa_mlp_wide_fwd_kernel(MwFwdP p) {
     __syncthreads();
     MW_STAMP(4 + 3 * l)
     hcur = hid[l & 1];
+  }
+  // ---- sample tail: this network is a SAC actor and hcur holds z = [mean | raw_std] of the
+  // workgroup's MW_TS samples ([column][sample]).  One thread per (sample, action dimension), the
+  // A log-density terms of a sample summed in dimension order by one thread: aa_sac_sample_kernel's
+  // arithmetic (sac_sample.h) and Philox counters, without the launch.
+  if (p.tail.net == g) {
+    const MwTail& T = p.tail;
+    const int A = T.A;
+    const float* zf = reinterpret_cast<const float*>(hcur);
+    float* terms = &red[0][0][0];                 // [MW_TS][A]: the layers are done with `red`
+    const uint64_t call = T.call_counter != nullptr ? (uint64_t)T.call_counter[0] : 0ull;
+    for (int i = tid; i < MW_TS * A; i += MW_THREADS) {
+      const int sl = i / A, d = i - sl * A;
+      const int64_t b = s0 + sl;
+      float term = 0.f;
+      if (b < p.B) {
+        const AaSacElem o = aa_sac_sample_elem(zf[d * MW_TS + sl], zf[(A + d) * MW_TS + sl],
+                                               T.std_kind, T.eps_in, (uint64_t)(b * A + d), call,
+                                               T.seed_lo, T.seed_hi, T.act_mean[d], T.act_mag[d]);
+        T.action[b * A + d] = o.action;
+        term = o.term;
+        if (T.save_tanh != nullptr) {
+          T.save_tanh[b * A + d] = o.t;
+          T.save_sigma[b * A + d] = o.sigma;
+          T.save_eps[b * A + d] = o.eps;
+        }
+      }
+      terms[i] = term;
+    }
+    __syncthreads();
+    if (tid < MW_TS && s0 + tid < p.B) {
+      float lp = 0.f;
+      for (int k = 0; k < A; ++k) lp += terms[tid * A + k];   // dimension order
+      T.logp[s0 + tid] = lp;
+    }
+    if (T.arrival != nullptr && T.eps_in == nullptr && T.call_counter != nullptr)
+      aa_advance_when_all_done(T.call_counter, T.arrival, 1, gridDim.x);
   }
 }
 
@@ -637,7 +691,19 @@ int aa_mlp_wide_supported(const aa_mlp_layout* layout, int64_t B) {
   return mw_check_layout(layout) == AA_OK ? 1 : 0;
 }
 
+static int mw_forward(const aa_mlp_wide_fwd* d, const aa_sac_sample_tail* t, void* stream);
+
 int aa_mlp_wide_forward(const aa_mlp_wide_fwd* d, void* stream) {
+  return mw_forward(d, nullptr, stream);
+}
+
+int aa_mlp_wide_forward_sample(const aa_mlp_wide_fwd* d, const aa_sac_sample_tail* tail,
+                               void* stream) {
+  if (tail == nullptr) return AA_ERR_INVALID;
+  return mw_forward(d, tail, stream);
+}
+
+static int mw_forward(const aa_mlp_wide_fwd* d, const aa_sac_sample_tail* t, void* stream) {
   if (d == nullptr || d->B < 1 || d->n_nets < 1 || d->n_nets > AA_MLPW_MAX_NETS) return AA_ERR_INVALID;
   int rc = mw_check_layout(&d->layout);
   if (rc != AA_OK) return rc;
@@ -663,6 +729,26 @@ int aa_mlp_wide_forward(const aa_mlp_wide_fwd* d, void* stream) {
       if (l < d->layout.n_layers && d->y[s][l] == nullptr) return AA_ERR_INVALID;
       p.net[g].y[l] = d->y[s][l];
     }
+  }
+  p.tail = MwTail{};
+  p.tail.net = -1;
+  if (t != nullptr) {
+    const int L = d->layout.n_layers;
+    if (t->net < 0 || t->net >= d->n_nets || t->A < 1 || d->layout.dims[L] != 2 * t->A ||
+        d->layout.acts[L - 1] != AA_ACT_NONE || MW_TS * t->A > MW_WAVES * MW_TS * MW_MAXW)
+      return AA_ERR_INVALID;
+    if (!t->act_mean || !t->act_mag || !t->action || !t->logp) return AA_ERR_INVALID;
+    if ((t->save_tanh == nullptr) != (t->save_sigma == nullptr) ||
+        (t->save_tanh == nullptr) != (t->save_eps == nullptr))
+      return AA_ERR_INVALID;
+    if (t->eps_in == nullptr && t->call_counter_dev == nullptr) return AA_ERR_INVALID;
+    p.tail.net = t->net; p.tail.A = t->A; p.tail.std_kind = t->std_kind;
+    p.tail.act_mean = t->act_mean; p.tail.act_mag = t->act_mag; p.tail.eps_in = t->eps_in;
+    p.tail.seed_lo = (uint32_t)t->seed; p.tail.seed_hi = (uint32_t)(t->seed >> 32);
+    p.tail.call_counter = t->call_counter_dev; p.tail.arrival = t->arrival_dev;
+    p.tail.action = t->action; p.tail.logp = t->logp;
+    p.tail.save_tanh = t->save_tanh; p.tail.save_sigma = t->save_sigma;
+    p.tail.save_eps = t->save_eps;
   }
   const int64_t gx = (d->B + MW_TS - 1) / MW_TS;
   if (gx > 0x7fffffffLL) return AA_ERR_RANGE;

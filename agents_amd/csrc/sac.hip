@@ -14,14 +14,8 @@
 // atanh(action).
 #include "common.h"
 #include "agents_amd.h"
+#include "sac_sample.h"
 #include <math.h>
-
-#define AA_HALF_LOG_2PI_SAC 0.91893853320467274178f
-#define AA_LOG2_SAC 0.69314718055994530942f
-
-__device__ static inline float aa_softplus_f(float t) {
-  return fmaxf(t, 0.f) + log1pf(expf(-fabsf(t)));
-}
 
 // One thread per (sample, action dimension); the A per-dimension log-density terms of a sample are
 // then summed in dimension order by its d == 0 thread through LDS (deterministic; a thread per
@@ -44,32 +38,15 @@ aa_sac_sample_kernel(const float* __restrict__ z, int64_t B, int A, int per_bloc
   const bool live = local < per_block && b < B;
   float term = 0.f;
   if (live) {
-    const float mu = z[b * 2 * A + d];
-    float raw = z[b * 2 * A + A + d];
-    if (std_kind == AA_SAC_STD_CLIP_EXP) raw = fminf(fmaxf(raw, -20.f), 2.f);
-    const float sigma = expf(raw);
-    float eps;
-    if (eps_in != nullptr) {
-      eps = eps_in[b * A + d];
-    } else {
-      const uint64_t i = (uint64_t)(b * A + d);
-      const Philox4 r = philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)call,
-                                      (uint32_t)(call >> 32), seed_lo, seed_hi);
-      const float u1 = 1.0f - aa_u01(r.x);
-      const float u2 = aa_u01(r.y);
-      eps = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
-    }
-    const float x = mu + sigma * eps;
-    const float t = tanhf(x);
-    const float mag = act_mag[d];
-    action[b * A + d] = act_mean[d] + mag * t;
-    const float e = (x - mu) / sigma;   // what MultivariateNormalDiag.log_prob recomputes
-    const float fldj = 2.0f * (AA_LOG2_SAC - x - aa_softplus_f(-2.0f * x));
-    term = -0.5f * (e * e) - logf(sigma) - AA_HALF_LOG_2PI_SAC - logf(fabsf(mag)) - fldj;
+    const AaSacElem o = aa_sac_sample_elem(z[b * 2 * A + d], z[b * 2 * A + A + d], std_kind, eps_in,
+                                           (uint64_t)(b * A + d), call, seed_lo, seed_hi,
+                                           act_mean[d], act_mag[d]);
+    action[b * A + d] = o.action;
+    term = o.term;
     if (save_tanh != nullptr) {
-      save_tanh[b * A + d] = t;
-      save_sigma[b * A + d] = sigma;
-      save_eps[b * A + d] = eps;
+      save_tanh[b * A + d] = o.t;
+      save_sigma[b * A + d] = o.sigma;
+      save_eps[b * A + d] = o.eps;
     }
   }
   terms[threadIdx.x] = term;

@@ -179,6 +179,22 @@ class ActorDistributionNetwork(network.Network):
         return self._body.forward(observation.reshape((B,) + tuple(
             self._body._input_tensor_spec.shape)), slot=slot, need_grad=need_grad)
 
+    def forward_sample_ok(self, observation):
+        """The body runs as ONE wide-MLP launch at this batch size, which can then also draw the
+        tanh-squashed sample of its own head output (`forward_sample`)."""
+        B = int(observation.shape[0])
+        return observation.dtype == torch.float32 and observation.is_cuda and \
+            not self._body._fused_small_ok() and self._body.wide_ok(B)
+
+    def forward_sample(self, observation, tail, slot=0, need_grad=False):
+        """`forward` + the actor head's sample in one launch (csrc/mlp_wide.hip:
+        aa_mlp_wide_forward_sample); `tail`: a filled `_lib.SacSampleTail` with net = 0."""
+        from agents_amd.networks import sequential
+        B = observation.shape[0]
+        x = observation.reshape((B,) + tuple(self._body._input_tensor_spec.shape))
+        return sequential.forward_wide([self._body], [x], slot=slot, need_grad=need_grad,
+                                       sample_tail=tail)[0]
+
     def backward(self, dz, slot=0, side_stream=None):
         self._body.backward(dz, slot=slot, side_stream=side_stream)
 

@@ -1066,13 +1066,17 @@ def _wide_group(nets, B):
     return nets[0].wide_layout()
 
 
-def forward_wide(nets, xs, slot=0, need_grad=False, x2s=None, slots=None, need_grads=None):
+def forward_wide(nets, xs, slot=0, need_grad=False, x2s=None, slots=None, need_grads=None,
+                 sample_tail=None):
     """`net.forward(x, slot, need_grad)` of up to four Sequential networks of the same layout in
     ONE launch.  xs[g]: float32 [B, d] with unit column stride (any row stride); with x2s the
     network input is [xs[g] | x2s[g]] -- a critic's (observation, action) -- read from the two
     tensors in place.  `slots` / `need_grads` (optional lists) give every network its own slot and
     flag -- SAC's critic update evaluates the twin TARGET critics on (next observation, next
     action) and the twin critics on (observation, action) in one launch of four networks.
+    `sample_tail` (a filled `_lib.SacSampleTail`): network `sample_tail.net` is a SAC actor and the
+    launch also draws its tanh-squashed actions and log-probabilities
+    (aa_mlp_wide_forward_sample).
     Returns the networks' output buffers (owned by their slots)."""
     B = int(xs[0].shape[0])
     lay = _wide_group(nets, B)
@@ -1117,8 +1121,13 @@ def forward_wide(nets, xs, slot=0, need_grad=False, x2s=None, slots=None, need_g
     if WIDE_FWD_LOG is not None:
         WIDE_FWD_LOG.append((len(nets), B, [int(lay.dims[i]) for i in range(n + 1)]))
     with torch.cuda.device(xs[0].device):
-        _lib.check(_lib.load().aa_mlp_wide_forward(ctypes.byref(d), _lib.stream_ptr()),
-                   "aa_mlp_wide_forward")
+        if sample_tail is not None:
+            _lib.check(_lib.load().aa_mlp_wide_forward_sample(
+                ctypes.byref(d), ctypes.byref(sample_tail), _lib.stream_ptr()),
+                "aa_mlp_wide_forward_sample")
+        else:
+            _lib.check(_lib.load().aa_mlp_wide_forward(ctypes.byref(d), _lib.stream_ptr()),
+                       "aa_mlp_wide_forward")
     return outs
 
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 15
+#define AA_ABI_VERSION 16
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -774,6 +774,24 @@ typedef struct {
 /* 1 when (layout, B) is within the limits above, else 0 (callers then take the per-layer path) */
 int aa_mlp_wide_supported(const aa_mlp_layout* layout, int64_t B);
 int aa_mlp_wide_forward(const aa_mlp_wide_fwd* d, void* stream);
+/* aa_mlp_wide_forward whose network `net` is a SAC actor (last layer = [mean | raw_std], 2A wide):
+ * the workgroup that has just produced a sample's head output also draws its tanh-squashed action
+ * and log-probability -- aa_sac_sample's arithmetic and Philox stream, bit for bit -- instead of a
+ * second launch reading the head output back (SacAgent._actions_and_log_probs,
+ * agents/sac/sac_agent.py:533-558, right behind the actor network's call).  Fields as the
+ * arguments of aa_sac_sample (below); the head output is still written to y[net][last] (the
+ * backward pass reads it). */
+typedef struct {
+  int32_t net, A, std_kind;
+  const float* act_mean; const float* act_mag;
+  const float* eps_in;                       /* nullable */
+  uint64_t seed;
+  int64_t* call_counter_dev; int64_t* arrival_dev;   /* arrival nullable, as in aa_sac_sample */
+  float* action; float* logp;
+  float* save_tanh; float* save_sigma; float* save_eps;   /* all or none */
+} aa_sac_sample_tail;
+int aa_mlp_wide_forward_sample(const aa_mlp_wide_fwd* d, const aa_sac_sample_tail* tail,
+                               void* stream);
 int aa_mlp_wide_backward(const aa_mlp_wide_bwd* d, void* stream);
 /* Measurement aid: the workgroups of the following aa_mlp_wide_backward launches write
  * wall_clock64() stamps (10 ns ticks) at the phase boundaries of the gradient chain to

@@ -85,7 +85,7 @@ def test_struct_layouts_match_the_header(tmp_path):
 
 
 def test_abi_version(lib):
-    assert lib.aa_abi_version() == 15
+    assert lib.aa_abi_version() == 16
 
 
 def test_argument_validation_without_gpu(lib):

@@ -346,3 +346,55 @@ def test_fused_alpha_tail_is_bit_identical(dev, cfg):
     for x, y in zip(a_fused.replicated_state(), a_three.replicated_state()):
         assert torch.equal(x, y)
     assert a_fused._alpha_optimizer.iterations == a_three._alpha_optimizer.iterations == 5
+
+
+@pytest.mark.parametrize("B", [7, 256])
+@pytest.mark.parametrize("kind", ["exp", "clip_exp"])
+def test_fused_forward_sample_is_bit_identical(dev, B, kind, monkeypatch):
+    """aa_mlp_wide_forward_sample (the actor's forward launch also draws the tanh-squashed action
+    and its log-probability) against forward + aa_sac_sample: head output, actions, log pi and the
+    tensors kept for the backward pass, with supplied noise and with the policy's own Philox stream
+    (whose call counter must move the same way), bit for bit; and whole train steps either way."""
+    def policy():
+        actor = adn.ActorDistributionNetwork(
+            OBS, ACT, fc_layer_params=(128, 96),
+            continuous_projection_net=lambda spec: adn.TanhNormalProjectionNetwork(
+                spec, std_transform=kind), seed=4)
+        actor.create_variables(device=dev)
+        return sac_agent.SacPolicy(TSS, ACT, actor, seed=99)
+    pf, ps = policy(), policy()
+    assert pf._actor_network.forward_sample_ok(torch.zeros(B, OBS_DIM, device=dev))
+    g = torch.Generator().manual_seed(8)
+    obs = torch.tanh(torch.randn(B, OBS_DIM, generator=g)).to(dev)
+    eps = torch.randn(B, A, generator=g).to(dev)
+    mk = lambda: {k: torch.empty(B, A, device=dev) for k in ("tanh", "sigma", "eps")}
+    for use_eps in (True, False, False):
+        sv_f, sv_s = mk(), mk()
+        monkeypatch.setattr(sac_agent, "_FUSE_SAMPLE", True)
+        a_f, lp_f, z_f = pf.sample(obs, slot="t", need_grad=True, eps=eps if use_eps else None,
+                                   save=sv_f)
+        monkeypatch.setattr(sac_agent, "_FUSE_SAMPLE", False)
+        a_s, lp_s, z_s = ps.sample(obs, slot="t", need_grad=True, eps=eps if use_eps else None,
+                                   save=sv_s)
+        torch.cuda.synchronize()
+        assert torch.equal(z_f, z_s) and torch.equal(a_f, a_s) and torch.equal(lp_f, lp_s)
+        for k in sv_f:
+            assert torch.equal(sv_f[k], sv_s[k]), k
+        assert int(pf._call_counter.item()) == int(ps._call_counter.item())
+    assert int(pf._call_counter.item()) == 2          # two draws of the policy's own noise
+    # the agent's train step (critic / actor / alpha phases each sample once) either way
+    monkeypatch.setattr(sac_agent, "_FUSE_SAMPLE", True)
+    ag_f, _ = make_pair(dev, actor_fc=(128, 96), critic_fc=(128, 128), kind=kind)
+    monkeypatch.setattr(sac_agent, "_FUSE_SAMPLE", False)
+    ag_s, _ = make_pair(dev, actor_fc=(128, 96), critic_fc=(128, 128), kind=kind)
+    for step in range(3):
+        exp_d, _, eps_d, _ = batch(dev, 64, 500 + step)
+        for fused, ag in ((True, ag_f), (False, ag_s)):
+            monkeypatch.setattr(sac_agent, "_FUSE_SAMPLE", fused)
+            li = ag.train(exp_d) if step == 2 else ag.train(exp_d, eps=eps_d)
+            if fused:
+                li_f = li
+        for x, y in zip([li_f.loss] + list(li_f.extra), [li.loss] + list(li.extra)):
+            assert torch.equal(x, y)
+    for x, y in zip(ag_f.replicated_state(), ag_s.replicated_state()):
+        assert torch.equal(x, y)
