@@ -303,6 +303,8 @@ _SIGNATURES = {
     "aa_ppo_loss_dist": (c_int, [c_void_p] * 11 + [c_int64, c_int32] + [c_float] * 6 +
                          [c_void_p, c_float, c_float] + [c_void_p] * 5),
     "aa_ppo_head_forward": (c_int, [c_void_p] * 4 + [c_int64, c_int32] + [c_void_p] * 3),
+    "aa_ppo_head_forward_sample": (c_int, [c_void_p] * 4 + [c_int64, c_int32, c_void_p, c_void_p,
+                                           c_uint64] + [c_void_p] * 6),
     "aa_ppo_head_backward": (c_int, [c_void_p] * 5 + [c_int64, c_int32] + [c_void_p] * 3),
     "aa_normal_log_prob": (c_int, [c_void_p] * 3 + [c_int64, c_int32, c_void_p, c_void_p]),
     "aa_normal_sample": (c_int, [c_void_p, c_void_p, c_int64, c_uint64, c_void_p, c_void_p,

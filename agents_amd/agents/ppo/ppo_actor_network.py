@@ -204,6 +204,24 @@ class TanhNormalActorNet(NormalActorNet):
             "aa_ppo_head_forward")
         return b["loc"], b["scale"]
 
+    def forward_sample(self, obs, seed, call_counter, arrival, clip_lo, clip_hi, slot=0):
+        """(loc, scale, action) as FRESH tensors of the caller's: `forward` + one draw of
+        Normal(loc, scale) (+ the clip to [clip_lo, clip_hi], tensors [D] or None) in the head's
+        launch (aa_ppo_head_forward_sample), which also advances `call_counter` -- the collect
+        policy's step without the sample / counter launches and without copying loc and scale
+        out of the network's buffers."""
+        lib = _lib.load()
+        z = self._body.forward(obs, slot=slot, need_grad=False)
+        N = z.shape[0]
+        f = lambda: torch.empty((N, self._D), dtype=torch.float32, device=z.device)
+        loc, scale, action = f(), f(), f()
+        _lib.check(lib.aa_ppo_head_forward_sample(
+            z.data_ptr(), self._head_params.data_ptr(), _lib.ptr(self._mean), _lib.ptr(self._mag),
+            N, self._D, loc.data_ptr(), scale.data_ptr(), seed, call_counter.data_ptr(),
+            arrival.data_ptr(), _lib.ptr(clip_lo), _lib.ptr(clip_hi), action.data_ptr(),
+            _lib.stream_ptr()), "aa_ppo_head_forward_sample")
+        return loc, scale, action
+
     def backward(self, dloc, dscale, slot=0, side_stream=None):
         lib = _lib.load()
         N = dloc.shape[0]
@@ -272,7 +290,11 @@ class ValueNet(network.Network):
     def kernel_grads(self):
         return self._body.kernel_grads
 
-    def forward(self, obs, slot=0, need_grad=False):
+    def forward(self, obs, slot=0, need_grad=False, out=None):
+        """`out` (a contiguous float32 [B] or [B, 1] tensor of the caller's, inference only): the
+        value head writes it instead of the network's own buffer."""
+        if out is not None and not need_grad:
+            return self._body.forward(obs, slot=slot, need_grad=False, out=out.view(-1, 1)).view(-1)
         return self._body.forward(obs, slot=slot, need_grad=need_grad).view(-1)
 
     def backward(self, dv, slot=0, side_stream=None):

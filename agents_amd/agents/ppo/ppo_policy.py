@@ -7,6 +7,9 @@ distribution parameters (and, in collect mode with precomputed values, the value
   tf_agents/policies/greedy_policy.py:70-89   (mode of the distribution = loc)
 Sampling is `aa_normal_sample` (Box-Muller on the package's Philox stream, csrc/ppo.hip).
 """
+import inspect
+import os
+
 import numpy as np
 import torch
 
@@ -15,6 +18,18 @@ from agents_amd.policies import tf_policy
 from agents_amd.specs import tensor_spec
 from agents_amd.trajectories import policy_step
 from agents_amd.utils import nest_utils
+
+# AA_PPO_FUSE_SAMPLE=0: head, draw and counter advance of a policy step stay three launches and the
+# policy info is copied out of the networks' buffers (A/B measurements; bit-identical either way)
+_FUSE_SAMPLE = os.environ.get("AA_PPO_FUSE_SAMPLE", "1") != "0"
+
+
+def _value_takes_out(net):
+    """The value network's forward can write a caller's tensor (ValueNet of this package)."""
+    try:
+        return "out" in inspect.signature(net.forward).parameters
+    except (TypeError, ValueError):
+        return False
 
 
 class PPOPolicy(tf_policy.TFPolicy):
@@ -43,7 +58,9 @@ class PPOPolicy(tf_policy.TFPolicy):
         super().__init__(time_step_spec, action_spec, info_spec=info_spec, clip=clip, name=name)
         self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self._call_counter = None
+        self._arrival = None
         self._lo = self._hi = None
+        self._value_out_ok = _value_takes_out(value_network)
 
     def _variables(self):
         var_list = self._actor_network.variables + self._value_network.variables
@@ -88,6 +105,40 @@ class PPOPolicy(tf_policy.TFPolicy):
         dev = obs.device
         with torch.cuda.device(dev):
             obs = self._normalized(obs)
+            fused = _FUSE_SAMPLE and not self._greedy and \
+                hasattr(self._actor_network, "forward_sample")
+            if fused:
+                # head + draw + clip + counter in one launch, loc / scale written where the policy
+                # info wants them (csrc/ppo.hip: aa_ppo_head_forward_sample; bit-identical to the
+                # launches below)
+                if self._call_counter is None:
+                    self._call_counter = torch.zeros((1,), dtype=torch.int64, device=dev)
+                if self._arrival is None:
+                    self._arrival = torch.zeros((1,), dtype=torch.int64, device=dev)
+                if self._clip and self._lo is None:
+                    self._lo = torch.as_tensor(np.broadcast_to(
+                        np.asarray(self._spec.minimum, np.float32), (self._D,)).copy(), device=dev)
+                    self._hi = torch.as_tensor(np.broadcast_to(
+                        np.asarray(self._spec.maximum, np.float32), (self._D,)).copy(), device=dev)
+                loc, scale, action = self._actor_network.forward_sample(
+                    obs, self._seed, self._call_counter, self._arrival,
+                    self._lo if self._clip else None, self._hi if self._clip else None,
+                    slot="policy")
+                N = loc.shape[0]
+                shp = (N,) + tuple(self._spec.shape)
+                action = action.view(shp)
+                info = ()
+                if self._collect:
+                    info = {"dist_params": {"loc": loc.view(shp), "scale": scale.view(shp)}}
+                    if not self._compute_value_in_train:
+                        v = torch.empty((N,), dtype=torch.float32, device=dev)
+                        info["value_prediction"] = self._value_network.forward(
+                            obs, slot="policy", out=v) if self._value_out_ok \
+                            else self._value_network.forward(obs, slot="policy").clone()
+                if not batched:
+                    action = action.squeeze(0)
+                    info = nest_utils.map_structure(lambda t: t.squeeze(0), info)
+                return policy_step.PolicyStep(action, policy_state, info)
             loc, scale = self._actor_network.forward(obs, slot="policy")
             N = loc.shape[0]
             if self._greedy:

@@ -373,6 +373,38 @@ aa_ppo_head_fwd_kernel(const float* __restrict__ z, const float* __restrict__ st
     scale[e] = aa_softplus(std_bias[d]);
   }
 }
+// aa_ppo_head_fwd_kernel + aa_normal_sample_kernel (+ the clip to the action spec and the advance of
+// the Philox call counter) in one launch: the collect policy's PPOPolicy._action
+// (policies/actor_policy.py through agents/ppo/ppo_policy.py) per environment step.  Element e
+// draws from Philox(counter = (e, call), key = seed) exactly as aa_normal_sample does.
+__global__ void __launch_bounds__(256)
+aa_ppo_head_fwd_sample_kernel(const float* __restrict__ z, const float* __restrict__ std_bias,
+                              const float* __restrict__ act_mean,
+                              const float* __restrict__ act_mag, int64_t N, int D,
+                              float* __restrict__ loc, float* __restrict__ scale,
+                              uint32_t seed_lo, uint32_t seed_hi, int64_t* __restrict__ call_counter,
+                              int64_t* __restrict__ arrival, const float* __restrict__ clip_lo,
+                              const float* __restrict__ clip_hi, float* __restrict__ action) {
+  const uint64_t call = (uint64_t)call_counter[0];
+  const int64_t total = N * D, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int d = (int)(e % D);
+    const float zz = z[e];
+    const float l = act_mag != nullptr ? act_mean[d] + act_mag[d] * tanhf(zz) : zz;
+    const float sc = aa_softplus(std_bias[d]);
+    loc[e] = l;
+    scale[e] = sc;
+    const Philox4 r = philox4x32_10((uint32_t)e, (uint32_t)((uint64_t)e >> 32), (uint32_t)call,
+                                    (uint32_t)(call >> 32), seed_lo, seed_hi);
+    const float u1 = 1.0f - aa_u01(r.x);  // (0, 1]
+    const float u2 = aa_u01(r.y);
+    const float eps = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    float a = l + sc * eps;
+    if (clip_lo != nullptr) a = fmaxf(fminf(a, clip_hi[d]), clip_lo[d]);
+    action[e] = a;
+  }
+  aa_advance_when_all_done(call_counter, arrival, 1, gridDim.x);
+}
 __global__ void __launch_bounds__(256)
 aa_ppo_head_bwd_kernel(const float* __restrict__ z, const float* __restrict__ std_bias,
                        const float* __restrict__ act_mag, const float* __restrict__ dloc,
@@ -648,6 +680,26 @@ int aa_ppo_head_forward(const float* z, const float* std_bias, const float* act_
   if ((act_mean == nullptr) != (act_mag == nullptr)) return AA_ERR_INVALID;
   hipLaunchKernelGGL(aa_ppo_head_fwd_kernel, dim3(aa_ew_blocks(N * D)), dim3(256), 0,
                      (hipStream_t)stream, z, std_bias, act_mean, act_mag, N, (int)D, loc, scale);
+  return aa_launch_status();
+}
+
+int aa_ppo_head_forward_sample(const float* z, const float* std_bias, const float* act_mean,
+                               const float* act_mag, int64_t N, int32_t D, float* loc, float* scale,
+                               uint64_t seed, int64_t* call_counter_dev, int64_t* arrival_dev,
+                               const float* clip_lo, const float* clip_hi, float* action,
+                               void* stream) {
+  if (!z || !std_bias || !loc || !scale || !call_counter_dev || !arrival_dev || !action ||
+      N <= 0 || D <= 0)
+    return AA_ERR_INVALID;
+  if ((act_mean == nullptr) != (act_mag == nullptr) || (clip_lo == nullptr) != (clip_hi == nullptr))
+    return AA_ERR_INVALID;
+  // (at most 64 workgroups: they all arrive on one word when they are done)
+  unsigned blocks = aa_ew_blocks(N * D);
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(aa_ppo_head_fwd_sample_kernel, dim3(blocks), dim3(256), 0,
+                     (hipStream_t)stream, z, std_bias, act_mean, act_mag, N, (int)D, loc, scale,
+                     (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), call_counter_dev,
+                     arrival_dev, clip_lo, clip_hi, action);
   return aa_launch_status();
 }
 

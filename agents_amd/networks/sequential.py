@@ -370,9 +370,23 @@ class Sequential(network.Network):
                                    device=dev)
         return s
 
-    def forward(self, x, slot=0, need_grad=False):
+    def forward(self, x, slot=0, need_grad=False, out=None):
         """Runs the stack on x [B, *input_shape]; returns the last layer's output buffer
-        (owned by the network, overwritten by the next forward on the same slot and batch)."""
+        (owned by the network, overwritten by the next forward on the same slot and batch).
+        `out` (inference only; contiguous float32 [B, units]): receives the output instead -- the
+        small-MLP launch writes it directly, the other paths copy."""
+        if out is not None:
+            if need_grad:
+                raise ValueError("forward(out=...) is for inference (the backward pass reads the "
+                                 "network's own output buffer)")
+            B_ = x.shape[0]
+            if self._built and self._fused_small_ok() and x.dtype == torch.float32 and \
+                    out.is_contiguous() and out.dtype == torch.float32 and \
+                    tuple(out.shape) == (B_, self._shapes[-1][0][1]):
+                _lib.require_cuda(x)
+                return self._forward_fused(x, self._slot(slot, B_, False), B_, out=out)
+            out.copy_(self.forward(x, slot=slot))
+            return out
         self._require_built()
         _lib.require_cuda(x)
         spec = self._input_tensor_spec
@@ -747,11 +761,14 @@ class Sequential(network.Network):
         return (n, tuple(lay.dims[:n + 1]), tuple(lay.acts[:n]), tuple(lay.k_off[:n]),
                 tuple(lay.b_off[:n]))
 
-    def _fused_ptrs(self, s):
+    def _fused_ptrs(self, s, out=None):
         n = len(self._param_layers)
-        return (ctypes.c_void_p * n)(*[y.data_ptr() for y in s.ys])
+        ptrs = [y.data_ptr() for y in s.ys]
+        if out is not None:
+            ptrs[-1] = out.data_ptr()
+        return (ctypes.c_void_p * n)(*ptrs)
 
-    def _forward_fused(self, x, s, B):
+    def _forward_fused(self, x, s, B, out=None):
         x2 = x.reshape(B, -1)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
@@ -761,9 +778,9 @@ class Sequential(network.Network):
             s.xs[i] = s.ys[i - 1]
         _lib.check(_lib.load().aa_mlp_small_forward(
             x2.data_ptr(), x2.shape[1], self.flat_params.data_ptr(), n, self._f_dims,
-            self._f_acts, self._f_koff, self._f_boff, B, self._fused_ptrs(s), _lib.stream_ptr()),
-            "aa_mlp_small_forward")
-        return s.ys[-1]
+            self._f_acts, self._f_koff, self._f_boff, B, self._fused_ptrs(s, out),
+            _lib.stream_ptr()), "aa_mlp_small_forward")
+        return s.ys[-1] if out is None else out
 
     def _backward_fused(self, dout, s, B, input_grad):
         lib = _lib.load()

@@ -671,6 +671,17 @@ int aa_ppo_loss_dist(const float* loc, const float* scale, const float* old_loc,
 int aa_ppo_head_forward(const float* z, const float* std_bias, const float* act_mean,
                         const float* act_mag, int64_t N, int32_t D, float* loc, float* scale,
                         void* stream);
+/* aa_ppo_head_forward + aa_normal_sample (+ the clip of the action to [clip_lo, clip_hi], both [D]
+ * or both NULL, and the advance of *call_counter_dev by one once every workgroup has read it;
+ * arrival_dev: one int64 of scratch, zero before the first call) in one launch: what
+ * PPOPolicy._action does per environment step (policies/actor_policy.py:150-230 under
+ * agents/ppo/ppo_policy.py).  loc / scale are written where the caller wants them (the policy
+ * info of the trajectory), action = loc + scale * eps with aa_normal_sample's Philox draw. */
+int aa_ppo_head_forward_sample(const float* z, const float* std_bias, const float* act_mean,
+                               const float* act_mag, int64_t N, int32_t D, float* loc, float* scale,
+                               uint64_t seed, int64_t* call_counter_dev, int64_t* arrival_dev,
+                               const float* clip_lo, const float* clip_hi, float* action,
+                               void* stream);
 int aa_ppo_head_backward(const float* z, const float* std_bias, const float* act_mag,
                          const float* dloc, const float* dscale, int64_t N, int32_t D, float* dz,
                          float* dbias_elem, void* stream);

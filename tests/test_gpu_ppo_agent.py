@@ -13,6 +13,7 @@ from agents_amd.networks import sequential
 from agents_amd.specs import tensor_spec
 from agents_amd.trajectories import time_step as ts
 from agents_amd.trajectories import trajectory
+from agents_amd.utils import nest_utils
 from oracle import optim as ooptim
 from oracle import ppo as oppo
 
@@ -340,6 +341,40 @@ def test_collect_policy_samples_and_info(dev):
     g = agent.policy.action(step)
     close(g.action, oloc.numpy(), rtol=1e-5, atol=1e-6)  # greedy eval = mode of the Normal
     assert g.info == ()
+
+
+@pytest.mark.parametrize("B", [5, 2048, 20000])
+def test_fused_policy_step_is_bit_identical(dev, B, monkeypatch):
+    """aa_ppo_head_forward_sample (head + Normal draw + clip + counter advance in one launch, loc /
+    scale / value written straight into the policy info's tensors) against the four launches and
+    three copies it replaces: actions, info and the Philox call counter over three steps, bit for
+    bit; the returned tensors are the caller's (a later step does not overwrite them)."""
+    from agents_amd.agents.ppo import ppo_policy
+    agents = []
+    for fused in (True, False):
+        monkeypatch.setattr(ppo_policy, "_FUSE_SAMPLE", fused)
+        agents.append(build_tanh_agent(dev, initial_adaptive_kl_beta=0.0, kl_cutoff_factor=0.0)[0])
+    agents[1].load_state_dict(agents[0].state_dict())
+    g = torch.Generator().manual_seed(3)
+    kept = []
+    for step_i in range(3):
+        obs = torch.randn(B, 5, generator=g).to(dev) * 3.0      # some actions reach the clip
+        step = ts.restart(obs, batch_size=B)
+        outs = []
+        for fused, agent in zip((True, False), agents):
+            monkeypatch.setattr(ppo_policy, "_FUSE_SAMPLE", fused)
+            outs.append(agent.collect_policy.action(step))
+        pf, pu = outs
+        assert torch.equal(pf.action, pu.action)
+        for a, b in zip(nest_utils.flatten(pf.info), nest_utils.flatten(pu.info)):
+            assert torch.equal(a, b)
+        assert int(agents[0].collect_policy._call_counter.item()) == \
+            int(agents[1].collect_policy._call_counter.item()) == step_i + 1
+        kept.append((pf, nest_utils.map_structure(lambda t: t.clone(), pf)))
+    torch.cuda.synchronize()
+    for live, copy in kept:      # fresh tensors per call: earlier results are still intact
+        for a, b in zip(nest_utils.flatten(live), nest_utils.flatten(copy)):
+            assert torch.equal(a, b)
 
 
 def test_constructor_errors(dev):
