@@ -201,6 +201,9 @@ _SIGNATURES = {
     "aa_mlp_small_forward": (c_int, [c_void_p, c_int64, c_void_p, c_int32, POINTER(c_int32),
                                      POINTER(c_int32), POINTER(c_int64), POINTER(c_int64), c_int64,
                                      POINTER(c_void_p), c_void_p]),
+    "aa_mlp_small_forward2": (c_int, [c_void_p, c_int64, c_int64] + 2 * [
+        c_void_p, c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_int64), POINTER(c_int64),
+        c_void_p] + [c_void_p]),
     "aa_mlp_small_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "aa_mlp_wide_supported": (c_int, [POINTER(MlpLayout), c_int64]),
     "aa_mlp_wide_forward": (c_int, [POINTER(MlpWideFwd), c_void_p]),

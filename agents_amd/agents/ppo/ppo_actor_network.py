@@ -204,14 +204,15 @@ class TanhNormalActorNet(NormalActorNet):
             "aa_ppo_head_forward")
         return b["loc"], b["scale"]
 
-    def forward_sample(self, obs, seed, call_counter, arrival, clip_lo, clip_hi, slot=0):
+    def forward_sample(self, obs, seed, call_counter, arrival, clip_lo, clip_hi, slot=0, z=None):
         """(loc, scale, action) as FRESH tensors of the caller's: `forward` + one draw of
         Normal(loc, scale) (+ the clip to [clip_lo, clip_hi], tensors [D] or None) in the head's
         launch (aa_ppo_head_forward_sample), which also advances `call_counter` -- the collect
         policy's step without the sample / counter launches and without copying loc and scale
-        out of the network's buffers."""
+        out of the network's buffers.  `z`: the body's output when the caller has already
+        computed it (PPOPolicy runs the actor's and the value network's bodies in one launch)."""
         lib = _lib.load()
-        z = self._body.forward(obs, slot=slot, need_grad=False)
+        z = self._body.forward(obs, slot=slot, need_grad=False) if z is None else z
         N = z.shape[0]
         f = lambda: torch.empty((N, self._D), dtype=torch.float32, device=z.device)
         loc, scale, action = f(), f(), f()

@@ -120,17 +120,33 @@ class PPOPolicy(tf_policy.TFPolicy):
                         np.asarray(self._spec.minimum, np.float32), (self._D,)).copy(), device=dev)
                     self._hi = torch.as_tensor(np.broadcast_to(
                         np.asarray(self._spec.maximum, np.float32), (self._D,)).copy(), device=dev)
+                want_v = self._collect and not self._compute_value_in_train
+                z = v = None
+                if want_v and self._value_out_ok:
+                    # the actor's and the value network's bodies on the same normalised
+                    # observation in ONE launch (csrc/mlp_small.hip: aa_mlp_small_forward2)
+                    from agents_amd.networks import sequential
+                    N0 = int(obs.shape[0])
+                    abody, vbody = self._actor_network.body, self._value_network.body
+                    if abody._built and vbody._built and abody._fused_small_ok():
+                        z = torch.empty((N0, int(abody._f_dims[len(abody._param_layers)])),
+                                        dtype=torch.float32, device=dev)
+                        v = torch.empty((N0,), dtype=torch.float32, device=dev)
+                        if not sequential.forward_small_pair(abody, vbody, obs, z, v):
+                            z = v = None
                 loc, scale, action = self._actor_network.forward_sample(
                     obs, self._seed, self._call_counter, self._arrival,
                     self._lo if self._clip else None, self._hi if self._clip else None,
-                    slot="policy")
+                    slot="policy", z=z)
                 N = loc.shape[0]
                 shp = (N,) + tuple(self._spec.shape)
                 action = action.view(shp)
                 info = ()
                 if self._collect:
                     info = {"dist_params": {"loc": loc.view(shp), "scale": scale.view(shp)}}
-                    if not self._compute_value_in_train:
+                    if want_v and v is not None:
+                        info["value_prediction"] = v
+                    elif want_v:
                         v = torch.empty((N,), dtype=torch.float32, device=dev)
                         info["value_prediction"] = self._value_network.forward(
                             obs, slot="policy", out=v) if self._value_out_ok \

@@ -288,6 +288,16 @@ int aa_dense_small_dw(const float* x, int64_t ldx, const float* dz, int64_t M, i
 int aa_mlp_small_forward(const float* x, int64_t ldx, const float* params, int32_t n_layers,
                          const int32_t* dims, const int32_t* acts, const int64_t* k_off,
                          const int64_t* b_off, int64_t B, float* const* y_out_h, void* stream);
+/* Two such stacks on the SAME input x [B, dims_a[0] == dims_b[0]] in one launch, inference only:
+ * only the last layer's output of each is written (y_last_*: [B, last width]).  The actor and the
+ * value network of PPOPolicy._action (agents/ppo/ppo_policy.py:231-241 feeds both the same
+ * normalised observation); per network the same arithmetic as aa_mlp_small_forward. */
+int aa_mlp_small_forward2(const float* x, int64_t ldx, int64_t B, const float* params_a,
+                          int32_t n_layers_a, const int32_t* dims_a, const int32_t* acts_a,
+                          const int64_t* k_off_a, const int64_t* b_off_a, float* y_last_a,
+                          const float* params_b, int32_t n_layers_b, const int32_t* dims_b,
+                          const int32_t* acts_b, const int64_t* k_off_b, const int64_t* b_off_b,
+                          float* y_last_b, void* stream);
 int64_t aa_mlp_small_workspace_bytes(int64_t B, int64_t total_params);
 int aa_mlp_small_backward(const float* x, int64_t ldx, const float* params, int32_t n_layers,
                           const int32_t* dims, const int32_t* acts, const int64_t* k_off,
