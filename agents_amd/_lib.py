@@ -80,6 +80,24 @@ class SacSampleTail(Structure):
                 ("save_eps", c_void_p)]
 
 
+class PpoPolicyStepDesc(Structure):
+    """aa_ppo_policy_step_desc (include/agents_amd.h)."""
+    _fields_ = [("x", c_void_p), ("ldx", c_int64), ("B", c_int64),
+                ("nrm_mean", c_void_p), ("nrm_var_num", c_void_p), ("nrm_var_den", c_void_p),
+                ("nrm_eps", c_float), ("nrm_clip", c_float),
+                ("params_a", c_void_p), ("n_layers_a", c_int32), ("dims_a", POINTER(c_int32)),
+                ("acts_a", POINTER(c_int32)), ("k_off_a", POINTER(c_int64)),
+                ("b_off_a", POINTER(c_int64)),
+                ("params_b", c_void_p), ("n_layers_b", c_int32), ("dims_b", POINTER(c_int32)),
+                ("acts_b", POINTER(c_int32)), ("k_off_b", POINTER(c_int64)),
+                ("b_off_b", POINTER(c_int64)),
+                ("value_out", c_void_p),
+                ("std_bias", c_void_p), ("act_mean", c_void_p), ("act_mag", c_void_p),
+                ("D", c_int32), ("loc", c_void_p), ("scale", c_void_p),
+                ("seed", c_uint64), ("call_counter_dev", c_void_p), ("arrival_dev", c_void_p),
+                ("clip_lo", c_void_p), ("clip_hi", c_void_p), ("action", c_void_p)]
+
+
 class MlpWideBwd(Structure):
     """aa_mlp_wide_bwd (include/agents_amd.h)."""
     _fields_ = [("layout", MlpLayout), ("n_nets", c_int32), ("x_split", c_int32), ("B", c_int64),
@@ -201,9 +219,6 @@ _SIGNATURES = {
     "aa_mlp_small_forward": (c_int, [c_void_p, c_int64, c_void_p, c_int32, POINTER(c_int32),
                                      POINTER(c_int32), POINTER(c_int64), POINTER(c_int64), c_int64,
                                      POINTER(c_void_p), c_void_p]),
-    "aa_mlp_small_forward2": (c_int, [c_void_p, c_int64, c_int64] + 2 * [
-        c_void_p, c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_int64), POINTER(c_int64),
-        c_void_p] + [c_void_p]),
     "aa_mlp_small_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "aa_mlp_wide_supported": (c_int, [POINTER(MlpLayout), c_int64]),
     "aa_mlp_wide_forward": (c_int, [POINTER(MlpWideFwd), c_void_p]),
@@ -306,6 +321,7 @@ _SIGNATURES = {
     "aa_ppo_loss_dist": (c_int, [c_void_p] * 11 + [c_int64, c_int32] + [c_float] * 6 +
                          [c_void_p, c_float, c_float] + [c_void_p] * 5),
     "aa_ppo_head_forward": (c_int, [c_void_p] * 4 + [c_int64, c_int32] + [c_void_p] * 3),
+    "aa_ppo_policy_step": (c_int, [POINTER(PpoPolicyStepDesc), c_void_p]),
     "aa_ppo_head_forward_sample": (c_int, [c_void_p] * 4 + [c_int64, c_int32, c_void_p, c_void_p,
                                            c_uint64] + [c_void_p] * 6),
     "aa_ppo_head_backward": (c_int, [c_void_p] * 5 + [c_int64, c_int32] + [c_void_p] * 3),

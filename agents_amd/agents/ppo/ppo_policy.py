@@ -96,6 +96,74 @@ class PPOPolicy(tf_policy.TFPolicy):
                     (1,), dtype=torch.int64, device=self._actor_network.body.flat_params.device)
             self._call_counter.fill_(int(sd["call_counter"]))
 
+    def _ensure_draw_state(self, dev):
+        if self._call_counter is None:
+            self._call_counter = torch.zeros((1,), dtype=torch.int64, device=dev)
+        if self._arrival is None:
+            self._arrival = torch.zeros((1,), dtype=torch.int64, device=dev)
+        if self._clip and self._lo is None:
+            self._lo = torch.as_tensor(np.broadcast_to(
+                np.asarray(self._spec.minimum, np.float32), (self._D,)).copy(), device=dev)
+            self._hi = torch.as_tensor(np.broadcast_to(
+                np.asarray(self._spec.maximum, np.float32), (self._D,)).copy(), device=dev)
+
+    def _one_launch_step(self, obs, dev):
+        """The whole collect step -- observation normalisation, actor body, value body, actor
+        head, Normal draw, clip, Philox counter -- as ONE launch (csrc/ppo.hip: aa_ppo_policy_step;
+        every piece with the arithmetic of the launch it replaces).  (action, info) or None when
+        the configuration does not qualify: PPOActorNetwork-style head on a <= 64-wide body, a
+        <= 64-wide value body, float32 rank-1 observations, collect mode with value predictions,
+        no normaliser or one with a single float32 leaf."""
+        from agents_amd.networks import sequential
+        from agents_amd.utils import tensor_normalizer as tn
+        act, val = self._actor_network, self._value_network
+        if not (self._collect and not self._compute_value_in_train and self._value_out_ok and
+                hasattr(act, "forward_sample") and hasattr(act, "_head_params")):
+            return None
+        if obs.dim() != 2 or obs.dtype != torch.float32 or not obs.is_cuda or obs.stride(1) != 1:
+            return None
+        la, lv = sequential.small_mlp_layout(act.body), sequential.small_mlp_layout(val.body)
+        if la is None or lv is None:
+            return None
+        nrm = self._observation_normalizer
+        mean = num = den = None
+        if nrm is not None:
+            if not isinstance(nrm, tn.TensorNormalizer) or nrm._state is None or \
+                    len(nrm._state) != 1 or \
+                    nrm._flat_specs[0].dtype != torch.float32 or \
+                    len(nrm._flat_specs[0].shape) != 1:
+                return None
+            mean, num, den = nrm._mean_var_ptrs(nrm._state[0])
+        self._ensure_draw_state(dev)
+        N = int(obs.shape[0])
+        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        loc, scale, action, v = f(N, self._D), f(N, self._D), f(N, self._D), f(N)
+        d = _lib.PpoPolicyStepDesc()
+        d.x, d.ldx, d.B = obs.data_ptr(), obs.stride(0), N
+        d.nrm_mean, d.nrm_var_num, d.nrm_var_den = mean, num, den
+        d.nrm_eps, d.nrm_clip = 1e-3, 5.0          # TensorNormalizer.normalize's defaults
+        (d.params_a, d.n_layers_a, d.dims_a, d.acts_a, d.k_off_a, d.b_off_a) = la
+        (d.params_b, d.n_layers_b, d.dims_b, d.acts_b, d.k_off_b, d.b_off_b) = lv
+        d.value_out = v.data_ptr()
+        d.std_bias = act._head_params.data_ptr()
+        d.act_mean, d.act_mag = _lib.ptr(act._mean), _lib.ptr(act._mag)
+        d.D = self._D
+        d.loc, d.scale = loc.data_ptr(), scale.data_ptr()
+        d.seed = self._seed
+        d.call_counter_dev = self._call_counter.data_ptr()
+        d.arrival_dev = self._arrival.data_ptr()
+        d.clip_lo = self._lo.data_ptr() if self._clip else None
+        d.clip_hi = self._hi.data_ptr() if self._clip else None
+        d.action = action.data_ptr()
+        import ctypes
+        rc = _lib.load().aa_ppo_policy_step(ctypes.byref(d), _lib.stream_ptr())
+        if rc in (-22, -34):       # AA_ERR_INVALID / AA_ERR_RANGE: not this kernel's shapes
+            return None
+        _lib.check(rc, "aa_ppo_policy_step")
+        shp = (N,) + tuple(self._spec.shape)
+        return action.view(shp), {"dist_params": {"loc": loc.view(shp), "scale": scale.view(shp)},
+                                  "value_prediction": v}
+
     def _action(self, time_step, policy_state, seed):
         lib = _lib.load()
         obs = time_step.observation
@@ -104,6 +172,14 @@ class PPOPolicy(tf_policy.TFPolicy):
             obs = obs.unsqueeze(0)
         dev = obs.device
         with torch.cuda.device(dev):
+            if _FUSE_SAMPLE and not self._greedy:
+                step = self._one_launch_step(obs, dev)
+                if step is not None:
+                    action, info = step
+                    if not batched:
+                        action = action.squeeze(0)
+                        info = nest_utils.map_structure(lambda t: t.squeeze(0), info)
+                    return policy_step.PolicyStep(action, policy_state, info)
             obs = self._normalized(obs)
             fused = _FUSE_SAMPLE and not self._greedy and \
                 hasattr(self._actor_network, "forward_sample")
@@ -111,42 +187,18 @@ class PPOPolicy(tf_policy.TFPolicy):
                 # head + draw + clip + counter in one launch, loc / scale written where the policy
                 # info wants them (csrc/ppo.hip: aa_ppo_head_forward_sample; bit-identical to the
                 # launches below)
-                if self._call_counter is None:
-                    self._call_counter = torch.zeros((1,), dtype=torch.int64, device=dev)
-                if self._arrival is None:
-                    self._arrival = torch.zeros((1,), dtype=torch.int64, device=dev)
-                if self._clip and self._lo is None:
-                    self._lo = torch.as_tensor(np.broadcast_to(
-                        np.asarray(self._spec.minimum, np.float32), (self._D,)).copy(), device=dev)
-                    self._hi = torch.as_tensor(np.broadcast_to(
-                        np.asarray(self._spec.maximum, np.float32), (self._D,)).copy(), device=dev)
-                want_v = self._collect and not self._compute_value_in_train
-                z = v = None
-                if want_v and self._value_out_ok:
-                    # the actor's and the value network's bodies on the same normalised
-                    # observation in ONE launch (csrc/mlp_small.hip: aa_mlp_small_forward2)
-                    from agents_amd.networks import sequential
-                    N0 = int(obs.shape[0])
-                    abody, vbody = self._actor_network.body, self._value_network.body
-                    if abody._built and vbody._built and abody._fused_small_ok():
-                        z = torch.empty((N0, int(abody._f_dims[len(abody._param_layers)])),
-                                        dtype=torch.float32, device=dev)
-                        v = torch.empty((N0,), dtype=torch.float32, device=dev)
-                        if not sequential.forward_small_pair(abody, vbody, obs, z, v):
-                            z = v = None
+                self._ensure_draw_state(dev)
                 loc, scale, action = self._actor_network.forward_sample(
                     obs, self._seed, self._call_counter, self._arrival,
                     self._lo if self._clip else None, self._hi if self._clip else None,
-                    slot="policy", z=z)
+                    slot="policy")
                 N = loc.shape[0]
                 shp = (N,) + tuple(self._spec.shape)
                 action = action.view(shp)
                 info = ()
                 if self._collect:
                     info = {"dist_params": {"loc": loc.view(shp), "scale": scale.view(shp)}}
-                    if want_v and v is not None:
-                        info["value_prediction"] = v
-                    elif want_v:
+                    if not self._compute_value_in_train:
                         v = torch.empty((N,), dtype=torch.float32, device=dev)
                         info["value_prediction"] = self._value_network.forward(
                             obs, slot="policy", out=v) if self._value_out_ok \

@@ -20,38 +20,7 @@
 #include "common.h"
 #include "agents_amd.h"
 
-#define AA_MLP_MAXW 64
-
-struct AaMlpDesc {
-  int n_layers;
-  int dims[AA_MLP_MAX_LAYERS + 1];     // dims[0] = input width
-  int acts[AA_MLP_MAX_LAYERS];
-  int64_t k_off[AA_MLP_MAX_LAYERS];    // float offsets into the flat parameter / gradient buffer
-  int64_t b_off[AA_MLP_MAX_LAYERS];
-};
-
-__device__ static inline float aa_mlp_act(float v, int act) {
-  if (act == AA_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == AA_ACT_TANH) return tanhf(v);
-  return v;
-}
-__device__ static inline float aa_mlp_actgrad(float y, int act) {
-  if (act == AA_ACT_RELU) return y > 0.f ? 1.f : 0.f;
-  if (act == AA_ACT_TANH) return 1.f - y * y;
-  return 1.f;
-}
-
-// W [n_in][n_out] row-major in HBM -> LDS [64][64] (zero padded); bias -> LDS [64].
-__device__ static inline void aa_mlp_stage_w(const float* __restrict__ params, int64_t k_off,
-                                             int64_t b_off, int n_in, int n_out, float* Ws,
-                                             float* bs) {
-  for (int i = threadIdx.x; i < AA_MLP_MAXW * AA_MLP_MAXW; i += blockDim.x) {
-    const int k = i >> 6, j = i & 63;
-    Ws[i] = (k < n_in && j < n_out) ? params[k_off + (int64_t)k * n_out + j] : 0.f;
-  }
-  if (threadIdx.x < AA_MLP_MAXW) bs[threadIdx.x] = threadIdx.x < n_out ? params[b_off + threadIdx.x]
-                                                                       : 0.f;
-}
+#include "mlp_small_common.h"
 
 struct AaMlpOut {
   float* y[AA_MLP_MAX_LAYERS];
@@ -104,66 +73,6 @@ aa_mlp_small_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* _
       const float v = aa_mlp_act(acc[j], d.acts[l]);
       h[cur ^ 1][s][col] = col < n_out ? v : 0.f;
       if (b < B && col < n_out) yo[b * n_out + col] = v;
-    }
-    cur ^= 1;
-  }
-}
-
-// Two networks on the SAME input in one launch, inference only (blockIdx.y = network; only the
-// last layer's output is written): PPOPolicy's actor and value forwards of a collect step
-// (agents/ppo/ppo_policy.py:231-241: both see the same normalised observation).  Same arithmetic
-// per network as aa_mlp_small_fwd_kernel.
-struct AaMlpTwo {
-  const float* params[2];
-  AaMlpDesc d[2];
-  float* y_last[2];
-};
-template <int TILE>
-__global__ void __launch_bounds__(256)
-aa_mlp_small_fwd2_kernel(const float* __restrict__ x, int64_t ldx, AaMlpTwo P, int64_t B) {
-  constexpr int QN = 256 / TILE, OPT = AA_MLP_MAXW / QN;
-  __shared__ __attribute__((aligned(16))) float Ws[AA_MLP_MAXW * AA_MLP_MAXW];
-  __shared__ __attribute__((aligned(16))) float bs[AA_MLP_MAXW];
-  __shared__ __attribute__((aligned(16))) float h[2][TILE][AA_MLP_MAXW + 4];
-  const int g = blockIdx.y;
-  const float* __restrict__ params = P.params[g];
-  const AaMlpDesc& d = P.d[g];
-  const int s = threadIdx.x / QN, q = threadIdx.x % QN;
-  const int64_t b = (int64_t)blockIdx.x * TILE + s;
-  for (int i = threadIdx.x; i < TILE * AA_MLP_MAXW; i += blockDim.x) {
-    const int ss = i >> 6, k = i & 63;
-    const int64_t bb = (int64_t)blockIdx.x * TILE + ss;
-    h[0][ss][k] = (bb < B && k < d.dims[0]) ? x[bb * ldx + k] : 0.f;
-  }
-  int cur = 0;
-  for (int l = 0; l < d.n_layers; ++l) {
-    const int n_in = d.dims[l], n_out = d.dims[l + 1];
-    __syncthreads();
-    aa_mlp_stage_w(params, d.k_off[l], d.b_off[l], n_in, n_out, Ws, bs);
-    __syncthreads();
-    float acc[OPT];
-#pragma unroll
-    for (int j = 0; j < OPT; ++j) acc[j] = bs[OPT * q + j];
-    for (int k = 0; k < n_in; ++k) {
-      const float hk = h[cur][s][k];
-      const float4* wr = reinterpret_cast<const float4*>(Ws + k * AA_MLP_MAXW + OPT * q);
-#pragma unroll
-      for (int v = 0; v < OPT / 4; ++v) {
-        const float4 w = wr[v];
-        acc[4 * v + 0] = fmaf(hk, w.x, acc[4 * v + 0]);
-        acc[4 * v + 1] = fmaf(hk, w.y, acc[4 * v + 1]);
-        acc[4 * v + 2] = fmaf(hk, w.z, acc[4 * v + 2]);
-        acc[4 * v + 3] = fmaf(hk, w.w, acc[4 * v + 3]);
-      }
-    }
-    const bool last = l == d.n_layers - 1;
-    float* yo = P.y_last[g];
-#pragma unroll
-    for (int j = 0; j < OPT; ++j) {
-      const int col = OPT * q + j;
-      const float v = aa_mlp_act(acc[j], d.acts[l]);
-      h[cur ^ 1][s][col] = col < n_out ? v : 0.f;
-      if (last && b < B && col < n_out) yo[b * n_out + col] = v;
     }
     cur ^= 1;
   }
@@ -320,30 +229,6 @@ aa_mlp_slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int64_t 
 }
 
 // samples per workgroup: the smallest tile that still gives every CU a workgroup
-static int aa_mlp_tile(int64_t B) {
-  if (B >= 64 * 512) return 64;
-  if (B >= 32 * 512) return 32;
-  return 16;
-}
-
-static int aa_mlp_fill(AaMlpDesc& d, int n_layers, const int32_t* dims, const int32_t* acts,
-                       const int64_t* k_off, const int64_t* b_off) {
-  if (n_layers < 1 || n_layers > AA_MLP_MAX_LAYERS || !dims || !acts || !k_off || !b_off)
-    return AA_ERR_INVALID;
-  d.n_layers = n_layers;
-  for (int i = 0; i <= n_layers; ++i) {
-    if (dims[i] < 1 || dims[i] > AA_MLP_MAXW) return AA_ERR_RANGE;
-    d.dims[i] = dims[i];
-  }
-  for (int i = 0; i < n_layers; ++i) {
-    if (acts[i] < AA_ACT_NONE || acts[i] > AA_ACT_TANH) return AA_ERR_INVALID;
-    d.acts[i] = acts[i];
-    d.k_off[i] = k_off[i];
-    d.b_off[i] = b_off[i];
-  }
-  return AA_OK;
-}
-
 extern "C" {
 
 int aa_mlp_small_forward(const float* x, int64_t ldx, const float* params, int32_t n_layers,
@@ -372,35 +257,6 @@ int aa_mlp_small_forward(const float* x, int64_t ldx, const float* params, int32
   else
     hipLaunchKernelGGL(aa_mlp_small_fwd_kernel<64>, dim3((unsigned)grid), dim3(256), 0, st, x, ldx,
                        params, d, B, out);
-  return aa_launch_status();
-}
-
-int aa_mlp_small_forward2(const float* x, int64_t ldx, int64_t B, const float* params_a,
-                          int32_t n_layers_a, const int32_t* dims_a, const int32_t* acts_a,
-                          const int64_t* k_off_a, const int64_t* b_off_a, float* y_last_a,
-                          const float* params_b, int32_t n_layers_b, const int32_t* dims_b,
-                          const int32_t* acts_b, const int64_t* k_off_b, const int64_t* b_off_b,
-                          float* y_last_b, void* stream) {
-  if (!x || !params_a || !params_b || !y_last_a || !y_last_b || B <= 0) return AA_ERR_INVALID;
-  AaMlpTwo P;
-  int rc = aa_mlp_fill(P.d[0], n_layers_a, dims_a, acts_a, k_off_a, b_off_a);
-  if (rc != AA_OK) return rc;
-  rc = aa_mlp_fill(P.d[1], n_layers_b, dims_b, acts_b, k_off_b, b_off_b);
-  if (rc != AA_OK) return rc;
-  if (dims_a[0] != dims_b[0] || ldx < dims_a[0]) return AA_ERR_INVALID;
-  P.params[0] = params_a; P.params[1] = params_b;
-  P.y_last[0] = y_last_a; P.y_last[1] = y_last_b;
-  const int tile = aa_mlp_tile(B);
-  const int64_t grid = (B + tile - 1) / tile;
-  if (grid > 0x7fffffffLL) return AA_ERR_RANGE;
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 g((unsigned)grid, 2);
-  if (tile == 16)
-    hipLaunchKernelGGL(aa_mlp_small_fwd2_kernel<16>, g, dim3(256), 0, st, x, ldx, P, B);
-  else if (tile == 32)
-    hipLaunchKernelGGL(aa_mlp_small_fwd2_kernel<32>, g, dim3(256), 0, st, x, ldx, P, B);
-  else
-    hipLaunchKernelGGL(aa_mlp_small_fwd2_kernel<64>, g, dim3(256), 0, st, x, ldx, P, B);
   return aa_launch_status();
 }
 

@@ -12,6 +12,7 @@
 // denominator (ppo_agent_test.py:701-708) -- divided additionally by the replica count.
 #include "common.h"
 #include "agents_amd.h"
+#include "mlp_small_common.h"
 
 #define AA_PPO_MAXD 64
 #define AA_PPO_P 256
@@ -405,6 +406,126 @@ aa_ppo_head_fwd_sample_kernel(const float* __restrict__ z, const float* __restri
   }
   aa_advance_when_all_done(call_counter, arrival, 1, gridDim.x);
 }
+// ---- a whole collect-policy step in ONE launch ---------------------------------------------------
+// PPOPolicy._action (agents/ppo/ppo_policy.py:231-241 on policies/actor_policy.py): normalise the
+// observation, run the actor body and the value body on it, apply the actor head, draw the action,
+// clip it, advance the Philox counter.  blockIdx.y = 0: actor body + head + draw; 1: value body.
+// A workgroup owns TILE samples and walks its network's layers with activations and the layer's
+// weights in LDS -- aa_mlp_small_fwd_kernel's arithmetic (explicit fmaf), aa_norm_apply_kernel's
+// normalisation, aa_ppo_head_fwd_kernel's head and aa_normal_sample_kernel's draw, each as in the
+// launch it replaces (this file is built without FMA contraction, as normalizer.hip is).
+struct AaPolicyStep {
+  const float* x;
+  int64_t ldx, B;
+  const float* nrm_mean;      // all three NULL: no normalisation
+  const float* nrm_var_num;
+  const float* nrm_var_den;   // nullable (EMA normaliser: var_num is the variance)
+  float nrm_eps, nrm_clip;
+  int has_norm;
+  const float* params[2];
+  AaMlpDesc d[2];
+  float* value_out;           // [B] (network 1's single output)
+  const float* std_bias;
+  const float* act_mean;
+  const float* act_mag;
+  int D;
+  float* loc;
+  float* scale;
+  uint32_t seed_lo, seed_hi;
+  int64_t* call_counter;
+  int64_t* arrival;
+  const float* clip_lo;
+  const float* clip_hi;
+  float* action;
+};
+
+template <int TILE>
+__global__ void __launch_bounds__(256) aa_ppo_policy_step_kernel(AaPolicyStep P) {
+  constexpr int QN = 256 / TILE, OPT = AA_MLP_MAXW / QN;
+  __shared__ __attribute__((aligned(16))) float Ws[AA_MLP_MAXW * AA_MLP_MAXW];
+  __shared__ __attribute__((aligned(16))) float bs[AA_MLP_MAXW];
+  __shared__ __attribute__((aligned(16))) float h[2][TILE][AA_MLP_MAXW + 4];
+  const int g = blockIdx.y;
+  const float* __restrict__ params = P.params[g];
+  const AaMlpDesc& d = P.d[g];
+  const int s = threadIdx.x / QN, q = threadIdx.x % QN;
+  const int64_t b = (int64_t)blockIdx.x * TILE + s;
+  // the Philox call number is read before anything else (every workgroup has it by the time the
+  // last one reports in: aa_advance_when_all_done below)
+  const uint64_t call = g == 0 ? (uint64_t)P.call_counter[0] : 0ull;
+  for (int i = threadIdx.x; i < TILE * AA_MLP_MAXW; i += blockDim.x) {
+    const int ss = i >> 6, k = i & 63;
+    const int64_t bb = (int64_t)blockIdx.x * TILE + ss;
+    float v = 0.f;
+    if (bb < P.B && k < d.dims[0]) {
+      v = P.x[bb * P.ldx + k];
+      if (P.has_norm) {
+        float var = P.nrm_var_num[k];
+        if (P.nrm_var_den != nullptr) var = var / P.nrm_var_den[k];
+        const float inv = 1.0f / sqrtf(var + P.nrm_eps);
+        const float m = P.nrm_mean != nullptr ? P.nrm_mean[k] : 0.0f;
+        v = v * inv + (-m * inv);
+        if (P.nrm_clip > 0.f) v = fminf(fmaxf(v, -P.nrm_clip), P.nrm_clip);
+      }
+    }
+    h[0][ss][k] = v;
+  }
+  int cur = 0;
+  for (int l = 0; l < d.n_layers; ++l) {
+    const int n_in = d.dims[l], n_out = d.dims[l + 1];
+    __syncthreads();
+    aa_mlp_stage_w(params, d.k_off[l], d.b_off[l], n_in, n_out, Ws, bs);
+    __syncthreads();
+    float acc[OPT];
+#pragma unroll
+    for (int j = 0; j < OPT; ++j) acc[j] = bs[OPT * q + j];
+    for (int k = 0; k < n_in; ++k) {
+      const float hk = h[cur][s][k];
+      const float4* wr = reinterpret_cast<const float4*>(Ws + k * AA_MLP_MAXW + OPT * q);
+#pragma unroll
+      for (int v = 0; v < OPT / 4; ++v) {
+        const float4 w = wr[v];
+        acc[4 * v + 0] = fmaf(hk, w.x, acc[4 * v + 0]);
+        acc[4 * v + 1] = fmaf(hk, w.y, acc[4 * v + 1]);
+        acc[4 * v + 2] = fmaf(hk, w.z, acc[4 * v + 2]);
+        acc[4 * v + 3] = fmaf(hk, w.w, acc[4 * v + 3]);
+      }
+    }
+    const bool last = l == d.n_layers - 1;
+#pragma unroll
+    for (int j = 0; j < OPT; ++j) {
+      const int col = OPT * q + j;
+      const float v = aa_mlp_act(acc[j], d.acts[l]);
+      h[cur ^ 1][s][col] = col < n_out ? v : 0.f;
+      if (g == 1 && last && b < P.B && col == 0) P.value_out[b] = v;
+    }
+    cur ^= 1;
+  }
+  if (g != 0) return;
+  __syncthreads();      // h[cur][sample][dimension] = the actor body's output z of this tile
+  const int D = P.D;
+  for (int i = threadIdx.x; i < TILE * D; i += blockDim.x) {
+    const int ss = i / D, dd = i - ss * D;
+    const int64_t bb = (int64_t)blockIdx.x * TILE + ss;
+    if (bb >= P.B) continue;
+    const int64_t e = bb * D + dd;
+    const float zz = h[cur][ss][dd];
+    const float l = P.act_mag != nullptr ? P.act_mean[dd] + P.act_mag[dd] * tanhf(zz) : zz;
+    const float sc = aa_softplus(P.std_bias[dd]);
+    P.loc[e] = l;
+    P.scale[e] = sc;
+    const Philox4 r = philox4x32_10((uint32_t)e, (uint32_t)((uint64_t)e >> 32), (uint32_t)call,
+                                    (uint32_t)(call >> 32), P.seed_lo, P.seed_hi);
+    const float u1 = 1.0f - aa_u01(r.x);  // (0, 1]
+    const float u2 = aa_u01(r.y);
+    const float eps = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    float a = l + sc * eps;
+    if (P.clip_lo != nullptr) a = fmaxf(fminf(a, P.clip_hi[dd]), P.clip_lo[dd]);
+    P.action[e] = a;
+  }
+  aa_advance_when_all_done(P.call_counter, P.arrival, 1, gridDim.x);
+}
+
 __global__ void __launch_bounds__(256)
 aa_ppo_head_bwd_kernel(const float* __restrict__ z, const float* __restrict__ std_bias,
                        const float* __restrict__ act_mag, const float* __restrict__ dloc,
@@ -700,6 +821,45 @@ int aa_ppo_head_forward_sample(const float* z, const float* std_bias, const floa
                      (hipStream_t)stream, z, std_bias, act_mean, act_mag, N, (int)D, loc, scale,
                      (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), call_counter_dev,
                      arrival_dev, clip_lo, clip_hi, action);
+  return aa_launch_status();
+}
+
+int aa_ppo_policy_step(const aa_ppo_policy_step_desc* t, void* stream) {
+  if (t == nullptr || !t->x || t->B <= 0 || !t->params_a || !t->params_b || !t->value_out ||
+      !t->std_bias || !t->loc || !t->scale || !t->call_counter_dev || !t->arrival_dev ||
+      !t->action || t->D <= 0)
+    return AA_ERR_INVALID;
+  if ((t->act_mean == nullptr) != (t->act_mag == nullptr) ||
+      (t->clip_lo == nullptr) != (t->clip_hi == nullptr))
+    return AA_ERR_INVALID;
+  if (t->nrm_var_num == nullptr && (t->nrm_mean != nullptr || t->nrm_var_den != nullptr))
+    return AA_ERR_INVALID;
+  AaPolicyStep P = {};
+  int rc = aa_mlp_fill(P.d[0], t->n_layers_a, t->dims_a, t->acts_a, t->k_off_a, t->b_off_a);
+  if (rc != AA_OK) return rc;
+  rc = aa_mlp_fill(P.d[1], t->n_layers_b, t->dims_b, t->acts_b, t->k_off_b, t->b_off_b);
+  if (rc != AA_OK) return rc;
+  if (t->dims_a[0] != t->dims_b[0] || t->ldx < t->dims_a[0] ||
+      t->dims_a[t->n_layers_a] != t->D || t->dims_b[t->n_layers_b] != 1)
+    return AA_ERR_INVALID;
+  P.x = t->x; P.ldx = t->ldx; P.B = t->B;
+  P.nrm_mean = t->nrm_mean; P.nrm_var_num = t->nrm_var_num; P.nrm_var_den = t->nrm_var_den;
+  P.nrm_eps = t->nrm_eps; P.nrm_clip = t->nrm_clip; P.has_norm = t->nrm_var_num != nullptr;
+  P.params[0] = t->params_a; P.params[1] = t->params_b;
+  P.value_out = t->value_out;
+  P.std_bias = t->std_bias; P.act_mean = t->act_mean; P.act_mag = t->act_mag; P.D = t->D;
+  P.loc = t->loc; P.scale = t->scale;
+  P.seed_lo = (uint32_t)(t->seed & 0xffffffffu); P.seed_hi = (uint32_t)(t->seed >> 32);
+  P.call_counter = t->call_counter_dev; P.arrival = t->arrival_dev;
+  P.clip_lo = t->clip_lo; P.clip_hi = t->clip_hi; P.action = t->action;
+  const int tile = aa_mlp_tile(t->B);
+  const int64_t grid = (t->B + tile - 1) / tile;
+  if (grid > 0x7fffffffLL) return AA_ERR_RANGE;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g((unsigned)grid, 2);
+  if (tile == 16) hipLaunchKernelGGL(aa_ppo_policy_step_kernel<16>, g, dim3(256), 0, st, P);
+  else if (tile == 32) hipLaunchKernelGGL(aa_ppo_policy_step_kernel<32>, g, dim3(256), 0, st, P);
+  else hipLaunchKernelGGL(aa_ppo_policy_step_kernel<64>, g, dim3(256), 0, st, P);
   return aa_launch_status();
 }
 

@@ -1067,30 +1067,14 @@ class Sequential(network.Network):
 
 
 
-def forward_small_pair(net_a, net_b, x, out_a, out_b):
-    """`net_a.forward(x)` and `net_b.forward(x)` (inference; two <= 64-wide Dense stacks on the
-    same float32 [B, d] input) in ONE launch, outputs into the caller's contiguous float32
-    tensors [B, last width] (csrc/mlp_small.hip: aa_mlp_small_forward2).  Returns False -- nothing
-    launched -- when the pair does not qualify."""
-    if not (FUSED_SMALL_MLP and net_a._fused_small_ok() and net_b._fused_small_ok()):
-        return False
-    B = int(x.shape[0])
-    x2 = x.reshape(B, -1)
-    if x2.dtype != torch.float32 or not x2.is_cuda or x2.stride(1) != 1 or \
-            int(net_a._f_dims[0]) != int(net_b._f_dims[0]) or int(x2.shape[1]) != int(net_a._f_dims[0]):
-        return False
-    for net, out in ((net_a, out_a), (net_b, out_b)):
-        if out.dtype != torch.float32 or not out.is_contiguous() or \
-                out.numel() != B * int(net._f_dims[len(net._param_layers)]):
-            return False
-    na, nb = len(net_a._param_layers), len(net_b._param_layers)
-    _lib.check(_lib.load().aa_mlp_small_forward2(
-        x2.data_ptr(), x2.stride(0), B,
-        net_a.flat_params.data_ptr(), na, net_a._f_dims, net_a._f_acts, net_a._f_koff,
-        net_a._f_boff, out_a.data_ptr(),
-        net_b.flat_params.data_ptr(), nb, net_b._f_dims, net_b._f_acts, net_b._f_koff,
-        net_b._f_boff, out_b.data_ptr(), _lib.stream_ptr()), "aa_mlp_small_forward2")
-    return True
+def small_mlp_layout(net):
+    """(flat params pointer, n_layers, dims, acts, k_off, b_off) of a <= 64-wide Dense stack as the
+    small-MLP entry points take them (ctypes arrays owned by the network), or None when the stack
+    does not qualify (`Sequential._fused_small_ok`)."""
+    if not (FUSED_SMALL_MLP and net._built and net._fused_small_ok()):
+        return None
+    return (net.flat_params.data_ptr(), len(net._param_layers), net._f_dims, net._f_acts,
+            net._f_koff, net._f_boff)
 
 
 # ---- wide MLPs: several networks of one layout per launch (csrc/mlp_wide.hip) ---------------------

@@ -288,16 +288,6 @@ int aa_dense_small_dw(const float* x, int64_t ldx, const float* dz, int64_t M, i
 int aa_mlp_small_forward(const float* x, int64_t ldx, const float* params, int32_t n_layers,
                          const int32_t* dims, const int32_t* acts, const int64_t* k_off,
                          const int64_t* b_off, int64_t B, float* const* y_out_h, void* stream);
-/* Two such stacks on the SAME input x [B, dims_a[0] == dims_b[0]] in one launch, inference only:
- * only the last layer's output of each is written (y_last_*: [B, last width]).  The actor and the
- * value network of PPOPolicy._action (agents/ppo/ppo_policy.py:231-241 feeds both the same
- * normalised observation); per network the same arithmetic as aa_mlp_small_forward. */
-int aa_mlp_small_forward2(const float* x, int64_t ldx, int64_t B, const float* params_a,
-                          int32_t n_layers_a, const int32_t* dims_a, const int32_t* acts_a,
-                          const int64_t* k_off_a, const int64_t* b_off_a, float* y_last_a,
-                          const float* params_b, int32_t n_layers_b, const int32_t* dims_b,
-                          const int32_t* acts_b, const int64_t* k_off_b, const int64_t* b_off_b,
-                          float* y_last_b, void* stream);
 int64_t aa_mlp_small_workspace_bytes(int64_t B, int64_t total_params);
 int aa_mlp_small_backward(const float* x, int64_t ldx, const float* params, int32_t n_layers,
                           const int32_t* dims, const int32_t* acts, const int64_t* k_off,
@@ -692,6 +682,27 @@ int aa_ppo_head_forward_sample(const float* z, const float* std_bias, const floa
                                uint64_t seed, int64_t* call_counter_dev, int64_t* arrival_dev,
                                const float* clip_lo, const float* clip_hi, float* action,
                                void* stream);
+/* The WHOLE collect-policy step in one launch: observation normalisation (aa_norm_apply; nrm_var_num
+ * NULL = none, nrm_var_den NULL = var_num is the variance), the actor body (a) and the value body
+ * (b) -- two <= 64-wide Dense stacks (aa_mlp_small_forward's layout arguments, host arrays) on the
+ * same normalised observation x [B, dims_a[0] == dims_b[0]] --, the actor head, the Normal draw, the
+ * clip and the Philox counter advance of aa_ppo_head_forward_sample.  Each piece with the
+ * arithmetic of the launch it replaces (bit-identical results).  value_out: [B]. */
+typedef struct {
+  const float* x; int64_t ldx; int64_t B;
+  const float* nrm_mean; const float* nrm_var_num; const float* nrm_var_den;
+  float nrm_eps, nrm_clip;
+  const float* params_a; int32_t n_layers_a; const int32_t* dims_a; const int32_t* acts_a;
+  const int64_t* k_off_a; const int64_t* b_off_a;
+  const float* params_b; int32_t n_layers_b; const int32_t* dims_b; const int32_t* acts_b;
+  const int64_t* k_off_b; const int64_t* b_off_b;
+  float* value_out;
+  const float* std_bias; const float* act_mean; const float* act_mag; int32_t D;
+  float* loc; float* scale;
+  uint64_t seed; int64_t* call_counter_dev; int64_t* arrival_dev;
+  const float* clip_lo; const float* clip_hi; float* action;
+} aa_ppo_policy_step_desc;
+int aa_ppo_policy_step(const aa_ppo_policy_step_desc* d, void* stream);
 int aa_ppo_head_backward(const float* z, const float* std_bias, const float* act_mag,
                          const float* dloc, const float* dscale, int64_t N, int32_t D, float* dz,
                          float* dbias_elem, void* stream);

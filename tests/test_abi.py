@@ -64,7 +64,14 @@ def test_struct_layouts_match_the_header(tmp_path):
               "aa_ppo_fused_desc": ("PpoFusedDesc", [
                   "obs", "ld_obs", "obs_dim", "D", "actions", "old_vpred", "step_type", "N", "rows",
                   "nrm_count", "nrm_eps", "nrm_clip", "params", "total", "head_off", "actor",
-                  "value", "act_mean", "act_mag", "clip_eps", "denom", "adv_eps"])}
+                  "value", "act_mean", "act_mag", "clip_eps", "denom", "adv_eps"]),
+              "aa_sac_sample_tail": ("SacSampleTail", ["net", "A", "std_kind", "act_mean", "eps_in",
+                                                       "seed", "arrival_dev", "logp", "save_eps"]),
+              "aa_ppo_policy_step_desc": ("PpoPolicyStepDesc", [
+                  "x", "ldx", "B", "nrm_mean", "nrm_var_den", "nrm_eps", "nrm_clip", "params_a",
+                  "n_layers_a", "dims_a", "b_off_a", "params_b", "n_layers_b", "b_off_b",
+                  "value_out", "std_bias", "act_mag", "D", "loc", "seed", "call_counter_dev",
+                  "clip_hi", "action"])}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "agents_amd.h"', 'int main(void){']
     for cname, (_, fs) in fields.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
