@@ -28,6 +28,10 @@ def is_bandit_env(env):
     return False
 
 
+# A/B aid: False keeps the step counter a launch of its own in the eager loop
+COUNT_IN_ADD = True
+
+
 class DynamicStepDriver(driver.Driver):
     def __init__(self, env, policy, observers=None, transition_observers=None, num_steps=1):
         super().__init__(env, policy, observers, transition_observers)
@@ -75,11 +79,38 @@ class DynamicStepDriver(driver.Driver):
             policy_state = action_step.state
             next_time_step = self.env.step(action_step.action)
             traj = trajectory.from_transition(time_step, action_step, next_time_step)
-            for observer in self._observers:
-                observer(traj)
+            # the step count rides in the replay buffer's add_batch launch when the first observer
+            # is one that offers it (csrc/replay.hip: aa_rb_scatter_rows_count; same counter values,
+            # one launch less per loop body -- the eager loop is bound by its launches)
+            fused = self._counting_observer(traj.step_type) if COUNT_IN_ADD else None
+            for k, observer in enumerate(self._observers):
+                if k == 0 and fused is not None:
+                    fused.add_batch_counting(traj, traj.step_type, self._counter, self._total, None)
+                else:
+                    observer(traj)
             for observer in self._transition_observers:
                 observer((time_step, action_step, next_time_step))
-            upper += self._count(traj.step_type)
+            upper += traj.step_type.numel() if fused is not None else self._count(traj.step_type)
             time_step = next_time_step
             iterations += 1
         return time_step, policy_state
+
+    def _counting_observer(self, step_type):
+        """The replay buffer behind observers[0] if its add can also run this loop's counter on
+        `step_type` (int32 [B] on the device), with the counter tensors made ready; else None."""
+        if not self._observers:
+            return None
+        obs0 = self._observers[0]
+        owner = getattr(obs0, "__self__", None)
+        if getattr(obs0, "__name__", "") != "add_batch" or \
+                not getattr(owner, "supports_counting_add", lambda: False)() or \
+                step_type.dim() != 1 or step_type.dtype != torch.int32 or not step_type.is_cuda or \
+                not step_type.is_contiguous():
+            return None
+        B = step_type.numel()
+        if self._total is None or self._total.device != step_type.device:
+            self._total = torch.zeros((1,), dtype=torch.int64, device=step_type.device)
+        if self._counter is None or self._counter.numel() != B or \
+                self._counter.device != step_type.device:
+            self._counter = torch.zeros((B,), dtype=torch.int32, device=step_type.device)
+        return owner
