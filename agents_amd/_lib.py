@@ -80,6 +80,23 @@ class SacSampleTail(Structure):
                 ("save_eps", c_void_p)]
 
 
+class SacDoutGen(Structure):
+    """aa_sac_dout_gen (include/agents_amd.h)."""
+    _fields_ = [("kind", c_int32), ("q1", c_void_p), ("q2", c_void_p), ("tq1", c_void_p),
+                ("tq2", c_void_p), ("next_logp", c_void_p), ("reward", c_void_p),
+                ("discount", c_void_p), ("logp", c_void_p), ("weights", c_void_p),
+                ("log_alpha", c_void_p), ("gamma", c_float), ("reward_scale", c_float),
+                ("loss_kind", c_int32), ("loss_weight", c_float), ("global_batch", c_float),
+                ("loss_out", c_void_p), ("td_target_out", c_void_p), ("dlogp_out", c_void_p),
+                ("z", c_void_p), ("A", c_int32), ("std_kind", c_int32), ("act_mag", c_void_p),
+                ("save_tanh", c_void_p), ("save_sigma", c_void_p), ("save_eps", c_void_p),
+                ("daction", c_void_p), ("ld_daction", c_int64), ("daction2", c_void_p),
+                ("ld_daction2", c_int64), ("dlogp", c_void_p)]
+
+
+AA_SAC_GEN_CRITIC, AA_SAC_GEN_ACTOR, AA_SAC_GEN_HEAD = 1, 2, 3
+
+
 class PpoPolicyStepDesc(Structure):
     """aa_ppo_policy_step_desc (include/agents_amd.h)."""
     _fields_ = [("x", c_void_p), ("ldx", c_int64), ("B", c_int64),
@@ -223,6 +240,7 @@ _SIGNATURES = {
     "aa_mlp_wide_supported": (c_int, [POINTER(MlpLayout), c_int64]),
     "aa_mlp_wide_forward": (c_int, [POINTER(MlpWideFwd), c_void_p]),
     "aa_mlp_wide_forward_sample": (c_int, [POINTER(MlpWideFwd), POINTER(SacSampleTail), c_void_p]),
+    "aa_mlp_wide_backward_gen": (c_int, [POINTER(MlpWideBwd), POINTER(SacDoutGen), c_void_p]),
     "aa_mlp_wide_backward": (c_int, [POINTER(MlpWideBwd), c_void_p]),
     "aa_mlp_wide_debug_stamps": (c_int, [c_void_p]),
     "aa_mlp_small_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int32, POINTER(c_int32),
@@ -382,7 +400,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 16:
+    if lib.aa_abi_version() != 17:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

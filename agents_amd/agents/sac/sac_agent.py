@@ -49,6 +49,9 @@ _FUSE_TARGET_UPDATE = True
 # AA_SAC_FUSE_SAMPLE=0: the actor's tanh-normal sample stays a launch of its own behind the
 # network's forward (A/B measurements; bit-identical either way)
 _FUSE_SAMPLE = os.environ.get("AA_SAC_FUSE_SAMPLE", "1") != "0"
+# AA_SAC_FUSE_LOSSES=0: critic loss, actor loss and the actor head's backward stay launches of their
+# own in front of the gradient-chain launches that consume them (A/B; bit-identical either way)
+_FUSE_LOSSES = os.environ.get("AA_SAC_FUSE_LOSSES", "1") != "0"
 
 
 def _spec_means_and_magnitudes(spec):
@@ -392,6 +395,24 @@ class SacAgent(tf_agent.TFAgent):
                                                 x_cat=x_sa)
             q2 = self._critic_network_2.forward(obs, actions, slot="critic", need_grad=need_grad,
                                                 x_cat=x_sa)
+        if need_grad and pair and _FUSE_LOSSES:
+            # the critics' gradient-chain launch computes the loss and d loss / d q itself
+            # (csrc/mlp_wide.hip: aa_mlp_wide_backward_gen; aa_sac_critic_loss's arithmetic)
+            gen = _lib.SacDoutGen()
+            gen.kind = _lib.AA_SAC_GEN_CRITIC
+            gen.q1, gen.q2, gen.tq1, gen.tq2 = (q1.data_ptr(), q2.data_ptr(), tq1.data_ptr(),
+                                                tq2.data_ptr())
+            gen.next_logp, gen.reward, gen.discount = (nlogp.data_ptr(), reward.data_ptr(),
+                                                       discount.data_ptr())
+            gen.weights = _lib.ptr(weights)
+            gen.log_alpha = self._log_alpha_buf.data_ptr()
+            gen.gamma, gen.reward_scale = self._gamma, self._reward_scale_factor
+            gen.loss_kind, gen.loss_weight = self._loss_kind(), self._critic_loss_weight
+            gen.global_batch = float(B * self.num_replicas)
+            gen.loss_out, gen.td_target_out = w["closs"].data_ptr(), w["td"].data_ptr()
+            critic_network.backward_pair(self._critic_network_1, self._critic_network_2, None,
+                                         None, slot="critic", gen=gen, batch=B)
+            return w["closs"]
         _lib.check(lib.aa_sac_critic_loss(
             q1.data_ptr(), q2.data_ptr(), tq1.data_ptr(), tq2.data_ptr(), nlogp.data_ptr(),
             reward.data_ptr(), discount.data_ptr(), _lib.ptr(weights),
@@ -430,6 +451,37 @@ class SacAgent(tf_agent.TFAgent):
                                                 x_cat=x_pi)
             q2 = self._critic_network_2.forward(obs, a, slot="actor_q", need_grad=need_grad,
                                                 x_cat=x_pi)
+        if need_grad and pair and _FUSE_LOSSES and self._actor_network.body.wide_ok(B) and \
+                not self._actor_network.body._fused_small_ok():
+            # actor loss inside the critics' chain launch (d loss / d q, d loss / d log pi, the
+            # loss value), the head's backward inside the actor's (aa_mlp_wide_backward_gen)
+            gen = _lib.SacDoutGen()
+            gen.kind = _lib.AA_SAC_GEN_ACTOR
+            gen.q1, gen.q2, gen.logp = q1.data_ptr(), q2.data_ptr(), logp.data_ptr()
+            gen.weights = _lib.ptr(weights)
+            gen.log_alpha = self._log_alpha_buf.data_ptr()
+            gen.loss_weight = self._actor_loss_weight
+            gen.global_batch = float(B * self.num_replicas)
+            gen.loss_out, gen.dlogp_out = w["aloss"].data_ptr(), w["dlogp"].data_ptr()
+            da1, da2 = critic_network.backward_pair(
+                self._critic_network_1, self._critic_network_2, None, None, slot="actor_q",
+                param_grads=False, want_action_grad=True, gen=gen, batch=B)
+            mag = self._train_policy._consts(obs.device)[1]
+            hg = _lib.SacDoutGen()
+            hg.kind = _lib.AA_SAC_GEN_HEAD
+            hg.z, hg.A = z.data_ptr(), self._A
+            hg.std_kind = self._actor_network.projection.std_kind
+            hg.act_mag = mag.data_ptr()
+            hg.save_tanh, hg.save_sigma, hg.save_eps = (w["save"]["tanh"].data_ptr(),
+                                                        w["save"]["sigma"].data_ptr(),
+                                                        w["save"]["eps"].data_ptr())
+            hg.daction, hg.ld_daction = da1.data_ptr(), da1.stride(0)
+            hg.daction2, hg.ld_daction2 = da2.data_ptr(), da2.stride(0)
+            hg.dlogp = w["dlogp"].data_ptr()
+            from agents_amd.networks import sequential
+            sequential.backward_wide([self._actor_network.body], None, slot="actor", gen=hg,
+                                     batch=B)
+            return w["aloss"]
         _lib.check(lib.aa_sac_actor_loss(
             q1.data_ptr(), q2.data_ptr(), logp.data_ptr(), _lib.ptr(weights),
             self._log_alpha_buf.data_ptr(), self._actor_loss_weight, B,

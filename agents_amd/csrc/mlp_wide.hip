@@ -38,6 +38,7 @@
 #include "common.h"
 #include "agents_amd.h"
 #include "sac_sample.h"
+#include "sac_loss.h"
 
 #define MW_THREADS 512
 #define MW_WAVES 8
@@ -324,12 +325,35 @@ struct MwNetB {
   float* dx;
   int64_t ld_dx;
 };
+// dout generators (aa_mlp_wide_backward_gen): the launch computes d loss / d output itself instead
+// of reading what a loss launch left -- SAC's critic loss, actor loss and actor-head backward are a
+// few loads and flops per sample, and each was a launch of its own on the train step's chain.
+struct MwGen {
+  int kind;                 // 0 none, AA_SAC_GEN_CRITIC / _ACTOR / _HEAD
+  const float* q1; const float* q2;
+  const float* tq1; const float* tq2; const float* next_logp; const float* reward;
+  const float* discount;
+  const float* logp;
+  const float* weights;
+  const float* log_alpha;
+  float gamma, reward_scale;
+  int loss_kind;
+  float loss_weight, global_batch;
+  float* loss_out;
+  float* td_target_out;
+  float* dlogp_out;
+  const float* z; int A, std_kind;
+  const float* act_mag; const float* save_tanh; const float* save_sigma; const float* save_eps;
+  const float* daction; int64_t ld_da; const float* daction2; int64_t ld_da2;
+  const float* dlogp;
+};
 struct MwBwdP {
   aa_mlp_layout lay;
   MwNetB net[AA_MLPW_MAX_NETS];
   int64_t B;
   int dx_lo, dx_hi;
   long long* stamps;   // nullable (aa_mlp_wide_debug_stamps): [workgroup][16] wall_clock64 ticks
+  MwGen gen;
 };
 
 
@@ -390,7 +414,7 @@ __global__ void __launch_bounds__(MW_VT) aa_mlp_wide_chain_kernel(MwBwdP p) {
       yv[l][h] = y[live ? (s0 + s) * n_out + ec : 0];
     }
   }
-  {
+  if (p.gen.kind == 0) {
     const float* __restrict__ dout = p.net[g].dout;
     const int64_t ld = p.net[g].ld_dout;
     const int n = p.lay.dims[L];
@@ -400,6 +424,77 @@ __global__ void __launch_bounds__(MW_VT) aa_mlp_wide_chain_kernel(MwBwdP p) {
       const bool live = ec < n && s0 + s < p.B;
       const float v = dout[live ? (s0 + s) * ld + ec : 0];
       if (ec < n) gs[s][ec] = live ? v : 0.f;
+    }
+  } else {
+    // d loss / d output computed here (sac_loss.h: the loss kernels' own per-sample arithmetic)
+    const MwGen& G = p.gen;
+    const int n = p.lay.dims[L];
+    if (G.kind == AA_SAC_GEN_HEAD) {
+      const int A = G.A;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int s = es + 2 * h;
+        const int64_t b = s0 + s;
+        const bool live = ec < n && b < p.B;
+        float v = 0.f;
+        if (live) {
+          const int d = ec < A ? ec : ec - A;
+          const int64_t i = b * A + d;
+          float da = G.daction != nullptr ? G.daction[b * G.ld_da + d] : 0.f;
+          if (G.daction2 != nullptr) da = da + G.daction2[b * G.ld_da2 + d];
+          float gx, draw;
+          aa_sac_head_bwd_elem(G.save_tanh[i], G.save_sigma[i], G.save_eps[i], G.dlogp[b], da,
+                               G.act_mag[d], G.z[b * 2 * A + A + d], G.std_kind, &gx, &draw);
+          v = ec < A ? gx : draw;
+        }
+        if (ec < n) gs[s][ec] = v;
+      }
+    } else {
+      // the twin critics (networks 0 and 1 of the launch): one output column each
+      const float alpha = expf(G.log_alpha[0]);
+      if (ec == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int s = es + 2 * h;
+          const int64_t b = s0 + s;
+          float v = 0.f;
+          if (b < p.B) {
+            if (G.kind == AA_SAC_GEN_CRITIC) {
+              const AaSacCriticElem o = aa_sac_critic_elem(
+                  G.q1[b], G.q2[b], G.tq1[b], G.tq2[b], G.next_logp[b], G.reward[b], G.discount[b],
+                  G.weights, b, alpha, G.gamma, G.reward_scale, G.loss_kind);
+              v = (G.loss_weight * (g == 0 ? o.g1 : o.g2) * o.w) / G.global_batch;
+              if (g == 0 && G.td_target_out != nullptr) G.td_target_out[b] = o.td;
+            } else {
+              const AaSacActorElem o = aa_sac_actor_elem(G.q1[b], G.q2[b], G.logp[b], G.weights, b,
+                                                         alpha, G.loss_weight, G.global_batch);
+              v = g == 0 ? o.dq1 : o.dq2;
+              if (g == 0) G.dlogp_out[b] = o.dlogp;
+            }
+          }
+          gs[s][0] = v;
+        }
+      }
+      // the loss value: workgroup (0, 0), with the loss kernel's own reduction (256 lanes walking
+      // the batch, fixed tree)
+      if (blockIdx.x == 0 && g == 0) {
+        __shared__ float gred[16];
+        float local = 0.f;
+        if (tid < 256) {
+          for (int64_t b = tid; b < p.B; b += 256) {
+            if (G.kind == AA_SAC_GEN_CRITIC) {
+              local += aa_sac_critic_elem(G.q1[b], G.q2[b], G.tq1[b], G.tq2[b], G.next_logp[b],
+                                          G.reward[b], G.discount[b], G.weights, b, alpha, G.gamma,
+                                          G.reward_scale, G.loss_kind).wl;
+            } else {
+              local += aa_sac_actor_elem(G.q1[b], G.q2[b], G.logp[b], G.weights, b, alpha,
+                                         G.loss_weight, G.global_batch).wl;
+            }
+          }
+        }
+        const float total = aa_block_sum(local, gred);
+        if (tid == 0) G.loss_out[0] = G.loss_weight * (total / G.global_batch);
+      }
     }
   }
   mw_lds_barrier();
@@ -757,7 +852,18 @@ static int mw_forward(const aa_mlp_wide_fwd* d, const aa_sac_sample_tail* t, voi
   return aa_launch_status();
 }
 
+static int mw_backward(const aa_mlp_wide_bwd* d, const aa_sac_dout_gen* gen, void* stream);
+
 int aa_mlp_wide_backward(const aa_mlp_wide_bwd* d, void* stream) {
+  return mw_backward(d, nullptr, stream);
+}
+
+int aa_mlp_wide_backward_gen(const aa_mlp_wide_bwd* d, const aa_sac_dout_gen* gen, void* stream) {
+  if (gen == nullptr) return AA_ERR_INVALID;
+  return mw_backward(d, gen, stream);
+}
+
+static int mw_backward(const aa_mlp_wide_bwd* d, const aa_sac_dout_gen* gen, void* stream) {
   if (d == nullptr || d->B < 1 || d->n_nets < 1 || d->n_nets > AA_MLPW_MAX_NETS) return AA_ERR_INVALID;
   int rc = mw_check_layout(&d->layout);
   if (rc != AA_OK) return rc;
@@ -780,7 +886,8 @@ int aa_mlp_wide_backward(const aa_mlp_wide_bwd* d, void* stream) {
   q.x_split = d->x_split;
   for (int g = 0; g < AA_MLPW_MAX_NETS; ++g) {
     const int s = g < d->n_nets ? g : 0;
-    if (d->params[s] == nullptr || d->dout[s] == nullptr || d->ld_dout[s] < lay.dims[L])
+    if (d->params[s] == nullptr) return AA_ERR_INVALID;
+    if (gen == nullptr && (d->dout[s] == nullptr || d->ld_dout[s] < lay.dims[L]))
       return AA_ERR_INVALID;
     if ((d->dx[s] != nullptr) != want_dx || (d->grads[s] != nullptr) != want_dw)
       return AA_ERR_INVALID;
@@ -807,6 +914,40 @@ int aa_mlp_wide_backward(const aa_mlp_wide_bwd* d, void* stream) {
       if (d->x_split < lay.dims[0] && (d->x2[s] == nullptr || d->ldx2[s] < lay.dims[0] - d->x_split))
         return AA_ERR_INVALID;
     }
+  }
+  p.gen = MwGen{};
+  if (gen != nullptr) {
+    const aa_sac_dout_gen& t = *gen;
+    MwGen& G = p.gen;
+    if (t.kind == AA_SAC_GEN_CRITIC || t.kind == AA_SAC_GEN_ACTOR) {
+      if (d->n_nets != 2 || lay.dims[L] != 1 || !t.q1 || !t.q2 || !t.log_alpha || !t.loss_out ||
+          !(t.global_batch > 0.f))
+        return AA_ERR_INVALID;
+      if (t.kind == AA_SAC_GEN_CRITIC &&
+          (!t.tq1 || !t.tq2 || !t.next_logp || !t.reward || !t.discount ||
+           (t.loss_kind != AA_LOSS_HUBER && t.loss_kind != AA_LOSS_SQUARED)))
+        return AA_ERR_INVALID;
+      if (t.kind == AA_SAC_GEN_ACTOR && (!t.logp || !t.dlogp_out)) return AA_ERR_INVALID;
+    } else if (t.kind == AA_SAC_GEN_HEAD) {
+      if (d->n_nets != 1 || t.A < 1 || lay.dims[L] != 2 * t.A || !t.z || !t.act_mag ||
+          !t.save_tanh || !t.save_sigma || !t.save_eps || !t.dlogp)
+        return AA_ERR_INVALID;
+      if ((t.daction != nullptr && t.ld_daction < t.A) ||
+          (t.daction2 != nullptr && (t.ld_daction2 < t.A || t.daction == nullptr)))
+        return AA_ERR_INVALID;
+    } else {
+      return AA_ERR_INVALID;
+    }
+    G.kind = t.kind;
+    G.q1 = t.q1; G.q2 = t.q2; G.tq1 = t.tq1; G.tq2 = t.tq2; G.next_logp = t.next_logp;
+    G.reward = t.reward; G.discount = t.discount; G.logp = t.logp; G.weights = t.weights;
+    G.log_alpha = t.log_alpha; G.gamma = t.gamma; G.reward_scale = t.reward_scale;
+    G.loss_kind = t.loss_kind; G.loss_weight = t.loss_weight; G.global_batch = t.global_batch;
+    G.loss_out = t.loss_out; G.td_target_out = t.td_target_out; G.dlogp_out = t.dlogp_out;
+    G.z = t.z; G.A = t.A; G.std_kind = t.std_kind; G.act_mag = t.act_mag;
+    G.save_tanh = t.save_tanh; G.save_sigma = t.save_sigma; G.save_eps = t.save_eps;
+    G.daction = t.daction; G.ld_da = t.ld_daction; G.daction2 = t.daction2;
+    G.ld_da2 = t.ld_daction2; G.dlogp = t.dlogp;
   }
   if (d->B > 0x7fffffffLL) return AA_ERR_RANGE;
   const int64_t gx = (d->B + MW_TS - 1) / MW_TS;

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "agents_amd.h"
 #include "sac_sample.h"
+#include "sac_loss.h"
 #include <math.h>
 
 // One thread per (sample, action dimension); the A per-dimension log-density terms of a sample are
@@ -76,16 +77,13 @@ aa_sac_head_bwd_kernel(const float* __restrict__ z, int64_t B, int A,
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int64_t b = i / A;
     const int d = (int)(i - b * A);
-    const float t = save_tanh[i], sigma = save_sigma[i], eps = save_eps[i];
     const float dl = dlogp[b];
     // d loss / d action: one tensor, or the sum of two (the twin critics' input gradients)
     float da = daction != nullptr ? daction[b * ld_da + d] : 0.f;
     if (daction2 != nullptr) da = da + daction2[b * ld_da2 + d];
-    const float gx = da * (act_mag[d] * (1.0f - t * t)) + dl * (2.0f * t);
-    const float dsigma = gx * eps - dl / sigma;
-    const float raw = z[b * 2 * A + A + d];
-    float draw = dsigma * sigma;
-    if (std_kind == AA_SAC_STD_CLIP_EXP && (raw < -20.f || raw > 2.f)) draw = 0.f;
+    float gx, draw;
+    aa_sac_head_bwd_elem(save_tanh[i], save_sigma[i], save_eps[i], dl, da, act_mag[d],
+                         z[b * 2 * A + A + d], std_kind, &gx, &draw);
     dz[b * 2 * A + d] = gx;
     dz[b * 2 * A + A + d] = draw;
   }
@@ -105,33 +103,14 @@ aa_sac_critic_loss_kernel(const float* __restrict__ q1, const float* __restrict_
   const float alpha = expf(log_alpha[0]);
   float local = 0.f;
   for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
-    const float tq = fminf(tq1[b], tq2[b]) - alpha * next_logp[b];
-    const float td = reward_scale * reward[b] + (gamma * discount[b]) * tq;
-    float l = 0.f, g1, g2;
-    if (loss_kind == AA_LOSS_SQUARED) {   // tf.math.squared_difference(td_targets, pred)
-      const float e1 = td - q1[b], e2 = td - q2[b];
-      l = e1 * e1 + e2 * e2;
-      g1 = -2.0f * e1;
-      g2 = -2.0f * e2;
-    } else {                              // element_wise_huber_loss
-      const float e1 = q1[b] - td, e2 = q2[b] - td;
-      const float a1 = fabsf(e1), a2 = fabsf(e2);
-      const float c1 = fminf(a1, 1.f), c2 = fminf(a2, 1.f);
-      l = (0.5f * c1 * c1 + (a1 - c1)) + (0.5f * c2 * c2 + (a2 - c2));
-      g1 = e1 > 1.f ? 1.f : (e1 < -1.f ? -1.f : e1);
-      g2 = e2 > 1.f ? 1.f : (e2 < -1.f ? -1.f : e2);
-    }
-    float w = 1.f;
-    float wl = l;
-    if (weights != nullptr) {
-      w = weights[b];
-      wl = (w == 0.f) ? 0.f : l * w;
-    }
-    local += wl;
-    if (td_target_out != nullptr) td_target_out[b] = td;
+    const AaSacCriticElem o = aa_sac_critic_elem(q1[b], q2[b], tq1[b], tq2[b], next_logp[b],
+                                                 reward[b], discount[b], weights, b, alpha, gamma,
+                                                 reward_scale, loss_kind);
+    local += o.wl;
+    if (td_target_out != nullptr) td_target_out[b] = o.td;
     if (dq1 != nullptr) {
-      dq1[b] = (loss_weight * g1 * w) / global_batch;
-      dq2[b] = (loss_weight * g2 * w) / global_batch;
+      dq1[b] = (loss_weight * o.g1 * o.w) / global_batch;
+      dq2[b] = (loss_weight * o.g2 * o.w) / global_batch;
     }
   }
   const float total = aa_block_sum(local, red);
@@ -150,20 +129,13 @@ aa_sac_actor_loss_kernel(const float* __restrict__ q1, const float* __restrict__
   const float alpha = expf(log_alpha[0]);
   float local = 0.f;
   for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
-    const float a = q1[b], c = q2[b];
-    const float l = alpha * logp[b] - fminf(a, c);
-    float w = 1.f, wl = l;
-    if (weights != nullptr) {
-      w = weights[b];
-      wl = (w == 0.f) ? 0.f : l * w;
-    }
-    local += wl;
+    const AaSacActorElem o = aa_sac_actor_elem(q1[b], q2[b], logp[b], weights, b, alpha,
+                                               loss_weight, global_batch);
+    local += o.wl;
     if (dq1 != nullptr) {
-      const float g = (loss_weight * w) / global_batch;
-      // tf.minimum: the gradient goes to x where x <= y, else to y
-      dq1[b] = a <= c ? -g : 0.f;
-      dq2[b] = a <= c ? 0.f : -g;
-      dlogp[b] = alpha * g;
+      dq1[b] = o.dq1;
+      dq2[b] = o.dq2;
+      dlogp[b] = o.dlogp;
     }
   }
   const float total = aa_block_sum(local, red);

@@ -311,16 +311,21 @@ def two_pairs_ok(pair_a, pair_b):
     return pair_a[0].body.wide_key() == pair_b[0].body.wide_key()
 
 
-def backward_pair(c1, c2, dq1, dq2, slot=0, param_grads=True, want_action_grad=False):
+def backward_pair(c1, c2, dq1, dq2, slot=0, param_grads=True, want_action_grad=False, gen=None,
+                  batch=None):
     """`backward` of both critics of a `forward_pair`: the gradient chains in one launch, all
-    weight gradients in a second one; returns (da1, da2) [B, act] views if asked."""
-    B = int(dq1.shape[0])
-    bufs = [c._input(slot, B, dq1.device) for c in (c1, c2)]
+    weight gradients in a second one; returns (da1, da2) [B, act] views if asked.  `gen` (a filled
+    `_lib.SacDoutGen` of kind CRITIC / ACTOR; then dq1 = dq2 = None and batch = B): the chain launch
+    computes d loss / d q itself (the loss launch in front of it is gone)."""
+    B = int(dq1.shape[0]) if gen is None else int(batch)
+    dev = c1.body.flat_params.device
+    bufs = [c._input(slot, B, dev) for c in (c1, c2)]
     lo, hi = c1._obs_dim, c1._obs_dim + c1._act_dim
-    sequential.backward_wide([c1.body, c2.body], [dq1.view(B, 1), dq2.view(B, 1)], slot=slot,
-                             param_grads=param_grads,
+    sequential.backward_wide([c1.body, c2.body],
+                             None if gen is not None else [dq1.view(B, 1), dq2.view(B, 1)],
+                             slot=slot, param_grads=param_grads,
                              input_grads=[b["dx"] for b in bufs] if want_action_grad else None,
-                             input_grad_cols=(lo, hi))
+                             input_grad_cols=(lo, hi), gen=gen, batch=B)
     if want_action_grad:
         return bufs[0]["dx"][:, lo:], bufs[1]["dx"][:, lo:]
     return None, None

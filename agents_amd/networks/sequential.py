@@ -1158,12 +1158,16 @@ def forward_wide(nets, xs, slot=0, need_grad=False, x2s=None, slots=None, need_g
     return outs
 
 
-def backward_wide(nets, douts, slot=0, param_grads=True, input_grads=None, input_grad_cols=None):
+def backward_wide(nets, douts, slot=0, param_grads=True, input_grads=None, input_grad_cols=None,
+                  gen=None, batch=None):
     """`net.backward(dout, slot, param_grads, input_grad)` of the networks of a `forward_wide`
     group: the gradient chain in one launch, every weight / bias gradient of every layer and
     network in a second one (skipped with param_grads=False).  input_grads[g]: [B, d] float32
-    buffers receiving d loss / d input columns `input_grad_cols` (default: all)."""
-    B = int(douts[0].shape[0])
+    buffers receiving d loss / d input columns `input_grad_cols` (default: all).
+    `gen` (a filled `_lib.SacDoutGen`; then douts = None and batch = B): the chain launch computes
+    d loss / d output itself (aa_mlp_wide_backward_gen: SAC's critic / actor loss, the actor head's
+    backward)."""
+    B = int(douts[0].shape[0]) if gen is None else int(batch)
     lay = _wide_group(nets, B)
     d = _lib.MlpWideBwd()
     d.layout = lay
@@ -1180,17 +1184,20 @@ def backward_wide(nets, douts, slot=0, param_grads=True, input_grads=None, input
         x, x2 = s.wide_in
         if g == 0:
             d.x_split = int(x.shape[1])
-        dout = douts[g] if douts[g].dim() == 2 else douts[g].reshape(B, -1)
-        if dout.dtype != torch.float32 or dout.stride(1) != 1 or int(dout.shape[1]) != lay.dims[n]:
-            raise ValueError("d loss / d output must be float32 [B, out] with unit column stride")
+        if gen is None:
+            dout = douts[g] if douts[g].dim() == 2 else douts[g].reshape(B, -1)
+            if dout.dtype != torch.float32 or dout.stride(1) != 1 or \
+                    int(dout.shape[1]) != lay.dims[n]:
+                raise ValueError("d loss / d output must be float32 [B, out] with unit column "
+                                 "stride")
+            d.dout[g] = dout.data_ptr()
+            d.ld_dout[g] = dout.stride(0)
         d.params[g] = net.flat_params.data_ptr()
         d.x[g] = x.data_ptr()
         d.ldx[g] = x.stride(0)
         if x2 is not None:
             d.x2[g] = x2.data_ptr()
             d.ldx2[g] = x2.stride(0)
-        d.dout[g] = dout.data_ptr()
-        d.ld_dout[g] = dout.stride(0)
         for i in range(n):
             d.y[g][i] = s.ys[i].data_ptr()
             d.dz[g][i] = s.dzs[i].data_ptr()
@@ -1202,6 +1209,11 @@ def backward_wide(nets, douts, slot=0, param_grads=True, input_grads=None, input
             d.ld_dx[g] = ig.stride(0)
         if param_grads:
             d.grads[g] = net.flat_grads.data_ptr()
-    with torch.cuda.device(douts[0].device):
-        _lib.check(_lib.load().aa_mlp_wide_backward(ctypes.byref(d), _lib.stream_ptr()),
-                   "aa_mlp_wide_backward")
+    with torch.cuda.device(nets[0].flat_params.device):
+        if gen is not None:
+            _lib.check(_lib.load().aa_mlp_wide_backward_gen(ctypes.byref(d), ctypes.byref(gen),
+                                                            _lib.stream_ptr()),
+                       "aa_mlp_wide_backward_gen")
+        else:
+            _lib.check(_lib.load().aa_mlp_wide_backward(ctypes.byref(d), _lib.stream_ptr()),
+                       "aa_mlp_wide_backward")

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 16
+#define AA_ABI_VERSION 17
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -825,6 +825,38 @@ typedef struct {
 int aa_mlp_wide_forward_sample(const aa_mlp_wide_fwd* d, const aa_sac_sample_tail* tail,
                                void* stream);
 int aa_mlp_wide_backward(const aa_mlp_wide_bwd* d, void* stream);
+/* aa_mlp_wide_backward whose d loss / d output is COMPUTED by the gradient-chain launch instead of
+ * read from dout (which is ignored): SAC's critic loss, actor loss and actor-head backward are a
+ * few loads and flops per sample, and each was a launch of its own on the train step's chain
+ * (agents/sac/sac_agent.py:559-694).  Same arithmetic as aa_sac_critic_loss / aa_sac_actor_loss /
+ * aa_sac_head_backward (csrc/sac_loss.h), bit for bit.
+ *   AA_SAC_GEN_CRITIC  networks 0, 1 = the twin critics: dout_g = d critic_loss / d q_g; also
+ *                      writes *loss_out and td_target_out[B] (nullable)
+ *   AA_SAC_GEN_ACTOR   networks 0, 1 = the twin critics: dout_g = d actor_loss / d q_g; also writes
+ *                      *loss_out and dlogp_out[B] (d actor_loss / d log_pi)
+ *   AA_SAC_GEN_HEAD    network 0 = the actor: dout = aa_sac_head_backward's dz from daction
+ *                      (+ daction2), dlogp and the tensors aa_sac_sample saved */
+#define AA_SAC_GEN_CRITIC 1
+#define AA_SAC_GEN_ACTOR 2
+#define AA_SAC_GEN_HEAD 3
+typedef struct {
+  int32_t kind;
+  const float* q1; const float* q2;
+  const float* tq1; const float* tq2; const float* next_logp; const float* reward;
+  const float* discount;
+  const float* logp;
+  const float* weights;            /* nullable */
+  const float* log_alpha;
+  float gamma, reward_scale;
+  int32_t loss_kind;
+  float loss_weight, global_batch;
+  float* loss_out; float* td_target_out; float* dlogp_out;
+  const float* z; int32_t A, std_kind;
+  const float* act_mag; const float* save_tanh; const float* save_sigma; const float* save_eps;
+  const float* daction; int64_t ld_daction; const float* daction2; int64_t ld_daction2;
+  const float* dlogp;
+} aa_sac_dout_gen;
+int aa_mlp_wide_backward_gen(const aa_mlp_wide_bwd* d, const aa_sac_dout_gen* gen, void* stream);
 /* Measurement aid: the workgroups of the following aa_mlp_wide_backward launches write
  * wall_clock64() stamps (10 ns ticks) at the phase boundaries of the gradient chain to
  * buf[workgroup][16] (0 start, 1 operands staged, then per layer from the top: dz ready, product

@@ -67,6 +67,11 @@ def test_struct_layouts_match_the_header(tmp_path):
                   "value", "act_mean", "act_mag", "clip_eps", "denom", "adv_eps"]),
               "aa_sac_sample_tail": ("SacSampleTail", ["net", "A", "std_kind", "act_mean", "eps_in",
                                                        "seed", "arrival_dev", "logp", "save_eps"]),
+              "aa_sac_dout_gen": ("SacDoutGen", ["kind", "q1", "discount", "logp", "log_alpha",
+                                                 "gamma", "loss_kind", "global_batch", "loss_out",
+                                                 "dlogp_out", "z", "A", "std_kind", "act_mag",
+                                                 "save_eps", "daction", "ld_daction", "daction2",
+                                                 "ld_daction2", "dlogp"]),
               "aa_ppo_policy_step_desc": ("PpoPolicyStepDesc", [
                   "x", "ldx", "B", "nrm_mean", "nrm_var_den", "nrm_eps", "nrm_clip", "params_a",
                   "n_layers_a", "dims_a", "b_off_a", "params_b", "n_layers_b", "b_off_b",
@@ -92,7 +97,7 @@ def test_struct_layouts_match_the_header(tmp_path):
 
 
 def test_abi_version(lib):
-    assert lib.aa_abi_version() == 16
+    assert lib.aa_abi_version() == 17
 
 
 def test_argument_validation_without_gpu(lib):

@@ -398,3 +398,35 @@ def test_fused_forward_sample_is_bit_identical(dev, B, kind, monkeypatch):
             assert torch.equal(x, y)
     for x, y in zip(ag_f.replicated_state(), ag_s.replicated_state()):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(critic_loss_weight=1.0, initial_log_alpha=0.7,
+                                              td_errors_loss_fn=common.element_wise_huber_loss)])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_losses_inside_the_gradient_chain_are_bit_identical(dev, cfg, weighted, monkeypatch):
+    """aa_mlp_wide_backward_gen (critic loss / actor loss / actor-head backward computed by the
+    gradient-chain launches that consume them) against the three launches it replaces: losses, every
+    parameter, optimizer slot and log_alpha after four train steps, bit for bit."""
+    kw = dict(cfg)
+    loss_fn = kw.pop("td_errors_loss_fn", None)
+
+    def build(fused):
+        monkeypatch.setattr(sac_agent, "_FUSE_LOSSES", fused)
+        ag, _ = make_pair(dev, actor_fc=(128, 96), critic_fc=(128, 128), **kw)
+        if loss_fn is not None:
+            ag._td_errors_loss_fn = loss_fn
+        return ag
+    ag_f, ag_s = build(True), build(False)
+    g = torch.Generator().manual_seed(21)
+    for step in range(4):
+        exp_d, _, eps_d, _ = batch(dev, 64, 700 + step)
+        wts = (torch.rand(64, generator=g) * (torch.rand(64, generator=g) > 0.2)).to(dev) \
+            if weighted else None
+        outs = []
+        for fused, ag in ((True, ag_f), (False, ag_s)):
+            monkeypatch.setattr(sac_agent, "_FUSE_LOSSES", fused)
+            outs.append(ag.train(exp_d, weights=wts, eps=eps_d))
+        for x, y in zip([outs[0].loss] + list(outs[0].extra), [outs[1].loss] + list(outs[1].extra)):
+            assert torch.equal(x, y)
+    for x, y in zip(ag_f.replicated_state(), ag_s.replicated_state()):
+        assert torch.equal(x, y)
