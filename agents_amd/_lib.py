@@ -270,6 +270,7 @@ _SIGNATURES = {
                                           c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32,
                                           c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "aa_ppo_fused_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "aa_ppo_fused_merge_apply": (c_int32, [c_int32]),
     "aa_ppo_fused_debug_stamps": (c_int, [c_void_p]),
     "aa_ppo_fused_step": (c_int, [POINTER(PpoFusedDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p,
@@ -400,8 +401,11 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 17:
+    if lib.aa_abi_version() != 18:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
+    # A/B knob: AA_PPO_MERGE_APPLY=0 keeps the fused PPO step's reduce and clip + Adam as two launches
+    if os.environ.get("AA_PPO_MERGE_APPLY", "1") == "0":
+        lib.aa_ppo_fused_merge_apply(0)
     _lib = lib
     return lib
 

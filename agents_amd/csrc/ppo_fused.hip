@@ -15,6 +15,12 @@
 //                                   squares, LossInfo scalars, Adam step counter
 //   K3  aa_ppo_fused_apply_kernel   tf.clip_by_global_norm (:948-949) + Adam (TF ApplyAdam)
 //
+// K2 and K3 run as ONE launch by default (aa_ppo_fused_reduce_kernel<true>, <= 16,384 parameters):
+// every K2 workgroup keeps its 64 summed gradients in registers and applies K3 to them once all
+// workgroups have published their sum of squares through tagged 8-byte slots -- a grid barrier
+// that moves 8 bytes per workgroup and nothing else; 42.3 -> 40.7 us per step, same bits
+// (aa_ppo_fused_merge_apply(0) restores the two launches).
+//
 // against ~28 launches of the layer-by-layer path (mask, log-prob, moments, normaliser, 2 x MLP
 // forward, head forward, loss, head backward, column sums, 2 x MLP backward + slab reduces,
 // segment sum of squares, clip, counter, Adam, pack): at 4,096 samples x (64, 64) the step is pure
@@ -64,6 +70,8 @@ struct PfArgs {
   float* partial;      // [n_wg][8]
   const float* moments;  // nullable: {mean, var} of this step's advantages, computed per epoch
   long long* stamps;   // nullable (aa_ppo_fused_debug_stamps): [n_wg][32] wall_clock64 ticks (10 ns)
+  unsigned long long* seq;   // launch sequence of this workspace: += 1 per K1 launch (workgroup 0);
+                             // the tag of the merged K2's barrier slots
 };
 
 static long long* g_pf_stamps = nullptr;
@@ -360,6 +368,7 @@ __global__ void __launch_bounds__(PF_THREADS) aa_ppo_fused_step_kernel(PfArgs P)
   auto row_of = [&](int64_t b) -> int64_t { return S.rowi[b - b0]; };
   PfW wq[PF_MAXL];
   PF_STAMP(0)
+  if (tid == 0 && blockIdx.x == 0) *P.seq += 1;
   if (tid == 0) S.nets[0] = d.actor;
   if (tid == 256) S.nets[1] = d.value;
   // every layer of this group's network is in flight during the prologue below
@@ -606,11 +615,34 @@ __global__ void __launch_bounds__(PF_THREADS) aa_ppo_fused_step_kernel(PfArgs P)
 // global norm; workgroup 0 also turns the loss partials into the LossInfo vector and advances the
 // optimizer's step counter.  Alignment padding of the flat layout is never written by K1: the
 // slabs are zero-filled ONCE when the workspace is allocated, so padding gradients read as zero.
+//
+// MERGED = true is K2 + K3 in one launch (n_red <= PF_MERGE_MAX_WG workgroups, all co-resident):
+// each workgroup keeps its 64 summed gradients in registers, publishes its sum of squares, waits
+// at a grid barrier until every workgroup has done so, re-adds the partials in K3's order and
+// applies K3's arithmetic to its own 64 parameters.  ONLY the sumsq partials and the barrier
+// ticket cross workgroups (agent-scope atomics); every other word is read and written by the
+// workgroup that owns it, so the results are those of the three-launch path bit for bit.
+#define PF_MERGE_MAX_WG 256u
+static int32_t g_pf_merge_apply = 1;
+
+struct PfApply {
+  float* p; float* m; float* v;
+  float lr, beta1, beta2, eps, clip;
+  float* sumsq_out;
+  // grid barrier: workgroup b publishes {tag = low word of *seq, its sum of squares} as ONE 8-byte
+  // word in slot[b]; the tag (bumped by K1, a launch earlier) never repeats in consecutive
+  // launches, so a slot that carries it was written by this launch
+  unsigned long long* slot;
+  const unsigned long long* seq;
+};
+
+template <bool MERGED>
 __global__ void __launch_bounds__(256)
 aa_ppo_fused_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int64_t total,
                            float* __restrict__ grads, float* __restrict__ sumsq_part,
                            const float* __restrict__ partial, aa_ppo_fused_desc d,
-                           float* __restrict__ stats, int64_t* __restrict__ step_dev) {
+                           float* __restrict__ stats, int64_t* __restrict__ step_dev,
+                           PfApply ap) {
   // workgroup = 64 consecutive parameters (16 float4) x 16 z-lanes: a 16-lane group reads 256
   // contiguous bytes of one slab (the first version read 4-byte columns 44 KB apart: 30 us for
   // 11 MB); z-lane zl sums slabs zl, zl + 16, ... in that order, the 16 partials are combined
@@ -640,22 +672,36 @@ aa_ppo_fused_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int64_t
   }
   part[zl][q] = v;
   __syncthreads();
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
   if (zl == 0) {
-    float4 r = part[0][q];
+    r = part[0][q];
 #pragma unroll
     for (int j = 1; j < 16; ++j) {
       const float4 t = part[j][q];
       r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
     }
-    if (i < total) reinterpret_cast<float4*>(grads)[i >> 2] = r;
-    else r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < total) {
+      if (!MERGED) reinterpret_cast<float4*>(grads)[i >> 2] = r;   // MERGED stores the clipped one
+    } else {
+      r = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     sq[q] = ((r.x * r.x + r.y * r.y) + r.z * r.z) + r.w * r.w;
   }
   __syncthreads();
+  float t_adam = 0.f;
   if (threadIdx.x == 0) {
     float s = 0.f;
     for (int j = 0; j < 16; ++j) s += sq[j];
-    sumsq_part[blockIdx.x] = s;
+    if (MERGED) {
+      // the optimizer step this launch applies: workgroup 0 stores it only AFTER the barrier, so
+      // every workgroup reads the old value here, before it publishes its slot
+      t_adam = (float)(*step_dev + 1);
+      const unsigned long long word =
+          ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)(*ap.seq);
+      __hip_atomic_store(&ap.slot[blockIdx.x], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      sumsq_part[blockIdx.x] = s;
+    }
   }
   if (blockIdx.x == 0) {
     // the five loss sums over the n_slabs workgroups of K1: thread t adds workgroups t, t + 256, ...
@@ -684,8 +730,78 @@ aa_ppo_fused_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int64_t
       stats[6] = pg + vl + e;             // total
       stats[7] = 0.f;
       stats[8] = 0.f;                     // l2_regularization_loss
-      if (step_dev != nullptr) *step_dev += 1;
+      if (!MERGED && step_dev != nullptr) *step_dev += 1;
     }
+  }
+  if (!MERGED) return;
+  // ---- grid barrier, then K3's clip + Adam on this workgroup's own 64 parameters ----
+  __shared__ float s_bc[2];
+  __shared__ float red[16];
+  // thread k waits for slot k (gridDim.x <= 256 = blockDim.x): value and tag arrive in one word,
+  // no other memory is exchanged, so no fence is needed.  K3 has thread k add partials k, k + 256,
+  // ... from zero: one partial per thread here, the same sum.
+  // this workgroup's own parameters and Adam slots, and the step-dependent factor, are fetched
+  // BEFORE the wait: behind the barrier only the clip scale is new
+  const int64_t i4 = i >> 2;
+  float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f), m4 = p4, v4 = p4;
+  if (zl == 0 && i < total) {
+    p4 = reinterpret_cast<const float4*>(ap.p)[i4];
+    m4 = reinterpret_cast<const float4*>(ap.m)[i4];
+    v4 = reinterpret_cast<const float4*>(ap.v)[i4];
+  }
+  if (threadIdx.x == 0) {
+    const float b1p = powf(ap.beta1, t_adam), b2p = powf(ap.beta2, t_adam);
+    s_bc[1] = ap.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+  }
+  float s = 0.f;
+  if (threadIdx.x < gridDim.x) {
+    const unsigned tag = (unsigned)(*ap.seq);
+    unsigned spins = 0;
+    unsigned long long word;
+    while ((unsigned)(word = __hip_atomic_load(&ap.slot[threadIdx.x], __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT)) != tag) {
+      // a workgroup that never publishes means the launch was not co-resident (the host refuses
+      // such grids): abort loudly instead of hanging the queue
+      if (++spins > (1u << 24)) __builtin_trap();
+    }
+    s += __uint_as_float((unsigned)(word >> 32));
+  }
+  const float tot = aa_block_sum(s, red);
+  if (threadIdx.x == 0) {
+    float scale = 1.0f;
+    if (ap.clip > 0.f) {
+      const float gn = sqrtf(tot);
+      scale = ap.clip * fminf(1.0f / gn, 1.0f / ap.clip);
+    }
+    s_bc[0] = scale;
+    if (blockIdx.x == 0) {
+      if (ap.sumsq_out != nullptr) ap.sumsq_out[0] = tot;
+      *step_dev += 1;
+    }
+  }
+  __syncthreads();
+  if (zl == 0 && i < total) {
+    const float scale = s_bc[0], alpha = s_bc[1];
+    const float omb1 = 1.0f - ap.beta1, omb2 = 1.0f - ap.beta2;
+    float gg[4] = {r.x, r.y, r.z, r.w};
+    float pp[4] = {p4.x, p4.y, p4.z, p4.w};
+    float mm[4] = {m4.x, m4.y, m4.z, m4.w};
+    float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float gi = gg[c] * scale;
+      gg[c] = gi;
+      float mi = mm[c], vi = vv[c];
+      mi = mi + (gi - mi) * omb1;
+      vi = vi + (gi * gi - vi) * omb2;
+      pp[c] = pp[c] - (mi * alpha) / (sqrtf(vi) + ap.eps);
+      mm[c] = mi;
+      vv[c] = vi;
+    }
+    reinterpret_cast<float4*>(grads)[i4] = make_float4(gg[0], gg[1], gg[2], gg[3]);
+    reinterpret_cast<float4*>(ap.p)[i4] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    reinterpret_cast<float4*>(ap.m)[i4] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    reinterpret_cast<float4*>(ap.v)[i4] = make_float4(vv[0], vv[1], vv[2], vv[3]);
   }
 }
 
@@ -759,11 +875,18 @@ int aa_ppo_fused_debug_stamps(int64_t* buf) {
   return AA_OK;
 }
 
+// Process-wide switch of the merged reduce + apply launch (1 by default); returns the old value.
+int32_t aa_ppo_fused_merge_apply(int32_t on) {
+  const int32_t old = g_pf_merge_apply;
+  if (on >= 0) g_pf_merge_apply = on != 0;
+  return old;
+}
+
 int64_t aa_ppo_fused_workspace_bytes(int64_t N, int64_t total_params) {
   if (N <= 0 || total_params <= 0) return -1;
   const int64_t n_wg = (N + PF_TS - 1) / PF_TS;
-  return (n_wg * total_params + n_wg * 8 + (total_params + 15) / 16 + 16 + 2 * PF_MAX_EPOCH_STEPS) *
-         (int64_t)sizeof(float);
+  return (n_wg * total_params + n_wg * 8 + (total_params + 15) / 16 + 16 + 2 * PF_MAX_EPOCH_STEPS +
+          2 + 2 * (PF_MERGE_MAX_WG + 1)) * (int64_t)sizeof(float);
 }
 
 // n_steps consecutive minibatch steps from ONE host call: step s trains on rows
@@ -823,6 +946,19 @@ int aa_ppo_fused_epoch(const aa_ppo_fused_desc* dsc, const int64_t* rows_dev, in
   int64_t blocks = (d.total + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   P.moments = nullptr;
+  // K2 + K3 in one launch when its grid barrier is safe: every workgroup of it resident at once
+  // (256 threads and < 6 KB of LDS each: one per CU leaves room on any gfx950 part)
+  const bool merged = g_pf_merge_apply != 0 && n_red <= PF_MERGE_MAX_WG;
+  PfApply ap;
+  ap.p = const_cast<float*>(d.params); ap.m = adam_m; ap.v = adam_v;
+  ap.lr = lr; ap.beta1 = beta1; ap.beta2 = beta2; ap.eps = adam_eps; ap.clip = grad_clip;
+  ap.sumsq_out = sumsq_out;
+  // the barrier slots (8 bytes per K2 workgroup) and the launch sequence live behind the moments;
+  // the workspace is zero-filled once by its owner (the slab padding already relies on that)
+  ap.slot = reinterpret_cast<unsigned long long*>(
+      moments + 2 * PF_MAX_EPOCH_STEPS + ((n_wg * d.total + n_wg * 8 + (d.total + 15) / 16) & 1));
+  P.seq = ap.slot + PF_MERGE_MAX_WG;
+  ap.seq = P.seq;
   const bool ahead = rows_dev != nullptr && n_steps > 1 && n_steps <= PF_MAX_EPOCH_STEPS;
   if (ahead)     // the advantage moments of every minibatch of this call, one launch
     hipLaunchKernelGGL(aa_ppo_fused_moments_kernel, dim3((unsigned)n_steps), dim3(PF_THREADS), 0,
@@ -832,9 +968,15 @@ int aa_ppo_fused_epoch(const aa_ppo_fused_desc* dsc, const int64_t* rows_dev, in
     if (ahead) P.moments = moments + 2 * s;
     hipLaunchKernelGGL(aa_ppo_fused_step_kernel, dim3((unsigned)n_wg), dim3(PF_THREADS),
                        sizeof(PfLds), st, P);
-    hipLaunchKernelGGL(aa_ppo_fused_reduce_kernel, dim3(n_red), dim3(256), 0, st,
+    if (merged) {
+      hipLaunchKernelGGL(aa_ppo_fused_reduce_kernel<true>, dim3(n_red), dim3(256), 0, st,
+                         (const float*)P.slabs, (int)n_wg, d.total, grads, sumsq_part,
+                         (const float*)P.partial, d, stats9, adam_step_dev, ap);
+      continue;
+    }
+    hipLaunchKernelGGL(aa_ppo_fused_reduce_kernel<false>, dim3(n_red), dim3(256), 0, st,
                        (const float*)P.slabs, (int)n_wg, d.total, grads, sumsq_part,
-                       (const float*)P.partial, d, stats9, adam_step_dev);
+                       (const float*)P.partial, d, stats9, adam_step_dev, ap);
     hipLaunchKernelGGL(aa_ppo_fused_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
                        const_cast<float*>(d.params), grads, adam_m, adam_v, d.total, lr, beta1,
                        beta2, adam_eps, (const int64_t*)adam_step_dev, (const float*)sumsq_part,

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 17
+#define AA_ABI_VERSION 18
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -882,6 +882,14 @@ int64_t aa_ppo_fused_workspace_bytes(int64_t N, int64_t total_params);
 /* Measurement aid: the workgroups of the following aa_ppo_fused_step calls write wall_clock64()
  * stamps (10 ns ticks) at their phase boundaries to buf[ceil(N / 16)][32]; NULL = off. */
 int aa_ppo_fused_debug_stamps(int64_t* buf);
+/* The slab reduction and clip + Adam of a fused step run as ONE launch when the flat parameter
+ * vector has <= 16384 floats (<= 256 workgroups, all co-resident): each workgroup publishes its
+ * sum of squares in a tagged 8-byte slot of the workspace and waits for the others' -- nothing
+ * else crosses workgroups, and the results are those of the two-launch form bit for bit.
+ * on = 0 / 1 sets the process-wide switch (default 1), on < 0 only reads it; returns the previous
+ * value.  The workspace must have been zero-filled once by its owner (slots, launch sequence and
+ * the slab padding live in it). */
+int32_t aa_ppo_fused_merge_apply(int32_t on);
 int aa_ppo_fused_step(const aa_ppo_fused_desc* d, float* grads, float* adam_m, float* adam_v,
                       int64_t* adam_step_dev, float lr, float beta1, float beta2, float adam_eps,
                       float grad_clip /* <= 0: none */, float* stats9, float* sumsq_out,

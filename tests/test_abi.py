@@ -97,7 +97,7 @@ def test_struct_layouts_match_the_header(tmp_path):
 
 
 def test_abi_version(lib):
-    assert lib.aa_abi_version() == 17
+    assert lib.aa_abi_version() == 18
 
 
 def test_argument_validation_without_gpu(lib):
@@ -108,6 +108,23 @@ def test_argument_validation_without_gpu(lib):
     assert lib.aa_gemm_f32_workspace_bytes(ctypes.byref(d)) == -1
     assert lib.aa_colsum_workspace_bytes(0, 4) == -1
     assert lib.aa_colsum_workspace_bytes(1000, 32) > 0
+
+
+def test_ppo_merge_apply_switch(lib):
+    """aa_ppo_fused_merge_apply: reads with a negative argument, returns the previous value, and
+    the workspace it sizes has room for the barrier slots of the merged launch."""
+    before = lib.aa_ppo_fused_merge_apply(-1)
+    try:
+        assert before in (0, 1)
+        assert lib.aa_ppo_fused_merge_apply(0) == before
+        assert lib.aa_ppo_fused_merge_apply(-1) == 0
+        assert lib.aa_ppo_fused_merge_apply(7) == 0
+        assert lib.aa_ppo_fused_merge_apply(-1) == 1
+    finally:
+        lib.aa_ppo_fused_merge_apply(before)
+    n_wg, total = 256, 11092
+    floats = n_wg * total + n_wg * 8 + (total + 15) // 16 + 16 + 2 * 4096
+    assert lib.aa_ppo_fused_workspace_bytes(4096, total) >= (floats + 1) * 4 + 8 * 257
 
 
 def test_round3_entries_validate_on_the_host(lib):

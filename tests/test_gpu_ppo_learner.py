@@ -167,3 +167,46 @@ def test_fused_epochs_equal_one_train_call_per_minibatch(dev):
         assert float(li_f.loss) == float(li_s.loss)
         assert float(li_f.extra.clip_fraction) == float(li_s.extra.clip_fraction)
         assert w_f["learner"].train_step_numpy == w_s["learner"].train_step_numpy == n
+
+
+@pytest.mark.parametrize("clip", [0.5, 0.0])
+def test_merged_reduce_apply_launch_is_bit_identical(dev, clip):
+    """The fused step's slab reduction and clip + Adam in ONE launch (a grid barrier that carries
+    only the per-workgroup sums of squares, aa_ppo_fused_merge_apply) against the two-launch form:
+    parameters, gradients, Adam slots, step counters, the global norm and the LossInfo after two
+    epochs of minibatch steps, bit for bit (clip 0 = no clipping: the norm is still reported)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "tools"))
+    import bench_ppo
+    from agents_amd import _lib
+    lib = _lib.load()
+    before = lib.aa_ppo_fused_merge_apply(-1)
+    try:
+        with torch.cuda.device(dev):
+            stacks = []
+            for on in (1, 0):
+                lib.aa_ppo_fused_merge_apply(on)
+                w = bench_ppo.build(dev, envs=64, steps=31, minibatch=256, epochs=2,
+                                    episode_end_probability=0.05)
+                w["agent"]._gradient_clipping = clip
+                w["collect_driver"].run()
+                li = w["learner"].run()
+                torch.cuda.synchronize()
+                stacks.append((w, li))
+    finally:
+        lib.aa_ppo_fused_merge_apply(before)
+    (w_m, li_m), (w_s, li_s) = stacks
+    a_m, a_s = w_m["agent"], w_s["agent"]
+    n = (64 * 32 // 256) * 2
+    assert a_m._optimizer.iterations == a_s._optimizer.iterations == n
+    assert torch.equal(a_m.flat_params, a_s.flat_params)
+    assert torch.equal(a_m.flat_grads, a_s.flat_grads)
+    assert bool(a_m.flat_grads.abs().sum() > 0)
+    for x, y in zip(a_m._optimizer.variables(), a_s._optimizer.variables()):
+        assert torch.equal(x, y)
+    assert torch.equal(a_m._norm_sumsq, a_s._norm_sumsq) and float(a_m._norm_sumsq) > 0
+    assert float(li_m.loss) == float(li_s.loss)
+    for f in li_m.extra._fields:
+        assert float(getattr(li_m.extra, f)) == float(getattr(li_s.extra, f)), f
