@@ -902,7 +902,7 @@ def main_other_config(args):
             log(f"[bench] ppo in-loop pass failed: {il['error']}")
         pmc = _pmc_other("ppo_fused_step")
         k1_ms = k1["avg_us"] / 1e3 if k1 else None
-        roof = {"kernel": "aa_ppo_fused_step_kernel (K1 of the 3-launch minibatch step: row "
+        roof = {"kernel": "aa_ppo_fused_step_kernel (K1 of the 2-launch minibatch step: row "
                           "gather, both (64,64) MLPs forward + backward, loss; csrc/ppo_fused.hip)",
                 "bound": "hbm",
                 "achieved": k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms else None,
