@@ -357,6 +357,10 @@ _SIGNATURES = {
     "aa_prio_sample_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                     c_uint64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
+    "aa_prio_draw_workspace_bytes": (c_int64, [c_int64]),
+    "aa_prio_draw_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                  c_uint64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p]),
     "aa_prio_set": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_int64, c_void_p,
                             c_void_p, c_void_p]),
     "aa_prio_on_add": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
@@ -401,7 +405,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 18:
+    if lib.aa_abi_version() != 19:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     # A/B knob: AA_PPO_MERGE_APPLY=0 keeps the fused PPO step's reduce and clip + Adam as two launches
     if os.environ.get("AA_PPO_MERGE_APPLY", "1") == "0":

@@ -17,13 +17,20 @@ weights, new rows enter with the running maximum priority, and `update_prioritie
 (|td_error| + eps)^alpha.  Kernels: csrc/prio.hip (flat two-level scan on uint32 fixed-point
 priorities -- exact sums, bit-exact indices against oracle/prioritized.py).
 """
+import os
+
 import torch
 
 from agents_amd import _lib
+from agents_amd.replay_buffers import replay_buffer
 from agents_amd.replay_buffers import tf_uniform_replay_buffer as uniform
-from agents_amd.utils import graph
+from agents_amd.replay_buffers.dataset import Dataset
+from agents_amd.utils import graph, nest_utils
 
 BufferInfo = uniform.BufferInfo
+
+# A/B knob: 0 = block sums, draw and counter advance as three launches (aa_prio_sample_rows)
+ONE_LAUNCH_DRAW = os.environ.get("AA_PRIO_ONE_LAUNCH", "1") != "0"
 
 
 class TFPrioritizedReplayBuffer(uniform.TFUniformReplayBuffer):
@@ -42,6 +49,11 @@ class TFPrioritizedReplayBuffer(uniform.TFUniformReplayBuffer):
         lib = _lib.load()
         self._prio_ws = torch.empty((max(int(lib.aa_prio_workspace_bytes(self._capacity)), 8),),
                                     dtype=torch.uint8, device=dev)
+        # the one-launch draw's slots + launch sequence + arrival count: zero-filled ONCE
+        n_draw = int(lib.aa_prio_draw_workspace_bytes(self._capacity))
+        self._draw_ws = torch.zeros((n_draw // 8,), dtype=torch.int64, device=dev) \
+            if ONE_LAUNCH_DRAW and n_draw > 0 else None
+        self._start_rows = None
 
     @property
     def priority_exponent(self):
@@ -52,13 +64,19 @@ class TFPrioritizedReplayBuffer(uniform.TFUniformReplayBuffer):
         return (self._prio_q.to(torch.int64) & 0xFFFFFFFF).to(torch.float32) / 65536.0
 
     # ---- writes ---------------------------------------------------------------------------------
-    def _add_batch(self, items):
-        super()._add_batch(items)
+    def _add_batch(self, items, count=None):
+        super()._add_batch(items, count)
         with torch.cuda.device(self._device):
             _lib.check(_lib.load().aa_prio_on_add(
                 self._last_id.data_ptr(), self._batch_size, self._max_length,
                 self._max_prio_q.data_ptr(), self._prio_q.data_ptr(), _lib.stream_ptr()),
                 "aa_prio_on_add")
+
+    def supports_counting_add(self):
+        # the add is the plain scatter (which can carry a graphed driver's step count) followed by
+        # the priority write of this class: offered unless a further subclass changes either hook
+        return type(self)._add_batch is TFPrioritizedReplayBuffer._add_batch and \
+            type(self).add_batch is replay_buffer.ReplayBuffer.add_batch
 
     def _clear(self, clear_all_variables=False):
         super()._clear(clear_all_variables)
@@ -69,7 +87,8 @@ class TFPrioritizedReplayBuffer(uniform.TFUniformReplayBuffer):
         """p[row] = (|priority| + eps)^alpha.  `ids=None`: the window-start ROWS of the most recent
         `get_next` (`self.last_sampled_rows`); otherwise explicit row indices (a global frame id
         alone does not name the env block, so BufferInfo.ids cannot address a row)."""
-        rows = self.last_sampled_rows if ids is None else ids
+        rows = (self._start_rows if self._start_rows is not None else self.last_sampled_rows) \
+            if ids is None else ids
         if rows is None:
             raise RuntimeError("update_priorities: nothing has been sampled yet")
         rows = rows.reshape(-1).to(torch.int64).contiguous()
@@ -89,16 +108,32 @@ class TFPrioritizedReplayBuffer(uniform.TFUniformReplayBuffer):
         self.update_priorities(None, loss_info.extra.td_error)
 
     # ---- sampling -------------------------------------------------------------------------------
-    def _sample_rows(self, S, T):
+    def _sample_rows(self, S, T, out=None):
+        """S window starts drawn with P(row) = p_row / sum; `out` = (rows [S, T], start_rows [S],
+        probabilities [S]) to draw into (a dataset ring slot), else fresh tensors."""
         lib = _lib.load()
-        rows = torch.empty((S, T), dtype=torch.int64, device=self._device)
-        probs = torch.empty((S,), dtype=torch.float32, device=self._device)
-        _lib.check(lib.aa_prio_sample_rows(
-            self._prio_q.data_ptr(), self._id_table.variables()[0].data_ptr(),
-            self._last_id.data_ptr(), self._batch_size, self._max_length, S, T, self._seed,
-            self._sample_calls_dev.data_ptr(), self._prio_ws.data_ptr(), self._prio_ws.numel(),
-            rows.data_ptr(), probs.data_ptr(), self._err_flag.data_ptr(), _lib.stream_ptr()),
-            "aa_prio_sample_rows")
+        dev = self._device
+        if out is None:
+            out = (torch.empty((S, T), dtype=torch.int64, device=dev),
+                   torch.empty((S,), dtype=torch.int64, device=dev),
+                   torch.empty((S,), dtype=torch.float32, device=dev))
+        rows, start, probs = out
+        if self._draw_ws is not None:
+            _lib.check(lib.aa_prio_draw_rows(
+                self._prio_q.data_ptr(), self._id_table.variables()[0].data_ptr(),
+                self._last_id.data_ptr(), self._batch_size, self._max_length, S, T, self._seed,
+                self._sample_calls_dev.data_ptr(), self._draw_ws.data_ptr(),
+                self._draw_ws.numel() * 8, rows.data_ptr(), start.data_ptr(), probs.data_ptr(),
+                self._err_flag.data_ptr(), _lib.stream_ptr()), "aa_prio_draw_rows")
+            self._start_rows = start
+        else:
+            _lib.check(lib.aa_prio_sample_rows(
+                self._prio_q.data_ptr(), self._id_table.variables()[0].data_ptr(),
+                self._last_id.data_ptr(), self._batch_size, self._max_length, S, T, self._seed,
+                self._sample_calls_dev.data_ptr(), self._prio_ws.data_ptr(),
+                self._prio_ws.numel(), rows.data_ptr(), probs.data_ptr(),
+                self._err_flag.data_ptr(), _lib.stream_ptr()), "aa_prio_sample_rows")
+            self._start_rows = None
         graph.on_replay(self._bump_sample_calls)
         self.last_sampled_rows = rows[:, 0]
         return rows, probs
@@ -107,11 +142,52 @@ class TFPrioritizedReplayBuffer(uniform.TFUniformReplayBuffer):
 
     def _as_dataset(self, sample_batch_size=None, num_steps=None, sequence_preprocess_fn=None,
                     num_parallel_calls=None):
-        # priorities change between draws and `last_sampled_rows` must name the batch being
-        # trained on: no graph ring (a replayed draw would leave `last_sampled_rows` pointing at
-        # whichever slot was captured last), no sampling ahead
-        return super()._as_dataset(sample_batch_size, num_steps, sequence_preprocess_fn,
-                                   num_parallel_calls, ring=0)
+        """Priorities change between draws and `last_sampled_rows` must name the batch being
+        trained on: no graph replay of the draw (a replayed draw would leave `last_sampled_rows`
+        pointing at whichever slot was captured last) and no sampling ahead.  The elements do live
+        in a ring of `dataset_ring` static output slots, drawn into eagerly in turn (as the uniform
+        buffer's dataset elements do): a train step that is a HIP graph of its input addresses
+        then replays on them instead of copying a fresh batch in.  An element (and
+        `last_sampled_rows`) is valid until `dataset_ring` further elements have been drawn;
+        dataset_ring = 0: fresh tensors every time."""
+        if sequence_preprocess_fn is not None:
+            raise NotImplementedError("sequence_preprocess_fn is not supported.")
+        n_ring = self._dataset_ring
+        if n_ring <= 0 or sample_batch_size is None or num_steps is None:
+            return super()._as_dataset(sample_batch_size, num_steps, sequence_preprocess_fn,
+                                       num_parallel_calls, ring=0)
+        S, T = int(sample_batch_size), int(num_steps)
+
+        def gen():
+            dev = self._device
+            slots = []
+            k = 0
+            while True:
+                if len(slots) < n_ring:
+                    outs = self._data_table.alloc_out((S, T))
+                    ids = torch.empty((S, T), dtype=torch.int64, device=dev)
+                    draw = (torch.empty((S, T), dtype=torch.int64, device=dev),     # rows
+                            torch.empty((S,), dtype=torch.int64, device=dev),       # start rows
+                            torch.empty((S,), dtype=torch.float32, device=dev))     # P(row)
+                    # the element OBJECT is the slot's too: a graphed train step recognises it
+                    # by identity and skips its structure checks (utils/graph.py)
+                    slots.append((self._data_table.pack(outs), ids, draw,
+                                  (nest_utils.pack_sequence_as(self._data_spec, outs),
+                                   BufferInfo(ids=ids, probabilities=draw[2]))))
+                p, ids, draw, element = slots[k % n_ring]
+                k += 1
+                graph.join_lanes(dev)
+                if not graph.capturing():
+                    self._check_not_empty(T)
+                with torch.cuda.device(dev):
+                    rows, _ = self._sample_rows(S, T, out=draw)
+                    _lib.check(_lib.load().aa_rb_gather_rows(
+                        p.tables, p.ios, p.row_bytes, p.n,
+                        self._id_table.variables()[0].data_ptr(), ids.data_ptr(),
+                        rows.data_ptr(), S * T, _lib.stream_ptr()), "aa_rb_gather_rows")
+                yield element
+
+        return Dataset(gen, infinite=True)
 
     def state_dict(self):
         sd = super().state_dict()

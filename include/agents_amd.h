@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 18
+#define AA_ABI_VERSION 19
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -918,6 +918,19 @@ int aa_prio_sample_rows(const uint32_t* prio_q, const int64_t* id_table,
                         int64_t T, uint64_t seed, int64_t* call_counter_dev, void* workspace,
                         int64_t workspace_bytes, int64_t* rows_out, float* prob_out,
                         int* err_flag_dev, void* stream);
+/* The same draw (same rows, probabilities, counter advance, bit for bit) as ONE launch: the
+ * block sums cross workgroups as tagged 8-byte words, the first ceil(S / 4) workgroups build
+ * their prefix in LDS once and find a sample's row with one round of loads.  workspace:
+ * aa_prio_draw_workspace_bytes(capacity) bytes (-1: more than 8,000 blocks of 1,024 rows -- use
+ * aa_prio_sample_rows), 8-byte aligned, zero-filled ONCE by its owner (launch sequence and
+ * arrival count live in it).  start_rows_out (nullable): [S] = rows_out[:, 0], contiguous, the
+ * argument aa_prio_set wants for the priorities of this batch. */
+int64_t aa_prio_draw_workspace_bytes(int64_t capacity);
+int aa_prio_draw_rows(const uint32_t* prio_q, const int64_t* id_table, const int64_t* last_id_dev,
+                      int64_t batch, int64_t max_len, int64_t S, int64_t T, uint64_t seed,
+                      int64_t* call_counter_dev, void* workspace, int64_t workspace_bytes,
+                      int64_t* rows_out, int64_t* start_rows_out, float* prob_out,
+                      int* err_flag_dev, void* stream);
 /* prio_q[rows[i]] = clamp(round((|priorities[i]| + eps)^alpha * 65536), 1, 2^32-1);
  * *max_prio_q_dev = max(itself, those). */
 int aa_prio_set(const int64_t* rows, const float* priorities, int64_t n, float alpha, float eps,

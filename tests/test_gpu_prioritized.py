@@ -118,3 +118,86 @@ def test_learner_hook_updates_priorities(dev):
             last.setdefault(int(r), set()).add(int(w))   # any of the duplicates' values is valid
         for r, ws in last.items():
             assert int(got[r]) in ws
+
+
+@pytest.mark.parametrize("B,L,S,T", [(256, 600, 256, 2), (5, 1024, 97, 1), (7, 3000, 1031, 3),
+                                     (3, 341, 8, 2)])
+def test_one_launch_draw_equals_the_three_launch_form(dev, B, L, S, T):
+    """aa_prio_draw_rows (block sums through tagged slots, prefix in LDS, one round of row loads)
+    against aa_prio_sample_rows and the oracle: rows, start rows, probabilities, counter -- on
+    tables of several 1,024-row blocks, with whole blocks of zero mass, a ragged last block, more
+    samples than sampling workgroups can take in one round, repeated launches on one workspace."""
+    from agents_amd import _lib
+    lib = _lib.load()
+    rb = prb.TFPrioritizedReplayBuffer(SPEC, batch_size=B, max_length=L, device=dev, seed=11)
+    assert rb._draw_ws is not None
+    n_add = L + L // 3                      # wrapped ring
+    ids = torch.full((B, L), -1, dtype=torch.int64)
+    for i in range(n_add):
+        ids[:, i % L] = i
+    rb._id_table.variables()[0].copy_(ids.reshape(-1).to(dev))
+    rb._last_id.fill_(n_add - 1)
+    rb._last_id_host = n_add - 1
+    rng = np.random.default_rng(B * 1000 + L)
+    pq = rng.integers(1, 2 ** 32, size=B * L, dtype=np.uint64).astype(np.uint32)
+    pq[rng.random(B * L) < 0.5] = 1
+    cap = B * L
+    for b0 in range(0, cap, 1024):          # every third block without mass
+        if (b0 // 1024) % 3 == 1:
+            pq[b0:b0 + 1024] = 0
+    rb._prio_q.copy_(torch.from_numpy(pq.view(np.int32)).to(dev))
+    ws3 = torch.empty((int(lib.aa_prio_workspace_bytes(cap)),), dtype=torch.uint8, device=dev)
+    calls3 = torch.zeros((1,), dtype=torch.int64, device=dev)
+    ids_np = rb._id_table.variables()[0].cpu().numpy()
+    for call in range(5):
+        rows1, probs1 = rb._sample_rows(S, T)
+        start1 = rb._start_rows
+        rows3 = torch.empty((S, T), dtype=torch.int64, device=dev)
+        probs3 = torch.empty((S,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.aa_prio_sample_rows(
+                rb._prio_q.data_ptr(), rb._id_table.variables()[0].data_ptr(),
+                rb._last_id.data_ptr(), B, L, S, T, 11, calls3.data_ptr(), ws3.data_ptr(),
+                ws3.numel(), rows3.data_ptr(), probs3.data_ptr(), rb._err_flag.data_ptr(),
+                _lib.stream_ptr()), "aa_prio_sample_rows")
+        assert torch.equal(rows1, rows3) and torch.equal(probs1, probs3)
+        assert torch.equal(start1, rows1[:, 0])
+        assert int(rb._sample_calls_dev) == int(calls3) == call + 1
+        want_rows, want_p, empty = op.sample(pq, ids_np, n_add - 1, B, L, S, T, 11, call)
+        assert not empty
+        np.testing.assert_array_equal(rows1.cpu().numpy(), want_rows)
+        np.testing.assert_array_equal(probs1.cpu().numpy(), want_p)
+    assert int(rb._err_flag) == 0
+    # no mass at all: the error flag, rows 0, probability 0 -- as the three-launch form
+    rb._prio_q.zero_()
+    rows1, probs1 = rb._sample_rows(S, T)
+    assert int(rb._err_flag) == 1 and int(rows1.abs().sum()) == 0 and float(probs1.sum()) == 0.0
+    assert int(rb._sample_calls_dev) == 6
+
+
+def test_dataset_elements_live_in_a_ring_of_static_slots(dev):
+    """as_dataset(sample_batch_size, num_steps) draws eagerly into `dataset_ring` static slots in
+    turn: addresses recur with period dataset_ring, every element equals what get_next returns
+    for the same call number, `last_sampled_rows` names the element just drawn, and
+    update_priorities(None, ...) lands on its rows."""
+    B, L, S, T = 6, 50, 16, 2
+    mk = lambda ring: prb.TFPrioritizedReplayBuffer(SPEC, batch_size=B, max_length=L, device=dev,
+                                                    seed=5, dataset_ring=ring)
+    rb, rb0 = mk(3), mk(0)
+    fill(rb, B, 70, dev)
+    fill(rb0, B, 70, dev)
+    it = iter(rb.as_dataset(sample_batch_size=S, num_steps=T))
+    ptrs = []
+    for k in range(7):
+        data, info = next(it)
+        want, winfo = rb0.get_next(sample_batch_size=S, num_steps=T)
+        ptrs.append(data[0].data_ptr())
+        assert torch.equal(data[0], want[0]) and torch.equal(data[1], want[1])
+        assert torch.equal(info.ids, winfo.ids)
+        assert torch.equal(info.probabilities, winfo.probabilities)
+        assert torch.equal(rb.last_sampled_rows, rb0.last_sampled_rows)
+        pr = torch.rand(S, device=dev) * 3
+        rb.update_priorities(None, pr)
+        rb0.update_priorities(None, pr)
+        assert torch.equal(rb._prio_q, rb0._prio_q)
+    assert ptrs[0] == ptrs[3] == ptrs[6] and ptrs[1] == ptrs[4] and len(set(ptrs)) == 3
