@@ -159,7 +159,8 @@ aa_prio_sample_kernel(const unsigned* __restrict__ pq, const int64_t* __restrict
 // (the two-launch form has each sample's wave scan all of them), find a sample's block by binary
 // search and its row with ONE round of loads (a lane takes 16 consecutive rows: lane-local prefix,
 // wave scan of the lane totals, ballot) where the old kernel walks sixteen dependent 64-row chunks;
-// the last of them advances the Philox call counter and the launch sequence.  Only the tagged
+// workgroup 0 advances the Philox call counter and the launch sequence once it has seen every
+// slot (every workgroup reads both before it publishes).  Only the tagged
 // words cross workgroups: no fence.  Integer sums: the selected rows are those of the two-launch
 // form and of oracle/prioritized.py whatever the order.
 #define AA_PRIO_TAG_BITS 22
@@ -170,7 +171,7 @@ __global__ void __launch_bounds__(256)
 aa_prio_draw_kernel(const unsigned* __restrict__ pq, const int64_t* __restrict__ ids,
                     const int64_t* __restrict__ last_id_p, int64_t capacity, int64_t max_len,
                     int64_t T, unsigned long long* slots, int n_blocks, int64_t S, uint32_t k0,
-                    uint32_t k1, int64_t* call_dev, unsigned long long* ctl /* seq, arrival */,
+                    uint32_t k1, int64_t* call_dev, unsigned long long* ctl /* launch sequence */,
                     int64_t* __restrict__ rows, int64_t* __restrict__ start_rows,
                     float* __restrict__ probs, int* __restrict__ err) {
   extern __shared__ unsigned long long pre[];     // [n_blocks + 1] exclusive prefix of block sums
@@ -203,27 +204,38 @@ aa_prio_draw_kernel(const unsigned* __restrict__ pq, const int64_t* __restrict__
   // ---- every block sum, as soon as its workgroup has published it -----------------------------
   for (int kb = tid; kb < n_blocks; kb += 1024) {
     unsigned long long w[4];
+    unsigned spins = 0;
+    bool all;
+    // every slot of this thread that is not in yet is re-read in ONE round of loads (a round
+    // costs a trip to the memory side; re-reading them one after the other cost four)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = kb + 256 * u;
-      w[u] = k < n_blocks ? __hip_atomic_load(&slots[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                          : tag;
-    }
+    for (int u = 0; u < 4; ++u) w[u] = ~tag;
+    do {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = kb + 256 * u;
-      if (k >= n_blocks) continue;
-      unsigned spins = 0;
-      while ((w[u] & AA_PRIO_TAG_MASK) != tag) {
-        // a slot that never carries this launch's tag: a workgroup that cannot run (no such grid
-        // is launched); abort loudly instead of hanging the queue
-        if (++spins > (1u << 24)) __builtin_trap();
-        w[u] = __hip_atomic_load(&slots[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int u = 0; u < 4; ++u) {
+        const int k = kb + 256 * u;
+        if (k < n_blocks && (w[u] & AA_PRIO_TAG_MASK) != tag)
+          w[u] = __hip_atomic_load(&slots[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      pre[k] = w[u] >> AA_PRIO_TAG_BITS;
-    }
+      all = true;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (kb + 256 * u < n_blocks && (w[u] & AA_PRIO_TAG_MASK) != tag) all = false;
+      // a slot that never carries this launch's tag: a workgroup that cannot run (no such grid
+      // is launched); abort loudly instead of hanging the queue
+      if (!all && ++spins > (1u << 24)) __builtin_trap();
+    } while (!all);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (kb + 256 * u < n_blocks) pre[kb + 256 * u] = w[u] >> AA_PRIO_TAG_BITS;
   }
   __syncthreads();
+  // This workgroup has seen every slot: every workgroup has published, hence read the call counter
+  // and the launch sequence before -- workgroup 0 may advance them now (no arrival count needed).
+  if (blockIdx.x == 0 && tid == 0) {
+    *call_dev += 1;
+    ctl[0] += 1;
+  }
   // ---- exclusive prefix in place: a contiguous run per thread, runs combined across the block --
   {
     const int per = (n_blocks + 255) / 256;
@@ -316,17 +328,6 @@ aa_prio_draw_kernel(const unsigned* __restrict__ pq, const int64_t* __restrict__
       for (int64_t t = 0; t < T; ++t) rows[s * T + t] = (sid + t) % max_len + seg * max_len;
       if (start_rows) start_rows[s] = sid % max_len + seg * max_len;
       if (probs) probs[s] = (float)((double)sp / (double)tot);
-    }
-  }
-  // ---- the last sampling workgroup advances the Philox call counter and the launch sequence ----
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned long long prev =
-        __hip_atomic_fetch_add(&ctl[1], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == (unsigned long long)n_samp - 1ull) {
-      __hip_atomic_store(&ctl[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *call_dev += 1;
-      ctl[0] += 1;
     }
   }
 }
