@@ -52,6 +52,9 @@ _FUSE_SAMPLE = os.environ.get("AA_SAC_FUSE_SAMPLE", "1") != "0"
 # AA_SAC_FUSE_LOSSES=0: critic loss, actor loss and the actor head's backward stay launches of their
 # own in front of the gradient-chain launches that consume them (A/B; bit-identical either way)
 _FUSE_LOSSES = os.environ.get("AA_SAC_FUSE_LOSSES", "1") != "0"
+# A/B knob: 1 = the actor's loss + gradient open part (b) of a graphed train step (behind the
+# collect step) instead of closing part (a) (beside it)
+_ACTOR_PHASE_IN_B = os.environ.get("AA_SAC_ACTOR_IN_B", "0") == "1"
 
 
 def _spec_means_and_magnitudes(spec):
@@ -648,9 +651,13 @@ class SacAgent(tf_agent.TFAgent):
         return self._train_part_b()
 
     def _train_part_a(self, experience, weights, eps=None):
-        """The critic update (sac_agent.py:286-330, first third): reads the actor, writes the
-        critics -- nothing the collect policy uses is modified, so a graphed loop runs it beside
-        the collect step (utils/graph.py: GraphedTrain, whole mode in two parts)."""
+        """The critic update (sac_agent.py:286-330, first third) and the actor's loss + gradient
+        (second third, without its optimizer step): reads the actor, writes the critics and the
+        actor's GRADIENT buffer -- nothing the collect policy uses is modified, so a graphed loop
+        runs it beside the collect step (utils/graph.py: GraphedTrain, whole mode in two parts).
+        (Until round 6 the actor phase opened part (b): the GPU timeline of tools/bench_sac.py had
+        part (b) start 16 us after part (a) had ended, waiting for the collect step to release
+        weights that only the actor's optimizer launch -- 70 us further down -- overwrites.)"""
         eps = eps or {}
         obs, actions, next_obs, reward, discount = self._as_transition(experience)
         B = obs.shape[0]
@@ -664,14 +671,18 @@ class SacAgent(tf_agent.TFAgent):
                         self._critic_bodies(),
                         soft_target=(self._target_params, self._target_update_tau)
                         if self._fuse_target_update() else None)
-        self._part_a = (obs, wts, closs, eps)
+            aloss = None if _ACTOR_PHASE_IN_B else \
+                self._actor_phase(obs, wts, True, eps=eps.get("actor"))
+        self._part_a = (obs, wts, closs, aloss, eps)
 
     def _train_part_b(self):
-        """Actor and alpha updates, LossInfo, counters and the soft target update."""
-        obs, wts, closs, eps = self._part_a
+        """The actor's optimizer step, the alpha update, LossInfo, counters and the soft target
+        update."""
+        obs, wts, closs, aloss, eps = self._part_a
         dev = obs.device
         with torch.cuda.device(dev):
-            aloss = self._actor_phase(obs, wts, True, eps=eps.get("actor"))
+            if aloss is None:
+                aloss = self._actor_phase(obs, wts, True, eps=eps.get("actor"))
             self._apply(self._actor_optimizer, self._actor_network.flat_params,
                         self._actor_network.flat_grads, [self._actor_network.body])
             # total + storage of its own for the three terms
@@ -706,6 +717,11 @@ class SacAgent(tf_agent.TFAgent):
         # the periodic target update is a host decision unless it happens every step
         return self._target_update_period == 1 and self._gradient_clipping is None or \
             (self._target_update_period == 1 and bool(self._clip_state))
+
+    @property
+    def graph_train_whole_b_eager_ok(self):
+        # with the actor phase in part (a), part (b) is three or four launches and no host decision
+        return not _ACTOR_PHASE_IN_B
 
     def _graph_train_whole(self, experience, weights):
         """The train step is device work plus host counters registered with graph.on_replay:

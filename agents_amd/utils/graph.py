@@ -79,6 +79,9 @@ COUNT_IN_ADD = True
 
 # A/B knob: replay the optimizer phase as its own HIP graph (0) or launch it directly (1)
 APPLY_EAGER = True
+# A/B knob: 0 = part (b) of a two-part whole-mode train step (SAC: the actor's optimizer launch, the
+# alpha update, the target update) is replayed as its HIP graph instead of being issued directly
+WHOLE_B_EAGER = os.environ.get("AA_WHOLE_B_EAGER", "1") != "0"
 
 
 # AA_EARLY_TARGET (0 = off, default on): with overlap on, GraphedTrain runs the target network's
@@ -537,6 +540,7 @@ class _Entry:
         self.g_grads_b = None     # _Captured, bucket mode: second half of the backward
         self.captured = None      # _Captured, whole mode (part (a) when the agent splits it)
         self.captured_b = None    # _Captured, whole mode, part (b)
+        self.part_a_state = None  # the agent's hand-over from part (a) to part (b), this entry's
         self.out = None
         # early target forward (ring-slot entries of agents with `_train_phase_target`)
         self.ptr0 = None          # first-leaf address of the batch this entry reads in place
@@ -833,6 +837,14 @@ class GraphedTrain:
                 if lanes is not None and lanes.collect_done is not None:
                     cur.wait_event(lanes.collect_done)
                 _mark("train.part_b_begin")
+                if WHOLE_B_EAGER and getattr(agent, "graph_train_whole_b_eager_ok", False):
+                    # part (b) is a handful of launches: issued directly they follow part (a)
+                    # without a second graph-launch boundary on the critical stream
+                    agent._part_a = e.part_a_state
+                    out = agent._graph_train_whole_b()
+                    _mark("train.apply_done")
+                    self.replays += 1
+                    return out
                 e.captured_b.replay()
                 _mark("train.apply_done")
             elif self._whole:
@@ -976,6 +988,9 @@ class GraphedTrain:
                     # (b) the rest -- with overlap on, (a) runs beside the collect step
                     e.captured = _Captured("train.whole_a")
                     e.captured.capture(lambda: agent._graph_train_whole_a(e.static_in, w_arg))
+                    # what part (a) hands to part (b): THIS entry's static tensors (an eagerly
+                    # issued part (b) must not see the ones of whichever entry was captured last)
+                    e.part_a_state = getattr(agent, "_part_a", None)
                     e.captured_b = _Captured("train.whole_b")
                     e.out = e.captured_b.capture(agent._graph_train_whole_b)
                     return

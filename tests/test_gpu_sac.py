@@ -295,11 +295,15 @@ def test_discrete_action_spec_is_rejected(dev):
                            actor_optimizer=None, critic_optimizer=None, alpha_optimizer=None)
 
 
-def test_sac_train_graph_matches_eager(dev):
-    """SacAgent.train through the Learner (one HIP graph per sampler ring slot) == eager train:
-    same parameters, log_alpha, targets and counters after 30 steps on the same replay stream."""
+@pytest.mark.parametrize("b_eager", [True, False])
+def test_sac_train_graph_matches_eager(dev, b_eager, monkeypatch):
+    """SacAgent.train through the Learner (one HIP graph per sampler ring slot; part (b) -- the
+    actor's optimizer launch, the alpha update -- issued directly behind part (a)'s graph, or as
+    a graph of its own) == eager train: same parameters, log_alpha, targets and counters after 30
+    steps on the same replay stream."""
     from agents_amd.train import learner
     from agents_amd.utils import graph
+    monkeypatch.setattr(graph, "WHOLE_B_EAGER", b_eager)
     stacks = []
     for _ in range(2):
         agent, _ = make_pair(dev)
