@@ -127,6 +127,29 @@ def test_ppo_merge_apply_switch(lib):
     assert lib.aa_ppo_fused_workspace_bytes(4096, total) >= (floats + 1) * 4 + 8 * 257
 
 
+def test_prio_draw_validates_on_the_host(lib):
+    """aa_prio_draw_rows refuses what it cannot run before any launch: null arguments, a workspace
+    that is too small or misaligned, tables of more than 8,000 blocks of 1,024 rows (those take
+    the three-launch aa_prio_sample_rows)."""
+    assert lib.aa_prio_draw_workspace_bytes(0) == -1
+    assert lib.aa_prio_draw_workspace_bytes(1) == 3 * 8             # one slot + two control words
+    assert lib.aa_prio_draw_workspace_bytes(1024 * 8000) == 8002 * 8
+    assert lib.aa_prio_draw_workspace_bytes(1024 * 8000 + 1) == -1
+    assert lib.aa_prio_workspace_bytes(1024 * 8000 + 1) == 8001 * 8  # the fallback still sizes it
+    buf = (ctypes.c_uint64 * 64)()
+    a = ctypes.addressof(buf)
+    a16 = (a + 15) & ~15
+    args = lambda **kw: [kw.get("pq", a16), kw.get("ids", a16), a16, kw.get("batch", 4),
+                         kw.get("L", 16), kw.get("S", 8), 2, 7, a16, kw.get("ws", a16),
+                         kw.get("ws_bytes", 24), a16, None, None, None, None]
+    assert lib.aa_prio_draw_rows(*args(pq=None)) == -22
+    assert lib.aa_prio_draw_rows(*args(S=0)) == -22
+    assert lib.aa_prio_draw_rows(*args(ws_bytes=16)) == -34
+    assert lib.aa_prio_draw_rows(*args(ws=a16 + 4)) == -34
+    assert lib.aa_prio_draw_rows(*args(batch=1024, L=8001, ws_bytes=1 << 20)) == -34
+    assert lib.aa_prio_draw_rows(*args(ids=a16 + 8)) == -22
+
+
 def test_round3_entries_validate_on_the_host(lib):
     """The entry points added in round 3 reject what they cannot run before any launch: the
     wide-MLP limits (widths <= 256 behind a <= 1,024-wide input, <= 4 layers, batch <= 1,024),
