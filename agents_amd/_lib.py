@@ -240,6 +240,8 @@ _SIGNATURES = {
     "aa_mlp_wide_supported": (c_int, [POINTER(MlpLayout), c_int64]),
     "aa_mlp_wide_forward": (c_int, [POINTER(MlpWideFwd), c_void_p]),
     "aa_mlp_wide_forward_sample": (c_int, [POINTER(MlpWideFwd), POINTER(SacSampleTail), c_void_p]),
+    "aa_mlp_wide_forward_sample2": (c_int, [POINTER(MlpWideFwd), POINTER(SacSampleTail),
+                                            POINTER(SacSampleTail), c_void_p]),
     "aa_mlp_wide_backward_gen": (c_int, [POINTER(MlpWideBwd), POINTER(SacDoutGen), c_void_p]),
     "aa_mlp_wide_backward": (c_int, [POINTER(MlpWideBwd), c_void_p]),
     "aa_mlp_wide_debug_stamps": (c_int, [c_void_p]),
@@ -405,7 +407,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 19:
+    if lib.aa_abi_version() != 20:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     # A/B knob: AA_PPO_MERGE_APPLY=0 keeps the fused PPO step's reduce and clip + Adam as two launches
     if os.environ.get("AA_PPO_MERGE_APPLY", "1") == "0":

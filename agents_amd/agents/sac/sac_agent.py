@@ -52,6 +52,9 @@ _FUSE_SAMPLE = os.environ.get("AA_SAC_FUSE_SAMPLE", "1") != "0"
 # AA_SAC_FUSE_LOSSES=0: critic loss, actor loss and the actor head's backward stay launches of their
 # own in front of the gradient-chain launches that consume them (A/B; bit-identical either way)
 _FUSE_LOSSES = os.environ.get("AA_SAC_FUSE_LOSSES", "1") != "0"
+# A/B knob: 0 = the actor's forward + sample on the observations is a launch of its own instead of
+# sharing the one on the next observations (aa_mlp_wide_forward_sample2)
+_PAIR_SAMPLE = os.environ.get("AA_SAC_PAIR_SAMPLE", "1") != "0"
 # A/B knob: 1 = the actor's loss + gradient open part (b) of a graphed train step (behind the
 # collect step) instead of closing part (a) (beside it)
 _ACTOR_PHASE_IN_B = os.environ.get("AA_SAC_ACTOR_IN_B", "0") == "1"
@@ -92,6 +95,53 @@ class SacPolicy(tf_policy.TFPolicy):
             self._arrival = torch.zeros((16,), dtype=torch.int64, device=dev)
         return self._dev_consts
 
+    def _tail(self, b, mean, mag, eps, save, out, net_index=0):
+        t = _lib.SacSampleTail()
+        t.net, t.A, t.std_kind = net_index, self._A, self._actor_network.projection.std_kind
+        t.act_mean, t.act_mag = mean.data_ptr(), mag.data_ptr()
+        t.eps_in = _lib.ptr(eps)
+        t.seed = self._seed
+        t.call_counter_dev = self._call_counter.data_ptr()
+        t.arrival_dev = self._arrival.data_ptr()
+        t.action = (b["action"] if out is None else out).data_ptr()
+        t.logp = b["logp"].data_ptr()
+        if save:
+            t.save_tanh, t.save_sigma, t.save_eps = (_lib.ptr(save["tanh"]),
+                                                     _lib.ptr(save["sigma"]),
+                                                     _lib.ptr(save["eps"]))
+        return t
+
+    def _sample_bufs(self, slot, B, dev):
+        key = (slot, B)
+        b = self._bufs.get(key)
+        if b is None:
+            b = {"action": torch.empty((B, self._A), dtype=torch.float32, device=dev),
+                 "logp": torch.empty((B,), dtype=torch.float32, device=dev)}
+            self._bufs[key] = b
+        return b
+
+    @staticmethod
+    def sample_pair(pol_a, obs_a, slot_a, eps_a, save_a, pol_b, obs_b, slot_b, eps_b, save_b):
+        """`pol_a.sample(obs_a, slot_a)` and `pol_b.sample(obs_b, slot_b, need_grad=True)` of two
+        policies over ONE actor network as one launch (two inputs, two slots, each policy's own
+        Philox counter): what the two calls return, or None when the launch does not apply."""
+        net = pol_a._actor_network
+        if not _FUSE_SAMPLE or pol_b._actor_network is not net or pol_a is pol_b or \
+                getattr(net, "forward_sample2", None) is None or \
+                obs_a.dtype != torch.float32 or obs_b.dtype != torch.float32 or \
+                obs_a.shape != obs_b.shape or not net.forward_sample_ok(obs_a) or \
+                not net.forward_sample_ok(obs_b):
+            return None
+        dev = obs_a.device
+        B = int(obs_a.shape[0])
+        mean_a, mag_a = pol_a._consts(dev)
+        mean_b, mag_b = pol_b._consts(dev)
+        ba, bb = pol_a._sample_bufs(slot_a, B, dev), pol_b._sample_bufs(slot_b, B, dev)
+        ta = pol_a._tail(ba, mean_a, mag_a, eps_a, save_a, None, net_index=0)
+        tb = pol_b._tail(bb, mean_b, mag_b, eps_b, save_b, None, net_index=1)
+        za, zb = net.forward_sample2(obs_a, ta, slot_a, False, obs_b, tb, slot_b, True)
+        return (ba["action"], ba["logp"], za), (bb["action"], bb["logp"], zb)
+
     def sample(self, observation, slot, need_grad=False, eps=None, save=None, out=None):
         """(action [B,A], log_pi [B], z) for a batch of observations; `save` = dict of [B,A]
         buffers (tanh, sigma, eps) kept for the backward pass; `out` = a contiguous float32 [B,A]
@@ -114,19 +164,7 @@ class SacPolicy(tf_policy.TFPolicy):
             # the actor's forward launch also draws the sample of its own head output (the
             # workgroup that produced a row's [mean | raw_std] has it in LDS): aa_sac_sample's
             # arithmetic and Philox counters, one launch less on the train step's chain
-            t = _lib.SacSampleTail()
-            t.net, t.A, t.std_kind = 0, self._A, net.projection.std_kind
-            t.act_mean, t.act_mag = mean.data_ptr(), mag.data_ptr()
-            t.eps_in = _lib.ptr(eps)
-            t.seed = self._seed
-            t.call_counter_dev = self._call_counter.data_ptr()
-            t.arrival_dev = self._arrival.data_ptr()
-            t.action = (b["action"] if out is None else out).data_ptr()
-            t.logp = b["logp"].data_ptr()
-            if save:
-                t.save_tanh, t.save_sigma, t.save_eps = (_lib.ptr(save["tanh"]),
-                                                         _lib.ptr(save["sigma"]),
-                                                         _lib.ptr(save["eps"]))
+            t = self._tail(b, mean, mag, eps, save, out)
             z = net.forward_sample(observation, t, slot=slot, need_grad=need_grad)
             return (b["action"] if out is None else out), b["logp"], z
         z = net.forward(observation, slot=slot, need_grad=need_grad)
@@ -357,7 +395,11 @@ class SacAgent(tf_agent.TFAgent):
 
     # ---- the three losses (forward + gradients) --------------------------------------------------
     def _critic_phase(self, obs, actions, next_obs, reward, discount, weights, need_grad,
-                      eps_next=None):
+                      eps_next=None, actor_obs=None, eps_actor=None):
+        """`actor_obs` (train steps): the actor update that follows evaluates the SAME actor
+        weights on these observations -- its forward + sample then shares the launch of this
+        phase's forward + sample on the next observations (`SacPolicy.sample_pair`) and
+        `_actor_phase` picks the result up."""
         lib = _lib.load()
         B = obs.shape[0]
         dev = obs.device
@@ -369,8 +411,17 @@ class SacAgent(tf_agent.TFAgent):
         pair = critic_network.pair_ok(self._critic_network_1, self._critic_network_2, obs, actions) \
             and critic_network.pair_ok(self._target_critic_network_1,
                                        self._target_critic_network_2, next_obs, actions)
-        na, nlogp, _ = self._loss_policy.sample(next_obs, slot="next", eps=eps_next,
-                                                save=w.get("save_next"))
+        self._pre_actor = None
+        pre = None
+        if actor_obs is not None and need_grad and _PAIR_SAMPLE:
+            pre = SacPolicy.sample_pair(self._loss_policy, next_obs, "next", eps_next,
+                                        w.get("save_next"), self._train_policy, actor_obs,
+                                        "actor", eps_actor, w["save"])
+        if pre is not None:
+            (na, nlogp, _), self._pre_actor = pre
+        else:
+            na, nlogp, _ = self._loss_policy.sample(next_obs, slot="next", eps=eps_next,
+                                                    save=w.get("save_next"))
         targets = (self._target_critic_network_1, self._target_critic_network_2)
         critics = (self._critic_network_1, self._critic_network_2)
         if pair and _QUAD_FORWARD and critic_network.two_pairs_ok(targets, critics):
@@ -438,8 +489,12 @@ class SacAgent(tf_agent.TFAgent):
         B = obs.shape[0]
         w = self._w(B, obs.device)
         pol = self._train_policy if need_grad else self._loss_policy
-        a, logp, z = pol.sample(obs, slot="actor", need_grad=need_grad, eps=eps,
-                                save=w["save"] if need_grad else None)
+        pre, self._pre_actor = getattr(self, "_pre_actor", None), None
+        if pre is not None and need_grad:
+            a, logp, z = pre       # drawn by the critic phase's launch (same actor weights)
+        else:
+            a, logp, z = pol.sample(obs, slot="actor", need_grad=need_grad, eps=eps,
+                                    save=w["save"] if need_grad else None)
         x_pi = None
         xc = self._xcat
         pair = critic_network.pair_ok(self._critic_network_1, self._critic_network_2, obs, a)
@@ -666,7 +721,8 @@ class SacAgent(tf_agent.TFAgent):
         with torch.cuda.device(dev):
             wts = self._weights(weights, B, dev)
             closs = self._critic_phase(obs, actions, next_obs, reward, discount, wts, True,
-                                       eps_next=eps.get("next"))
+                                       eps_next=eps.get("next"), actor_obs=obs,
+                                       eps_actor=eps.get("actor"))
             self._apply(self._critic_optimizer, self._critic_params, self._critic_grads,
                         self._critic_bodies(),
                         soft_target=(self._target_params, self._target_update_tau)

@@ -89,7 +89,8 @@ struct MwFwdP {
   int64_t B;
   int x_split;
   long long* stamps;   // nullable (aa_mlp_wide_debug_stamps): [workgroup][16] wall_clock64 ticks
-  MwTail tail;
+  MwTail tail[2];      // up to two networks of the launch draw their sample (SAC: the actor on the
+                       // next observations and on the observations, two policies' counters)
 };
 static long long* g_mw_stamps = nullptr;
 #define MW_STAMP(i)                                  \
@@ -280,8 +281,8 @@ __global__ void __launch_bounds__(MW_THREADS) aa_mlp_wide_fwd_kernel(MwFwdP p) {
   // workgroup's MW_TS samples ([column][sample]).  One thread per (sample, action dimension), the
   // A log-density terms of a sample summed in dimension order by one thread: aa_sac_sample_kernel's
   // arithmetic (sac_sample.h) and Philox counters, without the launch.
-  if (p.tail.net == g) {
-    const MwTail& T = p.tail;
+  if (p.tail[0].net == g || p.tail[1].net == g) {
+    const MwTail& T = p.tail[0].net == g ? p.tail[0] : p.tail[1];
     const int A = T.A;
     const float* zf = reinterpret_cast<const float*>(hcur);
     float* terms = &red[0][0][0];                 // [MW_TS][A]: the layers are done with `red`
@@ -786,19 +787,33 @@ int aa_mlp_wide_supported(const aa_mlp_layout* layout, int64_t B) {
   return mw_check_layout(layout) == AA_OK ? 1 : 0;
 }
 
-static int mw_forward(const aa_mlp_wide_fwd* d, const aa_sac_sample_tail* t, void* stream);
+static int mw_forward(const aa_mlp_wide_fwd* d, const aa_sac_sample_tail* t,
+                      const aa_sac_sample_tail* t2, void* stream);
 
 int aa_mlp_wide_forward(const aa_mlp_wide_fwd* d, void* stream) {
-  return mw_forward(d, nullptr, stream);
+  return mw_forward(d, nullptr, nullptr, stream);
 }
 
 int aa_mlp_wide_forward_sample(const aa_mlp_wide_fwd* d, const aa_sac_sample_tail* tail,
                                void* stream) {
   if (tail == nullptr) return AA_ERR_INVALID;
-  return mw_forward(d, tail, stream);
+  return mw_forward(d, tail, nullptr, stream);
 }
 
-static int mw_forward(const aa_mlp_wide_fwd* d, const aa_sac_sample_tail* t, void* stream) {
+int aa_mlp_wide_forward_sample2(const aa_mlp_wide_fwd* d, const aa_sac_sample_tail* tail_a,
+                                const aa_sac_sample_tail* tail_b, void* stream) {
+  if (tail_a == nullptr || tail_b == nullptr || tail_a->net == tail_b->net) return AA_ERR_INVALID;
+  // two draws of one launch must not share a Philox counter: each tail's last workgroup advances
+  // its own
+  if (tail_a->eps_in == nullptr && tail_b->eps_in == nullptr &&
+      (tail_a->call_counter_dev == tail_b->call_counter_dev ||
+       tail_a->arrival_dev == tail_b->arrival_dev))
+    return AA_ERR_INVALID;
+  return mw_forward(d, tail_a, tail_b, stream);
+}
+
+static int mw_forward(const aa_mlp_wide_fwd* d, const aa_sac_sample_tail* t_a,
+                      const aa_sac_sample_tail* t_b, void* stream) {
   if (d == nullptr || d->B < 1 || d->n_nets < 1 || d->n_nets > AA_MLPW_MAX_NETS) return AA_ERR_INVALID;
   int rc = mw_check_layout(&d->layout);
   if (rc != AA_OK) return rc;
@@ -825,9 +840,12 @@ static int mw_forward(const aa_mlp_wide_fwd* d, const aa_sac_sample_tail* t, voi
       p.net[g].y[l] = d->y[s][l];
     }
   }
-  p.tail = MwTail{};
-  p.tail.net = -1;
-  if (t != nullptr) {
+  for (int i = 0; i < 2; ++i) {
+    const aa_sac_sample_tail* t = i == 0 ? t_a : t_b;
+    MwTail& T = p.tail[i];
+    T = MwTail{};
+    T.net = -1;
+    if (t == nullptr) continue;
     const int L = d->layout.n_layers;
     if (t->net < 0 || t->net >= d->n_nets || t->A < 1 || d->layout.dims[L] != 2 * t->A ||
         d->layout.acts[L - 1] != AA_ACT_NONE || MW_TS * t->A > MW_WAVES * MW_TS * MW_MAXW)
@@ -837,13 +855,13 @@ static int mw_forward(const aa_mlp_wide_fwd* d, const aa_sac_sample_tail* t, voi
         (t->save_tanh == nullptr) != (t->save_eps == nullptr))
       return AA_ERR_INVALID;
     if (t->eps_in == nullptr && t->call_counter_dev == nullptr) return AA_ERR_INVALID;
-    p.tail.net = t->net; p.tail.A = t->A; p.tail.std_kind = t->std_kind;
-    p.tail.act_mean = t->act_mean; p.tail.act_mag = t->act_mag; p.tail.eps_in = t->eps_in;
-    p.tail.seed_lo = (uint32_t)t->seed; p.tail.seed_hi = (uint32_t)(t->seed >> 32);
-    p.tail.call_counter = t->call_counter_dev; p.tail.arrival = t->arrival_dev;
-    p.tail.action = t->action; p.tail.logp = t->logp;
-    p.tail.save_tanh = t->save_tanh; p.tail.save_sigma = t->save_sigma;
-    p.tail.save_eps = t->save_eps;
+    T.net = t->net; T.A = t->A; T.std_kind = t->std_kind;
+    T.act_mean = t->act_mean; T.act_mag = t->act_mag; T.eps_in = t->eps_in;
+    T.seed_lo = (uint32_t)t->seed; T.seed_hi = (uint32_t)(t->seed >> 32);
+    T.call_counter = t->call_counter_dev; T.arrival = t->arrival_dev;
+    T.action = t->action; T.logp = t->logp;
+    T.save_tanh = t->save_tanh; T.save_sigma = t->save_sigma;
+    T.save_eps = t->save_eps;
   }
   const int64_t gx = (d->B + MW_TS - 1) / MW_TS;
   if (gx > 0x7fffffffLL) return AA_ERR_RANGE;

@@ -195,6 +195,19 @@ class ActorDistributionNetwork(network.Network):
         return sequential.forward_wide([self._body], [x], slot=slot, need_grad=need_grad,
                                        sample_tail=tail)[0]
 
+    def forward_sample2(self, obs_a, tail_a, slot_a, need_grad_a, obs_b, tail_b, slot_b,
+                        need_grad_b):
+        """Two `forward_sample`s of THIS network (same weights, two inputs, two slots, two draws)
+        in one launch: tail_a.net = 0, tail_b.net = 1 (aa_mlp_wide_forward_sample2)."""
+        from agents_amd.networks import sequential
+        shp = tuple(self._body._input_tensor_spec.shape)
+        xa = obs_a.reshape((obs_a.shape[0],) + shp)
+        xb = obs_b.reshape((obs_b.shape[0],) + shp)
+        return sequential.forward_wide([self._body, self._body], [xa, xb],
+                                       slots=[slot_a, slot_b],
+                                       need_grads=[need_grad_a, need_grad_b],
+                                       sample_tail=(tail_a, tail_b))
+
     def backward(self, dz, slot=0, side_stream=None):
         self._body.backward(dz, slot=slot, side_stream=side_stream)
 

@@ -1101,7 +1101,8 @@ def forward_wide(nets, xs, slot=0, need_grad=False, x2s=None, slots=None, need_g
     tensors in place.  `slots` / `need_grads` (optional lists) give every network its own slot and
     flag -- SAC's critic update evaluates the twin TARGET critics on (next observation, next
     action) and the twin critics on (observation, action) in one launch of four networks.
-    `sample_tail` (a filled `_lib.SacSampleTail`): network `sample_tail.net` is a SAC actor and the
+    `sample_tail` (a filled `_lib.SacSampleTail`, or a pair of them for two networks of the launch
+    -- the same actor listed twice with two inputs and slots): network `sample_tail.net` is a SAC actor and the
     launch also draws its tanh-squashed actions and log-probabilities
     (aa_mlp_wide_forward_sample).
     Returns the networks' output buffers (owned by their slots)."""
@@ -1148,7 +1149,11 @@ def forward_wide(nets, xs, slot=0, need_grad=False, x2s=None, slots=None, need_g
     if WIDE_FWD_LOG is not None:
         WIDE_FWD_LOG.append((len(nets), B, [int(lay.dims[i]) for i in range(n + 1)]))
     with torch.cuda.device(xs[0].device):
-        if sample_tail is not None:
+        if isinstance(sample_tail, (tuple, list)):       # two networks draw (forward_sample2)
+            _lib.check(_lib.load().aa_mlp_wide_forward_sample2(
+                ctypes.byref(d), ctypes.byref(sample_tail[0]), ctypes.byref(sample_tail[1]),
+                _lib.stream_ptr()), "aa_mlp_wide_forward_sample2")
+        elif sample_tail is not None:
             _lib.check(_lib.load().aa_mlp_wide_forward_sample(
                 ctypes.byref(d), ctypes.byref(sample_tail), _lib.stream_ptr()),
                 "aa_mlp_wide_forward_sample")

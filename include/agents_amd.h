@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 19
+#define AA_ABI_VERSION 20
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -824,6 +824,12 @@ typedef struct {
 } aa_sac_sample_tail;
 int aa_mlp_wide_forward_sample(const aa_mlp_wide_fwd* d, const aa_sac_sample_tail* tail,
                                void* stream);
+/* Two networks of the launch draw their samples (tail_a->net != tail_b->net; drawn noise: two
+ * different call counters and arrival words) -- SAC's critic update evaluates the actor on the next
+ * observations and its actor update on the observations: the same weights, one launch
+ * (sac_agent.py:533-560 and :620-650 read the actor before any of its variables changes). */
+int aa_mlp_wide_forward_sample2(const aa_mlp_wide_fwd* d, const aa_sac_sample_tail* tail_a,
+                                const aa_sac_sample_tail* tail_b, void* stream);
 int aa_mlp_wide_backward(const aa_mlp_wide_bwd* d, void* stream);
 /* aa_mlp_wide_backward whose d loss / d output is COMPUTED by the gradient-chain launch instead of
  * read from dout (which is ignored): SAC's critic loss, actor loss and actor-head backward are a

@@ -97,7 +97,7 @@ def test_struct_layouts_match_the_header(tmp_path):
 
 
 def test_abi_version(lib):
-    assert lib.aa_abi_version() == 19
+    assert lib.aa_abi_version() == 20
 
 
 def test_argument_validation_without_gpu(lib):

@@ -434,3 +434,41 @@ def test_losses_inside_the_gradient_chain_are_bit_identical(dev, cfg, weighted, 
             assert torch.equal(x, y)
     for x, y in zip(ag_f.replicated_state(), ag_s.replicated_state()):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("kind", ["exp", "clip_exp"])
+def test_paired_actor_sample_is_bit_identical(dev, kind, monkeypatch):
+    """aa_mlp_wide_forward_sample2: the actor's forward + sample on the next observations (critic
+    update) and on the observations (actor update) as ONE launch -- the same weights, two inputs,
+    two policies' Philox counters -- against the two launches: losses of every step, every
+    variable and optimizer slot, the policies' call counters, with supplied noise and with the
+    policies' own; and the path must actually be taken."""
+    calls = []
+    real = sac_agent.SacPolicy.sample_pair
+
+    def spy(*a, **k):
+        out = real(*a, **k)
+        calls.append(out is not None)
+        return out
+    monkeypatch.setattr(sac_agent.SacPolicy, "sample_pair", staticmethod(spy))
+    monkeypatch.setattr(sac_agent, "_PAIR_SAMPLE", True)
+    ag_p, _ = make_pair(dev, actor_fc=(128, 96), critic_fc=(128, 128), kind=kind)
+    monkeypatch.setattr(sac_agent, "_PAIR_SAMPLE", False)
+    ag_s, _ = make_pair(dev, actor_fc=(128, 96), critic_fc=(128, 128), kind=kind)
+    for step in range(4):
+        exp_d, _, eps_d, _ = batch(dev, 64, 700 + step)
+        outs = []
+        for paired, ag in ((True, ag_p), (False, ag_s)):
+            monkeypatch.setattr(sac_agent, "_PAIR_SAMPLE", paired)
+            outs.append(ag.train(exp_d) if step >= 2 else ag.train(exp_d, eps=eps_d))
+        for x, y in zip([outs[0].loss] + list(outs[0].extra), [outs[1].loss] + list(outs[1].extra)):
+            assert torch.equal(x, y), f"step {step}"
+    assert calls == [True] * 4
+    for x, y in zip(ag_p.replicated_state(), ag_s.replicated_state()):
+        assert torch.equal(x, y)
+    for pp, ps in ((ag_p._loss_policy, ag_s._loss_policy), (ag_p._train_policy, ag_s._train_policy)):
+        assert int(pp._call_counter.item()) == int(ps._call_counter.item()) > 0
+    for op, os_ in ((ag_p._actor_optimizer, ag_s._actor_optimizer),
+                    (ag_p._critic_optimizer, ag_s._critic_optimizer)):
+        for x, y in zip(op.variables(), os_.variables()):
+            assert torch.equal(x, y)
