@@ -763,7 +763,18 @@ class SacAgent(tf_agent.TFAgent):
             graph.on_replay(self._bump_counter)
             if not self._fuse_target_update():
                 self._update_target()
+        # issued directly (not recorded into a graph), `packed` is storage of this step's own
+        self._own_info = None if graph.capturing() else info
         return info
+
+    reduced_owns_storage = False
+
+    def reduce_loss_info(self, loss_info):
+        """Learner.run sums every LossInfo field over all axes and hands out storage of its own
+        (train/learner.py:322-337).  The LossInfo of a train step whose last part was issued
+        directly already is four scalars in a tensor allocated for that step: nothing to launch."""
+        self.reduced_owns_storage = loss_info is getattr(self, "_own_info", None)
+        return loss_info if self.reduced_owns_storage else None
 
     def _bump_counter(self):
         self._train_step_counter.assign_add(1)

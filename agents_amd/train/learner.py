@@ -30,7 +30,7 @@ POLICY_SAVED_MODEL_DIR = "policies"
 
 
 # AA_FIELD_SUMS=0: always reduce LossInfo fields with generic reductions (A/B measurements)
-_FIELD_SUMS = True
+_FIELD_SUMS = os.environ.get("AA_FIELD_SUMS", "1") != "0"
 
 
 class Learner:

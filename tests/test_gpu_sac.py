@@ -321,8 +321,13 @@ def test_sac_train_graph_matches_eager(dev, b_eager, monkeypatch):
     for i in range(30):
         exp_e, _ = rb_e.get_next(32, 2)
         li_e = ag_e.train(exp_e)
+        prev = None if i == 0 else (li_g, [float(li_g.loss)] + [float(x) for x in li_g.extra])
         li_g = lrn.run(iterations=1, iterator=it_g)
         assert float(li_e.loss) == float(li_g.loss), f"step {i}"
+        for x, y in zip(li_e.extra, li_g.extra):
+            assert float(x) == float(y), f"step {i}"
+        if prev is not None:       # what Learner.run returned owns its storage: the next step left it alone
+            assert [float(prev[0].loss)] + [float(x) for x in prev[0].extra] == prev[1]
     assert graph.graphed_train(ag_g).replays > 15
     assert torch.equal(ag_e.actor_network.flat_params, ag_g.actor_network.flat_params)
     assert torch.equal(ag_e._critic_params, ag_g._critic_params)
