@@ -125,6 +125,14 @@ class MlpWideBwd(Structure):
                 ("dx_hi", c_int32), ("grads", c_void_p * 4)]
 
 
+class MlpWideAdam(Structure):
+    """aa_mlp_wide_adam (include/agents_amd.h)."""
+    _fields_ = [("p", c_void_p * 4), ("m", c_void_p * 4), ("v", c_void_p * 4),
+                ("target", c_void_p * 4), ("lr", c_float), ("beta1", c_float), ("beta2", c_float),
+                ("eps", c_float), ("tau", c_float), ("step_dev", c_void_p),
+                ("arrival_dev", c_void_p)]
+
+
 class PpoFusedDesc(Structure):
     """aa_ppo_fused_desc (include/agents_amd.h)."""
     _fields_ = [("obs", c_void_p), ("ld_obs", c_int64), ("obs_dim", c_int32), ("D", c_int32),
@@ -243,6 +251,9 @@ _SIGNATURES = {
     "aa_mlp_wide_forward_sample2": (c_int, [POINTER(MlpWideFwd), POINTER(SacSampleTail),
                                             POINTER(SacSampleTail), c_void_p]),
     "aa_mlp_wide_backward_gen": (c_int, [POINTER(MlpWideBwd), POINTER(SacDoutGen), c_void_p]),
+    "aa_mlp_wide_backward_gen_adam": (c_int, [POINTER(MlpWideBwd), POINTER(SacDoutGen),
+                                              POINTER(MlpWideAdam), c_void_p]),
+    "aa_mlp_wide_dw_adam": (c_int, [POINTER(MlpWideBwd), POINTER(MlpWideAdam), c_void_p]),
     "aa_mlp_wide_backward": (c_int, [POINTER(MlpWideBwd), c_void_p]),
     "aa_mlp_wide_debug_stamps": (c_int, [c_void_p]),
     "aa_mlp_small_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int32, POINTER(c_int32),
@@ -407,7 +418,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.aa_abi_version() != 20:
+    if lib.aa_abi_version() != 21:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
     # A/B knob: AA_PPO_MERGE_APPLY=0 keeps the fused PPO step's reduce and clip + Adam as two launches
     if os.environ.get("AA_PPO_MERGE_APPLY", "1") == "0":

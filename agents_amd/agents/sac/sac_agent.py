@@ -55,6 +55,9 @@ _FUSE_LOSSES = os.environ.get("AA_SAC_FUSE_LOSSES", "1") != "0"
 # A/B knob: 0 = the actor's forward + sample on the observations is a launch of its own instead of
 # sharing the one on the next observations (aa_mlp_wide_forward_sample2)
 _PAIR_SAMPLE = os.environ.get("AA_SAC_PAIR_SAMPLE", "1") != "0"
+# A/B knob: 0 = the critics' Adam step (+ soft target update) is a launch of its own behind their
+# weight-gradient launch instead of that launch's epilogue (aa_mlp_wide_backward_gen_adam)
+_FUSE_DW_ADAM = os.environ.get("AA_SAC_FUSE_DW_ADAM", "1") != "0"
 # A/B knob: 1 = the actor's loss + gradient open part (b) of a graphed train step (behind the
 # collect step) instead of closing part (a) (beside it)
 _ACTOR_PHASE_IN_B = os.environ.get("AA_SAC_ACTOR_IN_B", "0") == "1"
@@ -395,7 +398,7 @@ class SacAgent(tf_agent.TFAgent):
 
     # ---- the three losses (forward + gradients) --------------------------------------------------
     def _critic_phase(self, obs, actions, next_obs, reward, discount, weights, need_grad,
-                      eps_next=None, actor_obs=None, eps_actor=None):
+                      eps_next=None, actor_obs=None, eps_actor=None, fuse_apply=False):
         """`actor_obs` (train steps): the actor update that follows evaluates the SAME actor
         weights on these observations -- its forward + sample then shares the launch of this
         phase's forward + sample on the next observations (`SacPolicy.sample_pair`) and
@@ -464,8 +467,17 @@ class SacAgent(tf_agent.TFAgent):
             gen.loss_kind, gen.loss_weight = self._loss_kind(), self._critic_loss_weight
             gen.global_batch = float(B * self.num_replicas)
             gen.loss_out, gen.td_target_out = w["closs"].data_ptr(), w["td"].data_ptr()
+            adam = None
+            if fuse_apply and self._critic_apply_fusable():
+                # the critics' weight-gradient launch steps their optimizer (and the soft update
+                # of the targets) itself: aa_mlp_wide_backward_gen_adam
+                adam = self._critic_optimizer.fused_step_desc(
+                    self._critic_params,
+                    soft_target=(self._target_params, self._target_update_tau)
+                    if self._fuse_target_update() else None)
+                self._critic_applied = True
             critic_network.backward_pair(self._critic_network_1, self._critic_network_2, None,
-                                         None, slot="critic", gen=gen, batch=B)
+                                         None, slot="critic", gen=gen, batch=B, adam=adam)
             return w["closs"]
         _lib.check(lib.aa_sac_critic_loss(
             q1.data_ptr(), q2.data_ptr(), tq1.data_ptr(), tq2.data_ptr(), nlogp.data_ptr(),
@@ -484,7 +496,13 @@ class SacAgent(tf_agent.TFAgent):
                 self._critic_network_2.backward(w["dq2"], slot="critic")
         return w["closs"]
 
-    def _actor_phase(self, obs, weights, need_grad, eps=None):
+    def _actor_apply_fusable(self):
+        from agents_amd import optimizers as _opt
+        return _FUSE_DW_ADAM and self._gradient_clipping is None and \
+            self.gradient_hook is None and \
+            type(self._actor_optimizer) in (_opt.Adam, _opt.AdamOptimizer)
+
+    def _actor_phase(self, obs, weights, need_grad, eps=None, defer_dw=False):
         lib = _lib.load()
         B = obs.shape[0]
         w = self._w(B, obs.device)
@@ -537,8 +555,12 @@ class SacAgent(tf_agent.TFAgent):
             hg.daction2, hg.ld_daction2 = da2.data_ptr(), da2.stride(0)
             hg.dlogp = w["dlogp"].data_ptr()
             from agents_amd.networks import sequential
+            defer = defer_dw and self._actor_apply_fusable()
+            # (defer: the weight gradients are computed by the launch that also applies them, in
+            # part (b) behind the collect step -- `_train_part_b`)
             sequential.backward_wide([self._actor_network.body], None, slot="actor", gen=hg,
-                                     batch=B)
+                                     batch=B, param_grads=not defer)
+            self._actor_dw_pending = B if defer else None
             return w["aloss"]
         _lib.check(lib.aa_sac_actor_loss(
             q1.data_ptr(), q2.data_ptr(), logp.data_ptr(), _lib.ptr(weights),
@@ -668,6 +690,22 @@ class SacAgent(tf_agent.TFAgent):
         else:
             optimizer.apply_flat(params, grads)
 
+    def _critic_apply_fusable(self):
+        """Nothing stands between the critics' weight gradients and their Adam step (no clipping,
+        no cross-replica reduction), and both critics' parameters are views of the one flat buffer
+        the optimizer's slots mirror."""
+        from agents_amd import optimizers as _opt
+        if not _FUSE_DW_ADAM or self._gradient_clipping is not None or \
+                self.gradient_hook is not None or \
+                type(self._critic_optimizer) not in (_opt.Adam, _opt.AdamOptimizer):
+            return False
+        lo = self._critic_params.data_ptr()
+        hi = lo + 4 * self._critic_params.numel()
+        return all(lo <= b.flat_params.data_ptr() and
+                   b.flat_params.data_ptr() + 4 * b.flat_params.numel() <= hi
+                   for b in (self._critic_network_1.body, self._critic_network_2.body)) and \
+            not self._critic_network_1.has_towers and not self._critic_network_2.has_towers
+
     def _fuse_target_update(self):
         """The soft update of the target critics rides in the critic optimizer's launch when it
         happens every step (sac_agent.py:385-410 with target_update_period == 1): the critics do not
@@ -720,27 +758,41 @@ class SacAgent(tf_agent.TFAgent):
         graph.join_lanes(dev)
         with torch.cuda.device(dev):
             wts = self._weights(weights, B, dev)
+            self._critic_applied = False
             closs = self._critic_phase(obs, actions, next_obs, reward, discount, wts, True,
                                        eps_next=eps.get("next"), actor_obs=obs,
-                                       eps_actor=eps.get("actor"))
-            self._apply(self._critic_optimizer, self._critic_params, self._critic_grads,
-                        self._critic_bodies(),
-                        soft_target=(self._target_params, self._target_update_tau)
-                        if self._fuse_target_update() else None)
+                                       eps_actor=eps.get("actor"), fuse_apply=True)
+            if not self._critic_applied:
+                self._apply(self._critic_optimizer, self._critic_params, self._critic_grads,
+                            self._critic_bodies(),
+                            soft_target=(self._target_params, self._target_update_tau)
+                            if self._fuse_target_update() else None)
+            self._actor_dw_pending = None
             aloss = None if _ACTOR_PHASE_IN_B else \
-                self._actor_phase(obs, wts, True, eps=eps.get("actor"))
-        self._part_a = (obs, wts, closs, aloss, eps)
+                self._actor_phase(obs, wts, True, eps=eps.get("actor"), defer_dw=True)
+        # (the deferred weight-gradient launch travels with the hand-over: an eagerly issued part
+        # (b) behind a REPLAYED part (a) sees the state of that graph's capture)
+        self._part_a = (obs, wts, closs, aloss, eps, self._actor_dw_pending)
 
     def _train_part_b(self):
         """The actor's optimizer step, the alpha update, LossInfo, counters and the soft target
         update."""
-        obs, wts, closs, aloss, eps = self._part_a
+        obs, wts, closs, aloss, eps, pending = self._part_a
         dev = obs.device
         with torch.cuda.device(dev):
             if aloss is None:
                 aloss = self._actor_phase(obs, wts, True, eps=eps.get("actor"))
-            self._apply(self._actor_optimizer, self._actor_network.flat_params,
-                        self._actor_network.flat_grads, [self._actor_network.body])
+                pending = None
+            if pending is not None:
+                # the actor's weight gradients and its Adam step in one launch (the gradient
+                # chain ran in part (a)): aa_mlp_wide_dw_adam
+                from agents_amd.networks import sequential
+                sequential.backward_wide(
+                    [self._actor_network.body], None, slot="actor", batch=pending, dw_only=True,
+                    adam=self._actor_optimizer.fused_step_desc(self._actor_network.flat_params))
+            else:
+                self._apply(self._actor_optimizer, self._actor_network.flat_params,
+                            self._actor_network.flat_grads, [self._actor_network.body])
             # total + storage of its own for the three terms
             packed = torch.empty((4,), dtype=torch.float32, device=dev)
             from agents_amd import optimizers as _opt

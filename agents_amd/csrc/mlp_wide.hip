@@ -39,6 +39,7 @@
 #include "agents_amd.h"
 #include "sac_sample.h"
 #include "sac_loss.h"
+#include "adam_elem.h"
 
 #define MW_THREADS 512
 #define MW_WAVES 8
@@ -652,19 +653,37 @@ struct MwNetW {
   const float* dz[AA_MLP_MAX_LAYERS];
   float* grads;
 };
+// The optimizer step of the networks' parameters inside the weight-gradient launch
+// (aa_mlp_wide_backward_gen_adam): a tile's workgroup holds the finished gradient of its 32 x 32
+// parameters -- Adam (and the soft update of a target copy) is elementwise, so it applies it on
+// the spot: aa_adam_kernel's arithmetic (adam_elem.h) and in-launch step counter, one launch less.
+struct MwAdam {
+  int on;
+  float* p[AA_MLPW_MAX_NETS];
+  float* m[AA_MLPW_MAX_NETS];
+  float* v[AA_MLPW_MAX_NETS];
+  float* target[AA_MLPW_MAX_NETS];     // nullable: soft_variables_update of a target copy
+  float lr, beta1, beta2, eps, tau;
+  int64_t* step_dev;                   // steps taken so far; the last workgroup adds one
+  int64_t* arrival;
+};
 struct MwDwP {
   aa_mlp_layout lay;
   MwNetW net[AA_MLPW_MAX_NETS];
   int64_t B;
   int x_split;
   int tile_start[AA_MLP_MAX_LAYERS + 1];
+  MwAdam adam;
 };
 
 __global__ void __launch_bounds__(256) aa_mlp_wide_dw_kernel(MwDwP p) {
   __shared__ float part[4][32][33];
   __shared__ float bsum[8][32];
+  __shared__ float s_alpha;
   const int g = blockIdx.y;
   const int t = blockIdx.x;
+  if (p.adam.on && threadIdx.x == 0)     // every workgroup reads the step count before any adds to it
+    s_alpha = adam_alpha(p.adam.lr, p.adam.beta1, p.adam.beta2, (float)(*p.adam.step_dev + 1));
   int l = 0;
   while (l + 1 < p.lay.n_layers && t >= p.tile_start[l + 1]) ++l;
   const int n_in = p.lay.dims[l], n_out = p.lay.dims[l + 1];
@@ -690,6 +709,23 @@ __global__ void __launch_bounds__(256) aa_mlp_wide_dw_kernel(MwDwP p) {
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = mw_acc4{0.f, 0.f, 0.f, 0.f};
+  // the optimizer's operands of this thread's four tile elements are requested now and land
+  // under the batch loop (clamped addresses, unconditional loads)
+  float ap[4], am[4], avv[4], at[4];
+  const bool adam_on = p.adam.on != 0;
+  const bool has_target = adam_on && p.adam.target[g] != nullptr;
+  if (adam_on) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid + 256 * j, r = e >> 5, c = e & 31;
+      const int rr = i0 + r < n_in ? i0 + r : n_in - 1, cc = o0 + c < n_out ? o0 + c : n_out - 1;
+      const int64_t idx = p.lay.k_off[l] + (int64_t)rr * n_out + cc;
+      ap[j] = p.adam.p[g][idx];
+      am[j] = p.adam.m[g][idx];
+      avv[j] = p.adam.v[g][idx];
+      at[j] = has_target ? p.adam.target[g][idx] : 0.f;
+    }
+  }
   const int lr = lane & 15, lk = lane >> 4;
   // chunks of 64 samples: every operand of the chunk is requested before the first MFMA (one
   // round trip per chunk -- a batch of 256 is one chunk per wave)
@@ -746,18 +782,45 @@ __global__ void __launch_bounds__(256) aa_mlp_wide_dw_kernel(MwDwP p) {
   }
   __syncthreads();
   float* __restrict__ grads = p.net[g].grads;
-  for (int e = tid; e < 32 * 32; e += 256) {
+  const bool adam = p.adam.on != 0;
+  const float alpha = adam ? s_alpha : 0.f;       // (written before the barrier above)
+  const float omb1 = 1.0f - p.adam.beta1, omb2 = 1.0f - p.adam.beta2;
+  auto step = [&](int64_t idx, float gv) {
+    float pv = p.adam.p[g][idx], mv = p.adam.m[g][idx], vv = p.adam.v[g][idx];
+    adam_elem(pv, gv, mv, vv, alpha, omb1, omb2, p.adam.eps);
+    p.adam.p[g][idx] = pv;
+    p.adam.m[g][idx] = mv;
+    p.adam.v[g][idx] = vv;
+    if (p.adam.target[g] != nullptr)
+      p.adam.target[g][idx] = soft_update_elem(p.adam.target[g][idx], pv, p.adam.tau);
+  };
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + 256 * j;
     const int r = e >> 5, c = e & 31;
     const float v = ((part[0][r][c] + part[1][r][c]) + part[2][r][c]) + part[3][r][c];
-    if (i0 + r < n_in && o0 + c < n_out)
-      grads[p.lay.k_off[l] + (int64_t)(i0 + r) * n_out + o0 + c] = v;
+    if (i0 + r < n_in && o0 + c < n_out) {
+      const int64_t idx = p.lay.k_off[l] + (int64_t)(i0 + r) * n_out + o0 + c;
+      grads[idx] = v;
+      if (adam) {
+        float pv = ap[j], mv = am[j], vv = avv[j];
+        adam_elem(pv, v, mv, vv, alpha, omb1, omb2, p.adam.eps);
+        p.adam.p[g][idx] = pv;
+        p.adam.m[g][idx] = mv;
+        p.adam.v[g][idx] = vv;
+        if (has_target) p.adam.target[g][idx] = soft_update_elem(at[j], pv, p.adam.tau);
+      }
+    }
   }
   if (do_bias && tid < 32 && o0 + tid < n_out) {
     float v = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) v += bsum[q][tid];
-    grads[p.lay.b_off[l] + o0 + tid] = v;
+    const int64_t idx = p.lay.b_off[l] + o0 + tid;
+    grads[idx] = v;
+    if (adam) step(idx, v);
   }
+  if (adam) aa_advance_when_all_done(p.adam.step_dev, p.adam.arrival, 1, gridDim.x * gridDim.y);
 }
 
 static int mw_check_layout(const aa_mlp_layout* lay) {
@@ -870,18 +933,31 @@ static int mw_forward(const aa_mlp_wide_fwd* d, const aa_sac_sample_tail* t_a,
   return aa_launch_status();
 }
 
-static int mw_backward(const aa_mlp_wide_bwd* d, const aa_sac_dout_gen* gen, void* stream);
+static int mw_backward(const aa_mlp_wide_bwd* d, const aa_sac_dout_gen* gen,
+                       const aa_mlp_wide_adam* adam, void* stream, bool dw_only = false);
 
 int aa_mlp_wide_backward(const aa_mlp_wide_bwd* d, void* stream) {
-  return mw_backward(d, nullptr, stream);
+  return mw_backward(d, nullptr, nullptr, stream);
 }
 
 int aa_mlp_wide_backward_gen(const aa_mlp_wide_bwd* d, const aa_sac_dout_gen* gen, void* stream) {
   if (gen == nullptr) return AA_ERR_INVALID;
-  return mw_backward(d, gen, stream);
+  return mw_backward(d, gen, nullptr, stream);
 }
 
-static int mw_backward(const aa_mlp_wide_bwd* d, const aa_sac_dout_gen* gen, void* stream) {
+int aa_mlp_wide_backward_gen_adam(const aa_mlp_wide_bwd* d, const aa_sac_dout_gen* gen,
+                                  const aa_mlp_wide_adam* adam, void* stream) {
+  if (adam == nullptr) return AA_ERR_INVALID;
+  return mw_backward(d, gen, adam, stream);
+}
+
+int aa_mlp_wide_dw_adam(const aa_mlp_wide_bwd* d, const aa_mlp_wide_adam* adam, void* stream) {
+  if (d == nullptr || d->grads[0] == nullptr) return AA_ERR_INVALID;
+  return mw_backward(d, nullptr, adam, stream, true);
+}
+
+static int mw_backward(const aa_mlp_wide_bwd* d, const aa_sac_dout_gen* gen,
+                       const aa_mlp_wide_adam* adam, void* stream, bool dw_only) {
   if (d == nullptr || d->B < 1 || d->n_nets < 1 || d->n_nets > AA_MLPW_MAX_NETS) return AA_ERR_INVALID;
   int rc = mw_check_layout(&d->layout);
   if (rc != AA_OK) return rc;
@@ -905,7 +981,7 @@ static int mw_backward(const aa_mlp_wide_bwd* d, const aa_sac_dout_gen* gen, voi
   for (int g = 0; g < AA_MLPW_MAX_NETS; ++g) {
     const int s = g < d->n_nets ? g : 0;
     if (d->params[s] == nullptr) return AA_ERR_INVALID;
-    if (gen == nullptr && (d->dout[s] == nullptr || d->ld_dout[s] < lay.dims[L]))
+    if (gen == nullptr && !dw_only && (d->dout[s] == nullptr || d->ld_dout[s] < lay.dims[L]))
       return AA_ERR_INVALID;
     if ((d->dx[s] != nullptr) != want_dx || (d->grads[s] != nullptr) != want_dw)
       return AA_ERR_INVALID;
@@ -967,12 +1043,28 @@ static int mw_backward(const aa_mlp_wide_bwd* d, const aa_sac_dout_gen* gen, voi
     G.daction = t.daction; G.ld_da = t.ld_daction; G.daction2 = t.daction2;
     G.ld_da2 = t.ld_daction2; G.dlogp = t.dlogp;
   }
+  q.adam = MwAdam{};
+  if (adam != nullptr) {
+    if (!want_dw || !adam->step_dev || !adam->arrival_dev) return AA_ERR_INVALID;
+    for (int g = 0; g < d->n_nets; ++g) {
+      if (!adam->p[g] || !adam->m[g] || !adam->v[g]) return AA_ERR_INVALID;
+      // the parameters this launch steps are the ones the gradient chain in front of it read
+      if (adam->p[g] != d->params[g]) return AA_ERR_INVALID;
+      q.adam.p[g] = adam->p[g]; q.adam.m[g] = adam->m[g]; q.adam.v[g] = adam->v[g];
+      q.adam.target[g] = adam->target[g];
+    }
+    q.adam.on = 1;
+    q.adam.lr = adam->lr; q.adam.beta1 = adam->beta1; q.adam.beta2 = adam->beta2;
+    q.adam.eps = adam->eps; q.adam.tau = adam->tau;
+    q.adam.step_dev = adam->step_dev; q.adam.arrival = adam->arrival_dev;
+  }
   if (d->B > 0x7fffffffLL) return AA_ERR_RANGE;
   const int64_t gx = (d->B + MW_TS - 1) / MW_TS;
   if (gx > 0x7fffffffLL) return AA_ERR_RANGE;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(aa_mlp_wide_chain_kernel, dim3((unsigned)gx, (unsigned)d->n_nets),
-                     dim3(MW_VT), 0, st, p);
+  if (!dw_only)      // (dw_only: the chain ran in an earlier call, its dz buffers still hold it)
+    hipLaunchKernelGGL(aa_mlp_wide_chain_kernel, dim3((unsigned)gx, (unsigned)d->n_nets),
+                       dim3(MW_VT), 0, st, p);
   if (want_dw) {
     int tiles = 0;
     for (int l = 0; l < L; ++l) {

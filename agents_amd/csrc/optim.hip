@@ -8,6 +8,7 @@
 //   tf.clip_by_global_norm          tf_agents/agents/ppo/ppo_agent.py:948-949
 #include "common.h"
 #include "agents_amd.h"
+#include "adam_elem.h"
 #include "x6_common.h"
 #include "splitk_reduce.h"
 
@@ -55,13 +56,6 @@ static inline unsigned aa_ew_blocks(int64_t n_vec) {
   return (unsigned)b;
 }
 
-__device__ static inline float adam_elem(float& p, float g, float& m, float& v, float alpha,
-                                         float omb1, float omb2, float eps) {
-  m = m + (g - m) * omb1;
-  v = v + (g * g - v) * omb2;
-  p = p - (m * alpha) / (sqrtf(v) + eps);
-  return p;
-}
 
 // `arrival` != nullptr: *step_dev holds the number of steps taken so far; every workgroup reads it
 // at its start (t = that + 1) and the LAST one to finish advances it -- instead of a one-thread
@@ -75,8 +69,7 @@ aa_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __rest
   __shared__ float s_alpha;
   if (threadIdx.x == 0) {
     const float t = (float)(*step_dev + (arrival != nullptr ? 1 : 0));
-    const float b1p = powf(beta1, t), b2p = powf(beta2, t);
-    s_alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    s_alpha = adam_alpha(lr, beta1, beta2, t);
   }
   __syncthreads();
   const float alpha = s_alpha, omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
@@ -97,12 +90,11 @@ aa_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __rest
     if (target != nullptr) {
       // soft_variables_update of the target copy from the parameters just written
       // (aa_soft_update_kernel's expression), in the same pass
-      const float omt = 1.0f - tau;
       float4 a = reinterpret_cast<float4*>(target)[i];
-      a.x = omt * a.x + tau * pp.x;
-      a.y = omt * a.y + tau * pp.y;
-      a.z = omt * a.z + tau * pp.z;
-      a.w = omt * a.w + tau * pp.w;
+      a.x = soft_update_elem(a.x, pp.x, tau);
+      a.y = soft_update_elem(a.y, pp.y, tau);
+      a.z = soft_update_elem(a.z, pp.z, tau);
+      a.w = soft_update_elem(a.w, pp.w, tau);
       reinterpret_cast<float4*>(target)[i] = a;
     }
     if (PLANES && aa_planes_touch(S, 4 * i, 4 * i + 4)) {

@@ -312,7 +312,7 @@ def two_pairs_ok(pair_a, pair_b):
 
 
 def backward_pair(c1, c2, dq1, dq2, slot=0, param_grads=True, want_action_grad=False, gen=None,
-                  batch=None):
+                  batch=None, adam=None):
     """`backward` of both critics of a `forward_pair`: the gradient chains in one launch, all
     weight gradients in a second one; returns (da1, da2) [B, act] views if asked.  `gen` (a filled
     `_lib.SacDoutGen` of kind CRITIC / ACTOR; then dq1 = dq2 = None and batch = B): the chain launch
@@ -325,7 +325,7 @@ def backward_pair(c1, c2, dq1, dq2, slot=0, param_grads=True, want_action_grad=F
                              None if gen is not None else [dq1.view(B, 1), dq2.view(B, 1)],
                              slot=slot, param_grads=param_grads,
                              input_grads=[b["dx"] for b in bufs] if want_action_grad else None,
-                             input_grad_cols=(lo, hi), gen=gen, batch=B)
+                             input_grad_cols=(lo, hi), gen=gen, batch=B, adam=adam)
     if want_action_grad:
         return bufs[0]["dx"][:, lo:], bufs[1]["dx"][:, lo:]
     return None, None

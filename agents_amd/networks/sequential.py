@@ -1164,7 +1164,7 @@ def forward_wide(nets, xs, slot=0, need_grad=False, x2s=None, slots=None, need_g
 
 
 def backward_wide(nets, douts, slot=0, param_grads=True, input_grads=None, input_grad_cols=None,
-                  gen=None, batch=None):
+                  gen=None, batch=None, adam=None, dw_only=False):
     """`net.backward(dout, slot, param_grads, input_grad)` of the networks of a `forward_wide`
     group: the gradient chain in one launch, every weight / bias gradient of every layer and
     network in a second one (skipped with param_grads=False).  input_grads[g]: [B, d] float32
@@ -1172,7 +1172,7 @@ def backward_wide(nets, douts, slot=0, param_grads=True, input_grads=None, input
     `gen` (a filled `_lib.SacDoutGen`; then douts = None and batch = B): the chain launch computes
     d loss / d output itself (aa_mlp_wide_backward_gen: SAC's critic / actor loss, the actor head's
     backward)."""
-    B = int(douts[0].shape[0]) if gen is None else int(batch)
+    B = int(batch) if (gen is not None or dw_only) else int(douts[0].shape[0])
     lay = _wide_group(nets, B)
     d = _lib.MlpWideBwd()
     d.layout = lay
@@ -1189,7 +1189,7 @@ def backward_wide(nets, douts, slot=0, param_grads=True, input_grads=None, input
         x, x2 = s.wide_in
         if g == 0:
             d.x_split = int(x.shape[1])
-        if gen is None:
+        if gen is None and not dw_only:
             dout = douts[g] if douts[g].dim() == 2 else douts[g].reshape(B, -1)
             if dout.dtype != torch.float32 or dout.stride(1) != 1 or \
                     int(dout.shape[1]) != lay.dims[n]:
@@ -1214,8 +1214,31 @@ def backward_wide(nets, douts, slot=0, param_grads=True, input_grads=None, input
             d.ld_dx[g] = ig.stride(0)
         if param_grads:
             d.grads[g] = net.flat_grads.data_ptr()
+    if adam is not None:
+        # `adam` (Adam.fused_step_desc over the flat buffer the networks' parameters are views
+        # of): the weight-gradient launch steps the optimizer itself; every network's slice of
+        # m / v / target sits at the offset of its parameters
+        if not param_grads:
+            raise ValueError("backward_wide(adam=...) needs the weight gradients")
+        base = adam.p[0]
+        m0, v0, t0 = adam.m[0], adam.v[0], adam.target[0]
+        for g, net in enumerate(nets):
+            off = net.flat_params.data_ptr() - base
+            if off < 0:
+                raise ValueError("backward_wide(adam=...): a network outside the flat buffer")
+            adam.p[g], adam.m[g], adam.v[g] = base + off, m0 + off, v0 + off
+            adam.target[g] = (t0 + off) if t0 else None
     with torch.cuda.device(nets[0].flat_params.device):
-        if gen is not None:
+        if dw_only:
+            # (the gradient chain ran in an earlier call with param_grads=False; batch = B)
+            _lib.check(_lib.load().aa_mlp_wide_dw_adam(
+                ctypes.byref(d), None if adam is None else ctypes.byref(adam),
+                _lib.stream_ptr()), "aa_mlp_wide_dw_adam")
+        elif adam is not None:
+            _lib.check(_lib.load().aa_mlp_wide_backward_gen_adam(
+                ctypes.byref(d), None if gen is None else ctypes.byref(gen), ctypes.byref(adam),
+                _lib.stream_ptr()), "aa_mlp_wide_backward_gen_adam")
+        elif gen is not None:
             _lib.check(_lib.load().aa_mlp_wide_backward_gen(ctypes.byref(d), ctypes.byref(gen),
                                                             _lib.stream_ptr()),
                        "aa_mlp_wide_backward_gen")

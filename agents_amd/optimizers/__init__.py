@@ -127,6 +127,32 @@ class Adam(Optimizer):
         graph.on_replay(self._bump_iterations)
 
 
+    def fused_step_desc(self, params, soft_target=None):
+        """What `apply_flat(params, grads, soft_target=...)` would launch, as the descriptor a
+        weight-gradient launch takes to do it itself (`_lib.MlpWideAdam` with the BASE pointers of
+        the flat buffers in slot 0: the caller fills the per-network offsets), plus the host
+        bookkeeping of a step (`graph.on_replay(self._bump_iterations)`): call once per step."""
+        _lib.require_cuda(params)
+        s = self._slot(params, ("m", "v"))
+        key = params.data_ptr()
+        arrive = self._arrive.get(key)
+        if arrive is None:
+            arrive = self._arrive[key] = torch.zeros((16,), dtype=torch.int64,
+                                                     device=params.device)
+        a = _lib.MlpWideAdam()
+        a.p[0], a.m[0], a.v[0] = params.data_ptr(), s["m"].data_ptr(), s["v"].data_ptr()
+        if soft_target is not None:
+            target, tau = soft_target
+            _lib.require_cuda(target)
+            if target.numel() != params.numel() or target.dtype != torch.float32:
+                raise ValueError("soft_target must mirror the parameter buffer")
+            a.target[0], a.tau = target.data_ptr(), float(tau)
+        a.lr, a.beta1, a.beta2, a.eps = self.learning_rate, self.beta_1, self.beta_2, self.epsilon
+        a.step_dev, a.arrival_dev = s["step"].data_ptr(), arrive.data_ptr()
+        graph.on_replay(self._bump_iterations)
+        return a
+
+
 class AdamOptimizer(Adam):
     """tf.compat.v1.train.AdamOptimizer signature (epsilon 1e-8)."""
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 20
+#define AA_ABI_VERSION 21
 int aa_abi_version(void);
 
 /* ---- activations (epilogues / derivative masks) ---------------------------------------- */
@@ -863,6 +863,28 @@ typedef struct {
   const float* dlogp;
 } aa_sac_dout_gen;
 int aa_mlp_wide_backward_gen(const aa_mlp_wide_bwd* d, const aa_sac_dout_gen* gen, void* stream);
+/* aa_mlp_wide_backward[_gen] whose weight-gradient launch also STEPS the optimizer of the networks'
+ * parameters: Adam is elementwise, and the workgroup that finishes a 32 x 32 tile of a weight
+ * gradient holds it -- TensorFlow's ApplyAdam (aa_adam_step_counted's arithmetic and in-launch
+ * step counter: *step_dev = steps taken so far, advanced by the last workgroup; arrival_dev: a
+ * zeroed int64 word) and, with target[g] set, soft_variables_update(tau) of a target copy from the
+ * parameters just written (aa_adam_step_counted_target).  p[g] must be d->params[g]; m / v /
+ * target [g] the same offsets into their flat buffers.  gen may be NULL.  For callers without
+ * gradient clipping or a cross-replica gradient reduction in front of the optimizer
+ * (sac_agent.py:286-330: critic_loss -> apply_gradients, no clipping by default). */
+typedef struct {
+  float* p[AA_MLPW_MAX_NETS]; float* m[AA_MLPW_MAX_NETS]; float* v[AA_MLPW_MAX_NETS];
+  float* target[AA_MLPW_MAX_NETS];          /* each nullable */
+  float lr, beta1, beta2, eps, tau;
+  int64_t* step_dev; int64_t* arrival_dev;
+} aa_mlp_wide_adam;
+int aa_mlp_wide_backward_gen_adam(const aa_mlp_wide_bwd* d, const aa_sac_dout_gen* gen,
+                                  const aa_mlp_wide_adam* adam, void* stream);
+/* The weight-gradient launch of aa_mlp_wide_backward alone (the gradient chain of an earlier
+ * aa_mlp_wide_backward[_gen] call with grads = NULL left dz in place), with the optimizer step if
+ * adam != NULL: SAC's actor gradient chain runs beside the collect step, the launch that writes
+ * the actor's weights behind it. */
+int aa_mlp_wide_dw_adam(const aa_mlp_wide_bwd* d, const aa_mlp_wide_adam* adam, void* stream);
 /* Measurement aid: the workgroups of the following aa_mlp_wide_backward launches write
  * wall_clock64() stamps (10 ns ticks) at the phase boundaries of the gradient chain to
  * buf[workgroup][16] (0 start, 1 operands staged, then per layer from the top: dz ready, product

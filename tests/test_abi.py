@@ -72,6 +72,9 @@ def test_struct_layouts_match_the_header(tmp_path):
                                                  "dlogp_out", "z", "A", "std_kind", "act_mag",
                                                  "save_eps", "daction", "ld_daction", "daction2",
                                                  "ld_daction2", "dlogp"]),
+              "aa_mlp_wide_adam": ("MlpWideAdam", ["p", "m", "v", "target", "lr", "beta1",
+                                                   "beta2", "eps", "tau", "step_dev",
+                                                   "arrival_dev"]),
               "aa_ppo_policy_step_desc": ("PpoPolicyStepDesc", [
                   "x", "ldx", "B", "nrm_mean", "nrm_var_den", "nrm_eps", "nrm_clip", "params_a",
                   "n_layers_a", "dims_a", "b_off_a", "params_b", "n_layers_b", "b_off_b",
@@ -97,7 +100,7 @@ def test_struct_layouts_match_the_header(tmp_path):
 
 
 def test_abi_version(lib):
-    assert lib.aa_abi_version() == 20
+    assert lib.aa_abi_version() == 21
 
 
 def test_argument_validation_without_gpu(lib):

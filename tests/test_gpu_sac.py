@@ -477,3 +477,39 @@ def test_paired_actor_sample_is_bit_identical(dev, kind, monkeypatch):
                     (ag_p._critic_optimizer, ag_s._critic_optimizer)):
         for x, y in zip(op.variables(), os_.variables()):
             assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(critic_loss_weight=1.0, initial_log_alpha=0.7)])
+def test_adam_step_inside_the_weight_gradient_launch_is_bit_identical(dev, cfg, monkeypatch):
+    """aa_mlp_wide_backward_gen_adam / aa_mlp_wide_dw_adam: the critics' weight-gradient launch
+    applies their Adam step (and the soft update of the target critics) to the tile it has just
+    finished; the actor's weight-gradient launch, deferred behind its gradient chain, does the
+    same for the actor -- against the optimizer launches behind them: every variable, target, optimizer slot,
+    step counter and loss over five steps, bit for bit; and the path must actually be taken."""
+    monkeypatch.setattr(sac_agent, "_FUSE_DW_ADAM", True)
+    ag_f, _ = make_pair(dev, actor_fc=(128, 96), critic_fc=(128, 128), **cfg)
+    monkeypatch.setattr(sac_agent, "_FUSE_DW_ADAM", False)
+    ag_s, _ = make_pair(dev, actor_fc=(128, 96), critic_fc=(128, 128), **cfg)
+    took = []
+    for step in range(5):
+        exp_d, _, eps_d, _ = batch(dev, 64, 900 + step)
+        outs = []
+        for fused, ag in ((True, ag_f), (False, ag_s)):
+            monkeypatch.setattr(sac_agent, "_FUSE_DW_ADAM", fused)
+            outs.append(ag.train(exp_d, eps=eps_d))
+            if fused:
+                took.append(ag._critic_applied and ag._part_a[5] == 64)
+            else:
+                assert ag._part_a[5] is None
+        for x, y in zip([outs[0].loss] + list(outs[0].extra), [outs[1].loss] + list(outs[1].extra)):
+            assert torch.equal(x, y), f"step {step}"
+    assert took == [True] * 5 and not ag_s._critic_applied
+    for x, y in zip(ag_f.replicated_state(), ag_s.replicated_state()):
+        assert torch.equal(x, y)
+    assert torch.equal(ag_f._critic_grads, ag_s._critic_grads)
+    assert torch.equal(ag_f._actor_network.flat_grads, ag_s._actor_network.flat_grads)
+    for of, os_ in ((ag_f._critic_optimizer, ag_s._critic_optimizer),
+                    (ag_f._actor_optimizer, ag_s._actor_optimizer)):
+        for x, y in zip(of.variables(), os_.variables()):
+            assert torch.equal(x, y)
+        assert of.iterations == os_.iterations == 5
