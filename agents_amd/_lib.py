@@ -420,9 +420,6 @@ def load():
         fn.argtypes = args
     if lib.aa_abi_version() != 21:
         raise AgentsAmdError("libagents_amd.so ABI version mismatch; rebuild")
-    # A/B knob: AA_PPO_MERGE_APPLY=0 keeps the fused PPO step's reduce and clip + Adam as two launches
-    if os.environ.get("AA_PPO_MERGE_APPLY", "1") == "0":
-        lib.aa_ppo_fused_merge_apply(0)
     _lib = lib
     return lib
 

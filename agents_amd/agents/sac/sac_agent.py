@@ -52,15 +52,14 @@ _FUSE_SAMPLE = os.environ.get("AA_SAC_FUSE_SAMPLE", "1") != "0"
 # AA_SAC_FUSE_LOSSES=0: critic loss, actor loss and the actor head's backward stay launches of their
 # own in front of the gradient-chain launches that consume them (A/B; bit-identical either way)
 _FUSE_LOSSES = os.environ.get("AA_SAC_FUSE_LOSSES", "1") != "0"
-# A/B knob: 0 = the actor's forward + sample on the observations is a launch of its own instead of
-# sharing the one on the next observations (aa_mlp_wide_forward_sample2)
-_PAIR_SAMPLE = os.environ.get("AA_SAC_PAIR_SAMPLE", "1") != "0"
-# A/B knob: 0 = the critics' Adam step (+ soft target update) is a launch of its own behind their
-# weight-gradient launch instead of that launch's epilogue (aa_mlp_wide_backward_gen_adam)
-_FUSE_DW_ADAM = os.environ.get("AA_SAC_FUSE_DW_ADAM", "1") != "0"
-# A/B knob: 1 = the actor's loss + gradient open part (b) of a graphed train step (behind the
-# collect step) instead of closing part (a) (beside it)
-_ACTOR_PHASE_IN_B = os.environ.get("AA_SAC_ACTOR_IN_B", "0") == "1"
+# Switches of the round-6 launch fusions (module variables, not environment knobs: each was
+# A/B'd through one -- profiles/r06_zzzz_sac_part_split_ab.txt -- and the bit-identity tests flip
+# them): False = the actor's forward + sample on the observations is a launch of its own instead
+# of sharing the one on the next observations (aa_mlp_wide_forward_sample2) ...
+_PAIR_SAMPLE = True
+# ... / the critics' and the actor's Adam steps (+ soft target update) are launches of their own
+# instead of the epilogue of their weight-gradient launches (aa_mlp_wide_backward_gen_adam)
+_FUSE_DW_ADAM = True
 
 
 def _spec_means_and_magnitudes(spec):
@@ -768,8 +767,7 @@ class SacAgent(tf_agent.TFAgent):
                             soft_target=(self._target_params, self._target_update_tau)
                             if self._fuse_target_update() else None)
             self._actor_dw_pending = None
-            aloss = None if _ACTOR_PHASE_IN_B else \
-                self._actor_phase(obs, wts, True, eps=eps.get("actor"), defer_dw=True)
+            aloss = self._actor_phase(obs, wts, True, eps=eps.get("actor"), defer_dw=True)
         # (the deferred weight-gradient launch travels with the hand-over: an eagerly issued part
         # (b) behind a REPLAYED part (a) sees the state of that graph's capture)
         self._part_a = (obs, wts, closs, aloss, eps, self._actor_dw_pending)
@@ -780,9 +778,6 @@ class SacAgent(tf_agent.TFAgent):
         obs, wts, closs, aloss, eps, pending = self._part_a
         dev = obs.device
         with torch.cuda.device(dev):
-            if aloss is None:
-                aloss = self._actor_phase(obs, wts, True, eps=eps.get("actor"))
-                pending = None
             if pending is not None:
                 # the actor's weight gradients and its Adam step in one launch (the gradient
                 # chain ran in part (a)): aa_mlp_wide_dw_adam
@@ -840,7 +835,7 @@ class SacAgent(tf_agent.TFAgent):
     @property
     def graph_train_whole_b_eager_ok(self):
         # with the actor phase in part (a), part (b) is three or four launches and no host decision
-        return not _ACTOR_PHASE_IN_B
+        return True
 
     def _graph_train_whole(self, experience, weights):
         """The train step is device work plus host counters registered with graph.on_replay:

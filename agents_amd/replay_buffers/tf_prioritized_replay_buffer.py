@@ -17,8 +17,6 @@ weights, new rows enter with the running maximum priority, and `update_prioritie
 (|td_error| + eps)^alpha.  Kernels: csrc/prio.hip (flat two-level scan on uint32 fixed-point
 priorities -- exact sums, bit-exact indices against oracle/prioritized.py).
 """
-import os
-
 import torch
 
 from agents_amd import _lib
@@ -29,8 +27,9 @@ from agents_amd.utils import graph, nest_utils
 
 BufferInfo = uniform.BufferInfo
 
-# A/B knob: 0 = block sums, draw and counter advance as three launches (aa_prio_sample_rows)
-ONE_LAUNCH_DRAW = os.environ.get("AA_PRIO_ONE_LAUNCH", "1") != "0"
+# False = block sums, draw and counter advance as three launches (aa_prio_sample_rows; 7 % slower
+# in the loop: profiles/r06_zzzz_prio_one_launch_ab.txt)
+ONE_LAUNCH_DRAW = True
 
 
 class TFPrioritizedReplayBuffer(uniform.TFUniformReplayBuffer):

@@ -29,8 +29,8 @@ TRAIN_DIR = "train"
 POLICY_SAVED_MODEL_DIR = "policies"
 
 
-# AA_FIELD_SUMS=0: always reduce LossInfo fields with generic reductions (A/B measurements)
-_FIELD_SUMS = os.environ.get("AA_FIELD_SUMS", "1") != "0"
+# False: always reduce LossInfo fields with generic reductions (A/B measurements)
+_FIELD_SUMS = True
 
 
 class Learner:

@@ -79,9 +79,10 @@ COUNT_IN_ADD = True
 
 # A/B knob: replay the optimizer phase as its own HIP graph (0) or launch it directly (1)
 APPLY_EAGER = True
-# A/B knob: 0 = part (b) of a two-part whole-mode train step (SAC: the actor's optimizer launch, the
+# False = part (b) of a two-part whole-mode train step (SAC: the actor's optimizer launch, the
 # alpha update, the target update) is replayed as its HIP graph instead of being issued directly
-WHOLE_B_EAGER = os.environ.get("AA_WHOLE_B_EAGER", "1") != "0"
+# (3.2 % slower: profiles/r06_zzzz_sac_part_split_ab.txt; tests flip it)
+WHOLE_B_EAGER = True
 
 
 # AA_EARLY_TARGET (0 = off, default on): with overlap on, GraphedTrain runs the target network's
