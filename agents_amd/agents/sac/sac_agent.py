@@ -744,8 +744,10 @@ class SacAgent(tf_agent.TFAgent):
 
     def _train_part_a(self, experience, weights, eps=None):
         """The critic update (sac_agent.py:286-330, first third) and the actor's loss + gradient
-        (second third, without its optimizer step): reads the actor, writes the critics and the
-        actor's GRADIENT buffer -- nothing the collect policy uses is modified, so a graphed loop
+        (second third, without its optimizer step): reads the actor, writes the critics (their
+        Adam step rides in their weight-gradient launch) and the actor's gradient CHAIN (its weight
+        gradients are computed in part (b), by the launch that also applies them, unless clipping
+        or a gradient hook stands in between) -- nothing the collect policy uses is modified, so a graphed loop
         runs it beside the collect step (utils/graph.py: GraphedTrain, whole mode in two parts).
         (Until round 6 the actor phase opened part (b): the GPU timeline of tools/bench_sac.py had
         part (b) start 16 us after part (a) had ended, waiting for the collect step to release
